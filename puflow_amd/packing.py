@@ -1,0 +1,172 @@
+"""state_dict -> inference plan: folded dense matrices, then MFMA-fragment-ordered blobs.
+
+Folds (all exact algebra), done once on the host in float64 and
+rounded to fp32 once:
+  * BatchNorm2d(eval) into the preceding 1x1 conv          (interpflow.py:203-221,91-98,144-151)
+  * EdgeConv edge feature [x_i, x_j, x_j-x_i] -> per-point linear maps
+        W.[x_i; x_j; x_j-x_i] = (W1-W3) x_i + (W2+W3) x_j   (interpflow.py:229-232)
+    so every conv of a dense block gets its edge-feature part from two per-point vectors
+    P[i] (with the bias) and Q[j]; only the growth-feature part runs per edge.
+  * DistanceEncoder's first conv on [x_i, x_j, x_i-x_j, |x_i-x_j|] -> per-point P/Q + one
+    column for the norm                                     (interpflow.py:106-113)
+  * ActNorm o inv1x1 -> one 3x3 affine;  W^-1 precomputed   (normalize.py:34, permutate.py:118,123)
+  * coupling1's first layer split into the h1 columns and the c columns
+        W0.[h1; c] = W0[:, :tdim] h1 + W0[:, tdim:] c        (interpflow.py:38-41, coupling.py:114-118)
+    the c part is per ORIGINAL point and shared by f and the R replicas of g.
+  * WeightEstimationUnit's last conv truncated to its first R rows (interpflow.py:180).
+
+`fold_state_dict` returns plain fp32 numpy matrices (tests/emulate_plan.py consumes them to
+prove the algebra on CPU); `pack_plan` re-orders them into the 16x16x4 MFMA A-operand fragment
+order used by csrc/ and concatenates everything into ONE device blob with an offset table.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+
+NUM_BLOCKS = 6
+FEAT_CHANNELS = [3, 32, 64, 128, 128, 128, 128]
+GROWTH = [8, 16, 32, 32, 32, 32]
+COND_CHANNELS = [32, 64, 128, 128, 128, 128]
+HDIM = 64
+BN_EPS = 1e-5
+
+
+def _np(sd, k):
+    return sd[k].detach().cpu().double().numpy()
+
+
+def _fold_bn(sd, conv: str, bn: str):
+    W = _np(sd, conv + ".weight")
+    W = W.reshape(W.shape[0], -1)
+    b = _np(sd, conv + ".bias")
+    s = _np(sd, bn + ".weight") / np.sqrt(_np(sd, bn + ".running_var") + BN_EPS)
+    return W * s[:, None], s * (b - _np(sd, bn + ".running_mean")) + _np(sd, bn + ".bias")
+
+
+def fold_edgeconv(sd, pfx: str, C: int, g: int, nconv: int, odim: int, gpad: int) -> Dict[str, np.ndarray]:
+    """Dense block -> per-point matrices PA (with bias pb) / QB [S,C] and per-edge growth
+    matrices G[t] ([gpad, gpad*t], t=1..nconv-1) + Gout [odim, gpad*nconv].
+    Row layout of S = gpad*nconv + odim: conv0 | conv1 | ... | conv_out; rows/cols beyond g
+    inside each gpad block are zero (unit 0 has g=8, padded to 16 for the 16-row MFMA tile)."""
+    S = gpad * nconv + odim
+    PA = np.zeros((S, C)); QB = np.zeros((S, C)); pb = np.zeros(S)
+    G: List[np.ndarray] = []
+    for t in range(nconv + 1):
+        if t < nconv:
+            W, b = _fold_bn(sd, f"{pfx}.convs.{t}.0", f"{pfx}.convs.{t}.1")
+            r0, rows = gpad * t, g
+        else:
+            W = _np(sd, pfx + ".conv_out.weight"); W = W.reshape(W.shape[0], -1)
+            b = _np(sd, pfx + ".conv_out.bias")
+            r0, rows = gpad * nconv, odim
+        assert W.shape[1] == 3 * C + g * t
+        W1, W2, W3, Gt = W[:, :C], W[:, C:2 * C], W[:, 2 * C:3 * C], W[:, 3 * C:]
+        PA[r0:r0 + rows] = W1 - W3
+        QB[r0:r0 + rows] = W2 + W3
+        pb[r0:r0 + rows] = b
+        if t >= 1:
+            rp = gpad if t < nconv else odim
+            Gp = np.zeros((rp, gpad * t))
+            for u in range(t):
+                Gp[:rows, gpad * u:gpad * u + g] = Gt[:, g * u:g * (u + 1)]
+            G.append(Gp)
+    out = {"PA": PA, "QB": QB, "pb": pb}
+    for t, Gp in enumerate(G):
+        out[f"G{t + 1}"] = Gp                         # G1..G{nconv-1}, G{nconv} = conv_out growth part
+    return {k: v.astype(np.float32) for k, v in out.items()}
+
+
+def _lin_a1d(sd, pfx):
+    return (_np(sd, pfx + ".layers.0.weight"), _np(sd, pfx + ".layers.2.weight"), _np(sd, pfx + ".layers.2.bias"),
+            _np(sd, pfx + ".layers.4.weight"), _np(sd, pfx + ".layers.4.bias"))
+
+
+def fold_state_dict(sd, upratio: int = 4) -> Dict[str, object]:
+    """All folded fp32 matrices of the inference plan (dense, un-permuted)."""
+    plan: Dict[str, object] = {"upratio": upratio}
+    units = []
+    for i in range(NUM_BLOCKS):
+        C, g, odim = FEAT_CHANNELS[i], GROWTH[i], FEAT_CHANNELS[i + 1]
+        units.append(fold_edgeconv(sd, f"feat_convs.{i}", C, g, odim // g, odim, max(g, 16)))
+    plan["units"] = units
+    merges, flows = [], []
+    for i in range(NUM_BLOCKS):
+        p = f"merge_convs.{i}"
+        merges.append({"W1": _np(sd, p + ".conv1.weight").astype(np.float32),
+                       "b1": _np(sd, p + ".conv1.bias").astype(np.float32),
+                       "W2": _np(sd, p + ".conv2.weight").astype(np.float32)})
+        pf = f"flow_blocks.{i}"
+        tdim = 1 if i % 2 == 0 else 2
+        logs = _np(sd, pf + ".actnorm.logs").reshape(3)
+        ab = _np(sd, pf + ".actnorm.bias").reshape(3)
+        W = _np(sd, pf + ".permutate1.permutater.W")
+        # forward:  p' = W (p*exp(logs) + ab) = A p + a0
+        A = W * np.exp(logs)[None, :]
+        a0 = W @ ab
+        # inverse:  p = (W^-1 u - ab) * exp(-logs) = Ai u + ai0
+        Winv = np.linalg.inv(W)
+        Ai = Winv * np.exp(-logs)[:, None]
+        ai0 = -ab * np.exp(-logs)
+        ld_const = float(np.sum(logs) + np.linalg.slogdet(W)[1])      # per point
+        c1 = _lin_a1d(sd, pf + ".coupling1.bias_net")
+        sn = _lin_a1d(sd, pf + ".coupling2.scale_net")
+        bn = _lin_a1d(sd, pf + ".coupling2.bias_net")
+        flows.append({
+            "tdim": tdim, "A": A.astype(np.float32), "a0": a0.astype(np.float32),
+            "Ai": Ai.astype(np.float32), "ai0": ai0.astype(np.float32), "ld_const": ld_const,
+            "c1_W0h": c1[0][:, :tdim].astype(np.float32), "c1_W0c": c1[0][:, tdim:].astype(np.float32),
+            "c1_W2": c1[1].astype(np.float32), "c1_b2": c1[2].astype(np.float32),
+            "c1_W4": c1[3].astype(np.float32), "c1_b4": c1[4].astype(np.float32),
+            "s_W0": sn[0].astype(np.float32), "s_W2": sn[1].astype(np.float32), "s_b2": sn[2].astype(np.float32),
+            "s_W4": sn[3].astype(np.float32), "s_b4": sn[4].astype(np.float32),
+            "t_W0": bn[0].astype(np.float32), "t_W2": bn[1].astype(np.float32), "t_b2": bn[2].astype(np.float32),
+            "t_W4": bn[3].astype(np.float32), "t_b4": bn[4].astype(np.float32),
+        })
+    plan["merges"], plan["flows"] = merges, flows
+    # ---- interpolation module
+    ip: Dict[str, np.ndarray] = {}
+    p = "interp.knn_context.distance_encoder.mlp"
+    W0, b0 = _fold_bn(sd, p + ".0", p + ".1")            # [64,10]: x_i(3) x_j(3) x_i-x_j(3) |.|(1)
+    ip["d_PA"] = (W0[:, 0:3] + W0[:, 6:9]).astype(np.float32)   # multiplies x_i
+    ip["d_QB"] = (W0[:, 3:6] - W0[:, 6:9]).astype(np.float32)   # multiplies x_j
+    ip["d_wn"] = W0[:, 9].astype(np.float32)                    # multiplies ||x_i - x_j||
+    ip["d_b0"] = b0.astype(np.float32)
+    W3, b3 = _fold_bn(sd, p + ".3", p + ".4")
+    ip["d_W3"], ip["d_b3"] = W3.astype(np.float32), b3.astype(np.float32)
+    W6 = _np(sd, p + ".6.weight")
+    ip["d_W6"], ip["d_b6"] = W6.reshape(W6.shape[0], -1).astype(np.float32), _np(sd, p + ".6.bias").astype(np.float32)
+    ip["ec"] = fold_edgeconv(sd, "interp.knn_context.feat_conv", 3, 16, 8, 128, 16)
+    p = "interp.weight_unit.mlp"
+    W0, b0 = _fold_bn(sd, p + ".0", p + ".1")
+    ip["w_W0"], ip["w_b0"] = W0.astype(np.float32), b0.astype(np.float32)
+    W3, b3 = _fold_bn(sd, p + ".3", p + ".4")
+    ip["w_W3"], ip["w_b3"] = W3.astype(np.float32), b3.astype(np.float32)
+    W6 = _np(sd, p + ".6.weight"); W6 = W6.reshape(W6.shape[0], -1)
+    ip["w_W6"], ip["w_b6"] = W6[:upratio].astype(np.float32), _np(sd, p + ".6.bias")[:upratio].astype(np.float32)
+    plan["interp"] = ip
+    return plan
+
+
+# ---------------------------------------------------------------------------------------
+# MFMA fragment order (v_mfma_f32_16x16x4_f32 A operand; csrc/pf_mfma.h)
+# ---------------------------------------------------------------------------------------
+def frag_pack(W: np.ndarray) -> np.ndarray:
+    """[OUT, IN] fp32 -> fragment order [OB][CB][lane 64][4] (rows/cols zero-padded to 16).
+
+    Lane l of a wave holds, for 16-row block `ob` and 16-channel block `cb`, the four values
+    W[ob*16 + (l & 15)][cb*16 + 4*(l >> 4) + r], r = 0..3 - i.e. the A operands of the four
+    16x16x4 MFMA steps that consume accumulator register r of a 16-channel feature block."""
+    out, inn = W.shape
+    OB, CB = (out + 15) // 16, (inn + 15) // 16
+    Wp = np.zeros((OB * 16, CB * 16), dtype=np.float32)
+    Wp[:out, :inn] = W
+    f = Wp.reshape(OB, 16, CB, 4, 4)            # ob,row,cb,q,r
+    return np.ascontiguousarray(f.transpose(0, 2, 3, 1, 4)).reshape(OB, CB, 64, 4)
+
+
+def frag_unpack(F: np.ndarray, out: int, inn: int) -> np.ndarray:
+    OB, CB = F.shape[0], F.shape[1]
+    f = F.reshape(OB, CB, 4, 16, 4).transpose(0, 3, 1, 2, 4)
+    return f.reshape(OB * 16, CB * 16)[:out, :inn]

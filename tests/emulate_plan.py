@@ -1,0 +1,119 @@
+"""CPU emulation of the *folded* inference plan (puflow_amd.packing.fold_state_dict).
+
+Test infrastructure: proves on CPU (no GPU needed) that the algebraic folds the HIP kernels
+rely on (BN fold, per-point P/Q shortcut, actnorm o inv1x1, split coupling layer, truncated
+weight conv) reproduce the oracle within the fp32 tolerance.  It mirrors the kernels' data
+flow (per-point P/Q, growth features per edge), not their instruction order.
+"""
+import numpy as np
+import torch
+
+LOG2PI = float(np.log(2 * np.pi))
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _gather(x, idx):
+    B = x.shape[0]
+    return x[torch.arange(B).view(B, 1, 1), idx]
+
+
+def _lrelu(x, s):
+    return torch.where(x >= 0, x, x * s)
+
+
+def edgeconv(u, x, idx, g, nconv, odim, gpad, pooling=True):
+    """x [B,N,C]; returns pooled [B,N,odim] or [B,N,K,odim]."""
+    PA, QB, pb = _t(u["PA"]), _t(u["QB"]), _t(u["pb"])
+    P = x @ PA.T + pb                     # [B,N,S]
+    Q = x @ QB.T
+    E = P.unsqueeze(2) + _gather(Q, idx)   # [B,N,K,S]
+    feats = []
+    for t in range(nconv):
+        y = E[..., gpad * t:gpad * (t + 1)]
+        if t >= 1:
+            y = y + torch.cat(feats, dim=-1) @ _t(u[f"G{t}"]).T
+        feats.append(_lrelu(y, 0.05))
+    y = E[..., gpad * nconv:] + torch.cat(feats, dim=-1) @ _t(u[f"G{nconv}"]).T
+    return y.max(dim=2)[0] if pooling else y
+
+
+def forward(plan, xyz, idx16, stages=False):
+    R = plan["upratio"]
+    from puflow_amd.packing import FEAT_CHANNELS, GROWTH, NUM_BLOCKS
+    B, N, _ = xyz.shape
+    h = xyz
+    cs, st, cp = [], [], []
+    for i in range(NUM_BLOCKS):
+        g, odim = GROWTH[i], FEAT_CHANNELS[i + 1]
+        h = edgeconv(plan["units"][i], h, idx16, g, odim // g, odim, max(g, 16))
+        m = plan["merges"][i]
+        c = torch.relu(h @ _t(m["W1"]).T + _t(m["b1"])) @ _t(m["W2"]).T
+        cs.append(c)
+        f = plan["flows"][i]
+        s = _lrelu(c @ _t(f["s_W0"]).T, 0.01)
+        s = _lrelu(s @ _t(f["s_W2"]).T + _t(f["s_b2"]), 0.01) @ _t(f["s_W4"]).T + _t(f["s_b4"])
+        t = _lrelu(c @ _t(f["t_W0"]).T, 0.01)
+        t = _lrelu(t @ _t(f["t_W2"]).T + _t(f["t_b2"]), 0.01) @ _t(f["t_W4"]).T + _t(f["t_b4"])
+        st.append((s, t))
+        cp.append(c @ _t(f["c1_W0c"]).T)
+
+    def c1_net(f, h1, cpart):
+        a = _lrelu(h1 @ _t(f["c1_W0h"]).T + cpart, 0.01)
+        a = _lrelu(a @ _t(f["c1_W2"]).T + _t(f["c1_b2"]), 0.01)
+        return a @ _t(f["c1_W4"]).T + _t(f["c1_b4"])
+
+    # ---- f
+    p = xyz
+    ld_pt = torch.zeros(B, N)
+    ld_const = 0.0
+    for i in range(NUM_BLOCKS):
+        f = plan["flows"][i]
+        td = f["tdim"]
+        p = p @ _t(f["A"]).T + _t(f["a0"])
+        h1, h2 = p[..., :td], p[..., td:]
+        h2 = h2 - c1_net(f, h1, cp[i])
+        p = torch.cat([h1, h2], -1).flip(-1)
+        s, t = st[i]
+        p = (p - t) * torch.exp(-s)
+        ld_pt = ld_pt - s.sum(-1)
+        ld_const += f["ld_const"]
+    z = p
+    ldj = ld_pt.sum(1) + np.float32(ld_const * N)
+    logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + LOG2PI), dim=(1, 2)) + ldj)
+    # ---- interp
+    ip = plan["interp"]
+    idx8 = idx16[..., :8]
+    xj = _gather(xyz, idx8)
+    xi = xyz.unsqueeze(2).expand_as(xj)
+    nrm = torch.sqrt(((xi - xj) ** 2).sum(-1, keepdim=True))
+    d = xi @ _t(ip["d_PA"]).T + xj @ _t(ip["d_QB"]).T + nrm * _t(ip["d_wn"]) + _t(ip["d_b0"])
+    d = _lrelu(d, 0.01)
+    d = _lrelu(d @ _t(ip["d_W3"]).T + _t(ip["d_b3"]), 0.01)
+    d = d @ _t(ip["d_W6"]).T + _t(ip["d_b6"])                         # [B,N,8,128]
+    e = edgeconv(ip["ec"], xyz, idx8, 16, 8, 128, 16, pooling=False)    # [B,N,8,128]
+    ctx = torch.cat([d, e], -1)
+    w = _lrelu(ctx @ _t(ip["w_W0"]).T + _t(ip["w_b0"]), 0.01)
+    w = _lrelu(w @ _t(ip["w_W3"]).T + _t(ip["w_b3"]), 0.01)
+    w = w @ _t(ip["w_W6"]).T + _t(ip["w_b6"])                         # [B,N,8,R]
+    a = torch.softmax(w, dim=2)                                       # over k
+    zj = _gather(z, idx8)                                             # [B,N,8,3]
+    fz = torch.einsum("bnkc,bnkr->bncr", zj, a)                       # [B,N,3,R]
+    # ---- g
+    u = fz.permute(0, 1, 3, 2).reshape(B, N * R, 3)
+    rep = lambda v: torch.repeat_interleave(v, R, dim=1)
+    for i in reversed(range(NUM_BLOCKS)):
+        f = plan["flows"][i]
+        td = f["tdim"]
+        s, t = st[i]
+        u = u * torch.exp(rep(s)) + rep(t)
+        u = u.flip(-1)
+        h1, h2 = u[..., :td], u[..., td:]
+        h2 = h2 + c1_net(f, h1, rep(cp[i]))
+        u = torch.cat([h1, h2], -1)
+        u = u @ _t(f["Ai"]).T + _t(f["ai0"])
+    if stages:
+        return dict(cs=cs, z=z, ldj=ldj, logp=logp, w=a, fz=fz, x=u)
+    return u, logp

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python on CPU.
+
+Runs only in the build container (needs /root/reference, read-only).  Nothing from the
+reference is copied: the fixtures hold arrays only (inputs are regenerated from seeds by
+puflow_amd.weights, outputs are what the reference computed).
+
+Harness shims - none of them touches reference files:
+  1. `pytorch3d.ops` is not installed -> stub module with `knn_points` implementing the
+     build's canonical definition (unfused fp32 squared distance, order (dist, idx)),
+     `knn_gather` (plain indexing) and a placeholder `sample_farthest_points`.
+  2. numpy 2 has no `np.long` (permutate.py:44) -> alias to int64.
+  3. `GaussianDistribution.__init__` defaults to device 'cuda:0' (probs.py:51) -> 'cpu'.
+
+usage: python tools/make_golden.py            (writes tests/golden/)
+"""
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def _install_shims():
+    if not hasattr(np, "long"):
+        np.long = np.int64
+    sys.path.insert(0, REF)
+    p3d = types.ModuleType("pytorch3d")
+    ops = types.ModuleType("pytorch3d.ops")
+
+    def knn_points(p1, p2, K, return_nn=False, return_sorted=True, **kw):
+        d = p1[:, :, None, :] - p2[:, None, :, :]
+        dist = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        ds, order = torch.sort(dist, dim=-1, stable=True)
+        return ds[..., :K].contiguous(), order[..., :K].contiguous(), None
+
+    def knn_gather(x, idx):
+        B = x.shape[0]
+        return x[torch.arange(B).view(B, 1, 1), idx]
+
+    ops.knn_points, ops.knn_gather, ops.sample_farthest_points = knn_points, knn_gather, None
+    p3d.ops = ops
+    sys.modules["pytorch3d"] = p3d
+    sys.modules["pytorch3d.ops"] = ops
+    import modules.utils.probs as probs
+    probs.GaussianDistribution.__init__.__defaults__ = (1.0, "cpu")
+
+
+def build_reference(sd):
+    from modules.discrete.interpflow import PointInterpFlow
+    net = PointInterpFlow(3)
+    missing = net.load_state_dict(sd)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    net.set_to_initialized_state()
+    net.eval()
+    return net
+
+
+@torch.no_grad()
+def capture(net, xyz, upratio=4):
+    from pytorch3d.ops import knn_points
+    out = {}
+    _, idx16, _ = knn_points(xyz, xyz, K=16)
+    out["idx16"] = idx16
+    cs = net.feat_extract(xyz, idx16)
+    for i, c in enumerate(cs):
+        out[f"cs{i}"] = c
+    p = xyz
+    lds = []
+    for i in range(6):
+        p, ld = net.flow_blocks[i](p, cs[i])
+        lds.append(ld)
+        out[f"p{i}"] = p
+    out["block_ld"] = torch.stack(lds, 0)          # [6,B]
+    z, logp = net.log_prob(xyz, cs)
+    _, ldj = net.f(xyz, cs)
+    out["z"], out["logp"], out["ldj"] = z, logp, ldj
+    fz = net.interp(z, xyz, upratio)
+    out["fz"] = fz
+    x = net.g(fz, cs, upratio)
+    out["x"] = x
+    x2, logp2 = net(xyz, upratio)                   # whole forward (its own kNN call)
+    assert torch.equal(x2, x) and torch.equal(logp2, logp)
+    # round trip residual of one block
+    rt = net.flow_blocks[2].inverse(net.flow_blocks[2](xyz, cs[2])[0], cs[2])
+    out["roundtrip_err"] = (rt - xyz).abs().max()
+    return out
+
+
+def main():
+    _install_shims()
+    from puflow_amd.weights import synth_state_dict, synth_patches, state_dict_spec
+    torch.set_num_threads(1)                        # fixed reduction order for the fixtures
+    gdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gdir, exist_ok=True)
+    cases = [  # name, weight seed, data seed, B, N, surface, keep
+        ("n256_s0", 0, 0, 2, 256, True, "all"),
+        ("n256_s1", 1, 1, 1, 256, False, "small"),
+        ("n2048_s1", 1, 3, 1, 2048, True, "small"),
+    ]
+    for name, wseed, dseed, B, N, surface, keep in cases:
+        sd = synth_state_dict(wseed)
+        net = build_reference(sd)
+        xyz = synth_patches(B, N, seed=dseed, surface=surface)
+        out = capture(net, xyz)
+        arrays = {"meta_wseed": np.int64(wseed), "meta_dseed": np.int64(dseed), "meta_B": np.int64(B),
+                  "meta_N": np.int64(N), "meta_surface": np.int64(int(surface)),
+                  "meta_torch": np.array(torch.__version__), "meta_threads": np.int64(1)}
+        for k, v in out.items():
+            a = v.numpy()
+            if k == "idx16":
+                a = a.astype(np.int16)
+            if k.startswith("cs") or (k.startswith("p") and k[1:].isdigit()):
+                a = a[:, :(32 if keep == "small" else 96)]   # first points only (fixture size)
+            arrays[k] = a
+        path = os.path.join(gdir, f"forward_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(name, "x", tuple(out["x"].shape), "logp", float(out["logp"]), "rt_err", float(out["roundtrip_err"]),
+              "size", os.path.getsize(path))
+    # key/shape census of the reference checkpoints (data about the on-disk format, not weights)
+    import json
+    census = {}
+    for ck in ("puflow-x4-pu1k.pt", "puflow-x4-pugan.pt", "puflow-x4-pugeo.pt"):
+        ref = torch.load(os.path.join(REF, "pretrain", ck), map_location="cpu")
+        census[ck] = [[k, list(v.shape), str(v.dtype)] for k, v in ref.items()]
+    assert census["puflow-x4-pu1k.pt"] == census["puflow-x4-pugan.pt"] == census["puflow-x4-pugeo.pt"]
+    with open(os.path.join(gdir, "state_dict_census.json"), "w") as f:
+        json.dump(census["puflow-x4-pu1k.pt"], f)
+    print("census", len(census["puflow-x4-pu1k.pt"]))
+
+
+if __name__ == "__main__":
+    main()
