@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Headline benchmark: patches/sec, discrete PU-Flow x4, 2048 -> 8192 points per patch
+(BASELINE.json metric; workload = configs[1]: batch of 32 x 2048-point patches per GPU, eval).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  Patches are independent, so the batch is sharded over ranks with NO
+data-path collective (weak scaling: 32 patches per GPU); the only collectives are the timing
+barrier and the MAX over ranks of the elapsed time.  A step = one PointInterpFlow.forward over
+the rank's 32 patches, inputs resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 peak
+
+
+def edgeconv_ref_flops(T, C, g, nconv, odim, K=16):
+    """Algorithmic FLOPs of one EdgeConv unit in the REFERENCE's dense formulation
+    (2 x MACs of the 1x1 convs on [3C + g t] channels over T*K edges)."""
+    macs = sum((3 * C + g * t) * g for t in range(nconv)) + (3 * C + g * nconv) * odim
+    return 2.0 * T * K * macs
+
+
+def model_ref_flops_per_patch():
+    return 36.70e9               # 18.351 GMAC per 2048-pt patch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="patches per GPU")
+    ap.add_argument("--npoint", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from puflow_amd.interpflow import PointInterpFlow
+    from puflow_amd.weights import synth_patches, synth_state_dict
+
+    sd = synth_state_dict(2021)
+    net = PointInterpFlow(3)
+    net.load_state_dict(sd)
+    net.set_to_initialized_state()
+    net = net.to(dev).eval()
+    xyz_cpu = synth_patches(args.batch, args.npoint, seed=2021 + rank)     # each rank its own shard
+    xyz = xyz_cpu.to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        net(xyz, 4)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x, logp = net(xyz, 4)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    patches = world * args.batch * args.steps
+    value = patches / el
+
+    out = None
+    if rank == 0:
+        # ---- dominant kernel: EdgeConv (units 2..5 share one kernel); live HIP-event timing on the launch stream
+        eng = net._engine(4)
+        prof = eng.profile_stages(xyz, iters=5)
+        T = args.batch * args.npoint
+        ec_ms = prof["edgeconv3"]                       # C=128 unit: avg ms per launch
+        ec_fl = edgeconv_ref_flops(T, 128, 32, 4, 128)
+        knn_ms = prof["knn"]
+        knn_bytes = T * (3 * 4 + 16 * 4)               # 155 648 B per 2048-pt patch
+        roof = {"bound": "mfma", "kernel": "edgeconv_kernel<GB=2,NCONV=4,ODIM=128> (unit 3)",
+                "achieved": ec_fl / (ec_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": ec_fl / (ec_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None,
+                "flops_basis": "reference dense formulation (SURVEY 8d); executed MFMA flops are lower (P/Q fold)",
+                "avg_launch_ms": ec_ms}
+        extra = {"stage_ms": prof,
+                 "knn_hbm": {"achieved": knn_bytes / (knn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "note": "kNN is VALU/selection-bound by construction (216 flop/B)"},
+                 "model_mfma_frac": model_ref_flops_per_patch() * value / world / 1e12 / FP32_MFMA_PEAK_TF}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ref_cpu as O
+            ncpu = os.cpu_count() or 1
+            torch.set_num_threads(ncpu)
+            bs = 2
+            xs = xyz_cpu[:bs]
+            O.forward(sd, xs, 4)                        # warm-up
+            n, t1 = 0, time.perf_counter()
+            while True:
+                xr, lr = O.forward(sd, xs, 4)
+                n += 1
+                if time.perf_counter() - t1 > args.cpu_seconds:
+                    break
+            cel = time.perf_counter() - t1
+            cpu = {"value": bs * n / cel, "unit": "patches/s", "cores": ncpu, "kind": "port",
+                   "sample": f"{n} forwards of {bs} x {args.npoint}-pt patches, fp32 torch-CPU oracle (oracle/ref_cpu.py)"}
+            err = (x[:bs].cpu() - xr).abs().max().item()
+            extra["parity"] = {"max_abs_dx_vs_oracle": err,
+                               "logp_note": "logp is a batch mean; compared in tests on equal batches"}
+        out = {"metric": "patches/sec x4 2048->8192 (PU1K discrete, eval)", "value": value, "unit": "patches/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: PU1K discrete x4 inference, 32 x 2048-pt patches per GPU "
+                                      "(f32 exact-parity mode)", "patches_per_gpu": args.batch, "npoint": args.npoint,
+                          "upratio": 4, "sharding": f"patch batch over {world} rank(s), no data-path collective"},
+               "roofline": roof, "cpu_baseline": cpu}
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""ctypes binding of libpuflow_hip.so (C ABI: include/puflow_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, we raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpuflow_hip.so")
+_lib = None
+
+# name -> (restype, argtypes); must list every symbol declared in include/puflow_hip.h
+SIGNATURES = {
+    "pf_version": (c_int, []),
+    "pf_error_string": (c_char_p, [c_int]),
+    "pf_knn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pf_nn1": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pf_edgeconv": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pf_post": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                        c_void_p]),
+    "pf_flow_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "pf_flow_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pf_logp": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_interp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_int, c_int, c_int,
+                          c_void_p]),
+}
+
+
+class PuflowHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PuflowHipError(
+            f"{LIB_PATH} not found: build it with `python -m puflow_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().pf_error_string(rc).decode()
+        raise PuflowHipError(f"{what}: {msg} (code {rc})")
+
+
+def offsets(vals):
+    return (c_longlong * len(vals))(*[int(v) for v in vals])

@@ -1,0 +1,131 @@
+// Device helpers shared by the PU-Flow HIP kernels (gfx950 / CDNA4 only).
+//
+// Register data layout used by every MLP-shaped kernel here ("channel-major chain"):
+//   v_mfma_f32_16x16x4_f32 computes D(16x16) = A(16x4) * B(4x16) + C with
+//     A: lane l holds A[row = l&15][k = l>>4]          (one float)
+//     B: lane l holds B[k = l>>4][col = l&15]          (one float)
+//     C/D: lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3   (float4)
+//   We put OUTPUT CHANNELS on rows and POINTS/EDGES on the 16 columns, so a 16-channel block of
+//   activations for 16 columns is one float4 per lane:  lane (col = l&15, q = l>>4), register r
+//   <-> channel 16*cb + 4*q + r.  That is exactly the B operand the NEXT layer needs if its
+//   K-step "r" consumes channels {16*cb + 4*q + r | q = 0..3}: no LDS round trip, no shuffles
+//   between layers.  The host packs each weight matrix accordingly (packing.frag_pack):
+//   fragment (ob, cb) is 64 lanes x float4, lane l = W[16*ob + (l&15)][16*cb + 4*(l>>4) + r].
+//   The f32 MFMA is an exact k-ordered fp32 fma chain (no reduced precision).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define PF_WAVE 64
+
+__device__ __forceinline__ f4 pf_mfma(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f4 pf_splat(float v) { f4 r = {v, v, v, v}; return r; }
+
+__device__ __forceinline__ f4 pf_lrelu(f4 v, float slope) {
+    f4 r;
+    r.x = v.x >= 0.f ? v.x : v.x * slope;
+    r.y = v.y >= 0.f ? v.y : v.y * slope;
+    r.z = v.z >= 0.f ? v.z : v.z * slope;
+    r.w = v.w >= 0.f ? v.w : v.w * slope;
+    return r;
+}
+
+__device__ __forceinline__ f4 pf_relu(f4 v) {
+    f4 r;
+    r.x = fmaxf(v.x, 0.f); r.y = fmaxf(v.y, 0.f); r.z = fmaxf(v.z, 0.f); r.w = fmaxf(v.w, 0.f);
+    return r;
+}
+
+__device__ __forceinline__ float pf_lrelu1(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+// ---- weight fragment sources -----------------------------------------------------------
+// Every lane-address of a weight fragment is (wave-uniform base) + lane*16.  hipcc otherwise
+// hoists one 64-bit VGPR address pair PER FRAGMENT out of the persistent tile loop (hundreds of
+// VGPRs); both sources below keep it to ONE VGPR:
+//   PfWLds : fragments resident in LDS, ds_read_b128 with a 16-bit immediate offset
+//   PfWBuf : fragments in global memory through a buffer descriptor (SGPRs), uniform soffset
+struct PfWLds {
+    const f4* base;     // LDS
+    int lane;
+    __device__ __forceinline__ f4 load(int frag) const { return base[frag * PF_WAVE + lane]; }
+};
+
+struct PfWBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;           // lane * 16
+    __device__ __forceinline__ PfWBuf(const void* p, int lane)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000)), voff(lane * 16) {}
+    __device__ __forceinline__ f4 load(int frag) const {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, frag * (PF_WAVE * 16), 0);
+        return __builtin_bit_cast(f4, v);
+    }
+};
+
+// acc[p][acc0+ob] += W[ob][cb] * in[p][in0+cb]  for ob < OB, cb < CB.
+// Fragment (ob, cb) of this matrix is `frag0 + ob*WCB + cb` of the weight source
+// (WCB = number of 16-channel input blocks of the packed matrix = its row stride).
+// P independent column tiles share each weight fragment (and give independent MFMA chains).
+// Software pipeline: D fragments are kept in flight; a sched_barrier after every fragment's MFMAs
+// stops hipcc from hoisting ALL loads to the top of the kernel.
+template <int OB, int CB, int WCB, int D = 3, class WS, int P, int NIN, int NACC>
+__device__ __forceinline__ void pf_mm(const WS& ws, int frag0, const f4 (&in)[P][NIN], int in0,
+                                      f4 (&acc)[P][NACC], int acc0) {
+    constexpr int NFRAG = OB * CB;
+    constexpr int DD = D < NFRAG ? D : NFRAG;
+    f4 wb[DD];
+#pragma unroll
+    for (int i = 0; i < DD; ++i) wb[i] = ws.load(frag0 + (i / CB) * WCB + (i % CB));
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) {
+        const int ob = i / CB, cb = i % CB;
+        const f4 wv = wb[i % DD];
+        if (i + DD < NFRAG) wb[i % DD] = ws.load(frag0 + ((i + DD) / CB) * WCB + ((i + DD) % CB));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                acc[p][acc0 + ob] = pf_mfma(wv[r], in[p][in0 + cb][r], acc[p][acc0 + ob]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// cooperative global -> LDS copy of `nf4` float4 by the whole workgroup (call before a __syncthreads)
+__device__ __forceinline__ void pf_stage_lds(f4* __restrict__ dst, const f4* __restrict__ src, int nf4) {
+    for (int i = threadIdx.x; i < nf4; i += blockDim.x) dst[i] = src[i];
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void pf_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pf_static_for<I + 1, N>(f);
+    }
+}
+
+// bias / per-channel vector as accumulator initialiser: channels 16*ob + 4*q .. +3
+__device__ __forceinline__ f4 pf_bias(const float* __restrict__ b, int ob, int q) {
+    return *reinterpret_cast<const f4*>(b + ob * 16 + 4 * q);
+}
+
+// max over the 16 lanes of a DPP row (= the 16 columns of one MFMA tile); every lane gets the max.
+__device__ __forceinline__ float pf_rowmax16(float v) {
+    // row_ror:n = 0x120 + n
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));
+    return v;
+}
+
+// XCD-aware tile order (guide T1): virtual id v -> logical tile so that the workgroups that
+// share an XCD (equal blockIdx % 8 under round-robin dispatch) walk one contiguous chunk of
+// tiles (= the same batch items -> their gather table stays in that XCD's L2).  Speed only.
+__device__ __forceinline__ int pf_xcd_tile(int v, int chunk) { return (v & 7) * chunk + (v >> 3); }

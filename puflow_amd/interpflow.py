@@ -1,0 +1,365 @@
+"""PointInterpFlow on MI355X: the reference's module surface over the HIP kernels.
+
+Drop-in for `modules/discrete/interpflow.py:262-350` (reference): same constructor, same
+`forward / sample / feat_extract / f / g / log_prob / set_to_initialized_state` methods and the
+same 408-entry `state_dict` (reference checkpoints load unchanged, ours load into the reference).
+The sub-modules below only HOLD parameters under the reference's names; all arithmetic of the
+inference path runs in libpuflow_hip.so (no torch math, no CPU fallback).
+
+Weights are folded + packed once (puflow_amd/packing.py) and cached on the device; the cache is
+dropped by load_state_dict(), .to()/.cuda() and train().
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib
+from .packing import COND_CHANNELS, FEAT_CHANNELS, GROWTH, NUM_BLOCKS, fold_state_dict, pack_plan
+
+_EC_CFG = [0, 1, 2, 2, 2, 2]
+
+
+# ----------------------------------------------------------------------------------------
+# parameter holders (names = reference state_dict keys)
+# ----------------------------------------------------------------------------------------
+def _conv_bn(cin: int, cout: int, slope: float) -> nn.Sequential:
+    return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1), nn.BatchNorm2d(cout), nn.LeakyReLU(slope))
+
+
+class _EdgeConvParams(nn.Module):
+    """FeatureExtractUnit parameters (interpflow.py:190-221)."""
+
+    def __init__(self, cin: int, odim: int, growth: int):
+        super().__init__()
+        nconv = odim // growth
+        self.convs = nn.ModuleList([_conv_bn(3 * cin + growth * t, growth, 0.05) for t in range(nconv)])
+        self.conv_out = nn.Conv2d(3 * cin + growth * nconv, odim, kernel_size=1)
+
+
+class _MergeParams(nn.Module):
+    """FeatMergeUnit parameters (interpflow.py:251-255)."""
+
+    def __init__(self, idim: int, odim: int):
+        super().__init__()
+        self.conv1 = nn.Linear(idim, idim // 2, bias=True)
+        self.conv2 = nn.Linear(idim // 2, odim, bias=False)
+
+
+class _CondNet(nn.Module):
+    """LinearA1D parameters (interpflow.py:22-36); last layer zero-initialised like the reference."""
+
+    def __init__(self, din: int, dh: int, dout: int):
+        super().__init__()
+        last = nn.Linear(dh, dout, bias=True)
+        nn.init.zeros_(last.weight)
+        nn.init.zeros_(last.bias)
+        self.layers = nn.Sequential(nn.Linear(din, dh, bias=False), nn.LeakyReLU(), nn.Linear(dh, dh, bias=True),
+                                    nn.LeakyReLU(), last)
+
+
+class _ActNormParams(nn.Module):
+    def __init__(self, ch: int):
+        super().__init__()
+        self.logs = nn.Parameter(torch.zeros(1, 1, ch))
+        self.bias = nn.Parameter(torch.zeros(1, 1, ch))
+        self.is_inited = False           # plain attribute, not in the state_dict (normalize.py:28)
+
+
+class _Holder(nn.Module):
+    pass
+
+
+class _FlowBlockParams(nn.Module):
+    """FlowBlock parameters (interpflow.py:46-63)."""
+
+    def __init__(self, idim: int, hdim: int, cdim: int, is_even: bool):
+        super().__init__()
+        self.actnorm = _ActNormParams(idim)
+        self.permutate1 = _Holder()
+        self.permutate1.permutater = _Holder()
+        q, _ = np.linalg.qr(np.random.randn(idim, idim))          # permutate.py:102-105
+        self.permutate1.permutater.W = nn.Parameter(torch.from_numpy(q.astype(np.float32)))
+        self.permutate2 = _Holder()
+        self.permutate2.permutater = _Holder()
+        rev = torch.arange(idim - 1, -1, -1, dtype=torch.int64)
+        self.permutate2.permutater.register_buffer("direct_idx", rev.clone())
+        self.permutate2.permutater.register_buffer("inverse_idx", rev.clone())
+        tdim = 1 if is_even else 2
+        self.coupling1 = _Holder()
+        self.coupling1.bias_net = _CondNet(tdim + cdim, hdim, idim - tdim)
+        self.coupling2 = _Holder()
+        self.coupling2.bias_net = _CondNet(cdim, hdim, idim)
+        self.coupling2.scale_net = _CondNet(cdim, hdim, idim)
+
+
+class _InterpParams(nn.Module):
+    """InterpolationModule parameters (interpflow.py:85-151)."""
+
+    def __init__(self):
+        super().__init__()
+        self.knn_context = _Holder()
+        self.knn_context.distance_encoder = _Holder()
+        self.knn_context.distance_encoder.mlp = nn.Sequential(
+            *_conv_bn(10, 64, 0.01), *_conv_bn(64, 64, 0.01), nn.Conv2d(64, 128, kernel_size=1))
+        self.knn_context.feat_conv = _EdgeConvParams(3, 128, 16)
+        self.weight_unit = _Holder()
+        self.weight_unit.mlp = nn.Sequential(
+            *_conv_bn(256, 128, 0.01), *_conv_bn(128, 64, 0.01), nn.Conv2d(64, 32, kernel_size=1))
+
+
+class CondList(list):
+    """`cs` as returned by feat_extract: the 6 conditioning tensors plus the per-point conditioner
+    outputs (cp, st) the flow kernels consume."""
+    cp: Tensor
+    st: Tensor
+
+
+# ----------------------------------------------------------------------------------------
+# HIP engine
+# ----------------------------------------------------------------------------------------
+class _Engine:
+    def __init__(self, sd, device: torch.device, upratio: int):
+        self.lib = _lib.load()
+        self.device = device
+        self.R = upratio
+        pk = pack_plan(fold_state_dict(sd, upratio))
+        self.blob = torch.from_numpy(pk["blob"]).to(device)
+        self.base = self.blob.data_ptr()
+        self.ec_tab0 = pk["ec_tab0"]
+        self.ec_w = pk["ec_w"]
+        self.post = [_lib.offsets(o) for o in pk["post"]]
+        self.flow = pk["flow"]
+        self.interp_off = _lib.offsets(pk["interp"])
+        self.ld_const = pk["ld_const"]
+
+    def _p(self, off: int) -> int:
+        return self.base + 4 * off
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def knn(self, xyz: Tensor) -> Tensor:
+        B, N, _ = xyz.shape
+        idx = torch.empty((B, N, 16), dtype=torch.int32, device=xyz.device)
+        _lib.check(self.lib.pf_knn(xyz.data_ptr(), xyz.data_ptr(), B, N, N, 16, idx.data_ptr(), None, self._stream()),
+                   "pf_knn")
+        return idx
+
+    def features(self, xyz: Tensor, idx16: Tensor, want_cs: bool):
+        """6x (EdgeConv -> per-point stage).  Returns cs (or None), cp [6,T,64], st [6,T,8]."""
+        B, N, _ = xyz.shape
+        T, dev, s = B * N, xyz.device, self._stream()
+        cp = torch.empty((NUM_BLOCKS, T, 64), dtype=torch.float32, device=dev)
+        st = torch.empty((NUM_BLOCKS, T, 8), dtype=torch.float32, device=dev)
+        pq = torch.empty((T, 512), dtype=torch.float32, device=dev)
+        cs: List[Optional[Tensor]] = []
+        for u in range(NUM_BLOCKS):
+            odim = FEAT_CHANNELS[u + 1]
+            h = torch.empty((T, odim), dtype=torch.float32, device=dev)
+            src = xyz.data_ptr() if u == 0 else pq.data_ptr()
+            tab = self._p(self.ec_tab0) if u == 0 else None
+            _lib.check(self.lib.pf_edgeconv(_EC_CFG[u], src, tab, idx16.data_ptr(), self._p(self.ec_w[u]),
+                                            h.data_ptr(), B, N, s), f"pf_edgeconv[{u}]")
+            c = torch.empty((B, N, COND_CHANNELS[u]), dtype=torch.float32, device=dev) if want_cs else None
+            _lib.check(self.lib.pf_post(u, h.data_ptr(), self.base, self.post[u], c.data_ptr() if want_cs else None,
+                                        st[u].data_ptr(), cp[u].data_ptr(), pq.data_ptr() if u < 5 else None, T, s),
+                       f"pf_post[{u}]")
+            cs.append(c)
+        return (cs if want_cs else None), cp, st
+
+    def flow_f(self, xyz: Tensor, cp: Tensor, st: Tensor):
+        B, N, _ = xyz.shape
+        T, dev, s = B * N, xyz.device, self._stream()
+        z = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        ld_pt = torch.empty((T,), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.pf_flow_fwd(xyz.data_ptr(), cp.data_ptr(), st.data_ptr(), self._p(self.flow),
+                                        z.data_ptr(), ld_pt.data_ptr(), T, s), "pf_flow_fwd")
+        ldj = torch.empty((B,), dtype=torch.float32, device=dev)
+        lps = torch.empty((B,), dtype=torch.float32, device=dev)
+        logp = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.pf_logp(z.data_ptr(), ld_pt.data_ptr(), self.ld_const, B, N, ldj.data_ptr(),
+                                    lps.data_ptr(), logp.data_ptr(), s), "pf_logp")
+        return z, ldj, logp
+
+    def interp(self, xyz: Tensor, z: Tensor, idx16: Tensor) -> Tensor:
+        B, N, _ = xyz.shape
+        u = torch.empty((B, N * self.R, 3), dtype=torch.float32, device=xyz.device)
+        _lib.check(self.lib.pf_interp(xyz.data_ptr(), z.data_ptr(), idx16.data_ptr(), self.base, self.interp_off,
+                                      u.data_ptr(), B, N, self.R, self._stream()), "pf_interp")
+        return u
+
+    def flow_g(self, u: Tensor, cp: Tensor, st: Tensor, R: int) -> Tensor:
+        B, NR, _ = u.shape
+        T = B * NR // R
+        x = torch.empty_like(u)
+        _lib.check(self.lib.pf_flow_inv(u.data_ptr(), cp.data_ptr(), st.data_ptr(), self._p(self.flow), x.data_ptr(),
+                                        T, R, self._stream()), "pf_flow_inv")
+        return x
+
+
+    def profile_stages(self, xyz: Tensor, iters: int = 5) -> dict:
+        """Average ms per launch of each stage, timed with HIP events on the launch stream
+        (torch's current stream IS the stream the kernels are enqueued on)."""
+        B, N, _ = xyz.shape
+        T, dev, s = B * N, xyz.device, self._stream()
+        acc: dict = {}
+
+        def timed(name, fn):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = fn()
+            b.record()
+            acc.setdefault(name, []).append((a, b))
+            return r
+
+        for _ in range(iters + 1):
+            idx16 = timed("knn", lambda: self.knn(xyz))
+            cp = torch.empty((NUM_BLOCKS, T, 64), dtype=torch.float32, device=dev)
+            st = torch.empty((NUM_BLOCKS, T, 8), dtype=torch.float32, device=dev)
+            pq = torch.empty((T, 512), dtype=torch.float32, device=dev)
+            for u in range(NUM_BLOCKS):
+                h = torch.empty((T, FEAT_CHANNELS[u + 1]), dtype=torch.float32, device=dev)
+                src = xyz.data_ptr() if u == 0 else pq.data_ptr()
+                tab = self._p(self.ec_tab0) if u == 0 else None
+                timed(f"edgeconv{u}", lambda: _lib.check(self.lib.pf_edgeconv(
+                    _EC_CFG[u], src, tab, idx16.data_ptr(), self._p(self.ec_w[u]), h.data_ptr(), B, N, s)))
+                timed(f"post{u}", lambda: _lib.check(self.lib.pf_post(
+                    u, h.data_ptr(), self.base, self.post[u], None, st[u].data_ptr(), cp[u].data_ptr(),
+                    pq.data_ptr() if u < 5 else None, T, s)))
+            z, _, _ = timed("flow_f+logp", lambda: self.flow_f(xyz, cp, st))
+            u_ = timed("interp", lambda: self.interp(xyz, z, idx16))
+            timed("flow_g", lambda: self.flow_g(u_, cp, st, self.R))
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v[1:]) / (len(v) - 1) for k, v in acc.items()}
+
+
+# ----------------------------------------------------------------------------------------
+class PointInterpFlow(nn.Module):
+    """Reference surface: modules/discrete/interpflow.py:262-350."""
+
+    def __init__(self, pc_channel: int = 3):
+        super().__init__()
+        if pc_channel != 3:
+            raise ValueError("the HIP path is built for 3-D points (pc_channel=3)")
+        self.num_blocks = NUM_BLOCKS
+        self.num_neighbors = 16
+        self.interp = _InterpParams()
+        self.feat_convs = nn.ModuleList(
+            [_EdgeConvParams(FEAT_CHANNELS[i], FEAT_CHANNELS[i + 1], GROWTH[i]) for i in range(NUM_BLOCKS)])
+        self.merge_convs = nn.ModuleList(
+            [_MergeParams(FEAT_CHANNELS[i + 1], COND_CHANNELS[i]) for i in range(NUM_BLOCKS)])
+        self.flow_blocks = nn.ModuleList(
+            [_FlowBlockParams(pc_channel, 64, COND_CHANNELS[i], i % 2 == 0) for i in range(NUM_BLOCKS)])
+        self._engine_cache: Optional[_Engine] = None
+
+    # ---- plan cache ---------------------------------------------------------------------
+    def invalidate_plan(self) -> None:
+        self._engine_cache = None
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate_plan()
+        return super().load_state_dict(*a, **kw)
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_plan()
+        return super()._apply(fn, *a, **kw)
+
+    def train(self, mode: bool = True):
+        self.invalidate_plan()
+        return super().train(mode)
+
+    def _engine(self, upratio: int) -> _Engine:
+        e = self._engine_cache
+        dev = self.flow_blocks[0].actnorm.logs.device
+        if e is None or e.R != upratio or e.device != dev:
+            if dev.type != "cuda":
+                raise _lib.PuflowHipError("PointInterpFlow runs on the GPU only: move the module with .to('cuda')")
+            e = _Engine(self.state_dict(), dev, upratio)
+            self._engine_cache = e
+        return e
+
+    def _check_mode(self):
+        if self.training:
+            raise NotImplementedError("HIP path covers eval mode; the training step (BN batch statistics, "
+                                      "backward) is not built yet - call .eval()")
+        for b in self.flow_blocks:
+            if not b.actnorm.is_inited:
+                raise RuntimeError("ActNorm not initialised: load a checkpoint and call set_to_initialized_state() "
+                                   "(reference upsample.py:32-33)")
+
+    @staticmethod
+    def _prep(xyz: Tensor) -> Tensor:
+        if not xyz.is_cuda:
+            raise _lib.PuflowHipError("input must be a GPU tensor (no CPU fallback)")
+        return xyz.detach().contiguous().float()
+
+    # ---- reference surface ---------------------------------------------------------------
+    def set_to_initialized_state(self) -> None:
+        for b in self.flow_blocks:
+            b.actnorm.is_inited = True
+
+    @torch.no_grad()
+    def feat_extract(self, xyz: Tensor, knn_idx: Tensor) -> CondList:
+        self._check_mode()
+        xyz = self._prep(xyz)
+        e = self._engine(4)
+        cs, cp, st = e.features(xyz, knn_idx.to(torch.int32).contiguous(), want_cs=True)
+        out = CondList(cs)
+        out.cp, out.st = cp, st
+        return out
+
+    @torch.no_grad()
+    def f(self, xyz: Tensor, cs: CondList) -> Tuple[Tensor, Tensor]:
+        self._check_mode()
+        z, ldj, _ = self._engine(4).flow_f(self._prep(xyz), cs.cp, cs.st)
+        return z, ldj
+
+    @torch.no_grad()
+    def log_prob(self, xyz: Tensor, cs: CondList) -> Tuple[Tensor, Tensor]:
+        self._check_mode()
+        z, _, logp = self._engine(4).flow_f(self._prep(xyz), cs.cp, cs.st)
+        return z, logp
+
+    @torch.no_grad()
+    def g(self, z: Tensor, cs: CondList, upratio: int) -> Tensor:
+        """z: [B,N,3,R] (reference layout) -> [B,N*R,3]."""
+        self._check_mode()
+        u = torch.flatten(self._prep(z).transpose(2, 3), 1, 2).contiguous()
+        return self._engine(upratio).flow_g(u, cs.cp, cs.st, upratio)
+
+    @torch.no_grad()
+    def forward(self, xyz: Tensor, upratio: int = 4) -> Tuple[Tensor, Tensor]:
+        self._check_mode()
+        xyz = self._prep(xyz)
+        e = self._engine(upratio)
+        idx16 = e.knn(xyz)
+        _, cp, st = e.features(xyz, idx16, want_cs=False)
+        z, _, logp = e.flow_f(xyz, cp, st)
+        u = e.interp(xyz, z, idx16)
+        x = e.flow_g(u, cp, st, upratio)
+        return x, logp
+
+    @torch.no_grad()
+    def forward_stages(self, xyz: Tensor, upratio: int = 4) -> dict:
+        """Every intermediate of forward() (parity tests)."""
+        self._check_mode()
+        xyz = self._prep(xyz)
+        e = self._engine(upratio)
+        idx16 = e.knn(xyz)
+        cs, cp, st = e.features(xyz, idx16, want_cs=True)
+        z, ldj, logp = e.flow_f(xyz, cp, st)
+        u = e.interp(xyz, z, idx16)
+        x = e.flow_g(u, cp, st, upratio)
+        B, N, _ = xyz.shape
+        fz = u.view(B, N, upratio, 3).transpose(2, 3)
+        return dict(idx16=idx16, cs=cs, cp=cp, st=st, z=z, ldj=ldj, logp=logp, fz=fz, x=x)
+
+    def sample(self, sparse: Tensor, upratio: int = 4) -> Tensor:
+        dense, _ = self(sparse, upratio)
+        return dense

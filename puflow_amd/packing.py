@@ -170,3 +170,122 @@ def frag_unpack(F: np.ndarray, out: int, inn: int) -> np.ndarray:
     OB, CB = F.shape[0], F.shape[1]
     f = F.reshape(OB, CB, 4, 16, 4).transpose(0, 3, 1, 2, 4)
     return f.reshape(OB * 16, CB * 16)[:out, :inn]
+
+
+# ---------------------------------------------------------------------------------------
+# Device blob: every folded matrix in kernel order + offset tables (float units, 64-aligned)
+# ---------------------------------------------------------------------------------------
+POST_SLOTS = ["M1", "b1", "M2", "H1", "S2", "bS2", "T2", "bT2", "ST4", "bST4", "PQ", "bPQ"]
+INTERP_SLOTS = ["dtab", "d_W3", "d_b3", "d_W6", "d_b6", "ectab", "ec_w", "w_W0", "w_b0", "w_W3", "w_b3", "w_W6", "w_b6"]
+FLOW_REC = 5360
+
+
+class _Blob:
+    def __init__(self):
+        self.parts: List[np.ndarray] = []
+        self.n = 0
+
+    def add(self, a: np.ndarray) -> int:
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+        off = self.n
+        pad = (-a.size) % 64
+        self.parts.append(a)
+        if pad:
+            self.parts.append(np.zeros(pad, np.float32))
+        self.n += a.size + pad
+        return off
+
+    def data(self) -> np.ndarray:
+        return np.concatenate(self.parts) if self.parts else np.zeros(0, np.float32)
+
+
+def _pad_vec(v: np.ndarray, n: int) -> np.ndarray:
+    out = np.zeros(n, np.float32)
+    out[:v.size] = v
+    return out
+
+
+def _edge_table(u: Dict[str, np.ndarray]) -> np.ndarray:
+    """[S][8] rows: PA(3) QB(3) pb 0   (C = 3 units; csrc/edgeconv.hip C3 variant, interp.hip)."""
+    S = u["PA"].shape[0]
+    t = np.zeros((S, 8), np.float32)
+    t[:, 0:3], t[:, 3:6], t[:, 6] = u["PA"], u["QB"], u["pb"]
+    return t
+
+
+def _ec_frags(u: Dict[str, np.ndarray], nconv: int) -> np.ndarray:
+    return np.concatenate([frag_pack(u[f"G{t}"]).reshape(-1) for t in range(1, nconv + 1)])
+
+
+def pack_flow_record(f: Dict[str, object]) -> np.ndarray:
+    """One 5360-float flow-block record (layout: csrc/flow.hip header)."""
+    rec = np.zeros(FLOW_REC, np.float32)
+    rec[0:4096] = frag_pack(f["c1_W2"]).reshape(-1)
+    W4 = f["c1_W4"]                                   # [3-td, 64]
+    W4r = np.zeros((16, 64), np.float32)
+    b4r = np.zeros(16, np.float32)
+    for q in range(4):
+        W4r[4 * q:4 * q + W4.shape[0]] = W4
+        b4r[4 * q:4 * q + W4.shape[0]] = f["c1_b4"]
+    rec[4096:5120] = frag_pack(W4r).reshape(-1)
+    rec[5120:5184] = f["c1_b2"]
+    rec[5184:5200] = b4r
+    W0h = np.zeros((64, 2), np.float32)
+    W0h[:, :f["tdim"]] = f["c1_W0h"]
+    rec[5200:5328] = W0h.reshape(-1)
+    rec[5328:5337] = f["A"].reshape(-1); rec[5337:5340] = f["a0"]
+    rec[5340:5349] = f["Ai"].reshape(-1); rec[5349:5352] = f["ai0"]
+    return rec
+
+
+def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
+    """-> {'blob': fp32 1-D array, 'ec_tab0', 'ec_w'[6], 'post'[6][12], 'flow', 'interp'[13], 'ld_const'}."""
+    B = _Blob()
+    out: Dict[str, object] = {}
+    units = plan["units"]
+    out["ec_tab0"] = B.add(_edge_table(units[0]))
+    out["ec_w"] = [B.add(_ec_frags(units[i], 4)) for i in range(NUM_BLOCKS)]
+    post = []
+    for i in range(NUM_BLOCKS):
+        m, f = plan["merges"][i], plan["flows"][i]
+        H1 = np.concatenate([f["s_W0"], f["t_W0"], f["c1_W0c"]], axis=0)            # [192, cdim]
+        ST4 = np.zeros((6, 128), np.float32)
+        ST4[0:3, 0:64] = f["s_W4"]; ST4[3:6, 64:128] = f["t_W4"]
+        bST4 = _pad_vec(np.concatenate([f["s_b4"], f["t_b4"]]), 16)
+        offs = {
+            "M1": B.add(frag_pack(m["W1"])), "b1": B.add(_pad_vec(m["b1"], ((m["b1"].size + 15) // 16) * 16)),
+            "M2": B.add(frag_pack(m["W2"])), "H1": B.add(frag_pack(H1)),
+            "S2": B.add(frag_pack(f["s_W2"])), "bS2": B.add(f["s_b2"]),
+            "T2": B.add(frag_pack(f["t_W2"])), "bT2": B.add(f["t_b2"]),
+            "ST4": B.add(frag_pack(ST4)), "bST4": B.add(bST4),
+        }
+        if i + 1 < NUM_BLOCKS:
+            nu = units[i + 1]
+            offs["PQ"] = B.add(frag_pack(np.concatenate([nu["PA"], nu["QB"]], axis=0)))
+            offs["bPQ"] = B.add(np.concatenate([nu["pb"], np.zeros_like(nu["pb"])]))
+        else:
+            offs["PQ"], offs["bPQ"] = 0, 0
+        post.append([offs[k] for k in POST_SLOTS])
+    out["post"] = post
+    out["flow"] = B.add(np.concatenate([pack_flow_record(f) for f in plan["flows"]]))
+    out["ld_const"] = float(sum(f["ld_const"] for f in plan["flows"]))
+    ip = plan["interp"]
+    dtab = np.zeros((64, 8), np.float32)
+    dtab[:, 0:3], dtab[:, 3:6], dtab[:, 6], dtab[:, 7] = ip["d_PA"], ip["d_QB"], ip["d_wn"], ip["d_b0"]
+    R = plan["upratio"]
+    W6r = np.zeros((16, 64), np.float32)
+    b6r = np.zeros(16, np.float32)
+    for q in range(4):
+        W6r[4 * q:4 * q + R] = ip["w_W6"]
+        b6r[4 * q:4 * q + R] = ip["w_b6"]
+    io = {
+        "dtab": B.add(dtab), "d_W3": B.add(frag_pack(ip["d_W3"])), "d_b3": B.add(ip["d_b3"]),
+        "d_W6": B.add(frag_pack(ip["d_W6"])), "d_b6": B.add(ip["d_b6"]),
+        "ectab": B.add(_edge_table(ip["ec"])), "ec_w": B.add(_ec_frags(ip["ec"], 8)),
+        "w_W0": B.add(frag_pack(ip["w_W0"])), "w_b0": B.add(ip["w_b0"]),
+        "w_W3": B.add(frag_pack(ip["w_W3"])), "w_b3": B.add(ip["w_b3"]),
+        "w_W6": B.add(frag_pack(W6r)), "w_b6": B.add(b6r),
+    }
+    out["interp"] = [io[k] for k in INTERP_SLOTS]
+    out["blob"] = B.data()
+    return out

@@ -1,0 +1,168 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors.  Needs a real MI355X:  python -m pytest tests -m gpu"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as O
+from puflow_amd.weights import synth_patches, synth_state_dict
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from puflow_amd import _lib
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return _lib.load()          # raises if the HIP library is missing: no silent fallback
+
+
+def _net(sd):
+    from puflow_amd.interpflow import PointInterpFlow
+    net = PointInterpFlow(3)
+    net.load_state_dict(sd)
+    net.set_to_initialized_state()
+    return net.to(DEV).eval()
+
+
+# ------------------------------------------------------------------------------------- kNN
+@pytest.mark.parametrize("B,N,M,K", [(2, 256, 256, 16), (1, 2048, 2048, 16), (3, 100, 77, 8), (1, 65, 300, 4),
+                                     (2, 130, 130, 32), (1, 16, 16, 16)])
+def test_knn_bit_exact(lib, B, N, M, K):
+    from puflow_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N + K)
+    p1 = torch.rand(B, N, 3, generator=g) * 2 - 1
+    p2 = p1.clone() if N == M else torch.rand(B, M, 3, generator=g) * 2 - 1
+    d_ref, i_ref = O.knn_canonical(p1, p2, K)
+    d, i, _ = ops.knn_points(p1.to(DEV), p2.to(DEV), K)
+    assert torch.equal(i.cpu(), i_ref)                       # indices bit-exact
+    assert torch.equal(d.cpu(), d_ref)                       # distances bit-exact (unfused fp32)
+
+
+def test_knn_ties_and_duplicates(lib):
+    from puflow_amd import ops
+    p = synth_patches(1, 128, seed=3, surface=False)
+    p[0, 10] = p[0, 3]; p[0, 50] = p[0, 3]; p[0, 77] = p[0, 76]      # exact duplicates
+    p[0, 100:110] = torch.round(p[0, 100:110] * 4) / 4                # lattice points: many equal distances
+    d_ref, i_ref = O.knn_canonical(p, p, 16)
+    d, i, _ = ops.knn_points(p.to(DEV), p.to(DEV), 16)
+    assert torch.equal(i.cpu(), i_ref)
+    assert i[0, 3, 0] == 3 and i[0, 3, 1] == 10 and i[0, 3, 2] == 50  # (dist, idx) order on ties
+
+
+def test_nn1_first_minimum(lib):
+    from puflow_amd import _lib
+    x = synth_patches(2, 300, seed=5, surface=False)
+    y = synth_patches(2, 200, seed=6, surface=False)
+    y[0, 7] = y[0, 2]
+    d1, i1, d2, i2 = O.chamfer_nn(x, y)
+    xd, yd = x.to(DEV), y.to(DEV)
+    dist = torch.empty(2, 300, device=DEV); idx = torch.empty(2, 300, dtype=torch.int32, device=DEV)
+    _lib.check(lib.pf_nn1(xd.data_ptr(), yd.data_ptr(), 2, 300, 200, dist.data_ptr(), idx.data_ptr(), None))
+    assert torch.equal(dist.cpu(), d1) and torch.equal(idx.cpu().long(), i1)
+
+
+# --------------------------------------------------------------------------- stage parity
+def _check_stages(st, ref, atol=1e-5):
+    assert torch.equal(st["idx16"].cpu().long(), ref["idx16"])
+    for i in range(6):
+        assert (st["cs"][i].cpu() - ref["cs"][i]).abs().max() < atol, f"cs[{i}]"
+    assert (st["z"].cpu() - ref["z"]).abs().max() < atol
+    assert ((st["ldj"].cpu() - ref["ldj"]).abs() / ref["ldj"].abs()).max() < 1e-5     # relative: |ldj| ~ 1e3..1e4
+    assert abs(float(st["logp"]) - float(ref["logp"])) / abs(float(ref["logp"])) < 1e-5
+    assert (st["fz"].cpu() - ref["fz"]).abs().max() < atol
+    assert (st["x"].cpu() - ref["x"]).abs().max() < atol                               # north_star: xyz within 1e-5
+
+
+@pytest.mark.parametrize("wseed,dseed,B,N,surface", [(0, 0, 2, 256, True), (1, 1, 1, 256, False), (2, 9, 3, 512, True),
+                                                     (3, 4, 1, 200, True), (4, 2, 5, 61, False)])
+def test_forward_stages_match_oracle(lib, wseed, dseed, B, N, surface):
+    sd = synth_state_dict(wseed)
+    xyz = synth_patches(B, N, seed=dseed, surface=surface)
+    ref = O.forward(sd, xyz, 4, stages=True)
+    st = _net(sd).forward_stages(xyz.to(DEV), 4)
+    _check_stages(st, ref)
+
+
+@pytest.mark.parametrize("name", ["n256_s0", "n256_s1", "n2048_s1"])
+def test_forward_matches_reference_golden(lib, golden_dir, name):
+    """HIP output against what the REFERENCE's own Python produced (tools/make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, f"forward_{name}.npz"))
+    sd = synth_state_dict(int(g["meta_wseed"]))
+    xyz = synth_patches(int(g["meta_B"]), int(g["meta_N"]), seed=int(g["meta_dseed"]), surface=bool(g["meta_surface"]))
+    net = _net(sd)
+    st = net.forward_stages(xyz.to(DEV), 4)
+    assert np.array_equal(st["idx16"].cpu().numpy().astype(np.int64), g["idx16"].astype(np.int64))
+    np.testing.assert_allclose(st["x"].cpu().numpy(), g["x"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(st["z"].cpu().numpy(), g["z"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(st["fz"].cpu().numpy(), g["fz"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(st["ldj"].cpu().numpy(), g["ldj"], rtol=1e-5)
+    np.testing.assert_allclose(float(st["logp"]), float(g["logp"]), rtol=1e-5)
+    for i in range(6):
+        n = g[f"cs{i}"].shape[1]
+        np.testing.assert_allclose(st["cs"][i].cpu().numpy()[:, :n], g[f"cs{i}"], rtol=0, atol=1e-5)
+    x, logp = net(xyz.to(DEV), 4)                         # plain forward == staged forward, bit for bit
+    assert torch.equal(x, st["x"]) and torch.equal(logp, st["logp"])
+
+
+def test_reference_method_surface(lib):
+    """feat_extract / f / log_prob / g / sample called the way the reference's callers do."""
+    from puflow_amd import ops
+    sd = synth_state_dict(7)
+    xyz = synth_patches(2, 256, seed=8)
+    ref = O.forward(sd, xyz, 4, stages=True)
+    net = _net(sd)
+    xd = xyz.to(DEV)
+    _, knn_idx, _ = ops.knn_points(xd, xd, K=16, return_nn=False, return_sorted=False)
+    assert knn_idx.dtype == torch.int64
+    cs = net.feat_extract(xd, knn_idx)
+    assert len(cs) == 6 and tuple(cs[5].shape) == (2, 256, 128)
+    z, ldj = net.f(xd, cs)
+    z2, logp = net.log_prob(xd, cs)
+    assert torch.equal(z, z2)
+    assert (z.cpu() - ref["z"]).abs().max() < 1e-5
+    x = net.g(ref["fz"].to(DEV), cs, 4)
+    assert (x.cpu() - ref["x"]).abs().max() < 1e-5
+    assert (net.sample(xd, 4).cpu() - ref["x"]).abs().max() < 1e-5
+    # exact invertibility of the flow: g(f(x)) with one replica returns x
+    back = net.g(z.unsqueeze(-1), cs, 1)
+    assert (back - xd).abs().max() < 2e-6
+    g = ops.knn_gather(xd, knn_idx)
+    assert torch.equal(g.cpu(), O.knn_gather(xyz, ref["idx16"]))
+
+
+# ------------------------------------------------------------------- full-size properties
+def test_full_size_properties(lib):
+    """BASELINE config 2 shape (32 x 2048): size-independent properties + oracle on a slice."""
+    sd = synth_state_dict(2021)
+    xyz = synth_patches(32, 2048, seed=2021)
+    net = _net(sd)
+    xd = xyz.to(DEV)
+    st = net.forward_stages(xd, 4)
+    x, z = st["x"], st["z"]
+    assert tuple(x.shape) == (32, 8192, 3) and torch.isfinite(x).all() and torch.isfinite(st["logp"])
+    # self is the nearest neighbour; neighbour lists are sorted by distance
+    idx = st["idx16"].long()
+    assert torch.equal(idx[..., 0], torch.arange(2048, device=DEV).expand(32, -1))
+    nb = xd[torch.arange(32, device=DEV).view(32, 1, 1), idx]
+    d = ((nb - xd.unsqueeze(2)) ** 2).sum(-1)
+    assert (d[..., 1:] >= d[..., :-1] - 1e-7).all()
+    # flow invertibility at full size
+    cs = net.feat_extract(xd, idx)
+    back = net.g(z.unsqueeze(-1), cs, 1)
+    assert (back - xd).abs().max() < 2e-6
+    # patches are independent: a batch item alone gives the same bits
+    xs, _ = net(xd[5:6].contiguous(), 4)
+    assert torch.equal(xs[0], x[5])
+    # interpolated latents are convex combinations of neighbour latents
+    zn = z[torch.arange(32, device=DEV).view(32, 1, 1), idx[..., :8]]        # [B,N,8,3]
+    fz = st["fz"]                                                            # [B,N,3,R]
+    assert (fz <= zn.max(2)[0].unsqueeze(-1) + 1e-5).all() and (fz >= zn.min(2)[0].unsqueeze(-1) - 1e-5).all()
+    # oracle on two batch items
+    ref = O.forward(sd, xyz[3:5], 4, stages=True)
+    assert (x[3:5].cpu() - ref["x"]).abs().max() < 1e-5
+    assert ((st["ldj"][3:5].cpu() - ref["ldj"]).abs() / ref["ldj"].abs()).max() < 1e-5

@@ -1,0 +1,91 @@
+"""Host logic without a GPU: the C-ABI library loads and exports every symbol declared in
+include/puflow_hip.h; the module surface matches the reference state_dict; packing invariants."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from puflow_amd import build
+    return build.build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from puflow_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "puflow_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.pf_version() >= 100
+    assert lib.pf_error_string(-2) == b"shape precondition violated"
+
+
+def test_argument_validation_without_gpu(built_lib):
+    """Entry points reject bad arguments before touching the device."""
+    from puflow_amd import _lib
+    lib = _lib.load()
+    assert lib.pf_knn(None, None, 1, 16, 16, 16, None, None, None) == -1
+    assert lib.pf_knn(8, 8, 1, 16, 16, 17, 8, None, None) == -2        # K > M
+    assert lib.pf_knn(8, 8, 1, 16, 16, 5, 8, None, None) == -3         # K not built
+    assert lib.pf_edgeconv(7, 8, 8, 8, 8, 8, 1, 64, None) == -3
+    assert lib.pf_interp(8, 8, 8, 8, _lib.offsets([0] * 13), 8, 1, 64, 3, None) == -3
+
+
+def test_module_state_dict_matches_reference_census(golden_dir):
+    import json
+    from puflow_amd.interpflow import PointInterpFlow
+    from puflow_amd.weights import synth_state_dict
+    with open(os.path.join(golden_dir, "state_dict_census.json")) as f:
+        census = json.load(f)
+    net = PointInterpFlow(3)
+    sd = net.state_dict()
+    assert [k for k, _, _ in census] == list(sd.keys())
+    for k, shape, dt in census:
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == dt, k
+    res = net.load_state_dict(synth_state_dict(5))
+    assert not res.missing_keys and not res.unexpected_keys
+    # zero-initialised last conditioner layers, like the reference (interpflow.py:26-28)
+    fresh = PointInterpFlow(3)
+    assert float(fresh.flow_blocks[0].coupling1.bias_net.layers[4].weight.abs().sum()) == 0.0
+
+
+def test_product_fails_loudly_on_cpu():
+    from puflow_amd import _lib
+    from puflow_amd.interpflow import PointInterpFlow
+    net = PointInterpFlow(3).eval()
+    net.set_to_initialized_state()
+    with pytest.raises(_lib.PuflowHipError):
+        net(torch.zeros(1, 64, 3))
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 64, 3))
+
+
+def test_pack_plan_layout():
+    from puflow_amd.packing import FLOW_REC, fold_state_dict, frag_unpack, pack_plan
+    from puflow_amd.weights import synth_state_dict
+    plan = fold_state_dict(synth_state_dict(0))
+    pk = pack_plan(plan)
+    blob = pk["blob"]
+    assert blob.dtype == np.float32 and blob.size % 64 == 0
+    for offs in [pk["ec_w"], pk["interp"], [pk["flow"], pk["ec_tab0"]]] + pk["post"]:
+        assert all(o % 4 == 0 for o in offs)                   # 16-byte aligned float4 loads
+    # unit 3 growth weights: G1 (2x2 frags) first
+    g1 = frag_unpack(blob[pk["ec_w"][3]:pk["ec_w"][3] + 4 * 256].reshape(2, 2, 64, 4), 32, 32)
+    np.testing.assert_array_equal(g1, plan["units"][3]["G1"])
+    # flow record: W2 fragments then replicated W4 rows
+    rec = blob[pk["flow"] + 2 * FLOW_REC: pk["flow"] + 3 * FLOW_REC]
+    np.testing.assert_array_equal(frag_unpack(rec[:4096].reshape(4, 4, 64, 4), 64, 64), plan["flows"][2]["c1_W2"])
+    w4 = frag_unpack(rec[4096:5120].reshape(1, 4, 64, 4), 16, 64)
+    np.testing.assert_array_equal(w4[4:6], plan["flows"][2]["c1_W4"])
+    np.testing.assert_array_equal(rec[5328:5337].reshape(3, 3), plan["flows"][2]["A"])
