@@ -38,15 +38,18 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ p1, c
 
     for (int j = 0; j < M; ++j) {
         float d = sqdist(qx, qy, qz, r[j * 3 + 0], r[j * 3 + 1], r[j * 3 + 2]);
-        if (d < bd[K - 1]) {             // wave-divergent guard; body is a branch-free bubble insert
-            int id = j;
+        if (d < bd[K - 1]) {             // wave-divergent guard; body is a branch-free shifting insert
+            // lt[i] = d < bd[i] is monotone in i (bd ascending).  Slot i takes its left neighbour when
+            // the new element lands left of it, the new element when it lands exactly here, else keeps.
+            // Strict `<` puts the new (larger-index) element AFTER existing equal distances and never
+            // reorders existing entries.
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const bool c = d < bd[i];
-                const float lo = c ? d : bd[i], hi = c ? bd[i] : d;
-                const int ilo = c ? id : bi[i], ihi = c ? bi[i] : id;
-                bd[i] = lo; bi[i] = ilo; d = hi; id = ihi;
+            for (int i = K - 1; i >= 1; --i) {
+                const bool ltl = d < bd[i - 1], lti = d < bd[i];
+                bi[i] = ltl ? bi[i - 1] : (lti ? j : bi[i]);
+                bd[i] = ltl ? bd[i - 1] : (lti ? d : bd[i]);
             }
+            if (d < bd[0]) { bd[0] = d; bi[0] = j; }
         }
     }
     if (live) {
