@@ -116,7 +116,13 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ref_cpu as O
-            ncpu = os.cpu_count() or 1
+            # cores this process may actually use (the GPU box exposes 256 logical CPUs but a one-GPU
+            # job owns a 16-core share; oversubscribing torch's pool makes the baseline meaninglessly slow)
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
+            ncpu = max(1, min(ncpu, int(os.environ.get("PF_CPU_THREADS", "16"))))
             torch.set_num_threads(ncpu)
             bs = 2
             xs = xyz_cpu[:bs]

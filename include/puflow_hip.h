@@ -47,6 +47,11 @@ int pf_nn1(const float* p1, const float* p2, int B, int N, int M, float* dist_ou
 int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, const int* idx, const float* wfrag, float* out,
                 int B, int N, void* stream);
 
+/* Same as pf_edgeconv with an explicit tuning variant (points per wave / waves per workgroup);
+ * variant 0 is what pf_edgeconv ships.  Used by tools/tune_edgeconv.py for in-process A/B timing. */
+int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, const float* tab, const int* idx,
+                      const float* wfrag, float* out, int B, int N, void* stream);
+
 /* Per-point stage after EdgeConv unit `unit` (0..5): FeatMergeUnit (interpflow.py:251-258), the
  * injector conditioner nets (coupling.py:132-134), coupling1's c-part and the next unit's PQ.
  * off[12] = float offsets into `w` of: M1,b1,M2,H1,S2,bS2,T2,bT2,ST4,bST4,PQ,bPQ.
@@ -79,6 +84,34 @@ int pf_logp(const float* z, const float* ld_pt, float ld_const, int B, int N, fl
  * off[13]: float offsets into w (csrc/interp.hip header, packing.INTERP_SLOTS). */
 int pf_interp(const float* xyz, const float* z, const int* idx16, const float* w, const long long* off, float* u_out,
               int B, int N, int R, void* stream);
+
+/* Chamfer forward: dist1/idx1 [B,N] (x -> y), dist2/idx2 [B,M] (y -> x), squared L2, first-minimum ties.
+ * per_sample [B] = mean_n dist1 + mean_m dist2 (nullable); mean_sum [2] = {mean_b, sum_b} of per_sample
+ * (nullable).  Replaces pytorch3d chamfer_distance (metric/loss.py:42), kaolin chamfer (metric/loss.py:35)
+ * and chamfer_3DDist (modules/utils/patch.py:199-203). */
+int pf_chamfer_fwd(const float* x, const float* y, int B, int N, int M, float* dist1, int* idx1, float* dist2,
+                   int* idx2, float* per_sample, float* mean_sum, void* stream);
+
+/* Chamfer backward: g1 [B,N] = dL/d dist1, g2 [B,M] = dL/d dist2; ACCUMULATES into gx [B,N,3], gy [B,M,3]
+ * (caller zero-fills).  d dist/d x_i = 2 (x_i - y_j), d dist/d y_j = -2 (x_i - y_j). */
+int pf_chamfer_bwd(const float* x, const float* y, const int* idx1, const int* idx2, const float* g1, const float* g2,
+                   float* gx, float* gy, int B, int N, int M, void* stream);
+
+/* Auction EMD forward.  Replaces emd.forward (metric/emd/emd.cpp:14-19 -> emd_cuda.cu:228-282).
+ * Same ownership rule as the reference: the caller allocates outputs AND scratch (emd_module.py:43-56):
+ * xyz1 (prediction), xyz2 (ground truth) [B,n,3]; dist [B,n] out; assignment [B,n] in/out (-1 = free);
+ * price [B,n] in/out (0); assignment_inv [B,n] in/out (-1); bid, bid_increments, max_increments,
+ * unass_idx, max_idx: [B,n] scratch.  The reference's unass_cnt / unass_cnt_sum / cnt_tmp (512-entry
+ * batch prefix sums for its multi-kernel pipeline) have no counterpart: one workgroup owns one sample.
+ * No n % 1024 or B <= 512 restriction.  Returns PF_OK / PF_ERR_* (the reference returns 1 / 0 / -1). */
+int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist, int* assignment, float* price,
+                   int* assignment_inv, int* bid, float* bid_increments, float* max_increments, int* unass_idx,
+                   int* max_idx, float eps, int iters, int B, int n, void* stream);
+
+/* Auction EMD backward.  Replaces emd.backward (emd.cpp:21-24 -> emd_cuda.cu:284-316):
+ * gradxyz [B,n,3] += 2 graddist (xyz1 - xyz2[idx]); gradient wrt xyz2 is zero (emd_module.py:68-72). */
+int pf_emd_backward(const float* xyz1, const float* xyz2, float* gradxyz, const float* graddist, const int* idx, int B,
+                    int n, void* stream);
 
 #ifdef __cplusplus
 }

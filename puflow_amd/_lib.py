@@ -19,6 +19,8 @@ SIGNATURES = {
     "pf_knn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_nn1": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_edgeconv": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pf_edgeconv_tuned": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_void_p]),
     "pf_post": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                         c_void_p]),
     "pf_flow_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -26,6 +28,12 @@ SIGNATURES = {
     "pf_logp": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_interp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_int, c_int, c_int,
                           c_void_p]),
+    "pf_chamfer_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
+    "pf_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                               c_int, c_int, c_void_p]),
+    "pf_emd_forward": (c_int, [c_void_p] * 11 + [c_float, c_int, c_int, c_int, c_void_p]),
+    "pf_emd_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }
 
 

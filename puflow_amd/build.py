@@ -19,12 +19,14 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") -> str:
+    """defines/tag: build a tuning variant `libpuflow_hip_<tag>.so` with extra -D flags (tools/tune_*.py)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    lib = LIB if not tag else LIB.replace(".so", f"_{tag}.so")
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "puflow_hip.h"))
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + (f"_{tag}" if tag else ""))
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
@@ -32,19 +34,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(objdir, os.path.basename(s).replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or procs or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

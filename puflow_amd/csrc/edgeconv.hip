@@ -88,21 +88,41 @@ __global__ __launch_bounds__(NW * 64) void edgeconv_kernel(EcArgs a) {
             }
         };
 
+        // Accumulator initialisers are gathered ONE STAGE AHEAD (stage = growth layer or conv_out chunk):
+        // the loads for stage s+1 are issued before stage s's MFMA chain, so their L2 latency hides
+        // under ~100+ MFMAs instead of stalling every layer.  Weights come from LDS (lgkmcnt), the
+        // gathers from global memory (vmcnt): the two wait counters do not serialise each other.
+        constexpr int NI = GB > OCH ? GB : OCH;
+        f4 ini[2][P][NI];
+        auto load_init = [&](auto nbc, int row0, f4 (&dst)[P][NI]) {
+            constexpr int NB = decltype(nbc)::value;
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                for (int p = 0; p < P; ++p) dst[p][ob] = init(p, row0 + ob * 16 + 4 * q);
+        };
+        using IGB = std::integral_constant<int, GB>;
+        using IOC = std::integral_constant<int, OCH>;
+        load_init(IGB{}, 0, ini[0]);
+        if constexpr (NCONV > 1) load_init(IGB{}, G, ini[1]); else load_init(IOC{}, G * NCONV, ini[1]);
+
         f4 feat[P][NF];
         // layer 0: edge part only
 #pragma unroll
         for (int ob = 0; ob < GB; ++ob)
 #pragma unroll
-            for (int p = 0; p < P; ++p) feat[p][ob] = pf_lrelu(init(p, ob * 16 + 4 * q), 0.05f);
+            for (int p = 0; p < P; ++p) feat[p][ob] = pf_lrelu(ini[0][p][ob], 0.05f);
 
         // growth layers t = 1..NCONV-1: inputs = feature blocks [0, GB*t)
         pf_static_for<1, NCONV>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
+            if constexpr (t + 1 < NCONV) load_init(IGB{}, G * (t + 1), ini[(t + 1) & 1]);
+            else load_init(IOC{}, G * NCONV, ini[(t + 1) & 1]);
             f4 acc[P][GB];
 #pragma unroll
             for (int ob = 0; ob < GB; ++ob)
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[p][ob] = init(p, G * t + ob * 16 + 4 * q);
+                for (int p = 0; p < P; ++p) acc[p][ob] = ini[t & 1][p][ob];
             pf_mm<GB, GB * t, GB * t>(ws, GB * GB * (t * (t - 1) / 2), feat, 0, acc, 0);
 #pragma unroll
             for (int ob = 0; ob < GB; ++ob)
@@ -116,12 +136,15 @@ __global__ __launch_bounds__(NW * 64) void edgeconv_kernel(EcArgs a) {
 #pragma unroll
         for (int p = 0; p < P; ++p) sel[p] = pf_splat(0.f);
         pf_static_for<0, OBO / OCH>([&](auto cc) {
-            constexpr int ob0 = decltype(cc)::value * OCH;
+            constexpr int c = decltype(cc)::value;
+            constexpr int ob0 = c * OCH;
+            constexpr int st = NCONV + c;
+            if constexpr (c + 1 < OBO / OCH) load_init(IOC{}, G * NCONV + (ob0 + OCH) * 16, ini[(st + 1) & 1]);
             f4 acc[P][OCH];
 #pragma unroll
             for (int o = 0; o < OCH; ++o)
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[p][o] = init(p, G * NCONV + (ob0 + o) * 16 + 4 * q);
+                for (int p = 0; p < P; ++p) acc[p][o] = ini[st & 1][p][o];
             pf_mm<OCH, NF, NF>(ws, FO + ob0 * NF, feat, 0, acc, 0);
 #pragma unroll
             for (int o = 0; o < OCH; ++o)
@@ -140,25 +163,43 @@ __global__ __launch_bounds__(NW * 64) void edgeconv_kernel(EcArgs a) {
     }
 }
 
-template <int GB, int NCONV, int ODIM, bool C3>
-int launch(const EcArgs& a0, hipStream_t s) {
-    constexpr int P = 2, NW = 4;
+template <int GB, int NCONV, int ODIM, bool C3, int P, int NW>
+int launch_v(const EcArgs& a0, hipStream_t s) {
     EcArgs a = a0;
     a.ntiles = (a.T + NW * P - 1) / (NW * P);
     a.chunk = (a.ntiles + 7) / 8;
+    constexpr int NF = GB * NCONV;
+    constexpr int lds = (GB * GB * (NCONV * (NCONV - 1) / 2) + (ODIM / 16) * NF) * 1024;
+    int per_cu = (160 * 1024) / lds;                       // workgroups that fit one CU's LDS
+    const int by_waves = 32 / NW;                          // 32 waves per CU
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
     int grid = 8 * a.chunk;
-    const int cap = 256 * 8;                       // persistent cap: 8 workgroups of 256 threads per CU
+    const int cap = 256 * per_cu;                          // persistent: resident workgroups only
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL((edgeconv_kernel<GB, NCONV, ODIM, C3, P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
     return pf_last_launch_status();
+}
+
+template <int GB, int NCONV, int ODIM, bool C3>
+int launch(const EcArgs& a, hipStream_t s, int variant) {
+    switch (variant) {
+        case 0: return launch_v<GB, NCONV, ODIM, C3, 2, 8>(a, s);       // default
+        case 1: return launch_v<GB, NCONV, ODIM, C3, 2, 4>(a, s);
+        case 2: return launch_v<GB, NCONV, ODIM, C3, 1, 8>(a, s);
+        case 3: return launch_v<GB, NCONV, ODIM, C3, 1, 16>(a, s);
+        case 4: return launch_v<GB, NCONV, ODIM, C3, 2, 16>(a, s);
+        default: return PF_ERR_UNSUPPORTED;
+    }
 }
 
 }  // namespace
 
 // cfg: 0 = unit 0 (C=3, g=8 padded to 16, 4 convs, odim 32; C3 table variant)
 //      1 = unit 1 (g=16, odim 64)    2 = units 2..5 (g=32, odim 128)
-extern "C" int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, const int* idx, const float* wfrag,
-                           float* out, int B, int N, void* stream) {
+// variant: tuning knob (points per wave P, waves per workgroup NW); 0 = shipped default.
+extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, const float* tab, const int* idx,
+                                 const float* wfrag, float* out, int B, int N, void* stream) {
     if (!pq_or_xyz || !idx || !wfrag || !out) return PF_ERR_NULL;
     if (B <= 0 || N < 16 || (long long)B * N > (1ll << 30)) return PF_ERR_SHAPE;
     EcArgs a{};
@@ -168,9 +209,18 @@ extern "C" int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, co
         case 0:
             if (!tab) return PF_ERR_NULL;
             a.xyz = pq_or_xyz; a.tab = tab;
-            return launch<1, 4, 32, true>(a, s);
-        case 1: a.pq = pq_or_xyz; return launch<1, 4, 64, false>(a, s);
-        case 2: a.pq = pq_or_xyz; return launch<2, 4, 128, false>(a, s);
+            return launch<1, 4, 32, true>(a, s, variant);
+        case 1: a.pq = pq_or_xyz; return launch<1, 4, 64, false>(a, s, variant);
+        case 2: a.pq = pq_or_xyz; return launch<2, 4, 128, false>(a, s, variant);
         default: return PF_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, const int* idx, const float* wfrag,
+                           float* out, int B, int N, void* stream) {
+    // shipped variants (tools/tune_edgeconv.py, MI355X): unit 0 -> (P=2, NW=8); unit 1 -> (1, 8);
+    // units 2..5 -> (1, 16): one point per wave, 16 waves share the 88 KiB of LDS-resident weights.
+    static const int best[3] = {0, 2, 3};
+    if (cfg < 0 || cfg > 2) return PF_ERR_UNSUPPORTED;
+    return pf_edgeconv_tuned(cfg, best[cfg], pq_or_xyz, tab, idx, wfrag, out, B, N, stream);
 }

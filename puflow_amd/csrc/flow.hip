@@ -20,6 +20,14 @@
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
 
+// tuned on MI355X with tools/tune_variants.py (P = column tiles per wave, NW = waves per workgroup)
+#ifndef PF_FLOW_P
+#define PF_FLOW_P 1
+#endif
+#ifndef PF_FLOW_NW
+#define PF_FLOW_NW 4
+#endif
+
 namespace {
 
 constexpr int FLOW_REC = 5360;
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(FlowArgs a) {
 
 template <bool INV>
 int launch(FlowArgs a, hipStream_t s) {
-    constexpr int P = 2, NW = 4;
+    constexpr int P = PF_FLOW_P, NW = PF_FLOW_NW;
     a.ntiles = (a.rows + NW * P * 16 - 1) / (NW * P * 16);
     const int grid = a.ntiles < 2048 ? a.ntiles : 2048;
     hipLaunchKernelGGL((flow_kernel<INV, P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);

@@ -16,6 +16,14 @@
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
 
+// tuned on MI355X with tools/tune_variants.py (P = column tiles per wave, NW = waves per workgroup)
+#ifndef PF_INTERP_P
+#define PF_INTERP_P 2
+#endif
+#ifndef PF_INTERP_NW
+#define PF_INTERP_NW 8
+#endif
+
 namespace {
 
 struct InterpArgs {
@@ -183,7 +191,7 @@ extern "C" int pf_interp(const float* xyz, const float* z, const int* idx16, con
     if (!xyz || !z || !idx16 || !w || !off || !u_out) return PF_ERR_NULL;
     if (B <= 0 || N < 8 || (long long)B * N > (1ll << 28)) return PF_ERR_SHAPE;
     if (R != 4) return PF_ERR_UNSUPPORTED;
-    constexpr int P = 2, NW = 4;
+    constexpr int P = PF_INTERP_P, NW = PF_INTERP_NW;
     InterpArgs a{};
     a.xyz = xyz; a.z = z; a.idx = idx16; a.w = w; a.u = u_out; a.T = B * N; a.N = N;
     for (int i = 0; i < 13; ++i) a.off[i] = off[i];

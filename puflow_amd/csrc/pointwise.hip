@@ -11,6 +11,13 @@
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
 
+#ifndef PF_POST_P
+#define PF_POST_P 2
+#endif
+#ifndef PF_POST_NW
+#define PF_POST_NW 4
+#endif
+
 namespace {
 
 struct PostArgs {
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
 
 template <int ODIM, int CDIM, int SNEXT>
 int launch(PostArgs a, hipStream_t s) {
-    constexpr int P = 2, NW = 4;
+    constexpr int P = PF_POST_P, NW = PF_POST_NW;
     a.ntiles = (a.T + NW * P * 16 - 1) / (NW * P * 16);
     int grid = a.ntiles < 2048 ? a.ntiles : 2048;
     hipLaunchKernelGGL((post_kernel<ODIM, CDIM, SNEXT, P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);

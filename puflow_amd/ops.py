@@ -51,3 +51,72 @@ def knn_gather(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """out[b,n,k,:] = x[b, idx[b,n,k], :]  (plain indexing; data movement only)."""
     B = x.shape[0]
     return x[torch.arange(B, device=x.device).view(B, 1, 1), idx.long()]
+
+
+# ----------------------------------------------------------------------------------------
+# Chamfer
+# ----------------------------------------------------------------------------------------
+def chamfer_nn(x: torch.Tensor, y: torch.Tensor):
+    """dist1 [B,N], dist2 [B,M], idx1, idx2 (int32) + per-sample (mean+mean) [B] and {mean_b, sum_b} [2]."""
+    lib = _lib.load()
+    x, y = _f32c(x), _f32c(y)
+    B, N, _ = x.shape
+    M = y.shape[1]
+    dev = x.device
+    d1 = torch.empty((B, N), dtype=torch.float32, device=dev)
+    d2 = torch.empty((B, M), dtype=torch.float32, device=dev)
+    i1 = torch.empty((B, N), dtype=torch.int32, device=dev)
+    i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
+    per = torch.empty((B,), dtype=torch.float32, device=dev)
+    ms = torch.empty((2,), dtype=torch.float32, device=dev)
+    _lib.check(lib.pf_chamfer_fwd(x.data_ptr(), y.data_ptr(), B, N, M, d1.data_ptr(), i1.data_ptr(), d2.data_ptr(),
+                                  i2.data_ptr(), per.data_ptr(), ms.data_ptr(), _stream()), "pf_chamfer_fwd")
+    return d1, d2, i1, i2, per, ms
+
+
+class _ChamferFn(torch.autograd.Function):
+    """outputs: per-sample chamfer [B] (mean over points of both directions)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        xc, yc = _f32c(x), _f32c(y)
+        d1, d2, i1, i2, per, _ = chamfer_nn(xc, yc)
+        ctx.save_for_backward(xc, yc, i1, i2)
+        return per
+
+    @staticmethod
+    def backward(ctx, gper):
+        x, y, i1, i2 = ctx.saved_tensors
+        lib = _lib.load()
+        B, N, _ = x.shape
+        M = y.shape[1]
+        gper = gper.contiguous().float()
+        g1 = (gper / N).view(B, 1).expand(B, N).contiguous()
+        g2 = (gper / M).view(B, 1).expand(B, M).contiguous()
+        gx, gy = torch.zeros_like(x), torch.zeros_like(y)
+        _lib.check(lib.pf_chamfer_bwd(x.data_ptr(), y.data_ptr(), i1.data_ptr(), i2.data_ptr(), g1.data_ptr(),
+                                      g2.data_ptr(), gx.data_ptr(), gy.data_ptr(), B, N, M, _stream()), "pf_chamfer_bwd")
+        return gx, gy
+
+
+def chamfer_distance(x, y, x_normals=None, y_normals=None, batch_reduction="mean", point_reduction="mean"):
+    """pytorch3d.loss.chamfer_distance surface used by the reference (metric/loss.py:42): -> (loss, None)."""
+    if x_normals is not None or y_normals is not None:
+        raise NotImplementedError("normals are never passed on the PU-Flow path (train_pugan.py:60)")
+    if point_reduction != "mean" or batch_reduction not in ("mean", "sum"):
+        raise NotImplementedError("only the reductions the reference uses are built")
+    per = _ChamferFn.apply(x, y)
+    return (per.mean() if batch_reduction == "mean" else per.sum()), None
+
+
+def history_chamfer_distance(p1, p2):
+    """kaolin.metrics.pointcloud.chamfer_distance surface (metric/loss.py:35): per-sample [B]."""
+    return _ChamferFn.apply(p1, p2)
+
+
+class chamfer_3DDist:
+    """ChamferDistancePytorch surface used by PatchHelper.remove_outliers (modules/utils/patch.py:199-203)."""
+
+    def __call__(self, a, b):
+        d1, d2, i1, i2, _, _ = chamfer_nn(a, b)
+        return d1, d2, i1, i2

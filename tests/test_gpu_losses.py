@@ -1,0 +1,92 @@
+"""Chamfer and auction-EMD HIP operators against their CPU oracles (GPU needed)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import emd_ref as E
+from oracle import ref_cpu as O
+from puflow_amd.weights import synth_patches
+
+DEV = "cuda:0"
+
+
+def _unit_cube(B, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(B, n, 3, generator=g)
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 256, 1024), (3, 1000, 777), (1, 8192, 8192)])
+def test_chamfer_forward(B, N, M):
+    from puflow_amd import ops
+    x = synth_patches(B, N, seed=N, surface=False)
+    y = synth_patches(B, M, seed=M + 1, surface=False)
+    d1r, i1r, d2r, i2r = O.chamfer_nn(x, y)
+    d1, d2, i1, i2 = ops.chamfer_3DDist()(x.to(DEV), y.to(DEV))
+    assert torch.equal(d1.cpu(), d1r) and torch.equal(d2.cpu(), d2r)            # bit-exact distances
+    assert torch.equal(i1.cpu().long(), i1r) and torch.equal(i2.cpu().long(), i2r)
+    loss, _ = ops.chamfer_distance(x.to(DEV), y.to(DEV))
+    ref = O.chamfer_distance_mean(x, y)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))    # north_star: CD within 1e-5
+    per = ops.history_chamfer_distance(x.to(DEV), y.to(DEV))
+    np.testing.assert_allclose(per.cpu().numpy(), O.chamfer_distance_per_sample(x, y).numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_chamfer_backward_matches_autograd():
+    from puflow_amd import ops
+    x = synth_patches(2, 300, seed=1, surface=False).requires_grad_(True)
+    y = synth_patches(2, 200, seed=2, surface=False).requires_grad_(True)
+    d = ((x[:, :, None] - y[:, None]) ** 2).sum(-1)
+    ref = (d.min(2)[0].mean(1) + d.min(1)[0].mean(1)).mean()
+    ref.backward()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    yd = y.detach().to(DEV).requires_grad_(True)
+    loss, _ = ops.chamfer_distance(xd, yd)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-6
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(yd.grad.cpu().numpy(), y.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,n,eps,iters", [(2, 256, 0.005, 50), (3, 1024, 0.005, 50), (1, 1024, 0.002, 300),
+                                           (2, 192, 0.01, 7)])
+def test_emd_matches_oracle(B, n, eps, iters):
+    from puflow_amd.loss import emdFunction
+    x, y = _unit_cube(B, n, 10 + n), _unit_cube(B, n, 20 + n)
+    dref, aref = E.emd_forward(x.numpy(), y.numpy(), eps, iters)
+    dist, ass = emdFunction.apply(x.to(DEV), y.to(DEV), eps, iters)
+    dist, ass = dist.cpu().numpy(), ass.cpu().numpy()
+    # self-consistency (the reference's own check, emd_module.py:91-95): dist == |x - y[assignment]|^2
+    ya = np.take_along_axis(y.numpy(), ass[..., None].astype(np.int64), axis=1)
+    np.testing.assert_allclose(dist, ((x.numpy() - ya) ** 2).sum(-1), rtol=1e-5, atol=1e-7)
+    assert ass.min() >= 0 and ass.max() < n
+    # same deterministic rules as the oracle -> same assignment
+    assert (ass == aref).mean() > 0.999
+    assert abs(dist.sum() - dref.sum()) <= 1e-4 * dref.sum()
+
+
+def test_emd_quality_and_backward():
+    from scipy.optimize import linear_sum_assignment
+    from puflow_amd.loss import EarthMoverDistance, emdFunction
+    n = 128
+    x, y = _unit_cube(1, n, 3), _unit_cube(1, n, 4)
+    cost = np.sqrt(((x[0, :, None] - y[0, None]) ** 2).sum(-1).numpy())
+    r, c = linear_sum_assignment(cost)
+    opt = cost[r, c].sum()
+    dist, ass = emdFunction.apply(x.to(DEV), y.to(DEV), 0.0005, 3000)
+    got = np.sqrt(dist.cpu().numpy()).sum()
+    assert len(np.unique(ass.cpu().numpy())) >= n - 2                  # (almost) a bijection after many iterations
+    assert got <= opt + n * 0.0005 * 2 + 1e-3                          # auction bound: within n*eps of optimal
+    few = len(np.unique(emdFunction.apply(x.to(DEV), y.to(DEV), 0.005, 3)[1].cpu().numpy()))
+    assert few <= len(np.unique(ass.cpu().numpy()))                    # bijection rate rises with iterations
+    # backward: 2 g (x - y[assignment]) with the assignment frozen; nothing flows to y
+    xd = x.to(DEV).requires_grad_(True)
+    yd = y.to(DEV).requires_grad_(True)
+    loss = EarthMoverDistance(eps=0.005, iters=50)(xd, yd, radius=torch.tensor([2.0], device=DEV))
+    loss.backward()
+    d2, a2 = emdFunction.apply(x.to(DEV), y.to(DEV), 0.005, 50)
+    gref = E.emd_backward(x.numpy(), y.numpy(), np.full((1, n), 0.5, np.float32), a2.cpu().numpy())
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-7)
+    assert float(yd.grad.abs().sum()) == 0.0
+    assert abs(float(loss) - float(d2.sum()) / 2.0) < 1e-4
