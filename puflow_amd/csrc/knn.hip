@@ -7,9 +7,19 @@
 // ((dx*dx)+(dy*dy))+(dz*dz), result ordered by (distance asc, index asc), self included.
 // Bit-exact against oracle/ref_cpu.py::knn_canonical.
 //
-// v1 mapping: one lane per query, reference points read with wave-uniform (scalar) loads,
-// per-lane sorted top-K kept in registers.  Candidates are visited in increasing index, so a
-// strict `<` keeps equal distances in index order.
+// Two kernels, same results bit for bit:
+//  * knn_kernel (simple): one lane per query, references read with wave-uniform scalar loads,
+//    per-lane sorted top-K in registers, branch-free shifting insert.  Its cost is the insert:
+//    a lane inserts only ~K ln(M/K) times, but SOME lane of the 64 inserts at almost every
+//    candidate, so the wave executes the 5K-op insert ~M times.
+//  * knn2_kernel (default for K <= 16, M >= 256): two sweeps over LDS-staged references remove
+//    that divergence.  Sweep A keeps 32 strided group minima per query (1 op per candidate); the
+//    K-th smallest group minimum tau bounds the K-th neighbour distance (K distinct candidates
+//    are <= tau).  Sweep B appends every candidate with d <= tau to a per-lane LDS list (~22
+//    entries for K = 16: coupon-collector count of hitting K of 32 groups); only those are
+//    inserted.  A lane whose list overflows (heavy ties) makes its wave redo the exact simple scan.
+// Candidates are visited in increasing index in both kernels, so a strict `<` keeps equal
+// distances in index order.
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
 
@@ -18,6 +28,43 @@ namespace {
 __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float rx, float ry, float rz) {
     const float dx = __fsub_rn(qx, rx), dy = __fsub_rn(qy, ry), dz = __fsub_rn(qz, rz);
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// shifting insert of (d, j) into the ascending lists bd/bi (see header comment for the tie rule)
+template <int K>
+__device__ __forceinline__ void topk_insert(float (&bd)[K], int (&bi)[K], float d, int j) {
+#pragma unroll
+    for (int i = K - 1; i >= 1; --i) {
+        const bool ltl = d < bd[i - 1], lti = d < bd[i];
+        bi[i] = ltl ? bi[i - 1] : (lti ? j : bi[i]);
+        bd[i] = ltl ? bd[i - 1] : (lti ? d : bd[i]);
+    }
+    if (d < bd[0]) { bd[0] = d; bi[0] = j; }
+}
+
+// exact scan over all M references with wave-uniform (scalar) loads
+template <int K>
+__device__ __forceinline__ void exact_scan(float qx, float qy, float qz, const float* __restrict__ r, int M,
+                                           float (&bd)[K], int (&bi)[K]) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) { bd[i] = __builtin_inff(); bi[i] = -1; }
+    for (int j = 0; j < M; ++j) {
+        const float d = sqdist(qx, qy, qz, r[j * 3 + 0], r[j * 3 + 1], r[j * 3 + 2]);
+        if (d < bd[K - 1]) topk_insert<K>(bd, bi, d, j);      // wave-divergent guard
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void store_topk(const float (&bd)[K], const int (&bi)[K], size_t row, int* __restrict__ idx_out,
+                                           float* __restrict__ dist_out) {
+    int* o = idx_out + row * K;
+#pragma unroll
+    for (int i = 0; i < K; ++i) o[i] = bi[i];
+    if (dist_out) {
+        float* od = dist_out + row * K;
+#pragma unroll
+        for (int i = 0; i < K; ++i) od[i] = bd[i];
+    }
 }
 
 template <int K>
@@ -29,39 +76,116 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ p1, c
     const bool live = n < N;
     const float* q = p1 + ((size_t)b * N + (live ? n : N - 1)) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
+    float bd[K];
+    int bi[K];
+    exact_scan<K>(qx, qy, qz, p2 + (size_t)b * M * 3, M, bd, bi);
+    if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
+}
+
+// ascending bitonic sort of 16 registers (80 compare-exchanges, all indices compile-time)
+__device__ __forceinline__ void sort16(float (&v)[16]) {
+#pragma unroll
+    for (int k = 2; k <= 16; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float a = v[i], c = v[l];
+                    const bool up = (i & k) == 0;
+                    v[i] = up ? fminf(a, c) : fmaxf(a, c);
+                    v[l] = up ? fmaxf(a, c) : fminf(a, c);
+                }
+            }
+}
+
+constexpr int KNN2_T = 256;       // queries (threads) per workgroup
+constexpr int KNN2_MC = 2048;     // references staged in LDS per chunk
+constexpr int KNN2_CAP = 64;      // per-lane candidate list capacity (u16 indices)
+
+template <int K>
+__global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                      int N, int M, int* __restrict__ idx_out,
+                                                      float* __restrict__ dist_out) {
+    static_assert(K <= 16, "threshold selection uses two 16-element sorted halves");
+    __shared__ float sx[KNN2_MC], sy[KNN2_MC], sz[KNN2_MC];
+    __shared__ unsigned short lst[KNN2_CAP][KNN2_T];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int n = blockIdx.x * KNN2_T + tid;
+    const bool live = n < N;
+    const float* q = p1 + ((size_t)b * N + (live ? n : N - 1)) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
     const float* __restrict__ r = p2 + (size_t)b * M * 3;
+
+    auto stage = [&](int c0) {               // references [c0, c0 + MC) -> LDS, +inf padding past M
+        __syncthreads();
+        for (int i = tid; i < KNN2_MC; i += KNN2_T) {
+            const int j = c0 + i;
+            const bool in = j < M;
+            sx[i] = in ? r[j * 3 + 0] : __builtin_inff();
+            sy[i] = in ? r[j * 3 + 1] : 0.f;
+            sz[i] = in ? r[j * 3 + 2] : 0.f;
+        }
+        __syncthreads();
+    };
+
+    // ---- sweep A: 32 strided group minima
+    float gm[32];
+#pragma unroll
+    for (int g = 0; g < 32; ++g) gm[g] = __builtin_inff();
+    for (int c0 = 0; c0 < M; c0 += KNN2_MC) {
+        stage(c0);
+        const int lim = min(KNN2_MC, ((M - c0 + 31) / 32) * 32);
+        for (int j0 = 0; j0 < lim; j0 += 32) {
+#pragma unroll
+            for (int g = 0; g < 32; ++g)
+                gm[g] = fminf(gm[g], sqdist(qx, qy, qz, sx[j0 + g], sy[j0 + g], sz[j0 + g]));
+        }
+    }
+    // tau = K-th smallest of the 32 group minima: K-th smallest of two sorted halves = max_i min(A[i], B[K-1-i])
+    float tau;
+    {
+        float ha[16], hb[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { ha[g] = gm[g]; hb[g] = gm[16 + g]; }
+        sort16(ha);
+        sort16(hb);
+        tau = fminf(ha[0], hb[K - 1]);
+#pragma unroll
+        for (int i = 1; i < K; ++i) tau = fmaxf(tau, fminf(ha[i], hb[K - 1 - i]));
+    }
+
+    // ---- sweep B: collect every candidate with d <= tau (in index order)
+    int cnt = 0;
+    for (int c0 = 0; c0 < M; c0 += KNN2_MC) {
+        if (M > KNN2_MC) stage(c0);          // single-chunk case: LDS still holds the references
+        const int lim = min(KNN2_MC, M - c0);
+        for (int j = 0; j < lim; ++j) {
+            const float d = sqdist(qx, qy, qz, sx[j], sy[j], sz[j]);
+            if (d <= tau) {
+                if (cnt < KNN2_CAP) lst[cnt][tid] = (unsigned short)(c0 + j);
+                ++cnt;
+            }
+        }
+    }
 
     float bd[K];
     int bi[K];
+    if (__any(cnt > KNN2_CAP)) {
+        exact_scan<K>(qx, qy, qz, r, M, bd, bi);      // heavy ties: redo this wave exactly (rare)
+    } else {
 #pragma unroll
-    for (int i = 0; i < K; ++i) { bd[i] = __builtin_inff(); bi[i] = -1; }
-
-    for (int j = 0; j < M; ++j) {
-        float d = sqdist(qx, qy, qz, r[j * 3 + 0], r[j * 3 + 1], r[j * 3 + 2]);
-        if (d < bd[K - 1]) {             // wave-divergent guard; body is a branch-free shifting insert
-            // lt[i] = d < bd[i] is monotone in i (bd ascending).  Slot i takes its left neighbour when
-            // the new element lands left of it, the new element when it lands exactly here, else keeps.
-            // Strict `<` puts the new (larger-index) element AFTER existing equal distances and never
-            // reorders existing entries.
-#pragma unroll
-            for (int i = K - 1; i >= 1; --i) {
-                const bool ltl = d < bd[i - 1], lti = d < bd[i];
-                bi[i] = ltl ? bi[i - 1] : (lti ? j : bi[i]);
-                bd[i] = ltl ? bd[i - 1] : (lti ? d : bd[i]);
+        for (int i = 0; i < K; ++i) { bd[i] = __builtin_inff(); bi[i] = -1; }
+        for (int s = 0; __any(s < cnt); ++s) {
+            if (s < cnt) {
+                const int j = lst[s][tid];
+                const float d = sqdist(qx, qy, qz, r[j * 3 + 0], r[j * 3 + 1], r[j * 3 + 2]);
+                topk_insert<K>(bd, bi, d, j);
             }
-            if (d < bd[0]) { bd[0] = d; bi[0] = j; }
         }
     }
-    if (live) {
-        int* o = idx_out + ((size_t)b * N + n) * K;
-#pragma unroll
-        for (int i = 0; i < K; ++i) o[i] = bi[i];
-        if (dist_out) {
-            float* od = dist_out + ((size_t)b * N + n) * K;
-#pragma unroll
-            for (int i = 0; i < K; ++i) od[i] = bd[i];
-        }
-    }
+    if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
 }
 
 // K = 1: nearest neighbour distance + index (first minimum wins ties).
@@ -95,6 +219,16 @@ extern "C" int pf_knn(const float* p1, const float* p2, int B, int N, int M, int
     if (!p1 || !p2 || !idx_out) return PF_ERR_NULL;
     if (B <= 0 || N <= 0 || M <= 0 || K <= 0 || K > M || B > 65535) return PF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    if (K <= 16 && M >= 256 && M <= 65536) {           // two-sweep kernel (u16 candidate lists)
+        dim3 g2((N + KNN2_T - 1) / KNN2_T, B), b2(KNN2_T);
+        switch (K) {
+            case 4:  hipLaunchKernelGGL(knn2_kernel<4>, g2, b2, 0, s, p1, p2, N, M, idx_out, dist_out); break;
+            case 8:  hipLaunchKernelGGL(knn2_kernel<8>, g2, b2, 0, s, p1, p2, N, M, idx_out, dist_out); break;
+            case 16: hipLaunchKernelGGL(knn2_kernel<16>, g2, b2, 0, s, p1, p2, N, M, idx_out, dist_out); break;
+            default: return PF_ERR_UNSUPPORTED;
+        }
+        return pf_last_launch_status();
+    }
     dim3 grid((N + 63) / 64, B), block(64);
     switch (K) {
         case 8:  hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, s, p1, p2, N, M, idx_out, dist_out); break;

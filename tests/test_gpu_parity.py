@@ -31,7 +31,8 @@ def _net(sd):
 
 # ------------------------------------------------------------------------------------- kNN
 @pytest.mark.parametrize("B,N,M,K", [(2, 256, 256, 16), (1, 2048, 2048, 16), (3, 100, 77, 8), (1, 65, 300, 4),
-                                     (2, 130, 130, 32), (1, 16, 16, 16)])
+                                     (2, 130, 130, 32), (1, 16, 16, 16), (2, 1000, 5000, 16), (1, 3000, 2049, 8),
+                                     (1, 257, 4096, 16)])
 def test_knn_bit_exact(lib, B, N, M, K):
     from puflow_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + N + K)
@@ -52,6 +53,25 @@ def test_knn_ties_and_duplicates(lib):
     d, i, _ = ops.knn_points(p.to(DEV), p.to(DEV), 16)
     assert torch.equal(i.cpu(), i_ref)
     assert i[0, 3, 0] == 3 and i[0, 3, 1] == 10 and i[0, 3, 2] == 50  # (dist, idx) order on ties
+
+
+@pytest.mark.parametrize("mode", ["lattice", "identical", "clusters"])
+def test_knn_heavy_ties_two_sweep_kernel(lib, mode):
+    """M >= 256 takes the two-sweep kernel; heavy ties overflow its candidate lists -> exact fallback."""
+    from puflow_amd import ops
+    g = torch.Generator().manual_seed(5)
+    if mode == "lattice":
+        p = torch.round(torch.rand(2, 600, 3, generator=g) * 4) / 4          # 5^3 lattice sites, many duplicates
+    elif mode == "identical":
+        p = torch.full((1, 300, 3), 0.25)
+    else:
+        c = torch.rand(1, 8, 3, generator=g)
+        p = c[:, torch.randint(0, 8, (700,), generator=g)] + 0.001 * torch.rand(1, 700, 3, generator=g)
+        p[0, 100:200] = p[0, 0]                                               # 101 exact copies of one point
+    for K in (8, 16):
+        d_ref, i_ref = O.knn_canonical(p, p, K)
+        d, i, _ = ops.knn_points(p.to(DEV), p.to(DEV), K)
+        assert torch.equal(i.cpu(), i_ref) and torch.equal(d.cpu(), d_ref)
 
 
 def test_nn1_first_minimum(lib):
