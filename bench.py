@@ -114,6 +114,17 @@ def main():
                 "executed_achieved": ec_exec / (ec_ms * 1e-3) / 1e12,
                 "executed_frac": ec_exec / (ec_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
                 "avg_launch_ms": ec_ms}
+        # HBM traffic of the dominant kernel: PMC counters are collected offline with rocprofv3 (bench.py cannot
+        # run under --pmc and time itself); the committed summary of the same command is read back here.
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+                pmc = json.load(f)["kernels"]
+            key = [k for k in pmc if k.startswith("edgeconv_kernel<2, 4, 128")][0]
+            roof["traffic"] = pmc[key]["hbm_bytes_per_launch"]
+            roof["traffic_note"] = ("bytes per launch at 32 x 2048 from profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE x2 "
+                                    "+ WRITE_SIZE); algorithmic HBM bytes per launch = PQ 134.2 MB + idx 4.2 MB + out 33.6 MB")
+        except Exception:
+            pass
         extra = {"stage_ms": prof,
                  "knn_hbm": {"achieved": knn_bytes / (knn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "note": "kNN is VALU/selection-bound by construction (216 flop/B)"},
