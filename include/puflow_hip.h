@@ -113,6 +113,53 @@ int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist, int* assig
 int pf_emd_backward(const float* xyz1, const float* xyz2, float* gradxyz, const float* graddist, const int* idx, int B,
                     int n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-step building blocks (csrc/train_ops.hip): one kernel pair per eager op the reference's
+ * train-mode forward/backward runs (modules/discrete/interpflow.py:203-258, train_pu1k.py:53-74),
+ * on channels-last [rows, C] fp32 tensors.  Wired into autograd by puflow_amd/train_ops.py.
+ * ------------------------------------------------------------------------------------------- */
+
+/* C[M,N] = A(M,K) B(K,N) (+ bias[N]), generic element strides: A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn].
+ * Serves every Conv2d(1x1) / nn.Linear forward, dX and dW.  ws: split-K slabs, pf_gemm_ws_floats(M,N,K) floats. */
+long long pf_gemm_ws_floats(int M, int N, int K);
+int pf_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
+            long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats, void* stream);
+
+/* BatchNorm2d(training) + LeakyReLU(slope) on x [R,C] (interpflow.py:205-206,216-217; eps 1e-5, momentum 0.1):
+ * save [2][C] = batch mean, 1/sqrt(var+eps); running stats updated in place when non-NULL (unbiased variance).
+ * ws: (2*pf_bn_chunks(R) + 2) * C floats. */
+int pf_bn_chunks(long long R);
+int pf_bn_lrelu_fwd(const float* x, long long R, int C, const float* gamma, const float* beta, float slope, float eps,
+                    float momentum, float* run_mean, float* run_var, float* y, float* save, float* ws, void* stream);
+int pf_bn_lrelu_bwd(const float* x, const float* dy, long long R, int C, const float* gamma, const float* beta, float slope,
+                    const float* save, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
+/* column sums of g [R,C] -> out [C] (bias gradients); ws: 2*pf_bn_chunks(R)*C floats */
+int pf_colsum(const float* g, long long R, int C, float* out, float* ws, void* stream);
+
+/* y = x > 0 ? x : slope*x (LeakyReLU; slope 0 = ReLU) and its backward from the OUTPUT sign */
+int pf_act_fwd(const float* x, float slope, long long total, float* y, void* stream);
+int pf_act_bwd(const float* y, const float* dy, float slope, long long total, float* dx, void* stream);
+
+/* EdgeConv edge feature (interpflow.py:223-232): out [B*N*K, 3C] = [x_i, x_j, x_j - x_i]; backward ACCUMULATES into dx */
+int pf_edge_feature_fwd(const float* x, const int* idx, int B, int N, int K, int C, float* out, void* stream);
+int pf_edge_feature_bwd(const float* g, const int* idx, int B, int N, int K, int C, float* dx, void* stream);
+
+/* max over the K neighbours (interpflow.py:245): y [T,K,C] -> out [T,C], arg [T,C]; backward dx [T,K,C] */
+int pf_maxpool_k_fwd(const float* y, long long T, int K, int C, float* out, int* arg, void* stream);
+int pf_maxpool_k_bwd(const float* dy, const int* arg, long long T, int K, int C, float* dx, void* stream);
+
+/* backward of a neighbour-row gather x[idx] (interpflow.py:183): out [B*N,C] += g [B*N*K,C] (out zero-filled by caller) */
+int pf_scatter_rows(const float* g, const int* idx, int B, int N, int K, int C, float* out, void* stream);
+/* backward of repeat_interleave(c, R, dim=1) (interpflow.py:319): out [T,C] = sum_r g[T*R,C] */
+int pf_group_sum(const float* g, long long T, int R, int C, float* out, void* stream);
+
+/* interpolation tail (interpflow.py:180-185): softmax over K=8 of the first R channels of w [T,K,ldw], weighted sum of
+ * the gathered latents zj [T,K,3] -> a [T,K,R], fz [T,3,R]; backward -> dw [T,K,ldw], dzj [T,K,3] */
+int pf_softmax_wsum_fwd(const float* w, int ldw, const float* zj, int K, int R, long long T, float* a, float* fz,
+                        void* stream);
+int pf_softmax_wsum_bwd(const float* a, const float* zj, const float* dfz, int K, int R, int ldw, long long T, float* dw,
+                        float* dzj, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

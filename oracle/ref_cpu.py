@@ -266,3 +266,132 @@ def chamfer_distance_per_sample(x: Tensor, y: Tensor) -> Tensor:
     """kaolin-style per-sample mean+mean -> [B] (summed by ChamferCUDA2, loss.py:35-36)."""
     d1, _, d2, _ = chamfer_nn(x, y)
     return d1.mean(dim=1) + d2.mean(dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# Training-mode restatement (differentiable; BN batch statistics, ActNorm data-dependent init)
+# reference: train_pu1k.py:53-74 calls the same module in train() mode
+# --------------------------------------------------------------------------------------
+class TrainState:
+    """Side effects of one train-mode forward: BN running-stat updates and ActNorm init values."""
+
+    def __init__(self):
+        self.bn_updates: Dict[str, Tensor] = {}
+        self.actnorm_init: Dict[str, Tensor] = {}
+
+
+def _bn_train(sd: SD, pfx: str, y: Tensor, ts: TrainState) -> Tensor:
+    """BatchNorm2d in training mode on [B,C,N,K]: biased batch variance for normalisation,
+    unbiased for the running update, momentum 0.1."""
+    out = F.batch_norm(y, None, None, sd[pfx + ".weight"], sd[pfx + ".bias"], training=True, eps=1e-5)
+    with torch.no_grad():
+        mean = y.mean(dim=(0, 2, 3))
+        var_u = y.var(dim=(0, 2, 3), unbiased=True)
+        ts.bn_updates[pfx + ".running_mean"] = 0.9 * sd[pfx + ".running_mean"] + 0.1 * mean
+        ts.bn_updates[pfx + ".running_var"] = 0.9 * sd[pfx + ".running_var"] + 0.1 * var_u
+        ts.bn_updates[pfx + ".num_batches_tracked"] = sd[pfx + ".num_batches_tracked"] + 1
+    return out
+
+
+def edgeconv_unit_train(sd: SD, pfx: str, x: Tensor, idx: Tensor, ts: TrainState, pooling: bool = True) -> Tensor:
+    nconv = 0
+    while f"{pfx}.convs.{nconv}.0.weight" in sd:
+        nconv += 1
+    nb = knn_gather(x, idx)
+    xi = x.unsqueeze(2).expand_as(nb)
+    f = torch.cat([xi, nb, nb - xi], dim=-1).permute(0, 3, 1, 2)
+    for t in range(nconv):
+        y = F.conv2d(f, sd[f"{pfx}.convs.{t}.0.weight"], sd[f"{pfx}.convs.{t}.0.bias"])
+        g = F.leaky_relu(_bn_train(sd, f"{pfx}.convs.{t}.1", y, ts), 0.05)
+        f = torch.cat([f, g], dim=1)
+    y = F.conv2d(f, sd[pfx + ".conv_out.weight"], sd[pfx + ".conv_out.bias"])
+    if not pooling:
+        return y
+    return y.max(dim=-1)[0].transpose(1, 2)
+
+
+def _actnorm_params(sd: SD, i: int, p: Tensor, ts: TrainState, init: bool):
+    pf = f"flow_blocks.{i}.actnorm"
+    logs, bias = sd[pf + ".logs"], sd[pf + ".bias"]
+    if init:                                                    # normalize.py:45-54
+        with torch.no_grad():
+            b0 = -torch.mean(p.detach(), dim=(0, 1), keepdim=True)
+            l0 = -torch.log(torch.std(p.detach(), dim=(0, 1), keepdim=True) + 1e-6)
+            ts.actnorm_init[pf + ".bias"], ts.actnorm_init[pf + ".logs"] = b0, l0
+        # the parameters keep their identity (copy_ into .data): gradients still flow to them
+        logs = logs + (l0 - logs).detach()
+        bias = bias + (b0 - bias).detach()
+    return logs, bias
+
+
+def forward_train(sd: SD, xyz: Tensor, upratio: int = 4, actnorm_init: bool = False):
+    """Differentiable train-mode forward -> (x, logp, TrainState).  `sd` tensors may require grad."""
+    ts = TrainState()
+    xyz = xyz.float()
+    with torch.no_grad():
+        _, idx16 = knn_canonical(xyz, xyz, K_FEAT)
+        idx8 = idx16[..., :K_INTERP].contiguous()
+    # feature extractor
+    cs, h = [], xyz
+    for i in range(NUM_BLOCKS):
+        h = edgeconv_unit_train(sd, f"feat_convs.{i}", h, idx16, ts)
+        cs.append(feat_merge(sd, i, h))
+    # f
+    B, N, _ = xyz.shape
+    p = xyz
+    ldj = torch.zeros(B)
+    an = []
+    for i in range(NUM_BLOCKS):
+        pf = f"flow_blocks.{i}"
+        logs, bias = _actnorm_params(sd, i, p, ts, actnorm_init)
+        an.append((logs, bias))
+        p = p * torch.exp(logs) + bias
+        ld = torch.sum(logs) * N
+        W = sd[pf + ".permutate1.permutater.W"]
+        p = torch.einsum("ij,bnj->bni", W, p)
+        ld = ld + torch.slogdet(W)[1] * N
+        h1, h2 = _split(p, i)
+        h2 = h2 - lin_a1d(sd, pf + ".coupling1.bias_net", torch.cat([h1, cs[i]], dim=-1))
+        p = torch.cat([h1, h2], dim=-1)[:, :, [2, 1, 0]]
+        s = lin_a1d(sd, pf + ".coupling2.scale_net", cs[i])
+        t = lin_a1d(sd, pf + ".coupling2.bias_net", cs[i])
+        p = (p - t) * torch.exp(-s)
+        ldj = ldj + ld - torch.sum(torch.flatten(s, start_dim=1), dim=1)
+    z = p
+    logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + LOG2PI), dim=(1, 2)) + ldj)
+    # interp (train-mode BN inside)
+    nb = knn_gather(xyz, idx8)
+    xi = xyz.unsqueeze(2).expand_as(nb)
+    vec = xi - nb
+    dist = torch.sqrt(torch.sum(vec ** 2, dim=-1, keepdim=True))
+    fd = torch.cat([xi, nb, vec, dist], dim=-1).permute(0, 3, 1, 2)
+    pd = "interp.knn_context.distance_encoder.mlp"
+    d = fd
+    for a in (0, 3):
+        d = F.conv2d(d, sd[f"{pd}.{a}.weight"], sd[f"{pd}.{a}.bias"])
+        d = F.leaky_relu(_bn_train(sd, f"{pd}.{a + 1}", d, ts), 0.01)
+    d = F.conv2d(d, sd[pd + ".6.weight"], sd[pd + ".6.bias"])
+    feat = edgeconv_unit_train(sd, "interp.knn_context.feat_conv", xyz, idx8, ts, pooling=False)
+    w = torch.cat([d, feat], dim=1)
+    pw = "interp.weight_unit.mlp"
+    for a in (0, 3):
+        w = F.conv2d(w, sd[f"{pw}.{a}.weight"], sd[f"{pw}.{a}.bias"])
+        w = F.leaky_relu(_bn_train(sd, f"{pw}.{a + 1}", w, ts), 0.01)
+    w = F.conv2d(w, sd[pw + ".6.weight"], sd[pw + ".6.bias"]).permute(0, 2, 1, 3)
+    a_ = F.softmax(w[:, :, :upratio], dim=-1)
+    fz = torch.einsum("bnck,bnrk->bncr", knn_gather(z, idx8).permute(0, 1, 3, 2), a_)
+    # g
+    u = torch.flatten(fz.transpose(2, 3), 1, 2)
+    for i in reversed(range(NUM_BLOCKS)):
+        pf = f"flow_blocks.{i}"
+        c = torch.repeat_interleave(cs[i], upratio, dim=1)
+        s = lin_a1d(sd, pf + ".coupling2.scale_net", c)
+        t = lin_a1d(sd, pf + ".coupling2.bias_net", c)
+        u = (u * torch.exp(s) + t)[:, :, [2, 1, 0]]
+        h1, h2 = _split(u, i)
+        h2 = h2 + lin_a1d(sd, pf + ".coupling1.bias_net", torch.cat([h1, c], dim=-1))
+        u = torch.cat([h1, h2], dim=-1)
+        u = torch.einsum("ij,bnj->bni", torch.inverse(sd[pf + ".permutate1.permutater.W"]), u)
+        logs, bias = an[i]
+        u = (u - bias) * torch.exp(-logs)
+    return u, logp, ts

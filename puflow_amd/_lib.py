@@ -34,6 +34,26 @@ SIGNATURES = {
                                c_int, c_int, c_void_p]),
     "pf_emd_forward": (c_int, [c_void_p] * 11 + [c_float, c_int, c_int, c_int, c_void_p]),
     "pf_emd_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pf_gemm_ws_floats": (c_longlong, [c_int, c_int, c_int]),
+    "pf_gemm": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p,
+                        c_int, c_int, c_int, c_void_p, c_longlong, c_void_p]),
+    "pf_bn_chunks": (c_int, [c_longlong]),
+    "pf_bn_lrelu_fwd": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_bn_lrelu_bwd": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_colsum": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
+    "pf_act_fwd": (c_int, [c_void_p, c_float, c_longlong, c_void_p, c_void_p]),
+    "pf_act_bwd": (c_int, [c_void_p, c_void_p, c_float, c_longlong, c_void_p, c_void_p]),
+    "pf_edge_feature_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_edge_feature_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_maxpool_k_fwd": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pf_maxpool_k_bwd": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
+    "pf_scatter_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_group_sum": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
+    "pf_softmax_wsum_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p]),
+    "pf_softmax_wsum_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p,
+                                    c_void_p]),
 }
 
 

@@ -1,0 +1,494 @@
+// Building blocks of the TRAINING step (train-mode forward with BatchNorm batch statistics, and the
+// backward of every layer).  The reference trains with eager PyTorch ops on materialised
+// [B,C,N,K] tensors (modules/discrete/interpflow.py:203-258, train_pu1k.py:53-74); here each of those
+// ops is one hand-written kernel pair on channels-last [rows, C] fp32 tensors, wired into autograd
+// by puflow_amd/train_ops.py.  Training runs on 256-point patches (32 x 256 points, 131 072 edges),
+// so this first version is deliberately un-fused; the fused MFMA-chain kernels serve inference.
+//
+//   gemm            C = op(A) op(B) (+bias)    every Conv2d(1x1) / Linear forward, dX and dW (split-K slabs,
+//                                              deterministic reduce)            f32 MFMA 16x16x4, 64x64 tiles
+//   colstat / bn    BatchNorm2d(train) + LeakyReLU forward / backward (two-pass mean / variance)
+//   act             LeakyReLU / ReLU forward / backward
+//   edge_feature    [x_i, x_j, x_j - x_i] gather forward, scatter-add backward   (interpflow.py:223-232)
+//   maxpool_k       max over the K neighbours + argmax, backward                  (interpflow.py:245)
+//   scatter_rows    backward of a row gather (z[idx], interpflow.py:183)
+//   softmax_wsum    softmax over K of R logit channels, weighted sum of neighbour latents, backward (interpflow.py:180-185)
+//   group_sum       backward of repeat_interleave(cs, R) (interpflow.py:319)
+#include <hip/hip_runtime.h>
+#include "pf_api_internal.h"
+#include "pf_mfma.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ GEMM
+struct GemmArgs {
+    const float* A; long long sam, sak;      // A(m,k) = A[m*sam + k*sak]
+    const float* B; long long sbk, sbn;      // B(k,n) = B[k*sbk + n*sbn]
+    float* C; long long ldc;                 // C(m,n) = C[m*ldc + n]   (or slab z: C + z*M*ldc)
+    const float* bias;                       // per column n, nullable (ignored when splitk > 1: added by the reduce)
+    int M, N, K, kchunk;                     // kchunk = K range per blockIdx.z
+};
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    __shared__ float As[64][17];
+    __shared__ float Bs[16][65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int k_lo = blockIdx.z * g.kchunk;
+    const int k_hi = min(g.K, k_lo + g.kchunk);
+    const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
+    f4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = pf_splat(0.f);
+
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = a_kfast ? (tid >> 4) + 16 * i : (tid & 63);
+            const int k = a_kfast ? (tid & 15) : (tid >> 6) + 4 * i;
+            const int gm = m0 + r, gk = k0 + k;
+            As[r][k] = (gm < g.M && gk < k_hi) ? g.A[gm * g.sam + gk * g.sak] : 0.f;
+            const int n = b_nfast ? (tid & 63) : (tid >> 4) + 16 * i;
+            const int kb = b_nfast ? (tid >> 6) + 4 * i : (tid & 15);
+            const int gn = n0 + n, gkb = k0 + kb;
+            Bs[kb][n] = (gn < g.N && gkb < k_hi) ? g.B[gkb * g.sbk + gn * g.sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[wm * 32 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[kk * 4 + (lane >> 4)][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = pf_mfma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float* C = g.C + (long long)blockIdx.z * g.M * g.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 32 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + i * 16 + 4 * (lane >> 4) + r;
+                if (m < g.M && n < g.N) C[m * g.ldc + n] = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f);
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C,
+                                                         const float* __restrict__ bias, int M, int N, long long ldc,
+                                                         int nslab) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)M * N) return;
+    const int m = (int)(t / N), n = (int)(t % N);
+    float s = bias ? bias[n] : 0.f;
+    for (int z = 0; z < nslab; ++z) s += slabs[((long long)z * M + m) * N + n];
+    C[m * ldc + n] = s;
+}
+
+// ----------------------------------------------------------------------------- column statistics
+// partial[chunk][which][c] over rows [chunk*rows_per, ...): MODE 0: sum x          (1 value)
+//                                                             MODE 1: sum (x - mean[c])^2     (1)
+//                                                             MODE 2: sum dz, sum dz*xhat     (2)  dz = dy * lrelu'(pre)
+template <int MODE>
+__global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float slope, long long R, int C, int rows_per,
+                                                     float* __restrict__ partial) {
+    __shared__ float s0[4][64], s1[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const long long r_lo = (long long)blockIdx.y * rows_per, r_hi = min(R, r_lo + rows_per);
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        const float mu = MODE >= 1 ? mean[c] : 0.f;
+        const float is = MODE == 2 ? invstd[c] : 0.f, ga = MODE == 2 ? gamma[c] : 0.f, be = MODE == 2 ? beta[c] : 0.f;
+        for (long long r = r_lo + rl; r < r_hi; r += 4) {
+            const float v = x[r * C + c];
+            if (MODE == 0) a0 += v;
+            else if (MODE == 1) { const float d = v - mu; a0 += d * d; }
+            else {
+                const float xh = (v - mu) * is;
+                const float dz = dy[r * C + c] * ((xh * ga + be) > 0.f ? 1.f : slope);
+                a0 += dz; a1 += dz * xh;
+            }
+        }
+    }
+    s0[rl][threadIdx.x & 63] = a0; s1[rl][threadIdx.x & 63] = a1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const int l = threadIdx.x;
+        partial[((long long)blockIdx.y * 2 + 0) * C + c] = (s0[0][l] + s0[1][l]) + (s0[2][l] + s0[3][l]);
+        if (MODE == 2) partial[((long long)blockIdx.y * 2 + 1) * C + c] = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
+    }
+}
+
+// out[which][c] = scale * sum_chunks partial   (fixed order)
+__global__ void colstat_final_kernel(const float* __restrict__ partial, int nchunk, int C, int nwhich, float scale,
+                                     float* __restrict__ out) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    for (int w = 0; w < nwhich; ++w) {
+        float s = 0.f;
+        for (int k = 0; k < nchunk; ++k) s += partial[((long long)k * 2 + w) * C + c];
+        out[w * C + c] = s * scale;
+    }
+}
+
+__global__ void bn_finish_kernel(const float* __restrict__ var_b, int C, float eps, float momentum, float unbias,
+                                 const float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                 float* __restrict__ run_var) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    invstd[c] = 1.0f / sqrtf(var_b[c] + eps);
+    if (run_mean) {
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[c];
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (var_b[c] * unbias);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float slope, long long total, int C,
+                                                      float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float v = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        y[i] = v > 0.f ? v : v * slope;
+    }
+}
+
+// dx = gamma*invstd*(dz - s1/R - xhat*s2/R)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ sums /*[2][C] already / R*/,
+                                                          float slope, long long total, int C, float* __restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float xh = (x[i] - mean[c]) * invstd[c];
+        const float dz = dy[i] * ((xh * gamma[c] + beta[c]) > 0.f ? 1.f : slope);
+        dx[i] = gamma[c] * invstd[c] * (dz - sums[c] - xh * sums[C + c]);
+    }
+}
+
+// y = x > 0 ? x : slope*x  ;  dx = dy * (y > 0 ? 1 : slope)
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float slope, long long total,
+                                                     float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        y[i] = v > 0.f ? v : v * slope;
+    }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float slope,
+                                                     long long total, float* __restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        dx[i] = dy[i] * (y[i] > 0.f ? 1.f : slope);
+}
+
+// ------------------------------------------------------------------------- edge features / pooling
+// out[e][0:C] = x_i, [C:2C] = x_j, [2C:3C] = x_j - x_i ; e = t*K + k, j = (t / N)*N + idx[e]
+__global__ __launch_bounds__(256) void edge_feature_fwd_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                              int N, int K, int C, long long total /*E*C*/,
+                                                              float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long e = i / C;
+        const int c = (int)(i % C);
+        const long long t = e / K;
+        const long long j = (t / N) * N + idx[e];
+        const float xi = x[t * C + c], xj = x[j * C + c];
+        float* o = out + e * 3 * C;
+        o[c] = xi; o[C + c] = xj; o[2 * C + c] = xj - xi;
+    }
+}
+// dx[t] += g1 - g3 ; dx[j] += g2 + g3
+__global__ __launch_bounds__(256) void edge_feature_bwd_kernel(const float* __restrict__ g, const int* __restrict__ idx,
+                                                              int N, int K, int C, long long total,
+                                                              float* __restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long e = i / C;
+        const int c = (int)(i % C);
+        const long long t = e / K;
+        const long long j = (t / N) * N + idx[e];
+        const float* gg = g + e * 3 * C;
+        atomicAdd(&dx[t * C + c], gg[c] - gg[2 * C + c]);
+        atomicAdd(&dx[j * C + c], gg[C + c] + gg[2 * C + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ y, int K, int C, long long total /*T*C*/,
+                                                         float* __restrict__ out, int* __restrict__ arg) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long t = i / C;
+        const int c = (int)(i % C);
+        float best = y[(t * K) * C + c];
+        int bi = 0;
+        for (int k = 1; k < K; ++k) {
+            const float v = y[(t * K + k) * C + c];
+            if (v > best) { best = v; bi = k; }
+        }
+        out[i] = best; arg[i] = bi;
+    }
+}
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg, int K,
+                                                         int C, long long total /*T*K*C*/, float* __restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long e = i / C;
+        const int c = (int)(i % C);
+        const long long t = e / K;
+        const int k = (int)(e % K);
+        dx[i] = arg[t * C + c] == k ? dy[t * C + c] : 0.f;
+    }
+}
+
+// out[row[e]] += g[e]   (rows given as batch-local idx: row = (t / N)*N + idx[e], t = e / K)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ g, const int* __restrict__ idx, int N,
+                                                          int K, int C, long long total, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long e = i / C;
+        const int c = (int)(i % C);
+        const long long t = e / K;
+        const long long j = (t / N) * N + idx[e];
+        atomicAdd(&out[j * C + c], g[i]);
+    }
+}
+
+// out[t][c] = sum_r g[t*R + r][c]
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ g, int R, int C, long long total /*T*C*/,
+                                                       float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long t = i / C;
+        const int c = (int)(i % C);
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += g[(t * R + r) * C + c];
+        out[i] = s;
+    }
+}
+
+// ---- softmax over K of R logit channels + weighted latent sum; one thread per point (K = 8, R <= 8)
+constexpr int SW_K = 8, SW_RMAX = 8;
+__global__ __launch_bounds__(256) void softmax_wsum_fwd_kernel(const float* __restrict__ w /*[T,K,ldw] first R used*/,
+                                                              int ldw, const float* __restrict__ zj /*[T,K,3]*/, int R,
+                                                              long long T, float* __restrict__ a /*[T,K,R]*/,
+                                                              float* __restrict__ fz /*[T,3,R]*/) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    for (int r = 0; r < R; ++r) {
+        float m = -__builtin_inff();
+        for (int k = 0; k < SW_K; ++k) m = fmaxf(m, w[(t * SW_K + k) * ldw + r]);
+        float e[SW_K], s = 0.f;
+        for (int k = 0; k < SW_K; ++k) { e[k] = expf(w[(t * SW_K + k) * ldw + r] - m); s += e[k]; }
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        for (int k = 0; k < SW_K; ++k) {
+            const float ak = e[k] / s;
+            a[(t * SW_K + k) * R + r] = ak;
+            const float* z = zj + (t * SW_K + k) * 3;
+            o0 += ak * z[0]; o1 += ak * z[1]; o2 += ak * z[2];
+        }
+        fz[(t * 3 + 0) * R + r] = o0; fz[(t * 3 + 1) * R + r] = o1; fz[(t * 3 + 2) * R + r] = o2;
+    }
+}
+// dzj[t,k,c] = sum_r a dfz ; dw[t,k,r] = a (da - sum_k a da), da[t,k,r] = sum_c dfz[t,c,r] zj[t,k,c]; dw beyond R = 0
+__global__ __launch_bounds__(256) void softmax_wsum_bwd_kernel(const float* __restrict__ a, const float* __restrict__ zj,
+                                                              const float* __restrict__ dfz, int R, int ldw, long long T,
+                                                              float* __restrict__ dw, float* __restrict__ dzj) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    float dz[SW_K][3];
+    for (int k = 0; k < SW_K; ++k) dz[k][0] = dz[k][1] = dz[k][2] = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float g0 = dfz[(t * 3 + 0) * R + r], g1 = dfz[(t * 3 + 1) * R + r], g2 = dfz[(t * 3 + 2) * R + r];
+        float da[SW_K], dot = 0.f;
+        for (int k = 0; k < SW_K; ++k) {
+            const float* z = zj + (t * SW_K + k) * 3;
+            const float ak = a[(t * SW_K + k) * R + r];
+            da[k] = g0 * z[0] + g1 * z[1] + g2 * z[2];
+            dot += ak * da[k];
+            dz[k][0] += ak * g0; dz[k][1] += ak * g1; dz[k][2] += ak * g2;
+        }
+        for (int k = 0; k < SW_K; ++k) dw[(t * SW_K + k) * ldw + r] = a[(t * SW_K + k) * R + r] * (da[k] - dot);
+    }
+    for (int k = 0; k < SW_K; ++k) {
+        for (int r = R; r < ldw; ++r) dw[(t * SW_K + k) * ldw + r] = 0.f;
+        for (int c = 0; c < 3; ++c) dzj[(t * SW_K + k) * 3 + c] = dz[k][c];
+    }
+}
+
+inline unsigned grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+// C[M,N] = A(M,K) B(K,N) (+ bias[N]); generic element strides.  ws: split-K slabs (>= pf_gemm_ws_floats).
+extern "C" long long pf_gemm_ws_floats(int M, int N, int K) {
+    const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    int split = 1;
+    if (tiles < 256 && K >= 2048) { split = (int)((512 + tiles - 1) / tiles); if (split > K / 512) split = K / 512; if (split > 128) split = 128; }
+    return split > 1 ? (long long)split * M * N : 0;
+}
+
+extern "C" int pf_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
+                       long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats, void* stream) {
+    if (!A || !B || !C) return PF_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0) return PF_ERR_SHAPE;
+    const long long need = pf_gemm_ws_floats(M, N, K);
+    int split = need ? (int)(need / ((long long)M * N)) : 1;
+    if (need && (!ws || ws_floats < need)) return PF_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const bool use_ws = split > 1;
+    GemmArgs g{A, sam, sak, B, sbk, sbn, use_ws ? ws : C, use_ws ? (long long)N : ldc, use_ws ? nullptr : bias, M, N, K, 0};
+    g.kchunk = ((K + split - 1) / split + 15) / 16 * 16;
+    split = (K + g.kchunk - 1) / g.kchunk;
+    hipLaunchKernelGGL(gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, split), dim3(256), 0, s, g);
+    if (use_ws)
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, s, ws, C, bias, M,
+                           N, ldc, split);
+    return pf_last_launch_status();
+}
+
+// BatchNorm(train) + LeakyReLU forward on x [R,C].  save [2][C] = mean, invstd (out); running stats updated in place
+// (nullable); ws >= 2*nchunk*C + 2*C floats with nchunk = pf_bn_chunks(R).
+extern "C" int pf_bn_chunks(long long R) { long long n = (R + 1023) / 1024; return (int)(n > 1024 ? 1024 : (n < 1 ? 1 : n)); }
+
+extern "C" int pf_bn_lrelu_fwd(const float* x, long long R, int C, const float* gamma, const float* beta, float slope,
+                               float eps, float momentum, float* run_mean, float* run_var, float* y, float* save, float* ws,
+                               void* stream) {
+    if (!x || !gamma || !beta || !y || !save || !ws) return PF_ERR_NULL;
+    if (R <= 1 || C <= 0) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = pf_bn_chunks(R);
+    const int rows_per = (int)((R + nchunk - 1) / nchunk);
+    float* partial = ws;
+    float* var_b = ws + (long long)2 * nchunk * C;
+    dim3 grid((C + 63) / 64, nchunk), gc((C + 63) / 64);
+    hipLaunchKernelGGL(colstat_kernel<0>, grid, dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, R, C, rows_per, partial);
+    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(64), 0, s, partial, nchunk, C, 1, 1.0f / (float)R, save);
+    hipLaunchKernelGGL(colstat_kernel<1>, grid, dim3(256), 0, s, x, nullptr, save, nullptr, nullptr, nullptr, 0.f, R, C, rows_per, partial);
+    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(64), 0, s, partial, nchunk, C, 1, 1.0f / (float)R, var_b);
+    hipLaunchKernelGGL(bn_finish_kernel, gc, dim3(64), 0, s, var_b, C, eps, momentum, (float)R / (float)(R - 1), save, save + C,
+                       run_mean, run_var);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, save, save + C, gamma, beta, slope, R * C, C, y);
+    return pf_last_launch_status();
+}
+
+// backward: dx [R,C], dgamma [C], dbeta [C]
+extern "C" int pf_bn_lrelu_bwd(const float* x, const float* dy, long long R, int C, const float* gamma, const float* beta,
+                               float slope, const float* save, float* dx, float* dgamma, float* dbeta, float* ws,
+                               void* stream) {
+    if (!x || !dy || !gamma || !beta || !save || !dx || !dgamma || !dbeta || !ws) return PF_ERR_NULL;
+    if (R <= 1 || C <= 0) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = pf_bn_chunks(R);
+    const int rows_per = (int)((R + nchunk - 1) / nchunk);
+    float* partial = ws;
+    float* sums = ws + (long long)2 * nchunk * C;          // [2][C]: sum dz, sum dz*xhat
+    dim3 grid((C + 63) / 64, nchunk), gc((C + 63) / 64);
+    hipLaunchKernelGGL(colstat_kernel<2>, grid, dim3(256), 0, s, x, dy, save, save + C, gamma, beta, slope, R, C, rows_per, partial);
+    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(64), 0, s, partial, nchunk, C, 2, 1.0f, sums);
+    hipMemcpyAsync(dbeta, sums, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+    hipMemcpyAsync(dgamma, sums + C, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(64), 0, s, partial, nchunk, C, 2, 1.0f / (float)R, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, dy, save, save + C, gamma, beta, sums, slope,
+                       R * C, C, dx);
+    return pf_last_launch_status();
+}
+
+// column sums of g [R,C] -> out [C] (bias gradients).  ws >= 2*nchunk*C floats.
+extern "C" int pf_colsum(const float* g, long long R, int C, float* out, float* ws, void* stream) {
+    if (!g || !out || !ws) return PF_ERR_NULL;
+    if (R <= 0 || C <= 0) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = pf_bn_chunks(R);
+    const int rows_per = (int)((R + nchunk - 1) / nchunk);
+    hipLaunchKernelGGL(colstat_kernel<0>, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, g, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       0.f, R, C, rows_per, ws);
+    hipLaunchKernelGGL(colstat_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nchunk, C, 1, 1.0f, out);
+    return pf_last_launch_status();
+}
+
+extern "C" int pf_act_fwd(const float* x, float slope, long long total, float* y, void* stream) {
+    if (!x || !y) return PF_ERR_NULL;
+    if (total <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, slope, total, y);
+    return pf_last_launch_status();
+}
+extern "C" int pf_act_bwd(const float* y, const float* dy, float slope, long long total, float* dx, void* stream) {
+    if (!y || !dy || !dx) return PF_ERR_NULL;
+    if (total <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, dy, slope, total, dx);
+    return pf_last_launch_status();
+}
+
+extern "C" int pf_edge_feature_fwd(const float* x, const int* idx, int B, int N, int K, int C, float* out, void* stream) {
+    if (!x || !idx || !out) return PF_ERR_NULL;
+    if (B <= 0 || N <= 0 || K <= 0 || C <= 0) return PF_ERR_SHAPE;
+    const long long total = (long long)B * N * K * C;
+    hipLaunchKernelGGL(edge_feature_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, idx, N, K, C, total, out);
+    return pf_last_launch_status();
+}
+// dx [B*N, C] must be zero-filled by the caller (accumulates)
+extern "C" int pf_edge_feature_bwd(const float* g, const int* idx, int B, int N, int K, int C, float* dx, void* stream) {
+    if (!g || !idx || !dx) return PF_ERR_NULL;
+    if (B <= 0 || N <= 0 || K <= 0 || C <= 0) return PF_ERR_SHAPE;
+    const long long total = (long long)B * N * K * C;
+    hipLaunchKernelGGL(edge_feature_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, idx, N, K, C, total, dx);
+    return pf_last_launch_status();
+}
+
+extern "C" int pf_maxpool_k_fwd(const float* y, long long T, int K, int C, float* out, int* arg, void* stream) {
+    if (!y || !out || !arg) return PF_ERR_NULL;
+    if (T <= 0 || K <= 0 || C <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(T * C)), dim3(256), 0, (hipStream_t)stream, y, K, C, T * C, out, arg);
+    return pf_last_launch_status();
+}
+extern "C" int pf_maxpool_k_bwd(const float* dy, const int* arg, long long T, int K, int C, float* dx, void* stream) {
+    if (!dy || !arg || !dx) return PF_ERR_NULL;
+    if (T <= 0 || K <= 0 || C <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(T * K * C)), dim3(256), 0, (hipStream_t)stream, dy, arg, K, C, T * K * C, dx);
+    return pf_last_launch_status();
+}
+
+// out [B*N, C] += g [B*N*K, C] scattered by idx (out zero-filled by the caller)
+extern "C" int pf_scatter_rows(const float* g, const int* idx, int B, int N, int K, int C, float* out, void* stream) {
+    if (!g || !idx || !out) return PF_ERR_NULL;
+    if (B <= 0 || N <= 0 || K <= 0 || C <= 0) return PF_ERR_SHAPE;
+    const long long total = (long long)B * N * K * C;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, idx, N, K, C, total, out);
+    return pf_last_launch_status();
+}
+
+extern "C" int pf_group_sum(const float* g, long long T, int R, int C, float* out, void* stream) {
+    if (!g || !out) return PF_ERR_NULL;
+    if (T <= 0 || R <= 0 || C <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid_for(T * C)), dim3(256), 0, (hipStream_t)stream, g, R, C, T * C, out);
+    return pf_last_launch_status();
+}
+
+extern "C" int pf_softmax_wsum_fwd(const float* w, int ldw, const float* zj, int K, int R, long long T, float* a, float* fz,
+                                   void* stream) {
+    if (!w || !zj || !a || !fz) return PF_ERR_NULL;
+    if (K != SW_K || R <= 0 || R > SW_RMAX || R > ldw || T <= 0) return PF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(softmax_wsum_fwd_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, zj, R,
+                       T, a, fz);
+    return pf_last_launch_status();
+}
+extern "C" int pf_softmax_wsum_bwd(const float* a, const float* zj, const float* dfz, int K, int R, int ldw, long long T,
+                                   float* dw, float* dzj, void* stream) {
+    if (!a || !zj || !dfz || !dw || !dzj) return PF_ERR_NULL;
+    if (K != SW_K || R <= 0 || R > SW_RMAX || R > ldw || T <= 0) return PF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(softmax_wsum_bwd_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, zj, dfz, R,
+                       ldw, T, dw, dzj);
+    return pf_last_launch_status();
+}

@@ -7,7 +7,9 @@ The sub-modules below only HOLD parameters under the reference's names; all arit
 inference path runs in libpuflow_hip.so (no torch math, no CPU fallback).
 
 Weights are folded + packed once (puflow_amd/packing.py) and cached on the device; the cache is
-dropped by load_state_dict(), .to()/.cuda() and train().
+dropped by load_state_dict(), .to()/.cuda() and train().  In train() mode forward() is differentiable
+and runs the un-fused HIP training ops of puflow_amd/train_ops.py (BatchNorm batch statistics, ActNorm
+first-batch init) - see DESIGN.md section 7 for the HIP / torch split of that path.
 """
 from __future__ import annotations
 
@@ -286,8 +288,7 @@ class PointInterpFlow(nn.Module):
 
     def _check_mode(self):
         if self.training:
-            raise NotImplementedError("HIP path covers eval mode; the training step (BN batch statistics, "
-                                      "backward) is not built yet - call .eval()")
+            raise RuntimeError("this entry point is eval-only; in train() mode call forward() (differentiable path)")
         for b in self.flow_blocks:
             if not b.actnorm.is_inited:
                 raise RuntimeError("ActNorm not initialised: load a checkpoint and call set_to_initialized_state() "
@@ -333,8 +334,16 @@ class PointInterpFlow(nn.Module):
         u = torch.flatten(self._prep(z).transpose(2, 3), 1, 2).contiguous()
         return self._engine(upratio).flow_g(u, cs.cp, cs.st, upratio)
 
-    @torch.no_grad()
     def forward(self, xyz: Tensor, upratio: int = 4) -> Tuple[Tensor, Tensor]:
+        if self.training:                       # differentiable path: BN batch statistics, ActNorm init, autograd
+            from .train_ops import forward_train
+            if not xyz.is_cuda:
+                raise _lib.PuflowHipError("input must be a GPU tensor (no CPU fallback)")
+            return forward_train(self, xyz, upratio)
+        with torch.no_grad():
+            return self._forward_eval(xyz, upratio)
+
+    def _forward_eval(self, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         self._check_mode()
         xyz = self._prep(xyz)
         e = self._engine(upratio)

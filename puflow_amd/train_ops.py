@@ -1,0 +1,388 @@
+"""autograd wiring of the HIP training kernels (csrc/train_ops.hip) and the train-mode forward of
+PointInterpFlow composed from them.
+
+Split between HIP and torch in TRAINING mode (documented in DESIGN.md section 7):
+  HIP  : every Conv2d(1x1)/Linear (forward, dX, dW, db), BatchNorm(train)+LeakyReLU, ReLU/LeakyReLU,
+         edge-feature gather / scatter-add, max-pool over K, neighbour gather backward, softmax-weighted
+         latent sum, repeat_interleave backward, kNN, Chamfer, EMD.
+  torch: tensor re-layout (cat / slice / reshape / index) and the 3-channel flow algebra on [B,N,3]
+         tensors (actnorm, 3x3 inv1x1 + slogdet, coupling add, injector exp/mul, Gaussian log-likelihood):
+         O(points x 3) work, < 0.1 % of the step; plus the optimiser, exactly as in the reference.
+Activations are channels-last [rows, C] fp32 (rows = points or edges).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _lib
+
+LOG2PI = float(math.log(2 * math.pi))
+_WS = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(dev, n: int) -> Tensor:
+    """Grow-only fp32 scratch per device (stream-ordered reuse: every kernel that uses it is enqueued
+    on the same stream before the next one overwrites it)."""
+    t = _WS.get(dev)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=dev)
+        _WS[dev] = t
+    return t
+
+
+def _gemm(A: Tensor, sam: int, sak: int, Bm: Tensor, sbk: int, sbn: int, C: Tensor, ldc: int, bias, M: int, N: int, K: int):
+    lib = _lib.load()
+    need = lib.pf_gemm_ws_floats(M, N, K)
+    ws = _ws(C.device, need) if need else None
+    _lib.check(lib.pf_gemm(A.data_ptr(), sam, sak, Bm.data_ptr(), sbk, sbn, C.data_ptr(), ldc,
+                           bias.data_ptr() if bias is not None else None, M, N, K,
+                           ws.data_ptr() if ws is not None else None, need, _stream()), "pf_gemm")
+
+
+class LinearFn(Function):
+    """y[R,Cout] = x[R,Cin] W[Cout,Cin]^T + b   (nn.Linear / Conv2d 1x1 on channels-last rows)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        W = W.contiguous()
+        R, Cin = x2.shape
+        Cout = W.shape[0]
+        y = torch.empty((R, Cout), dtype=torch.float32, device=x.device)
+        _gemm(x2, Cin, 1, W, 1, Cin, y, Cout, b, R, Cout, Cin)
+        ctx.save_for_backward(x2, W)
+        ctx.has_bias = b is not None
+        ctx.shp = shp
+        return y.view(*shp[:-1], Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W = ctx.saved_tensors
+        R, Cin = x2.shape
+        Cout = W.shape[0]
+        dy2 = dy.reshape(R, Cout).contiguous()
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            _gemm(dy2, Cout, 1, W, Cin, 1, dx, Cin, None, R, Cin, Cout)
+            dx = dx.view(ctx.shp)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(W)
+            _gemm(dy2, 1, Cout, x2, Cin, 1, dW, Cin, None, Cout, Cin, R)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            lib = _lib.load()
+            db = torch.empty((Cout,), dtype=torch.float32, device=dy.device)
+            ws = _ws(dy.device, 2 * lib.pf_bn_chunks(R) * Cout)
+            _lib.check(lib.pf_colsum(dy2.data_ptr(), R, Cout, db.data_ptr(), ws.data_ptr(), _stream()), "pf_colsum")
+        return dx, dW, db
+
+
+def linear(x: Tensor, W: Tensor, b=None) -> Tensor:
+    return LinearFn.apply(x, W.reshape(W.shape[0], -1), b)
+
+
+class BnLreluFn(Function):
+    """BatchNorm(training, batch statistics over rows) + LeakyReLU; running stats updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, slope, eps, momentum):
+        lib = _lib.load()
+        x = x.contiguous()
+        R, C = x.shape
+        y = torch.empty_like(x)
+        save = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        ws = _ws(x.device, (2 * lib.pf_bn_chunks(R) + 2) * C)
+        g, b = gamma.contiguous(), beta.contiguous()
+        _lib.check(lib.pf_bn_lrelu_fwd(x.data_ptr(), R, C, g.data_ptr(), b.data_ptr(), slope, eps, momentum,
+                                       run_mean.data_ptr() if run_mean is not None else None,
+                                       run_var.data_ptr() if run_var is not None else None, y.data_ptr(), save.data_ptr(),
+                                       ws.data_ptr(), _stream()), "pf_bn_lrelu_fwd")
+        ctx.save_for_backward(x, g, b, save)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, g, b, save = ctx.saved_tensors
+        R, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty((C,), dtype=torch.float32, device=x.device)
+        db = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = _ws(x.device, (2 * lib.pf_bn_chunks(R) + 2) * C)
+        _lib.check(lib.pf_bn_lrelu_bwd(x.data_ptr(), dy.data_ptr(), R, C, g.data_ptr(), b.data_ptr(), ctx.slope,
+                                       save.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                       _stream()), "pf_bn_lrelu_bwd")
+        return dx, dg, db, None, None, None, None, None
+
+
+def bn_lrelu(x: Tensor, bn: torch.nn.BatchNorm2d, slope: float) -> Tensor:
+    y = BnLreluFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope, bn.eps, bn.momentum)
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    return y
+
+
+class ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        lib = _lib.load()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(lib.pf_act_fwd(x.data_ptr(), slope, x.numel(), y.data_ptr(), _stream()), "pf_act_fwd")
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        _lib.check(lib.pf_act_bwd(y.data_ptr(), dy.data_ptr(), ctx.slope, y.numel(), dx.data_ptr(), _stream()), "pf_act_bwd")
+        return dx, None
+
+
+class EdgeFeatureFn(Function):
+    """x [B,N,C], idx int32 [B,N,K] -> [B*N*K, 3C] = [x_i, x_j, x_j - x_i]."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        lib = _lib.load()
+        x = x.contiguous()
+        B, N, C = x.shape
+        K = idx.shape[-1]
+        out = torch.empty((B * N * K, 3 * C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.pf_edge_feature_fwd(x.data_ptr(), idx.data_ptr(), B, N, K, C, out.data_ptr(), _stream()), "pf_edge_feature_fwd")
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, K, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        B, N, K, C = ctx.dims
+        g = g.contiguous()
+        dx = torch.zeros((B, N, C), dtype=torch.float32, device=g.device)
+        _lib.check(lib.pf_edge_feature_bwd(g.data_ptr(), idx.data_ptr(), B, N, K, C, dx.data_ptr(), _stream()), "pf_edge_feature_bwd")
+        return dx, None
+
+
+class MaxPoolKFn(Function):
+    """y [T*K, C] -> max over the K rows of each point [T, C]."""
+
+    @staticmethod
+    def forward(ctx, y, K):
+        lib = _lib.load()
+        y = y.contiguous()
+        C = y.shape[1]
+        T = y.shape[0] // K
+        out = torch.empty((T, C), dtype=torch.float32, device=y.device)
+        arg = torch.empty((T, C), dtype=torch.int32, device=y.device)
+        _lib.check(lib.pf_maxpool_k_fwd(y.data_ptr(), T, K, C, out.data_ptr(), arg.data_ptr(), _stream()), "pf_maxpool_k_fwd")
+        ctx.save_for_backward(arg)
+        ctx.dims = (T, K, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (arg,) = ctx.saved_tensors
+        T, K, C = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty((T * K, C), dtype=torch.float32, device=dy.device)
+        _lib.check(lib.pf_maxpool_k_bwd(dy.data_ptr(), arg.data_ptr(), T, K, C, dx.data_ptr(), _stream()), "pf_maxpool_k_bwd")
+        return dx, None
+
+
+class GatherRowsFn(Function):
+    """z [B,N,C], idx int32 [B,N,K] -> z[b, idx] as [B*N*K, C] (forward = indexing, backward = HIP scatter-add)."""
+
+    @staticmethod
+    def forward(ctx, z, idx):
+        B, N, C = z.shape
+        K = idx.shape[-1]
+        out = z[torch.arange(B, device=z.device).view(B, 1, 1), idx.long()].reshape(B * N * K, C)
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, K, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        B, N, K, C = ctx.dims
+        g = g.contiguous()
+        dz = torch.zeros((B, N, C), dtype=torch.float32, device=g.device)
+        _lib.check(lib.pf_scatter_rows(g.data_ptr(), idx.data_ptr(), B, N, K, C, dz.data_ptr(), _stream()), "pf_scatter_rows")
+        return dz, None
+
+
+class RepeatRowsFn(Function):
+    """repeat_interleave(c, R, dim=1): forward = data movement, backward = HIP group sum."""
+
+    @staticmethod
+    def forward(ctx, c, R):
+        ctx.R = R
+        ctx.shp = c.shape
+        return torch.repeat_interleave(c, R, dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, N, C = ctx.shp
+        g = g.contiguous()
+        out = torch.empty((B, N, C), dtype=torch.float32, device=g.device)
+        _lib.check(lib.pf_group_sum(g.data_ptr(), B * N, ctx.R, C, out.data_ptr(), _stream()), "pf_group_sum")
+        return out, None
+
+
+class SoftmaxWsumFn(Function):
+    """w [T,K,ldw] logits (first R channels used), zj [T,K,3] -> fz [T,3,R]."""
+
+    @staticmethod
+    def forward(ctx, w, zj, R):
+        lib = _lib.load()
+        w, zj = w.contiguous(), zj.contiguous()
+        T, K, ldw = w.shape
+        a = torch.empty((T, K, R), dtype=torch.float32, device=w.device)
+        fz = torch.empty((T, 3, R), dtype=torch.float32, device=w.device)
+        _lib.check(lib.pf_softmax_wsum_fwd(w.data_ptr(), ldw, zj.data_ptr(), K, R, T, a.data_ptr(), fz.data_ptr(), _stream()),
+                   "pf_softmax_wsum_fwd")
+        ctx.save_for_backward(a, zj)
+        ctx.dims = (T, K, R, ldw)
+        return fz
+
+    @staticmethod
+    def backward(ctx, dfz):
+        lib = _lib.load()
+        a, zj = ctx.saved_tensors
+        T, K, R, ldw = ctx.dims
+        dfz = dfz.contiguous()
+        dw = torch.empty((T, K, ldw), dtype=torch.float32, device=dfz.device)
+        dzj = torch.empty((T, K, 3), dtype=torch.float32, device=dfz.device)
+        _lib.check(lib.pf_softmax_wsum_bwd(a.data_ptr(), zj.data_ptr(), dfz.data_ptr(), K, R, ldw, T, dw.data_ptr(),
+                                           dzj.data_ptr(), _stream()), "pf_softmax_wsum_bwd")
+        return dw, dzj, None
+
+
+# ----------------------------------------------------------------------------------------------------
+# train-mode network forward (differentiable)
+# ----------------------------------------------------------------------------------------------------
+def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True) -> Tensor:
+    """FeatureExtractUnit in train mode (interpflow.py:234-248). x [B,N,C]; returns [B,N,odim] or [B*N*K, odim]."""
+    B, N, _ = x.shape
+    K = idx.shape[-1]
+    f = EdgeFeatureFn.apply(x, idx)
+    for seq in p.convs:
+        conv, bn = seq[0], seq[1]
+        y = linear(f, conv.weight, conv.bias)
+        f = torch.cat([f, bn_lrelu(y, bn, 0.05)], dim=1)
+    y = linear(f, p.conv_out.weight, p.conv_out.bias)
+    if not pooling:
+        return y
+    return MaxPoolKFn.apply(y, K).view(B, N, -1)
+
+
+def cond_net(net, h: Tensor) -> Tensor:
+    """LinearA1D (interpflow.py:38-43)."""
+    L = net.layers
+    h = ActFn.apply(linear(h, L[0].weight), 0.01)
+    h = ActFn.apply(linear(h, L[2].weight, L[2].bias), 0.01)
+    return linear(h, L[4].weight, L[4].bias)
+
+
+def _mlp_bn(mlp, x: Tensor) -> Tensor:
+    """Conv,BN,LReLU(.01),Conv,BN,LReLU,Conv on rows (DistanceEncoder / WeightEstimationUnit)."""
+    x = bn_lrelu(linear(x, mlp[0].weight, mlp[0].bias), mlp[1], 0.01)
+    x = bn_lrelu(linear(x, mlp[3].weight, mlp[3].bias), mlp[4], 0.01)
+    return linear(x, mlp[6].weight, mlp[6].bias)
+
+
+def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
+    """PointInterpFlow.forward in train() mode (interpflow.py:327-337) with gradients."""
+    from . import ops
+    xyz = xyz.detach().contiguous().float()
+    B, N, _ = xyz.shape
+    R = upratio
+    idx16, _ = ops.knn_idx32(xyz, xyz, 16)
+    idx8 = idx16[..., :8].contiguous()
+
+    # ---- feature extractor
+    cs: List[Tensor] = []
+    h = xyz
+    for i in range(net.num_blocks):
+        h = edgeconv_train(net.feat_convs[i], h, idx16)
+        m = net.merge_convs[i]
+        cs.append(linear(ActFn.apply(linear(h, m.conv1.weight, m.conv1.bias), 0.0), m.conv2.weight))
+
+    # ---- f + log-likelihood
+    p = xyz
+    ldj = torch.zeros(B, device=xyz.device)
+    for i in range(net.num_blocks):
+        blk = net.flow_blocks[i]
+        an = blk.actnorm
+        if not an.is_inited:                                       # normalize.py:45-54
+            with torch.no_grad():
+                an.bias.data.copy_(-torch.mean(p.detach(), dim=(0, 1), keepdim=True))
+                an.logs.data.copy_(-torch.log(torch.std(p.detach(), dim=(0, 1), keepdim=True) + 1e-6))
+                an.is_inited = True
+        p = p * torch.exp(an.logs) + an.bias
+        W = blk.permutate1.permutater.W
+        p = torch.einsum("ij,bnj->bni", W, p)
+        ld = (torch.sum(an.logs) + torch.slogdet(W)[1]) * N
+        td = 1 if i % 2 == 0 else 2
+        h1, h2 = p[..., :td], p[..., td:]
+        h2 = h2 - cond_net(blk.coupling1.bias_net, torch.cat([h1, cs[i]], dim=-1))
+        p = torch.cat([h1, h2], dim=-1).flip(-1)
+        s = cond_net(blk.coupling2.scale_net, cs[i])
+        t = cond_net(blk.coupling2.bias_net, cs[i])
+        p = (p - t) * torch.exp(-s)
+        ldj = ldj + ld - s.flatten(1).sum(1)
+    z = p
+    logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + LOG2PI), dim=(1, 2)) + ldj)
+
+    # ---- interpolation
+    ip = net.interp
+    bidx = torch.arange(B, device=xyz.device).view(B, 1, 1)
+    nb = xyz[bidx, idx8.long()]                                   # [B,N,8,3]   (inputs only: no gradient)
+    xi = xyz.unsqueeze(2).expand_as(nb)
+    vec = xi - nb
+    dist = torch.sqrt(torch.sum(vec ** 2, dim=-1, keepdim=True))
+    fd = torch.cat([xi, nb, vec, dist], dim=-1).reshape(B * N * 8, 10)
+    d = _mlp_bn(ip.knn_context.distance_encoder.mlp, fd)          # [E8,128]
+    feat = edgeconv_train(ip.knn_context.feat_conv, xyz, idx8, pooling=False)
+    w = _mlp_bn(ip.weight_unit.mlp, torch.cat([d, feat], dim=1))  # [E8,32]
+    zj = GatherRowsFn.apply(z, idx8)                              # [E8,3]
+    fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)      # [T,3,R]
+    u = fz.transpose(1, 2).reshape(B, N * R, 3)
+
+    # ---- g (exact inverse); injector nets are evaluated per ORIGINAL point and replicated
+    for i in reversed(range(net.num_blocks)):
+        blk = net.flow_blocks[i]
+        s = RepeatRowsFn.apply(cond_net(blk.coupling2.scale_net, cs[i]), R)
+        t = RepeatRowsFn.apply(cond_net(blk.coupling2.bias_net, cs[i]), R)
+        u = (u * torch.exp(s) + t).flip(-1)
+        td = 1 if i % 2 == 0 else 2
+        h1, h2 = u[..., :td], u[..., td:]
+        h2 = h2 + cond_net(blk.coupling1.bias_net, torch.cat([h1, RepeatRowsFn.apply(cs[i], R)], dim=-1))
+        u = torch.cat([h1, h2], dim=-1)
+        W = blk.permutate1.permutater.W
+        u = torch.einsum("ij,bnj->bni", torch.inverse(W), u)
+        u = (u - blk.actnorm.bias) * torch.exp(-blk.actnorm.logs)
+    return u, logp

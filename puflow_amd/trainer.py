@@ -1,0 +1,126 @@
+"""TrainerModule: the reference's LightningModule surface (modules/discrete/train_pu1k.py:29-105,
+train_pugan.py:29-105, train_pugeo.py) without requiring pytorch_lightning (not installed here):
+`forward`, `configure_optimizers`, `training_step`, `validation_step`, `validation_epoch_end`, cfg fields
+`learning_rate, sched_patience, sched_factor` - plus `train_step()`, the explicit
+forward -> loss -> backward -> (RCCL all-reduce) -> clip -> Adam sequence Lightning would run
+(gradient_clip_val=1e-2, train_pu1k.py:149).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .dist import FlatGradBucket
+from .interpflow import PointInterpFlow
+from .loss import ChamferCUDA, ChamferCUDA2, EarthMoverDistance
+
+try:                                     # optional: behave as a LightningModule when Lightning exists
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:                        # pragma: no cover - not installed in this image
+    _Base = nn.Module
+
+
+def default_cfg(**kw):
+    cfg = dict(net="UpsamplingFlow", learning_rate=1e-3, sched_patience=10, sched_factor=0.5, seed=2021)
+    cfg.update(kw)
+    return SimpleNamespace(**cfg)
+
+
+class TrainerModule(_Base):
+    """loss_mix: 'pu1k' / 'pugeo' = 1e-4 logp + 5e-2 EMD (train_pu1k.py:65); 'pugan' adds 1e-1 CD and divides the
+    EMD by the patch radius (train_pugan.py:59-61)."""
+
+    def __init__(self, cfg=None, loss_mix: str = "pu1k"):
+        super().__init__()
+        self.cfg = cfg or default_cfg()
+        self.loss_mix = loss_mix
+        self.network = PointInterpFlow(pc_channel=3)
+        self.emd_loss = EarthMoverDistance()
+        self.chamfer_loss = ChamferCUDA()
+        self.chamfer_loss2 = ChamferCUDA2()
+        self.epoch = 0
+        self.min_CD = 100.0
+        self.min_Nor = 15.0
+        self.logged = {}
+        self._bucket: Optional[FlatGradBucket] = None
+
+    def log(self, name, value, **_kw):          # Lightning's self.log when running without Lightning
+        if _Base is nn.Module:
+            self.logged[name] = float(value.detach()) if isinstance(value, Tensor) else float(value)
+        else:                                   # pragma: no cover
+            super().log(name, value, **_kw)
+
+    def forward(self, p: Tensor, **kwargs):
+        return self.network(p, **kwargs)
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.cfg.learning_rate)
+        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, "min", factor=self.cfg.sched_factor, min_lr=1e-4,
+                                                               patience=self.cfg.sched_patience)
+        return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "monitor": "CD"}}
+
+    def _losses(self, batch):
+        if len(batch) == 3:
+            xyz_sparse, xyz_dense, radius = batch
+        else:
+            (xyz_sparse, xyz_dense), radius = batch, None
+        xyz_sparse, xyz_dense = xyz_sparse.squeeze(0) if xyz_sparse.dim() == 4 else xyz_sparse, \
+            xyz_dense.squeeze(0) if xyz_dense.dim() == 4 else xyz_dense
+        upratio = int(xyz_dense.shape[1] / xyz_sparse.shape[1])
+        xyz_pred, logpx = self(xyz_sparse, upratio=upratio)
+        if self.loss_mix == "pugan":
+            emd = self.emd_loss(xyz_pred, xyz_dense, radius=radius)
+            cd, _ = self.chamfer_loss(xyz_pred, xyz_dense)
+            loss = logpx * 1e-4 + emd * 5e-2 + cd * 1e-1
+            self.log("CD", cd * 1e-1)
+        else:
+            emd = self.emd_loss(xyz_pred, xyz_dense)
+            loss = logpx * 1e-4 + emd * 5e-2
+        self.log("EMD", emd * 5e-2)
+        self.log("logpx", logpx * 1e-4)
+        return loss
+
+    def training_step(self, batch, batch_idx=0):
+        loss = self._losses(batch)
+        if self.loss_mix != "pugan" and bool(torch.isnan(loss)):      # NaN guard, train_pu1k.py:71-73
+            print("loss is nan")
+            loss.data = torch.ones_like(loss) * 0.1
+        return loss
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0):
+        xyz_sparse, xyz_dense = batch[0], batch[1]
+        upratio = int(xyz_dense.shape[1] / xyz_sparse.shape[1])
+        was = self.training
+        self.eval()
+        predict_x, logpx = self(xyz_sparse, upratio=upratio)
+        cd = self.chamfer_loss2(predict_x, xyz_dense)
+        self.train(was)
+        return {"vloss": logpx.detach().cpu(), "CD": cd}
+
+    def validation_epoch_end(self, batch):
+        log_dict = {"vloss": torch.tensor([x["vloss"] * 1e-5 for x in batch]).sum().item(),
+                    "CD": torch.tensor([float(x["CD"]) for x in batch]).sum().item()}
+        self.log("CD", log_dict["CD"])
+        self.log("vloss", log_dict["vloss"])
+        self.epoch += 1
+        return log_dict
+
+    # ---- what Lightning's loop does around training_step, made explicit (and multi-GPU aware)
+    def train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2) -> Tensor:
+        self.train()
+        optimizer.zero_grad(set_to_none=True)
+        loss = self.training_step(batch, 0)
+        loss.backward()
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            if self._bucket is None:
+                self._bucket = FlatGradBucket(self.parameters())
+            self._bucket.all_reduce_mean()                      # ONE 3.2 MB RCCL all-reduce per step
+        torch.nn.utils.clip_grad_norm_(self.parameters(), clip)
+        optimizer.step()
+        return loss.detach()

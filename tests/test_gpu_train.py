@@ -1,0 +1,168 @@
+"""Training path on the GPU: every HIP training op against torch-CPU autograd, then a whole training step
+(train-mode forward, loss, all parameter gradients, BN running stats, ActNorm init) against the golden vectors
+captured from the reference's own module (tools/make_golden_train.py) and against the train-mode oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as O
+from puflow_amd.weights import synth_patches, synth_state_dict
+
+DEV = "cuda:0"
+
+
+def _close(a, b, rtol=2e-4, atol=1e-6):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("R,Cin,Cout,bias", [(1000, 9, 8, True), (4096, 96, 16, True), (333, 130, 64, False),
+                                             (70000, 40, 32, True), (64, 3, 3, False)])
+def test_linear_fwd_bwd(R, Cin, Cout, bias):
+    from puflow_amd.train_ops import linear
+    g = torch.Generator().manual_seed(R)
+    x = torch.randn(R, Cin, generator=g, requires_grad=True)
+    W = torch.randn(Cout, Cin, generator=g, requires_grad=True)
+    b = torch.randn(Cout, generator=g, requires_grad=True) if bias else None
+    gy = torch.randn(R, Cout, generator=g)
+    y = F.linear(x, W, b); y.backward(gy)
+    xd, Wd = x.detach().to(DEV).requires_grad_(True), W.detach().to(DEV).requires_grad_(True)
+    bd = b.detach().to(DEV).requires_grad_(True) if bias else None
+    yd = linear(xd, Wd, bd); yd.backward(gy.to(DEV))
+    _close(yd, y, atol=1e-5); _close(xd.grad, x.grad, atol=1e-5)
+    _close(Wd.grad, W.grad, rtol=1e-3, atol=1e-3 * float(W.grad.abs().max()))       # K = R long reductions
+    if bias:
+        _close(bd.grad, b.grad, rtol=1e-3, atol=1e-3 * float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("R,C,slope", [(4096, 8, 0.05), (131072, 32, 0.05), (1000, 128, 0.01), (50000, 64, 0.01)])
+def test_bn_lrelu_fwd_bwd(R, C, slope):
+    from puflow_amd.train_ops import BnLreluFn
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(R, C, generator=g) * 2 + 0.5).requires_grad_(True)
+    ga = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    be = torch.randn(C, generator=g).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.leaky_relu(F.batch_norm(x, rm, rv, ga, be, training=True, momentum=0.1, eps=1e-5), slope)
+    gy = torch.randn(R, C, generator=g)
+    y.backward(gy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    gd, bd = ga.detach().to(DEV).requires_grad_(True), be.detach().to(DEV).requires_grad_(True)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    yd = BnLreluFn.apply(xd, gd, bd, rmd, rvd, slope, 1e-5, 0.1)
+    yd.backward(gy.to(DEV))
+    _close(yd, y, atol=1e-5); _close(rmd, rm, atol=1e-6); _close(rvd, rv, rtol=1e-5)
+    _close(xd.grad, x.grad, rtol=1e-3, atol=1e-5)
+    _close(gd.grad, ga.grad, rtol=1e-3, atol=1e-3 * float(ga.grad.abs().max()))
+    _close(bd.grad, be.grad, rtol=1e-3, atol=1e-3 * float(be.grad.abs().max()))
+
+
+def test_edge_pool_gather_softmax_ops():
+    from puflow_amd import ops
+    from puflow_amd.train_ops import ActFn, EdgeFeatureFn, GatherRowsFn, MaxPoolKFn, RepeatRowsFn, SoftmaxWsumFn
+    B, N, C, K = 3, 100, 20, 16
+    g = torch.Generator().manual_seed(1)
+    pts = torch.rand(B, N, 3, generator=g)
+    _, idx = O.knn_canonical(pts, pts, K)
+    x = torch.randn(B, N, C, generator=g, requires_grad=True)
+    nb = O.knn_gather(x, idx); xi = x.unsqueeze(2).expand_as(nb)
+    e = torch.cat([xi, nb, nb - xi], -1).reshape(B * N * K, 3 * C)
+    pooled = e.view(B * N, K, 3 * C).max(1)[0]
+    ge = torch.randn(B * N, 3 * C, generator=g)
+    pooled.backward(ge)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    idx32 = idx.to(torch.int32).to(DEV)
+    ed = EdgeFeatureFn.apply(xd, idx32)
+    pd = MaxPoolKFn.apply(ed, K)
+    pd.backward(ge.to(DEV))
+    _close(ed, e); _close(pd, pooled); _close(xd.grad, x.grad, rtol=1e-4, atol=1e-5)
+    # gather rows + softmax weighted sum
+    z = torch.randn(B, N, 3, generator=g, requires_grad=True)
+    w = torch.randn(B * N, 8, 32, generator=g, requires_grad=True)
+    idx8 = idx[..., :8].contiguous()
+    zj = O.knn_gather(z, idx8).reshape(B * N, 8, 3)
+    a = F.softmax(w[:, :, :4], dim=1)
+    fz = torch.einsum("tkc,tkr->tcr", zj, a)
+    gf = torch.randn(B * N, 3, 4, generator=g)
+    fz.backward(gf)
+    zd, wd = z.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    fzd = SoftmaxWsumFn.apply(wd, GatherRowsFn.apply(zd, idx8.to(torch.int32).to(DEV)).view(B * N, 8, 3), 4)
+    fzd.backward(gf.to(DEV))
+    _close(fzd, fz, atol=1e-6); _close(zd.grad, z.grad, rtol=1e-4, atol=1e-6); _close(wd.grad, w.grad, rtol=1e-4, atol=1e-6)
+    # repeat rows + activation
+    c = torch.randn(B, N, C, generator=g, requires_grad=True)
+    r = F.relu(torch.repeat_interleave(c, 4, dim=1)); gr = torch.randn(B, N * 4, C, generator=g); r.backward(gr)
+    cd = c.detach().to(DEV).requires_grad_(True)
+    rd = ActFn.apply(RepeatRowsFn.apply(cd, 4), 0.0); rd.backward(gr.to(DEV))
+    _close(rd, r); _close(cd.grad, c.grad, rtol=1e-5, atol=1e-6)
+
+
+def _chamfer_cpu(x, y):
+    d = ((x[:, :, None] - y[:, None]) ** 2).sum(-1)
+    return (d.min(2)[0].mean(1) + d.min(1)[0].mean(1)).mean()
+
+
+def test_training_step_matches_reference_golden(golden_dir):
+    from puflow_amd import ops
+    from puflow_amd.interpflow import PointInterpFlow
+    g = np.load(os.path.join(golden_dir, "train_step.npz"))
+    B, N, R = int(g["meta_B"]), int(g["meta_N"]), 4
+    sd = synth_state_dict(int(g["meta_wseed"]))
+    dense = synth_patches(B, N * R, seed=int(g["meta_dseed"]))
+    sparse = dense[:, ::R].contiguous()
+    net = PointInterpFlow(3)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()                            # ActNorm not initialised: first-batch init, like the reference
+    x, logp = net(sparse.to(DEV), R)
+    cd, _ = ops.chamfer_distance(x, dense.to(DEV))
+    loss = logp * 1e-4 + cd * 1e-1
+    loss.backward()
+    np.testing.assert_allclose(x.detach().cpu().numpy(), g["x"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(float(logp), float(g["logp"]), rtol=1e-5)
+    np.testing.assert_allclose(float(cd), float(g["cd"]), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
+    norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    params = dict(net.named_parameters())
+    floor = 1e-5 * max(norms.values())
+    for k, ref in norms.items():
+        got = 0.0 if params[k].grad is None else float(params[k].grad.norm())
+        assert abs(got - ref) <= 2e-3 * ref + floor, (k, got, ref)
+    sd2 = net.state_dict()
+    for key in g.files:
+        if key.startswith("grad::"):
+            ref = g[key]
+            np.testing.assert_allclose(params[key[6:]].grad.cpu().numpy(), ref, rtol=5e-3, atol=2e-3 * np.abs(ref).max() + floor)
+        if key.startswith("state::"):
+            np.testing.assert_allclose(sd2[key[7:]].cpu().numpy(), g[key], rtol=1e-4, atol=1e-6)
+
+
+def test_trainer_module_step_and_eval_roundtrip():
+    """TrainerModule.train_step with the reference's loss mix (EMD via HIP), then eval() uses the fused path."""
+    from puflow_amd.trainer import TrainerModule, default_cfg
+    torch.manual_seed(0)
+    tm = TrainerModule(default_cfg(learning_rate=1e-3), loss_mix="pugan")
+    tm.network.load_state_dict(synth_state_dict(21))
+    tm = tm.to(DEV)
+    opt = tm.configure_optimizers()["optimizer"]
+    dense = synth_patches(4, 1024, seed=5)
+    dense01 = ((dense + 1) / 2).to(DEV)                  # EMD expects coordinates in [0,1]
+    sparse = dense01[:, ::4].contiguous()
+    radius = torch.ones(4, device=DEV)
+    w0 = tm.network.feat_convs[3].conv_out.weight.detach().clone()
+    l1 = tm.train_step((sparse, dense01, radius), opt)
+    l2 = tm.train_step((sparse, dense01, radius), opt)
+    assert torch.isfinite(l1) and torch.isfinite(l2)
+    assert not torch.equal(w0, tm.network.feat_convs[3].conv_out.weight.detach())   # weights moved
+    assert set(tm.logged) >= {"EMD", "logpx", "CD"}
+    out = tm.validation_step((sparse, dense01))
+    assert torch.isfinite(out["CD"]) and tm.network.training
+    # eval() after training: fused inference path agrees with the oracle on the trained weights
+    tm.eval()
+    x, logp = tm.network(sparse, 4)
+    sd = {k: v.detach().cpu() for k, v in tm.network.state_dict().items()}
+    xr, lr = O.forward(sd, sparse.cpu(), 4)
+    assert (x.cpu() - xr).abs().max() < 1e-5

@@ -67,7 +67,7 @@ def test_product_fails_loudly_on_cpu():
     with pytest.raises(_lib.PuflowHipError):
         net(torch.zeros(1, 64, 3))
     net.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.PuflowHipError):
         net(torch.zeros(1, 64, 3))
 
 
