@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU")
     ap.add_argument("--npoint", type=int, default=2048)
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = headline metric (BASELINE configs[1]); train = configs[2] training step (CD+EMD, RCCL all-reduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
@@ -62,6 +64,9 @@ def main():
 
     from puflow_amd.interpflow import PointInterpFlow
     from puflow_amd.weights import synth_patches, synth_state_dict
+
+    if args.mode == "train":
+        return bench_train(args, world, rank, dev, dist)
 
     sd = synth_state_dict(2021)
     net = PointInterpFlow(3)
@@ -166,6 +171,49 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_train(args, world, rank, dev, dist):
+    """BASELINE configs[2]: training step on 32 x (256 -> 1024) patches per GPU, loss 1e-4 logp + 5e-2 EMD(eps .005,
+    50 it) + 1e-1 CD (train_pugan.py:59-61), grad all-reduce (one 3.2 MB RCCL bucket), clip 1e-2, Adam 1e-3."""
+    from puflow_amd.trainer import TrainerModule, default_cfg
+    from puflow_amd.weights import synth_patches, synth_state_dict
+    from puflow_amd.dist import broadcast_module
+    tm = TrainerModule(default_cfg(learning_rate=1e-3), loss_mix="pugan")
+    tm.network.load_state_dict(synth_state_dict(2021))
+    tm = tm.to(dev)
+    broadcast_module(tm)
+    opt = tm.configure_optimizers()["optimizer"]
+    dense = ((synth_patches(args.batch, 1024, seed=2021 + rank) + 1) / 2).to(dev)      # [0,1] for the EMD
+    sparse = dense[:, ::4].contiguous()
+    batch = (sparse, dense, torch.ones(args.batch, device=dev))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        tm.train_step(batch, opt)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tm.train_step(batch, opt)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.destroy_process_group()
+    el = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "training patches/sec (256->1024 patches, CD+EMD loss, grad all-reduce)",
+                          "value": world * args.batch * args.steps / el, "unit": "patches/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "loss": float(loss),
+                          "config": {"workload": "BASELINE configs[2]: discrete x4 training step, 32 x (256->1024) patches per GPU",
+                                     "loss": "1e-4 logp + 5e-2 EMD(eps .005, 50 it) + 1e-1 CD", "optimizer": "Adam 1e-3, clip 1e-2"}}),
+              flush=True)
 
 
 if __name__ == "__main__":

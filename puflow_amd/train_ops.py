@@ -344,7 +344,7 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
                 an.is_inited = True
         p = p * torch.exp(an.logs) + an.bias
         W = blk.permutate1.permutater.W
-        p = torch.einsum("ij,bnj->bni", W, p)
+        p = linear(p, W)                                           # einsum 'ij,bnj->bni' (permutate.py:118)
         ld = (torch.sum(an.logs) + torch.slogdet(W)[1]) * N
         td = 1 if i % 2 == 0 else 2
         h1, h2 = p[..., :td], p[..., td:]
@@ -383,6 +383,6 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         h2 = h2 + cond_net(blk.coupling1.bias_net, torch.cat([h1, RepeatRowsFn.apply(cs[i], R)], dim=-1))
         u = torch.cat([h1, h2], dim=-1)
         W = blk.permutate1.permutater.W
-        u = torch.einsum("ij,bnj->bni", torch.inverse(W), u)
+        u = linear(u, torch.inverse(W))                            # permutate.py:123-124
         u = (u - blk.actnorm.bias) * torch.exp(-blk.actnorm.logs)
     return u, logp
