@@ -160,6 +160,20 @@ int pf_softmax_wsum_fwd(const float* w, int ldw, const float* zj, int K, int R, 
 int pf_softmax_wsum_bwd(const float* a, const float* zj, const float* dfz, int K, int R, int ldw, long long T, float* dw,
                         float* dzj, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Patch pipeline around the network (modules/utils/patch.py:35-214), csrc/patch_ops.hip
+ * ------------------------------------------------------------------------------------------- */
+
+/* Farthest point sampling.  Replaces pointnet2_ops furthest_point_sample (patch.py:102,156).
+ * xyz [B,N,3] -> idx_out [B,npoint] int32; starts at index 0; first maximum wins ties; mind: [B,N] float scratch. */
+int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, int* idx_out, void* stream);
+
+/* K nearest references of every query for large K (patch extraction, K = 256).  Replaces knn_cuda.KNN
+ * (patch.py:33,107).  ref [B,N,3], query [B,M,3], K <= N <= 16384 -> idx_out [B,M,K] int32 ordered by
+ * (distance, index); dist_out [B,M,K] squared L2 (nullable). */
+int pf_knn_large(const float* ref, const float* query, int B, int N, int M, int K, int* idx_out, float* dist_out,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,63 @@
+"""CPU oracle for the patch pipeline (FPS, large-K kNN, PatchHelper).  TEST INFRASTRUCTURE ONLY.
+
+Restates `modules/utils/patch.py:35-214` step by step.  The kernels it calls in the reference come from
+un-vendored, unpinned third-party packages (pointnet2_ops FPS, knn_cuda KNN, ChamferDistancePytorch;
+docker/Dockerfile:47-49, .gitmodules:1-3) and the reference has no tests for them: **parity unpinned** -
+the semantics are the ones stated in csrc/patch_ops.hip (FPS from index 0, first maximum; kNN by
+(distance, index); unfused fp32 squared distances)."""
+from __future__ import annotations
+
+import torch
+
+from . import ref_cpu as O
+
+Tensor = torch.Tensor
+
+
+def fps(xyz: Tensor, npoint: int) -> Tensor:
+    """[B,N,3] -> int64 [B,npoint]."""
+    B, N, _ = xyz.shape
+    out = torch.zeros(B, npoint, dtype=torch.int64)
+    for b in range(B):
+        p = xyz[b].float()
+        mind = torch.full((N,), 1e10)
+        cur = 0
+        for j in range(1, npoint):
+            d = p - p[cur]
+            dd = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            mind = torch.minimum(mind, dd)
+            cur = int(torch.argmax(mind))            # first maximal value
+            out[b, j] = cur
+    return out
+
+
+def normalize_pc(pc: Tensor):
+    centroid = torch.mean(pc, dim=1, keepdim=True)
+    pc = pc - centroid
+    fd, _ = torch.max(torch.sum(pc ** 2, dim=-1, keepdim=True).sqrt(), dim=1, keepdim=True)
+    return pc / fd, centroid, fd
+
+
+def extract_knn_patch(pc: Tensor, npoint_patch: int, expand_ratio: float) -> Tensor:
+    B, N, C = pc.shape
+    n_patch = int(N / npoint_patch * expand_ratio)
+    seeds = fps(pc, n_patch)
+    cent = pc[torch.arange(B).view(B, 1), seeds]                    # [B,n_patch,3]
+    _, idx = O.knn_canonical(cent, pc, npoint_patch)                # [B,n_patch,k]
+    return pc[torch.arange(B).view(B, 1, 1), idx]                   # [B,n_patch,k,3]
+
+
+def merge_patches(patches: Tensor, npoint: int) -> Tensor:
+    B, _, _, C = patches.shape
+    flat = patches.reshape(B, -1, C)
+    idx = fps(flat, npoint)
+    return flat[torch.arange(B).view(B, 1), idx]                    # [B,npoint,3]
+
+
+def remove_outliers(sr: Tensor, lr: Tensor, num_outliers: int) -> Tensor:
+    d1, _, _, _ = O.chamfer_nn(sr, lr)
+    B, N = d1.shape
+    order = torch.argsort(d1, dim=-1, descending=True, stable=True)[:, :num_outliers]
+    keep = torch.ones(B, N, dtype=torch.bool)
+    keep[torch.arange(B).view(B, 1), order] = False
+    return torch.stack([sr[b][keep[b]] for b in range(B)])

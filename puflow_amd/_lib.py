@@ -54,6 +54,8 @@ SIGNATURES = {
     "pf_softmax_wsum_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p]),
     "pf_softmax_wsum_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p,
                                     c_void_p]),
+    "pf_fps": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pf_knn_large": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 

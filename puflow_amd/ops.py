@@ -120,3 +120,52 @@ class chamfer_3DDist:
     def __call__(self, a, b):
         d1, d2, i1, i2, _, _ = chamfer_nn(a, b)
         return d1, d2, i1, i2
+
+
+# ----------------------------------------------------------------------------------------
+# Patch pipeline operators (pointnet2_ops / knn_cuda surfaces used by modules/utils/patch.py)
+# ----------------------------------------------------------------------------------------
+def furthest_point_sample(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+    """pointnet2_ops.pointnet2_utils.furthest_point_sample: xyz [B,N,3] -> int32 [B,npoint] (starts at index 0)."""
+    lib = _lib.load()
+    xyz = _f32c(xyz)
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    mind = torch.empty((B, N), dtype=torch.float32, device=xyz.device)
+    _lib.check(lib.pf_fps(xyz.data_ptr(), B, N, npoint, mind.data_ptr(), idx.data_ptr(), _stream()), "pf_fps")
+    return idx
+
+
+def gather_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """pointnet2 gather_operation: features [B,C,N], idx [B,M] -> [B,C,M] (indexing only)."""
+    B, C, _ = features.shape
+    return torch.gather(features, 2, idx.long().unsqueeze(1).expand(B, C, idx.shape[1]))
+
+
+class KNN:
+    """knn_cuda.KNN surface (modules/utils/patch.py:33,107): KNN(k, transpose_mode=False)(ref [B,C,N], query [B,C,M])
+    -> (dist [B,k,M] squared L2, idx [B,k,M] int64), ordered by (distance, index)."""
+
+    def __init__(self, k: int, transpose_mode: bool = False):
+        self.k = k
+        self.transpose_mode = transpose_mode
+
+    def __call__(self, ref: torch.Tensor, query: torch.Tensor):
+        lib = _lib.load()
+        if not self.transpose_mode:
+            ref, query = ref.transpose(1, 2), query.transpose(1, 2)
+        ref, query = _f32c(ref), _f32c(query)
+        B, N, _ = ref.shape
+        M = query.shape[1]
+        idx = torch.empty((B, M, self.k), dtype=torch.int32, device=ref.device)
+        dist = torch.empty((B, M, self.k), dtype=torch.float32, device=ref.device)
+        if self.k <= 32 and self.k in (4, 8, 16, 32):
+            _lib.check(lib.pf_knn(query.data_ptr(), ref.data_ptr(), B, M, N, self.k, idx.data_ptr(), dist.data_ptr(),
+                                  _stream()), "pf_knn")
+        else:
+            _lib.check(lib.pf_knn_large(ref.data_ptr(), query.data_ptr(), B, N, M, self.k, idx.data_ptr(), dist.data_ptr(),
+                                        _stream()), "pf_knn_large")
+        idx = idx.long()
+        if not self.transpose_mode:
+            return dist.transpose(1, 2).contiguous(), idx.transpose(1, 2).contiguous()
+        return dist, idx
