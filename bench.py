@@ -55,12 +55,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal knobs (one-GPU box): PF_BENCH_SINGLE_DEVICE=1 maps every rank to cuda:0 and PF_BENCH_BACKEND=gloo
+    # replaces RCCL (two ranks cannot share one device under RCCL); the driver's multi-GPU runs use neither.
+    if os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("PF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from puflow_amd.interpflow import PointInterpFlow
     from puflow_amd.weights import synth_patches, synth_state_dict
