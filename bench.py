@@ -24,6 +24,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 peak
+BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF; the 5 PF headline includes 2:1 sparsity)
 
 
 def edgeconv_ref_flops(T, C, g, nconv, odim, K=16):
@@ -117,22 +118,32 @@ def main():
         ec_fl = edgeconv_ref_flops(T, 128, 32, 4, 128)
         knn_ms = prof["knn"]
         knn_bytes = T * (3 * 4 + 16 * 4)               # 155 648 B per 2048-pt patch
-        ec_exec = T * 352 * 2048.0                      # executed: 352 v_mfma_f32_16x16x4_f32 per point x 2048 flop
-        roof = {"bound": "mfma", "kernel": "edgeconv_kernel<GB=2,NCONV=4,ODIM=128> (unit 3)",
-                "achieved": ec_fl / (ec_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": ec_fl / (ec_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None,
-                "flops_basis": "algorithmic = reference dense formulation (SURVEY 8d: 7.92 GFLOP per patch per unit); "
-                               "frac > 1 because the kernel EXECUTES 5.4x fewer flops (exact per-point P/Q fold, "
-                               "DESIGN.md section 3); executed_frac is the hardware MFMA utilisation",
+        if eng.ec_mode == "bf16x3":
+            kname, peak = "edgeconv3_kernel<NCONV=4,ODIM=128> (unit 3, split-bf16 on v_mfma_f32_16x16x32_bf16)", BF16_MFMA_PEAK_TF
+            ec_exec = T * 264 * 16384.0                 # executed: 264 bf16 MFMAs (16x16x32) per point
+            basis = ("algorithmic = reference dense fp32 formulation (SURVEY 8d: 7.92 GFLOP per patch per unit), priced "
+                     "against the DENSE bf16 MFMA peak because the kernel runs on the bf16 pipe: fp32-equivalent results "
+                     "from 6 bf16 MFMA terms per product (3-way split), after the exact per-point P/Q fold (5.4x fewer "
+                     "MACs than the reference formulation); executed_* counts the bf16 MFMA flops actually issued")
+        else:
+            kname, peak = "edgeconv_kernel<GB=2,NCONV=4,ODIM=128> (unit 3, v_mfma_f32_16x16x4_f32)", FP32_MFMA_PEAK_TF
+            ec_exec = T * 352 * 2048.0                  # executed: 352 f32 MFMAs (16x16x4) per point
+            basis = ("algorithmic = reference dense formulation (SURVEY 8d: 7.92 GFLOP per patch per unit); frac > 1 because "
+                     "the kernel EXECUTES 5.4x fewer flops (exact per-point P/Q fold); executed_frac = MFMA utilisation")
+        roof = {"bound": "mfma", "kernel": kname,
+                "achieved": ec_fl / (ec_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": ec_fl / (ec_ms * 1e-3) / 1e12 / peak, "traffic": None,
+                "flops_basis": basis,
                 "executed_achieved": ec_exec / (ec_ms * 1e-3) / 1e12,
-                "executed_frac": ec_exec / (ec_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+                "executed_frac": ec_exec / (ec_ms * 1e-3) / 1e12 / peak,
                 "avg_launch_ms": ec_ms}
         # HBM traffic of the dominant kernel: PMC counters are collected offline with rocprofv3 (bench.py cannot
         # run under --pmc and time itself); the committed summary of the same command is read back here.
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pmc = json.load(f)["kernels"]
-            key = [k for k in pmc if k.startswith("edgeconv_kernel<2, 4, 128")][0]
+            pref = "edgeconv3_kernel" if eng.ec_mode == "bf16x3" else "edgeconv_kernel<2, 4, 128"
+            key = [k for k in pmc if k.startswith(pref)][0]
             roof["traffic"] = pmc[key]["hbm_bytes_per_launch"]
             roof["traffic_note"] = ("bytes per launch at 32 x 2048 from profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE x2 "
                                     "+ WRITE_SIZE); algorithmic HBM bytes per launch = PQ 134.2 MB + idx 4.2 MB + out 33.6 MB")
@@ -141,7 +152,7 @@ def main():
         extra = {"stage_ms": prof,
                  "knn_hbm": {"achieved": knn_bytes / (knn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "note": "kNN is VALU/selection-bound by construction (216 flop/B)"},
-                 "model_mfma_frac": model_ref_flops_per_patch() * value / world / 1e12 / FP32_MFMA_PEAK_TF}
+                 "model_algorithmic_tflops": model_ref_flops_per_patch() * value / world / 1e12}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ref_cpu as O
@@ -172,7 +183,9 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[1]: PU1K discrete x4 inference, 32 x 2048-pt patches per GPU "
-                                      "(f32 exact-parity mode)", "patches_per_gpu": args.batch, "npoint": args.npoint,
+                                      "(fp32-parity mode)", "arithmetic": "fp32 results: f32 MFMA everywhere except the four 128-channel EdgeConv "
+                          "units, which use 3-term split-bf16 products on the bf16 MFMA pipe (fp32-class accuracy, "
+                          "PF_EC_MODE=f32 selects the bit-exact f32 MFMA kernel)", "patches_per_gpu": args.batch, "npoint": args.npoint,
                           "upratio": 4, "sharding": f"patch batch over {world} rank(s), no data-path collective"},
                "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)

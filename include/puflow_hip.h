@@ -80,7 +80,8 @@ int pf_logp(const float* z, const float* ld_pt, float ld_const, int B, int N, fl
 
 /* Interpolation module (interpflow.py:85-186), fused: kNN-8 context features -> weights ->
  * softmax_k -> weighted sum of neighbour latents.  idx16 [T,16] (first 8 columns used),
- * u_out [T*R,3] in the row order of g (row = n*R + r).  R must be 4.
+ * u_out [T*R,3] in the row order of g (row = n*R + r).  1 <= R <= 4 (the packed
+ * weight blob must have been made for the same R: packing.pack_plan).
  * off[13]: float offsets into w (csrc/interp.hip header, packing.INTERP_SLOTS). */
 int pf_interp(const float* xyz, const float* z, const int* idx16, const float* w, const long long* off, float* u_out,
               int B, int N, int R, void* stream);

@@ -163,6 +163,108 @@ __global__ __launch_bounds__(NW * 64) void edgeconv_kernel(EcArgs a) {
     }
 }
 
+// ---- split-bf16 variant of the 128-channel units (GB = 2: one growth layer = one 32-channel block pair) ----
+// Same data flow as edgeconv_kernel; growth features are kept as (hi, mid, lo) bf16 B operands, the weights
+// come pre-split from the host (packing.frag_pack_bf16x3).  Accuracy: fp32-class (tests compare to the oracle
+// with the same 1e-5 bar); MFMA cycles per point: 264 x 16 instead of 352 x 32.
+template <int NCONV, int ODIM, int P, int NW, int DBG = 0>   // DBG (timing-only builds): 1 = no gathers, 2 = no MFMAs
+__global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
+    constexpr int G = 32, S = G * NCONV + ODIM, OBO = ODIM / 16, OCH = 2;
+    constexpr int NWF = 2 * (NCONV * (NCONV - 1) / 2) + OBO * NCONV;      // (ob, pair) fragments, 3 KiB each
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    __shared__ u4 wlds[NWF * 3 * 64];
+    for (int i = threadIdx.x; i < NWF * 3 * 64; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
+    __syncthreads();
+    const PfW3Lds ws{wlds, lane};
+
+    for (int v = blockIdx.x; v < 8 * a.chunk; v += gridDim.x) {
+        const int tile = pf_xcd_tile(v, a.chunk);
+        if (tile >= a.ntiles) continue;
+        const int pt0 = (tile * NW + wave) * P;
+        int gi[P], gj[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int g = pt0 + p;
+            g = g < a.T ? g : a.T - 1;
+            gi[p] = g;
+            gj[p] = (g / a.N) * a.N + a.idx[(size_t)g * 16 + col];
+        }
+        auto init = [&](int p, int off) -> f4 {
+            if constexpr (DBG == 1) return pf_splat((float)(off + gi[p]) * 1e-6f);
+            const f4 pv = *reinterpret_cast<const f4*>(a.pq + (size_t)gi[p] * (2 * S) + off);
+            const f4 qv = *reinterpret_cast<const f4*>(a.pq + (size_t)gj[p] * (2 * S) + S + off);
+            return pv + qv;
+        };
+        f4 ini[2][P][2];
+        auto load_init = [&](int row0, f4 (&dst)[P][2]) {
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int p = 0; p < P; ++p) dst[p][ob] = init(p, row0 + ob * 16 + 4 * q);
+        };
+        load_init(0, ini[0]);
+        load_init(G, ini[1]);
+        PfPair feat[P][NCONV];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            feat[p][0] = pf_pair(pf_split3(pf_lrelu(ini[0][p][0], 0.05f)), pf_split3(pf_lrelu(ini[0][p][1], 0.05f)));
+        pf_static_for<1, NCONV>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            load_init(G * (t + 1), ini[(t + 1) & 1]);                 // next growth layer, or conv_out chunk 0
+            f4 acc[P][2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p][ob] = ini[t & 1][p][ob];
+            if constexpr (DBG != 2) pf_mm3<2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, 0, acc, 0);
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                feat[p][t] = pf_pair(pf_split3(pf_lrelu(acc[p][0], 0.05f)), pf_split3(pf_lrelu(acc[p][1], 0.05f)));
+        });
+        constexpr int FO = 2 * (NCONV * (NCONV - 1) / 2);
+        f4 sel[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) sel[p] = pf_splat(0.f);
+        pf_static_for<0, OBO / OCH>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int ob0 = c * OCH;
+            constexpr int st = NCONV + c;
+            if constexpr (c + 1 < OBO / OCH) load_init(G * NCONV + (ob0 + OCH) * 16, ini[(st + 1) & 1]);
+            f4 acc[P][OCH];
+#pragma unroll
+            for (int o = 0; o < OCH; ++o)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p][o] = ini[st & 1][p][o];
+            if constexpr (DBG != 2) pf_mm3<OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, 0, acc, 0);
+#pragma unroll
+            for (int o = 0; o < OCH; ++o)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    f4 m;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m[r] = pf_rowmax16(acc[p][o][r]);
+                    if (col == ob0 + o) sel[p] = m;
+                }
+        });
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            if (col < OBO && pt0 + p < a.T)
+                *reinterpret_cast<f4*>(a.out + (size_t)gi[p] * ODIM + col * 16 + 4 * q) = sel[p];
+    }
+}
+
+template <int P, int NW, int DBG = 0>
+int launch3(const EcArgs& a0, hipStream_t s) {
+    EcArgs a = a0;
+    a.ntiles = (a.T + NW * P - 1) / (NW * P);
+    a.chunk = (a.ntiles + 7) / 8;
+    int grid = 8 * a.chunk;
+    if (grid > 256) grid = 256;                           // 132 KiB of LDS: one persistent workgroup per CU
+    hipLaunchKernelGGL((edgeconv3_kernel<4, 128, P, NW, DBG>), dim3(grid), dim3(NW * 64), 0, s, a);
+    return pf_last_launch_status();
+}
+
 template <int GB, int NCONV, int ODIM, bool C3, int P, int NW>
 int launch_v(const EcArgs& a0, hipStream_t s) {
     EcArgs a = a0;
@@ -212,6 +314,17 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
             return launch<1, 4, 32, true>(a, s, variant);
         case 1: a.pq = pq_or_xyz; return launch<1, 4, 64, false>(a, s, variant);
         case 2: a.pq = pq_or_xyz; return launch<2, 4, 128, false>(a, s, variant);
+        case 3:                                   // units 2..5, split-bf16 weights (packing: ec3_w)
+            a.pq = pq_or_xyz;
+            switch (variant) {
+                case 0: return launch3<2, 8>(a, s);
+                case 1: return launch3<1, 8>(a, s);
+                case 2: return launch3<1, 16>(a, s);
+                case 3: return launch3<2, 16>(a, s);
+                case 8: return launch3<1, 16, 1>(a, s);      // timing only: no gathers (wrong results)
+                case 9: return launch3<1, 16, 2>(a, s);      // timing only: no MFMAs (wrong results)
+                default: return PF_ERR_UNSUPPORTED;
+            }
         default: return PF_ERR_UNSUPPORTED;
     }
 }
@@ -220,7 +333,7 @@ extern "C" int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, co
                            float* out, int B, int N, void* stream) {
     // shipped variants (tools/tune_edgeconv.py, MI355X): unit 0 -> (P=2, NW=8); unit 1 -> (1, 8);
     // units 2..5 -> (1, 16): one point per wave, 16 waves share the 88 KiB of LDS-resident weights.
-    static const int best[3] = {0, 2, 3};
-    if (cfg < 0 || cfg > 2) return PF_ERR_UNSUPPORTED;
+    static const int best[4] = {0, 2, 3, 0};
+    if (cfg < 0 || cfg > 3) return PF_ERR_UNSUPPORTED;
     return pf_edgeconv_tuned(cfg, best[cfg], pq_or_xyz, tab, idx, wfrag, out, B, N, stream);
 }

@@ -33,12 +33,12 @@ struct InterpArgs {
     const float* w;
     long long off[13];
     float* u;            // [T*R,3]  row = n*R + r
-    int T, N, ntiles;
+    int T, N, ntiles, R;     // R = upsampling ratio actually written (1..4)
 };
 
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
-    constexpr int R = 4;
+    constexpr int R = 4;                 // rows computed (W6 is packed with 4 rows per q group); a.R <= 4 are stored
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
     const int ps = col >> 3, k = col & 7;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
             for (int r = 0; r < R; ++r) {
                 float s = av[r] * zj;
                 s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-                if (ok[p] && k == 0 && q < 3) a.u[((size_t)gi[p] * R + r) * 3 + q] = s;
+                if (ok[p] && k == 0 && q < 3 && r < a.R) a.u[((size_t)gi[p] * a.R + r) * 3 + q] = s;
             }
         }
     }
@@ -190,10 +190,10 @@ extern "C" int pf_interp(const float* xyz, const float* z, const int* idx16, con
                          float* u_out, int B, int N, int R, void* stream) {
     if (!xyz || !z || !idx16 || !w || !off || !u_out) return PF_ERR_NULL;
     if (B <= 0 || N < 8 || (long long)B * N > (1ll << 28)) return PF_ERR_SHAPE;
-    if (R != 4) return PF_ERR_UNSUPPORTED;
+    if (R < 1 || R > 4) return PF_ERR_UNSUPPORTED;
     constexpr int P = PF_INTERP_P, NW = PF_INTERP_NW;
     InterpArgs a{};
-    a.xyz = xyz; a.z = z; a.idx = idx16; a.w = w; a.u = u_out; a.T = B * N; a.N = N;
+    a.xyz = xyz; a.z = z; a.idx = idx16; a.w = w; a.u = u_out; a.T = B * N; a.N = N; a.R = R;
     for (int i = 0; i < 13; ++i) a.off[i] = off[i];
     a.ntiles = (a.T + NW * P * 2 - 1) / (NW * P * 2);
     const int grid = a.ntiles < 4096 ? a.ntiles : 4096;

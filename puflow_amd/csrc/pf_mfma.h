@@ -96,6 +96,98 @@ __device__ __forceinline__ void pf_mm(const WS& ws, int frag0, const f4 (&in)[P]
     }
 }
 
+// ---- split-bf16 ("bf16x3") path: fp32 accuracy on the bf16 matrix pipe -------------------------
+// x = hi + mid + lo with three bf16 terms (3 x 8 mantissa bits = fp32's 24); a product keeps the six
+// largest cross terms (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; dropped terms < 2^-24 relative).
+// v_mfma_f32_16x16x32_bf16 runs 16 cycles for 16x16x32 (f32 16x16x4: 32 cycles for 16x16x4), so six of them
+// replace eight f32 MFMAs at 3/8 of the cycles.
+// K-slot <-> channel map of one 32-channel step (a PAIR of 16-channel blocks b0,b1): lane (q = l>>4) holds
+// k = 8q + j, j < 4 -> channel 16 b0 + 4q + j, j >= 4 -> channel 16 b1 + 4q + (j-4): exactly the two float4
+// accumulator registers the lane already owns, so layers still chain without moving data.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+struct PfSplit { unsigned h0, h1, m0, m1, l0, l1; };     // 4 values -> 3 x (4 bf16 in 2 dwords)
+
+__device__ __forceinline__ unsigned pf_cvt_pk(float a, float b) {
+    bf2 t = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ float pf_lo16(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float pf_hi16(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+__device__ __forceinline__ void pf_split_pair(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
+    ph = pf_cvt_pk(a, b);
+    const float ra = a - pf_lo16(ph), rb = b - pf_hi16(ph);
+    pm = pf_cvt_pk(ra, rb);
+    const float sa = ra - pf_lo16(pm), sb = rb - pf_hi16(pm);
+    pl = pf_cvt_pk(sa, sb);
+}
+
+__device__ __forceinline__ PfSplit pf_split3(f4 v) {
+    PfSplit s;
+    pf_split_pair(v.x, v.y, s.h0, s.m0, s.l0);
+    pf_split_pair(v.z, v.w, s.h1, s.m1, s.l1);
+    return s;
+}
+
+// B operands (hi / mid / lo) of one block pair
+struct PfPair { bf8 h, m, l; };
+__device__ __forceinline__ PfPair pf_pair(const PfSplit& a, const PfSplit& b) {
+    PfPair p;
+    p.h = __builtin_bit_cast(bf8, (u4){a.h0, a.h1, b.h0, b.h1});
+    p.m = __builtin_bit_cast(bf8, (u4){a.m0, a.m1, b.m0, b.m1});
+    p.l = __builtin_bit_cast(bf8, (u4){a.l0, a.l1, b.l0, b.l1});
+    return p;
+}
+
+__device__ __forceinline__ f4 pf_mfma_bf16(bf8 a, bf8 b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// weights: [frag][3 splits][64 lanes] x 16 B in LDS
+struct PfW3Lds {
+    const u4* base;
+    int lane;
+    __device__ __forceinline__ bf8 load(int frag, int split) const {
+        return __builtin_bit_cast(bf8, base[(frag * 3 + split) * PF_WAVE + lane]);
+    }
+};
+
+// acc[p][acc0+ob] += W[ob][cp] * in[p][in0+cp]  over block PAIRS cp < CP (six bf16 MFMAs per pair, small terms first).
+// The next fragment's three weight reads are issued before the current fragment's MFMAs (double buffer).
+template <int OB, int CP, int WCP, int P, int NIN, int NACC>
+__device__ __forceinline__ void pf_mm3(const PfW3Lds& ws, int frag0, const PfPair (&in)[P][NIN], int in0,
+                                       f4 (&acc)[P][NACC], int acc0) {
+    constexpr int NFRAG = OB * CP;
+    bf8 wb[2][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) wb[0][s] = ws.load(frag0, s);
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) {
+        const int ob = i / CP, cp = i % CP;
+        if (i + 1 < NFRAG) {
+            const int f = frag0 + ((i + 1) / CP) * WCP + ((i + 1) % CP);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) wb[(i + 1) & 1][s] = ws.load(f, s);
+        }
+        const bf8 wh = wb[i & 1][0], wm = wb[i & 1][1], wl = wb[i & 1][2];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            f4 a = acc[p][acc0 + ob];
+            a = pf_mfma_bf16(wh, in[p][in0 + cp].l, a);
+            a = pf_mfma_bf16(wl, in[p][in0 + cp].h, a);
+            a = pf_mfma_bf16(wm, in[p][in0 + cp].m, a);
+            a = pf_mfma_bf16(wh, in[p][in0 + cp].m, a);
+            a = pf_mfma_bf16(wm, in[p][in0 + cp].h, a);
+            a = pf_mfma_bf16(wh, in[p][in0 + cp].h, a);
+            acc[p][acc0 + ob] = a;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // cooperative global -> LDS copy of `nf4` float4 by the whole workgroup (call before a __syncthreads)
 __device__ __forceinline__ void pf_stage_lds(f4* __restrict__ dst, const f4* __restrict__ src, int nf4) {
     for (int i = threadIdx.x; i < nf4; i += blockDim.x) dst[i] = src[i];

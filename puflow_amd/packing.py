@@ -166,6 +166,37 @@ def frag_pack(W: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(f.transpose(0, 2, 3, 1, 4)).reshape(OB, CB, 64, 4)
 
 
+def _bf16_round(x: np.ndarray) -> np.ndarray:
+    """fp32 -> nearest-even bf16, returned as fp32 (exactly representable)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def frag_pack_bf16x3(W: np.ndarray) -> np.ndarray:
+    """[OUT, IN] fp32 -> split-bf16 A-operand fragments of v_mfma_f32_16x16x32_bf16, as a float32-typed byte
+    image [OB][CP][3 splits hi/mid/lo][64 lanes][8 bf16] (csrc/pf_mfma.h 'split-bf16 path').
+    Lane l (row = l & 15, q = l >> 4), element j of block pair cp: channel 32 cp + 4q + j (j < 4) or
+    32 cp + 16 + 4q + (j - 4) (j >= 4)."""
+    out, inn = W.shape
+    OB, CP = (out + 15) // 16, (inn + 31) // 32
+    Wp = np.zeros((OB * 16, CP * 32), dtype=np.float32)
+    Wp[:out, :inn] = W
+    hi = _bf16_round(Wp)
+    r1 = (Wp - hi).astype(np.float32)
+    mid = _bf16_round(r1)
+    lo = _bf16_round((r1 - mid).astype(np.float32))
+    lanes = np.arange(64)
+    row, q = lanes & 15, lanes >> 4
+    j = np.arange(8)
+    ch = np.where(j[None, :] < 4, 4 * q[:, None] + j[None, :], 16 + 4 * q[:, None] + (j[None, :] - 4))     # [64,8]
+    res = np.zeros((OB, CP, 3, 64, 8), dtype=np.uint16)
+    for si, part in enumerate((hi, mid, lo)):
+        bits = (part.view(np.uint32) >> 16).astype(np.uint16).reshape(OB, 16, CP, 32)
+        res[:, :, si] = bits[:, row[:, None], :, ch].transpose(2, 3, 0, 1)      # -> [OB,CP,64,8]
+    return res.reshape(-1).view(np.float32)
+
+
 def frag_unpack(F: np.ndarray, out: int, inn: int) -> np.ndarray:
     OB, CB = F.shape[0], F.shape[1]
     f = F.reshape(OB, CB, 4, 16, 4).transpose(0, 3, 1, 2, 4)
@@ -245,6 +276,9 @@ def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
     units = plan["units"]
     out["ec_tab0"] = B.add(_edge_table(units[0]))
     out["ec_w"] = [B.add(_ec_frags(units[i], 4)) for i in range(NUM_BLOCKS)]
+    # split-bf16 weight image of the 128-channel units (csrc/edgeconv.hip edgeconv3_kernel); None for units 0,1
+    out["ec3_w"] = [None, None] + [B.add(np.concatenate([frag_pack_bf16x3(units[i][f"G{t}"]) for t in range(1, 5)]))
+                                   for i in range(2, NUM_BLOCKS)]
     post = []
     for i in range(NUM_BLOCKS):
         m, f = plan["merges"][i], plan["flows"][i]

@@ -129,6 +129,34 @@ def test_forward_matches_reference_golden(lib, golden_dir, name):
     assert torch.equal(x, st["x"]) and torch.equal(logp, st["logp"])
 
 
+def test_edgeconv_arithmetic_modes(lib):
+    """Both EdgeConv arithmetic modes of the 128-channel units meet the parity bar: split-bf16 (default) and
+    the bit-exact f32 MFMA kernel; they agree with each other to fp32 rounding."""
+    sd = synth_state_dict(12)
+    xyz = synth_patches(2, 512, seed=13)
+    ref = O.forward(sd, xyz, 4, stages=True)
+    net = _net(sd)
+    outs = {}
+    for mode in ("bf16x3", "f32"):
+        net._engine(4).ec_mode = mode
+        st = net.forward_stages(xyz.to(DEV), 4)
+        _check_stages(st, ref)
+        outs[mode] = st
+    assert (outs["f32"]["x"] - outs["bf16x3"]["x"]).abs().max() < 5e-6
+    assert (outs["f32"]["cs"][5] - outs["bf16x3"]["cs"][5]).abs().max() < 5e-6
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_other_upsampling_ratios(lib, R):
+    sd = synth_state_dict(6)
+    xyz = synth_patches(2, 256, seed=3)
+    ref = O.forward(sd, xyz, R, stages=True)
+    x, logp = _net(sd)(xyz.to(DEV), R)
+    assert tuple(x.shape) == (2, 256 * R, 3)
+    assert (x.cpu() - ref["x"]).abs().max() < 1e-5
+    assert abs(float(logp) - float(ref["logp"])) / abs(float(ref["logp"])) < 1e-5
+
+
 def test_reference_method_surface(lib):
     """feat_extract / f / log_prob / g / sample called the way the reference's callers do."""
     from puflow_amd import ops

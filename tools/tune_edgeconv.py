@@ -49,3 +49,20 @@ for u in (0, 1, 3):
                 times[v].append(a.elapsed_time(b))
     res[u] = {v: (min(t), sorted(t)[len(t) // 2]) for v, t in times.items()}
     print("unit", u, {v: f"min {a:.3f} med {b:.3f} ms" for v, (a, b) in res[u].items()}, flush=True)
+
+# ---- split-bf16 variants of unit 3 (cfg 3): speed + deviation from the exact-f32 kernel
+u = 3
+times = {v: [] for v in (0, 1, 2, 3, 8, 9)}
+dev = {}
+for rnd in range(6):
+    for v in (0, 1, 2, 3, 8, 9):
+        out = torch.empty_like(hs[u])
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = lib.pf_edgeconv_tuned(3, v, pqs[u].data_ptr(), None, idx16.data_ptr(), e._p(e.ec3_w[u]), out.data_ptr(), B, N, s)
+        b.record(); torch.cuda.synchronize()
+        assert rc == 0, rc
+        dev[v] = (float((out - hs[u]).abs().max()), float(hs[u].abs().max()))
+        if rnd > 0:
+            times[v].append(a.elapsed_time(b))
+print("unit 3 bf16x3", {v: f"min {min(t):.3f} ms  max|d| {dev[v][0]:.2e} (|h|max {dev[v][1]:.2f})" for v, t in times.items()}, flush=True)
