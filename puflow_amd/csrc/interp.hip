@@ -4,14 +4,18 @@
 // its sub-modules (modules/discrete/interpflow.py:85-186) in eval mode.
 //
 // Mapping: one MFMA column tile = 2 points x 8 neighbours (col = 8*ps + k).  The 256-channel
-// context never exists in memory: the distance-encoder half is folded into the first
-// weight-unit layer before the EdgeConv half is produced (w1 = W0[:, :128] d + W0[:, 128:] e).
-// Only the first R rows of the last weight conv are computed (interpflow.py:180).
+// context never exists, not even in registers: both producers end in a linear layer (DistanceEncoder's
+// last conv, the EdgeConv's conv_out) that feeds the weight unit's first conv with no nonlinearity in
+// between (interpflow.py:134,144), so the host composes them (packing.fold_state_dict):
+//     w1 = [b0 + W0a b6] + (W0a W6) d2 + (W0b Gout) feat + W0b (PA x_i + QB x_j + pb)
+// -> 704 MFMAs per tile instead of 1216.  Only the first R rows of the last weight conv are
+// computed (interpflow.py:180).
 //
 // Weight blob (float offsets in `off[]`, see puflow_amd/packing.py::INTERP_SLOTS):
-//   0 dtab [64][8] (PA(3) QB(3) wn b0)   1 d_W3 frags [4x4]  2 d_b3 [64]  3 d_W6 frags [8x4]  4 d_b6 [128]
-//   5 ectab [256][8] (PA(3) QB(3) pb 0)  6 ec G1..G7,Gout frags           7 w_W0 frags [8x16]  8 w_b0 [128]
-//   9 w_W3 frags [4x8]  10 w_b3 [64]     11 w_W6 frags [1x4] (R rows replicated per q group)  12 w_b6 [16]
+//   0 dtab [64][8] (PA(3) QB(3) wn b0)   1 d_W3 frags [4x4]  2 d_b3 [64]  3 (W0a W6) frags [8x4]  4 b0 + W0a b6 [128]
+//   5 ectab [256][8] (PA(3) QB(3) pb 0; rows 0..127 used)    6 ec G1..G7 frags   7 (W0b Gout) frags [8x8]
+//   8 w1tab [128][8] = W0b.(edge table rows 128..255)        9 w_W3 frags [4x8]  10 w_b3 [64]
+//   11 w_W6 frags [1x4] (R rows replicated per q group)      12 w_b6 [16]
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
@@ -81,10 +85,10 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
             return r;
         };
 
-        // ---- distance encoder 10 -> 64 -> 64 -> 128
+        // ---- distance encoder 10 -> 64 -> 64, then its (folded) contribution to the weight unit's first layer
         f4 w1[P][8];
         {
-            f4 d1[P][4], d2[P][4], d3[P][8];
+            f4 d1[P][4], d2[P][4];
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
@@ -97,20 +101,16 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
                 for (int p = 0; p < P; ++p) d2[p][cb] = pf_lrelu(d2[p][cb], 0.01f);
+            // w1 = (b0 + W0a b6) + W0b.(edge table) + (W0a W6) d2
 #pragma unroll
             for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
-                for (int p = 0; p < P; ++p) d3[p][ob] = pf_bias(a.w + a.off[4], ob, q);
-            pf_mm<8, 4, 4>(wsD6, 0, d2, 0, d3, 0);
-            // first weight-unit layer, distance half:  w1 = b0 + W0[:, 0:128] d3
-#pragma unroll
-            for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-                for (int p = 0; p < P; ++p) w1[p][ob] = pf_bias(a.w + a.off[8], ob, q);
-            pf_mm<8, 8, 16>(wsW0, 0, d3, 0, w1, 0);
+                for (int p = 0; p < P; ++p)
+                    w1[p][ob] = pf_bias(a.w + a.off[4], ob, q) + tabrow(a.w + a.off[8], p, ob * 16 + 4 * q, false);
+            pf_mm<8, 4, 4>(wsD6, 0, d2, 0, w1, 0);
         }
 
-        // ---- EdgeConv (C=3, g=16, 8 convs, odim 128, no pooling) on the same 8 neighbours
+        // ---- EdgeConv growth features (C=3, g=16, 8 convs) on the same 8 neighbours; conv_out is folded into w1
         {
             f4 feat[P][8];
 #pragma unroll
@@ -124,17 +124,7 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) feat[p][t] = pf_lrelu(acc[p][0], 0.05f);
             });
-            // conv_out in chunks of 2 blocks, folded straight into w1 += W0[:, 128 + 16*eb ..] e
-            pf_static_for<0, 4>([&](auto cc) {
-                constexpr int eb0 = decltype(cc)::value * 2;
-                f4 e[P][2];
-#pragma unroll
-                for (int o = 0; o < 2; ++o)
-#pragma unroll
-                    for (int p = 0; p < P; ++p) e[p][o] = tabrow(ectab, p, 128 + (eb0 + o) * 16 + 4 * q, false);
-                pf_mm<2, 8, 8>(wsEC, 28 + eb0 * 8, feat, 0, e, 0);
-                pf_mm<8, 2, 16>(wsW0, 8 + eb0, e, 0, w1, 0);
-            });
+            pf_mm<8, 8, 8>(wsW0, 0, feat, 0, w1, 0);              // w1 += (W0b Gout) feat
         }
 
         // ---- rest of the weight unit: 128 -> 64 -> R

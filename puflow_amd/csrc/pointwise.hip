@@ -1,5 +1,6 @@
 // Per-point stage that follows each EdgeConv unit (one launch per unit):
 //   c   = W2 relu(W1 h + b1)                         FeatMergeUnit   (interpflow.py:251-258)
+//   (c itself is written only on request: W2 is folded into the first layers of the three nets below)
 //   s,t = LinearA1D_s(c), LinearA1D_t(c)             AffineInjectorLayer nets (coupling.py:132-134,
 //                                                    interpflow.py:22-43) - depend on c only, so they
 //                                                    are computed once per ORIGINAL point and shared by
@@ -24,7 +25,7 @@ struct PostArgs {
     const float* h;                       // [T, ODIM]
     const f4* wM1; const float* b1;       // [ODIM/2, ODIM]
     const f4* wM2;                        // [CDIM, ODIM/2]
-    const f4* wH1;                        // [192, CDIM]  rows: s_W0 | t_W0 | c1_W0c
+    const f4* wH1;                        // [192, ODIM/2]  rows: (s_W0 | t_W0 | c1_W0c) W2  (merge conv2 folded in)
     const f4* wS2; const float* bS2;      // [64, 64]
     const f4* wT2; const float* bT2;      // [64, 64]
     const f4* wST4; const float* bST4;    // [16, 128]    rows 0-2: s_W4 on cols 0-63, rows 3-5: t_W4 on cols 64-127
@@ -90,13 +91,15 @@ __global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
 #pragma unroll
             for (int p = 0; p < P; ++p) m[p][o] = pf_relu(m[p][o]);
 
-        f4 c[P][CB];
-#pragma unroll
-        for (int o = 0; o < CB; ++o)
-#pragma unroll
-            for (int p = 0; p < P; ++p) c[p][o] = pf_splat(0.f);
-        pf_mm<CB, MB, MB>(wsM2, 0, m, 0, c, 0);
+        // c = W2 m is only materialised when the caller wants `cs` (feat_extract API): everything downstream of c
+        // is linear in it, so the host folded W2 into those layers (H1 := [s_W0; t_W0; c1_W0c] W2, packing.pack_plan)
         if (a.c) {
+            f4 c[P][CB];
+#pragma unroll
+            for (int o = 0; o < CB; ++o)
+#pragma unroll
+                for (int p = 0; p < P; ++p) c[p][o] = pf_splat(0.f);
+            pf_mm<CB, MB, MB>(wsM2, 0, m, 0, c, 0);
 #pragma unroll
             for (int o = 0; o < CB; ++o)
 #pragma unroll
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
             for (int o = 0; o < 4; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][o] = pf_splat(0.f);
-            pf_mm<4, CB, CB>(wsH1, 8 * CB, c, 0, acc, 0);
+            pf_mm<4, MB, MB>(wsH1, 8 * MB, m, 0, acc, 0);
 #pragma unroll
             for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
             for (int o = 0; o < 4; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) h1[p][o] = pf_splat(0.f);
-            pf_mm<4, CB, CB>(wsH1, (4 * net) * CB, c, 0, h1, 0);
+            pf_mm<4, MB, MB>(wsH1, (4 * net) * MB, m, 0, h1, 0);
 #pragma unroll
             for (int o = 0; o < 4; ++o)
 #pragma unroll

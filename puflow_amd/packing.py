@@ -145,6 +145,20 @@ def fold_state_dict(sd, upratio: int = 4) -> Dict[str, object]:
     ip["w_W3"], ip["w_b3"] = W3.astype(np.float32), b3.astype(np.float32)
     W6 = _np(sd, p + ".6.weight"); W6 = W6.reshape(W6.shape[0], -1)
     ip["w_W6"], ip["w_b6"] = W6[:upratio].astype(np.float32), _np(sd, p + ".6.bias")[:upratio].astype(np.float32)
+    # linear o linear folds around the 256-channel context (no nonlinearity between the producers' last conv and the
+    # weight unit's first conv, interpflow.py:134,144):  W0.[d; e] with d = W6 d2 + b6 and e = Gout feat + (PA x_i + QB x_j + pb)
+    W0d = ip["w_W0"].astype(np.float64)
+    W0a, W0b = W0d[:, :128], W0d[:, 128:]
+    ec = ip["ec"]
+    nrow = 16 * 8                                            # conv_out rows of the interp EdgeConv start at 128
+    ip["f_dW"] = (W0a @ ip["d_W6"].astype(np.float64)).astype(np.float32)              # [128, 64]  on d2
+    ip["f_b0"] = (ip["w_b0"].astype(np.float64) + W0a @ ip["d_b6"].astype(np.float64)).astype(np.float32)
+    ip["f_eW"] = (W0b @ ec["G8"].astype(np.float64)).astype(np.float32)                # [128, 128] on the growth features
+    ftab = np.zeros((128, 8), np.float64)
+    ftab[:, 0:3] = W0b @ ec["PA"][nrow:].astype(np.float64)
+    ftab[:, 3:6] = W0b @ ec["QB"][nrow:].astype(np.float64)
+    ftab[:, 6] = W0b @ ec["pb"][nrow:].astype(np.float64)
+    ip["f_tab"] = ftab.astype(np.float32)
     plan["interp"] = ip
     return plan
 
@@ -282,7 +296,10 @@ def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
     post = []
     for i in range(NUM_BLOCKS):
         m, f = plan["merges"][i], plan["flows"][i]
-        H1 = np.concatenate([f["s_W0"], f["t_W0"], f["c1_W0c"]], axis=0)            # [192, cdim]
+        # [192, cdim] first layers of the injector nets + coupling1's c-part, composed with the merge unit's bias-free
+        # last Linear (c = W2 m, interpflow.py:258): linear o linear -> [192, odim/2] acting on m directly
+        H1 = (np.concatenate([f["s_W0"], f["t_W0"], f["c1_W0c"]], axis=0).astype(np.float64)
+              @ m["W2"].astype(np.float64)).astype(np.float32)
         ST4 = np.zeros((6, 128), np.float32)
         ST4[0:3, 0:64] = f["s_W4"]; ST4[3:6, 64:128] = f["t_W4"]
         bST4 = _pad_vec(np.concatenate([f["s_b4"], f["t_b4"]]), 16)
@@ -314,9 +331,9 @@ def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
         b6r[4 * q:4 * q + R] = ip["w_b6"]
     io = {
         "dtab": B.add(dtab), "d_W3": B.add(frag_pack(ip["d_W3"])), "d_b3": B.add(ip["d_b3"]),
-        "d_W6": B.add(frag_pack(ip["d_W6"])), "d_b6": B.add(ip["d_b6"]),
-        "ectab": B.add(_edge_table(ip["ec"])), "ec_w": B.add(_ec_frags(ip["ec"], 8)),
-        "w_W0": B.add(frag_pack(ip["w_W0"])), "w_b0": B.add(ip["w_b0"]),
+        "d_W6": B.add(frag_pack(ip["f_dW"])), "d_b6": B.add(ip["f_b0"]),          # folded: W0a.W6 on d2, b0 + W0a.b6
+        "ectab": B.add(_edge_table(ip["ec"])), "ec_w": B.add(_ec_frags(ip["ec"], 7)),   # growth layers only
+        "w_W0": B.add(frag_pack(ip["f_eW"])), "w_b0": B.add(ip["f_tab"]),           # folded: W0b.Gout, W0b.(edge table)
         "w_W3": B.add(frag_pack(ip["w_W3"])), "w_b3": B.add(ip["w_b3"]),
         "w_W6": B.add(frag_pack(W6r)), "w_b6": B.add(b6r),
     }

@@ -50,7 +50,8 @@ def forward(plan, xyz, idx16, stages=False):
         g, odim = GROWTH[i], FEAT_CHANNELS[i + 1]
         h = edgeconv(plan["units"][i], h, idx16, g, odim // g, odim, max(g, 16))
         m = plan["merges"][i]
-        c = torch.relu(h @ _t(m["W1"]).T + _t(m["b1"])) @ _t(m["W2"]).T
+        mm = torch.relu(h @ _t(m["W1"]).T + _t(m["b1"]))
+        c = mm @ _t(m["W2"]).T
         cs.append(c)
         f = plan["flows"][i]
         s = _lrelu(c @ _t(f["s_W0"]).T, 0.01)
@@ -91,11 +92,22 @@ def forward(plan, xyz, idx16, stages=False):
     nrm = torch.sqrt(((xi - xj) ** 2).sum(-1, keepdim=True))
     d = xi @ _t(ip["d_PA"]).T + xj @ _t(ip["d_QB"]).T + nrm * _t(ip["d_wn"]) + _t(ip["d_b0"])
     d = _lrelu(d, 0.01)
-    d = _lrelu(d @ _t(ip["d_W3"]).T + _t(ip["d_b3"]), 0.01)
-    d = d @ _t(ip["d_W6"]).T + _t(ip["d_b6"])                         # [B,N,8,128]
-    e = edgeconv(ip["ec"], xyz, idx8, 16, 8, 128, 16, pooling=False)    # [B,N,8,128]
-    ctx = torch.cat([d, e], -1)
-    w = _lrelu(ctx @ _t(ip["w_W0"]).T + _t(ip["w_b0"]), 0.01)
+    d2 = _lrelu(d @ _t(ip["d_W3"]).T + _t(ip["d_b3"]), 0.01)                # [B,N,8,64]
+    # growth features of the interp EdgeConv (conv_out is folded into the weight unit's first layer)
+    ec = ip["ec"]
+    P = xyz @ _t(ec["PA"]).T + _t(ec["pb"]); Q = xyz @ _t(ec["QB"]).T
+    E = P.unsqueeze(2) + _gather(Q, idx8)
+    feats = []
+    for t in range(8):
+        y = E[..., 16 * t:16 * (t + 1)]
+        if t >= 1:
+            y = y + torch.cat(feats, dim=-1) @ _t(ec[f"G{t}"]).T
+        feats.append(_lrelu(y, 0.05))
+    feat = torch.cat(feats, dim=-1)                                          # [B,N,8,128]
+    ft = _t(ip["f_tab"])
+    w = _t(ip["f_b0"]) + xi @ ft[:, 0:3].T + xj @ ft[:, 3:6].T + ft[:, 6] \
+        + d2 @ _t(ip["f_dW"]).T + feat @ _t(ip["f_eW"]).T
+    w = _lrelu(w, 0.01)
     w = _lrelu(w @ _t(ip["w_W3"]).T + _t(ip["w_b3"]), 0.01)
     w = w @ _t(ip["w_W6"]).T + _t(ip["w_b6"])                         # [B,N,8,R]
     a = torch.softmax(w, dim=2)                                       # over k
