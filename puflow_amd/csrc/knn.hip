@@ -12,8 +12,9 @@
 //    per-lane sorted top-K in registers, branch-free shifting insert.  Its cost is the insert:
 //    a lane inserts only ~K ln(M/K) times, but SOME lane of the 64 inserts at almost every
 //    candidate, so the wave executes the 5K-op insert ~M times.
-//  * knn2_kernel (default for K <= 16, M >= 256): two sweeps over LDS-staged references remove
-//    that divergence.  Sweep A keeps 32 strided group minima per query (1 op per candidate); the
+//  * knn2_kernel (default for K <= 16, M >= 256): two sweeps over the references remove
+//    that divergence (references are broadcast from registers with v_readlane: no LDS traffic for the
+//    candidates).  Sweep A keeps 32 strided group minima per query (1 op per candidate); the
 //    K-th smallest group minimum tau bounds the K-th neighbour distance (K distinct candidates
 //    are <= tau).  Sweep B appends every candidate with d <= tau to a per-lane LDS list (~22
 //    entries for K = 16: coupon-collector count of hitting K of 32 groups); only those are
@@ -101,46 +102,51 @@ __device__ __forceinline__ void sort16(float (&v)[16]) {
 }
 
 constexpr int KNN2_T = 256;       // queries (threads) per workgroup
-constexpr int KNN2_MC = 2048;     // references staged in LDS per chunk
 constexpr int KNN2_CAP = 64;      // per-lane candidate list capacity (u16 indices)
 
+__device__ __forceinline__ float bcast(float v, int srclane) {      // wave-uniform broadcast through an SGPR
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), srclane));
+}
+
+// References are streamed 64 at a time: lane l loads reference j0 + l (coalesced, no LDS), then every reference is
+// broadcast to the whole wave with v_readlane (an SGPR operand of the distance arithmetic).  LDS holds only the
+// per-lane candidate lists.
 template <int K>
 __global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
                                                       int N, int M, int* __restrict__ idx_out,
                                                       float* __restrict__ dist_out) {
     static_assert(K <= 16, "threshold selection uses two 16-element sorted halves");
-    __shared__ float sx[KNN2_MC], sy[KNN2_MC], sz[KNN2_MC];
     __shared__ unsigned short lst[KNN2_CAP][KNN2_T];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int n = blockIdx.x * KNN2_T + tid;
     const bool live = n < N;
     const float* q = p1 + ((size_t)b * N + (live ? n : N - 1)) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float* __restrict__ r = p2 + (size_t)b * M * 3;
 
-    auto stage = [&](int c0) {               // references [c0, c0 + MC) -> LDS, +inf padding past M
-        __syncthreads();
-        for (int i = tid; i < KNN2_MC; i += KNN2_T) {
-            const int j = c0 + i;
-            const bool in = j < M;
-            sx[i] = in ? r[j * 3 + 0] : __builtin_inff();
-            sy[i] = in ? r[j * 3 + 1] : 0.f;
-            sz[i] = in ? r[j * 3 + 2] : 0.f;
-        }
-        __syncthreads();
+    auto load_ref = [&](int j0, float& cx, float& cy, float& cz) {     // +inf padding past M never wins a minimum
+        const int j = j0 + lane;
+        const bool in = j < M;
+        const int jc = in ? j : M - 1;
+        cx = in ? r[jc * 3 + 0] : __builtin_inff();
+        cy = r[jc * 3 + 1];
+        cz = r[jc * 3 + 2];
     };
 
     // ---- sweep A: 32 strided group minima
     float gm[32];
 #pragma unroll
     for (int g = 0; g < 32; ++g) gm[g] = __builtin_inff();
-    for (int c0 = 0; c0 < M; c0 += KNN2_MC) {
-        stage(c0);
-        const int lim = min(KNN2_MC, ((M - c0 + 31) / 32) * 32);
-        for (int j0 = 0; j0 < lim; j0 += 32) {
+    {
+        float cx, cy, cz;
+        load_ref(0, cx, cy, cz);
+        for (int j0 = 0; j0 < M; j0 += 64) {
+            float nx = cx, ny = cy, nz = cz;
+            if (j0 + 64 < M) load_ref(j0 + 64, nx, ny, nz);          // prefetch the next 64 references
 #pragma unroll
-            for (int g = 0; g < 32; ++g)
-                gm[g] = fminf(gm[g], sqdist(qx, qy, qz, sx[j0 + g], sy[j0 + g], sz[j0 + g]));
+            for (int c = 0; c < 64; ++c)
+                gm[c & 31] = fminf(gm[c & 31], sqdist(qx, qy, qz, bcast(cx, c), bcast(cy, c), bcast(cz, c)));
+            cx = nx; cy = ny; cz = nz;
         }
     }
     // tau = K-th smallest of the 32 group minima: K-th smallest of two sorted halves = max_i min(A[i], B[K-1-i])
@@ -158,15 +164,21 @@ __global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ 
 
     // ---- sweep B: collect every candidate with d <= tau (in index order)
     int cnt = 0;
-    for (int c0 = 0; c0 < M; c0 += KNN2_MC) {
-        if (M > KNN2_MC) stage(c0);          // single-chunk case: LDS still holds the references
-        const int lim = min(KNN2_MC, M - c0);
-        for (int j = 0; j < lim; ++j) {
-            const float d = sqdist(qx, qy, qz, sx[j], sy[j], sz[j]);
-            if (d <= tau) {
-                if (cnt < KNN2_CAP) lst[cnt][tid] = (unsigned short)(c0 + j);
-                ++cnt;
+    {
+        float cx, cy, cz;
+        load_ref(0, cx, cy, cz);
+        for (int j0 = 0; j0 < M; j0 += 64) {
+            float nx = cx, ny = cy, nz = cz;
+            if (j0 + 64 < M) load_ref(j0 + 64, nx, ny, nz);
+#pragma unroll
+            for (int c = 0; c < 64; ++c) {
+                const float d = sqdist(qx, qy, qz, bcast(cx, c), bcast(cy, c), bcast(cz, c));
+                if (d <= tau) {                                       // padding has d = +inf > tau unless tau = +inf (M < 32K.. never)
+                    if (cnt < KNN2_CAP) lst[cnt][tid] = (unsigned short)(j0 + c);
+                    ++cnt;
+                }
             }
+            cx = nx; cy = ny; cz = nz;
         }
     }
 
