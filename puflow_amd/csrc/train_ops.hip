@@ -29,60 +29,122 @@ struct GemmArgs {
     int M, N, K, kchunk;                     // kchunk = K range per blockIdx.z
 };
 
+// Output tile BM x BN per 256-thread workgroup: WAVES_M x WAVES_N waves, each TM x TN MFMA tiles of 16x16; K-step 16.
+// The launcher picks the shape from (M, N): layer GEMMs here are very skinny (N = 8..128 forward, M = 8..128 for dW),
+// so a square tile would waste most of its MFMAs.
+// VEC: both operands are read with float4 loads along their contiguous dimension (requires that dimension's
+// extent and leading stride to be multiples of 4 and 16-byte aligned bases); otherwise scalar guarded loads.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ float As[64][17];
-    __shared__ float Bs[16][65];
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+    __shared__ float As[BM][20];          // [m][k], row stride 20 floats: 16-B aligned rows
+    __shared__ float Bs[16][BN + 4];      // [k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int k_lo = blockIdx.z * g.kchunk;
     const int k_hi = min(g.K, k_lo + g.kchunk);
     const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
-    f4 acc[2][2];
+    f4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = pf_splat(0.f);
+        for (int j = 0; j < TN; ++j) acc[i][j] = pf_splat(0.f);
 
     for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = a_kfast ? (tid >> 4) + 16 * i : (tid & 63);
-            const int k = a_kfast ? (tid & 15) : (tid >> 6) + 4 * i;
-            const int gm = m0 + r, gk = k0 + k;
-            As[r][k] = (gm < g.M && gk < k_hi) ? g.A[gm * g.sam + gk * g.sak] : 0.f;
-            const int n = b_nfast ? (tid & 63) : (tid >> 4) + 16 * i;
-            const int kb = b_nfast ? (tid >> 6) + 4 * i : (tid & 15);
-            const int gn = n0 + n, gkb = k0 + kb;
-            Bs[kb][n] = (gn < g.N && gkb < k_hi) ? g.B[gkb * g.sbk + gn * g.sbn] : 0.f;
+        if (VEC) {
+            for (int v = tid; v < BM * 4; v += 256) {           // A tile: BM x 16 floats = BM*4 float4
+                f4 x = pf_splat(0.f);
+                if (a_kfast) {                                  // float4 = 4 consecutive k of one row
+                    const int r = v >> 2, k = (v & 3) * 4;
+                    const int gm = m0 + r, gk = k0 + k;
+                    if (gm < g.M && gk < k_hi) x = *reinterpret_cast<const f4*>(g.A + gm * g.sam + gk);
+                    *reinterpret_cast<f4*>(&As[r][k]) = x;
+                } else {                                        // float4 = 4 consecutive rows of one k
+                    const int k = v / (BM / 4), r = (v % (BM / 4)) * 4;
+                    const int gm = m0 + r, gk = k0 + k;
+                    if (gm < g.M && gk < k_hi) x = *reinterpret_cast<const f4*>(g.A + gk * g.sak + gm);
+                    As[r][k] = x.x; As[r + 1][k] = x.y; As[r + 2][k] = x.z; As[r + 3][k] = x.w;
+                }
+            }
+            for (int v = tid; v < BN * 4; v += 256) {           // B tile: 16 x BN floats
+                f4 x = pf_splat(0.f);
+                if (b_nfast) {                                  // float4 = 4 consecutive n of one k
+                    const int k = v / (BN / 4), n = (v % (BN / 4)) * 4;
+                    const int gn = n0 + n, gk = k0 + k;
+                    if (gn < g.N && gk < k_hi) x = *reinterpret_cast<const f4*>(g.B + gk * g.sbk + gn);
+                    *reinterpret_cast<f4*>(&Bs[k][n]) = x;
+                } else {                                        // float4 = 4 consecutive k of one n
+                    const int n = v >> 2, k = (v & 3) * 4;
+                    const int gn = n0 + n, gk = k0 + k;
+                    if (gn < g.N && gk < k_hi) x = *reinterpret_cast<const f4*>(g.B + gn * g.sbn + gk);
+                    Bs[k][n] = x.x; Bs[k + 1][n] = x.y; Bs[k + 2][n] = x.z; Bs[k + 3][n] = x.w;
+                }
+            }
+        } else {
+            for (int v = tid; v < BM * 16; v += 256) {
+                const int r = a_kfast ? (v >> 4) : (v % BM);
+                const int k = a_kfast ? (v & 15) : (v / BM);
+                const int gm = m0 + r, gk = k0 + k;
+                As[r][k] = (gm < g.M && gk < k_hi) ? g.A[gm * g.sam + gk * g.sak] : 0.f;
+            }
+            for (int v = tid; v < BN * 16; v += 256) {
+                const int n = b_nfast ? (v % BN) : (v >> 4);
+                const int kb = b_nfast ? (v / BN) : (v & 15);
+                const int gn = n0 + n, gkb = k0 + kb;
+                Bs[kb][n] = (gn < g.N && gkb < k_hi) ? g.B[gkb * g.sbk + gn * g.sbn] : 0.f;
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            float a[2], b[2];
+            float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[wm * 32 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+            for (int i = 0; i < TM; ++i) a[i] = As[(wm * TM + i) * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[kk * 4 + (lane >> 4)][wn * 32 + j * 16 + (lane & 15)];
+            for (int j = 0; j < TN; ++j) b[j] = Bs[kk * 4 + (lane >> 4)][(wn * TN + j) * 16 + (lane & 15)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = pf_mfma(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = pf_mfma(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
     float* C = g.C + (long long)blockIdx.z * g.M * g.ldc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 32 + j * 16 + (lane & 15);
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 32 + i * 16 + 4 * (lane >> 4) + r;
+                const int m = m0 + (wm * TM + i) * 16 + 4 * (lane >> 4) + r;
                 if (m < g.M && n < g.N) C[m * g.ldc + n] = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f);
             }
         }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+void gemm_launch(const GemmArgs& g, int split, bool vec, hipStream_t s) {
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, split);
+    if (vec) hipLaunchKernelGGL((gemm_kernel<WAVES_M, WAVES_N, TM, TN, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<WAVES_M, WAVES_N, TM, TN, false>), grid, dim3(256), 0, s, g);
+}
+
+// tile shape for (M, N): 0 = 128x128, 1..3 = 256 x {16,32,64} (skinny N), 4..6 = {16,32,64} x 256 (skinny M)
+inline int gemm_shape(int M, int N) {
+    if (N <= 16) return 1;
+    if (N <= 32) return 2;
+    if (N <= 64 && M > 64) return 3;
+    if (M <= 16) return 4;
+    if (M <= 32) return 5;
+    if (M <= 64) return 6;
+    return 0;
+}
+inline void gemm_tile_dims(int shape, int& bm, int& bn) {
+    static const int d[7][2] = {{128, 128}, {256, 16}, {256, 32}, {256, 64}, {16, 256}, {32, 256}, {64, 256}};
+    bm = d[shape][0]; bn = d[shape][1];
 }
 
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C,
@@ -133,15 +195,82 @@ __global__ __launch_bounds__(256) void colstat_kernel(const float* __restrict__ 
     }
 }
 
-// out[which][c] = scale * sum_chunks partial   (fixed order)
-__global__ void colstat_final_kernel(const float* __restrict__ partial, int nchunk, int C, int nwhich, float scale,
-                                     float* __restrict__ out) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+// float4 variant for C % 4 == 0: a thread owns 4 consecutive channels, `cgl` (power of two <= 64) channel lanes cover
+// one row segment and 256 / cgl row lanes walk the rows, so every wave-instruction reads whole contiguous rows.
+template <int MODE>
+__global__ __launch_bounds__(256) void colstat4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float slope, long long R, int C, int rows_per, int cgl,
+                                                      float* __restrict__ partial) {
+    __shared__ f4 s0[256], s1[256];
+    const int cl = threadIdx.x % cgl, rl = threadIdx.x / cgl, nrl = 256 / cgl;
+    const int c = (blockIdx.x * cgl + cl) * 4;
+    const long long r_lo = (long long)blockIdx.y * rows_per, r_hi = min(R, r_lo + rows_per);
+    f4 a0 = pf_splat(0.f), a1 = pf_splat(0.f);
+    if (c < C) {
+        f4 mu = pf_splat(0.f), is = pf_splat(0.f), ga = pf_splat(0.f), be = pf_splat(0.f);
+        if (MODE >= 1) mu = *reinterpret_cast<const f4*>(mean + c);
+        if (MODE == 2) {
+            is = *reinterpret_cast<const f4*>(invstd + c);
+            ga = *reinterpret_cast<const f4*>(gamma + c);
+            be = *reinterpret_cast<const f4*>(beta + c);
+        }
+        for (long long r = r_lo + rl; r < r_hi; r += nrl) {
+            const f4 v = *reinterpret_cast<const f4*>(x + r * C + c);
+            if (MODE == 0) a0 += v;
+            else if (MODE == 1) { const f4 d = v - mu; a0 += d * d; }
+            else {
+                const f4 g = *reinterpret_cast<const f4*>(dy + r * C + c);
+                const f4 xh = (v - mu) * is;
+                const f4 pre = xh * ga + be;
+                f4 dz;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dz[i] = g[i] * (pre[i] > 0.f ? 1.f : slope);
+                a0 += dz; a1 += dz * xh;
+            }
+        }
+    }
+    s0[threadIdx.x] = a0; s1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int st = nrl >> 1; st > 0; st >>= 1) {                    // fixed tree over the row lanes
+        if (rl < st) { s0[threadIdx.x] += s0[threadIdx.x + st * cgl]; s1[threadIdx.x] += s1[threadIdx.x + st * cgl]; }
+        __syncthreads();
+    }
+    if (rl == 0 && c < C) {
+        *reinterpret_cast<f4*>(partial + ((long long)blockIdx.y * 2 + 0) * C + c) = s0[cl];
+        if (MODE == 2) *reinterpret_cast<f4*>(partial + ((long long)blockIdx.y * 2 + 1) * C + c) = s1[cl];
+    }
+}
+
+template <int MODE>
+void colstat_launch(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, float slope, long long R, int C, int nchunk, int rows_per, float* partial, hipStream_t s) {
+    if (C % 4 == 0) {
+        int cgl = 1;
+        while (cgl < C / 4 && cgl < 64) cgl <<= 1;
+        hipLaunchKernelGGL(colstat4_kernel<MODE>, dim3((C / 4 + cgl - 1) / cgl, nchunk), dim3(256), 0, s, x, dy, mean, invstd, gamma,
+                           beta, slope, R, C, rows_per, cgl, partial);
+    } else {
+        hipLaunchKernelGGL(colstat_kernel<MODE>, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, x, dy, mean, invstd, gamma, beta,
+                           slope, R, C, rows_per, partial);
+    }
+}
+
+// out[which][c] = scale * sum_chunks partial   (fixed order: 4 interleaved chunk lanes, then a fixed tree)
+__global__ __launch_bounds__(256) void colstat_final_kernel(const float* __restrict__ partial, int nchunk, int C, int nwhich,
+                                                           float scale, float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    const int l = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
     for (int w = 0; w < nwhich; ++w) {
         float s = 0.f;
-        for (int k = 0; k < nchunk; ++k) s += partial[((long long)k * 2 + w) * C + c];
-        out[w * C + c] = s * scale;
+        if (c < C)
+            for (int k = part; k < nchunk; k += 4) s += partial[((long long)k * 2 + w) * C + c];
+        sh[part][l] = s;
+        __syncthreads();
+        if (part == 0 && c < C) out[w * C + c] = ((sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l])) * scale;
+        __syncthreads();
     }
 }
 
@@ -333,9 +462,20 @@ inline unsigned grid_for(long long total) {
 
 // C[M,N] = A(M,K) B(K,N) (+ bias[N]); generic element strides.  ws: split-K slabs (>= pf_gemm_ws_floats).
 extern "C" long long pf_gemm_ws_floats(int M, int N, int K) {
-    const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    int bm, bn;
+    gemm_tile_dims(gemm_shape(M, N), bm, bn);
+    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    // split-K when the output has too few tiles to fill 256 CUs (dW GEMMs: tiny M x N, K = rows up to 131072):
+    // aim at ~1024 workgroups, K chunks of at least 128, slabs capped at 16 M floats
     int split = 1;
-    if (tiles < 256 && K >= 2048) { split = (int)((512 + tiles - 1) / tiles); if (split > K / 512) split = K / 512; if (split > 128) split = 128; }
+    if (tiles < 512 && K >= 1024) {
+        long long sp = (1024 + tiles - 1) / tiles;
+        if (sp > K / 128) sp = K / 128;
+        const long long cap = (16ll << 20) / ((long long)M * N);
+        if (sp > cap) sp = cap;
+        if (sp > 1024) sp = 1024;
+        split = sp < 1 ? 1 : (int)sp;
+    }
     return split > 1 ? (long long)split * M * N : 0;
 }
 
@@ -351,7 +491,20 @@ extern "C" int pf_gemm(const float* A, long long sam, long long sak, const float
     GemmArgs g{A, sam, sak, B, sbk, sbn, use_ws ? ws : C, use_ws ? (long long)N : ldc, use_ws ? nullptr : bias, M, N, K, 0};
     g.kchunk = ((K + split - 1) / split + 15) / 16 * 16;
     split = (K + g.kchunk - 1) / g.kchunk;
-    hipLaunchKernelGGL(gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, split), dim3(256), 0, s, g);
+    // float4 path: the contiguous dimension of each operand must be 4-aligned in extent, stride and base
+    auto al16 = [](const void* p) { return (reinterpret_cast<unsigned long long>(p) & 15ull) == 0; };
+    const bool va = (sak == 1) ? (K % 4 == 0 && sam % 4 == 0 && g.kchunk % 4 == 0) : (sam == 1 && M % 4 == 0 && sak % 4 == 0);
+    const bool vb = (sbn == 1) ? (N % 4 == 0 && sbk % 4 == 0) : (sbk == 1 && K % 4 == 0 && sbn % 4 == 0);
+    const bool vec = va && vb && al16(A) && al16(B);
+    switch (gemm_shape(M, N)) {
+        case 0: gemm_launch<2, 2, 4, 4>(g, split, vec, s); break;
+        case 1: gemm_launch<4, 1, 4, 1>(g, split, vec, s); break;
+        case 2: gemm_launch<4, 1, 4, 2>(g, split, vec, s); break;
+        case 3: gemm_launch<4, 1, 4, 4>(g, split, vec, s); break;
+        case 4: gemm_launch<1, 4, 1, 4>(g, split, vec, s); break;
+        case 5: gemm_launch<1, 4, 2, 4>(g, split, vec, s); break;
+        default: gemm_launch<1, 4, 4, 4>(g, split, vec, s); break;
+    }
     if (use_ws)
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, s, ws, C, bias, M,
                            N, ldc, split);
@@ -372,11 +525,11 @@ extern "C" int pf_bn_lrelu_fwd(const float* x, long long R, int C, const float* 
     const int rows_per = (int)((R + nchunk - 1) / nchunk);
     float* partial = ws;
     float* var_b = ws + (long long)2 * nchunk * C;
-    dim3 grid((C + 63) / 64, nchunk), gc((C + 63) / 64);
-    hipLaunchKernelGGL(colstat_kernel<0>, grid, dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, R, C, rows_per, partial);
-    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(64), 0, s, partial, nchunk, C, 1, 1.0f / (float)R, save);
-    hipLaunchKernelGGL(colstat_kernel<1>, grid, dim3(256), 0, s, x, nullptr, save, nullptr, nullptr, nullptr, 0.f, R, C, rows_per, partial);
-    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(64), 0, s, partial, nchunk, C, 1, 1.0f / (float)R, var_b);
+    dim3 gc((C + 63) / 64);
+    colstat_launch<0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, R, C, nchunk, rows_per, partial, s);
+    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(256), 0, s, partial, nchunk, C, 1, 1.0f / (float)R, save);
+    colstat_launch<1>(x, nullptr, save, nullptr, nullptr, nullptr, 0.f, R, C, nchunk, rows_per, partial, s);
+    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(256), 0, s, partial, nchunk, C, 1, 1.0f / (float)R, var_b);
     hipLaunchKernelGGL(bn_finish_kernel, gc, dim3(64), 0, s, var_b, C, eps, momentum, (float)R / (float)(R - 1), save, save + C,
                        run_mean, run_var);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, save, save + C, gamma, beta, slope, R * C, C, y);
@@ -394,12 +547,12 @@ extern "C" int pf_bn_lrelu_bwd(const float* x, const float* dy, long long R, int
     const int rows_per = (int)((R + nchunk - 1) / nchunk);
     float* partial = ws;
     float* sums = ws + (long long)2 * nchunk * C;          // [2][C]: sum dz, sum dz*xhat
-    dim3 grid((C + 63) / 64, nchunk), gc((C + 63) / 64);
-    hipLaunchKernelGGL(colstat_kernel<2>, grid, dim3(256), 0, s, x, dy, save, save + C, gamma, beta, slope, R, C, rows_per, partial);
-    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(64), 0, s, partial, nchunk, C, 2, 1.0f, sums);
+    dim3 gc((C + 63) / 64);
+    colstat_launch<2>(x, dy, save, save + C, gamma, beta, slope, R, C, nchunk, rows_per, partial, s);
+    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(256), 0, s, partial, nchunk, C, 2, 1.0f, sums);
     hipMemcpyAsync(dbeta, sums, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(dgamma, sums + C, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
-    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(64), 0, s, partial, nchunk, C, 2, 1.0f / (float)R, sums);
+    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(256), 0, s, partial, nchunk, C, 2, 1.0f / (float)R, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, dy, save, save + C, gamma, beta, sums, slope,
                        R * C, C, dx);
     return pf_last_launch_status();
@@ -412,9 +565,8 @@ extern "C" int pf_colsum(const float* g, long long R, int C, float* out, float* 
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = pf_bn_chunks(R);
     const int rows_per = (int)((R + nchunk - 1) / nchunk);
-    hipLaunchKernelGGL(colstat_kernel<0>, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, g, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       0.f, R, C, rows_per, ws);
-    hipLaunchKernelGGL(colstat_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nchunk, C, 1, 1.0f, out);
+    colstat_launch<0>(g, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, R, C, nchunk, rows_per, ws, s);
+    hipLaunchKernelGGL(colstat_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, nchunk, C, 1, 1.0f, out);
     return pf_last_launch_status();
 }
 

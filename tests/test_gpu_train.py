@@ -21,7 +21,9 @@ def _close(a, b, rtol=2e-4, atol=1e-6):
 
 
 @pytest.mark.parametrize("R,Cin,Cout,bias", [(1000, 9, 8, True), (4096, 96, 16, True), (333, 130, 64, False),
-                                             (70000, 40, 32, True), (64, 3, 3, False)])
+                                             (70000, 40, 32, True), (64, 3, 3, False), (5000, 512, 128, True),
+                                             (3000, 256, 32, True), (2048, 64, 64, True), (999, 128, 3, True),
+                                             (4100, 33, 8, True), (131072, 10, 64, True)])
 def test_linear_fwd_bwd(R, Cin, Cout, bias):
     from puflow_amd.train_ops import linear
     g = torch.Generator().manual_seed(R)
@@ -33,7 +35,7 @@ def test_linear_fwd_bwd(R, Cin, Cout, bias):
     xd, Wd = x.detach().to(DEV).requires_grad_(True), W.detach().to(DEV).requires_grad_(True)
     bd = b.detach().to(DEV).requires_grad_(True) if bias else None
     yd = linear(xd, Wd, bd); yd.backward(gy.to(DEV))
-    _close(yd, y, atol=1e-5); _close(xd.grad, x.grad, atol=1e-5)
+    _close(yd, y, atol=2e-6 * float(y.abs().max()) + 1e-6); _close(xd.grad, x.grad, atol=2e-6 * float(x.grad.abs().max()) + 1e-6)
     _close(Wd.grad, W.grad, rtol=1e-3, atol=1e-3 * float(W.grad.abs().max()))       # K = R long reductions
     if bias:
         _close(bd.grad, b.grad, rtol=1e-3, atol=1e-3 * float(b.grad.abs().max()))
@@ -56,7 +58,9 @@ def test_bn_lrelu_fwd_bwd(R, C, slope):
     yd = BnLreluFn.apply(xd, gd, bd, rmd, rvd, slope, 1e-5, 0.1)
     yd.backward(gy.to(DEV))
     _close(yd, y, atol=1e-5); _close(rmd, rm, atol=1e-6); _close(rvd, rv, rtol=1e-5)
-    _close(xd.grad, x.grad, rtol=1e-3, atol=1e-5)
+    # LeakyReLU' is discontinuous at 0: an element whose pre-activation is within rounding of 0 may take the other branch
+    bad = ~torch.isclose(xd.grad.cpu(), x.grad, rtol=1e-3, atol=1e-5)
+    assert int(bad.sum()) <= max(1, R * C // 1_000_000)
     _close(gd.grad, ga.grad, rtol=1e-3, atol=1e-3 * float(ga.grad.abs().max()))
     _close(bd.grad, be.grad, rtol=1e-3, atol=1e-3 * float(be.grad.abs().max()))
 
