@@ -321,8 +321,10 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
                 case 1: return launch3<1, 8>(a, s);
                 case 2: return launch3<1, 16>(a, s);
                 case 3: return launch3<2, 16>(a, s);
-                case 8: return launch3<1, 16, 1>(a, s);      // timing only: no gathers (wrong results)
-                case 9: return launch3<1, 16, 2>(a, s);      // timing only: no MFMAs (wrong results)
+#ifdef PF_TUNING_VARIANTS                                     // ablation builds only (tools/tune_edgeconv.py --ablate): wrong results
+                case 8: return launch3<1, 16, 1>(a, s);      // no gathers
+                case 9: return launch3<1, 16, 2>(a, s);      // no MFMAs
+#endif
                 default: return PF_ERR_UNSUPPORTED;
             }
         default: return PF_ERR_UNSUPPORTED;

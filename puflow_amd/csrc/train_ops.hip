@@ -147,15 +147,23 @@ inline void gemm_tile_dims(int shape, int& bm, int& bn) {
     bm = d[shape][0]; bn = d[shape][1];
 }
 
+// C = sum over split-K slabs (+ bias): 64 consecutive outputs x 4 slab lanes per workgroup, fixed combine order
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C,
                                                          const float* __restrict__ bias, int M, int N, long long ldc,
                                                          int nslab) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)M * N) return;
-    const int m = (int)(t / N), n = (int)(t % N);
-    float s = bias ? bias[n] : 0.f;
-    for (int z = 0; z < nslab; ++z) s += slabs[((long long)z * M + m) * N + n];
-    C[m * ldc + n] = s;
+    __shared__ float sh[4][64];
+    const int l = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const long long t = (long long)blockIdx.x * 64 + l;
+    const long long MN = (long long)M * N;
+    float s = 0.f;
+    if (t < MN)
+        for (int z = part; z < nslab; z += 4) s += slabs[(long long)z * MN + t];
+    sh[part][l] = s;
+    __syncthreads();
+    if (part == 0 && t < MN) {
+        const int m = (int)(t / N), n = (int)(t % N);
+        C[m * ldc + n] = ((sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l])) + (bias ? bias[n] : 0.f);
+    }
 }
 
 // ----------------------------------------------------------------------------- column statistics
@@ -473,7 +481,7 @@ extern "C" long long pf_gemm_ws_floats(int M, int N, int K) {
         if (sp > K / 128) sp = K / 128;
         const long long cap = (16ll << 20) / ((long long)M * N);
         if (sp > cap) sp = cap;
-        if (sp > 1024) sp = 1024;
+        if (sp > 256) sp = 256;
         split = sp < 1 ? 1 : (int)sp;
     }
     return split > 1 ? (long long)split * M * N : 0;
@@ -506,7 +514,7 @@ extern "C" int pf_gemm(const float* A, long long sam, long long sak, const float
         default: gemm_launch<1, 4, 4, 4>(g, split, vec, s); break;
     }
     if (use_ws)
-        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, s, ws, C, bias, M,
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(((long long)M * N + 63) / 64)), dim3(256), 0, s, ws, C, bias, M,
                            N, ldc, split);
     return pf_last_launch_status();
 }

@@ -140,6 +140,7 @@ class _Engine:
         # matrix pipe, fp32-class accuracy (measured 1.1e-6 from the exact kernel, same 1e-5 parity bar), 1.4x faster;
         # "f32" = v_mfma_f32_16x16x4_f32, bit-exact fp32 fma chain (PF_EC_MODE=f32)
         self.ec_mode = os.environ.get("PF_EC_MODE", "bf16x3")
+        self.ec3_variant = int(os.environ.get("PF_EC3_VARIANT", "0"))   # launch shape of edgeconv3_kernel (tuning knob)
         self.post = [_lib.offsets(o) for o in pk["post"]]
         self.flow = pk["flow"]
         self.interp_off = _lib.offsets(pk["interp"])
@@ -173,8 +174,8 @@ class _Engine:
             src = xyz.data_ptr() if u == 0 else pq.data_ptr()
             tab = self._p(self.ec_tab0) if u == 0 else None
             if u >= 2 and self.ec_mode == "bf16x3":
-                _lib.check(self.lib.pf_edgeconv(3, src, None, idx16.data_ptr(), self._p(self.ec3_w[u]), h.data_ptr(),
-                                                B, N, s), f"pf_edgeconv3[{u}]")
+                _lib.check(self.lib.pf_edgeconv_tuned(3, self.ec3_variant, src, None, idx16.data_ptr(), self._p(self.ec3_w[u]),
+                                                      h.data_ptr(), B, N, s), f"pf_edgeconv3[{u}]")
             else:
                 _lib.check(self.lib.pf_edgeconv(_EC_CFG[u], src, tab, idx16.data_ptr(), self._p(self.ec_w[u]),
                                                 h.data_ptr(), B, N, s), f"pf_edgeconv[{u}]")
@@ -240,8 +241,8 @@ class _Engine:
                 src = xyz.data_ptr() if u == 0 else pq.data_ptr()
                 tab = self._p(self.ec_tab0) if u == 0 else None
                 if u >= 2 and self.ec_mode == "bf16x3":
-                    timed(f"edgeconv{u}", lambda: _lib.check(self.lib.pf_edgeconv(
-                        3, src, None, idx16.data_ptr(), self._p(self.ec3_w[u]), h.data_ptr(), B, N, s)))
+                    timed(f"edgeconv{u}", lambda: _lib.check(self.lib.pf_edgeconv_tuned(
+                        3, self.ec3_variant, src, None, idx16.data_ptr(), self._p(self.ec3_w[u]), h.data_ptr(), B, N, s)))
                 else:
                     timed(f"edgeconv{u}", lambda: _lib.check(self.lib.pf_edgeconv(
                         _EC_CFG[u], src, tab, idx16.data_ptr(), self._p(self.ec_w[u]), h.data_ptr(), B, N, s)))
