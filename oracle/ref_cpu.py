@@ -277,6 +277,7 @@ class TrainState:
 
     def __init__(self):
         self.bn_updates: Dict[str, Tensor] = {}
+        self.bn_batch: Dict[str, Tuple[Tensor, Tensor]] = {}      # raw batch (mean, biased variance) per BN
         self.actnorm_init: Dict[str, Tensor] = {}
 
 
@@ -287,6 +288,7 @@ def _bn_train(sd: SD, pfx: str, y: Tensor, ts: TrainState) -> Tensor:
     with torch.no_grad():
         mean = y.mean(dim=(0, 2, 3))
         var_u = y.var(dim=(0, 2, 3), unbiased=True)
+        ts.bn_batch[pfx] = (mean, y.var(dim=(0, 2, 3), unbiased=False))
         ts.bn_updates[pfx + ".running_mean"] = 0.9 * sd[pfx + ".running_mean"] + 0.1 * mean
         ts.bn_updates[pfx + ".running_var"] = 0.9 * sd[pfx + ".running_var"] + 0.1 * var_u
         ts.bn_updates[pfx + ".num_batches_tracked"] = sd[pfx + ".num_batches_tracked"] + 1
@@ -395,3 +397,16 @@ def forward_train(sd: SD, xyz: Tensor, upratio: int = 4, actnorm_init: bool = Fa
         logs, bias = an[i]
         u = (u - bias) * torch.exp(-logs)
     return u, logp, ts
+
+
+def calibrate(sd: SD, xyz: Tensor, upratio: int = 4) -> SD:
+    """Make a synthetic "trained-style" state_dict self-consistent: BN running stats := the batch statistics
+    of `xyz` (so eval == train on that batch), ActNorm := its data-dependent init.  Test infrastructure."""
+    out = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        _, _, ts = forward_train(out, xyz, upratio, actnorm_init=True)
+    for pfx, (m, v) in ts.bn_batch.items():
+        out[pfx + ".running_mean"], out[pfx + ".running_var"] = m.clone(), v.clone()
+    for k, v in ts.actnorm_init.items():
+        out[k] = v.clone()
+    return out

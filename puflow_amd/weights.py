@@ -90,9 +90,49 @@ def state_dict_spec() -> List[Tuple[str, tuple, str]]:
     return spec
 
 
-def synth_state_dict(seed: int = 2021) -> "OrderedDict[str, torch.Tensor]":
+def synth_state_dict(seed: int = 2021, style: str = "unit") -> "OrderedDict[str, torch.Tensor]":
+    """style "unit": fan-in scaled weights, O(1) activations everywhere (default: benchmarks, most tests).
+    style "trained": the wide dynamic range of the reference's pretrained checkpoints (weight std ~0.17
+    independent of fan-in with a heavy tail, BN gamma ~N(1, 0.6), BN beta ~N(-0.3, 0.35): features reach
+    |h| ~ 50, BN variances ~1e3) - BN running statistics and ActNorm must then be calibrated on data
+    (tests do it with the oracle's train-mode forward) to obtain a self-consistent model."""
     rng = np.random.Generator(np.random.PCG64(seed))
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    if style == "trained":
+        for key, shape, kind in state_dict_spec():
+            if kind == "w":
+                fan_in = int(np.prod(shape[1:]))
+                gain = 2.5 if ("conv_out" in key or "feat_convs" in key) else 1.0     # un-normalised layers grow the range
+                v = rng.standard_t(5, shape) * (gain * 0.77 / np.sqrt(fan_in))         # heavy tail (t5: std 1.29)
+            elif kind == "w_last":                                       # zero-init in the reference: stays small when trained
+                v = rng.standard_normal(shape) * 0.002
+            elif kind == "b":
+                v = rng.standard_normal(shape) * 0.2 - (0.3 if ".1.bias" in key or ".4.bias" in key else 0.0)
+            elif kind == "b_last":
+                v = rng.standard_normal(shape) * 0.05
+            elif kind == "bn_w":
+                v = np.clip(rng.standard_normal(shape) * 0.5 + 1.04, 0.05, None)
+            elif kind == "bn_m":
+                v = np.zeros(shape)                                      # calibrated later
+            elif kind == "bn_v":
+                v = np.ones(shape)
+            elif kind == "an_logs":
+                v = rng.standard_normal(shape) * 0.3 + 0.3
+            elif kind == "an_bias":
+                v = rng.standard_normal(shape) * 0.06
+            elif kind == "inv1x1":
+                q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+                v = q * rng.uniform(0.7, 1.4, (1, 3))
+            elif kind == "rev":
+                sd[key] = torch.tensor([2, 1, 0], dtype=torch.int64)
+                continue
+            elif kind == "nbt":
+                sd[key] = torch.tensor(100, dtype=torch.int64)
+                continue
+            else:
+                raise KeyError(kind)
+            sd[key] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+        return sd
     for key, shape, kind in state_dict_spec():
         if kind == "w":
             fan_in = int(np.prod(shape[1:]))

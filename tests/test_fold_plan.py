@@ -32,3 +32,14 @@ def test_frag_pack_roundtrip_and_layout():
     # lane l, block (ob,cb), r  <->  W[ob*16 + (l&15)][cb*16 + 4*(l>>4) + r]
     l, ob, cb, r = 37, 1, 2, 3
     assert F[ob, cb, l, r] == W[ob * 16 + (l & 15), cb * 16 + 4 * (l >> 4) + r]
+
+
+def test_folded_plan_trained_style_weights():
+    """Same proof in the wide dynamic range of a trained checkpoint (|h| ~ 300): the folds stay within tolerance."""
+    sd = O.calibrate(synth_state_dict(3, style="trained"), synth_patches(4, 256, seed=1))
+    xyz = synth_patches(2, 256, seed=2)
+    st = O.forward(sd, xyz, 4, stages=True)
+    em = E.forward(fold_state_dict(sd), xyz, st["idx16"], stages=True)
+    assert (em["x"] - st["x"]).abs().max() < 1e-5
+    assert ((em["ldj"] - st["ldj"]).abs() / st["ldj"].abs()).max() < 1e-5
+    assert (em["cs"][5] - st["cs"][5]).abs().max() < 1e-5 * float(st["cs"][5].abs().max())

@@ -146,6 +146,28 @@ def test_edgeconv_arithmetic_modes(lib):
     assert (outs["f32"]["cs"][5] - outs["bf16x3"]["cs"][5]).abs().max() < 5e-6
 
 
+@pytest.mark.parametrize("seed", [3, 5])
+def test_trained_style_dynamic_range(lib, seed):
+    """Weights with the wide dynamic range of the reference's pretrained checkpoints (features up to |h| ~ 300,
+    BN variances ~1e3; statistics taken from pretrain/puflow-x4-pu1k.pt), calibrated on data by the oracle:
+    xyz still within 1e-5 absolute, log-det within 1e-5 relative, features within 1e-5 of their range - in both
+    EdgeConv arithmetic modes."""
+    sd = O.calibrate(synth_state_dict(seed, style="trained"), synth_patches(4, 256, seed=1))
+    xyz = synth_patches(2, 256, seed=2)
+    ref = O.forward(sd, xyz, 4, stages=True)
+    assert max(h.abs().max() for h in ref["hs"]) > 100          # the regime this test is about
+    net = _net(sd)
+    for mode in ("bf16x3", "f32"):
+        net._engine(4).ec_mode = mode
+        st = net.forward_stages(xyz.to(DEV), 4)
+        assert torch.equal(st["idx16"].cpu().long(), ref["idx16"])
+        assert (st["x"].cpu() - ref["x"]).abs().max() < 1e-5
+        assert ((st["ldj"].cpu() - ref["ldj"]).abs() / ref["ldj"].abs()).max() < 1e-5
+        assert (st["z"].cpu() - ref["z"]).abs().max() < 1e-5 * max(1.0, float(ref["z"].abs().max()))
+        for i in range(6):
+            assert (st["cs"][i].cpu() - ref["cs"][i]).abs().max() < 1e-5 * max(1.0, float(ref["cs"][i].abs().max())), (mode, i)
+
+
 @pytest.mark.parametrize("R", [2, 3])
 def test_other_upsampling_ratios(lib, R):
     sd = synth_state_dict(6)
