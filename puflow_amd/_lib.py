@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpuflow_hip.so")
+LIB_PATH = os.environ.get("PF_LIB_PATH", os.path.join(_HERE, "libpuflow_hip.so"))   # override: tuning builds only
 _lib = None
 
 # name -> (restype, argtypes); must list every symbol declared in include/puflow_hip.h

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
         PfPair feat[P][NCONV];
 #pragma unroll
         for (int p = 0; p < P; ++p)
-            feat[p][0] = pf_pair(pf_split3(pf_lrelu(ini[0][p][0], 0.05f)), pf_split3(pf_lrelu(ini[0][p][1], 0.05f)));
+            feat[p][0] = pf_pair(pf_lrelu(ini[0][p][0], 0.05f), pf_lrelu(ini[0][p][1], 0.05f));
         pf_static_for<1, NCONV>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             load_init(G * (t + 1), ini[(t + 1) & 1]);                 // next growth layer, or conv_out chunk 0
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
             if constexpr (DBG != 2) pf_mm3<2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, 0, acc, 0);
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                feat[p][t] = pf_pair(pf_split3(pf_lrelu(acc[p][0], 0.05f)), pf_split3(pf_lrelu(acc[p][1], 0.05f)));
+                feat[p][t] = pf_pair(pf_lrelu(acc[p][0], 0.05f), pf_lrelu(acc[p][1], 0.05f));
         });
         constexpr int FO = 2 * (NCONV * (NCONV - 1) / 2);
         f4 sel[P];
@@ -290,7 +290,6 @@ int launch(const EcArgs& a, hipStream_t s, int variant) {
         case 1: return launch_v<GB, NCONV, ODIM, C3, 2, 4>(a, s);
         case 2: return launch_v<GB, NCONV, ODIM, C3, 1, 8>(a, s);
         case 3: return launch_v<GB, NCONV, ODIM, C3, 1, 16>(a, s);
-        case 4: return launch_v<GB, NCONV, ODIM, C3, 2, 16>(a, s);
         default: return PF_ERR_UNSUPPORTED;
     }
 }
@@ -320,7 +319,6 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
                 case 0: return launch3<2, 8>(a, s);
                 case 1: return launch3<1, 8>(a, s);
                 case 2: return launch3<1, 16>(a, s);
-                case 3: return launch3<2, 16>(a, s);
 #ifdef PF_TUNING_VARIANTS                                     // ablation builds only (tools/tune_edgeconv.py --ablate): wrong results
                 case 8: return launch3<1, 16, 1>(a, s);      // no gathers
                 case 9: return launch3<1, 16, 2>(a, s);      // no MFMAs

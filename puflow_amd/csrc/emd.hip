@@ -38,15 +38,13 @@ struct EmdArgs {
     float eps;
 };
 
-struct Tri { float best, better; int idx; };
-
-__device__ __forceinline__ Tri tri_merge(const Tri& a, const Tri& b) {
-    Tri r;
-    const bool tb = (b.best > a.best) || (b.best == a.best && b.idx < a.idx);
-    r.best = tb ? b.best : a.best;
-    r.idx = tb ? b.idx : a.idx;
-    r.better = fmaxf(fminf(a.best, b.best), fmaxf(a.better, b.better));
-    return r;
+// merge of two (best, second-best, argbest) triples; kept as scalars (a struct version went through scratch)
+__device__ __forceinline__ void tri_merge(float& best, float& better, int& idx, float obest, float obetter, int oidx) {
+    const bool tb = (obest > best) || (obest == best && oidx < idx);
+    const float nbetter = fmaxf(fminf(best, obest), fmaxf(better, obetter));
+    best = tb ? obest : best;
+    idx = tb ? oidx : idx;
+    better = nbetter;
 }
 
 template <bool IN_LDS>
@@ -91,26 +89,24 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(EmdArgs a) {
         for (int u = wave; u < U; u += EMD_THREADS / 64) {
             const int i = ulist[u];
             const float x1 = x[i * 3 + 0], y1 = x[i * 3 + 1], z1 = x[i * 3 + 2];
-            Tri t{-1e9f, -1e9f, 0x7fffffff};
+            float tbest = -1e9f, tbetter = -1e9f;
+            int tidx = 0x7fffffff;
             for (int k = lane; k < n; k += 64) {
                 const float dx = __fsub_rn(yy[k * 3 + 0], x1), dy = __fsub_rn(yy[k * 3 + 1], y1),
                             dz = __fsub_rn(yy[k * 3 + 2], z1);
                 const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
                 const float v = (float)((3.0 - (double)sqrtf(d2)) - (double)price[k]);
-                if (v > t.best) { t.better = t.best; t.best = v; t.idx = k; }
-                else if (v > t.better) t.better = v;
+                if (v > tbest) { tbetter = tbest; tbest = v; tidx = k; }
+                else if (v > tbetter) tbetter = v;
             }
 #pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                Tri o;
-                o.best = __shfl_xor(t.best, m); o.better = __shfl_xor(t.better, m); o.idx = __shfl_xor(t.idx, m);
-                t = tri_merge(t, o);
-            }
+            for (int m = 1; m < 64; m <<= 1)
+                tri_merge(tbest, tbetter, tidx, __shfl_xor(tbest, m), __shfl_xor(tbetter, m), __shfl_xor(tidx, m));
             if (lane == 0) {
-                const float inc = __fadd_rn(__fsub_rn(t.best, t.better), a.eps);
-                bid[i] = t.idx;
+                const float inc = __fadd_rn(__fsub_rn(tbest, tbetter), a.eps);
+                bid[i] = tidx;
                 bid_inc[i] = inc;
-                atomicMax(&maxb[t.idx], __float_as_uint(inc));
+                atomicMax(&maxb[tidx], __float_as_uint(inc));
             }
         }
         __syncthreads();

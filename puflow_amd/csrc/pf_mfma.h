@@ -108,7 +108,7 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
-struct PfSplit { unsigned h0, h1, m0, m1, l0, l1; };     // 4 values -> 3 x (4 bf16 in 2 dwords)
+typedef unsigned int u3 __attribute__((ext_vector_type(3)));
 
 __device__ __forceinline__ unsigned pf_cvt_pk(float a, float b) {
     bf2 t = {(__bf16)a, (__bf16)b};
@@ -117,28 +117,25 @@ __device__ __forceinline__ unsigned pf_cvt_pk(float a, float b) {
 __device__ __forceinline__ float pf_lo16(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float pf_hi16(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
-__device__ __forceinline__ void pf_split_pair(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
-    ph = pf_cvt_pk(a, b);
+// two fp32 values -> packed (hi, mid, lo) bf16 pairs.  Everything stays an SSA value (ext vectors, no structs with
+// addressable members): an earlier struct-based version made hipcc bounce the pieces through scratch / LDS.
+__device__ __forceinline__ u3 pf_split_pair(float a, float b) {
+    const unsigned ph = pf_cvt_pk(a, b);
     const float ra = a - pf_lo16(ph), rb = b - pf_hi16(ph);
-    pm = pf_cvt_pk(ra, rb);
+    const unsigned pm = pf_cvt_pk(ra, rb);
     const float sa = ra - pf_lo16(pm), sb = rb - pf_hi16(pm);
-    pl = pf_cvt_pk(sa, sb);
+    return (u3){ph, pm, pf_cvt_pk(sa, sb)};
 }
 
-__device__ __forceinline__ PfSplit pf_split3(f4 v) {
-    PfSplit s;
-    pf_split_pair(v.x, v.y, s.h0, s.m0, s.l0);
-    pf_split_pair(v.z, v.w, s.h1, s.m1, s.l1);
-    return s;
-}
-
-// B operands (hi / mid / lo) of one block pair
+// B operands (hi / mid / lo) of one block pair (two 16-channel blocks b0, b1 = 8 k-slots per lane)
 struct PfPair { bf8 h, m, l; };
-__device__ __forceinline__ PfPair pf_pair(const PfSplit& a, const PfSplit& b) {
+__device__ __forceinline__ PfPair pf_pair(f4 b0, f4 b1) {
+    const u3 s0 = pf_split_pair(b0.x, b0.y), s1 = pf_split_pair(b0.z, b0.w);
+    const u3 s2 = pf_split_pair(b1.x, b1.y), s3 = pf_split_pair(b1.z, b1.w);
     PfPair p;
-    p.h = __builtin_bit_cast(bf8, (u4){a.h0, a.h1, b.h0, b.h1});
-    p.m = __builtin_bit_cast(bf8, (u4){a.m0, a.m1, b.m0, b.m1});
-    p.l = __builtin_bit_cast(bf8, (u4){a.l0, a.l1, b.l0, b.l1});
+    p.h = __builtin_bit_cast(bf8, (u4){s0.x, s1.x, s2.x, s3.x});
+    p.m = __builtin_bit_cast(bf8, (u4){s0.y, s1.y, s2.y, s3.y});
+    p.l = __builtin_bit_cast(bf8, (u4){s0.z, s1.z, s2.z, s3.z});
     return p;
 }
 
