@@ -118,7 +118,7 @@ extern "C" int pf_knn_large(const float* ref, const float* query, int B, int N, 
     while (np < N) np <<= 1;
     const size_t lds = (size_t)np * 8;
     if (lds > 64 * 1024)        // idempotent opt-in to > 64 KiB of dynamic LDS (no state kept on our side)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(knn_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             KS_NMAX * 8);
     hipLaunchKernelGGL(knn_sort_kernel, dim3(M, B), dim3(KS_T), lds, (hipStream_t)stream, ref, query, N, M, K, np, idx_out,
                        dist_out);

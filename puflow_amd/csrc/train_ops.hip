@@ -558,8 +558,8 @@ extern "C" int pf_bn_lrelu_bwd(const float* x, const float* dy, long long R, int
     dim3 gc((C + 63) / 64);
     colstat_launch<2>(x, dy, save, save + C, gamma, beta, slope, R, C, nchunk, rows_per, partial, s);
     hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(256), 0, s, partial, nchunk, C, 2, 1.0f, sums);
-    hipMemcpyAsync(dbeta, sums, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
-    hipMemcpyAsync(dgamma, sums + C, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(dbeta, sums, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(dgamma, sums + C, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(256), 0, s, partial, nchunk, C, 2, 1.0f / (float)R, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, dy, save, save + C, gamma, beta, sums, slope,
                        R * C, C, dx);

@@ -205,6 +205,22 @@ def test_reference_method_surface(lib):
     assert torch.equal(g.cpu(), O.knn_gather(xyz, ref["idx16"]))
 
 
+@pytest.mark.parametrize("B,N", [(1, 4096), (7, 333), (64, 256)])
+def test_other_batch_shapes(lib, B, N):
+    """Shapes off the benchmark point: one big patch, ragged sizes (no multiple of any tile), the CLI's 64 x 256."""
+    sd = synth_state_dict(31)
+    xyz = synth_patches(B, N, seed=B + N)
+    net = _net(sd)
+    x, logp = net(xyz.to(DEV), 4)
+    nb = min(B, 3)
+    ref = O.forward(sd, xyz[:nb], 4, stages=True)
+    assert (x[:nb].cpu() - ref["x"]).abs().max() < 1e-5
+    xs, _ = net(xyz[:nb].to(DEV).contiguous(), 4)                 # batch items are independent
+    assert torch.equal(xs, x[:nb])
+    st = net.forward_stages(xyz.to(DEV), 4)
+    assert ((st["ldj"][:nb].cpu() - ref["ldj"]).abs() / ref["ldj"].abs()).max() < 1e-5
+
+
 # ------------------------------------------------------------------- full-size properties
 def test_full_size_properties(lib):
     """BASELINE config 2 shape (32 x 2048): size-independent properties + oracle on a slice."""
