@@ -112,8 +112,23 @@ class TrainerModule(_Base):
         return log_dict
 
     # ---- what Lightning's loop does around training_step, made explicit (and multi-GPU aware)
+    def _sync_actnorm_init(self, batch) -> None:
+        """ActNorm's data-dependent first-batch init (normalize.py:45-54) would differ per rank under batch sharding and
+        gradient averaging never reconciles parameters: run the init forward once, then broadcast rank 0's module."""
+        if all(b.actnorm.is_inited for b in self.network.flow_blocks):
+            return
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if not multi:
+            return                      # single process: the init happens inside the first real forward, as in the reference
+        from .dist import broadcast_module
+        with torch.no_grad():
+            sparse, dense = batch[0], batch[1]
+            self(sparse, upratio=int(dense.shape[1] / sparse.shape[1]))
+        broadcast_module(self)
+
     def train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2) -> Tensor:
         self.train()
+        self._sync_actnorm_init(batch)
         optimizer.zero_grad(set_to_none=True)
         loss = self.training_step(batch, 0)
         loss.backward()
