@@ -161,6 +161,29 @@ int pf_softmax_wsum_fwd(const float* w, int ldw, const float* zj, int K, int R, 
 int pf_softmax_wsum_bwd(const float* a, const float* zj, const float* dfz, int K, int R, int ldw, long long T, float* dw,
                         float* dzj, void* stream);
 
+/* Flow-block elementwise algebra on [R,3] rows for the training path (csrc/train_ops.hip, second part), forward +
+ * backward: ActNorm (normalize.py:30-43; inv = 1: (x-bias) exp(-logs)); additive coupling + channel reverse + injector
+ * (coupling.py:55-58,114-118,132-137; permutate.py:75-80) and their inverse halves (coupling.py:82-85,141-151);
+ * per-batch sums for the log-det and the Gaussian log-likelihood (probs.py:73-75,87-93).  td = width of the first
+ * split (1 or 2).  Parameter-gradient rows (glogs_rows, gbias_rows [R,3]) are column-summed with pf_colsum. */
+int pf_actnorm_fwd(const float* x, const float* logs, const float* bias, int inv, long long R, float* y, void* stream);
+int pf_actnorm_bwd(const float* x, const float* dy, const float* logs, const float* bias, int inv, long long R, float* dx,
+                   float* glogs_rows, float* gbias_rows, void* stream);
+int pf_couple_inject_fwd(const float* y, const float* o, const float* s, const float* t, int td, long long R, float* out,
+                         void* stream);
+int pf_couple_inject_bwd(const float* out, const float* dout, const float* s, int td, long long R, float* dy, float* do_,
+                         float* ds, float* dt, void* stream);
+int pf_inject_inv_fwd(const float* u, const float* s, const float* t, long long R, float* v, void* stream);
+int pf_inject_inv_bwd(const float* u, const float* s, const float* dv, long long R, float* du, float* ds, float* dt,
+                      void* stream);
+int pf_couple_add(const float* v, const float* o, int td, long long R, float* out, void* stream);
+int pf_slice_tail(const float* g, int td, long long R, float* o, void* stream);
+/* out[b] = sum_m f(x[b*M+m]); mode 0: f = x, mode 1: f = -0.5 (x^2 + log 2 pi); backward dx = g[b] f'(x) */
+int pf_batch_sum_fwd(const float* x, int B, long long M, int mode, float* out, void* stream);
+int pf_batch_sum_bwd(const float* x, const float* g, int B, long long M, int mode, float* dx, void* stream);
+/* DistanceEncoder.distance_vec (interpflow.py:100-115): out [B*N*K,10] = [x_i, x_j, x_i - x_j, |x_i - x_j|] */
+int pf_dist_feature(const float* xyz, const int* idx, int B, int N, int K, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Patch pipeline around the network (modules/utils/patch.py:35-214), csrc/patch_ops.hip
  * ------------------------------------------------------------------------------------------- */

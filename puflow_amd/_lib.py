@@ -54,6 +54,18 @@ SIGNATURES = {
     "pf_softmax_wsum_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p]),
     "pf_softmax_wsum_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p,
                                     c_void_p]),
+    "pf_actnorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
+    "pf_actnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_couple_inject_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
+    "pf_couple_inject_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
+    "pf_inject_inv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
+    "pf_inject_inv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_couple_add": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
+    "pf_slice_tail": (c_int, [c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
+    "pf_batch_sum_fwd": (c_int, [c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p]),
+    "pf_batch_sum_bwd": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p]),
+    "pf_dist_feature": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_fps": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_knn_large": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }

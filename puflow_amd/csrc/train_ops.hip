@@ -652,3 +652,241 @@ extern "C" int pf_softmax_wsum_bwd(const float* a, const float* zj, const float*
                        ldw, T, dw, dzj);
     return pf_last_launch_status();
 }
+
+// ============================================================================================================
+// Flow-block elementwise algebra on [R,3] rows (training path): ActNorm scale/shift, the additive coupling +
+// channel reverse + conditional affine injector, and the Gaussian log-likelihood, each with its backward.
+// Reference: modules/flows/normalize.py:30-43, coupling.py:55-58,82-85,114-118,132-151, permutate.py:75-80,
+// modules/utils/probs.py:73-75.  One thread per row; parameter gradients are reduced with pf_colsum by the caller.
+// ============================================================================================================
+namespace {
+
+// y = x*exp(logs)+bias (inv=0)   or   y = (x-bias)*exp(-logs) (inv=1)
+__global__ __launch_bounds__(256) void actnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ logs,
+                                                         const float* __restrict__ bias, int inv, long long R,
+                                                         float* __restrict__ y) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = x[r * 3 + c];
+        y[r * 3 + c] = inv ? (v - bias[c]) * expf(-logs[c]) : v * expf(logs[c]) + bias[c];
+    }
+}
+// dx, and per-row contributions glogs / gbias [R,3] (column-summed by the caller)
+__global__ __launch_bounds__(256) void actnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ logs, const float* __restrict__ bias,
+                                                         int inv, long long R, float* __restrict__ dx,
+                                                         float* __restrict__ glogs, float* __restrict__ gbias) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = dy[r * 3 + c], v = x[r * 3 + c];
+        if (inv) {
+            const float e = expf(-logs[c]);
+            dx[r * 3 + c] = g * e;
+            gbias[r * 3 + c] = -g * e;
+            glogs[r * 3 + c] = -g * (v - bias[c]) * e;
+        } else {
+            const float e = expf(logs[c]);
+            dx[r * 3 + c] = g * e;
+            gbias[r * 3 + c] = g;
+            glogs[r * 3 + c] = g * v * e;
+        }
+    }
+}
+
+// forward direction: h2 = y[td:] - o ; v = reverse(cat[h1,h2]) ; out = (v - t) * exp(-s)
+__global__ __launch_bounds__(256) void couple_inject_fwd_kernel(const float* __restrict__ y, const float* __restrict__ o,
+                                                               const float* __restrict__ s, const float* __restrict__ t,
+                                                               int td, long long R, float* __restrict__ out) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float h[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) h[c] = y[r * 3 + c] - (c >= td ? o[r * (3 - td) + (c - td)] : 0.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[r * 3 + c] = (h[2 - c] - t[r * 3 + c]) * expf(-s[r * 3 + c]);
+}
+__global__ __launch_bounds__(256) void couple_inject_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                               const float* __restrict__ s, int td, long long R,
+                                                               float* __restrict__ dy, float* __restrict__ dobuf,
+                                                               float* __restrict__ ds, float* __restrict__ dt) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float dv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = dout[r * 3 + c];
+        dv[c] = g * expf(-s[r * 3 + c]);
+        ds[r * 3 + c] = -g * out[r * 3 + c];
+        dt[r * 3 + c] = -dv[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = dv[2 - c];                       // un-reverse
+        dy[r * 3 + c] = g;
+        if (c >= td) dobuf[r * (3 - td) + (c - td)] = -g;
+    }
+}
+
+// inverse direction, first half: v = reverse(u * exp(s) + t)
+__global__ __launch_bounds__(256) void inject_inv_fwd_kernel(const float* __restrict__ u, const float* __restrict__ s,
+                                                            const float* __restrict__ t, long long R, float* __restrict__ v) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[r * 3 + (2 - c)] = fmaf(u[r * 3 + c], expf(s[r * 3 + c]), t[r * 3 + c]);
+}
+__global__ __launch_bounds__(256) void inject_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ s,
+                                                            const float* __restrict__ dv, long long R, float* __restrict__ du,
+                                                            float* __restrict__ ds, float* __restrict__ dt) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = dv[r * 3 + (2 - c)], e = expf(s[r * 3 + c]);
+        du[r * 3 + c] = g * e;
+        ds[r * 3 + c] = g * u[r * 3 + c] * e;
+        dt[r * 3 + c] = g;
+    }
+}
+// inverse direction, second half: out = cat[v[:td], v[td:] + o]   (backward: dv = dout, do = dout[td:])
+__global__ __launch_bounds__(256) void couple_add_kernel(const float* __restrict__ v, const float* __restrict__ o, int td,
+                                                        long long R, float* __restrict__ out) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[r * 3 + c] = v[r * 3 + c] + (c >= td ? o[r * (3 - td) + (c - td)] : 0.f);
+}
+__global__ __launch_bounds__(256) void slice_tail_kernel(const float* __restrict__ g, int td, long long R, float* __restrict__ o) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    for (int c = td; c < 3; ++c) o[r * (3 - td) + (c - td)] = g[r * 3 + c];
+}
+
+// per-batch sums over M consecutive values: out[b] = sum_m f(x[b*M + m]);  mode 0: x, mode 1: -0.5*(x^2 + log 2 pi)
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ x, long long M, int mode, float* __restrict__ out) {
+    __shared__ float sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float acc = 0.f;
+    for (long long m = tid; m < M; m += 256) {
+        const float v = x[(long long)b * M + m];
+        acc += mode == 0 ? v : -0.5f * (v * v + 1.8378770664093453f);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) out[b] = sh[0];
+}
+// dx[b*M + m] = g[b] * (mode 0: 1, mode 1: -x)
+__global__ __launch_bounds__(256) void batch_sum_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, long long M,
+                                                           int mode, long long total, float* __restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const float gg = g[i / M];
+        dx[i] = mode == 0 ? gg : -gg * x[i];
+    }
+}
+
+inline unsigned rows_grid(long long R) { return (unsigned)((R + 255) / 256); }
+
+}  // namespace
+
+extern "C" int pf_actnorm_fwd(const float* x, const float* logs, const float* bias, int inv, long long R, float* y, void* stream) {
+    if (!x || !logs || !bias || !y) return PF_ERR_NULL;
+    if (R <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(actnorm_fwd_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, x, logs, bias, inv, R, y);
+    return pf_last_launch_status();
+}
+extern "C" int pf_actnorm_bwd(const float* x, const float* dy, const float* logs, const float* bias, int inv, long long R,
+                              float* dx, float* glogs_rows, float* gbias_rows, void* stream) {
+    if (!x || !dy || !logs || !bias || !dx || !glogs_rows || !gbias_rows) return PF_ERR_NULL;
+    if (R <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(actnorm_bwd_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, x, dy, logs, bias, inv, R, dx,
+                       glogs_rows, gbias_rows);
+    return pf_last_launch_status();
+}
+extern "C" int pf_couple_inject_fwd(const float* y, const float* o, const float* s, const float* t, int td, long long R,
+                                    float* out, void* stream) {
+    if (!y || !o || !s || !t || !out) return PF_ERR_NULL;
+    if (R <= 0 || td < 1 || td > 2) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(couple_inject_fwd_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, y, o, s, t, td, R, out);
+    return pf_last_launch_status();
+}
+extern "C" int pf_couple_inject_bwd(const float* out, const float* dout, const float* s, int td, long long R, float* dy,
+                                    float* do_, float* ds, float* dt, void* stream) {
+    if (!out || !dout || !s || !dy || !do_ || !ds || !dt) return PF_ERR_NULL;
+    if (R <= 0 || td < 1 || td > 2) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(couple_inject_bwd_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, out, dout, s, td, R, dy,
+                       do_, ds, dt);
+    return pf_last_launch_status();
+}
+extern "C" int pf_inject_inv_fwd(const float* u, const float* s, const float* t, long long R, float* v, void* stream) {
+    if (!u || !s || !t || !v) return PF_ERR_NULL;
+    if (R <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(inject_inv_fwd_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, u, s, t, R, v);
+    return pf_last_launch_status();
+}
+extern "C" int pf_inject_inv_bwd(const float* u, const float* s, const float* dv, long long R, float* du, float* ds, float* dt,
+                                 void* stream) {
+    if (!u || !s || !dv || !du || !ds || !dt) return PF_ERR_NULL;
+    if (R <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(inject_inv_bwd_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, u, s, dv, R, du, ds, dt);
+    return pf_last_launch_status();
+}
+extern "C" int pf_couple_add(const float* v, const float* o, int td, long long R, float* out, void* stream) {
+    if (!v || !o || !out) return PF_ERR_NULL;
+    if (R <= 0 || td < 1 || td > 2) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(couple_add_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, v, o, td, R, out);
+    return pf_last_launch_status();
+}
+extern "C" int pf_slice_tail(const float* g, int td, long long R, float* o, void* stream) {
+    if (!g || !o) return PF_ERR_NULL;
+    if (R <= 0 || td < 1 || td > 2) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(slice_tail_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, g, td, R, o);
+    return pf_last_launch_status();
+}
+extern "C" int pf_batch_sum_fwd(const float* x, int B, long long M, int mode, float* out, void* stream) {
+    if (!x || !out) return PF_ERR_NULL;
+    if (B <= 0 || M <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(batch_sum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, M, mode, out);
+    return pf_last_launch_status();
+}
+extern "C" int pf_batch_sum_bwd(const float* x, const float* g, int B, long long M, int mode, float* dx, void* stream) {
+    if (!x || !g || !dx) return PF_ERR_NULL;
+    if (B <= 0 || M <= 0) return PF_ERR_SHAPE;
+    const long long total = (long long)B * M;
+    hipLaunchKernelGGL(batch_sum_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, g, M, mode, total, dx);
+    return pf_last_launch_status();
+}
+
+// DistanceEncoder.distance_vec (interpflow.py:100-115): out [B*N*K, 10] = [x_i, x_j, x_i - x_j, |x_i - x_j|] (inputs only: no backward)
+namespace {
+__global__ __launch_bounds__(256) void dist_feature_kernel(const float* __restrict__ xyz, const int* __restrict__ idx, int N, int K,
+                                                          long long E, float* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const long long t = e / K;
+    const long long j = (t / N) * N + idx[e];
+    float* o = out + e * 10;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = xyz[t * 3 + c], b = xyz[j * 3 + c];
+        o[c] = a; o[3 + c] = b; v[c] = __fsub_rn(a, b); o[6 + c] = v[c];
+    }
+    o[9] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1])), __fmul_rn(v[2], v[2])));
+}
+}  // namespace
+
+extern "C" int pf_dist_feature(const float* xyz, const int* idx, int B, int N, int K, float* out, void* stream) {
+    if (!xyz || !idx || !out) return PF_ERR_NULL;
+    if (B <= 0 || N <= 0 || K <= 0) return PF_ERR_SHAPE;
+    const long long E = (long long)B * N * K;
+    hipLaunchKernelGGL(dist_feature_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz, idx, N, K, E, out);
+    return pf_last_launch_status();
+}

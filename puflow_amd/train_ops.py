@@ -5,9 +5,10 @@ Split between HIP and torch in TRAINING mode (documented in DESIGN.md section 7)
   HIP  : every Conv2d(1x1)/Linear (forward, dX, dW, db), BatchNorm(train)+LeakyReLU, ReLU/LeakyReLU,
          edge-feature gather / scatter-add, max-pool over K, neighbour gather backward, softmax-weighted
          latent sum, repeat_interleave backward, kNN, Chamfer, EMD.
-  torch: tensor re-layout (cat / slice / reshape / index) and the 3-channel flow algebra on [B,N,3]
-         tensors (actnorm, 3x3 inv1x1 + slogdet, coupling add, injector exp/mul, Gaussian log-likelihood):
-         O(points x 3) work, < 0.1 % of the step; plus the optimiser, exactly as in the reference.
+         ActNorm, coupling + reverse + injector (both directions), per-batch log-det / Gaussian sums.
+  torch: tensor re-layout (cat / slice / reshape / index and their autograd), parameter-only scalars
+         (sum(logs), slogdet / inverse of the 3x3 W), [B]-sized loss bookkeeping, and the optimiser
+         (torch.optim.Adam, exactly as in the reference).
 Activations are channels-last [rows, C] fp32 (rows = points or edges).
 """
 from __future__ import annotations
@@ -281,6 +282,148 @@ class SoftmaxWsumFn(Function):
         return dw, dzj, None
 
 
+def _colsum3(rows: Tensor) -> Tensor:
+    """[R,3] -> [3] column sums (HIP, deterministic)."""
+    lib = _lib.load()
+    R = rows.shape[0]
+    out = torch.empty((3,), dtype=torch.float32, device=rows.device)
+    ws = _ws(rows.device, 2 * lib.pf_bn_chunks(R) * 3)
+    _lib.check(lib.pf_colsum(rows.data_ptr(), R, 3, out.data_ptr(), ws.data_ptr(), _stream()), "pf_colsum")
+    return out
+
+
+class ActNormFn(Function):
+    """y = x exp(logs) + bias  (inv=0, normalize.py:34)   or   y = (x - bias) exp(-logs)  (inv=1, normalize.py:41)."""
+
+    @staticmethod
+    def forward(ctx, x, logs, bias, inv):
+        lib = _lib.load()
+        x = x.contiguous()
+        lg, bs = logs.reshape(3).contiguous(), bias.reshape(3).contiguous()
+        R = x.numel() // 3
+        y = torch.empty_like(x)
+        _lib.check(lib.pf_actnorm_fwd(x.data_ptr(), lg.data_ptr(), bs.data_ptr(), inv, R, y.data_ptr(), _stream()), "pf_actnorm_fwd")
+        ctx.save_for_backward(x, lg, bs)
+        ctx.inv, ctx.pshape = inv, logs.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, lg, bs = ctx.saved_tensors
+        R = x.numel() // 3
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        gl = torch.empty((R, 3), dtype=torch.float32, device=x.device)
+        gb = torch.empty((R, 3), dtype=torch.float32, device=x.device)
+        _lib.check(lib.pf_actnorm_bwd(x.data_ptr(), dy.data_ptr(), lg.data_ptr(), bs.data_ptr(), ctx.inv, R, dx.data_ptr(),
+                                      gl.data_ptr(), gb.data_ptr(), _stream()), "pf_actnorm_bwd")
+        return dx, _colsum3(gl).view(ctx.pshape), _colsum3(gb).view(ctx.pshape), None
+
+
+class CoupleInjectFn(Function):
+    """h2 = y[td:] - o ; v = reverse(cat[h1,h2]) ; out = (v - t) exp(-s)   (coupling.py:55-58,114-118,132-137; permutate.py:77)."""
+
+    @staticmethod
+    def forward(ctx, y, o, s, t, td):
+        lib = _lib.load()
+        y, o, s, t = y.contiguous(), o.contiguous(), s.contiguous(), t.contiguous()
+        R = y.numel() // 3
+        out = torch.empty_like(y)
+        _lib.check(lib.pf_couple_inject_fwd(y.data_ptr(), o.data_ptr(), s.data_ptr(), t.data_ptr(), td, R, out.data_ptr(), _stream()),
+                   "pf_couple_inject_fwd")
+        ctx.save_for_backward(out, s)
+        ctx.td, ctx.oshape = td, o.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        out, s = ctx.saved_tensors
+        R = out.numel() // 3
+        dout = dout.contiguous()
+        dy, ds, dt = torch.empty_like(out), torch.empty_like(out), torch.empty_like(out)
+        do = torch.empty(ctx.oshape, dtype=torch.float32, device=out.device)
+        _lib.check(lib.pf_couple_inject_bwd(out.data_ptr(), dout.data_ptr(), s.data_ptr(), ctx.td, R, dy.data_ptr(), do.data_ptr(),
+                                            ds.data_ptr(), dt.data_ptr(), _stream()), "pf_couple_inject_bwd")
+        return dy, do, ds, dt, None
+
+
+class InjectInvFn(Function):
+    """v = reverse(u exp(s) + t)   (coupling.py:147-149; permutate.py:79)."""
+
+    @staticmethod
+    def forward(ctx, u, s, t):
+        lib = _lib.load()
+        u, s, t = u.contiguous(), s.contiguous(), t.contiguous()
+        R = u.numel() // 3
+        v = torch.empty_like(u)
+        _lib.check(lib.pf_inject_inv_fwd(u.data_ptr(), s.data_ptr(), t.data_ptr(), R, v.data_ptr(), _stream()), "pf_inject_inv_fwd")
+        ctx.save_for_backward(u, s)
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        lib = _lib.load()
+        u, s = ctx.saved_tensors
+        R = u.numel() // 3
+        dv = dv.contiguous()
+        du, ds, dt = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+        _lib.check(lib.pf_inject_inv_bwd(u.data_ptr(), s.data_ptr(), dv.data_ptr(), R, du.data_ptr(), ds.data_ptr(), dt.data_ptr(),
+                                         _stream()), "pf_inject_inv_bwd")
+        return du, ds, dt
+
+
+class CoupleAddFn(Function):
+    """out = cat[v[:td], v[td:] + o]   (coupling.py:82-85)."""
+
+    @staticmethod
+    def forward(ctx, v, o, td):
+        lib = _lib.load()
+        v, o = v.contiguous(), o.contiguous()
+        R = v.numel() // 3
+        out = torch.empty_like(v)
+        _lib.check(lib.pf_couple_add(v.data_ptr(), o.data_ptr(), td, R, out.data_ptr(), _stream()), "pf_couple_add")
+        ctx.td, ctx.oshape = td, o.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        g = g.contiguous()
+        R = g.numel() // 3
+        do = torch.empty(ctx.oshape, dtype=torch.float32, device=g.device)
+        _lib.check(lib.pf_slice_tail(g.data_ptr(), ctx.td, R, do.data_ptr(), _stream()), "pf_slice_tail")
+        return g, do, None
+
+
+class BatchSumFn(Function):
+    """x [B, ...] -> [B]: mode 0 = sum, mode 1 = sum of -0.5 (x^2 + log 2 pi)  (probs.py:73-75,87-93)."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        lib = _lib.load()
+        x = x.contiguous()
+        B = x.shape[0]
+        M = x.numel() // B
+        out = torch.empty((B,), dtype=torch.float32, device=x.device)
+        _lib.check(lib.pf_batch_sum_fwd(x.data_ptr(), B, M, mode, out.data_ptr(), _stream()), "pf_batch_sum_fwd")
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        B = x.shape[0]
+        M = x.numel() // B
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(lib.pf_batch_sum_bwd(x.data_ptr(), g.data_ptr(), B, M, ctx.mode, dx.data_ptr(), _stream()), "pf_batch_sum_bwd")
+        return dx, None
+
+
 # ----------------------------------------------------------------------------------------------------
 # train-mode network forward (differentiable)
 # ----------------------------------------------------------------------------------------------------
@@ -342,29 +485,22 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
                 an.bias.data.copy_(-torch.mean(p.detach(), dim=(0, 1), keepdim=True))
                 an.logs.data.copy_(-torch.log(torch.std(p.detach(), dim=(0, 1), keepdim=True) + 1e-6))
                 an.is_inited = True
-        p = p * torch.exp(an.logs) + an.bias
         W = blk.permutate1.permutater.W
-        p = linear(p, W)                                           # einsum 'ij,bnj->bni' (permutate.py:118)
-        ld = (torch.sum(an.logs) + torch.slogdet(W)[1]) * N
+        y = linear(ActNormFn.apply(p, an.logs, an.bias, 0), W)     # einsum 'ij,bnj->bni' (permutate.py:118)
+        ld = (torch.sum(an.logs) + torch.slogdet(W)[1]) * N        # parameter-only scalars
         td = 1 if i % 2 == 0 else 2
-        h1, h2 = p[..., :td], p[..., td:]
-        h2 = h2 - cond_net(blk.coupling1.bias_net, torch.cat([h1, cs[i]], dim=-1))
-        p = torch.cat([h1, h2], dim=-1).flip(-1)
+        o = cond_net(blk.coupling1.bias_net, torch.cat([y[..., :td], cs[i]], dim=-1))
         s = cond_net(blk.coupling2.scale_net, cs[i])
         t = cond_net(blk.coupling2.bias_net, cs[i])
-        p = (p - t) * torch.exp(-s)
-        ldj = ldj + ld - s.flatten(1).sum(1)
+        p = CoupleInjectFn.apply(y, o, s, t, td)
+        ldj = ldj + ld - BatchSumFn.apply(s, 0)
     z = p
-    logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + LOG2PI), dim=(1, 2)) + ldj)
+    logp = -torch.mean(BatchSumFn.apply(z, 1) + ldj)
 
     # ---- interpolation
     ip = net.interp
-    bidx = torch.arange(B, device=xyz.device).view(B, 1, 1)
-    nb = xyz[bidx, idx8.long()]                                   # [B,N,8,3]   (inputs only: no gradient)
-    xi = xyz.unsqueeze(2).expand_as(nb)
-    vec = xi - nb
-    dist = torch.sqrt(torch.sum(vec ** 2, dim=-1, keepdim=True))
-    fd = torch.cat([xi, nb, vec, dist], dim=-1).reshape(B * N * 8, 10)
+    fd = torch.empty((B * N * 8, 10), dtype=torch.float32, device=xyz.device)        # inputs only: no gradient
+    _lib.check(_lib.load().pf_dist_feature(xyz.data_ptr(), idx8.data_ptr(), B, N, 8, fd.data_ptr(), _stream()), "pf_dist_feature")
     d = _mlp_bn(ip.knn_context.distance_encoder.mlp, fd)          # [E8,128]
     feat = edgeconv_train(ip.knn_context.feat_conv, xyz, idx8, pooling=False)
     w = _mlp_bn(ip.weight_unit.mlp, torch.cat([d, feat], dim=1))  # [E8,32]
@@ -377,12 +513,10 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         blk = net.flow_blocks[i]
         s = RepeatRowsFn.apply(cond_net(blk.coupling2.scale_net, cs[i]), R)
         t = RepeatRowsFn.apply(cond_net(blk.coupling2.bias_net, cs[i]), R)
-        u = (u * torch.exp(s) + t).flip(-1)
+        v = InjectInvFn.apply(u, s, t)
         td = 1 if i % 2 == 0 else 2
-        h1, h2 = u[..., :td], u[..., td:]
-        h2 = h2 + cond_net(blk.coupling1.bias_net, torch.cat([h1, RepeatRowsFn.apply(cs[i], R)], dim=-1))
-        u = torch.cat([h1, h2], dim=-1)
+        o = cond_net(blk.coupling1.bias_net, torch.cat([v[..., :td], RepeatRowsFn.apply(cs[i], R)], dim=-1))
         W = blk.permutate1.permutater.W
-        u = linear(u, torch.inverse(W))                            # permutate.py:123-124
-        u = (u - blk.actnorm.bias) * torch.exp(-blk.actnorm.logs)
+        u = linear(CoupleAddFn.apply(v, o, td), torch.inverse(W))  # permutate.py:123-124 (3x3 inverse: parameter-only)
+        u = ActNormFn.apply(u, blk.actnorm.logs, blk.actnorm.bias, 1)
     return u, logp
