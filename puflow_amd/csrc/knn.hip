@@ -200,23 +200,40 @@ __global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ 
     if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
 }
 
-// K = 1: nearest neighbour distance + index (first minimum wins ties).
-__global__ __launch_bounds__(64) void nn1_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
-                                                 int N, int M, float* __restrict__ dist_out,
-                                                 int* __restrict__ idx_out) {
-    const int b = blockIdx.y;
-    const int n = blockIdx.x * 64 + threadIdx.x;
+// K = 1: nearest neighbour distance + index (first minimum wins ties).  References are streamed 64 at a time
+// (lane l loads reference j0 + l) and broadcast with v_readlane, like knn2_kernel.
+__global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                  int N, int M, float* __restrict__ dist_out,
+                                                  int* __restrict__ idx_out) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 256 + threadIdx.x;
     const bool live = n < N;
     const float* q = p1 + ((size_t)b * N + (live ? n : N - 1)) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float* __restrict__ r = p2 + (size_t)b * M * 3;
+    auto load_ref = [&](int j0, float& cx, float& cy, float& cz) {
+        const int j = j0 + lane;
+        const bool in = j < M;
+        const int jc = in ? j : M - 1;
+        cx = in ? r[jc * 3 + 0] : __builtin_inff();           // padding: distance +inf never beats a real reference
+        cy = r[jc * 3 + 1];
+        cz = r[jc * 3 + 2];
+    };
     float best = __builtin_inff();
     int besti = 0;
-    for (int j = 0; j < M; ++j) {
-        const float d = sqdist(qx, qy, qz, r[j * 3 + 0], r[j * 3 + 1], r[j * 3 + 2]);
-        const bool c = d < best;
-        best = c ? d : best;
-        besti = c ? j : besti;
+    float cx, cy, cz;
+    load_ref(0, cx, cy, cz);
+    for (int j0 = 0; j0 < M; j0 += 64) {
+        float nx = cx, ny = cy, nz = cz;
+        if (j0 + 64 < M) load_ref(j0 + 64, nx, ny, nz);
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            const float d = sqdist(qx, qy, qz, bcast(cx, c), bcast(cy, c), bcast(cz, c));
+            const bool lt = d < best;                           // strict: the first minimum is kept
+            best = lt ? d : best;
+            besti = lt ? j0 + c : besti;
+        }
+        cx = nx; cy = ny; cz = nz;
     }
     if (live) {
         dist_out[(size_t)b * N + n] = best;
@@ -256,7 +273,7 @@ extern "C" int pf_nn1(const float* p1, const float* p2, int B, int N, int M, flo
                       void* stream) {
     if (!p1 || !p2 || !dist_out) return PF_ERR_NULL;
     if (B <= 0 || N <= 0 || M <= 0 || B > 65535) return PF_ERR_SHAPE;
-    hipLaunchKernelGGL(nn1_kernel, dim3((N + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, p1, p2, N, M, dist_out,
+    hipLaunchKernelGGL(nn1_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, p1, p2, N, M, dist_out,
                        idx_out);
     return pf_last_launch_status();
 }
