@@ -12,10 +12,13 @@
 // 64 -> 64 -> (1|2), run on the f32 MFMA with 16 rows per column tile.
 //
 // Per-block weight record (floats, 16-byte aligned pieces), stride FLOW_REC:
-//   [0,4096)  W2 fragments (4 ob x 4 cb)
+//   [0,4096)  W2 fragments (4 ob x 4 cb)                                  (f32 image; unused by the split-bf16 path)
 //   [4096,5120) W4 fragments (1 ob x 4 cb; rows replicated into every 4-row q group)
 //   [5120,5184) b2      [5184,5200) b4 (replicated likewise)      [5200,5328) W0h [64][2]
 //   [5328,5360) A(9) a0(3) Ai(9) ai0(3) pad
+//   [5360,13040) split-bf16 image (csrc/pf_mfma.h) of W2 (4 ob x 2 pairs) then W4 (1 ob x 2 pairs): 10 fragments x 768 floats.
+// The 64 -> 64 -> (1|2) coupling net runs on the bf16 pipe with fp32-class accuracy: 60 x 16 instead of 80 x 32 MFMA cycles
+// per 16 rows and block.
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
@@ -30,7 +33,7 @@
 
 namespace {
 
-constexpr int FLOW_REC = 5360;
+constexpr int FLOW_REC = 13040;
 constexpr float LOG2PI_F = 1.8378770664093453f;
 
 struct FlowArgs {
@@ -68,19 +71,23 @@ __device__ __forceinline__ void coupling_net(const WS& ws, const float* __restri
         }
     }
     f4 h2[P][4];
+    PfPair hp[P][2];
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob)
+    for (int p = 0; p < P; ++p) {
 #pragma unroll
-        for (int p = 0; p < P; ++p) h2[p][ob] = pf_bias(rec + 5120, ob, q);
-    pf_mm<4, 4, 4>(ws, 0, hid, 0, h2, 0);
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-        for (int p = 0; p < P; ++p) h2[p][ob] = pf_lrelu(h2[p][ob], 0.01f);
+        for (int ob = 0; ob < 4; ++ob) h2[p][ob] = pf_bias(rec + 5120, ob, q);
+        hp[p][0] = pf_pair(hid[p][0], hid[p][1]);
+        hp[p][1] = pf_pair(hid[p][2], hid[p][3]);
+    }
+    pf_mm3<4, 2, 2>(ws, 0, hp, 0, h2, 0);
     f4 acc[P][1];
 #pragma unroll
-    for (int p = 0; p < P; ++p) acc[p][0] = *reinterpret_cast<const f4*>(rec + 5184 + 4 * q);
-    pf_mm<1, 4, 4>(ws, 16, h2, 0, acc, 0);
+    for (int p = 0; p < P; ++p) {
+        acc[p][0] = *reinterpret_cast<const f4*>(rec + 5184 + 4 * q);
+        hp[p][0] = pf_pair(pf_lrelu(h2[p][0], 0.01f), pf_lrelu(h2[p][1], 0.01f));
+        hp[p][1] = pf_pair(pf_lrelu(h2[p][2], 0.01f), pf_lrelu(h2[p][3], 0.01f));
+    }
+    pf_mm3<1, 2, 2>(ws, 8, hp, 0, acc, 0);
 #pragma unroll
     for (int p = 0; p < P; ++p) { o[p][0] = acc[p][0].x; o[p][1] = acc[p][0].y; }
 }
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(FlowArgs a) {
             const float* rec = a.w + u * FLOW_REC;
             const float* cpu = a.cp + (size_t)u * a.T * 64;
             const float* stu = a.st + (size_t)u * a.T * 8;
-            const PfWBuf ws(rec, lane);
+            const PfW3Buf ws(rec + 5360, lane);
             const float* fc = rec + 5328;
             float s[P][3], t[P][3];
 #pragma unroll

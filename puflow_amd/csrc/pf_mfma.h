@@ -152,10 +152,21 @@ struct PfW3Lds {
     }
 };
 
+// same image read from global memory through a buffer descriptor (small matrices that stay in L1/L2)
+struct PfW3Buf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;           // lane * 16
+    __device__ __forceinline__ PfW3Buf(const void* p, int lane)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000)), voff(lane * 16) {}
+    __device__ __forceinline__ bf8 load(int frag, int split) const {
+        return __builtin_bit_cast(bf8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (frag * 3 + split) * (PF_WAVE * 16), 0));
+    }
+};
+
 // acc[p][acc0+ob] += W[ob][cp] * in[p][in0+cp]  over block PAIRS cp < CP (six bf16 MFMAs per pair, small terms first).
 // The next fragment's three weight reads are issued before the current fragment's MFMAs (double buffer).
-template <int OB, int CP, int WCP, int P, int NIN, int NACC>
-__device__ __forceinline__ void pf_mm3(const PfW3Lds& ws, int frag0, const PfPair (&in)[P][NIN], int in0,
+template <int OB, int CP, int WCP, class WS3, int P, int NIN, int NACC>
+__device__ __forceinline__ void pf_mm3(const WS3& ws, int frag0, const PfPair (&in)[P][NIN], int in0,
                                        f4 (&acc)[P][NACC], int acc0) {
     constexpr int NFRAG = OB * CP;
     bf8 wb[2][3];

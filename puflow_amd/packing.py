@@ -222,7 +222,7 @@ def frag_unpack(F: np.ndarray, out: int, inn: int) -> np.ndarray:
 # ---------------------------------------------------------------------------------------
 POST_SLOTS = ["M1", "b1", "M2", "H1", "S2", "bS2", "T2", "bT2", "ST4", "bST4", "PQ", "bPQ"]
 INTERP_SLOTS = ["dtab", "d_W3", "d_b3", "d_W6", "d_b6", "ectab", "ec_w", "w_W0", "w_b0", "w_W3", "w_b3", "w_W6", "w_b6"]
-FLOW_REC = 5360
+FLOW_REC = 13040
 
 
 class _Blob:
@@ -263,7 +263,7 @@ def _ec_frags(u: Dict[str, np.ndarray], nconv: int) -> np.ndarray:
 
 
 def pack_flow_record(f: Dict[str, object]) -> np.ndarray:
-    """One 5360-float flow-block record (layout: csrc/flow.hip header)."""
+    """One 13040-float flow-block record (layout: csrc/flow.hip header)."""
     rec = np.zeros(FLOW_REC, np.float32)
     rec[0:4096] = frag_pack(f["c1_W2"]).reshape(-1)
     W4 = f["c1_W4"]                                   # [3-td, 64]
@@ -280,6 +280,8 @@ def pack_flow_record(f: Dict[str, object]) -> np.ndarray:
     rec[5200:5328] = W0h.reshape(-1)
     rec[5328:5337] = f["A"].reshape(-1); rec[5337:5340] = f["a0"]
     rec[5340:5349] = f["Ai"].reshape(-1); rec[5349:5352] = f["ai0"]
+    rec[5360:5360 + 8 * 768] = frag_pack_bf16x3(f["c1_W2"])            # 4 ob x 2 pairs
+    rec[5360 + 8 * 768:13040] = frag_pack_bf16x3(W4r)                    # 1 ob x 2 pairs
     return rec
 
 

@@ -89,3 +89,4 @@ def test_pack_plan_layout():
     w4 = frag_unpack(rec[4096:5120].reshape(1, 4, 64, 4), 16, 64)
     np.testing.assert_array_equal(w4[4:6], plan["flows"][2]["c1_W4"])
     np.testing.assert_array_equal(rec[5328:5337].reshape(3, 3), plan["flows"][2]["A"])
+    assert FLOW_REC == 13040 and rec.size == FLOW_REC
