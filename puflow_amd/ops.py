@@ -33,8 +33,11 @@ def knn_idx32(p1: torch.Tensor, p2: torch.Tensor, K: int, want_dist: bool = Fals
     M = p2.shape[1]
     idx = torch.empty((B, N, K), dtype=torch.int32, device=p1.device)
     dist = torch.empty((B, N, K), dtype=torch.float32, device=p1.device) if want_dist else None
-    _lib.check(lib.pf_knn(p1.data_ptr(), p2.data_ptr(), B, N, M, K, idx.data_ptr(),
-                          dist.data_ptr() if want_dist else None, _stream()), "pf_knn")
+    dptr = dist.data_ptr() if want_dist else None
+    if K in (4, 8, 16, 32):
+        _lib.check(lib.pf_knn(p1.data_ptr(), p2.data_ptr(), B, N, M, K, idx.data_ptr(), dptr, _stream()), "pf_knn")
+    else:                       # any other K: sort-based kernel (same (distance, index) order), M <= 16384
+        _lib.check(lib.pf_knn_large(p2.data_ptr(), p1.data_ptr(), B, M, N, K, idx.data_ptr(), dptr, _stream()), "pf_knn_large")
     return idx, dist
 
 

@@ -31,12 +31,13 @@ def _stream() -> int:
 
 
 def _ws(dev, n: int) -> Tensor:
-    """Grow-only fp32 scratch per device (stream-ordered reuse: every kernel that uses it is enqueued
-    on the same stream before the next one overwrites it)."""
-    t = _WS.get(dev)
+    """Grow-only fp32 scratch per (device, stream): reuse is stream-ordered - every kernel that uses it is enqueued
+    on that stream before the next one overwrites it - so two streams never share a buffer."""
+    key = (dev, _stream())
+    t = _WS.get(key)
     if t is None or t.numel() < n:
         t = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=dev)
-        _WS[dev] = t
+        _WS[key] = t
     return t
 
 

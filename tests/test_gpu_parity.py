@@ -44,6 +44,16 @@ def test_knn_bit_exact(lib, B, N, M, K):
     assert torch.equal(d.cpu(), d_ref)                       # distances bit-exact (unfused fp32)
 
 
+def test_knn_any_k(lib):
+    """K outside the register-resident set {4, 8, 16, 32} goes through the sort-based kernel, same order."""
+    from puflow_amd import ops
+    p = synth_patches(2, 500, seed=4, surface=False)
+    for K in (1, 5, 20, 100):
+        d_ref, i_ref = O.knn_canonical(p, p, K)
+        d, i, _ = ops.knn_points(p.to(DEV), p.to(DEV), K)
+        assert torch.equal(i.cpu(), i_ref) and torch.equal(d.cpu(), d_ref)
+
+
 def test_knn_ties_and_duplicates(lib):
     from puflow_amd import ops
     p = synth_patches(1, 128, seed=3, surface=False)
