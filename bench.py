@@ -118,7 +118,14 @@ def main():
         ec_fl = edgeconv_ref_flops(T, 128, 32, 4, 128)
         knn_ms = prof["knn"]
         knn_bytes = T * (3 * 4 + 16 * 4)               # 155 648 B per 2048-pt patch
-        if eng.ec_mode == "bf16x3":
+        if eng.ec_mode == "f16x2":
+            kname, peak = "edgeconv3_kernel<NCONV=4,ODIM=128,NS=2> (unit 3, split-fp16 on v_mfma_f32_16x16x32_f16)", BF16_MFMA_PEAK_TF
+            ec_exec = T * 132 * 16384.0                 # executed: 132 fp16 MFMAs (16x16x32) per point
+            basis = ("algorithmic = reference dense fp32 formulation (SURVEY 8d: 7.92 GFLOP per patch per unit), priced "
+                     "against the DENSE fp16/bf16 MFMA peak because the kernel runs on the fp16 pipe: fp32-equivalent results "
+                     "from 3 fp16 MFMA terms per product (2-way split, hi.hi + hi.lo + lo.hi), after the exact per-point P/Q "
+                     "fold (5.4x fewer MACs than the reference formulation); executed_* counts the fp16 MFMA flops actually issued")
+        elif eng.ec_mode == "bf16x3":
             kname, peak = "edgeconv3_kernel<NCONV=4,ODIM=128> (unit 3, split-bf16 on v_mfma_f32_16x16x32_bf16)", BF16_MFMA_PEAK_TF
             ec_exec = T * 264 * 16384.0                 # executed: 264 bf16 MFMAs (16x16x32) per point
             basis = ("algorithmic = reference dense fp32 formulation (SURVEY 8d: 7.92 GFLOP per patch per unit), priced "
@@ -142,7 +149,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pmc = json.load(f)["kernels"]
-            pref = "edgeconv3_kernel" if eng.ec_mode == "bf16x3" else "edgeconv_kernel<2, 4, 128"
+            pref = "edgeconv3_kernel" if eng.ec_mode in ("f16x2", "bf16x3") else "edgeconv_kernel<2, 4, 128"
             key = [k for k in pmc if k.startswith(pref)][0]
             roof["traffic"] = pmc[key]["hbm_bytes_per_launch"]
             roof["traffic_note"] = ("bytes per launch at 32 x 2048 from profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE x2 "
@@ -183,9 +190,9 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[1]: PU1K discrete x4 inference, 32 x 2048-pt patches per GPU "
-                                      "(fp32-parity mode)", "arithmetic": "fp32 results: f32 MFMA everywhere except the four 128-channel EdgeConv "
-                          "units, which use 3-term split-bf16 products on the bf16 MFMA pipe (fp32-class accuracy, "
-                          "PF_EC_MODE=f32 selects the bit-exact f32 MFMA kernel)", "patches_per_gpu": args.batch, "npoint": args.npoint,
+                                      "(fp32-parity mode)", "arithmetic": "fp32 inputs, accumulators and results; the dense layers run as 2-term split-fp16 "
+                          "products on the fp16 MFMA pipe (hi.hi + hi.lo + lo.hi, fp32-class accuracy: parity tests hold the "
+                          "same 1e-5 bar; PF_EC_MODE=bf16x3 / f32 select the split-bf16 / bit-exact f32 EdgeConv kernels)", "patches_per_gpu": args.batch, "npoint": args.npoint,
                           "upratio": 4, "sharding": f"patch batch over {world} rank(s), no data-path collective"},
                "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)

@@ -10,6 +10,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpuflow_hip.so")
 SOURCES = ["api.hip", "knn.hip", "edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip", "chamfer.hip", "emd.hip", "train_ops.hip", "patch_ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-result"]
+# The fused MFMA kernels never see NaNs; without the flag every fmaxf() is preceded by a canonicalising v_max x,x and
+# the DPP row-max steps stay as v_mov_dpp + v_max instead of one v_max_f32_dpp (3x the instructions of a max-pool).
+# No reassociation is enabled; the exact-order kernels (kNN, Chamfer, EMD, FPS, training ops) keep default semantics.
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs; the AGPR form hipcc picks under pressure costs one
+# v_accvgpr_read per accumulator register before any VALU use (every layer here) and halves the occupancy.
+EXTRA_FLAGS = {s: ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] for s in ("edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip")}
 
 
 def _stale(target: str, deps) -> bool:
@@ -34,7 +40,7 @@ def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") 
         o = os.path.join(objdir, os.path.basename(s).replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + [f"-D{d}" for d in defines] + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))

@@ -163,20 +163,55 @@ __global__ __launch_bounds__(NW * 64) void edgeconv_kernel(EcArgs a) {
     }
 }
 
-// ---- split-bf16 variant of the 128-channel units (GB = 2: one growth layer = one 32-channel block pair) ----
-// Same data flow as edgeconv_kernel; growth features are kept as (hi, mid, lo) bf16 B operands, the weights
-// come pre-split from the host (packing.frag_pack_bf16x3).  Accuracy: fp32-class (tests compare to the oracle
-// with the same 1e-5 bar); MFMA cycles per point: 264 x 16 instead of 352 x 32.
-template <int NCONV, int ODIM, int P, int NW, int DBG = 0>   // DBG (timing-only builds): 1 = no gathers, 2 = no MFMAs
+// ---- split-precision variants of the 128-channel units (GB = 2: one growth layer = one 32-channel block pair) ----
+// Same data flow as edgeconv_kernel; growth features are kept as pre-split B operands, the weights come pre-split
+// from the host.  NS = 3: split-bf16 (hi, mid, lo; six MFMAs per pair; packing.frag_pack_bf16x3);
+// NS = 2: split-fp16 (hi, lo' = lo * 2^11; three MFMAs per pair into a main and a cross accumulator;
+// packing.frag_pack_f16x2).  Accuracy of both: fp32-class (tests compare to the oracle with the same 1e-5 bar).
+// MFMA cycles per point: 264 x 16 (NS = 3) or 132 x 16 (NS = 2) instead of 352 x 32 for the f32 pipe.
+template <int NS> struct EcSplit;
+template <> struct EcSplit<3> {
+    using Pair = PfPair;
+    using WLds = PfW3Lds;
+    static __device__ __forceinline__ Pair make(f4 a, f4 b) { return pf_pair(a, b); }
+};
+template <> struct EcSplit<2> {
+    using Pair = PfPair2;
+    using WLds = PfW2Lds;
+    static __device__ __forceinline__ Pair make(f4 a, f4 b) { return pf_pair2(a, b); }
+};
+
+// acc[p][0..OB) += W feat over CP pairs, in the arithmetic of the split
+template <int NS, int OB, int CP, int WCP, class WS, class Pair, int P, int NIN>
+__device__ __forceinline__ void ec_mm(const WS& ws, int frag0, const Pair (&feat)[P][NIN], f4 (&acc)[P][OB]) {
+    if constexpr (NS == 3) {
+        pf_mm3<OB, CP, WCP>(ws, frag0, feat, 0, acc, 0);
+    } else {
+        f4 accx[P][OB];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int o = 0; o < OB; ++o) accx[p][o] = pf_splat(0.f);
+        pf_mm2<OB, CP, WCP>(ws, frag0, feat, 0, acc, accx, 0);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int o = 0; o < OB; ++o) acc[p][o] += accx[p][o] * PF_LO_INV;
+    }
+}
+
+template <int NCONV, int ODIM, int P, int NW, int DBG = 0, int NS = 3>   // DBG (timing-only builds): 1 = no gathers, 2 = no MFMAs
 __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
     constexpr int G = 32, S = G * NCONV + ODIM, OBO = ODIM / 16, OCH = 2;
-    constexpr int NWF = 2 * (NCONV * (NCONV - 1) / 2) + OBO * NCONV;      // (ob, pair) fragments, 3 KiB each
+    constexpr int NWF = 2 * (NCONV * (NCONV - 1) / 2) + OBO * NCONV;      // (ob, pair) fragments, NS KiB each
+    using SP = EcSplit<NS>;
+    using Pair = typename SP::Pair;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
-    __shared__ u4 wlds[NWF * 3 * 64];
-    for (int i = threadIdx.x; i < NWF * 3 * 64; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
+    __shared__ u4 wlds[NWF * NS * 64];
+    for (int i = threadIdx.x; i < NWF * NS * 64; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
     __syncthreads();
-    const PfW3Lds ws{wlds, lane};
+    const typename SP::WLds ws{wlds, lane};
 
     for (int v = blockIdx.x; v < 8 * a.chunk; v += gridDim.x) {
         const int tile = pf_xcd_tile(v, a.chunk);
@@ -205,10 +240,10 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
         };
         load_init(0, ini[0]);
         load_init(G, ini[1]);
-        PfPair feat[P][NCONV];
+        Pair feat[P][NCONV];
 #pragma unroll
         for (int p = 0; p < P; ++p)
-            feat[p][0] = pf_pair(pf_lrelu(ini[0][p][0], 0.05f), pf_lrelu(ini[0][p][1], 0.05f));
+            feat[p][0] = SP::make(pf_lrelu(ini[0][p][0], 0.05f), pf_lrelu(ini[0][p][1], 0.05f));
         pf_static_for<1, NCONV>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             load_init(G * (t + 1), ini[(t + 1) & 1]);                 // next growth layer, or conv_out chunk 0
@@ -217,10 +252,10 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
             for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][ob] = ini[t & 1][p][ob];
-            if constexpr (DBG != 2) pf_mm3<2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, 0, acc, 0);
+            if constexpr (DBG != 2) ec_mm<NS, 2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, acc);
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                feat[p][t] = pf_pair(pf_lrelu(acc[p][0], 0.05f), pf_lrelu(acc[p][1], 0.05f));
+                feat[p][t] = SP::make(pf_lrelu(acc[p][0], 0.05f), pf_lrelu(acc[p][1], 0.05f));
         });
         constexpr int FO = 2 * (NCONV * (NCONV - 1) / 2);
         f4 sel[P];
@@ -236,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
             for (int o = 0; o < OCH; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][o] = ini[st & 1][p][o];
-            if constexpr (DBG != 2) pf_mm3<OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, 0, acc, 0);
+            if constexpr (DBG != 2) ec_mm<NS, OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, acc);
 #pragma unroll
             for (int o = 0; o < OCH; ++o)
 #pragma unroll
@@ -254,14 +289,14 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
     }
 }
 
-template <int P, int NW, int DBG = 0>
+template <int P, int NW, int DBG = 0, int NS = 3>
 int launch3(const EcArgs& a0, hipStream_t s) {
     EcArgs a = a0;
     a.ntiles = (a.T + NW * P - 1) / (NW * P);
     a.chunk = (a.ntiles + 7) / 8;
     int grid = 8 * a.chunk;
-    if (grid > 256) grid = 256;                           // 132 KiB of LDS: one persistent workgroup per CU
-    hipLaunchKernelGGL((edgeconv3_kernel<4, 128, P, NW, DBG>), dim3(grid), dim3(NW * 64), 0, s, a);
+    if (grid > 256) grid = 256;                           // 132 / 88 KiB of LDS: one persistent workgroup per CU
+    hipLaunchKernelGGL((edgeconv3_kernel<4, 128, P, NW, DBG, NS>), dim3(grid), dim3(NW * 64), 0, s, a);
     return pf_last_launch_status();
 }
 
@@ -325,6 +360,16 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
 #endif
                 default: return PF_ERR_UNSUPPORTED;
             }
+        case 4:                                   // units 2..5, split-fp16 weights (packing: ec2h_w)
+            a.pq = pq_or_xyz;
+            switch (variant) {
+                case 0: return launch3<2, 8, 0, 2>(a, s);
+                case 1: return launch3<1, 8, 0, 2>(a, s);
+                case 2: return launch3<1, 16, 0, 2>(a, s);
+                case 3: return launch3<2, 4, 0, 2>(a, s);
+                case 4: return launch3<4, 4, 0, 2>(a, s);
+                default: return PF_ERR_UNSUPPORTED;
+            }
         default: return PF_ERR_UNSUPPORTED;
     }
 }
@@ -333,7 +378,7 @@ extern "C" int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, co
                            float* out, int B, int N, void* stream) {
     // shipped variants (tools/tune_edgeconv.py, MI355X): unit 0 -> (P=2, NW=8); unit 1 -> (1, 8);
     // units 2..5 -> (1, 16): one point per wave, 16 waves share the 88 KiB of LDS-resident weights.
-    static const int best[4] = {0, 2, 3, 0};
-    if (cfg < 0 || cfg > 3) return PF_ERR_UNSUPPORTED;
+    static const int best[5] = {0, 2, 3, 0, 0};
+    if (cfg < 0 || cfg > 4) return PF_ERR_UNSUPPORTED;
     return pf_edgeconv_tuned(cfg, best[cfg], pq_or_xyz, tab, idx, wfrag, out, B, N, stream);
 }

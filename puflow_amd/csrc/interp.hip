@@ -7,22 +7,25 @@
 // context never exists, not even in registers: both producers end in a linear layer (DistanceEncoder's
 // last conv, the EdgeConv's conv_out) that feeds the weight unit's first conv with no nonlinearity in
 // between (interpflow.py:134,144), so the host composes them (packing.fold_state_dict):
-//     w1 = [b0 + W0a b6] + (W0a W6) d2 + (W0b Gout) feat + W0b (PA x_i + QB x_j + pb)
-// -> 704 MFMAs per tile instead of 1216.  Only the first R rows of the last weight conv are
-// computed (interpflow.py:180).
+//     w1 = (W0a W6) d2 + (W0b Gout) feat + [W0b (PA x_i + QB x_j + pb) + b0 + W0a b6]
+// Every term that is affine in the edge's raw inputs e = (x_i, x_j, |x_i - x_j|, 1) - the distance encoder's first
+// layer, the EdgeConv pre-activations, the bracket above - is one MFMA step against an 8-column "edge table"
+// (e occupies 8 of the 32 k-slots).  Only the first R rows of the last weight conv are computed (interpflow.py:180).
+// Arithmetic: split-fp16 products (pf_mfma.h "f16x2"), fp32-class accuracy; 91 fragment pairs = 273 fp16 MFMAs
+// per tile where the unfolded f32 formulation needs 1216.
 //
-// Weight blob (float offsets in `off[]`, see puflow_amd/packing.py::INTERP_SLOTS):
-//   0 dtab [64][8] (PA(3) QB(3) wn b0)   1 d_W3 frags [4x4]  2 d_b3 [64]  3 (W0a W6) frags [8x4]  4 b0 + W0a b6 [128]
-//   5 ectab [256][8] (PA(3) QB(3) pb 0; rows 0..127 used)    6 ec G1..G7 frags   7 (W0b Gout) frags [8x8]
-//   8 w1tab [128][8] = W0b.(edge table rows 128..255)        9 w_W3 frags [4x8]  10 w_b3 [64]
-//   11 w_W6 frags [1x4] (R rows replicated per q group)      12 w_b6 [16]
+// Weight blob (float offsets in `off[]`, see puflow_amd/packing.py::INTERP_SLOTS); matrices are f16x2 fragment images:
+//   0 dtab [64 x e]        1 d_W3 [64 x 64]     2 d_b3 [64] f32      3 (W0a W6) [128 x 64]    4 reserved
+//   5 ectab [128 x e]      6 ec G1..G7 (16 pair fragments; layer t starts at fragment floor(t/2) * ceil(t/2))
+//   7 (W0b Gout) [128 x 128]   8 w1tab [128 x e] (bracket above)   9 w_W3 [64 x 128]  10 w_b3 [64] f32
+//   11 w_W6 [16 x 64] (R rows replicated per q group)   12 w_b6 [16] f32
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
 
 // tuned on MI355X with tools/tune_variants.py (P = column tiles per wave, NW = waves per workgroup)
 #ifndef PF_INTERP_P
-#define PF_INTERP_P 2
+#define PF_INTERP_P 1
 #endif
 #ifndef PF_INTERP_NW
 #define PF_INTERP_NW 8
@@ -46,107 +49,139 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
     const int ps = col >> 3, k = col & 7;
-    const float* dtab = a.w + a.off[0];
-    const float* ectab = a.w + a.off[5];
-    const PfWBuf wsD3(a.w + a.off[1], lane), wsD6(a.w + a.off[3], lane), wsEC(a.w + a.off[6], lane),
-        wsW0(a.w + a.off[7], lane), wsW3(a.w + a.off[9], lane), wsW6(a.w + a.off[11], lane);
+    // the small, latency-critical matrices (edge tables, d_W3, the 7-step growth chain) live in LDS for the whole
+    // persistent workgroup: 44 fragments x 2 KiB; the three big ones stream from L2 with a deep prefetch
+    constexpr int L_DT = 0, L_ET = 4, L_WT = 12, L_D3 = 20, L_EC = 28, L_END = 44;
+    __shared__ u4 wl[L_END * 128];
+    {
+        auto stage = [&](int f0, int nf, long long off) {
+            const u4* src = reinterpret_cast<const u4*>(a.w + off);
+            for (int i = threadIdx.x; i < nf * 128; i += blockDim.x) wl[f0 * 128 + i] = src[i];
+        };
+        stage(L_DT, 4, a.off[0]); stage(L_ET, 8, a.off[5]); stage(L_WT, 8, a.off[8]); stage(L_D3, 8, a.off[1]);
+        stage(L_EC, 16, a.off[6]);
+        __syncthreads();
+    }
+    const PfW2Lds wsDT{wl + L_DT * 128, lane}, wsET{wl + L_ET * 128, lane}, wsWT{wl + L_WT * 128, lane},
+        wsD3{wl + L_D3 * 128, lane}, wsEC{wl + L_EC * 128, lane};
+    const PfW2Buf wsD6(a.w + a.off[3], lane), wsW0(a.w + a.off[7], lane), wsW3(a.w + a.off[9], lane),
+        wsW6(a.w + a.off[11], lane);
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int pt0 = (tile * NW + wave) * P * 2;
         int gi[P], gj[P];
         bool ok[P];
-        float xi[P][3], xj[P][3], nrm[P];
+        PfPair2 e[P][1];                 // raw edge inputs (x_i, x_j, |x_i - x_j|, 1) in k-slots 0..7 (lanes q = 0)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int g = pt0 + p * 2 + ps;
             ok[p] = g < a.T;
             gi[p] = ok[p] ? g : a.T - 1;
             gj[p] = (gi[p] / a.N) * a.N + a.idx[(size_t)gi[p] * 16 + k];
+            float xi[3], xj[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                xi[p][c] = a.xyz[(size_t)gi[p] * 3 + c];
-                xj[p][c] = a.xyz[(size_t)gj[p] * 3 + c];
+                xi[c] = a.xyz[(size_t)gi[p] * 3 + c];
+                xj[c] = a.xyz[(size_t)gj[p] * 3 + c];
             }
-            const float v0 = xi[p][0] - xj[p][0], v1 = xi[p][1] - xj[p][1], v2 = xi[p][2] - xj[p][2];
-            nrm[p] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(v0, v0), __fmul_rn(v1, v1)), __fmul_rn(v2, v2)));
+            const float v0 = xi[0] - xj[0], v1 = xi[1] - xj[1], v2 = xi[2] - xj[2];
+            const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(v0, v0), __fmul_rn(v1, v1)), __fmul_rn(v2, v2)));
+            const f4 z4 = pf_splat(0.f);
+            const f4 e0 = {xi[0], xi[1], xi[2], xj[0]}, e1 = {xj[1], xj[2], nrm, 1.f};
+            e[p][0] = pf_pair2(q == 0 ? e0 : z4, q == 0 ? e1 : z4);
         }
-        // rows [off, off+4) of a [*, 8] table: b + PA.xi + QB.xj (+ wn*|xi-xj| when NRM)
-        auto tabrow = [&](const float* tab, int p, int off, bool use_nrm) -> f4 {
-            f4 r;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const f4* t = reinterpret_cast<const f4*>(tab + (size_t)(off + kk) * 8);
-                const f4 t0 = t[0], t1 = t[1];
-                float s = use_nrm ? fmaf(t1.z, nrm[p], t1.w) : t1.z;
-                s = fmaf(t0.x, xi[p][0], s); s = fmaf(t0.y, xi[p][1], s); s = fmaf(t0.z, xi[p][2], s);
-                s = fmaf(t0.w, xj[p][0], s); s = fmaf(t1.x, xj[p][1], s); s = fmaf(t1.y, xj[p][2], s);
-                r[kk] = s;
-            }
-            return r;
-        };
 
         // ---- distance encoder 10 -> 64 -> 64, then its (folded) contribution to the weight unit's first layer
         f4 w1[P][8];
         {
-            f4 d1[P][4], d2[P][4];
+            f4 d[P][4];
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    d1[p][cb] = pf_lrelu(tabrow(dtab, p, cb * 16 + 4 * q, true), 0.01f);
-                    d2[p][cb] = pf_bias(a.w + a.off[2], cb, q);
-                }
-            pf_mm<4, 4, 4>(wsD3, 0, d1, 0, d2, 0);
+                for (int p = 0; p < P; ++p) d[p][cb] = pf_splat(0.f);
+            pf_mm2f<4, 1, 1>(wsDT, 0, e, 0, d, 0);
+            PfPair2 dp[P][2];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                dp[p][0] = pf_pair2(pf_lrelu(d[p][0], 0.01f), pf_lrelu(d[p][1], 0.01f));
+                dp[p][1] = pf_pair2(pf_lrelu(d[p][2], 0.01f), pf_lrelu(d[p][3], 0.01f));
+            }
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-                for (int p = 0; p < P; ++p) d2[p][cb] = pf_lrelu(d2[p][cb], 0.01f);
-            // w1 = (b0 + W0a b6) + W0b.(edge table) + (W0a W6) d2
+                for (int p = 0; p < P; ++p) d[p][cb] = pf_bias(a.w + a.off[2], cb, q);
+            pf_mm2f<4, 2, 2>(wsD3, 0, dp, 0, d, 0);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                dp[p][0] = pf_pair2(pf_lrelu(d[p][0], 0.01f), pf_lrelu(d[p][1], 0.01f));
+                dp[p][1] = pf_pair2(pf_lrelu(d[p][2], 0.01f), pf_lrelu(d[p][3], 0.01f));
+            }
+            // w1 = [b0 + W0a b6 + W0b.(edge table)] e + (W0a W6) d2
 #pragma unroll
             for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
-                for (int p = 0; p < P; ++p)
-                    w1[p][ob] = pf_bias(a.w + a.off[4], ob, q) + tabrow(a.w + a.off[8], p, ob * 16 + 4 * q, false);
-            pf_mm<8, 4, 4>(wsD6, 0, d2, 0, w1, 0);
+                for (int p = 0; p < P; ++p) w1[p][ob] = pf_splat(0.f);
+            pf_mm2f<8, 1, 1>(wsWT, 0, e, 0, w1, 0);
+            pf_mm2f<8, 2, 2>(wsD6, 0, dp, 0, w1, 0);
         }
 
         // ---- EdgeConv growth features (C=3, g=16, 8 convs) on the same 8 neighbours; conv_out is folded into w1
         {
-            f4 feat[P][8];
+            f4 pre[P][8];                      // pre-activations from the raw inputs: rows 16t.. of the edge table
 #pragma unroll
-            for (int p = 0; p < P; ++p) feat[p][0] = pf_lrelu(tabrow(ectab, p, 4 * q, false), 0.05f);
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int p = 0; p < P; ++p) pre[p][t] = pf_splat(0.f);
+            pf_mm2f<8, 1, 1>(wsET, 0, e, 0, pre, 0);
+            f4 feat[P][8];
+            PfPair2 fp[P][4];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                feat[p][0] = pf_lrelu(pre[p][0], 0.05f);
+                fp[p][0] = pf_pair2(feat[p][0], pf_splat(0.f));
+            }
             pf_static_for<1, 8>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
+                constexpr int CPT = (t + 1) / 2;                     // input pairs of growth layer t
+                constexpr int F0 = (t / 2) * ((t + 1) / 2);          // fragments of layers 1..t-1: sum ceil(s/2)
                 f4 acc[P][1];
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[p][0] = tabrow(ectab, p, 16 * t + 4 * q, false);
-                pf_mm<1, t, t>(wsEC, t * (t - 1) / 2, feat, 0, acc, 0);
+                for (int p = 0; p < P; ++p) acc[p][0] = pre[p][t];
+                pf_mm2f<1, CPT, CPT>(wsEC, F0, fp, 0, acc, 0);
 #pragma unroll
-                for (int p = 0; p < P; ++p) feat[p][t] = pf_lrelu(acc[p][0], 0.05f);
+                for (int p = 0; p < P; ++p) {
+                    feat[p][t] = pf_lrelu(acc[p][0], 0.05f);
+                    if constexpr (t % 2 == 1) fp[p][t / 2] = pf_pair2(feat[p][t - 1], feat[p][t]);
+                    else fp[p][t / 2] = pf_pair2(feat[p][t], pf_splat(0.f));
+                }
             });
-            pf_mm<8, 8, 8>(wsW0, 0, feat, 0, w1, 0);              // w1 += (W0b Gout) feat
+            pf_mm2f<8, 4, 4>(wsW0, 0, fp, 0, w1, 0);               // w1 += (W0b Gout) feat
         }
 
         // ---- rest of the weight unit: 128 -> 64 -> R
         f4 w3[P][1];
         {
+            PfPair2 w1p[P][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    w1p[p][c] = pf_pair2(pf_lrelu(w1[p][2 * c], 0.01f), pf_lrelu(w1[p][2 * c + 1], 0.01f));
             f4 w2[P][4];
-#pragma unroll
-            for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-                for (int p = 0; p < P; ++p) w1[p][ob] = pf_lrelu(w1[p][ob], 0.01f);
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
                 for (int p = 0; p < P; ++p) w2[p][ob] = pf_bias(a.w + a.off[10], ob, q);
-            pf_mm<4, 8, 8>(wsW3, 0, w1, 0, w2, 0);
+            pf_mm2f<4, 4, 4>(wsW3, 0, w1p, 0, w2, 0);
+            PfPair2 w2p[P][2];
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-                for (int p = 0; p < P; ++p) w2[p][ob] = pf_lrelu(w2[p][ob], 0.01f);
+            for (int p = 0; p < P; ++p) {
+                w2p[p][0] = pf_pair2(pf_lrelu(w2[p][0], 0.01f), pf_lrelu(w2[p][1], 0.01f));
+                w2p[p][1] = pf_pair2(pf_lrelu(w2[p][2], 0.01f), pf_lrelu(w2[p][3], 0.01f));
+            }
 #pragma unroll
             for (int p = 0; p < P; ++p) w3[p][0] = *reinterpret_cast<const f4*>(a.w + a.off[12] + 4 * q);
-            pf_mm<1, 4, 4>(wsW6, 0, w2, 0, w3, 0);
+            pf_mm2f<1, 2, 2>(wsW6, 0, w2p, 0, w3, 0);
         }
 
         // ---- softmax over the 8 neighbours (lanes k = 0..7 of the point), then weighted latent sum
@@ -158,10 +193,10 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
                 const float x = w3[p][0][r];
                 float m = x;
                 m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
-                const float e = expf(x - m);
-                float s = e;
+                const float ex = expf(x - m);
+                float s = ex;
                 s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-                av[r] = e / s;
+                av[r] = ex / s;
             }
             const float zj = a.z[(size_t)gj[p] * 3 + (q < 3 ? q : 0)];      // lane q handles latent channel q
 #pragma unroll
@@ -186,7 +221,7 @@ extern "C" int pf_interp(const float* xyz, const float* z, const int* idx16, con
     a.xyz = xyz; a.z = z; a.idx = idx16; a.w = w; a.u = u_out; a.T = B * N; a.N = N; a.R = R;
     for (int i = 0; i < 13; ++i) a.off[i] = off[i];
     a.ntiles = (a.T + NW * P * 2 - 1) / (NW * P * 2);
-    const int grid = a.ntiles < 4096 ? a.ntiles : 4096;
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;         // persistent: 88 KiB of LDS = one workgroup per CU
     hipLaunchKernelGGL((interp_kernel<P, NW>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, a);
     return pf_last_launch_status();
 }

@@ -26,12 +26,12 @@ __device__ __forceinline__ f4 pf_mfma(float a, float b, f4 c) {
 
 __device__ __forceinline__ f4 pf_splat(float v) { f4 r = {v, v, v, v}; return r; }
 
+// leaky ReLU for 0 <= slope <= 1 as max(x, slope * x): same bits as the select form (x >= 0 ? x : slope * x)
+// for every finite x including -0, one packed multiply + one max per value instead of compare + multiply + select
 __device__ __forceinline__ f4 pf_lrelu(f4 v, float slope) {
+    const f4 s = v * slope;
     f4 r;
-    r.x = v.x >= 0.f ? v.x : v.x * slope;
-    r.y = v.y >= 0.f ? v.y : v.y * slope;
-    r.z = v.z >= 0.f ? v.z : v.z * slope;
-    r.w = v.w >= 0.f ? v.w : v.w * slope;
+    r.x = fmaxf(v.x, s.x); r.y = fmaxf(v.y, s.y); r.z = fmaxf(v.z, s.z); r.w = fmaxf(v.w, s.w);
     return r;
 }
 
@@ -41,7 +41,7 @@ __device__ __forceinline__ f4 pf_relu(f4 v) {
     return r;
 }
 
-__device__ __forceinline__ float pf_lrelu1(float v, float slope) { return v >= 0.f ? v : v * slope; }
+__device__ __forceinline__ float pf_lrelu1(float v, float slope) { return fmaxf(v, v * slope); }
 
 // ---- weight fragment sources -----------------------------------------------------------
 // Every lane-address of a weight fragment is (wave-uniform base) + lane*16.  hipcc otherwise
@@ -194,6 +194,126 @@ __device__ __forceinline__ void pf_mm3(const WS3& ws, int frag0, const PfPair (&
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// ---- split-fp16 ("f16x2") path: fp32 accuracy in THREE fp16 MFMAs per 32-channel step ---------------
+// x = hi + lo' * 2^-11 with hi = rne_f16(x) and lo' = rne_f16((x - hi) * 2^11): x - hi is exact in fp32 and at most
+// half an fp16 ulp of x, so lo' never exceeds |x| (no overflow from the scale), is a normal fp16 number whenever x
+// is (precision independent of magnitude) and hi + lo' 2^-11 carries 22+ significant bits.  A product keeps
+// hi.hi in the main accumulator and hi.lo' + lo'.hi in a second one that is folded in as  acc + accx * 2^-11;
+// the dropped lo.lo term is < 2^-24 relative.  gfx950's fp16 MFMA honours subnormal operands (probed), so tiny
+// values degrade gracefully.  Range: |x| must stay below 65504 (fp16 max) - activations of this network are O(1..100);
+// beyond it the result is inf/NaN (loud), and PF_EC_MODE=bf16x3 / f32 remain available.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+constexpr float PF_LO_SCALE = 2048.f, PF_LO_INV = 1.f / 2048.f;
+
+__device__ __forceinline__ u2 pf_split2_pair(float a, float b) {
+    unsigned hb = __builtin_bit_cast(unsigned, (h2){(_Float16)a, (_Float16)b});
+    asm("" : "+v"(hb));          // opaque: read hi back from the packed register instead of converting twice
+    const h2 h = __builtin_bit_cast(h2, hb);
+    const h2 l = {(_Float16)((a - (float)h.x) * PF_LO_SCALE), (_Float16)((b - (float)h.y) * PF_LO_SCALE)};
+    return (u2){hb, __builtin_bit_cast(unsigned, l)};
+}
+
+struct PfPair2 { h8 h, l; };
+__device__ __forceinline__ PfPair2 pf_pair2(f4 b0, f4 b1) {
+    const u2 s0 = pf_split2_pair(b0.x, b0.y), s1 = pf_split2_pair(b0.z, b0.w);
+    const u2 s2 = pf_split2_pair(b1.x, b1.y), s3 = pf_split2_pair(b1.z, b1.w);
+    PfPair2 p;
+    p.h = __builtin_bit_cast(h8, (u4){s0.x, s1.x, s2.x, s3.x});
+    p.l = __builtin_bit_cast(h8, (u4){s0.y, s1.y, s2.y, s3.y});
+    return p;
+}
+
+__device__ __forceinline__ f4 pf_mfma_f16(h8 a, h8 b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+#ifndef PF_MM2_DEPTH
+#define PF_MM2_DEPTH 8
+#endif
+// weights: [frag][2 splits hi / lo'][64 lanes] x 16 B in LDS
+struct PfW2Lds {
+    static constexpr int DEPTH = 2;          // fragments in flight (pf_mm2f): LDS latency
+    const u4* base;
+    int lane;
+    __device__ __forceinline__ h8 load(int frag, int split) const {
+        return __builtin_bit_cast(h8, base[(frag * 2 + split) * PF_WAVE + lane]);
+    }
+};
+
+struct PfW2Buf {
+    static constexpr int DEPTH = PF_MM2_DEPTH;   // L2 latency wants ~500 cycles of MFMA work in flight
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;           // lane * 16
+    __device__ __forceinline__ PfW2Buf(const void* p, int lane)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000)), voff(lane * 16) {}
+    __device__ __forceinline__ h8 load(int frag, int split) const {
+        return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (frag * 2 + split) * (PF_WAVE * 16), 0));
+    }
+};
+
+// acc[p][acc0+ob] += Wh xh ;  accx[p][acc0+ob] += Wh xl' + Wl' xh   over block PAIRS cp < CP.
+// Caller folds:  value = acc + accx * PF_LO_INV.  D fragments (two 16-B reads each) are kept in flight: 2 is enough
+// for LDS-resident weights, L2-resident weights behind buffer loads want ~500 cycles of cover (PF_MM2_DEPTH).
+template <int OB, int CP, int WCP, int D = 2, class WS2, int P, int NIN, int NACC>
+__device__ __forceinline__ void pf_mm2(const WS2& ws, int frag0, const PfPair2 (&in)[P][NIN], int in0,
+                                       f4 (&acc)[P][NACC], f4 (&accx)[P][NACC], int acc0) {
+    constexpr int NFRAG = OB * CP;
+    constexpr int DD = D < NFRAG ? D : NFRAG;
+    h8 wb[DD][2];
+#pragma unroll
+    for (int i = 0; i < DD; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wb[i][s] = ws.load(frag0 + (i / CP) * WCP + (i % CP), s);
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) {
+        const int ob = i / CP, cp = i % CP;
+        const h8 wh = wb[i % DD][0], wl = wb[i % DD][1];
+        if (i + DD < NFRAG) {
+            const int f = frag0 + ((i + DD) / CP) * WCP + ((i + DD) % CP);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) wb[i % DD][s] = ws.load(f, s);
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            f4 x = accx[p][acc0 + ob];
+            x = pf_mfma_f16(wh, in[p][in0 + cp].l, x);
+            x = pf_mfma_f16(wl, in[p][in0 + cp].h, x);
+            accx[p][acc0 + ob] = x;
+            acc[p][acc0 + ob] = pf_mfma_f16(wh, in[p][in0 + cp].h, acc[p][acc0 + ob]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// NB 16-channel blocks in[p][in0 .. in0+NB) -> (NB+1)/2 split block pairs (an odd tail pairs with a zero block)
+template <int NB, int P, int NIN>
+__device__ __forceinline__ void pf_pairs2(const f4 (&in)[P][NIN], int in0, PfPair2 (&out)[P][(NB + 1) / 2]) {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int c = 0; c < (NB + 1) / 2; ++c)
+            out[p][c] = pf_pair2(in[p][in0 + 2 * c], 2 * c + 1 < NB ? in[p][in0 + 2 * c + 1] : pf_splat(0.f));
+}
+
+// acc[p][acc0+ob] += W[ob][cp] in[p][cp] with the cross accumulator folded in (complete split-fp16 product)
+template <int OB, int CP, int WCP, class WS2, int P, int NIN, int NACC>
+__device__ __forceinline__ void pf_mm2f(const WS2& ws, int frag0, const PfPair2 (&in)[P][NIN], int in0,
+                                        f4 (&acc)[P][NACC], int acc0) {
+    f4 accx[P][OB];
+    f4 accm[P][OB];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int o = 0; o < OB; ++o) { accx[p][o] = pf_splat(0.f); accm[p][o] = acc[p][acc0 + o]; }
+    pf_mm2<OB, CP, WCP, WS2::DEPTH>(ws, frag0, in, in0, accm, accx, 0);
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int o = 0; o < OB; ++o) acc[p][acc0 + o] = accm[p][o] + accx[p][o] * PF_LO_INV;
 }
 
 // cooperative global -> LDS copy of `nf4` float4 by the whole workgroup (call before a __syncthreads)

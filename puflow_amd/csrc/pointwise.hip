@@ -7,7 +7,9 @@
 //                                                    f and by the R replicas of g
 //   cp  = W0[:, tdim:] c                             c-part of coupling1's first layer (interpflow.py:38-41)
 //   PQ' = Wpq h + bpq                                next unit's per-point EdgeConv vectors (packing.py)
-// MFMA columns = 16 points; all intermediates stay in registers (pf_mfma.h layout).
+// MFMA columns = 16 points; all intermediates stay in registers (pf_mfma.h layout).  Arithmetic: split-fp16
+// products (pf_mfma.h "f16x2": three fp16 MFMAs per 32-channel step, fp32-class accuracy); weights arrive
+// pre-split from the host (packing.frag_pack_f16x2) and stream through buffer loads (they stay in L1/L2).
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
@@ -40,36 +42,44 @@ struct PostArgs {
 template <int ODIM, int CDIM, int SNEXT, int P, int NW>
 __global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
     constexpr int HB = ODIM / 16, MB = ODIM / 32, CB = CDIM / 16;
+    constexpr int HP = (HB + 1) / 2, MP = (MB + 1) / 2;              // block pairs (32 input channels per MFMA step)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
-    const PfWBuf wsPQ(a.wPQ, lane), wsM1(a.wM1, lane), wsM2(a.wM2, lane), wsH1(a.wH1, lane), wsS2(a.wS2, lane),
+    const PfW2Buf wsPQ(a.wPQ, lane), wsM1(a.wM1, lane), wsM2(a.wM2, lane), wsH1(a.wH1, lane), wsS2(a.wS2, lane),
         wsT2(a.wT2, lane), wsST4(a.wST4, lane);
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int pt0 = (tile * NW + wave) * P * 16;
         int pt[P];
         bool ok[P];
-        f4 h[P][HB];
+        PfPair2 hp[P][HP];
+        {
+            f4 h[P][HB];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const int g = pt0 + p * 16 + col;
-            ok[p] = g < a.T;
-            pt[p] = ok[p] ? g : a.T - 1;
+            for (int p = 0; p < P; ++p) {
+                const int g = pt0 + p * 16 + col;
+                ok[p] = g < a.T;
+                pt[p] = ok[p] ? g : a.T - 1;
 #pragma unroll
-            for (int b = 0; b < HB; ++b)
-                h[p][b] = *reinterpret_cast<const f4*>(a.h + (size_t)pt[p] * ODIM + b * 16 + 4 * q);
+                for (int b = 0; b < HB; ++b)
+                    h[p][b] = *reinterpret_cast<const f4*>(a.h + (size_t)pt[p] * ODIM + b * 16 + 4 * q);
+            }
+            pf_pairs2<HB>(h, 0, hp);
         }
 
         // ---- next unit's P|Q vectors
         if constexpr (SNEXT > 0) {
             pf_static_for<0, (2 * SNEXT) / 32>([&](auto cc) {
                 constexpr int ob0 = decltype(cc)::value * 2;
+#ifdef PF_POST_SYNC
+                if constexpr (decltype(cc)::value % PF_POST_SYNC == 0) __syncthreads();   // waves stream the weights in step -> L1 hits
+#endif
                 f4 acc[P][2];
 #pragma unroll
                 for (int o = 0; o < 2; ++o)
 #pragma unroll
                     for (int p = 0; p < P; ++p) acc[p][o] = pf_bias(a.bPQ, ob0 + o, q);
-                pf_mm<2, HB, HB>(wsPQ, ob0 * HB, h, 0, acc, 0);
+                pf_mm2f<2, HP, HP>(wsPQ, ob0 * HP, hp, 0, acc, 0);
 #pragma unroll
                 for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -80,16 +90,20 @@ __global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
         }
 
         // ---- merge MLP
-        f4 m[P][MB];
+        PfPair2 mp[P][MP];
+        {
+            f4 m[P][MB];
 #pragma unroll
-        for (int o = 0; o < MB; ++o)
+            for (int o = 0; o < MB; ++o)
 #pragma unroll
-            for (int p = 0; p < P; ++p) m[p][o] = pf_bias(a.b1, o, q);
-        pf_mm<MB, HB, HB>(wsM1, 0, h, 0, m, 0);
+                for (int p = 0; p < P; ++p) m[p][o] = pf_bias(a.b1, o, q);
+            pf_mm2f<MB, HP, HP>(wsM1, 0, hp, 0, m, 0);
 #pragma unroll
-        for (int o = 0; o < MB; ++o)
+            for (int o = 0; o < MB; ++o)
 #pragma unroll
-            for (int p = 0; p < P; ++p) m[p][o] = pf_relu(m[p][o]);
+                for (int p = 0; p < P; ++p) m[p][o] = pf_relu(m[p][o]);
+            pf_pairs2<MB>(m, 0, mp);
+        }
 
         // c = W2 m is only materialised when the caller wants `cs` (feat_extract API): everything downstream of c
         // is linear in it, so the host folded W2 into those layers (H1 := [s_W0; t_W0; c1_W0c] W2, packing.pack_plan)
@@ -99,7 +113,7 @@ __global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
             for (int o = 0; o < CB; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) c[p][o] = pf_splat(0.f);
-            pf_mm<CB, MB, MB>(wsM2, 0, m, 0, c, 0);
+            pf_mm2f<CB, MP, MP>(wsM2, 0, mp, 0, c, 0);
 #pragma unroll
             for (int o = 0; o < CB; ++o)
 #pragma unroll
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
             for (int o = 0; o < 4; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][o] = pf_splat(0.f);
-            pf_mm<4, MB, MB>(wsH1, 8 * MB, m, 0, acc, 0);
+            pf_mm2f<4, MP, MP>(wsH1, 8 * MP, mp, 0, acc, 0);
 #pragma unroll
             for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -122,8 +136,8 @@ __global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
                     if (ok[p]) *reinterpret_cast<f4*>(a.cp + (size_t)pt[p] * 64 + o * 16 + 4 * q) = acc[p][o];
         }
 
-        // ---- injector nets: hidden1 -> hidden2 for s (blocks 0..3) and t (blocks 4..7)
-        f4 h2[P][8];
+        // ---- injector nets: hidden1 -> hidden2 for s (pairs 0..1) and t (pairs 2..3)
+        PfPair2 h2p[P][4];
         pf_static_for<0, 2>([&](auto nc) {
             constexpr int net = decltype(nc)::value;
             f4 h1[P][4];
@@ -131,25 +145,29 @@ __global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
             for (int o = 0; o < 4; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) h1[p][o] = pf_splat(0.f);
-            pf_mm<4, MB, MB>(wsH1, (4 * net) * MB, m, 0, h1, 0);
+            pf_mm2f<4, MP, MP>(wsH1, (4 * net) * MP, mp, 0, h1, 0);
+            f4 h2[P][4];
 #pragma unroll
             for (int o = 0; o < 4; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     h1[p][o] = pf_lrelu(h1[p][o], 0.01f);
-                    h2[p][4 * net + o] = pf_bias(net == 0 ? a.bS2 : a.bT2, o, q);
+                    h2[p][o] = pf_bias(net == 0 ? a.bS2 : a.bT2, o, q);
                 }
-            if constexpr (net == 0) pf_mm<4, 4, 4>(wsS2, 0, h1, 0, h2, 0); else pf_mm<4, 4, 4>(wsT2, 0, h1, 0, h2, 4);
+            PfPair2 h1p[P][2];
+            pf_pairs2<4>(h1, 0, h1p);
+            if constexpr (net == 0) pf_mm2f<4, 2, 2>(wsS2, 0, h1p, 0, h2, 0); else pf_mm2f<4, 2, 2>(wsT2, 0, h1p, 0, h2, 0);
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-#pragma unroll
-                for (int p = 0; p < P; ++p) h2[p][4 * net + o] = pf_lrelu(h2[p][4 * net + o], 0.01f);
+            for (int p = 0; p < P; ++p) {
+                h2p[p][2 * net + 0] = pf_pair2(pf_lrelu(h2[p][0], 0.01f), pf_lrelu(h2[p][1], 0.01f));
+                h2p[p][2 * net + 1] = pf_pair2(pf_lrelu(h2[p][2], 0.01f), pf_lrelu(h2[p][3], 0.01f));
+            }
         });
         {
             f4 acc[P][1];
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[p][0] = pf_bias(a.bST4, 0, q);
-            pf_mm<1, 8, 8>(wsST4, 0, h2, 0, acc, 0);
+            pf_mm2f<1, 4, 4>(wsST4, 0, h2p, 0, acc, 0);
 #pragma unroll
             for (int p = 0; p < P; ++p)
                 if (ok[p] && q < 2) *reinterpret_cast<f4*>(a.st + (size_t)pt[p] * 8 + 4 * q) = acc[p][0];

@@ -25,6 +25,7 @@ from . import _lib
 from .packing import COND_CHANNELS, FEAT_CHANNELS, GROWTH, NUM_BLOCKS, fold_state_dict, pack_plan
 
 _EC_CFG = [0, 1, 2, 2, 2, 2]
+_EC_SPLIT = {"bf16x3": (3, "ec3_w"), "f16x2": (4, "ec2h_w")}     # PF_EC_MODE -> (pf_edgeconv cfg, weight image)
 
 
 # ----------------------------------------------------------------------------------------
@@ -136,11 +137,15 @@ class _Engine:
         self.ec_tab0 = pk["ec_tab0"]
         self.ec_w = pk["ec_w"]
         self.ec3_w = pk["ec3_w"]
-        # EdgeConv arithmetic of the 128-channel units: "bf16x3" (default) = 3-term split-bf16 products on the bf16
-        # matrix pipe, fp32-class accuracy (measured 1.1e-6 from the exact kernel, same 1e-5 parity bar), 1.4x faster;
-        # "f32" = v_mfma_f32_16x16x4_f32, bit-exact fp32 fma chain (PF_EC_MODE=f32)
-        self.ec_mode = os.environ.get("PF_EC_MODE", "bf16x3")
-        self.ec3_variant = int(os.environ.get("PF_EC3_VARIANT", "0"))   # launch shape of edgeconv3_kernel (tuning knob)
+        self.ec2h_w = pk["ec2h_w"]
+        # EdgeConv arithmetic of the 128-channel units (PF_EC_MODE), all within the same 1e-5 parity bar:
+        #   "f16x2" (default)  2-term split-fp16 products, three fp16 MFMAs per 32-channel step (8e-7 from the exact
+        #                      kernel); needs |activation| < 65504 - beyond that the output is inf/NaN, never silently wrong
+        #   "bf16x3"           3-term split-bf16 products, six bf16 MFMAs per step (1.1e-6), fp32 exponent range
+        #   "f32"              v_mfma_f32_16x16x4_f32, bit-exact fp32 fma chain
+        self.ec_mode = os.environ.get("PF_EC_MODE", "f16x2")
+        # launch shape of edgeconv3_kernel (tuning knob; tools/tune_edgeconv.py): (P=1, NW=16) for f16x2
+        self.ec3_variant = int(os.environ.get("PF_EC3_VARIANT", "2" if self.ec_mode == "f16x2" else "0"))
         self.post = [_lib.offsets(o) for o in pk["post"]]
         self.flow = pk["flow"]
         self.interp_off = _lib.offsets(pk["interp"])
@@ -173,9 +178,11 @@ class _Engine:
             h = torch.empty((T, odim), dtype=torch.float32, device=dev)
             src = xyz.data_ptr() if u == 0 else pq.data_ptr()
             tab = self._p(self.ec_tab0) if u == 0 else None
-            if u >= 2 and self.ec_mode == "bf16x3":
-                _lib.check(self.lib.pf_edgeconv_tuned(3, self.ec3_variant, src, None, idx16.data_ptr(), self._p(self.ec3_w[u]),
-                                                      h.data_ptr(), B, N, s), f"pf_edgeconv3[{u}]")
+            if u >= 2 and self.ec_mode in _EC_SPLIT:
+                cfg, wname = _EC_SPLIT[self.ec_mode]
+                _lib.check(self.lib.pf_edgeconv_tuned(cfg, self.ec3_variant, src, None, idx16.data_ptr(),
+                                                      self._p(getattr(self, wname)[u]), h.data_ptr(), B, N, s),
+                           f"pf_edgeconv[{self.ec_mode}][{u}]")
             else:
                 _lib.check(self.lib.pf_edgeconv(_EC_CFG[u], src, tab, idx16.data_ptr(), self._p(self.ec_w[u]),
                                                 h.data_ptr(), B, N, s), f"pf_edgeconv[{u}]")
@@ -240,9 +247,11 @@ class _Engine:
                 h = torch.empty((T, FEAT_CHANNELS[u + 1]), dtype=torch.float32, device=dev)
                 src = xyz.data_ptr() if u == 0 else pq.data_ptr()
                 tab = self._p(self.ec_tab0) if u == 0 else None
-                if u >= 2 and self.ec_mode == "bf16x3":
+                if u >= 2 and self.ec_mode in _EC_SPLIT:
+                    cfg, wname = _EC_SPLIT[self.ec_mode]
                     timed(f"edgeconv{u}", lambda: _lib.check(self.lib.pf_edgeconv_tuned(
-                        3, self.ec3_variant, src, None, idx16.data_ptr(), self._p(self.ec3_w[u]), h.data_ptr(), B, N, s)))
+                        cfg, self.ec3_variant, src, None, idx16.data_ptr(), self._p(getattr(self, wname)[u]),
+                        h.data_ptr(), B, N, s)))
                 else:
                     timed(f"edgeconv{u}", lambda: _lib.check(self.lib.pf_edgeconv(
                         _EC_CFG[u], src, tab, idx16.data_ptr(), self._p(self.ec_w[u]), h.data_ptr(), B, N, s)))

@@ -211,6 +211,32 @@ def frag_pack_bf16x3(W: np.ndarray) -> np.ndarray:
     return res.reshape(-1).view(np.float32)
 
 
+F16_LO_SCALE = 2048.0
+
+
+def frag_pack_f16x2(W: np.ndarray) -> np.ndarray:
+    """[OUT, IN] fp32 -> split-fp16 A-operand fragments of v_mfma_f32_16x16x32_f16, as a float32-typed byte
+    image [OB][CP][2 splits hi / lo'][64 lanes][8 fp16], lo' = fp16((W - hi) * 2^11) (csrc/pf_mfma.h
+    'split-fp16 path').  Same lane / K-slot map as frag_pack_bf16x3."""
+    out, inn = W.shape
+    OB, CP = (out + 15) // 16, (inn + 31) // 32
+    Wp = np.zeros((OB * 16, CP * 32), dtype=np.float32)
+    Wp[:out, :inn] = W
+    if np.abs(Wp).max(initial=0.0) >= 65504.0:
+        raise ValueError("weight magnitude exceeds the fp16 range of the f16x2 path; use PF_EC_MODE=bf16x3")
+    hi = Wp.astype(np.float16)
+    lo = ((Wp - hi.astype(np.float32)).astype(np.float32) * np.float32(F16_LO_SCALE)).astype(np.float16)
+    lanes = np.arange(64)
+    row, q = lanes & 15, lanes >> 4
+    j = np.arange(8)
+    ch = np.where(j[None, :] < 4, 4 * q[:, None] + j[None, :], 16 + 4 * q[:, None] + (j[None, :] - 4))     # [64,8]
+    res = np.zeros((OB, CP, 2, 64, 8), dtype=np.uint16)
+    for si, part in enumerate((hi, lo)):
+        bits = part.view(np.uint16).reshape(OB, 16, CP, 32)
+        res[:, :, si] = bits[:, row[:, None], :, ch].transpose(2, 3, 0, 1)      # -> [OB,CP,64,8]
+    return res.reshape(-1).view(np.float32)
+
+
 def frag_unpack(F: np.ndarray, out: int, inn: int) -> np.ndarray:
     OB, CB = F.shape[0], F.shape[1]
     f = F.reshape(OB, CB, 4, 16, 4).transpose(0, 3, 1, 2, 4)
@@ -258,6 +284,21 @@ def _edge_table(u: Dict[str, np.ndarray]) -> np.ndarray:
     return t
 
 
+def _etab_frag(xi: np.ndarray, xj: np.ndarray, nrm, const: np.ndarray) -> np.ndarray:
+    """'Edge table' [rows x e] as an f16x2 fragment image: the affine map of the raw edge inputs
+    e = (x_i[3], x_j[3], |x_i - x_j|, 1).  The kernel (csrc/interp.hip) puts e into k-slots 0..7 of one 32-channel
+    MFMA step = channels 0..3 of the pair's first block and 0..3 of its second block (columns 0..3 and 16..19)."""
+    rows = xi.shape[0]
+    W = np.zeros((rows, 32), np.float32)
+    W[:, 0:3] = xi
+    W[:, 3] = xj[:, 0]
+    W[:, 16:18] = xj[:, 1:3]
+    if nrm is not None:
+        W[:, 18] = nrm
+    W[:, 19] = const
+    return frag_pack_f16x2(W)
+
+
 def _ec_frags(u: Dict[str, np.ndarray], nconv: int) -> np.ndarray:
     return np.concatenate([frag_pack(u[f"G{t}"]).reshape(-1) for t in range(1, nconv + 1)])
 
@@ -293,6 +334,8 @@ def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
     out["ec_tab0"] = B.add(_edge_table(units[0]))
     out["ec_w"] = [B.add(_ec_frags(units[i], 4)) for i in range(NUM_BLOCKS)]
     # split-bf16 weight image of the 128-channel units (csrc/edgeconv.hip edgeconv3_kernel); None for units 0,1
+    out["ec2h_w"] = [None, None] + [B.add(np.concatenate([frag_pack_f16x2(units[i][f"G{t}"]) for t in range(1, 5)]))
+                                    for i in range(2, NUM_BLOCKS)]
     out["ec3_w"] = [None, None] + [B.add(np.concatenate([frag_pack_bf16x3(units[i][f"G{t}"]) for t in range(1, 5)]))
                                    for i in range(2, NUM_BLOCKS)]
     post = []
@@ -306,15 +349,16 @@ def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
         ST4[0:3, 0:64] = f["s_W4"]; ST4[3:6, 64:128] = f["t_W4"]
         bST4 = _pad_vec(np.concatenate([f["s_b4"], f["t_b4"]]), 16)
         offs = {
-            "M1": B.add(frag_pack(m["W1"])), "b1": B.add(_pad_vec(m["b1"], ((m["b1"].size + 15) // 16) * 16)),
-            "M2": B.add(frag_pack(m["W2"])), "H1": B.add(frag_pack(H1)),
-            "S2": B.add(frag_pack(f["s_W2"])), "bS2": B.add(f["s_b2"]),
-            "T2": B.add(frag_pack(f["t_W2"])), "bT2": B.add(f["t_b2"]),
-            "ST4": B.add(frag_pack(ST4)), "bST4": B.add(bST4),
+            # matrices: split-fp16 fragment images (csrc/pointwise.hip runs on the fp16 matrix pipe, f16x2 products)
+            "M1": B.add(frag_pack_f16x2(m["W1"])), "b1": B.add(_pad_vec(m["b1"], ((m["b1"].size + 15) // 16) * 16)),
+            "M2": B.add(frag_pack_f16x2(m["W2"])), "H1": B.add(frag_pack_f16x2(H1)),
+            "S2": B.add(frag_pack_f16x2(f["s_W2"])), "bS2": B.add(f["s_b2"]),
+            "T2": B.add(frag_pack_f16x2(f["t_W2"])), "bT2": B.add(f["t_b2"]),
+            "ST4": B.add(frag_pack_f16x2(ST4)), "bST4": B.add(bST4),
         }
         if i + 1 < NUM_BLOCKS:
             nu = units[i + 1]
-            offs["PQ"] = B.add(frag_pack(np.concatenate([nu["PA"], nu["QB"]], axis=0)))
+            offs["PQ"] = B.add(frag_pack_f16x2(np.concatenate([nu["PA"], nu["QB"]], axis=0)))
             offs["bPQ"] = B.add(np.concatenate([nu["pb"], np.zeros_like(nu["pb"])]))
         else:
             offs["PQ"], offs["bPQ"] = 0, 0
@@ -323,21 +367,24 @@ def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
     out["flow"] = B.add(np.concatenate([pack_flow_record(f) for f in plan["flows"]]))
     out["ld_const"] = float(sum(f["ld_const"] for f in plan["flows"]))
     ip = plan["interp"]
-    dtab = np.zeros((64, 8), np.float32)
-    dtab[:, 0:3], dtab[:, 3:6], dtab[:, 6], dtab[:, 7] = ip["d_PA"], ip["d_QB"], ip["d_wn"], ip["d_b0"]
     R = plan["upratio"]
     W6r = np.zeros((16, 64), np.float32)
     b6r = np.zeros(16, np.float32)
     for q in range(4):
         W6r[4 * q:4 * q + R] = ip["w_W6"]
         b6r[4 * q:4 * q + R] = ip["w_b6"]
-    io = {
-        "dtab": B.add(dtab), "d_W3": B.add(frag_pack(ip["d_W3"])), "d_b3": B.add(ip["d_b3"]),
-        "d_W6": B.add(frag_pack(ip["f_dW"])), "d_b6": B.add(ip["f_b0"]),          # folded: W0a.W6 on d2, b0 + W0a.b6
-        "ectab": B.add(_edge_table(ip["ec"])), "ec_w": B.add(_ec_frags(ip["ec"], 7)),   # growth layers only
-        "w_W0": B.add(frag_pack(ip["f_eW"])), "w_b0": B.add(ip["f_tab"]),           # folded: W0b.Gout, W0b.(edge table)
-        "w_W3": B.add(frag_pack(ip["w_W3"])), "w_b3": B.add(ip["w_b3"]),
-        "w_W6": B.add(frag_pack(W6r)), "w_b6": B.add(b6r),
+    ec = ip["ec"]
+    ft = ip["f_tab"]
+    io = {   # matrices: f16x2 fragment images (csrc/interp.hip header lists the slots)
+        "dtab": B.add(_etab_frag(ip["d_PA"], ip["d_QB"], ip["d_wn"], ip["d_b0"])),
+        "d_W3": B.add(frag_pack_f16x2(ip["d_W3"])), "d_b3": B.add(ip["d_b3"]),
+        "d_W6": B.add(frag_pack_f16x2(ip["f_dW"])), "d_b6": 0,                      # folded: W0a.W6 on d2; slot 4 reserved
+        "ectab": B.add(_etab_frag(ec["PA"][:128], ec["QB"][:128], None, ec["pb"][:128])),   # growth pre-activations
+        "ec_w": B.add(np.concatenate([frag_pack_f16x2(ec[f"G{t}"]) for t in range(1, 8)])),
+        "w_W0": B.add(frag_pack_f16x2(ip["f_eW"])),                                 # folded: W0b.Gout
+        "w_b0": B.add(_etab_frag(ft[:, 0:3], ft[:, 3:6], None, ft[:, 6] + ip["f_b0"])),   # W0b.(edge table) + b0 + W0a.b6
+        "w_W3": B.add(frag_pack_f16x2(ip["w_W3"])), "w_b3": B.add(ip["w_b3"]),
+        "w_W6": B.add(frag_pack_f16x2(W6r)), "w_b6": B.add(b6r),
     }
     out["interp"] = [io[k] for k in INTERP_SLOTS]
     out["blob"] = B.data()

@@ -140,35 +140,38 @@ def test_forward_matches_reference_golden(lib, golden_dir, name):
 
 
 def test_edgeconv_arithmetic_modes(lib):
-    """Both EdgeConv arithmetic modes of the 128-channel units meet the parity bar: split-bf16 (default) and
-    the bit-exact f32 MFMA kernel; they agree with each other to fp32 rounding."""
+    """All EdgeConv arithmetic modes of the 128-channel units meet the parity bar: split-fp16 (default), split-bf16
+    and the bit-exact f32 MFMA kernel; they agree with each other to fp32 rounding."""
     sd = synth_state_dict(12)
     xyz = synth_patches(2, 512, seed=13)
     ref = O.forward(sd, xyz, 4, stages=True)
     net = _net(sd)
     outs = {}
-    for mode in ("bf16x3", "f32"):
-        net._engine(4).ec_mode = mode
+    for mode in ("f16x2", "bf16x3", "f32"):
+        eng = net._engine(4)
+        eng.ec_mode, eng.ec3_variant = mode, 0
         st = net.forward_stages(xyz.to(DEV), 4)
         _check_stages(st, ref)
         outs[mode] = st
-    assert (outs["f32"]["x"] - outs["bf16x3"]["x"]).abs().max() < 5e-6
-    assert (outs["f32"]["cs"][5] - outs["bf16x3"]["cs"][5]).abs().max() < 5e-6
+    for mode in ("f16x2", "bf16x3"):
+        assert (outs["f32"]["x"] - outs[mode]["x"]).abs().max() < 5e-6
+        assert (outs["f32"]["cs"][5] - outs[mode]["cs"][5]).abs().max() < 5e-6
 
 
 @pytest.mark.parametrize("seed", [3, 5])
 def test_trained_style_dynamic_range(lib, seed):
     """Weights with the wide dynamic range of the reference's pretrained checkpoints (features up to |h| ~ 300,
     BN variances ~1e3; statistics taken from pretrain/puflow-x4-pu1k.pt), calibrated on data by the oracle:
-    xyz still within 1e-5 absolute, log-det within 1e-5 relative, features within 1e-5 of their range - in both
-    EdgeConv arithmetic modes."""
+    xyz still within 1e-5 absolute, log-det within 1e-5 relative, features within 1e-5 of their range - in every
+    EdgeConv arithmetic mode."""
     sd = O.calibrate(synth_state_dict(seed, style="trained"), synth_patches(4, 256, seed=1))
     xyz = synth_patches(2, 256, seed=2)
     ref = O.forward(sd, xyz, 4, stages=True)
     assert max(h.abs().max() for h in ref["hs"]) > 100          # the regime this test is about
     net = _net(sd)
-    for mode in ("bf16x3", "f32"):
-        net._engine(4).ec_mode = mode
+    for mode in ("f16x2", "bf16x3", "f32"):
+        eng = net._engine(4)
+        eng.ec_mode, eng.ec3_variant = mode, 0
         st = net.forward_stages(xyz.to(DEV), 4)
         assert torch.equal(st["idx16"].cpu().long(), ref["idx16"])
         assert (st["x"].cpu() - ref["x"]).abs().max() < 1e-5

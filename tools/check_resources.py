@@ -10,7 +10,7 @@ from puflow_amd import build as B
 rows = []
 for src in B.SOURCES:
     path = os.path.join(B.CSRC, src)
-    out = subprocess.run(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-c", path, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
+    out = subprocess.run(["/opt/rocm/bin/hipcc"] + B.FLAGS + B.EXTRA_FLAGS.get(os.path.basename(path), []) + ["-c", path, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
                          capture_output=True, text=True).stderr
     cur = {}
     for line in out.splitlines():

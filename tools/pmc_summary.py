@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output of tools/profile_gpu.sh: per-kernel mean of every collected counter
+(+ derived HBM bytes with the gfx950 FETCH_SIZE correction, MFMA utilisation, LDS conflict rate)
+and the kernel-trace average durations.  Usage: pmc_summary.py gpurun_out/<tag> > pmc_summary.json"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+SIMD_PER_CU, CUS = 4, 256
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void\s+", "", name)
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    return re.sub(r"\(.*$", "", name).strip()
+
+
+def main(root: str) -> None:
+    ctr = defaultdict(lambda: defaultdict(list))        # kernel -> counter -> values
+    for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                ctr[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = {}
+    for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                dur[short(r["Name"])] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3,
+                                             pct=float(r["Percentage"]))
+    out = {}
+    for k in sorted(set(ctr) | set(dur), key=lambda k: -dur.get(k, {}).get("pct", 0.0)):
+        e = dict(dur.get(k, {}))
+        for c, v in ctr.get(k, {}).items():
+            e[c + "_mean"] = sum(v) / len(v)
+            e["launches_" + c] = len(v)
+        if "FETCH_SIZE_mean" in e and "WRITE_SIZE_mean" in e:
+            # units KB; FETCH_SIZE under-counts 16 B/lane loads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)
+            e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE_mean"] + e["WRITE_SIZE_mean"]) * 1024.0
+        if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in e and e.get("GRBM_GUI_ACTIVE_mean"):
+            e["mfma_util_pct"] = 100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (e["GRBM_GUI_ACTIVE_mean"] * SIMD_PER_CU * CUS)
+        if e.get("SQ_LDS_IDX_ACTIVE_mean"):
+            e["lds_conflict_pct"] = 100.0 * e.get("SQ_LDS_BANK_CONFLICT_mean", 0.0) / e["SQ_LDS_IDX_ACTIVE_mean"]
+        out[k] = e
+    json.dump(dict(how="tools/profile_gpu.sh: rocprofv3 --kernel-trace --stats, then one --pmc group per pass "
+                       "(python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline, 32 x 2048-pt patches); counters are "
+                       "per-dispatch sums over all XCDs as rocprofv3 reports them; FETCH_SIZE doubled per the gfx950 note",
+                   kernels=out), sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -9,9 +9,11 @@ import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {
-    "a": ["PF_POST_P=1", "PF_POST_NW=8", "PF_FLOW_P=1", "PF_FLOW_NW=8", "PF_INTERP_P=1", "PF_INTERP_NW=8"],
-    "b": ["PF_POST_P=2", "PF_POST_NW=8", "PF_FLOW_P=2", "PF_FLOW_NW=4", "PF_INTERP_P=2", "PF_INTERP_NW=4"],
-    "c": ["PF_POST_P=1", "PF_POST_NW=4", "PF_FLOW_P=1", "PF_FLOW_NW=2", "PF_INTERP_P=1", "PF_INTERP_NW=4"],
+    "a": ["PF_POST_P=2", "PF_POST_NW=4", "PF_MM2_DEPTH=4"],
+    "b": ["PF_POST_P=2", "PF_POST_NW=4", "PF_MM2_DEPTH=8"],
+    "c": ["PF_POST_P=1", "PF_POST_NW=8", "PF_MM2_DEPTH=4"],
+    "d": ["PF_POST_P=1", "PF_POST_NW=8", "PF_MM2_DEPTH=8"],
+    "e": ["PF_POST_P=1", "PF_POST_NW=8", "PF_MM2_DEPTH=2"],
 }
 if sys.argv[1] == "build":
     from puflow_amd import build
