@@ -65,7 +65,7 @@ int pf_post(int unit, const float* h, const float* w, const long long* off, floa
  * FlowBlock.forward (modules/discrete/interpflow.py:302-313,:66-74; normalize.py:30-37,
  * permutate.py:117-120, coupling.py:55-58,114-118,127-139).
  * xyz [T,3]; cp [6][T][64] and st [6][T][8] as written by pf_post (unit-major, contiguous);
- * w = 6 flow records of 13040 floats (layout: csrc/flow.hip header, packing.pack_flow).
+ * w = 6 flow records of 5360 floats (layout: csrc/flow.hip header, packing.pack_flow).
  * z [T,3] out; ld_pt [T] out = per-point  -sum_blocks sum_ch s. */
 int pf_flow_fwd(const float* xyz, const float* cp, const float* st, const float* w, float* z, float* ld_pt, int T,
                 void* stream);

@@ -9,31 +9,35 @@
 // Host-side folds (puflow_amd/packing.py): actnorm o inv1x1 = one 3x3 affine (A, a0) and its
 // inverse (Ai, ai0); injector (s, t) and the c-part of coupling1's first layer (cp) come
 // precomputed per ORIGINAL point from pf_post.  What is left per row is the coupling MLP
-// 64 -> 64 -> (1|2), run on the f32 MFMA with 16 rows per column tile.
+// 64 -> 64 -> (1|2): split-fp16 products on the fp16 MFMA (pf_mfma.h "f16x2", fp32-class accuracy),
+// 16 rows per column tile, 30 MFMAs per tile and block.
 //
-// Per-block weight record (floats, 16-byte aligned pieces), stride FLOW_REC:
-//   [0,4096)  W2 fragments (4 ob x 4 cb)                                  (f32 image; unused by the split-bf16 path)
-//   [4096,5120) W4 fragments (1 ob x 4 cb; rows replicated into every 4-row q group)
+// The chain of 6 blocks is latency-bound, not throughput-bound (per tile: 6 x [gather cp/st -> 64 VALU ->
+// 24 MFMA -> split -> 6 MFMA -> exp/affine]), so the kernel is built for occupancy and short latencies:
+// all six weight records live in LDS for the whole persistent workgroup (126 KiB), 16 waves per workgroup
+// at <= 128 VGPRs (4 waves per SIMD), and the next block's cp / st rows are fetched while the current block computes.
+//
+// Per-block weight record (floats), stride FLOW_REC = 5360:
+//   [0,4096)    f16x2 image of W2 (4 ob x 2 pairs)      [4096,5120) f16x2 image of W4 (1 ob x 2 pairs; rows
+//               replicated into every 4-row q group)
 //   [5120,5184) b2      [5184,5200) b4 (replicated likewise)      [5200,5328) W0h [64][2]
-//   [5328,5360) A(9) a0(3) Ai(9) ai0(3) pad
-//   [5360,13040) split-bf16 image (csrc/pf_mfma.h) of W2 (4 ob x 2 pairs) then W4 (1 ob x 2 pairs): 10 fragments x 768 floats.
-// The 64 -> 64 -> (1|2) coupling net runs on the bf16 pipe with fp32-class accuracy: 60 x 16 instead of 80 x 32 MFMA cycles
-// per 16 rows and block.
+//   [5328,5352) A(9) a0(3) Ai(9) ai0(3)   [5352,5360) pad
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
 
-// tuned on MI355X with tools/tune_variants.py (P = column tiles per wave, NW = waves per workgroup)
-#ifndef PF_FLOW_P
-#define PF_FLOW_P 1
-#endif
+// waves per workgroup: g (inverse) fits 128 VGPRs -> 16 waves; f keeps (s, t) live across the coupling net and needs a
+// few more registers -> 12 waves (170 VGPRs each)
 #ifndef PF_FLOW_NW
-#define PF_FLOW_NW 4
+#define PF_FLOW_NW 16
+#endif
+#ifndef PF_FLOW_NW_FWD
+#define PF_FLOW_NW_FWD 12
 #endif
 
 namespace {
 
-constexpr int FLOW_REC = 13040;
+constexpr int FLOW_REC = 5360;
 constexpr float LOG2PI_F = 1.8378770664093453f;
 
 struct FlowArgs {
@@ -49,145 +53,129 @@ struct FlowArgs {
     int ntiles;
 };
 
-// coupling MLP for one column tile: returns o[0..1] (bias_net output, 3-td values), identical in all q lanes
-template <int TD, int P, class WS>
-__device__ __forceinline__ void coupling_net(const WS& ws, const float* __restrict__ rec, const float* __restrict__ cpu,
-                                             const int (&pt)[P], const float (&h1)[P][2], int q, float (&o)[P][2]) {
-    f4 hid[P][4];
+struct FlowCond { f4 cp[4]; f4 s0, s1; };        // one block's conditioning of one row: cp [64] (this lane's 16), s|t [8]
+
+__device__ __forceinline__ FlowCond flow_cond(const float* __restrict__ cp, const float* __restrict__ st, int T, int u,
+                                              int pt, int q) {
+    FlowCond c;
+    const float* cr = cp + ((size_t)u * T + pt) * 64 + 4 * q;
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const f4 wa = *reinterpret_cast<const f4*>(rec + 5200 + (cb * 16 + 4 * q) * 2);       // W0h rows ch, ch+1
-        const f4 wb = *reinterpret_cast<const f4*>(rec + 5200 + (cb * 16 + 4 * q) * 2 + 4);   // rows ch+2, ch+3
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            f4 v = *reinterpret_cast<const f4*>(cpu + (size_t)pt[p] * 64 + cb * 16 + 4 * q);
-            v.x = fmaf(wa.x, h1[p][0], v.x); v.y = fmaf(wa.z, h1[p][0], v.y);
-            v.z = fmaf(wb.x, h1[p][0], v.z); v.w = fmaf(wb.z, h1[p][0], v.w);
-            if (TD == 2) {
-                v.x = fmaf(wa.y, h1[p][1], v.x); v.y = fmaf(wa.w, h1[p][1], v.y);
-                v.z = fmaf(wb.y, h1[p][1], v.z); v.w = fmaf(wb.w, h1[p][1], v.w);
-            }
-            hid[p][cb] = pf_lrelu(v, 0.01f);
-        }
-    }
-    f4 h2[P][4];
-    PfPair hp[P][2];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob) h2[p][ob] = pf_bias(rec + 5120, ob, q);
-        hp[p][0] = pf_pair(hid[p][0], hid[p][1]);
-        hp[p][1] = pf_pair(hid[p][2], hid[p][3]);
-    }
-    pf_mm3<4, 2, 2>(ws, 0, hp, 0, h2, 0);
-    f4 acc[P][1];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        acc[p][0] = *reinterpret_cast<const f4*>(rec + 5184 + 4 * q);
-        hp[p][0] = pf_pair(pf_lrelu(h2[p][0], 0.01f), pf_lrelu(h2[p][1], 0.01f));
-        hp[p][1] = pf_pair(pf_lrelu(h2[p][2], 0.01f), pf_lrelu(h2[p][3], 0.01f));
-    }
-    pf_mm3<1, 2, 2>(ws, 8, hp, 0, acc, 0);
-#pragma unroll
-    for (int p = 0; p < P; ++p) { o[p][0] = acc[p][0].x; o[p][1] = acc[p][0].y; }
+    for (int cb = 0; cb < 4; ++cb) c.cp[cb] = *reinterpret_cast<const f4*>(cr + cb * 16);
+    const float* sr = st + ((size_t)u * T + pt) * 8;
+    c.s0 = *reinterpret_cast<const f4*>(sr);
+    c.s1 = *reinterpret_cast<const f4*>(sr + 4);
+    return c;
 }
 
-template <bool INV, int P, int NW>
+// coupling MLP of one column tile: o[0..1] = bias_net output (3 - TD values), identical in all q lanes
+template <int TD>
+__device__ __forceinline__ void coupling_net(const float* rec /*LDS*/, int lane, int q, const FlowCond& c,
+                                             const float (&h1)[2], float (&o)[2]) {
+    PfPair2 hp[1][2];
+    {
+        f4 hid[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const f4 wa = *reinterpret_cast<const f4*>(rec + 5200 + (cb * 16 + 4 * q) * 2);       // W0h rows ch, ch+1
+            const f4 wb = *reinterpret_cast<const f4*>(rec + 5200 + (cb * 16 + 4 * q) * 2 + 4);   // rows ch+2, ch+3
+            f4 v = c.cp[cb];
+            v.x = fmaf(wa.x, h1[0], v.x); v.y = fmaf(wa.z, h1[0], v.y);
+            v.z = fmaf(wb.x, h1[0], v.z); v.w = fmaf(wb.z, h1[0], v.w);
+            if (TD == 2) {
+                v.x = fmaf(wa.y, h1[1], v.x); v.y = fmaf(wa.w, h1[1], v.y);
+                v.z = fmaf(wb.y, h1[1], v.z); v.w = fmaf(wb.w, h1[1], v.w);
+            }
+            hid[cb] = pf_lrelu(v, 0.01f);
+        }
+        hp[0][0] = pf_pair2(hid[0], hid[1]);
+        hp[0][1] = pf_pair2(hid[2], hid[3]);
+    }
+    const PfW2Lds ws{reinterpret_cast<const u4*>(rec), lane};
+    f4 h2[1][4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) h2[0][ob] = pf_bias(rec + 5120, ob, q);
+    pf_mm2f<4, 2, 2>(ws, 0, hp, 0, h2, 0);
+    hp[0][0] = pf_pair2(pf_lrelu(h2[0][0], 0.01f), pf_lrelu(h2[0][1], 0.01f));
+    hp[0][1] = pf_pair2(pf_lrelu(h2[0][2], 0.01f), pf_lrelu(h2[0][3], 0.01f));
+    f4 acc[1][1];
+    acc[0][0] = *reinterpret_cast<const f4*>(rec + 5184 + 4 * q);
+    pf_mm2f<1, 2, 2>(ws, 8, hp, 0, acc, 0);
+    o[0] = acc[0][0].x; o[1] = acc[0][0].y;
+}
+
+template <bool INV, int NW>
 __global__ __launch_bounds__(NW * 64) void flow_kernel(FlowArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
+    __shared__ f4 wl[6 * FLOW_REC / 4];
+    for (int i = threadIdx.x; i < 6 * FLOW_REC / 4; i += NW * 64) wl[i] = reinterpret_cast<const f4*>(a.w)[i];
+    __syncthreads();
+    const float* wlf = reinterpret_cast<const float*>(wl);
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int r0 = (tile * NW + wave) * P * 16;
-        int row[P], pt[P];
-        bool ok[P];
-        float v[P][3], ld[P];
+        const int g = (tile * NW + wave) * 16 + col;
+        const bool ok = g < a.rows;
+        const int row = ok ? g : a.rows - 1;
+        const int pt = row / a.R;
+        float v[3], ld = 0.f;
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const int g = r0 + p * 16 + col;
-            ok[p] = g < a.rows;
-            row[p] = ok[p] ? g : a.rows - 1;
-            pt[p] = row[p] / a.R;
-            ld[p] = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[p][c] = a.in[(size_t)row[p] * 3 + c];
-        }
+        for (int c = 0; c < 3; ++c) v[c] = a.in[(size_t)row * 3 + c];
+        FlowCond cn = flow_cond(a.cp, a.st, a.T, INV ? 5 : 0, pt, q);
 
         pf_static_for<0, 6>([&](auto uc) {
-            constexpr int u = INV ? 5 - decltype(uc)::value : decltype(uc)::value;
+            constexpr int i = decltype(uc)::value;
+            constexpr int u = INV ? 5 - i : i;
             constexpr int TD = (u % 2 == 0) ? 1 : 2;
-            const float* rec = a.w + u * FLOW_REC;
-            const float* cpu = a.cp + (size_t)u * a.T * 64;
-            const float* stu = a.st + (size_t)u * a.T * 8;
-            const PfW3Buf ws(rec + 5360, lane);
+            const float* rec = wlf + u * FLOW_REC;
             const float* fc = rec + 5328;
-            float s[P][3], t[P][3];
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const f4 s0 = *reinterpret_cast<const f4*>(stu + (size_t)pt[p] * 8);
-                const f4 s1 = *reinterpret_cast<const f4*>(stu + (size_t)pt[p] * 8 + 4);
-                s[p][0] = s0.x; s[p][1] = s0.y; s[p][2] = s0.z; t[p][0] = s0.w; t[p][1] = s1.x; t[p][2] = s1.y;
-            }
+            const FlowCond c = cn;
+            if constexpr (i < 5) cn = flow_cond(a.cp, a.st, a.T, INV ? u - 1 : u + 1, pt, q);    // next block's rows
+            __builtin_amdgcn_sched_barrier(0);
+            const float s[3] = {c.s0.x, c.s0.y, c.s0.z}, t[3] = {c.s0.w, c.s1.x, c.s1.y};
+            float h1[2], o[2];
             if constexpr (!INV) {
-                float h1[P][2], o[P][2];
+                const float x0 = v[0], x1 = v[1], x2 = v[2];                   // actnorm o inv1x1:  v = A v + a0
 #pragma unroll
-                for (int p = 0; p < P; ++p) {                 // actnorm o inv1x1:  v = A v + a0
-                    const float x0 = v[p][0], x1 = v[p][1], x2 = v[p][2];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        v[p][i] = fmaf(fc[3 * i + 2], x2, fmaf(fc[3 * i + 1], x1, fmaf(fc[3 * i], x0, fc[9 + i])));
-                    h1[p][0] = v[p][0]; h1[p][1] = v[p][1];
-                }
-                coupling_net<TD>(ws, rec, cpu, pt, h1, q, o);
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if (TD == 1) { v[p][1] -= o[p][0]; v[p][2] -= o[p][1]; } else { v[p][2] -= o[p][0]; }
-                    const float y0 = v[p][2], y1 = v[p][1], y2 = v[p][0];      // reverse channels
-                    v[p][0] = (y0 - t[p][0]) * expf(-s[p][0]);
-                    v[p][1] = (y1 - t[p][1]) * expf(-s[p][1]);
-                    v[p][2] = (y2 - t[p][2]) * expf(-s[p][2]);
-                    ld[p] -= (s[p][0] + s[p][1]) + s[p][2];
-                }
+                for (int k = 0; k < 3; ++k)
+                    v[k] = fmaf(fc[3 * k + 2], x2, fmaf(fc[3 * k + 1], x1, fmaf(fc[3 * k], x0, fc[9 + k])));
+                h1[0] = v[0]; h1[1] = v[1];
+                coupling_net<TD>(rec, lane, q, c, h1, o);
+                if (TD == 1) { v[1] -= o[0]; v[2] -= o[1]; } else { v[2] -= o[0]; }
+                const float y0 = v[2], y1 = v[1], y2 = v[0];                   // reverse channels
+                v[0] = (y0 - t[0]) * expf(-s[0]);
+                v[1] = (y1 - t[1]) * expf(-s[1]);
+                v[2] = (y2 - t[2]) * expf(-s[2]);
+                ld -= (s[0] + s[1]) + s[2];
             } else {
-                float h1[P][2], o[P][2];
+                const float y0 = fmaf(v[0], expf(s[0]), t[0]);
+                const float y1 = fmaf(v[1], expf(s[1]), t[1]);
+                const float y2 = fmaf(v[2], expf(s[2]), t[2]);
+                v[0] = y2; v[1] = y1; v[2] = y0;                               // reverse^-1 (self-inverse)
+                h1[0] = v[0]; h1[1] = v[1];
+                coupling_net<TD>(rec, lane, q, c, h1, o);
+                if (TD == 1) { v[1] += o[0]; v[2] += o[1]; } else { v[2] += o[0]; }
+                const float x0 = v[0], x1 = v[1], x2 = v[2];
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const float y0 = fmaf(v[p][0], expf(s[p][0]), t[p][0]);
-                    const float y1 = fmaf(v[p][1], expf(s[p][1]), t[p][1]);
-                    const float y2 = fmaf(v[p][2], expf(s[p][2]), t[p][2]);
-                    v[p][0] = y2; v[p][1] = y1; v[p][2] = y0;                  // reverse^-1 (self-inverse)
-                    h1[p][0] = v[p][0]; h1[p][1] = v[p][1];
-                }
-                coupling_net<TD>(ws, rec, cpu, pt, h1, q, o);
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if (TD == 1) { v[p][1] += o[p][0]; v[p][2] += o[p][1]; } else { v[p][2] += o[p][0]; }
-                    const float x0 = v[p][0], x1 = v[p][1], x2 = v[p][2];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)                 // (inv1x1 o actnorm)^-1:  v = Ai v + ai0
-                        v[p][i] = fmaf(fc[12 + 3 * i + 2], x2, fmaf(fc[12 + 3 * i + 1], x1, fmaf(fc[12 + 3 * i], x0, fc[21 + i])));
-                }
+                for (int k = 0; k < 3; ++k)                                    // (inv1x1 o actnorm)^-1:  v = Ai v + ai0
+                    v[k] = fmaf(fc[12 + 3 * k + 2], x2, fmaf(fc[12 + 3 * k + 1], x1, fmaf(fc[12 + 3 * k], x0, fc[21 + k])));
             }
         });
 
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            if (ok[p] && q == 0) {
-                a.out[(size_t)row[p] * 3 + 0] = v[p][0];
-                a.out[(size_t)row[p] * 3 + 1] = v[p][1];
-                a.out[(size_t)row[p] * 3 + 2] = v[p][2];
-                if (!INV) a.ld_pt[row[p]] = ld[p];
-            }
+        if (ok && q == 0) {
+            a.out[(size_t)row * 3 + 0] = v[0];
+            a.out[(size_t)row * 3 + 1] = v[1];
+            a.out[(size_t)row * 3 + 2] = v[2];
+            if (!INV) a.ld_pt[row] = ld;
         }
     }
 }
 
 template <bool INV>
 int launch(FlowArgs a, hipStream_t s) {
-    constexpr int P = PF_FLOW_P, NW = PF_FLOW_NW;
-    a.ntiles = (a.rows + NW * P * 16 - 1) / (NW * P * 16);
-    const int grid = a.ntiles < 2048 ? a.ntiles : 2048;
-    hipLaunchKernelGGL((flow_kernel<INV, P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    constexpr int NW = INV ? PF_FLOW_NW : PF_FLOW_NW_FWD;
+    a.ntiles = (a.rows + NW * 16 - 1) / (NW * 16);
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;          // persistent: 126 KiB of LDS = one workgroup per CU
+    hipLaunchKernelGGL((flow_kernel<INV, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
     return pf_last_launch_status();
 }
 

@@ -234,9 +234,12 @@ __device__ __forceinline__ f4 pf_mfma_f16(h8 a, h8 b, f4 c) {
 #ifndef PF_MM2_DEPTH
 #define PF_MM2_DEPTH 8
 #endif
+#ifndef PF_W2LDS_DEPTH
+#define PF_W2LDS_DEPTH 2
+#endif
 // weights: [frag][2 splits hi / lo'][64 lanes] x 16 B in LDS
 struct PfW2Lds {
-    static constexpr int DEPTH = 2;          // fragments in flight (pf_mm2f): LDS latency
+    static constexpr int DEPTH = PF_W2LDS_DEPTH;   // fragments in flight (pf_mm2f): LDS latency
     const u4* base;
     int lane;
     __device__ __forceinline__ h8 load(int frag, int split) const {

@@ -237,6 +237,20 @@ def frag_pack_f16x2(W: np.ndarray) -> np.ndarray:
     return res.reshape(-1).view(np.float32)
 
 
+def frag_unpack_f16x2(F: np.ndarray, out: int, inn: int) -> np.ndarray:
+    """Inverse of frag_pack_f16x2 (tests): float64 hi + lo' / 2^11 of the [out, inn] matrix."""
+    OB, CP = (out + 15) // 16, (inn + 31) // 32
+    img = np.ascontiguousarray(F, dtype=np.float32).view(np.uint16).reshape(OB, CP, 2, 64, 8).view(np.float16).astype(np.float64)
+    val = img[:, :, 0] + img[:, :, 1] / F16_LO_SCALE                                   # [OB,CP,64,8]
+    lanes = np.arange(64)
+    row, q = lanes & 15, lanes >> 4
+    j = np.arange(8)
+    ch = np.where(j[None, :] < 4, 4 * q[:, None] + j[None, :], 16 + 4 * q[:, None] + (j[None, :] - 4))
+    W = np.zeros((OB, 16, CP, 32))
+    W[:, row[:, None], :, ch] = val.transpose(2, 3, 0, 1)
+    return W.reshape(OB * 16, CP * 32)[:out, :inn]
+
+
 def frag_unpack(F: np.ndarray, out: int, inn: int) -> np.ndarray:
     OB, CB = F.shape[0], F.shape[1]
     f = F.reshape(OB, CB, 4, 16, 4).transpose(0, 3, 1, 2, 4)
@@ -248,7 +262,7 @@ def frag_unpack(F: np.ndarray, out: int, inn: int) -> np.ndarray:
 # ---------------------------------------------------------------------------------------
 POST_SLOTS = ["M1", "b1", "M2", "H1", "S2", "bS2", "T2", "bT2", "ST4", "bST4", "PQ", "bPQ"]
 INTERP_SLOTS = ["dtab", "d_W3", "d_b3", "d_W6", "d_b6", "ectab", "ec_w", "w_W0", "w_b0", "w_W3", "w_b3", "w_W6", "w_b6"]
-FLOW_REC = 13040
+FLOW_REC = 5360
 
 
 class _Blob:
@@ -304,16 +318,16 @@ def _ec_frags(u: Dict[str, np.ndarray], nconv: int) -> np.ndarray:
 
 
 def pack_flow_record(f: Dict[str, object]) -> np.ndarray:
-    """One 13040-float flow-block record (layout: csrc/flow.hip header)."""
+    """One 5360-float flow-block record (layout: csrc/flow.hip header)."""
     rec = np.zeros(FLOW_REC, np.float32)
-    rec[0:4096] = frag_pack(f["c1_W2"]).reshape(-1)
+    rec[0:4096] = frag_pack_f16x2(f["c1_W2"])         # 4 ob x 2 pairs
     W4 = f["c1_W4"]                                   # [3-td, 64]
     W4r = np.zeros((16, 64), np.float32)
     b4r = np.zeros(16, np.float32)
     for q in range(4):
         W4r[4 * q:4 * q + W4.shape[0]] = W4
         b4r[4 * q:4 * q + W4.shape[0]] = f["c1_b4"]
-    rec[4096:5120] = frag_pack(W4r).reshape(-1)
+    rec[4096:5120] = frag_pack_f16x2(W4r)             # 1 ob x 2 pairs
     rec[5120:5184] = f["c1_b2"]
     rec[5184:5200] = b4r
     W0h = np.zeros((64, 2), np.float32)
@@ -321,8 +335,6 @@ def pack_flow_record(f: Dict[str, object]) -> np.ndarray:
     rec[5200:5328] = W0h.reshape(-1)
     rec[5328:5337] = f["A"].reshape(-1); rec[5337:5340] = f["a0"]
     rec[5340:5349] = f["Ai"].reshape(-1); rec[5349:5352] = f["ai0"]
-    rec[5360:5360 + 8 * 768] = frag_pack_bf16x3(f["c1_W2"])            # 4 ob x 2 pairs
-    rec[5360 + 8 * 768:13040] = frag_pack_bf16x3(W4r)                    # 1 ob x 2 pairs
     return rec
 
 

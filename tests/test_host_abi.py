@@ -83,10 +83,15 @@ def test_pack_plan_layout():
     # unit 3 growth weights: G1 (2x2 frags) first
     g1 = frag_unpack(blob[pk["ec_w"][3]:pk["ec_w"][3] + 4 * 256].reshape(2, 2, 64, 4), 32, 32)
     np.testing.assert_array_equal(g1, plan["units"][3]["G1"])
-    # flow record: W2 fragments then replicated W4 rows
+    # flow record: split-fp16 images of W2 then the replicated W4 rows; hi + lo' 2^-11 reproduces fp32 to ~2^-22
+    from puflow_amd.packing import frag_unpack_f16x2
     rec = blob[pk["flow"] + 2 * FLOW_REC: pk["flow"] + 3 * FLOW_REC]
-    np.testing.assert_array_equal(frag_unpack(rec[:4096].reshape(4, 4, 64, 4), 64, 64), plan["flows"][2]["c1_W2"])
-    w4 = frag_unpack(rec[4096:5120].reshape(1, 4, 64, 4), 16, 64)
-    np.testing.assert_array_equal(w4[4:6], plan["flows"][2]["c1_W4"])
+    W2 = plan["flows"][2]["c1_W2"]
+    np.testing.assert_allclose(frag_unpack_f16x2(rec[:4096], 64, 64), W2, rtol=2.0 ** -21, atol=1e-12)
+    w4 = frag_unpack_f16x2(rec[4096:5120], 16, 64)
+    np.testing.assert_allclose(w4[4:6], plan["flows"][2]["c1_W4"], rtol=2.0 ** -21, atol=1e-12)
     np.testing.assert_array_equal(rec[5328:5337].reshape(3, 3), plan["flows"][2]["A"])
-    assert FLOW_REC == 13040 and rec.size == FLOW_REC
+    assert FLOW_REC == 5360 and rec.size == FLOW_REC
+    # EdgeConv unit 3, split-fp16 image: G1 [32, 32] = 2 ob x 1 pair
+    g1h = frag_unpack_f16x2(blob[pk["ec2h_w"][3]:pk["ec2h_w"][3] + 2 * 512], 32, 32)
+    np.testing.assert_allclose(g1h, plan["units"][3]["G1"], rtol=2.0 ** -21, atol=1e-12)
