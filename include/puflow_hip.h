@@ -43,7 +43,9 @@ int pf_nn1(const float* p1, const float* p2, int B, int N, int M, float* dist_ou
  * cfg 0: unit 0 (input = xyz [B*N,3], `tab` = [96,8] folded edge table);
  * cfg 1: unit 1, cfg 2: units 2..5 (input = PQ [B*N, 2S] per-point vectors, tab ignored);
  * cfg 3 / 4: units 2..5 on the bf16 / fp16 matrix pipe with split operands (wfrag = the bf16x3 / f16x2
- * image of the same weights; fp32-class results, see csrc/pf_mfma.h).
+ * image of the same weights; fp32-class results, see csrc/pf_mfma.h);
+ * cfg 5 / 6: units 0 / 1 on the fp16 matrix pipe (wfrag = f16x2 image; unit 0's edge table rides at its end,
+ * input = xyz [B*N,3], tab ignored).
  * idx [B*N,16] int32 (index inside the batch item); wfrag = fragment-packed growth weights;
  * out [B*N, odim]. */
 int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, const int* idx, const float* wfrag, float* out,

@@ -300,6 +300,139 @@ int launch3(const EcArgs& a0, hipStream_t s) {
     return pf_last_launch_status();
 }
 
+// ---- split-fp16 variant of the narrow units 0 / 1 (one 16-channel block per growth layer, four layers) ----
+// Two growth layers share one 32-channel MFMA step (a block pair); an odd layer count pairs with a zero block.
+// C3 (unit 0): the per-edge pre-activations of ALL S rows are one MFMA step against the folded edge table
+// (raw inputs e = (x_i, x_j, 1) in 8 of the 32 k-slots, packing._etab_frag) instead of 7 VALU fmas per row.
+// PQ (unit 1): P[i] + Q[j] gathers, all S rows issued at the top of the tile.
+// Fragments in LDS: G1 | G2 | G3 (2 pairs) | Gout (OBO x 2 pairs) | [C3: edge table, S/16 x 1 pair].
+template <int ODIM, bool C3, int P, int NW>
+__global__ __launch_bounds__(NW * 64) void edgeconv1h_kernel(EcArgs a) {
+    constexpr int NCONV = 4, S = 16 * NCONV + ODIM, SB = S / 16, OBO = ODIM / 16, OCH = 2;
+    constexpr int FO = 4, FT = FO + OBO * 2, NWF = FT + (C3 ? SB : 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    __shared__ u4 wlds[NWF * 128];
+    for (int i = threadIdx.x; i < NWF * 128; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
+    __syncthreads();
+    const PfW2Lds ws{wlds, lane};
+
+    for (int v = blockIdx.x; v < 8 * a.chunk; v += gridDim.x) {
+        const int tile = pf_xcd_tile(v, a.chunk);
+        if (tile >= a.ntiles) continue;
+        const int pt0 = (tile * NW + wave) * P;
+        int gi[P], gj[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int g = pt0 + p;
+            g = g < a.T ? g : a.T - 1;
+            gi[p] = g;
+            gj[p] = (g / a.N) * a.N + a.idx[(size_t)g * 16 + col];
+        }
+        f4 pre[P][SB];                       // P[i] + Q[j] (+ bias) of every stacked row, this lane's 4 channels per block
+        if constexpr (C3) {
+            PfPair2 e[P][1];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                float xi[3], xj[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    xi[c] = a.xyz[(size_t)gi[p] * 3 + c];
+                    xj[c] = a.xyz[(size_t)gj[p] * 3 + c];
+                }
+                const f4 z4 = pf_splat(0.f);
+                const f4 e0 = {xi[0], xi[1], xi[2], xj[0]}, e1 = {xj[1], xj[2], 0.f, 1.f};
+                e[p][0] = pf_pair2(q == 0 ? e0 : z4, q == 0 ? e1 : z4);
+#pragma unroll
+                for (int b = 0; b < SB; ++b) pre[p][b] = pf_splat(0.f);
+            }
+            pf_mm2f<SB, 1, 1>(ws, FT, e, 0, pre, 0);
+        } else {
+#pragma unroll
+            for (int b = 0; b < SB; ++b)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const f4 pv = *reinterpret_cast<const f4*>(a.pq + (size_t)gi[p] * (2 * S) + b * 16 + 4 * q);
+                    const f4 qv = *reinterpret_cast<const f4*>(a.pq + (size_t)gj[p] * (2 * S) + S + b * 16 + 4 * q);
+                    pre[p][b] = pv + qv;
+                }
+        }
+
+        PfPair2 fp[P][2];
+        f4 last[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            last[p] = pf_lrelu(pre[p][0], 0.05f);
+            fp[p][0] = pf_pair2(last[p], pf_splat(0.f));
+        }
+        pf_static_for<1, NCONV>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int CPT = (t + 1) / 2, F0 = (t / 2) * ((t + 1) / 2);
+            f4 acc[P][1];
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p][0] = pre[p][t];
+            pf_mm2f<1, CPT, CPT>(ws, F0, fp, 0, acc, 0);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const f4 f = pf_lrelu(acc[p][0], 0.05f);
+                if constexpr (t % 2 == 1) fp[p][t / 2] = pf_pair2(last[p], f);
+                else fp[p][t / 2] = pf_pair2(f, pf_splat(0.f));
+                last[p] = f;
+            }
+        });
+
+        f4 sel[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) sel[p] = pf_splat(0.f);
+        pf_static_for<0, OBO / OCH>([&](auto cc) {
+            constexpr int ob0 = decltype(cc)::value * OCH;
+            f4 acc[P][OCH];
+#pragma unroll
+            for (int o = 0; o < OCH; ++o)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p][o] = pre[p][NCONV + ob0 + o];
+            pf_mm2f<OCH, 2, 2>(ws, FO + ob0 * 2, fp, 0, acc, 0);
+#pragma unroll
+            for (int o = 0; o < OCH; ++o)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    f4 m;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m[r] = pf_rowmax16(acc[p][o][r]);
+                    if (col == ob0 + o) sel[p] = m;
+                }
+        });
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            if (col < OBO && pt0 + p < a.T)
+                *reinterpret_cast<f4*>(a.out + (size_t)gi[p] * ODIM + col * 16 + 4 * q) = sel[p];
+    }
+}
+
+template <int ODIM, bool C3, int P, int NW>
+int launch1h(const EcArgs& a0, hipStream_t s) {
+    EcArgs a = a0;
+    a.ntiles = (a.T + NW * P - 1) / (NW * P);
+    a.chunk = (a.ntiles + 7) / 8;
+    int grid = 8 * a.chunk;
+    const int cap = 256 * (32 / NW);                      // persistent: resident workgroups only (LDS < 32 KiB each)
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL((edgeconv1h_kernel<ODIM, C3, P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    return pf_last_launch_status();
+}
+
+template <int ODIM, bool C3>
+int launch1h_v(const EcArgs& a, hipStream_t s, int variant) {
+    switch (variant) {
+        case 0: return launch1h<ODIM, C3, 2, 8>(a, s);
+        case 1: return launch1h<ODIM, C3, 1, 8>(a, s);
+        case 2: return launch1h<ODIM, C3, 1, 16>(a, s);
+        case 3: return launch1h<ODIM, C3, 2, 4>(a, s);
+        case 4: return launch1h<ODIM, C3, 4, 4>(a, s);
+        default: return PF_ERR_UNSUPPORTED;
+    }
+}
+
 template <int GB, int NCONV, int ODIM, bool C3, int P, int NW>
 int launch_v(const EcArgs& a0, hipStream_t s) {
     EcArgs a = a0;
@@ -370,6 +503,12 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
                 case 4: return launch3<4, 4, 0, 2>(a, s);
                 default: return PF_ERR_UNSUPPORTED;
             }
+        case 5:                                   // unit 0, split-fp16 (packing: ec1h_w[0]; edge table inside wfrag)
+            a.xyz = pq_or_xyz;
+            return launch1h_v<32, true>(a, s, variant);
+        case 6:                                   // unit 1, split-fp16 (packing: ec1h_w[1])
+            a.pq = pq_or_xyz;
+            return launch1h_v<64, false>(a, s, variant);
         default: return PF_ERR_UNSUPPORTED;
     }
 }
@@ -378,7 +517,7 @@ extern "C" int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, co
                            float* out, int B, int N, void* stream) {
     // shipped variants (tools/tune_edgeconv.py, MI355X): unit 0 -> (P=2, NW=8); unit 1 -> (1, 8);
     // units 2..5 -> (1, 16): one point per wave, 16 waves share the 88 KiB of LDS-resident weights.
-    static const int best[5] = {0, 2, 3, 0, 0};
-    if (cfg < 0 || cfg > 4) return PF_ERR_UNSUPPORTED;
+    static const int best[7] = {0, 2, 3, 0, 2, 0, 2};
+    if (cfg < 0 || cfg > 6) return PF_ERR_UNSUPPORTED;
     return pf_edgeconv_tuned(cfg, best[cfg], pq_or_xyz, tab, idx, wfrag, out, B, N, stream);
 }

@@ -138,6 +138,7 @@ class _Engine:
         self.ec_w = pk["ec_w"]
         self.ec3_w = pk["ec3_w"]
         self.ec2h_w = pk["ec2h_w"]
+        self.ec1h_w = pk["ec1h_w"]
         # EdgeConv arithmetic of the 128-channel units (PF_EC_MODE), all within the same 1e-5 parity bar:
         #   "f16x2" (default)  2-term split-fp16 products, three fp16 MFMAs per 32-channel step (8e-7 from the exact
         #                      kernel); needs |activation| < 65504 - beyond that the output is inf/NaN, never silently wrong
@@ -153,6 +154,21 @@ class _Engine:
 
     def _p(self, off: int) -> int:
         return self.base + 4 * off
+
+    def _edgeconv(self, u: int, src: int, idx16: Tensor, h: Tensor, B: int, N: int, s) -> None:
+        """Fused EdgeConv unit u -> h [T, odim] in the arithmetic PF_EC_MODE selects (pf_edgeconv cfg table:
+        include/puflow_hip.h)."""
+        lib = self.lib
+        if self.ec_mode == "f16x2" and u < 2:               # narrow units, edge table of unit 0 rides in the image
+            rc = lib.pf_edgeconv(5 + u, src, None, idx16.data_ptr(), self._p(self.ec1h_w[u]), h.data_ptr(), B, N, s)
+        elif u >= 2 and self.ec_mode in _EC_SPLIT:
+            cfg, wname = _EC_SPLIT[self.ec_mode]
+            rc = lib.pf_edgeconv_tuned(cfg, self.ec3_variant, src, None, idx16.data_ptr(),
+                                       self._p(getattr(self, wname)[u]), h.data_ptr(), B, N, s)
+        else:
+            tab = self._p(self.ec_tab0) if u == 0 else None
+            rc = lib.pf_edgeconv(_EC_CFG[u], src, tab, idx16.data_ptr(), self._p(self.ec_w[u]), h.data_ptr(), B, N, s)
+        _lib.check(rc, f"pf_edgeconv[{self.ec_mode}][{u}]")
 
     @staticmethod
     def _stream() -> int:
@@ -177,15 +193,7 @@ class _Engine:
             odim = FEAT_CHANNELS[u + 1]
             h = torch.empty((T, odim), dtype=torch.float32, device=dev)
             src = xyz.data_ptr() if u == 0 else pq.data_ptr()
-            tab = self._p(self.ec_tab0) if u == 0 else None
-            if u >= 2 and self.ec_mode in _EC_SPLIT:
-                cfg, wname = _EC_SPLIT[self.ec_mode]
-                _lib.check(self.lib.pf_edgeconv_tuned(cfg, self.ec3_variant, src, None, idx16.data_ptr(),
-                                                      self._p(getattr(self, wname)[u]), h.data_ptr(), B, N, s),
-                           f"pf_edgeconv[{self.ec_mode}][{u}]")
-            else:
-                _lib.check(self.lib.pf_edgeconv(_EC_CFG[u], src, tab, idx16.data_ptr(), self._p(self.ec_w[u]),
-                                                h.data_ptr(), B, N, s), f"pf_edgeconv[{u}]")
+            self._edgeconv(u, src, idx16, h, B, N, s)
             c = torch.empty((B, N, COND_CHANNELS[u]), dtype=torch.float32, device=dev) if want_cs else None
             _lib.check(self.lib.pf_post(u, h.data_ptr(), self.base, self.post[u], c.data_ptr() if want_cs else None,
                                         st[u].data_ptr(), cp[u].data_ptr(), pq.data_ptr() if u < 5 else None, T, s),
@@ -246,15 +254,7 @@ class _Engine:
             for u in range(NUM_BLOCKS):
                 h = torch.empty((T, FEAT_CHANNELS[u + 1]), dtype=torch.float32, device=dev)
                 src = xyz.data_ptr() if u == 0 else pq.data_ptr()
-                tab = self._p(self.ec_tab0) if u == 0 else None
-                if u >= 2 and self.ec_mode in _EC_SPLIT:
-                    cfg, wname = _EC_SPLIT[self.ec_mode]
-                    timed(f"edgeconv{u}", lambda: _lib.check(self.lib.pf_edgeconv_tuned(
-                        cfg, self.ec3_variant, src, None, idx16.data_ptr(), self._p(getattr(self, wname)[u]),
-                        h.data_ptr(), B, N, s)))
-                else:
-                    timed(f"edgeconv{u}", lambda: _lib.check(self.lib.pf_edgeconv(
-                        _EC_CFG[u], src, tab, idx16.data_ptr(), self._p(self.ec_w[u]), h.data_ptr(), B, N, s)))
+                timed(f"edgeconv{u}", lambda: self._edgeconv(u, src, idx16, h, B, N, s))
                 timed(f"post{u}", lambda: _lib.check(self.lib.pf_post(
                     u, h.data_ptr(), self.base, self.post[u], None, st[u].data_ptr(), cp[u].data_ptr(),
                     pq.data_ptr() if u < 5 else None, T, s)))

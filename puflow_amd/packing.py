@@ -348,6 +348,15 @@ def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
     # split-bf16 weight image of the 128-channel units (csrc/edgeconv.hip edgeconv3_kernel); None for units 0,1
     out["ec2h_w"] = [None, None] + [B.add(np.concatenate([frag_pack_f16x2(units[i][f"G{t}"]) for t in range(1, 5)]))
                                     for i in range(2, NUM_BLOCKS)]
+    # split-fp16 images of the narrow units 0 / 1 (csrc/edgeconv.hip edgeconv1h_kernel): G1 | G2 | G3 | Gout,
+    # unit 0 additionally carries its folded edge table (raw inputs -> all S pre-activations) as S/16 fragments
+    ec1h = []
+    for i in range(2):
+        parts = [frag_pack_f16x2(units[i][f"G{t}"]) for t in range(1, 5)]
+        if i == 0:
+            parts.append(_etab_frag(units[0]["PA"], units[0]["QB"], None, units[0]["pb"]))
+        ec1h.append(B.add(np.concatenate(parts)))
+    out["ec1h_w"] = ec1h + [None] * (NUM_BLOCKS - 2)
     out["ec3_w"] = [None, None] + [B.add(np.concatenate([frag_pack_bf16x3(units[i][f"G{t}"]) for t in range(1, 5)]))
                                    for i in range(2, NUM_BLOCKS)]
     post = []

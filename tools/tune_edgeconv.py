@@ -84,3 +84,21 @@ for rnd in range(6):
         if rnd > 0:
             times[v].append(a.elapsed_time(b))
 print("unit 3 f16x2", {v: f"min {min(t):.3f} ms  max|d| {dev[v][0]:.2e} (|h|max {dev[v][1]:.2f})" for v, t in times.items()}, flush=True)
+
+# ---- split-fp16 kernels of the narrow units 0 / 1 (cfg 5 / 6)
+for u in (0, 1):
+    VARS = (0, 1, 2, 3, 4)
+    times = {v: [] for v in VARS}
+    dev = {}
+    for rnd in range(6):
+        for v in VARS:
+            out = torch.empty_like(hs[u])
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = lib.pf_edgeconv_tuned(5 + u, v, pqs[u].data_ptr(), None, idx16.data_ptr(), e._p(e.ec1h_w[u]), out.data_ptr(), B, N, s)
+            b.record(); torch.cuda.synchronize()
+            assert rc == 0, rc
+            dev[v] = (float((out - hs[u]).abs().max()), float(hs[u].abs().max()))
+            if rnd > 0:
+                times[v].append(a.elapsed_time(b))
+    print(f"unit {u} f16x2", {v: f"min {min(t):.3f} ms  max|d| {dev[v][0]:.2e} (|h|max {dev[v][1]:.2f})" for v, t in times.items()}, flush=True)
