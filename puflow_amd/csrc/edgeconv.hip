@@ -181,6 +181,15 @@ template <> struct EcSplit<2> {
     static __device__ __forceinline__ Pair make(f4 a, f4 b) { return pf_pair2(a, b); }
 };
 
+struct EcWConst {                                             // DBG 3 (timing-only builds): weights without memory traffic
+    static constexpr int DEPTH = 2;
+    int lane;
+    __device__ __forceinline__ h8 load(int frag, int split) const {
+        const _Float16 x = (_Float16)(float)((lane + frag + split) & 7);
+        return (h8){x, x, x, x, x, x, x, x};
+    }
+};
+
 // acc[p][0..OB) += W feat over CP pairs, in the arithmetic of the split
 template <int NS, int OB, int CP, int WCP, class WS, class Pair, int P, int NIN>
 __device__ __forceinline__ void ec_mm(const WS& ws, int frag0, const Pair (&feat)[P][NIN], f4 (&acc)[P][OB]) {
@@ -211,7 +220,8 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
     __shared__ u4 wlds[NWF * NS * 64];
     for (int i = threadIdx.x; i < NWF * NS * 64; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
     __syncthreads();
-    const typename SP::WLds ws{wlds, lane};
+    const typename SP::WLds ws_lds{wlds, lane};
+    const auto ws = [&] { if constexpr (DBG == 3) return EcWConst{lane}; else return ws_lds; }();
 
     for (int v = blockIdx.x; v < 8 * a.chunk; v += gridDim.x) {
         const int tile = pf_xcd_tile(v, a.chunk);
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
                 for (int p = 0; p < P; ++p) {
                     f4 m;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m[r] = pf_rowmax16(acc[p][o][r]);
+                    for (int r = 0; r < 4; ++r) m[r] = DBG == 4 ? acc[p][o][r] : pf_rowmax16(acc[p][o][r]);
                     if (col == ob0 + o) sel[p] = m;
                 }
         });
@@ -501,6 +511,12 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
                 case 2: return launch3<1, 16, 0, 2>(a, s);
                 case 3: return launch3<2, 4, 0, 2>(a, s);
                 case 4: return launch3<4, 4, 0, 2>(a, s);
+#ifdef PF_TUNING_VARIANTS                                     // ablation builds only: wrong results
+                case 8: return launch3<1, 16, 1, 2>(a, s);      // no gathers
+                case 9: return launch3<1, 16, 2, 2>(a, s);      // no MFMAs
+                case 10: return launch3<1, 16, 3, 2>(a, s);     // no LDS weight reads
+                case 11: return launch3<1, 16, 4, 2>(a, s);     // no max-pool
+#endif
                 default: return PF_ERR_UNSUPPORTED;
             }
         case 5:                                   // unit 0, split-fp16 (packing: ec1h_w[0]; edge table inside wfrag)
