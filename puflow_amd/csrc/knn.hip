@@ -200,6 +200,124 @@ __global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ 
     if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
 }
 
+// ---- knn4_kernel: the two-sweep algorithm with the references split over the 4 waves of a workgroup ----
+// A workgroup owns 64 queries (lane = query in every wave); wave w scans reference quarter w.  Same 32 group
+// minima (8 strided groups per quarter), same tau, same candidates - but 4x the waves of knn2_kernel for the same
+// work: at 32 x 2048 that kernel puts ONE wave on each SIMD, so nothing hides its readlane / LDS / dependent-issue stalls.
+// Candidate lists are per (wave, lane); wave 0 inserts them in wave order = increasing index, which keeps the
+// (distance, index) tie rule.  Overflow of any list -> exact scan of that query tile by wave 0.
+#ifndef PF_KNN4_W
+#define PF_KNN4_W 4
+#endif
+constexpr int KNN4_W = PF_KNN4_W; // waves per workgroup = reference slices (4 or 8)
+constexpr int KNN4_G = 32 / KNN4_W;   // strided minimum groups per slice
+constexpr int KNN4_CAP = 32;      // per-(wave, lane) candidate list capacity
+
+template <int K>
+__global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                           int N, int M, int* __restrict__ idx_out,
+                                                           float* __restrict__ dist_out) {
+    static_assert(K <= 16, "threshold selection uses two 16-element sorted halves");
+    __shared__ float gms[32][64];
+    __shared__ unsigned short lst[KNN4_W][KNN4_CAP][64];
+    __shared__ int cnts[KNN4_W][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const bool live = n < N;
+    const float* q = p1 + ((size_t)b * N + (live ? n : N - 1)) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float* __restrict__ r = p2 + (size_t)b * M * 3;
+    const int mq = ((M + KNN4_W * 64 - 1) / (KNN4_W * 64)) * 64;      // quarter length, multiple of 64
+    const int jb = wave * mq, je = min(jb + mq, M);                   // this wave's references [jb, je)
+
+    auto load_ref = [&](int j0, float& cx, float& cy, float& cz) {     // +inf padding past the end never wins a minimum
+        const int j = j0 + lane;
+        const bool in = j < je;
+        const int jc = in ? j : M - 1;
+        cx = in ? r[jc * 3 + 0] : __builtin_inff();
+        cy = r[jc * 3 + 1];
+        cz = r[jc * 3 + 2];
+    };
+
+    // ---- sweep A: KNN4_G strided group minima of this slice
+    {
+        float gm[KNN4_G];
+#pragma unroll
+        for (int g = 0; g < KNN4_G; ++g) gm[g] = __builtin_inff();
+        float cx, cy, cz;
+        load_ref(jb, cx, cy, cz);
+        for (int j0 = jb; j0 < je; j0 += 64) {
+            float nx = cx, ny = cy, nz = cz;
+            if (j0 + 64 < je) load_ref(j0 + 64, nx, ny, nz);
+#pragma unroll
+            for (int c = 0; c < 64; ++c)
+                gm[c % KNN4_G] = fminf(gm[c % KNN4_G], sqdist(qx, qy, qz, bcast(cx, c), bcast(cy, c), bcast(cz, c)));
+            cx = nx; cy = ny; cz = nz;
+        }
+#pragma unroll
+        for (int g = 0; g < KNN4_G; ++g) gms[wave * KNN4_G + g][lane] = gm[g];
+    }
+    __syncthreads();
+    // tau = K-th smallest of the 32 group minima (every wave computes it for its lanes: same value in all four)
+    float tau;
+    {
+        float ha[16], hb[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { ha[g] = gms[g][lane]; hb[g] = gms[16 + g][lane]; }
+        sort16(ha);
+        sort16(hb);
+        tau = fminf(ha[0], hb[K - 1]);
+#pragma unroll
+        for (int i = 1; i < K; ++i) tau = fmaxf(tau, fminf(ha[i], hb[K - 1 - i]));
+    }
+
+    // ---- sweep B: collect this quarter's candidates with d <= tau (in index order)
+    int cnt = 0;
+    {
+        float cx, cy, cz;
+        load_ref(jb, cx, cy, cz);
+        for (int j0 = jb; j0 < je; j0 += 64) {
+            float nx = cx, ny = cy, nz = cz;
+            if (j0 + 64 < je) load_ref(j0 + 64, nx, ny, nz);
+#pragma unroll
+            for (int c = 0; c < 64; ++c) {
+                const float d = sqdist(qx, qy, qz, bcast(cx, c), bcast(cy, c), bcast(cz, c));
+                if (d <= tau) {
+                    if (cnt < KNN4_CAP) lst[wave][cnt][lane] = (unsigned short)(j0 + c);
+                    ++cnt;
+                }
+            }
+            cx = nx; cy = ny; cz = nz;
+        }
+    }
+    cnts[wave][lane] = cnt;
+    __syncthreads();
+    if (wave != 0) return;
+
+    float bd[K];
+    int bi[K];
+    bool over = false;
+#pragma unroll
+    for (int w = 0; w < KNN4_W; ++w) over |= cnts[w][lane] > KNN4_CAP;
+    if (__any(over)) {
+        exact_scan<K>(qx, qy, qz, r, M, bd, bi);      // heavy ties: redo this query tile exactly (rare)
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { bd[i] = __builtin_inff(); bi[i] = -1; }
+        for (int w = 0; w < KNN4_W; ++w) {
+            const int cw = cnts[w][lane];
+            for (int s = 0; __any(s < cw); ++s) {
+                if (s < cw) {
+                    const int j = lst[w][s][lane];
+                    const float d = sqdist(qx, qy, qz, r[j * 3 + 0], r[j * 3 + 1], r[j * 3 + 2]);
+                    topk_insert<K>(bd, bi, d, j);
+                }
+            }
+        }
+    }
+    if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
+}
+
 // K = 1: nearest neighbour distance + index (first minimum wins ties).  References are streamed 64 at a time
 // (lane l loads reference j0 + l) and broadcast with v_readlane, like knn2_kernel.
 __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
@@ -248,6 +366,16 @@ extern "C" int pf_knn(const float* p1, const float* p2, int B, int N, int M, int
     if (!p1 || !p2 || !idx_out) return PF_ERR_NULL;
     if (B <= 0 || N <= 0 || M <= 0 || K <= 0 || K > M || B > 65535) return PF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    if (K <= 16 && M >= 1024 && M <= 65536) {          // two-sweep kernel, references split over 4 waves
+        dim3 g4((N + 63) / 64, B), b4(KNN4_W * 64);
+        switch (K) {
+            case 4:  hipLaunchKernelGGL(knn4_kernel<4>, g4, b4, 0, s, p1, p2, N, M, idx_out, dist_out); break;
+            case 8:  hipLaunchKernelGGL(knn4_kernel<8>, g4, b4, 0, s, p1, p2, N, M, idx_out, dist_out); break;
+            case 16: hipLaunchKernelGGL(knn4_kernel<16>, g4, b4, 0, s, p1, p2, N, M, idx_out, dist_out); break;
+            default: return PF_ERR_UNSUPPORTED;
+        }
+        return pf_last_launch_status();
+    }
     if (K <= 16 && M >= 256 && M <= 65536) {           // two-sweep kernel (u16 candidate lists)
         dim3 g2((N + KNN2_T - 1) / KNN2_T, B), b2(KNN2_T);
         switch (K) {

@@ -9,11 +9,9 @@ import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {
-    "a": ["PF_POST_P=2", "PF_POST_NW=4", "PF_MM2_DEPTH=4"],
-    "b": ["PF_POST_P=2", "PF_POST_NW=4", "PF_MM2_DEPTH=8"],
-    "c": ["PF_POST_P=1", "PF_POST_NW=8", "PF_MM2_DEPTH=4"],
-    "d": ["PF_POST_P=1", "PF_POST_NW=8", "PF_MM2_DEPTH=8"],
-    "e": ["PF_POST_P=1", "PF_POST_NW=8", "PF_MM2_DEPTH=2"],
+    "a": ["PF_KNN4_W=8"],
+    "b": ["PF_INTERP_P=1", "PF_INTERP_NW=8", "PF_MM2_DEPTH=4"],
+    "c": ["PF_POST_P=1", "PF_POST_NW=8", "PF_MM2_DEPTH=8"],
 }
 if sys.argv[1] == "build":
     from puflow_amd import build
@@ -48,5 +46,5 @@ for rnd in range(5):
         if rnd:
             for k, v in pr.items(): acc.setdefault(k, {}).setdefault(tag, []).append(v)
 for k in acc:
-    if k.startswith("edgeconv") or k == "knn": continue
+    if k.startswith("edgeconv"): continue
     print(f"{k:12s}", {t: f"{min(v):.3f}" for t, v in acc[k].items()}, flush=True)
