@@ -10,7 +10,7 @@ import re
 import sys
 from collections import defaultdict
 
-SIMD_PER_CU, CUS = 4, 256
+SIMD_PER_CU, CUS, XCDS = 4, 256, 8
 
 
 def short(name: str) -> str:
@@ -41,7 +41,12 @@ def main(root: str) -> None:
             # units KB; FETCH_SIZE under-counts 16 B/lane loads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)
             e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE_mean"] + e["WRITE_SIZE_mean"]) * 1024.0
         if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in e and e.get("GRBM_GUI_ACTIVE_mean"):
-            e["mfma_util_pct"] = 100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (e["GRBM_GUI_ACTIVE_mean"] * SIMD_PER_CU * CUS)
+            # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs (value / 8 / duration = the ~2.1-2.5 GHz shader clock);
+            # MfmaUtil = busy cycles / (active cycles x SIMDs), as in counter_defs.yaml with reduce(max) over XCDs
+            gui = e["GRBM_GUI_ACTIVE_mean"] / XCDS
+            e["mfma_util_pct"] = 100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (gui * SIMD_PER_CU * CUS)
+            if e.get("avg_us"):
+                e["shader_clock_ghz"] = gui / e["avg_us"] / 1e3
         if e.get("SQ_LDS_IDX_ACTIVE_mean"):
             e["lds_conflict_pct"] = 100.0 * e.get("SQ_LDS_BANK_CONFLICT_mean", 0.0) / e["SQ_LDS_IDX_ACTIVE_mean"]
         out[k] = e

@@ -9,9 +9,9 @@ import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {
-    "a": ["PF_KNN4_W=8"],
+    "a": ["PF_INTERP_P=2", "PF_INTERP_NW=8", "PF_MM2_DEPTH=4"],
     "b": ["PF_INTERP_P=1", "PF_INTERP_NW=8", "PF_MM2_DEPTH=4"],
-    "c": ["PF_POST_P=1", "PF_POST_NW=8", "PF_MM2_DEPTH=8"],
+    "c": ["PF_INTERP_P=2", "PF_INTERP_NW=8", "PF_MM2_DEPTH=3"],
 }
 if sys.argv[1] == "build":
     from puflow_amd import build
