@@ -183,8 +183,22 @@ def main():
             cel = time.perf_counter() - t1
             cpu = {"value": bs * n / cel, "unit": "patches/s", "cores": ncpu, "kind": "port",
                    "sample": f"{n} forwards of {bs} x {args.npoint}-pt patches, fp32 torch-CPU oracle (oracle/ref_cpu.py)"}
+            # SURVEY 8(d) parity report, on the same sample the CPU baseline just computed (checker use of the oracle)
+            from puflow_amd import ops
             err = (x[:bs].cpu() - xr).abs().max().item()
-            extra["parity"] = {"max_abs_dx_vs_oracle": err,
+            _, i_ref = O.knn_canonical(xs, xs, 16)
+            knn_match = (eng.knn(xyz[:bs]).cpu().long() == i_ref).float().mean().item()
+            st_b = net.forward_stages(xyz[:bs], 4)
+            st_o = O.forward(sd, xs, 4, stages=True)
+            ld_rel = ((st_b["ldj"].cpu() - st_o["ldj"]).abs() / st_o["ldj"].abs()).max().item()
+            xr_d = xr.to(dev)
+            cd_bo = ops.history_chamfer_distance(x[:bs].contiguous(), xr_d).max().item()     # CD(build, oracle)
+            gt = synth_patches(bs, 4 * args.npoint, seed=7, surface=True).to(dev)            # a common target cloud
+            cd_diff = (ops.history_chamfer_distance(x[:bs].contiguous(), gt)
+                       - ops.history_chamfer_distance(xr_d, gt)).abs().max().item()
+            extra["parity"] = {"max_abs_dx_vs_oracle": err, "knn_idx_exact_match_rate": knn_match,
+                               "max_rel_err_log_det": ld_rel, "cd_build_vs_oracle": cd_bo,
+                               "abs_cd_diff_vs_common_target": cd_diff,
                                "logp_note": "logp is a batch mean; compared in tests on equal batches"}
         out = {"metric": "patches/sec x4 2048->8192 (PU1K discrete, eval)", "value": value, "unit": "patches/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
