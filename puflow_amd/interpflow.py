@@ -25,6 +25,7 @@ from . import _lib
 from .packing import COND_CHANNELS, FEAT_CHANNELS, GROWTH, NUM_BLOCKS, fold_state_dict, pack_plan
 
 _EC_CFG = [0, 1, 2, 2, 2, 2]
+_CHECK_FINITE = os.environ.get("PF_CHECK_FINITE", "0") == "1"      # debug aid: verify every eval forward is finite (syncs)
 _EC_SPLIT = {"bf16x3": (3, "ec3_w"), "f16x2": (4, "ec2h_w")}     # PF_EC_MODE -> (pf_edgeconv cfg, weight image)
 
 
@@ -376,6 +377,11 @@ class PointInterpFlow(nn.Module):
         z, _, logp = e.flow_f(xyz, cp, st)
         u = e.interp(xyz, z, idx16)
         x = e.flow_g(u, cp, st, upratio)
+        if _CHECK_FINITE and not bool(torch.isfinite(x).all() & torch.isfinite(logp)):
+            # the split-fp16 kernels overflow to inf/NaN when an activation or weight leaves the fp16 range (65504):
+            # loud by construction; this opt-in check (it synchronises) turns it into an error with the remedy
+            raise _lib.PuflowHipError("non-finite output: an activation left the fp16 range of the split-fp16 kernels "
+                                      "(or the input holds NaN/inf); check the input normalisation (patch.py:168-178)")
         return x, logp
 
     @torch.no_grad()

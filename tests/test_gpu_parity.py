@@ -265,3 +265,19 @@ def test_full_size_properties(lib):
     ref = O.forward(sd, xyz[3:5], 4, stages=True)
     assert (x[3:5].cpu() - ref["x"]).abs().max() < 1e-5
     assert ((st["ldj"][3:5].cpu() - ref["ldj"]).abs() / ref["ldj"].abs()).max() < 1e-5
+
+
+def test_fp16_range_violation_is_loud(lib, monkeypatch):
+    """The split-fp16 kernels need |activation| < 65504.  A grossly un-normalised input must not produce a plausible
+    finite cloud: the output is non-finite, and with PF_CHECK_FINITE the forward raises."""
+    import puflow_amd.interpflow as M
+    sd = synth_state_dict(3)
+    net = _net(sd)
+    xyz = synth_patches(1, 256, seed=3).to(DEV) * 1e7
+    x, _ = net(xyz, 4)
+    assert not bool(torch.isfinite(x).all())
+    monkeypatch.setattr(M, "_CHECK_FINITE", True)
+    with pytest.raises(M._lib.PuflowHipError):
+        net(xyz, 4)
+    x_ok, _ = net(synth_patches(1, 256, seed=3).to(DEV), 4)          # the same net on a normalised patch is fine
+    assert bool(torch.isfinite(x_ok).all())
