@@ -181,7 +181,7 @@ template <> struct EcSplit<2> {
     static __device__ __forceinline__ Pair make(f4 a, f4 b) { return pf_pair2(a, b); }
 };
 
-struct EcWConst {                                             // DBG 3 (timing-only builds): weights without memory traffic
+struct EcWConst {                                             // DBG & 4 (timing-only builds): weights without memory traffic
     static constexpr int DEPTH = 2;
     int lane;
     __device__ __forceinline__ h8 load(int frag, int split) const {
@@ -209,7 +209,7 @@ __device__ __forceinline__ void ec_mm(const WS& ws, int frag0, const Pair (&feat
     }
 }
 
-template <int NCONV, int ODIM, int P, int NW, int DBG = 0, int NS = 3>   // DBG (timing-only builds): 1 = no gathers, 2 = no MFMAs
+template <int NCONV, int ODIM, int P, int NW, int DBG = 0, int NS = 3>   // DBG bit mask (timing-only builds): 1 no gathers, 2 no MFMAs, 4 no LDS weight reads, 8 no max-pool
 __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
     constexpr int G = 32, S = G * NCONV + ODIM, OBO = ODIM / 16, OCH = 2;
     constexpr int NWF = 2 * (NCONV * (NCONV - 1) / 2) + OBO * NCONV;      // (ob, pair) fragments, NS KiB each
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
     for (int i = threadIdx.x; i < NWF * NS * 64; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
     __syncthreads();
     const typename SP::WLds ws_lds{wlds, lane};
-    const auto ws = [&] { if constexpr (DBG == 3) return EcWConst{lane}; else return ws_lds; }();
+    const auto ws = [&] { if constexpr ((DBG & 4) != 0) return EcWConst{lane}; else return ws_lds; }();
 
     for (int v = blockIdx.x; v < 8 * a.chunk; v += gridDim.x) {
         const int tile = pf_xcd_tile(v, a.chunk);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
             gj[p] = (g / a.N) * a.N + a.idx[(size_t)g * 16 + col];
         }
         auto init = [&](int p, int off) -> f4 {
-            if constexpr (DBG == 1) return pf_splat((float)(off + gi[p]) * 1e-6f);
+            if constexpr (DBG & 1) return pf_splat((float)(off + gi[p]) * 1e-6f);
             const f4 pv = *reinterpret_cast<const f4*>(a.pq + (size_t)gi[p] * (2 * S) + off);
             const f4 qv = *reinterpret_cast<const f4*>(a.pq + (size_t)gj[p] * (2 * S) + S + off);
             return pv + qv;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
             for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][ob] = ini[t & 1][p][ob];
-            if constexpr (DBG != 2) ec_mm<NS, 2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, acc);
+            if constexpr (!(DBG & 2)) ec_mm<NS, 2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, acc);
 #pragma unroll
             for (int p = 0; p < P; ++p)
                 feat[p][t] = SP::make(pf_lrelu(acc[p][0], 0.05f), pf_lrelu(acc[p][1], 0.05f));
@@ -281,14 +281,14 @@ __global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
             for (int o = 0; o < OCH; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][o] = ini[st & 1][p][o];
-            if constexpr (DBG != 2) ec_mm<NS, OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, acc);
+            if constexpr (!(DBG & 2)) ec_mm<NS, OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, acc);
 #pragma unroll
             for (int o = 0; o < OCH; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     f4 m;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m[r] = DBG == 4 ? acc[p][o][r] : pf_rowmax16(acc[p][o][r]);
+                    for (int r = 0; r < 4; ++r) m[r] = (DBG & 8) ? acc[p][o][r] : pf_rowmax16(acc[p][o][r]);
                     if (col == ob0 + o) sel[p] = m;
                 }
         });
@@ -514,8 +514,11 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
 #ifdef PF_TUNING_VARIANTS                                     // ablation builds only: wrong results
                 case 8: return launch3<1, 16, 1, 2>(a, s);      // no gathers
                 case 9: return launch3<1, 16, 2, 2>(a, s);      // no MFMAs
-                case 10: return launch3<1, 16, 3, 2>(a, s);     // no LDS weight reads
-                case 11: return launch3<1, 16, 4, 2>(a, s);     // no max-pool
+                case 10: return launch3<1, 16, 4, 2>(a, s);     // no LDS weight reads
+                case 11: return launch3<1, 16, 8, 2>(a, s);     // no max-pool
+                case 12: return launch3<1, 16, 5, 2>(a, s);     // no gathers, no LDS weight reads
+                case 13: return launch3<1, 16, 13, 2>(a, s);    // ... and no max-pool: MFMA + split only
+                case 14: return launch3<1, 16, 15, 2>(a, s);    // nothing but the split / lrelu VALU work
 #endif
                 default: return PF_ERR_UNSUPPORTED;
             }

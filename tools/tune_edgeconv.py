@@ -69,7 +69,7 @@ for rnd in range(6):
 print("unit 3 bf16x3", {v: f"min {min(t):.3f} ms  max|d| {dev[v][0]:.2e} (|h|max {dev[v][1]:.2f})" for v, t in times.items()}, flush=True)
 
 # ---- split-fp16 variants of unit 3 (cfg 4); 8..11 = ablations (need a -DPF_TUNING_VARIANTS build)
-VARS = (0, 1, 2, 8, 9, 10, 11) if '--ablate' in sys.argv else (0, 1, 2, 3, 4)
+VARS = (2, 8, 9, 10, 11, 12, 13, 14) if '--ablate' in sys.argv else (0, 1, 2, 3, 4)
 times = {v: [] for v in VARS}
 dev = {}
 for rnd in range(6):
