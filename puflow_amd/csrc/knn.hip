@@ -27,6 +27,7 @@
 namespace {
 
 __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float rx, float ry, float rz) {
+#pragma clang fp contract(off)          // ((dx*dx) + (dy*dy)) + (dz*dz), never an fma: bit-exact with the reference order
     const float dx = __fsub_rn(qx, rx), dy = __fsub_rn(qy, ry), dz = __fsub_rn(qz, rz);
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
@@ -211,6 +212,10 @@ __global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ 
 #endif
 constexpr int KNN4_W = PF_KNN4_W; // waves per workgroup = reference slices (4 or 8)
 constexpr int KNN4_G = 32 / KNN4_W;   // strided minimum groups per slice
+#ifndef PF_KNN4_U
+#define PF_KNN4_U 32
+#endif
+constexpr int KNN4_U = PF_KNN4_U;     // references per unrolled chunk (multiple of KNN4_G)
 constexpr int KNN4_CAP = 32;      // per-(wave, lane) candidate list capacity
 
 template <int K>
@@ -221,38 +226,38 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
     __shared__ float gms[32][64];
     __shared__ unsigned short lst[KNN4_W][KNN4_CAP][64];
     __shared__ int cnts[KNN4_W][64];
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform (SGPR) by construction
     const int n = blockIdx.x * 64 + lane;
     const bool live = n < N;
     const float* q = p1 + ((size_t)b * N + (live ? n : N - 1)) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float* __restrict__ r = p2 + (size_t)b * M * 3;
-    const int mq = ((M + KNN4_W * 64 - 1) / (KNN4_W * 64)) * 64;      // quarter length, multiple of 64
+    const int mq = ((M + KNN4_W * 64 - 1) / (KNN4_W * 64)) * 64;      // slice length, multiple of 64
     const int jb = wave * mq, je = min(jb + mq, M);                   // this wave's references [jb, je)
-
-    auto load_ref = [&](int j0, float& cx, float& cy, float& cz) {     // +inf padding past the end never wins a minimum
-        const int j = j0 + lane;
-        const bool in = j < je;
-        const int jc = in ? j : M - 1;
-        cx = in ? r[jc * 3 + 0] : __builtin_inff();
-        cy = r[jc * 3 + 1];
-        cz = r[jc * 3 + 2];
-    };
+    const int jfull = jb + ((je - jb) > 0 ? ((je - jb) / KNN4_U) * KNN4_U : 0);   // end of the unguarded chunks
+    // References are wave-uniform: r[j] below compiles to scalar loads (s_load_dwordx*), the coordinates are SGPR
+    // operands of the distance arithmetic - no VALU slot, no LDS, no cross-lane traffic is spent on them.
 
     // ---- sweep A: KNN4_G strided group minima of this slice
     {
         float gm[KNN4_G];
 #pragma unroll
         for (int g = 0; g < KNN4_G; ++g) gm[g] = __builtin_inff();
-        float cx, cy, cz;
-        load_ref(jb, cx, cy, cz);
-        for (int j0 = jb; j0 < je; j0 += 64) {
-            float nx = cx, ny = cy, nz = cz;
-            if (j0 + 64 < je) load_ref(j0 + 64, nx, ny, nz);
+        for (int j0 = jb; j0 < jfull; j0 += KNN4_U) {
 #pragma unroll
-            for (int c = 0; c < 64; ++c)
-                gm[c % KNN4_G] = fminf(gm[c % KNN4_G], sqdist(qx, qy, qz, bcast(cx, c), bcast(cy, c), bcast(cz, c)));
-            cx = nx; cy = ny; cz = nz;
+            for (int c = 0; c < KNN4_U; ++c) {
+                const float* rr = r + (size_t)(j0 + c) * 3;
+                gm[c % KNN4_G] = fminf(gm[c % KNN4_G], sqdist(qx, qy, qz, rr[0], rr[1], rr[2]));
+            }
+        }
+        for (int j0 = jfull; j0 < je; j0 += KNN4_G) {                   // tail: uniform guards, same group order
+#pragma unroll
+            for (int g = 0; g < KNN4_G; ++g)
+                if (j0 + g < je) {
+                    const float* rr = r + (size_t)(j0 + g) * 3;
+                    gm[g] = fminf(gm[g], sqdist(qx, qy, qz, rr[0], rr[1], rr[2]));
+                }
         }
 #pragma unroll
         for (int g = 0; g < KNN4_G; ++g) gms[wave * KNN4_G + g][lane] = gm[g];
@@ -271,25 +276,21 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
         for (int i = 1; i < K; ++i) tau = fmaxf(tau, fminf(ha[i], hb[K - 1 - i]));
     }
 
-    // ---- sweep B: collect this quarter's candidates with d <= tau (in index order)
+    // ---- sweep B: collect this slice's candidates with d <= tau (in index order)
     int cnt = 0;
-    {
-        float cx, cy, cz;
-        load_ref(jb, cx, cy, cz);
-        for (int j0 = jb; j0 < je; j0 += 64) {
-            float nx = cx, ny = cy, nz = cz;
-            if (j0 + 64 < je) load_ref(j0 + 64, nx, ny, nz);
-#pragma unroll
-            for (int c = 0; c < 64; ++c) {
-                const float d = sqdist(qx, qy, qz, bcast(cx, c), bcast(cy, c), bcast(cz, c));
-                if (d <= tau) {
-                    if (cnt < KNN4_CAP) lst[wave][cnt][lane] = (unsigned short)(j0 + c);
-                    ++cnt;
-                }
-            }
-            cx = nx; cy = ny; cz = nz;
+    auto visit = [&](int j) {
+        const float* rr = r + (size_t)j * 3;
+        const float d = sqdist(qx, qy, qz, rr[0], rr[1], rr[2]);
+        if (d <= tau) {
+            if (cnt < KNN4_CAP) lst[wave][cnt][lane] = (unsigned short)j;
+            ++cnt;
         }
+    };
+    for (int j0 = jb; j0 < jfull; j0 += KNN4_U) {
+#pragma unroll
+        for (int c = 0; c < KNN4_U; ++c) visit(j0 + c);
     }
+    for (int j = jfull; j < je; ++j) visit(j);
     cnts[wave][lane] = cnt;
     __syncthreads();
     if (wave != 0) return;
@@ -318,41 +319,32 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
     if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
 }
 
-// K = 1: nearest neighbour distance + index (first minimum wins ties).  References are streamed 64 at a time
-// (lane l loads reference j0 + l) and broadcast with v_readlane, like knn2_kernel.
+// K = 1: nearest neighbour distance + index (first minimum wins ties).
 __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
                                                   int N, int M, float* __restrict__ dist_out,
                                                   int* __restrict__ idx_out) {
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
     const bool live = n < N;
     const float* q = p1 + ((size_t)b * N + (live ? n : N - 1)) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float* __restrict__ r = p2 + (size_t)b * M * 3;
-    auto load_ref = [&](int j0, float& cx, float& cy, float& cz) {
-        const int j = j0 + lane;
-        const bool in = j < M;
-        const int jc = in ? j : M - 1;
-        cx = in ? r[jc * 3 + 0] : __builtin_inff();           // padding: distance +inf never beats a real reference
-        cy = r[jc * 3 + 1];
-        cz = r[jc * 3 + 2];
-    };
+    // references are wave-uniform: scalar loads, SGPR operands (see knn4_kernel)
     float best = __builtin_inff();
     int besti = 0;
-    float cx, cy, cz;
-    load_ref(0, cx, cy, cz);
-    for (int j0 = 0; j0 < M; j0 += 64) {
-        float nx = cx, ny = cy, nz = cz;
-        if (j0 + 64 < M) load_ref(j0 + 64, nx, ny, nz);
+    auto visit = [&](int j) {
+        const float* rr = r + (size_t)j * 3;
+        const float d = sqdist(qx, qy, qz, rr[0], rr[1], rr[2]);
+        const bool lt = d < best;                               // strict: the first minimum is kept
+        best = lt ? d : best;
+        besti = lt ? j : besti;
+    };
+    const int mfull = (M / 32) * 32;
+    for (int j0 = 0; j0 < mfull; j0 += 32) {
 #pragma unroll
-        for (int c = 0; c < 64; ++c) {
-            const float d = sqdist(qx, qy, qz, bcast(cx, c), bcast(cy, c), bcast(cz, c));
-            const bool lt = d < best;                           // strict: the first minimum is kept
-            best = lt ? d : best;
-            besti = lt ? j0 + c : besti;
-        }
-        cx = nx; cy = ny; cz = nz;
+        for (int c = 0; c < 32; ++c) visit(j0 + c);
     }
+    for (int j = mfull; j < M; ++j) visit(j);
     if (live) {
         dist_out[(size_t)b * N + n] = best;
         if (idx_out) idx_out[(size_t)b * N + n] = besti;

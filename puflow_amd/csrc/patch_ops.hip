@@ -11,6 +11,7 @@
 namespace {
 
 __device__ __forceinline__ float sqd(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)          // unfused, whatever -ffp-contract says
     const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
