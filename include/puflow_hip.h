@@ -193,7 +193,9 @@ int pf_dist_feature(const float* xyz, const int* idx, int B, int N, int K, float
  * ------------------------------------------------------------------------------------------- */
 
 /* Farthest point sampling.  Replaces pointnet2_ops furthest_point_sample (patch.py:102,156).
- * xyz [B,N,3] -> idx_out [B,npoint] int32; starts at index 0; first maximum wins ties; mind: [B,N] float scratch. */
+ * xyz [B,N,3] -> idx_out [B,npoint] int32; starts at index 0; first maximum wins ties; mind: [B,N] float scratch,
+ * 8-byte aligned (running min-distances, or - clouds of >= 8192 points, <= 32 cooperating workgroups per cloud -
+ * the candidate exchange ring; overwritten either way). */
 int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, int* idx_out, void* stream);
 
 /* K nearest references of every query for large K (patch extraction, K = 256).  Replaces knn_cuda.KNN

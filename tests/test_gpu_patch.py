@@ -14,12 +14,15 @@ from puflow_amd.weights import synth_patches, synth_state_dict
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("B,N,npoint", [(2, 2048, 32), (1, 5000, 78), (3, 700, 700), (1, 10240, 2054)])
+@pytest.mark.parametrize("B,N,npoint", [(2, 2048, 32), (1, 5000, 78), (3, 700, 700), (1, 10240, 2054),
+                                        (3, 40960, 600), (1, 99840, 300), (2, 200001, 64), (9, 8192, 100)])
 def test_fps_bit_exact(B, N, npoint):
+    """N >= 8192 takes the cooperative multi-workgroup kernel (1, 4 or 8 points per thread; several clouds at once)."""
     from puflow_amd import ops
     xyz = synth_patches(B, N, seed=N, surface=(N % 2 == 0))
-    if N == 700:
+    if N == 700 or N == 40960:
         xyz[0, 5] = xyz[0, 9]                          # duplicates: ties resolve to the first maximum
+        xyz[0, N - 1] = xyz[0, 3]
     ref = P.fps(xyz, npoint)
     got = ops.furthest_point_sample(xyz.to(DEV), npoint)
     assert torch.equal(got.cpu().long(), ref)
