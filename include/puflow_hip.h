@@ -204,6 +204,31 @@ int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, int* idx_out
 int pf_knn_large(const float* ref, const float* query, int B, int N, int M, int K, int* idx_out, float* dist_out,
                  void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Continuous (CNF) flow blocks (modules/continuous/), csrc/cnf.hip.  State rows are [y0 y1 y2 logp].
+ * ------------------------------------------------------------------------------------------- */
+
+/* One right-hand-side evaluation of a block's ODE, fused with the Runge-Kutta stage state:
+ *   yi = y0 + h * sum_{j<ncoef} coef[j] * k[j]          (k: [7][rows][4] stage buffer; coef: host array)
+ *   kout = sgn * ( f(t, yi), -e^T (df/dy) e )            (ODEfunc.forward odefunc.py:121-148, ODEnet :60-104,
+ *                                                          ConcatSquashLinear diffeq_layers.py:72-86,
+ *                                                          divergence_approx odefunc.py:9-31)
+ * ctx [T,288]: per-point context terms (packing.pack_cnf_block), e [T,3] Hutchinson vector, row -> point = row / R,
+ * rec: the block's weight record.  yout (nullable) receives yi.  sgn = -1 integrates backwards in time the way
+ * torchdiffeq does (t' = -t, f' = -f). */
+int pf_cnf_rhs(const float* y0, const float* k, const float* coef, int ncoef, float h, float t, float sgn,
+               const float* ctx, const float* e, const float* rec, float* kout, float* yout, int rows, int R,
+               void* stream);
+
+/* out[i] = sum_{j<n_terms} w[j] * ptrs[j][i]   (n_terms <= 8; ptrs / w are HOST arrays).  Runge-Kutta solution,
+ * mid-point and dense-output combinations of torchdiffeq's dopri5 (cnf.py:97-113 call site). */
+int pf_lincomb(const float* const* ptrs, const float* w, int n_terms, float* out, long long n, void* stream);
+
+/* out[0] (double, device) = sum_i (v_i / (atol + rtol * max(|s0_i|, |s1_i|)))^2, v = a - b (b, s1 nullable), or
+ * v = h * sum_j w[j] * k[j][i] when n_terms > 0 (the embedded error estimate).  ws: >= 256 doubles.  Deterministic. */
+int pf_scaled_sumsq(const float* a, const float* b, const float* s0, const float* s1, const float* k, const float* w,
+                    int n_terms, float h, float rtol, float atol, long long n, double* ws, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,14 +8,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpuflow_hip.so")
-SOURCES = ["api.hip", "knn.hip", "edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip", "chamfer.hip", "emd.hip", "train_ops.hip", "patch_ops.hip"]
+SOURCES = ["api.hip", "knn.hip", "edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip", "chamfer.hip", "emd.hip", "train_ops.hip", "patch_ops.hip", "cnf.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-result"]
 # The fused MFMA kernels never see NaNs; without the flag every fmaxf() is preceded by a canonicalising v_max x,x and
 # the DPP row-max steps stay as v_mov_dpp + v_max instead of one v_max_f32_dpp (3x the instructions of a max-pool).
 # No reassociation is enabled; the exact-order kernels (kNN, Chamfer, EMD, FPS, training ops) keep default semantics.
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs; the AGPR form hipcc picks under pressure costs one
 # v_accvgpr_read per accumulator register before any VALU use (every layer here) and halves the occupancy.
-EXTRA_FLAGS = {s: ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] for s in ("edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip")}
+EXTRA_FLAGS = {s: ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] for s in ("edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip", "cnf.hip")}
 
 
 def _stale(target: str, deps) -> bool:

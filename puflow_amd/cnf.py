@@ -1,0 +1,317 @@
+"""Continuous (CNF) PU-Flow: `modules/continuous/interpflow.py` on the HIP library.
+
+Same constructor, methods and the 390 state-dict keys of the reference's continuous `PointInterpFlow`
+(`pretrain/puflow-x4-cnf-pu1k.pt` loads with `load_state_dict`).  Eval / inference only.
+
+What runs where:
+  * kNN, the six EdgeConv units, the merge units and the interpolation module are the discrete model's kernels
+    (the reference imports those modules from the discrete file too, continuous/interpflow.py:14);
+  * the per-point context terms of every ConcatSquash layer: one GEMM per block (`pf_gemm`);
+  * every ODE right-hand side incl. the Hutchinson term, the Runge-Kutta stage states, the error / step norms:
+    `pf_cnf_rhs`, `pf_lincomb`, `pf_scaled_sumsq` (csrc/cnf.hip);
+  * the adaptive step-size CONTROL of dopri5 (torchdiffeq semantics restated from its published algorithm, see
+    oracle/cnf_ref.py header): a few host scalars per step - one device->host read of the error norm per step.
+
+Parity: UNPINNED against the reference (torchdiffeq is not installed and not vendored); the tests pin this path to
+oracle/cnf_ref.py, a from-text restatement.  Tolerance is the solver's own (atol = rtol = 1e-5).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib
+from .interpflow import (COND_CHANNELS, FEAT_CHANNELS, GROWTH, NUM_BLOCKS, CondList, _EdgeConvParams, _Engine,
+                         _InterpParams, _MergeParams)
+from .packing import CNF_CTX, pack_cnf_block
+from .train_ops import _gemm
+from .weights import state_dict_spec
+
+ATOL = RTOL = 1e-5                       # continuous/interpflow.py:28
+SAFETY, IFACTOR, DFACTOR, ORDER = 0.9, 10.0, 0.2, 5
+DP_ALPHA = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+DP_BETA = [
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+DP_C_ERR = [35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+            -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1. / 60.]
+DP_C_MID = [6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+            187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
+
+
+# ---- parameter holders (key names of the reference) ------------------------------------------------
+class _ConcatSquashParams(nn.Module):
+    """diffeq_layers.py:72-86."""
+
+    def __init__(self, din: int, dout: int, dc: int):
+        super().__init__()
+        self._layer = nn.Linear(din, dout)
+        self._hyper_bias = nn.Linear(1 + dc, dout, bias=False)
+        self._hyper_gate = nn.Linear(1 + dc, dout)
+
+
+class _ODEnetParams(nn.Module):
+    def __init__(self, dc: int):
+        super().__init__()
+        self.layers = nn.ModuleList([_ConcatSquashParams(3, 64, dc), _ConcatSquashParams(64, 64, dc),
+                                     _ConcatSquashParams(64, 3, dc)])
+
+
+class _ODEfuncParams(nn.Module):
+    def __init__(self, dc: int):
+        super().__init__()
+        self.diffeq = _ODEnetParams(dc)
+        self.register_buffer("_num_evals", torch.tensor(0.))
+
+
+class _CNFParams(nn.Module):
+    def __init__(self, dc: int):
+        super().__init__()
+        self.register_parameter("sqrt_end_time", nn.Parameter(torch.sqrt(torch.tensor(0.5))))     # cnf.py:41
+        self.odefunc = _ODEfuncParams(dc)
+
+
+class _CNFBlockParams(nn.Module):
+    def __init__(self, dc: int):
+        super().__init__()
+        self.cnf = _CNFParams(dc)
+
+
+def _discrete_shell(sd) -> dict:
+    """A discrete-model state dict around the shared extractor / interpolation weights: the discrete engine is reused
+    for kNN, EdgeConv, merge (-> cs) and interpolation; its flow blocks get neutral parameters and are never run."""
+    out = {}
+    for key, shape, kind in state_dict_spec():
+        if key in sd:
+            out[key] = sd[key]
+        elif kind == "inv1x1":
+            out[key] = torch.eye(3)
+        elif kind == "rev":
+            out[key] = torch.tensor([2, 1, 0], dtype=torch.int64)
+        elif kind == "nbt":
+            out[key] = torch.tensor(0, dtype=torch.int64)
+        else:
+            out[key] = torch.zeros(shape)
+    return out
+
+
+class _CnfEngine:
+    """Device-side plan of the continuous model + the dopri5 driver."""
+
+    def __init__(self, sd, device: torch.device, upratio: int):
+        self.lib = _lib.load()
+        self.device = device
+        self.R = upratio
+        self.base = _Engine(_discrete_shell(sd), device, upratio)
+        self.rec, self.Hc, self.hb, self.T_end = [], [], [], []
+        for i in range(NUM_BLOCKS):
+            rec, Hc, hb, T_end = pack_cnf_block(sd, i)
+            self.rec.append(torch.from_numpy(rec).to(device))
+            self.Hc.append(torch.from_numpy(Hc).to(device))
+            self.hb.append(torch.from_numpy(hb).to(device))
+            self.T_end.append(T_end)
+        self.ws = torch.empty(256, dtype=torch.float64, device=device)
+        self.red = torch.empty(1, dtype=torch.float64, device=device)
+        self.nfe = 0
+        self.accepted = 0
+        self.rejected = 0
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    # ---- kernels ----------------------------------------------------------------------------------
+    def context(self, i: int, c: Tensor) -> Tensor:
+        """ctx [T,288] = c Hc^T + hb: everything a ConcatSquash layer takes from the context."""
+        T, cd = c.shape
+        ctx = torch.empty((T, CNF_CTX), dtype=torch.float32, device=c.device)
+        _gemm(c, cd, 1, self.Hc[i], 1, cd, ctx, CNF_CTX, self.hb[i], T, CNF_CTX, cd)
+        return ctx
+
+    def _rhs(self, i, y0, K, coef, h, t, sgn, ctx, e, kout, yout, rows, R):
+        n = len(coef)
+        arr = (ctypes.c_float * max(n, 1))(*[float(v) for v in coef])
+        _lib.check(self.lib.pf_cnf_rhs(y0.data_ptr(), K.data_ptr() if n else None, arr, n, float(h), float(t), float(sgn),
+                                       ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), kout.data_ptr(),
+                                       yout.data_ptr() if yout is not None else None, rows, R, self._stream()), "pf_cnf_rhs")
+        self.nfe += 1
+
+    def _lincomb(self, ptrs: List[Tensor], w: List[float], out: Tensor) -> None:
+        n = len(ptrs)
+        pa = (ctypes.c_void_p * n)(*[p.data_ptr() for p in ptrs])
+        wa = (ctypes.c_float * n)(*[float(v) for v in w])
+        _lib.check(self.lib.pf_lincomb(pa, wa, n, out.data_ptr(), out.numel(), self._stream()), "pf_lincomb")
+
+    def _sumsq(self, a, b, s0, s1, K=None, w=None, h=0.0) -> float:
+        n_terms = len(w) if w is not None else 0
+        wa = (ctypes.c_float * max(n_terms, 1))(*([float(v) for v in w] if w is not None else [0.0]))
+        _lib.check(self.lib.pf_scaled_sumsq(a.data_ptr() if a is not None else None, b.data_ptr() if b is not None else None,
+                                            s0.data_ptr(), s1.data_ptr() if s1 is not None else None,
+                                            K.data_ptr() if K is not None else None, wa, n_terms, float(h), RTOL, ATOL,
+                                            s0.numel(), self.ws.data_ptr(), self.red.data_ptr(), self._stream()),
+                   "pf_scaled_sumsq")
+        return float(self.red.item())                       # the one device->host read per norm
+
+    # ---- dopri5 (control flow of torchdiffeq's adaptive solver, restated: oracle/cnf_ref.py::dopri5) ------
+    def integrate(self, i: int, x: Tensor, ctx: Tensor, e: Tensor, R: int, reverse: bool, extra_n: int,
+                  extra_d0: float) -> Tensor:
+        """x [rows,3] -> state [rows,4] = (x', delta logp) at the end time of block i."""
+        rows = x.shape[0]
+        dev = x.device
+        T = self.T_end[i]
+        t0, t1 = (0.0, T) if not reverse else (-T, 0.0)
+        sgn = 1.0 if not reverse else -1.0
+        n_tot = float(rows * 4 + extra_n)
+
+        def net_t(s: float) -> float:                         # the time the network sees
+            return s if not reverse else -s
+
+        y = torch.zeros((rows, 4), dtype=torch.float32, device=dev)
+        y[:, :3] = x
+        K = torch.empty((7, rows, 4), dtype=torch.float32, device=dev)
+        y1 = torch.empty_like(y)
+        tmp = torch.empty_like(y)
+        f1 = torch.empty_like(y)
+        # f0 and the initial step
+        self._rhs(i, y, K, [], 0.0, net_t(t0), sgn, ctx, e, K[0], None, rows, R)
+        d0 = math.sqrt((self._sumsq(y, None, y, None) + extra_d0) / n_tot)
+        d1 = math.sqrt(self._sumsq(K[0], None, y, None) / n_tot)
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        self._rhs(i, y, K, [1.0], h0, net_t(t0 + h0), sgn, ctx, e, f1, None, rows, R)
+        d2 = math.sqrt(self._sumsq(f1, K[0], y, None) / n_tot) / h0
+        h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / ORDER)
+        dt = min(100 * h0, h1)
+
+        t = t0
+        last = None
+        while t1 > t:
+            for s in range(6):
+                self._rhs(i, y, K, DP_BETA[s], dt, net_t(t + DP_ALPHA[s] * dt), sgn, ctx, e, K[s + 1],
+                          y1 if s == 5 else None, rows, R)
+            ratio = math.sqrt(self._sumsq(None, None, y, y1, K, DP_C_ERR, dt) / n_tot)
+            if ratio <= 1.0:
+                self.accepted += 1
+                nxt = t + dt
+                if t1 <= nxt:                                  # the step covers the end time: dense output there
+                    self._lincomb([y] + [K[j] for j in range(7)], [1.0] + [dt * c for c in DP_C_MID], tmp)     # y_mid
+                    xx = (t1 - t) / dt
+                    x2, x3, x4 = xx * xx, xx ** 3, xx ** 4
+                    w = [-8 * x4 + 18 * x3 - 11 * x2 + 1, -8 * x4 + 14 * x3 - 5 * x2, 16 * x4 - 32 * x3 + 16 * x2,
+                         dt * (-2 * x4 + 5 * x3 - 4 * x2 + xx), dt * (2 * x4 - 3 * x3 + x2)]
+                    out = torch.empty_like(y)
+                    self._lincomb([y, y1, tmp, K[0], K[6]], w, out)
+                    last = out
+                t = nxt
+                y, y1 = y1, y                                  # accepted state; FSAL derivative moves to slot 0
+                K[0].copy_(K[6])
+            else:
+                self.rejected += 1
+            if ratio == 0:
+                dt = dt * IFACTOR
+            else:
+                dfac = 1.0 if ratio < 1 else DFACTOR
+                dt = dt * min(IFACTOR, max(SAFETY / ratio ** (1.0 / ORDER), dfac))
+        return last
+
+
+class PointInterpFlow(nn.Module):
+    """Reference surface: modules/continuous/interpflow.py:53-139 (the continuous `PointInterpFlow`)."""
+
+    def __init__(self, pc_channel: int = 3):
+        super().__init__()
+        if pc_channel != 3:
+            raise ValueError("the HIP path is built for 3-D points (pc_channel=3)")
+        self.num_blocks = NUM_BLOCKS
+        self.num_neighbors = 16
+        self.interp = _InterpParams()
+        self.feat_convs = nn.ModuleList(
+            [_EdgeConvParams(FEAT_CHANNELS[i], FEAT_CHANNELS[i + 1], GROWTH[i]) for i in range(NUM_BLOCKS)])
+        self.merge_convs = nn.ModuleList(
+            [_MergeParams(FEAT_CHANNELS[i + 1], COND_CHANNELS[i]) for i in range(NUM_BLOCKS)])
+        self.flow_blocks = nn.ModuleList([_CNFBlockParams(COND_CHANNELS[i]) for i in range(NUM_BLOCKS)])
+        self._engine_cache: Optional[_CnfEngine] = None
+        self.last_stats: dict = {}
+
+    def invalidate_plan(self) -> None:
+        self._engine_cache = None
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate_plan()
+        return super().load_state_dict(*a, **kw)
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_plan()
+        return super()._apply(fn, *a, **kw)
+
+    def _engine(self, upratio: int) -> _CnfEngine:
+        e = self._engine_cache
+        dev = self.flow_blocks[0].cnf.sqrt_end_time.device
+        if e is None or e.R != upratio or e.device != dev:
+            if dev.type != "cuda":
+                raise _lib.PuflowHipError("PointInterpFlow runs on the GPU only: move the module with .to('cuda')")
+            e = _CnfEngine({k: v.detach().cpu() for k, v in self.state_dict().items()}, dev, upratio)
+            self._engine_cache = e
+        return e
+
+    def set_to_initialized_state(self) -> None:      # continuous/interpflow.py:113-114: nothing to initialise
+        pass
+
+    @torch.no_grad()
+    def forward(self, xyz: Tensor, upratio: int = 4, noise: Optional[List[Tensor]] = None,
+                stages: bool = False):
+        """-> (x [B, N*upratio, 3], logp).  `noise[i]` [B,N,3]: block i's Hutchinson vector (default: torch.randn,
+        like the reference, which draws it at the first right-hand-side call of f and re-uses it in g)."""
+        if self.training:
+            raise RuntimeError("the continuous model is built for inference only (call .eval())")
+        if not xyz.is_cuda:
+            raise _lib.PuflowHipError("input must be a GPU tensor (no CPU fallback)")
+        xyz = xyz.detach().contiguous().float()
+        B, N, _ = xyz.shape
+        T = B * N
+        eng = self._engine(upratio)
+        eng.nfe = eng.accepted = eng.rejected = 0
+        base = eng.base
+        idx16 = base.knn(xyz)
+        cs, _, _ = base.features(xyz, idx16, want_cs=True)
+        if noise is None:
+            noise = [torch.randn(B, N, 3, device=xyz.device) for _ in range(NUM_BLOCKS)]
+        es = [n.reshape(T, 3).contiguous().float() for n in noise]
+        cflat = [c.reshape(T, -1) for c in cs]
+        ctx = [eng.context(i, cflat[i]) for i in range(NUM_BLOCKS)]
+        # the context is a state of the reference's ODE (zero derivative): it only enters the solver's norms
+        d0c = [float(((c / (ATOL + RTOL * c.abs())) ** 2).sum(dtype=torch.float64).item()) for c in cflat]
+        # ---- f
+        p = xyz.reshape(T, 3)
+        ldj = torch.zeros(B, dtype=torch.float32, device=xyz.device)
+        for i in range(NUM_BLOCKS):
+            st = eng.integrate(i, p, ctx[i], es[i], 1, False, cflat[i].numel(), d0c[i])
+            p = st[:, :3].contiguous()
+            ldj = ldj + st[:, 3].view(B, N).sum(1)
+        z = p.view(B, N, 3)
+        logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + math.log(2 * math.pi)), dim=(1, 2)) - ldj)
+        u = base.interp(xyz, z.contiguous(), idx16)                                   # [B, N*R, 3], row n*R + r
+        # ---- g
+        u = u.reshape(T * upratio, 3)
+        for i in reversed(range(NUM_BLOCKS)):
+            st = eng.integrate(i, u, ctx[i], es[i], upratio, True, cflat[i].numel() * upratio, d0c[i] * upratio)
+            u = st[:, :3].contiguous()
+        x = u.view(B, N * upratio, 3)
+        self.last_stats = dict(nfe=eng.nfe, accepted=eng.accepted, rejected=eng.rejected)
+        if stages:
+            return dict(idx16=idx16, cs=cs, z=z, ldj=ldj, logp=logp, x=x, **self.last_stats)
+        return x, logp
+
+    def sample(self, sparse: Tensor, upratio: int = 4) -> Tensor:
+        dense, _ = self(sparse, upratio)
+        return dense

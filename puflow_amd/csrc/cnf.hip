@@ -1,0 +1,293 @@
+// Continuous (CNF) variant of the flow blocks: the ODE right-hand side and the Runge-Kutta
+// bookkeeping of an adaptive Dormand-Prince solver.  Replaces ODEfunc.forward + ODEnet + ConcatSquashLinear
+// (modules/continuous/odefunc.py:60-148, diffeq_layers.py:72-86) and the arithmetic of torchdiffeq's dopri5
+// stages (called from modules/continuous/cnf.py:97-113).  The step-size CONTROL (a handful of scalars per step)
+// stays on the host: puflow_amd/cnf.py.
+//
+// State rows are [y0 y1 y2 logp]; one MFMA column tile = 16 rows.  A ConcatSquash layer is
+//     out = (W x + b) * sigmoid(Wg [t; c] + bg) + Wb [t; c]
+// and everything that depends on the context c only is precomputed per ORIGINAL point by a GEMM
+// (ctx = Hc c + hb, 288 floats per point and block), so a right-hand-side evaluation is
+//     3 -> 64 (VALU) -> tanh -> 64 -> 64 (split-fp16 MFMA) -> tanh -> 64 -> 3 (MFMA)
+// plus the Hutchinson term  e^T (d f / d y) e  that the reference obtains with autograd (odefunc.py:9-31):
+// here the vector-Jacobian product is written out (W3^T, tanh', W2^T as a second MFMA image, tanh', W1^T).
+//
+// Weight record of one block (floats; packing.pack_cnf_record), resident in LDS:
+//   [0,4096)      f16x2 image of W2          [4096,8192)  f16x2 image of W2^T
+//   [8192,9216)   f16x2 image of W3 (3 rows replicated into every 4-row q group)
+//   [9216,9472)   W1  [64][4] (3 used)       [9472,9728)  W3^T [64][4] (3 used)
+//   [9728,9792) b1   [9792,9856) b2   [9856,9872) b3 (replicated)   [9872,10160) time coefficients, ctx layout
+// ctx layout (per point, 288 floats): gate1[64] bias1[64] gate2[64] bias2[64] gate3[16, replicated] bias3[16, replicated]
+#include <hip/hip_runtime.h>
+#include "pf_api_internal.h"
+#include "pf_mfma.h"
+
+namespace {
+
+constexpr int CNF_REC = 10160;
+constexpr int CNF_CTX = 288;
+constexpr int CNF_NW = 4;                 // waves per workgroup
+
+struct CnfArgs {
+    const float* y0;        // [rows,4] state at the start of the step
+    const float* k;         // [7][rows][4] stage derivatives
+    float coef[6];          // yi = y0 + h * sum_j coef[j] k[j], j < ncoef
+    int ncoef;
+    float h;
+    float t;                // time the net sees
+    float sgn;              // -1: reversed integration (returns -f)
+    const float* ctx;       // [T, 288]
+    const float* e;         // [T, 3]
+    const float* rec;       // CNF_REC floats
+    float* kout;            // [rows,4]
+    float* yout;            // nullable: the stage state yi (the last stage's is the step's solution)
+    int rows, R, ntiles;
+};
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ __launch_bounds__(CNF_NW * 64) void cnf_rhs_kernel(CnfArgs a) {
+    __shared__ f4 wl[CNF_REC / 4];
+    for (int i = threadIdx.x; i < CNF_REC / 4; i += CNF_NW * 64) wl[i] = reinterpret_cast<const f4*>(a.rec)[i];
+    __syncthreads();
+    const float* rec = reinterpret_cast<const float*>(wl);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    const PfW2Lds wsW2{reinterpret_cast<const u4*>(rec), lane}, wsW2T{reinterpret_cast<const u4*>(rec + 4096), lane},
+        wsW3{reinterpret_cast<const u4*>(rec + 8192), lane};
+    const float* tv = rec + 9872;
+    const size_t kstride = (size_t)a.rows * 4;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int g = (tile * CNF_NW + wave) * 16 + col;
+        const bool ok = g < a.rows;
+        const int row = ok ? g : a.rows - 1;
+        const int pt = row / a.R;
+        f4 y = *reinterpret_cast<const f4*>(a.y0 + (size_t)row * 4);
+        for (int j = 0; j < a.ncoef; ++j) {
+            const f4 kj = *reinterpret_cast<const f4*>(a.k + j * kstride + (size_t)row * 4);
+            y += kj * (a.h * a.coef[j]);
+        }
+        if (a.yout && ok && q == 0) *reinterpret_cast<f4*>(a.yout + (size_t)row * 4) = y;
+        const float* cx = a.ctx + (size_t)pt * CNF_CTX;
+        const float e0 = a.e[(size_t)pt * 3 + 0], e1 = a.e[(size_t)pt * 3 + 1], e2 = a.e[(size_t)pt * 3 + 2];
+        const float t = a.t;
+
+        // ---- layer 1 (3 -> 64): this lane's channels 16 cb + 4 q + r
+        f4 h1[1][4], g1[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int ch = cb * 16 + 4 * q;
+            const f4 gc = *reinterpret_cast<const f4*>(cx + ch), bc = *reinterpret_cast<const f4*>(cx + 64 + ch);
+            const f4 gt = *reinterpret_cast<const f4*>(tv + ch), bt = *reinterpret_cast<const f4*>(tv + 64 + ch);
+            const f4 b1 = *reinterpret_cast<const f4*>(rec + 9728 + ch);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f4 w = *reinterpret_cast<const f4*>(rec + 9216 + (ch + r) * 4);
+                const float lin = fmaf(w.z, y.z, fmaf(w.y, y.y, fmaf(w.x, y.x, b1[r])));
+                const float gate = sigm(fmaf(gt[r], t, gc[r]));
+                g1[cb][r] = gate;
+                h1[0][cb][r] = tanhf(fmaf(lin, gate, fmaf(bt[r], t, bc[r])));
+            }
+        }
+        // ---- layer 2 (64 -> 64)
+        f4 h2[1][4], g2[4];
+        {
+            PfPair2 hp[1][2];
+            hp[0][0] = pf_pair2(h1[0][0], h1[0][1]);
+            hp[0][1] = pf_pair2(h1[0][2], h1[0][3]);
+            f4 a2[1][4];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) a2[0][ob] = pf_bias(rec + 9792, ob, q);
+            pf_mm2f<4, 2, 2>(wsW2, 0, hp, 0, a2, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int ch = cb * 16 + 4 * q;
+                const f4 gc = *reinterpret_cast<const f4*>(cx + 128 + ch), bc = *reinterpret_cast<const f4*>(cx + 192 + ch);
+                const f4 gt = *reinterpret_cast<const f4*>(tv + 128 + ch), bt = *reinterpret_cast<const f4*>(tv + 192 + ch);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gate = sigm(fmaf(gt[r], t, gc[r]));
+                    g2[cb][r] = gate;
+                    h2[0][cb][r] = tanhf(fmaf(a2[0][cb][r], gate, fmaf(bt[r], t, bc[r])));
+                }
+            }
+        }
+        // ---- layer 3 (64 -> 3; rows replicated: every q group holds channels 0..2 in .x .y .z)
+        f4 dy, g3;
+        {
+            PfPair2 hp[1][2];
+            hp[0][0] = pf_pair2(h2[0][0], h2[0][1]);
+            hp[0][1] = pf_pair2(h2[0][2], h2[0][3]);
+            f4 a3[1][1];
+            a3[0][0] = *reinterpret_cast<const f4*>(rec + 9856 + 4 * q);
+            pf_mm2f<1, 2, 2>(wsW3, 0, hp, 0, a3, 0);
+            const f4 gc = *reinterpret_cast<const f4*>(cx + 256 + 4 * q), bc = *reinterpret_cast<const f4*>(cx + 272 + 4 * q);
+            const f4 gt = *reinterpret_cast<const f4*>(tv + 256 + 4 * q), bt = *reinterpret_cast<const f4*>(tv + 272 + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                g3[r] = sigm(fmaf(gt[r], t, gc[r]));
+                dy[r] = fmaf(a3[0][0][r], g3[r], fmaf(bt[r], t, bc[r]));
+            }
+        }
+        // ---- Hutchinson term e^T J e by the vector-Jacobian product of e through the three layers
+        const float v0 = e0 * g3.x, v1 = e1 * g3.y, v2 = e2 * g3.z;
+        f4 w2[1][4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f4 w = *reinterpret_cast<const f4*>(rec + 9472 + (cb * 16 + 4 * q + r) * 4);      // W3[:, ch]
+                const float u = fmaf(w.z, v2, fmaf(w.y, v1, w.x * v0));
+                const float hh = h2[0][cb][r];
+                w2[0][cb][r] = u * (1.f - hh * hh) * g2[cb][r];
+            }
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        {
+            PfPair2 wp[1][2];
+            wp[0][0] = pf_pair2(w2[0][0], w2[0][1]);
+            wp[0][1] = pf_pair2(w2[0][2], w2[0][3]);
+            f4 u1[1][4];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) u1[0][ob] = pf_splat(0.f);
+            pf_mm2f<4, 2, 2>(wsW2T, 0, wp, 0, u1, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hh = h1[0][cb][r];
+                    const float w1v = u1[0][cb][r] * (1.f - hh * hh) * g1[cb][r];
+                    const f4 w = *reinterpret_cast<const f4*>(rec + 9216 + (cb * 16 + 4 * q + r) * 4);  // W1[ch, :]
+                    r0 = fmaf(w.x, w1v, r0); r1 = fmaf(w.y, w1v, r1); r2 = fmaf(w.z, w1v, r2);
+                }
+        }
+        // sum over the 4 q groups of the column (lanes col, col+16, col+32, col+48)
+        r0 += __shfl_xor(r0, 16); r1 += __shfl_xor(r1, 16); r2 += __shfl_xor(r2, 16);
+        r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
+        const float div = fmaf(r2, e2, fmaf(r1, e1, r0 * e0));
+        if (ok && q == 0) {
+            const f4 o = {a.sgn * dy.x, a.sgn * dy.y, a.sgn * dy.z, -a.sgn * div};
+            *reinterpret_cast<f4*>(a.kout + (size_t)row * 4) = o;
+        }
+    }
+}
+
+// ---- Runge-Kutta bookkeeping -----------------------------------------------------------------------
+struct LinArgs {
+    const float* p[8];
+    float w[8];
+    int n_terms;
+    float* out;
+    long long n;
+};
+
+__global__ __launch_bounds__(256) void lincomb_kernel(LinArgs a) {                 // out = sum_j w[j] p[j]
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    float s = 0.f;
+    for (int j = 0; j < a.n_terms; ++j) s = fmaf(a.w[j], a.p[j][i], s);
+    a.out[i] = s;
+}
+
+// sum over elements of ((A - B) / (atol + rtol * max(|S0|, |S1|)))^2, two deterministic levels, double accumulation.
+// A may be given as h * sum_j w[j] K_j (error estimate) by passing n_terms > 0.
+struct SumsqArgs {
+    const float* a;          // nullable when n_terms > 0
+    const float* b;          // nullable
+    const float* s0;         // scale state
+    const float* s1;         // nullable (second state of the max)
+    const float* k;          // [n_terms][n]
+    float w[8];
+    int n_terms;
+    float h, rtol, atol;
+    long long n;
+    double* partial;         // [gridDim.x]
+};
+
+__global__ __launch_bounds__(256) void sumsq_kernel(SumsqArgs s) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.n; i += (long long)gridDim.x * 256) {
+        float v;
+        if (s.n_terms > 0) {
+            v = 0.f;
+            for (int j = 0; j < s.n_terms; ++j) v = fmaf(s.w[j], s.k[(long long)j * s.n + i], v);
+            v *= s.h;
+        } else {
+            v = s.a[i] - (s.b ? s.b[i] : 0.f);
+        }
+        float m = fabsf(s.s0[i]);
+        if (s.s1) m = fmaxf(m, fabsf(s.s1[i]));
+        const float r = v / (s.atol + s.rtol * m);
+        acc += (double)r * (double)r;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) s.partial[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ partial, int np, double* __restrict__ out) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+constexpr int SUMSQ_BLOCKS = 256;
+
+}  // namespace
+
+extern "C" int pf_cnf_rhs(const float* y0, const float* k, const float* coef, int ncoef, float h, float t, float sgn,
+                          const float* ctx, const float* e, const float* rec, float* kout, float* yout, int rows, int R,
+                          void* stream) {
+    if (!y0 || !ctx || !e || !rec || !kout || (ncoef > 0 && (!k || !coef))) return PF_ERR_NULL;
+    if (rows <= 0 || R <= 0 || ncoef < 0 || ncoef > 6) return PF_ERR_SHAPE;
+    CnfArgs a{};
+    a.y0 = y0; a.k = k; a.ncoef = ncoef; a.h = h; a.t = t; a.sgn = sgn; a.ctx = ctx; a.e = e; a.rec = rec;
+    a.kout = kout; a.yout = yout; a.rows = rows; a.R = R;
+    for (int j = 0; j < ncoef; ++j) a.coef[j] = coef[j];
+    a.ntiles = (rows + CNF_NW * 16 - 1) / (CNF_NW * 16);
+    const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
+    hipLaunchKernelGGL(cnf_rhs_kernel, dim3(grid), dim3(CNF_NW * 64), 0, (hipStream_t)stream, a);
+    return pf_last_launch_status();
+}
+
+// out[i] = sum_j w[j] * p[j][i], j < n_terms <= 8 (host arrays of device pointers / weights)
+extern "C" int pf_lincomb(const float* const* ptrs, const float* w, int n_terms, float* out, long long n, void* stream) {
+    if (!ptrs || !w || !out) return PF_ERR_NULL;
+    if (n_terms <= 0 || n_terms > 8 || n <= 0) return PF_ERR_SHAPE;
+    LinArgs a{};
+    for (int j = 0; j < n_terms; ++j) {
+        if (!ptrs[j]) return PF_ERR_NULL;
+        a.p[j] = ptrs[j]; a.w[j] = w[j];
+    }
+    a.n_terms = n_terms; a.out = out; a.n = n;
+    hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return pf_last_launch_status();
+}
+
+// out[0] (double) = sum_i (v_i / (atol + rtol * max(|s0_i|, |s1_i|)))^2 with v = a - b, or v = h * sum_j w[j] k[j] when
+// n_terms > 0 (k: [n_terms][n]).  ws: >= 256 doubles of scratch.  Deterministic (fixed two-level tree).
+extern "C" int pf_scaled_sumsq(const float* a, const float* b, const float* s0, const float* s1, const float* k,
+                               const float* w, int n_terms, float h, float rtol, float atol, long long n, double* ws,
+                               double* out, void* stream) {
+    if (!s0 || !ws || !out || (n_terms == 0 && !a) || (n_terms > 0 && (!k || !w))) return PF_ERR_NULL;
+    if (n <= 0 || n_terms < 0 || n_terms > 8) return PF_ERR_SHAPE;
+    SumsqArgs s{};
+    s.a = a; s.b = b; s.s0 = s0; s.s1 = s1; s.k = k; s.n_terms = n_terms; s.h = h; s.rtol = rtol; s.atol = atol;
+    s.n = n; s.partial = ws;
+    for (int j = 0; j < n_terms; ++j) s.w[j] = w[j];
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, s);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, SUMSQ_BLOCKS, out);
+    return pf_last_launch_status();
+}

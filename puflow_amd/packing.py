@@ -410,3 +410,65 @@ def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
     out["interp"] = [io[k] for k in INTERP_SLOTS]
     out["blob"] = B.data()
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# Continuous (CNF) blocks: weight record of csrc/cnf.hip and the per-point context GEMM
+# ---------------------------------------------------------------------------------------
+CNF_REC = 10160
+CNF_CTX = 288
+
+
+def _np32(t) -> np.ndarray:
+    return t.detach().cpu().numpy().astype(np.float32) if hasattr(t, "detach") else np.asarray(t, np.float32)
+
+
+def pack_cnf_block(sd, i: int):
+    """-> (rec [CNF_REC] fp32, Hc [288, cdim], hb [288], T_end).  A ConcatSquash layer (diffeq_layers.py:72-86) is
+    (W x + b) * sigmoid(Wg [t; c] + bg) + Wb [t; c]: the c-columns of Wg / Wb form the context GEMM `Hc` (with bg
+    as its bias), their t-columns the time coefficients inside the record (same 288-row layout as the GEMM output:
+    gate1 bias1 gate2 bias2 gate3 bias3, the 3-row layer-3 pieces replicated into every 4-row q group)."""
+    p = f"flow_blocks.{i}.cnf.odefunc.diffeq.layers"
+    L = [{k: _np32(sd[f"{p}.{j}.{k}"]) for k in ("_layer.weight", "_layer.bias", "_hyper_bias.weight",
+                                               "_hyper_gate.weight", "_hyper_gate.bias")} for j in range(3)]
+    cdim = L[0]["_hyper_gate.weight"].shape[1] - 1
+    Hc = np.zeros((CNF_CTX, cdim), np.float32)
+    hb = np.zeros(CNF_CTX, np.float32)
+    tv = np.zeros(CNF_CTX, np.float32)
+
+    def put(row0, Wg, bg, rep):
+        rows = Wg.shape[0]
+        for qq in range(4 if rep else 1):
+            r0 = row0 + 4 * qq if rep else row0
+            Hc[r0:r0 + rows] = Wg[:, 1:]
+            tv[r0:r0 + rows] = Wg[:, 0]
+            if bg is not None:
+                hb[r0:r0 + rows] = bg
+
+    put(0, L[0]["_hyper_gate.weight"], L[0]["_hyper_gate.bias"], False)
+    put(64, L[0]["_hyper_bias.weight"], None, False)
+    put(128, L[1]["_hyper_gate.weight"], L[1]["_hyper_gate.bias"], False)
+    put(192, L[1]["_hyper_bias.weight"], None, False)
+    put(256, L[2]["_hyper_gate.weight"], L[2]["_hyper_gate.bias"], True)
+    put(272, L[2]["_hyper_bias.weight"], None, True)
+
+    rec = np.zeros(CNF_REC, np.float32)
+    W1, W2, W3 = L[0]["_layer.weight"], L[1]["_layer.weight"], L[2]["_layer.weight"]
+    rec[0:4096] = frag_pack_f16x2(W2)
+    rec[4096:8192] = frag_pack_f16x2(np.ascontiguousarray(W2.T))
+    W3r = np.zeros((16, 64), np.float32)
+    b3r = np.zeros(16, np.float32)
+    for qq in range(4):
+        W3r[4 * qq:4 * qq + 3] = W3
+        b3r[4 * qq:4 * qq + 3] = L[2]["_layer.bias"]
+    rec[8192:9216] = frag_pack_f16x2(W3r)
+    W1t = np.zeros((64, 4), np.float32); W1t[:, :3] = W1
+    W3t = np.zeros((64, 4), np.float32); W3t[:, :3] = W3.T
+    rec[9216:9472] = W1t.reshape(-1)
+    rec[9472:9728] = W3t.reshape(-1)
+    rec[9728:9792] = L[0]["_layer.bias"]
+    rec[9792:9856] = L[1]["_layer.bias"]
+    rec[9856:9872] = b3r
+    rec[9872:10160] = tv
+    T_end = float(_np32(sd[f"flow_blocks.{i}.cnf.sqrt_end_time"])) ** 2
+    return rec, Hc, hb, T_end

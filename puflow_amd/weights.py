@@ -185,3 +185,48 @@ def synth_patches(batch: int, npoint: int, seed: int = 2021, surface: bool = Tru
     pts = pts - pts.mean(axis=1, keepdims=True, dtype=np.float32)
     scale = np.sqrt((pts ** 2).sum(-1, keepdims=True)).max(axis=1, keepdims=True)
     return torch.from_numpy((pts / scale).astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------
+# Continuous (CNF) variant: modules/continuous/interpflow.py.  Shares the interp / feat_convs / merge_convs
+# keys with the discrete model (288 of them); flow_blocks.{i} holds a CNF (17 entries each, 390 keys in total -
+# the key list of pretrain/puflow-x4-cnf-pu1k.pt).
+# ---------------------------------------------------------------------------------------
+CNF_COND_CHANNELS = [32, 64, 128, 128, 128, 128]
+
+
+def cnf_state_dict_spec():
+    """[(key, shape, kind)] in the reference's registration order."""
+    spec = [e for e in state_dict_spec() if not e[0].startswith("flow_blocks.")]
+    for i, cd in enumerate(CNF_COND_CHANNELS):
+        p = f"flow_blocks.{i}.cnf"
+        spec.append((p + ".sqrt_end_time", (), "T"))
+        spec.append((p + ".odefunc._num_evals", (), "nfe"))
+        for j, (din, dout) in enumerate([(3, 64), (64, 64), (64, 3)]):
+            q = f"{p}.odefunc.diffeq.layers.{j}"
+            spec.append((q + "._layer.weight", (dout, din), "w"))
+            spec.append((q + "._layer.bias", (dout,), "b"))
+            spec.append((q + "._hyper_bias.weight", (dout, 1 + cd), "w"))
+            spec.append((q + "._hyper_gate.weight", (dout, 1 + cd), "w"))
+            spec.append((q + "._hyper_gate.bias", (dout,), "b"))
+    return spec
+
+
+def synth_cnf_state_dict(seed: int = 2021) -> "OrderedDict[str, torch.Tensor]":
+    """Random-init weights of the continuous model: the shared extractor / interpolation part is the discrete
+    generator's, the ODE nets get nn.Linear-style fan-in scaling (large enough that dopri5 takes real steps)."""
+    base = synth_state_dict(seed)
+    rng = np.random.Generator(np.random.PCG64(seed + 104729))
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for key, shape, kind in cnf_state_dict_spec():
+        if not key.startswith("flow_blocks."):
+            sd[key] = base[key].clone()
+        elif kind == "T":
+            sd[key] = torch.tensor(float(np.sqrt(0.5)), dtype=torch.float32)           # cnf.py:41, T = 0.5
+        elif kind == "nfe":
+            sd[key] = torch.tensor(0.0, dtype=torch.float32)
+        else:
+            fan_in = shape[1] if len(shape) == 2 else 64
+            scale = (1.6 if "_layer" in key else 1.0) / np.sqrt(fan_in)
+            sd[key] = torch.from_numpy((rng.uniform(-1, 1, shape) * scale).astype(np.float32))
+    return sd

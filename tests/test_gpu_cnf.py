@@ -1,0 +1,94 @@
+"""Continuous (CNF) variant on the GPU against oracle/cnf_ref.py.  PARITY UNPINNED against the
+reference (torchdiffeq absent): the oracle is a from-text restatement, see its header."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cnf_ref as C
+from oracle import ref_cpu as O
+from puflow_amd.weights import cnf_state_dict_spec, synth_cnf_state_dict, synth_patches
+
+DEV = "cuda:0"
+
+
+def _net(sd):
+    from puflow_amd.cnf import PointInterpFlow
+    net = PointInterpFlow(3)
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return net.to(DEV).eval()
+
+
+def test_state_dict_surface():
+    from puflow_amd.cnf import PointInterpFlow
+    keys = list(PointInterpFlow(3).state_dict().keys())
+    assert keys == [k for k, _, _ in cnf_state_dict_spec()] and len(keys) == 390
+
+
+@pytest.mark.parametrize("block,R,reverse", [(0, 1, False), (3, 1, False), (5, 4, True), (2, 4, True)])
+def test_rhs_matches_autograd_oracle(block, R, reverse):
+    """One right-hand side (network + Hutchinson term by explicit VJP) against the oracle's autograd evaluation."""
+    sd = synth_cnf_state_dict(7)
+    net = _net(sd)
+    eng = net._engine(4)
+    g = torch.Generator().manual_seed(block)
+    T = 200
+    cd = sd[f"flow_blocks.{block}.cnf.odefunc.diffeq.layers.0._hyper_gate.weight"].shape[1] - 1
+    c = torch.randn(T, cd, generator=g) * 0.7
+    e = torch.randn(T, 3, generator=g)
+    rows = T * R
+    state = torch.randn(rows, 4, generator=g) * 0.8
+    t = 0.137
+    cr = torch.repeat_interleave(c, R, dim=0)
+    er = torch.repeat_interleave(e, R, dim=0)
+    ref = C.rhs(sd, block, t, state, cr, er)
+    if reverse:
+        ref = -ref
+    ctx = eng.context(block, c.to(DEV))
+    out = torch.empty(rows, 4, device=DEV)
+    yd = state.to(DEV)
+    eng._rhs(block, yd, yd, [], 0.0, t, -1.0 if reverse else 1.0, ctx, e.to(DEV), out, None, rows, R)
+    assert (out.cpu() - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,N,seed", [(1, 256, 0), (2, 200, 1)])
+def test_forward_matches_oracle(B, N, seed):
+    sd = synth_cnf_state_dict(seed)
+    xyz = synth_patches(B, N, seed=seed + 10)
+    g = torch.Generator().manual_seed(seed)
+    noise = [torch.randn(B, N, 3, generator=g) for _ in range(6)]
+    ref = C.forward(sd, xyz, 4, noise=noise, stages=True)
+    net = _net(sd)
+    st = net(xyz.to(DEV), 4, noise=[n.to(DEV) for n in noise], stages=True)
+    assert torch.equal(st["idx16"].cpu().long(), ref["idx16"])
+    # same step sequence (the controller sees the same norms up to fp32 rounding) -> same function-evaluation count
+    assert st["nfe"] == ref["nfe"] and st["accepted"] == ref["accepted"] and st["rejected"] == ref["rejected"]
+    # tolerance = the solver's own (atol = rtol = 1e-5 per step, 12 integrations chained)
+    assert (st["z"].cpu() - ref["z"]).abs().max() < 1e-4
+    assert (st["x"].cpu() - ref["x"]).abs().max() < 1e-4
+    assert ((st["ldj"].cpu() - ref["ldj"]).abs() / ref["ldj"].abs().clamp_min(1.0)).max() < 1e-4
+    assert abs(float(st["logp"]) - float(ref["logp"])) / abs(float(ref["logp"])) < 1e-4
+
+
+def test_flow_is_invertible_and_batch_independent_given_steps():
+    """f then g with R = 1 on the same latents returns the input within the solver tolerance."""
+    sd = synth_cnf_state_dict(3)
+    net = _net(sd)
+    xyz = synth_patches(2, 256, seed=5).to(DEV)
+    eng = net._engine(1)
+    base = eng.base
+    idx16 = base.knn(xyz)
+    cs, _, _ = base.features(xyz, idx16, want_cs=True)
+    T = 512
+    e = torch.randn(T, 3, device=DEV)
+    p = xyz.reshape(T, 3)
+    ctxs = [eng.context(i, cs[i].reshape(T, -1)) for i in range(6)]
+    for i in range(6):
+        p = eng.integrate(i, p, ctxs[i], e, 1, False, 0, 0.0)[:, :3].contiguous()
+    for i in reversed(range(6)):
+        p = eng.integrate(i, p, ctxs[i], e, 1, True, 0, 0.0)[:, :3].contiguous()
+    assert (p.view(2, 256, 3) - xyz).abs().max() < 2e-4
