@@ -19,13 +19,13 @@ from .patch import PatchHelper
 
 @torch.no_grad()
 def upsampling(data_paths: List[str], target_path: str, checkpoint_path: str, up_ratio: int, num_outlier: int,
-               num_patch: int, num_upsampling: int = None, seed=None, state_dict=None):
+               num_patch: int, num_upsampling: int = None, seed=None, state_dict=None, network_cls=PointInterpFlow):
     if seed is not None:
         np.random.seed(seed)
         torch.random.manual_seed(seed)
         torch.cuda.manual_seed(seed)
     device = torch.device("cuda:0")
-    network = PointInterpFlow(3)
+    network = network_cls(3)
     network.load_state_dict(state_dict if state_dict is not None else torch.load(checkpoint_path, map_location="cpu"))
     network.set_to_initialized_state()
     network = network.to(device).eval()
@@ -44,7 +44,7 @@ def upsampling(data_paths: List[str], target_path: str, checkpoint_path: str, up
         np.savetxt(Path(target_path) / file_name, pred.squeeze().cpu().numpy(), fmt="%.6f")
 
 
-def main(argv=None):
+def main(argv=None, network_cls=PointInterpFlow):
     parser = ArgumentParser()
     parser.add_argument("--source", type=str, help="Path of input directory")
     parser.add_argument("--target", type=str, help="Path of output directory")
@@ -60,7 +60,7 @@ def main(argv=None):
     for root, _dirs, files in os.walk(args.source):
         data_paths.extend([os.path.join(root, f) for f in files if ".xyz" in f])
     upsampling(data_paths, args.target, args.checkpoint, up_ratio=args.up_ratio, num_outlier=24, num_patch=args.num_patch,
-               num_upsampling=args.num_out, seed=args.seed)
+               num_upsampling=args.num_out, seed=args.seed, network_cls=network_cls)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,73 @@
+"""CPU checks of the continuous-model oracle (oracle/cnf_ref.py; parity unpinned, see its header): the dopri5
+restatement against closed-form ODE solutions, the state-dict surface, and the host-side packing of a CNF block."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import cnf_ref as C
+from puflow_amd.weights import cnf_state_dict_spec, synth_cnf_state_dict, synth_patches
+
+
+def test_dopri5_closed_forms():
+    # y' = -2 y, y(0) = [1, 3]  and the rotation  (u, v)' = (v, -u)
+    y0 = torch.tensor([[1.0, 3.0, 0.5, -0.25]])
+    st = C.Dopri5Stats()
+    y = C.dopri5(lambda t, y: -2 * y, y0, 0.0, 1.0, stats=st)
+    assert torch.allclose(y, y0 * math.exp(-2.0), rtol=2e-4, atol=2e-5)
+    assert st.accepted >= 2 and st.nfe == 2 + 6 * (st.accepted + st.rejected)
+    rot = lambda t, y: torch.stack([y[:, 1], -y[:, 0], y[:, 3], -y[:, 2]], dim=1)
+    y = C.dopri5(rot, y0, 0.0, 2.0)
+    c, s = math.cos(2.0), math.sin(2.0)
+    exp = torch.tensor([[c * 1 + s * 3, -s * 1 + c * 3, c * .5 + s * -.25, -s * .5 + c * -.25]])
+    assert torch.allclose(y, exp, rtol=3e-4, atol=5e-5)
+    # reversed integration (s = -t, f' = -f) undoes the forward one
+    back = C.dopri5(lambda s_, y: -rot(-s_, y), y, -2.0, 0.0)
+    assert torch.allclose(back, y0, rtol=5e-4, atol=1e-4)
+
+
+def test_dense_output_weights_interpolate_endpoints():
+    w0 = C.interp_weights5(0.0, 0.3)
+    w1 = C.interp_weights5(1.0, 0.3)
+    wm = C.interp_weights5(0.5, 0.3)
+    assert np.allclose(w0, (1, 0, 0, 0, 0)) and np.allclose(w1, (0, 1, 0, 0, 0)) and np.allclose(wm, (0, 0, 1, 0, 0))
+
+
+def test_tableau_consistency():
+    for i, row in enumerate(C.DP_BETA):
+        assert abs(sum(row) - C.DP_ALPHA[i]) < 1e-12           # stage times are the row sums
+    assert abs(sum(C.DP_C_SOL) - 1) < 1e-12 and abs(sum(C.DP_C_ERR)) < 1e-12 and abs(sum(C.DP_C_MID) - 0.5) < 1e-9
+
+
+def test_cnf_forward_small_and_hutchinson_is_exact_trace_in_expectation():
+    sd = synth_cnf_state_dict(2)
+    assert len(cnf_state_dict_spec()) == 390 and list(sd) == [k for k, _, _ in cnf_state_dict_spec()]
+    xyz = synth_patches(1, 64, seed=4)
+    torch.manual_seed(0)
+    st = C.forward(sd, xyz, 2, stages=True)
+    assert tuple(st["x"].shape) == (1, 128, 3) and torch.isfinite(st["x"]).all() and st["accepted"] >= 12
+    # e^T J e with e = unit vectors sums to the exact trace of the 3x3 Jacobian
+    c = torch.randn(5, 32)
+    y = torch.randn(5, 4)
+    tr = sum(C.rhs(sd, 0, 0.2, y, c, torch.eye(3)[k].expand(5, 3))[:, 3] for k in range(3))
+    yy = y[:, :3].clone().requires_grad_(True)
+    f = C.odenet(sd, 0, torch.cat([torch.full((5, 1), 0.2), c], -1), yy)
+    exact = sum(torch.autograd.grad(f[:, k].sum(), yy, retain_graph=True)[0][:, k] for k in range(3))
+    assert torch.allclose(-tr, exact, atol=1e-5)
+
+
+def test_pack_cnf_block_layout():
+    from puflow_amd.packing import CNF_CTX, CNF_REC, frag_unpack_f16x2, pack_cnf_block
+    sd = synth_cnf_state_dict(9)
+    rec, Hc, hb, T_end = pack_cnf_block(sd, 3)
+    p = "flow_blocks.3.cnf.odefunc.diffeq.layers"
+    assert rec.size == CNF_REC and Hc.shape == (CNF_CTX, 128) and abs(T_end - 0.5) < 1e-6
+    W2 = sd[p + ".1._layer.weight"].numpy()
+    np.testing.assert_allclose(frag_unpack_f16x2(rec[0:4096], 64, 64), W2, rtol=2.0 ** -21, atol=1e-10)   # tiny |w|: hi is a subnormal fp16
+    np.testing.assert_allclose(frag_unpack_f16x2(rec[4096:8192], 64, 64), W2.T, rtol=2.0 ** -21, atol=1e-10)
+    g3 = sd[p + ".2._hyper_gate.weight"].numpy()
+    for q in range(4):                                      # 3-row layer-3 pieces replicated per q group
+        np.testing.assert_array_equal(Hc[256 + 4 * q:256 + 4 * q + 3], g3[:, 1:])
+        np.testing.assert_array_equal(rec[9872 + 256 + 4 * q:9872 + 256 + 4 * q + 3], g3[:, 0])
+    np.testing.assert_array_equal(hb[0:64], sd[p + ".0._hyper_gate.bias"].numpy())
+    assert not hb[64:128].any()                             # hyper_bias has no bias term (diffeq_layers.py:76)
