@@ -17,6 +17,11 @@ from .interpflow import PointInterpFlow
 from .patch import PatchHelper
 
 
+def shard_paths(paths: List[str], rank: int, world: int) -> List[str]:
+    """Files of rank `rank` out of `world`: sorted, then strided (balanced for any count)."""
+    return sorted(paths)[rank::world] if world > 1 else list(paths)
+
+
 @torch.no_grad()
 def upsampling(data_paths: List[str], target_path: str, checkpoint_path: str, up_ratio: int, num_outlier: int,
                num_patch: int, num_upsampling: int = None, seed=None, state_dict=None, network_cls=PointInterpFlow):
@@ -24,7 +29,11 @@ def upsampling(data_paths: List[str], target_path: str, checkpoint_path: str, up
         np.random.seed(seed)
         torch.random.manual_seed(seed)
         torch.cuda.manual_seed(seed)
-    device = torch.device("cuda:0")
+    # One process per GPU (torchrun): every rank upsamples its own files - clouds are independent, so the CLI shards
+    # by file with no collective at all (BASELINE configs[3]); a plain `python -m puflow_amd.upsample` is rank 0 of 1.
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    data_paths = shard_paths(data_paths, rank, world)
+    device = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)}")
     network = network_cls(3)
     network.load_state_dict(state_dict if state_dict is not None else torch.load(checkpoint_path, map_location="cpu"))
     network.set_to_initialized_state()
@@ -54,8 +63,7 @@ def main(argv=None, network_cls=PointInterpFlow):
     parser.add_argument("--num_patch", type=int, help="number of point in each patch", default=256)
     parser.add_argument("--num_out", type=int, default=None, help="number of point of output point cloud")
     args = parser.parse_args(argv)
-    if not os.path.exists(args.target):
-        os.mkdir(args.target)
+    os.makedirs(args.target, exist_ok=True)            # exist_ok: several ranks may race to create it
     data_paths = []
     for root, _dirs, files in os.walk(args.source):
         data_paths.extend([os.path.join(root, f) for f in files if ".xyz" in f])

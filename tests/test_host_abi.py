@@ -95,3 +95,12 @@ def test_pack_plan_layout():
     # EdgeConv unit 3, split-fp16 image: G1 [32, 32] = 2 ob x 1 pair
     g1h = frag_unpack_f16x2(blob[pk["ec2h_w"][3]:pk["ec2h_w"][3] + 2 * 512], 32, 32)
     np.testing.assert_allclose(g1h, plan["units"][3]["G1"], rtol=2.0 ** -21, atol=1e-12)
+
+
+def test_cli_file_sharding_covers_every_file_once():
+    from puflow_amd.upsample import shard_paths
+    files = [f"c{i:02d}.xyz" for i in (5, 1, 9, 3, 0, 7, 2)]
+    for world in (1, 2, 3, 8):
+        parts = [shard_paths(files, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == sorted(files)
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
