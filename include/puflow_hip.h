@@ -220,6 +220,15 @@ int pf_cnf_rhs(const float* y0, const float* k, const float* coef, int ncoef, fl
                const float* ctx, const float* e, const float* rec, float* kout, float* yout, int rows, int R,
                void* stream);
 
+/* One whole Dormand-Prince 5(4) step attempt per launch (the six stage evaluations fused, stage derivatives in
+ * registers): y1 = y0 + h sum b_j k_j with k_1 = f0 (FSAL), f1 = k_7, ymid (nullable) = dense-output mid-point,
+ * out[0] (double, device) = sum_i (err_i / (atol + rtol max(|y0_i|, |y1_i|)))^2 of the embedded error estimate.
+ * t = start of the step in solver time; reverse != 0: torchdiffeq's decreasing-time convention (net time = -t, f negated).
+ * ws: >= 1024 doubles.  Arithmetic of torchdiffeq's `_runge_kutta_step` / `_compute_error_ratio` called from cnf.py:97-113. */
+int pf_cnf_step(const float* y0, const float* f0, float t, float h, int reverse, const float* ctx, const float* e,
+                const float* rec, float* y1, float* f1, float* ymid, float rtol, float atol, int rows, int R, double* ws,
+                double* out, void* stream);
+
 /* out[i] = sum_{j<n_terms} w[j] * ptrs[j][i]   (n_terms <= 8; ptrs / w are HOST arrays).  Runge-Kutta solution,
  * mid-point and dense-output combinations of torchdiffeq's dopri5 (cnf.py:97-113 call site). */
 int pf_lincomb(const float* const* ptrs, const float* w, int n_terms, float* out, long long n, void* stream);

@@ -70,6 +70,8 @@ SIGNATURES = {
     "pf_knn_large": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_cnf_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_float), c_int, c_float, c_float, c_float, c_void_p, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pf_cnf_step": (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_float, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_lincomb": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, c_void_p, c_longlong, c_void_p]),
     "pf_scaled_sumsq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_float), c_int, c_float, c_float,
                                 c_float, c_longlong, c_void_p, c_void_p, c_void_p]),

@@ -7,8 +7,8 @@ What runs where:
   * kNN, the six EdgeConv units, the merge units and the interpolation module are the discrete model's kernels
     (the reference imports those modules from the discrete file too, continuous/interpflow.py:14);
   * the per-point context terms of every ConcatSquash layer: one GEMM per block (`pf_gemm`);
-  * every ODE right-hand side incl. the Hutchinson term, the Runge-Kutta stage states, the error / step norms:
-    `pf_cnf_rhs`, `pf_lincomb`, `pf_scaled_sumsq` (csrc/cnf.hip);
+  * every ODE right-hand side incl. the Hutchinson term, the Runge-Kutta stages (one fused launch per step attempt),
+    the error / step norms: `pf_cnf_step`, `pf_cnf_rhs`, `pf_lincomb`, `pf_scaled_sumsq` (csrc/cnf.hip);
   * the adaptive step-size CONTROL of dopri5 (torchdiffeq semantics restated from its published algorithm, see
     oracle/cnf_ref.py header): a few host scalars per step - one device->host read of the error norm per step.
 
@@ -122,6 +122,7 @@ class _CnfEngine:
             self.hb.append(torch.from_numpy(hb).to(device))
             self.T_end.append(T_end)
         self.ws = torch.empty(256, dtype=torch.float64, device=device)
+        self.ws1k = torch.empty(1024, dtype=torch.float64, device=device)
         self.red = torch.empty(1, dtype=torch.float64, device=device)
         self.nfe = 0
         self.accepted = 0
@@ -193,28 +194,33 @@ class _CnfEngine:
         h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / ORDER)
         dt = min(100 * h0, h1)
 
+        # ---- adaptive steps: ONE launch per attempt (six fused stage evaluations), one host read of the error norm
+        ws = self.ws1k
+        f0, f1 = K[0], K[6]
         t = t0
         last = None
         while t1 > t:
-            for s in range(6):
-                self._rhs(i, y, K, DP_BETA[s], dt, net_t(t + DP_ALPHA[s] * dt), sgn, ctx, e, K[s + 1],
-                          y1 if s == 5 else None, rows, R)
-            ratio = math.sqrt(self._sumsq(None, None, y, y1, K, DP_C_ERR, dt) / n_tot)
+            want_mid = t1 <= t + dt                            # this step would cover the end time: emit the mid-point too
+            _lib.check(self.lib.pf_cnf_step(y.data_ptr(), f0.data_ptr(), float(t), float(dt), 1 if reverse else 0,
+                                            ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), y1.data_ptr(),
+                                            f1.data_ptr(), tmp.data_ptr() if want_mid else None, RTOL, ATOL, rows, R,
+                                            ws.data_ptr(), self.red.data_ptr(), self._stream()), "pf_cnf_step")
+            self.nfe += 6
+            ratio = math.sqrt(float(self.red.item()) / n_tot)
             if ratio <= 1.0:
                 self.accepted += 1
                 nxt = t + dt
-                if t1 <= nxt:                                  # the step covers the end time: dense output there
-                    self._lincomb([y] + [K[j] for j in range(7)], [1.0] + [dt * c for c in DP_C_MID], tmp)     # y_mid
+                if t1 <= nxt:                                  # dense output at the end time (quartic through y0, y_mid, y1)
                     xx = (t1 - t) / dt
                     x2, x3, x4 = xx * xx, xx ** 3, xx ** 4
                     w = [-8 * x4 + 18 * x3 - 11 * x2 + 1, -8 * x4 + 14 * x3 - 5 * x2, 16 * x4 - 32 * x3 + 16 * x2,
                          dt * (-2 * x4 + 5 * x3 - 4 * x2 + xx), dt * (2 * x4 - 3 * x3 + x2)]
                     out = torch.empty_like(y)
-                    self._lincomb([y, y1, tmp, K[0], K[6]], w, out)
+                    self._lincomb([y, y1, tmp, f0, f1], w, out)
                     last = out
                 t = nxt
-                y, y1 = y1, y                                  # accepted state; FSAL derivative moves to slot 0
-                K[0].copy_(K[6])
+                y, y1 = y1, y                                  # accepted state; FSAL: f1 is the next step's f0
+                f0, f1 = f1, f0
             else:
                 self.rejected += 1
             if ratio == 0:

@@ -46,18 +46,125 @@ struct CnfArgs {
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
 
-__global__ __launch_bounds__(CNF_NW * 64) void cnf_rhs_kernel(CnfArgs a) {
-    __shared__ f4 wl[CNF_REC / 4];
-    for (int i = threadIdx.x; i < CNF_REC / 4; i += CNF_NW * 64) wl[i] = reinterpret_cast<const f4*>(a.rec)[i];
+// One evaluation for this lane's row: k = sgn * (f(t, y), -e^T (df/dy) e).  All four q groups of a column return the same f4.
+struct CnfW {
+    const float* rec;          // LDS copy of the record
+    PfW2Lds w2, w2t, w3;
+};
+
+__device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, float sgn, const float* __restrict__ cx,
+                                       float e0, float e1, float e2) {
+    const float* rec = w.rec;
+    const float* tv = rec + 9872;
+    // ---- layer 1 (3 -> 64): this lane's channels 16 cb + 4 q + r
+    f4 h1[1][4], g1[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int ch = cb * 16 + 4 * q;
+        const f4 gc = *reinterpret_cast<const f4*>(cx + ch), bc = *reinterpret_cast<const f4*>(cx + 64 + ch);
+        const f4 gt = *reinterpret_cast<const f4*>(tv + ch), bt = *reinterpret_cast<const f4*>(tv + 64 + ch);
+        const f4 b1 = *reinterpret_cast<const f4*>(rec + 9728 + ch);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f4 wr = *reinterpret_cast<const f4*>(rec + 9216 + (ch + r) * 4);
+            const float lin = fmaf(wr.z, y.z, fmaf(wr.y, y.y, fmaf(wr.x, y.x, b1[r])));
+            const float gate = sigm(fmaf(gt[r], t, gc[r]));
+            g1[cb][r] = gate;
+            h1[0][cb][r] = tanhf(fmaf(lin, gate, fmaf(bt[r], t, bc[r])));
+        }
+    }
+    // ---- layer 2 (64 -> 64)
+    f4 h2[1][4], g2[4];
+    {
+        PfPair2 hp[1][2];
+        hp[0][0] = pf_pair2(h1[0][0], h1[0][1]);
+        hp[0][1] = pf_pair2(h1[0][2], h1[0][3]);
+        f4 a2[1][4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) a2[0][ob] = pf_bias(rec + 9792, ob, q);
+        pf_mm2f<4, 2, 2>(w.w2, 0, hp, 0, a2, 0);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int ch = cb * 16 + 4 * q;
+            const f4 gc = *reinterpret_cast<const f4*>(cx + 128 + ch), bc = *reinterpret_cast<const f4*>(cx + 192 + ch);
+            const f4 gt = *reinterpret_cast<const f4*>(tv + 128 + ch), bt = *reinterpret_cast<const f4*>(tv + 192 + ch);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gate = sigm(fmaf(gt[r], t, gc[r]));
+                g2[cb][r] = gate;
+                h2[0][cb][r] = tanhf(fmaf(a2[0][cb][r], gate, fmaf(bt[r], t, bc[r])));
+            }
+        }
+    }
+    // ---- layer 3 (64 -> 3; rows replicated: every q group holds channels 0..2 in .x .y .z)
+    f4 dy, g3;
+    {
+        PfPair2 hp[1][2];
+        hp[0][0] = pf_pair2(h2[0][0], h2[0][1]);
+        hp[0][1] = pf_pair2(h2[0][2], h2[0][3]);
+        f4 a3[1][1];
+        a3[0][0] = *reinterpret_cast<const f4*>(rec + 9856 + 4 * q);
+        pf_mm2f<1, 2, 2>(w.w3, 0, hp, 0, a3, 0);
+        const f4 gc = *reinterpret_cast<const f4*>(cx + 256 + 4 * q), bc = *reinterpret_cast<const f4*>(cx + 272 + 4 * q);
+        const f4 gt = *reinterpret_cast<const f4*>(tv + 256 + 4 * q), bt = *reinterpret_cast<const f4*>(tv + 272 + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            g3[r] = sigm(fmaf(gt[r], t, gc[r]));
+            dy[r] = fmaf(a3[0][0][r], g3[r], fmaf(bt[r], t, bc[r]));
+        }
+    }
+    // ---- Hutchinson term e^T J e by the vector-Jacobian product of e through the three layers
+    const float v0 = e0 * g3.x, v1 = e1 * g3.y, v2 = e2 * g3.z;
+    f4 w2v[1][4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f4 wr = *reinterpret_cast<const f4*>(rec + 9472 + (cb * 16 + 4 * q + r) * 4);      // W3[:, ch]
+            const float u = fmaf(wr.z, v2, fmaf(wr.y, v1, wr.x * v0));
+            const float hh = h2[0][cb][r];
+            w2v[0][cb][r] = u * (1.f - hh * hh) * g2[cb][r];
+        }
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    {
+        PfPair2 wp[1][2];
+        wp[0][0] = pf_pair2(w2v[0][0], w2v[0][1]);
+        wp[0][1] = pf_pair2(w2v[0][2], w2v[0][3]);
+        f4 u1[1][4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) u1[0][ob] = pf_splat(0.f);
+        pf_mm2f<4, 2, 2>(w.w2t, 0, wp, 0, u1, 0);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hh = h1[0][cb][r];
+                const float w1v = u1[0][cb][r] * (1.f - hh * hh) * g1[cb][r];
+                const f4 wr = *reinterpret_cast<const f4*>(rec + 9216 + (cb * 16 + 4 * q + r) * 4);  // W1[ch, :]
+                r0 = fmaf(wr.x, w1v, r0); r1 = fmaf(wr.y, w1v, r1); r2 = fmaf(wr.z, w1v, r2);
+            }
+    }
+    // sum over the 4 q groups of the column (lanes col, col+16, col+32, col+48)
+    r0 += __shfl_xor(r0, 16); r1 += __shfl_xor(r1, 16); r2 += __shfl_xor(r2, 16);
+    r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
+    const float div = fmaf(r2, e2, fmaf(r1, e1, r0 * e0));
+    return (f4){sgn * dy.x, sgn * dy.y, sgn * dy.z, -sgn * div};
+}
+
+__device__ __forceinline__ CnfW cnf_stage_weights(f4* wl, const float* rec_g, int nthreads, int lane) {
+    for (int i = threadIdx.x; i < CNF_REC / 4; i += nthreads) wl[i] = reinterpret_cast<const f4*>(rec_g)[i];
     __syncthreads();
     const float* rec = reinterpret_cast<const float*>(wl);
+    return CnfW{rec, PfW2Lds{reinterpret_cast<const u4*>(rec), lane}, PfW2Lds{reinterpret_cast<const u4*>(rec + 4096), lane},
+                PfW2Lds{reinterpret_cast<const u4*>(rec + 8192), lane}};
+}
+
+__global__ __launch_bounds__(CNF_NW * 64) void cnf_rhs_kernel(CnfArgs a) {
+    __shared__ f4 wl[CNF_REC / 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
-    const PfW2Lds wsW2{reinterpret_cast<const u4*>(rec), lane}, wsW2T{reinterpret_cast<const u4*>(rec + 4096), lane},
-        wsW3{reinterpret_cast<const u4*>(rec + 8192), lane};
-    const float* tv = rec + 9872;
+    const CnfW w = cnf_stage_weights(wl, a.rec, CNF_NW * 64, lane);
     const size_t kstride = (size_t)a.rows * 4;
-
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int g = (tile * CNF_NW + wave) * 16 + col;
         const bool ok = g < a.rows;
@@ -70,105 +177,99 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_rhs_kernel(CnfArgs a) {
         }
         if (a.yout && ok && q == 0) *reinterpret_cast<f4*>(a.yout + (size_t)row * 4) = y;
         const float* cx = a.ctx + (size_t)pt * CNF_CTX;
-        const float e0 = a.e[(size_t)pt * 3 + 0], e1 = a.e[(size_t)pt * 3 + 1], e2 = a.e[(size_t)pt * 3 + 2];
-        const float t = a.t;
+        const f4 k = cnf_eval(w, q, y, a.t, a.sgn, cx, a.e[(size_t)pt * 3 + 0], a.e[(size_t)pt * 3 + 1],
+                              a.e[(size_t)pt * 3 + 2]);
+        if (ok && q == 0) *reinterpret_cast<f4*>(a.kout + (size_t)row * 4) = k;
+    }
+}
 
-        // ---- layer 1 (3 -> 64): this lane's channels 16 cb + 4 q + r
-        f4 h1[1][4], g1[4];
+// ---- one whole Dormand-Prince step per launch: the six stage evaluations run back to back on register-held stage
+// derivatives (the context rows are re-read from L1/L2, not HBM); outputs the step's solution, its FSAL derivative,
+// optionally the dense-output mid-point, and this workgroup's share of the scaled error sum.
+struct CnfStepArgs {
+    const float* y0;        // [rows,4]
+    const float* f0;        // [rows,4]  derivative at the start (FSAL)
+    const float* ctx;
+    const float* e;
+    const float* rec;
+    float* y1;              // [rows,4]
+    float* f1;              // [rows,4]
+    float* ymid;            // nullable
+    double* partial;        // [gridDim.x]
+    float t, h, sgn, tsign; // net time of stage s: tsign * (t + alpha_s h)
+    float rtol, atol;
+    int rows, R, ntiles;
+};
+
+__global__ __launch_bounds__(CNF_NW * 64) void cnf_step_kernel(CnfStepArgs a) {
+    __shared__ f4 wl[CNF_REC / 4];
+    __shared__ double red[CNF_NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    const CnfW w = cnf_stage_weights(wl, a.rec, CNF_NW * 64, lane);
+    constexpr float AL[6] = {1.f / 5, 3.f / 10, 4.f / 5, 8.f / 9, 1.f, 1.f};
+    constexpr float BE[6][6] = {
+        {1.f / 5, 0, 0, 0, 0, 0},
+        {3.f / 40, 9.f / 40, 0, 0, 0, 0},
+        {44.f / 45, -56.f / 15, 32.f / 9, 0, 0, 0},
+        {19372.f / 6561, -25360.f / 2187, 64448.f / 6561, -212.f / 729, 0, 0},
+        {9017.f / 3168, -355.f / 33, 46732.f / 5247, 49.f / 176, -5103.f / 18656, 0},
+        {35.f / 384, 0, 500.f / 1113, 125.f / 192, -2187.f / 6784, 11.f / 84}};
+    constexpr float CE[7] = {(float)(35. / 384 - 1951. / 21600), 0, (float)(500. / 1113 - 22642. / 50085),
+                             (float)(125. / 192 - 451. / 720), (float)(-2187. / 6784 + 12231. / 42400),
+                             (float)(11. / 84 - 649. / 6300), (float)(-1. / 60)};
+    constexpr float CM[7] = {(float)(6025192743. / 30085553152 / 2), 0, (float)(51252292925. / 65400821598 / 2),
+                             (float)(-2691868925. / 45128329728 / 2), (float)(187940372067. / 1594534317056 / 2),
+                             (float)(-1776094331. / 19743644256 / 2), (float)(11237099. / 235043384 / 2)};
+    double acc = 0.0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int g = (tile * CNF_NW + wave) * 16 + col;
+        const bool ok = g < a.rows;
+        const int row = ok ? g : a.rows - 1;
+        const int pt = row / a.R;
+        const f4 y0 = *reinterpret_cast<const f4*>(a.y0 + (size_t)row * 4);
+        const float* cx = a.ctx + (size_t)pt * CNF_CTX;
+        const float e0 = a.e[(size_t)pt * 3 + 0], e1 = a.e[(size_t)pt * 3 + 1], e2 = a.e[(size_t)pt * 3 + 2];
+        f4 k[7];
+        k[0] = *reinterpret_cast<const f4*>(a.f0 + (size_t)row * 4);
+        f4 yi = y0;
+        pf_static_for<0, 6>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f4 comb = k[0] * BE[s][0];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            const int ch = cb * 16 + 4 * q;
-            const f4 gc = *reinterpret_cast<const f4*>(cx + ch), bc = *reinterpret_cast<const f4*>(cx + 64 + ch);
-            const f4 gt = *reinterpret_cast<const f4*>(tv + ch), bt = *reinterpret_cast<const f4*>(tv + 64 + ch);
-            const f4 b1 = *reinterpret_cast<const f4*>(rec + 9728 + ch);
+            for (int j = 1; j <= s; ++j) comb += k[j] * BE[s][j];
+            yi = y0 + comb * a.h;
+            k[s + 1] = cnf_eval(w, q, yi, a.tsign * (a.t + AL[s] * a.h), a.sgn, cx, e0, e1, e2);
+        });
+        f4 err = k[0] * CE[0];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f4 w = *reinterpret_cast<const f4*>(rec + 9216 + (ch + r) * 4);
-                const float lin = fmaf(w.z, y.z, fmaf(w.y, y.y, fmaf(w.x, y.x, b1[r])));
-                const float gate = sigm(fmaf(gt[r], t, gc[r]));
-                g1[cb][r] = gate;
-                h1[0][cb][r] = tanhf(fmaf(lin, gate, fmaf(bt[r], t, bc[r])));
-            }
-        }
-        // ---- layer 2 (64 -> 64)
-        f4 h2[1][4], g2[4];
-        {
-            PfPair2 hp[1][2];
-            hp[0][0] = pf_pair2(h1[0][0], h1[0][1]);
-            hp[0][1] = pf_pair2(h1[0][2], h1[0][3]);
-            f4 a2[1][4];
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob) a2[0][ob] = pf_bias(rec + 9792, ob, q);
-            pf_mm2f<4, 2, 2>(wsW2, 0, hp, 0, a2, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                const int ch = cb * 16 + 4 * q;
-                const f4 gc = *reinterpret_cast<const f4*>(cx + 128 + ch), bc = *reinterpret_cast<const f4*>(cx + 192 + ch);
-                const f4 gt = *reinterpret_cast<const f4*>(tv + 128 + ch), bt = *reinterpret_cast<const f4*>(tv + 192 + ch);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gate = sigm(fmaf(gt[r], t, gc[r]));
-                    g2[cb][r] = gate;
-                    h2[0][cb][r] = tanhf(fmaf(a2[0][cb][r], gate, fmaf(bt[r], t, bc[r])));
-                }
-            }
-        }
-        // ---- layer 3 (64 -> 3; rows replicated: every q group holds channels 0..2 in .x .y .z)
-        f4 dy, g3;
-        {
-            PfPair2 hp[1][2];
-            hp[0][0] = pf_pair2(h2[0][0], h2[0][1]);
-            hp[0][1] = pf_pair2(h2[0][2], h2[0][3]);
-            f4 a3[1][1];
-            a3[0][0] = *reinterpret_cast<const f4*>(rec + 9856 + 4 * q);
-            pf_mm2f<1, 2, 2>(wsW3, 0, hp, 0, a3, 0);
-            const f4 gc = *reinterpret_cast<const f4*>(cx + 256 + 4 * q), bc = *reinterpret_cast<const f4*>(cx + 272 + 4 * q);
-            const f4 gt = *reinterpret_cast<const f4*>(tv + 256 + 4 * q), bt = *reinterpret_cast<const f4*>(tv + 272 + 4 * q);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                g3[r] = sigm(fmaf(gt[r], t, gc[r]));
-                dy[r] = fmaf(a3[0][0][r], g3[r], fmaf(bt[r], t, bc[r]));
-            }
-        }
-        // ---- Hutchinson term e^T J e by the vector-Jacobian product of e through the three layers
-        const float v0 = e0 * g3.x, v1 = e1 * g3.y, v2 = e2 * g3.z;
-        f4 w2[1][4];
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f4 w = *reinterpret_cast<const f4*>(rec + 9472 + (cb * 16 + 4 * q + r) * 4);      // W3[:, ch]
-                const float u = fmaf(w.z, v2, fmaf(w.y, v1, w.x * v0));
-                const float hh = h2[0][cb][r];
-                w2[0][cb][r] = u * (1.f - hh * hh) * g2[cb][r];
-            }
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-        {
-            PfPair2 wp[1][2];
-            wp[0][0] = pf_pair2(w2[0][0], w2[0][1]);
-            wp[0][1] = pf_pair2(w2[0][2], w2[0][3]);
-            f4 u1[1][4];
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob) u1[0][ob] = pf_splat(0.f);
-            pf_mm2f<4, 2, 2>(wsW2T, 0, wp, 0, u1, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float hh = h1[0][cb][r];
-                    const float w1v = u1[0][cb][r] * (1.f - hh * hh) * g1[cb][r];
-                    const f4 w = *reinterpret_cast<const f4*>(rec + 9216 + (cb * 16 + 4 * q + r) * 4);  // W1[ch, :]
-                    r0 = fmaf(w.x, w1v, r0); r1 = fmaf(w.y, w1v, r1); r2 = fmaf(w.z, w1v, r2);
-                }
-        }
-        // sum over the 4 q groups of the column (lanes col, col+16, col+32, col+48)
-        r0 += __shfl_xor(r0, 16); r1 += __shfl_xor(r1, 16); r2 += __shfl_xor(r2, 16);
-        r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
-        const float div = fmaf(r2, e2, fmaf(r1, e1, r0 * e0));
+        for (int j = 1; j < 7; ++j) err += k[j] * CE[j];
+        err *= a.h;
         if (ok && q == 0) {
-            const f4 o = {a.sgn * dy.x, a.sgn * dy.y, a.sgn * dy.z, -a.sgn * div};
-            *reinterpret_cast<f4*>(a.kout + (size_t)row * 4) = o;
+            *reinterpret_cast<f4*>(a.y1 + (size_t)row * 4) = yi;
+            *reinterpret_cast<f4*>(a.f1 + (size_t)row * 4) = k[6];
+            if (a.ymid) {
+                f4 m = k[0] * CM[0];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) m += k[j] * CM[j];
+                *reinterpret_cast<f4*>(a.ymid + (size_t)row * 4) = y0 + m * a.h;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float r = err[c] / (a.atol + a.rtol * fmaxf(fabsf(y0[c]), fabsf(yi[c])));
+                acc += (double)r * (double)r;
+            }
         }
+    }
+    // workgroup sum (fixed order): lanes -> wave -> workgroup
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < CNF_NW; ++i) t += red[i];
+        a.partial[blockIdx.x] = t;
     }
 }
 
@@ -289,5 +390,26 @@ extern "C" int pf_scaled_sumsq(const float* a, const float* b, const float* s0, 
     for (int j = 0; j < n_terms; ++j) s.w[j] = w[j];
     hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, s);
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, SUMSQ_BLOCKS, out);
+    return pf_last_launch_status();
+}
+
+// One Dormand-Prince 5(4) step attempt: y1 = y0 + h sum b_j k_j (k_1 = f0 given, FSAL), f1 = k_7, optional dense-output
+// mid-point, and out[0] (double) = sum_i (err_i / (atol + rtol max(|y0_i|, |y1_i|)))^2 of the embedded error estimate.
+// t: start of the step in solver time; reverse != 0 integrates the way torchdiffeq does for decreasing times
+// (net time = -solver time, derivative negated).  ws: >= 1024 doubles.
+extern "C" int pf_cnf_step(const float* y0, const float* f0, float t, float h, int reverse, const float* ctx, const float* e,
+                           const float* rec, float* y1, float* f1, float* ymid, float rtol, float atol, int rows, int R,
+                           double* ws, double* out, void* stream) {
+    if (!y0 || !f0 || !ctx || !e || !rec || !y1 || !f1 || !ws || !out) return PF_ERR_NULL;
+    if (rows <= 0 || R <= 0) return PF_ERR_SHAPE;
+    CnfStepArgs a{};
+    a.y0 = y0; a.f0 = f0; a.ctx = ctx; a.e = e; a.rec = rec; a.y1 = y1; a.f1 = f1; a.ymid = ymid; a.partial = ws;
+    a.t = t; a.h = h; a.sgn = reverse ? -1.f : 1.f; a.tsign = reverse ? -1.f : 1.f; a.rtol = rtol; a.atol = atol;
+    a.rows = rows; a.R = R;
+    a.ntiles = (rows + CNF_NW * 16 - 1) / (CNF_NW * 16);
+    const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cnf_step_kernel, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, ws, grid, out);
     return pf_last_launch_status();
 }
