@@ -19,16 +19,15 @@ from __future__ import annotations
 
 import ctypes
 import math
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
-import numpy as np
 import torch
 import torch.nn as nn
 from torch import Tensor
 
 from . import _lib
-from .interpflow import (COND_CHANNELS, FEAT_CHANNELS, GROWTH, NUM_BLOCKS, CondList, _EdgeConvParams, _Engine,
-                         _InterpParams, _MergeParams)
+from .interpflow import (COND_CHANNELS, FEAT_CHANNELS, GROWTH, NUM_BLOCKS, _EdgeConvParams, _Engine, _InterpParams,
+                         _MergeParams)
 from .packing import CNF_CTX, pack_cnf_block
 from .train_ops import _gemm
 from .weights import state_dict_spec

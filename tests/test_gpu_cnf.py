@@ -1,7 +1,5 @@
 """Continuous (CNF) variant on the GPU against oracle/cnf_ref.py.  PARITY UNPINNED against the
 reference (torchdiffeq absent): the oracle is a from-text restatement, see its header."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch

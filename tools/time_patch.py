@@ -5,7 +5,7 @@ which part of the CLI's per-cloud time is the network and which the patch operat
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from puflow_amd import ops, _lib
+from puflow_amd import ops
 from puflow_amd.interpflow import PointInterpFlow
 from puflow_amd.patch import PatchHelper
 from puflow_amd.weights import synth_patches, synth_state_dict
