@@ -41,8 +41,8 @@ def model_ref_flops_per_patch():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU")
     ap.add_argument("--npoint", type=int, default=2048)
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
