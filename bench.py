@@ -89,14 +89,25 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # One step = the whole hot path on one batch.  By default the 18 launches of a step are replayed as ONE hipGraph
+    # (PointInterpFlow.graphed: same kernels, same order, bit-identical results - tests/test_gpu_parity.py); the input is
+    # copied into the graph's static buffer inside the timed step.  PF_BENCH_GRAPH=0 times the eager path.
+    use_graph = os.environ.get("PF_BENCH_GRAPH", "1") == "1"
+    step = lambda inp: net(inp, 4)
+    if use_graph:
+        try:
+            step = net.graphed(args.batch, args.npoint, 4)
+        except Exception as ex:                                  # capture unsupported on this stack: time the eager path
+            print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); timing the eager path", file=sys.stderr)
+            use_graph = False
     for _ in range(args.warmup):
-        net(xyz, 4)
+        step(xyz)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        x, logp = net(xyz, 4)
+        x, logp = step(xyz)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -206,7 +217,8 @@ def main():
                "config": {"workload": "BASELINE configs[1]: PU1K discrete x4 inference, 32 x 2048-pt patches per GPU "
                                       "(fp32-parity mode)", "arithmetic": "fp32 inputs, accumulators and results; the dense layers run as 2-term split-fp16 "
                           "products on the fp16 MFMA pipe (hi.hi + hi.lo + lo.hi, fp32-class accuracy: parity tests hold the "
-                          "same 1e-5 bar; PF_EC_MODE=bf16x3 / f32 select the split-bf16 / bit-exact f32 EdgeConv kernels)", "patches_per_gpu": args.batch, "npoint": args.npoint,
+                          "same 1e-5 bar; PF_EC_MODE=bf16x3 / f32 select the split-bf16 / bit-exact f32 EdgeConv kernels)", "launch": "hipGraph replay (one launch per step)" if use_graph else "eager (18 launches per step)",
+                          "patches_per_gpu": args.batch, "npoint": args.npoint,
                           "upratio": 4, "sharding": f"patch batch over {world} rank(s), no data-path collective"},
                "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)

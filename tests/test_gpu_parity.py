@@ -281,3 +281,17 @@ def test_fp16_range_violation_is_loud(lib, monkeypatch):
         net(xyz, 4)
     x_ok, _ = net(synth_patches(1, 256, seed=3).to(DEV), 4)          # the same net on a normalised patch is fine
     assert bool(torch.isfinite(x_ok).all())
+
+
+def test_graphed_forward_is_bit_identical(lib):
+    """hipGraph replay of the eval forward (one launch per step) returns the eager path's bits, for fresh inputs too."""
+    sd = synth_state_dict(17)
+    net = _net(sd)
+    run = net.graphed(3, 256, 4)
+    for seed in (1, 2):
+        xyz = synth_patches(3, 256, seed=seed).to(DEV)
+        x_e, lp_e = net(xyz, 4)
+        x_g, lp_g = run(xyz)
+        assert torch.equal(x_g, x_e) and torch.equal(lp_g, lp_e)
+    with pytest.raises(ValueError):
+        run(synth_patches(2, 256, seed=1).to(DEV))
