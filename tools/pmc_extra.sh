@@ -7,6 +7,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export PF_BENCH_GRAPH=0        # profile the eager launches (same kernels as the graph replay, one dispatch record each)
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 cd /tmp
 for pass in "issue:SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" \
