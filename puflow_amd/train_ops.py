@@ -469,18 +469,18 @@ def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True) -> Tensor:
     S = Wp.shape[0]
     bias = torch.cat([c.bias for c in convs] + [torch.zeros(S, dtype=torch.float32, device=x.device)])
     pq = linear(x.reshape(B * N, C), torch.cat([Wp, Wq], dim=0), bias)           # [B*N, 2S] = P (+ bias) | Q
-    E = RepeatRowsFn.apply(pq[:, :S].reshape(B, N, S), K).reshape(B * N * K, S) \
-        + GatherRowsFn.apply(pq[:, S:].reshape(B, N, S), idx)                     # P[i] + Q[j] per edge
+    Pp, Qp = torch.split(pq, [S, S], dim=1)
+    E = RepeatRowsFn.apply(Pp.reshape(B, N, S), K).reshape(B * N * K, S) \
+        + GatherRowsFn.apply(Qp.reshape(B, N, S), idx)                            # P[i] + Q[j] per edge
+    # split (not five slices): its backward is ONE concatenation instead of five zero-filled [B*N*K, S] tensors + adds
+    Es = torch.split(E, [w.shape[0] for w in Ws], dim=1)
     feats: List[Tensor] = []
-    off = 0
     for t, seq in enumerate(p.convs):
-        g = Ws[t].shape[0]
-        y = E[:, off:off + g]
+        y = Es[t]
         if feats:
             y = y + linear(feats[0] if len(feats) == 1 else torch.cat(feats, dim=1), Ws[t][:, 3 * C:])
         feats.append(bn_lrelu(y, seq[1], 0.05))
-        off += g
-    y = E[:, off:] + linear(torch.cat(feats, dim=1), Ws[-1][:, 3 * C:])
+    y = Es[-1] + linear(torch.cat(feats, dim=1), Ws[-1][:, 3 * C:])
     if not pooling:
         return y.contiguous()
     return MaxPoolKFn.apply(y.contiguous(), K).view(B, N, -1)
