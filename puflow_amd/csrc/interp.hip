@@ -121,24 +121,26 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
             for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
                 for (int p = 0; p < P; ++p) w1[p][ob] = pf_splat(0.f);
-            pf_mm2f<8, 1, 1>(wsWT, 0, e, 0, w1, 0);
-            pf_mm2f<8, 2, 2>(wsD6, 0, dp, 0, w1, 0);
+            pf_mm2f<4, 1, 1>(wsWT, 0, e, 0, w1, 0);
+            pf_mm2f<4, 1, 1>(wsWT, 4, e, 0, w1, 4);
+            pf_mm2f<4, 2, 2>(wsD6, 0, dp, 0, w1, 0);
+            pf_mm2f<4, 2, 2>(wsD6, 8, dp, 0, w1, 4);
         }
 
         // ---- EdgeConv growth features (C=3, g=16, 8 convs) on the same 8 neighbours; conv_out is folded into w1
         {
-            f4 pre[P][8];                      // pre-activations from the raw inputs: rows 16t.. of the edge table
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int p = 0; p < P; ++p) pre[p][t] = pf_splat(0.f);
-            pf_mm2f<8, 1, 1>(wsET, 0, e, 0, pre, 0);
-            f4 feat[P][8];
             PfPair2 fp[P][4];
+            f4 last[P];
+            {
+                f4 acc[P][1];
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                feat[p][0] = pf_lrelu(pre[p][0], 0.05f);
-                fp[p][0] = pf_pair2(feat[p][0], pf_splat(0.f));
+                for (int p = 0; p < P; ++p) acc[p][0] = pf_splat(0.f);
+                pf_mm2f<1, 1, 1>(wsET, 0, e, 0, acc, 0);                 // pre-activation from the raw inputs (edge table)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    last[p] = pf_lrelu(acc[p][0], 0.05f);
+                    fp[p][0] = pf_pair2(last[p], pf_splat(0.f));
+                }
             }
             pf_static_for<1, 8>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
@@ -146,16 +148,19 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
                 constexpr int F0 = (t / 2) * ((t + 1) / 2);          // fragments of layers 1..t-1: sum ceil(s/2)
                 f4 acc[P][1];
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[p][0] = pre[p][t];
+                for (int p = 0; p < P; ++p) acc[p][0] = pf_splat(0.f);
+                pf_mm2f<1, 1, 1>(wsET, t, e, 0, acc, 0);
                 pf_mm2f<1, CPT, CPT>(wsEC, F0, fp, 0, acc, 0);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    feat[p][t] = pf_lrelu(acc[p][0], 0.05f);
-                    if constexpr (t % 2 == 1) fp[p][t / 2] = pf_pair2(feat[p][t - 1], feat[p][t]);
-                    else fp[p][t / 2] = pf_pair2(feat[p][t], pf_splat(0.f));
+                    const f4 f = pf_lrelu(acc[p][0], 0.05f);
+                    if constexpr (t % 2 == 1) fp[p][t / 2] = pf_pair2(last[p], f);
+                    else fp[p][t / 2] = pf_pair2(f, pf_splat(0.f));
+                    last[p] = f;
                 }
             });
-            pf_mm2f<8, 4, 4>(wsW0, 0, fp, 0, w1, 0);               // w1 += (W0b Gout) feat
+            pf_mm2f<4, 4, 4>(wsW0, 0, fp, 0, w1, 0);               // w1 += (W0b Gout) feat, two chunks of 4 output blocks
+            pf_mm2f<4, 4, 4>(wsW0, 16, fp, 0, w1, 4);
         }
 
         // ---- rest of the weight unit: 128 -> 64 -> R
