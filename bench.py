@@ -213,7 +213,13 @@ def main():
                                "logp_note": "logp is a batch mean; compared in tests on equal batches"}
         out = {"metric": "patches/sec x4 2048->8192 (PU1K discrete, eval)", "value": value, "unit": "patches/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               # the arithmetic the path computes in: fp32 values, each product as 2-term split-fp16 on the fp16 MFMA
+               # with fp32 accumulation (PF_EC_MODE=f32: plain f32 MFMA in the 128-channel EdgeConv units)
+               "dtype": "f32 (split-fp16 MFMA products, fp32 accumulate)" if eng.ec_mode == "f16x2" else
+                        ("f32 (split-bf16 EdgeConv, split-fp16 elsewhere)" if eng.ec_mode == "bf16x3" else
+                         "f32 (f32 MFMA EdgeConv, split-fp16 elsewhere)"),
+               "data": "synthetic",
                "config": {"workload": "BASELINE configs[1]: PU1K discrete x4 inference, 32 x 2048-pt patches per GPU "
                                       "(fp32-parity mode)", "arithmetic": "fp32 inputs, accumulators and results; the dense layers run as 2-term split-fp16 "
                           "products on the fp16 MFMA pipe (hi.hi + hi.lo + lo.hi, fp32-class accuracy: parity tests hold the "
