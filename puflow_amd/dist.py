@@ -80,6 +80,16 @@ def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
         dist.broadcast(t.data, src=src)
 
 
+def broadcast_buffers(module: torch.nn.Module, src: int = 0) -> None:
+    """BatchNorm running statistics are updated from each rank's own shard (local batch statistics, like
+    DistributedDataParallel without SyncBN); like DDP's `broadcast_buffers`, rank `src`'s copies are made
+    authoritative before anything reads them in eval mode (validation, checkpoints)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for t in module.buffers():
+        dist.broadcast(t.data, src=src)
+
+
 def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:

@@ -97,6 +97,8 @@ class TrainerModule(_Base):
         xyz_sparse, xyz_dense = batch[0], batch[1]
         upratio = int(xyz_dense.shape[1] / xyz_sparse.shape[1])
         was = self.training
+        from .dist import broadcast_buffers
+        broadcast_buffers(self)                  # multi-rank: rank 0's BN running statistics, as DDP would have them
         self.eval()
         predict_x, logpx = self(xyz_sparse, upratio=upratio)
         cd = self.chamfer_loss2(predict_x, xyz_dense)

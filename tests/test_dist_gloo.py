@@ -35,7 +35,12 @@ def _worker(rank, world, port, q):
         bucket.all_reduce_mean()
         g = [float(p.grad.flatten()[0]) for p in list(net.parameters())[:2]]
         tmax = D.max_over_ranks(1.0 + rank, "cpu")
-        q.put((rank, lo, hi, bool(torch.equal(back, x * 2)), w, g, bucket.numel, tmax))
+        # BN running statistics drift apart with local batch statistics; rank 0's become authoritative before eval
+        bn = net.feat_convs[1].convs[0][1]
+        bn.running_mean.fill_(float(rank + 1))
+        D.broadcast_buffers(net, src=0)
+        rm = float(bn.running_mean[0])
+        q.put((rank, lo, hi, bool(torch.equal(back, x * 2)), w, g, bucket.numel, tmax, rm))
     finally:
         dist.destroy_process_group()
 
@@ -51,7 +56,8 @@ def test_two_rank_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, lo0, hi0, ok0, w0, g0, n0, t0), (r1, lo1, hi1, ok1, w1, g1, n1, t1) = res
+    (r0, lo0, hi0, ok0, w0, g0, n0, t0, rm0), (r1, lo1, hi1, ok1, w1, g1, n1, t1, rm1) = res
+    assert rm0 == rm1 == 1.0                                     # buffers follow rank 0
     assert (lo0, hi0, lo1, hi1) == (0, 19, 19, 37) and ok0 and ok1
     assert torch.equal(w0, w1)                                   # broadcast made the weights identical
     assert n0 == n1 == 806103                                    # the whole model is one 3.2 MB bucket
