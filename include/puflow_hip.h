@@ -138,6 +138,20 @@ int pf_bn_lrelu_fwd(const float* x, long long R, int C, const float* gamma, cons
                     float momentum, float* run_mean, float* run_var, float* y, float* save, float* ws, void* stream);
 int pf_bn_lrelu_bwd(const float* x, const float* dy, long long R, int C, const float* gamma, const float* beta, float slope,
                     const float* save, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
+/* The same BatchNorm + LeakyReLU in stages, so that per-column sums can be all-reduced between them (SyncBN across
+ * ranks; SURVEY 8e "decision to document" / f-3).  Sums are unscaled; the host divides by the global row count.
+ *   pf_bn_colstat:     out[c] = sum_r x (mean_in NULL) or sum_r (x - mean_in)^2;   ws: 2*pf_bn_chunks(R)*C floats
+ *   pf_bn_apply_stats: y from GIVEN mean / biased variance; save = [mean | invstd]; running stats updated (nullable)
+ *   pf_bn_bwd_sums:    sums[2][C] = (sum dz, sum dz*xhat) of this rank's rows (= dbeta, dgamma of the local loss)
+ *   pf_bn_bwd_apply:   dx from the global means[2][C] = all-reduced sums / global row count */
+int pf_bn_colstat(const float* x, long long R, int C, const float* mean_in, float* out, float* ws, void* stream);
+int pf_bn_apply_stats(const float* x, long long R, int C, const float* mean, const float* var_b, float unbias,
+                      const float* gamma, const float* beta, float slope, float eps, float momentum, float* run_mean,
+                      float* run_var, float* y, float* save, void* stream);
+int pf_bn_bwd_sums(const float* x, const float* dy, long long R, int C, const float* gamma, const float* beta, float slope,
+                   const float* save, float* sums, float* ws, void* stream);
+int pf_bn_bwd_apply(const float* x, const float* dy, long long R, int C, const float* gamma, const float* beta, float slope,
+                    const float* save, const float* means, float* dx, void* stream);
 /* column sums of g [R,C] -> out [C] (bias gradients); ws: 2*pf_bn_chunks(R)*C floats */
 int pf_colsum(const float* g, long long R, int C, float* out, float* ws, void* stream);
 

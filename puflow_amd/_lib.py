@@ -42,6 +42,13 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_bn_lrelu_bwd": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_bn_colstat": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_bn_apply_stats": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_float,
+                                  c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_bn_bwd_sums": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                               c_void_p]),
+    "pf_bn_bwd_apply": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                c_void_p]),
     "pf_colsum": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_act_fwd": (c_int, [c_void_p, c_float, c_longlong, c_void_p, c_void_p]),
     "pf_act_bwd": (c_int, [c_void_p, c_void_p, c_float, c_longlong, c_void_p, c_void_p]),

@@ -566,6 +566,59 @@ extern "C" int pf_bn_lrelu_bwd(const float* x, const float* dy, long long R, int
     return pf_last_launch_status();
 }
 
+// ---- the same BatchNorm in stages, so that the per-column sums can be all-reduced between them (SyncBN across ranks:
+// puflow_amd/train_ops.py SyncBnLreluFn).  Statistics are UNSCALED sums here; the host divides by the global row count.
+// out[c] = sum_r x[r,c]  (mean_in == NULL)  or  sum_r (x[r,c] - mean_in[c])^2.   ws >= 2*nchunk*C floats.
+extern "C" int pf_bn_colstat(const float* x, long long R, int C, const float* mean_in, float* out, float* ws, void* stream) {
+    if (!x || !out || !ws) return PF_ERR_NULL;
+    if (R <= 0 || C <= 0) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = pf_bn_chunks(R);
+    const int rows_per = (int)((R + nchunk - 1) / nchunk);
+    if (mean_in) colstat_launch<1>(x, nullptr, mean_in, nullptr, nullptr, nullptr, 0.f, R, C, nchunk, rows_per, ws, s);
+    else colstat_launch<0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, R, C, nchunk, rows_per, ws, s);
+    hipLaunchKernelGGL(colstat_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, nchunk, C, 1, 1.0f, out);
+    return pf_last_launch_status();
+}
+
+// y = lrelu(gamma (x - mean) / sqrt(var_b + eps) + beta) with GIVEN (global) mean / biased variance; save = [mean | invstd];
+// running statistics updated with momentum and var_b * unbias (nullable).
+extern "C" int pf_bn_apply_stats(const float* x, long long R, int C, const float* mean, const float* var_b, float unbias,
+                                 const float* gamma, const float* beta, float slope, float eps, float momentum,
+                                 float* run_mean, float* run_var, float* y, float* save, void* stream) {
+    if (!x || !mean || !var_b || !gamma || !beta || !y || !save) return PF_ERR_NULL;
+    if (R <= 0 || C <= 0) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemcpyAsync(save, mean, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, var_b, C, eps, momentum, unbias, save, save + C,
+                       run_mean, run_var);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, save, save + C, gamma, beta, slope, R * C, C, y);
+    return pf_last_launch_status();
+}
+
+// backward, stage 1: sums[2][C] = (sum dz, sum dz * xhat) over THIS rank's rows (= dbeta, dgamma of the local loss)
+extern "C" int pf_bn_bwd_sums(const float* x, const float* dy, long long R, int C, const float* gamma, const float* beta,
+                              float slope, const float* save, float* sums, float* ws, void* stream) {
+    if (!x || !dy || !gamma || !beta || !save || !sums || !ws) return PF_ERR_NULL;
+    if (R <= 0 || C <= 0) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = pf_bn_chunks(R);
+    const int rows_per = (int)((R + nchunk - 1) / nchunk);
+    colstat_launch<2>(x, dy, save, save + C, gamma, beta, slope, R, C, nchunk, rows_per, ws, s);
+    hipLaunchKernelGGL(colstat_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, nchunk, C, 2, 1.0f, sums);
+    return pf_last_launch_status();
+}
+
+// backward, stage 2: dx from the GLOBAL means[2][C] = all-reduced sums / global row count
+extern "C" int pf_bn_bwd_apply(const float* x, const float* dy, long long R, int C, const float* gamma, const float* beta,
+                               float slope, const float* save, const float* means, float* dx, void* stream) {
+    if (!x || !dy || !gamma || !beta || !save || !means || !dx) return PF_ERR_NULL;
+    if (R <= 0 || C <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, (hipStream_t)stream, x, dy, save, save + C, gamma,
+                       beta, means, slope, R * C, C, dx);
+    return pf_last_launch_status();
+}
+
 // column sums of g [R,C] -> out [C] (bias gradients).  ws >= 2*nchunk*C floats.
 extern "C" int pf_colsum(const float* g, long long R, int C, float* out, float* ws, void* stream) {
     if (!g || !out || !ws) return PF_ERR_NULL;

@@ -131,8 +131,75 @@ class BnLreluFn(Function):
         return dx, dg, db, None, None, None, None, None
 
 
+class SyncBnLreluFn(Function):
+    """BnLreluFn with statistics over the GLOBAL batch (all ranks): the per-column sums are all-reduced between the
+    kernel stages - 2 small all-reduces forward (mean, then centred variance: the same two-pass scheme as the local
+    kernel), 1 backward.  dgamma / dbeta stay the LOCAL sums (the gradient bucket's mean over ranks then gives the
+    gradient of the averaged loss, as with torch.nn.SyncBatchNorm under DDP); dx uses the global means."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, slope, eps, momentum):
+        import torch.distributed as dist
+        lib = _lib.load()
+        x = x.contiguous()
+        R, C = x.shape
+        dev = x.device
+        ws = _ws(dev, 2 * lib.pf_bn_chunks(R) * C)
+        g, b = gamma.contiguous(), beta.contiguous()
+        stat = torch.empty((C + 1,), dtype=torch.float32, device=dev)
+        _lib.check(lib.pf_bn_colstat(x.data_ptr(), R, C, None, stat.data_ptr(), ws.data_ptr(), _stream()), "pf_bn_colstat")
+        stat[C] = float(R)
+        dist.all_reduce(stat)
+        Rg = float(stat[C].item())
+        mean = (stat[:C] / Rg).contiguous()
+        var = torch.empty((C,), dtype=torch.float32, device=dev)
+        _lib.check(lib.pf_bn_colstat(x.data_ptr(), R, C, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), _stream()), "pf_bn_colstat")
+        dist.all_reduce(var)
+        var = (var / Rg).contiguous()
+        y = torch.empty_like(x)
+        save = torch.empty((2, C), dtype=torch.float32, device=dev)
+        _lib.check(lib.pf_bn_apply_stats(x.data_ptr(), R, C, mean.data_ptr(), var.data_ptr(), Rg / max(Rg - 1.0, 1.0),
+                                         g.data_ptr(), b.data_ptr(), slope, eps, momentum,
+                                         run_mean.data_ptr() if run_mean is not None else None,
+                                         run_var.data_ptr() if run_var is not None else None, y.data_ptr(), save.data_ptr(),
+                                         _stream()), "pf_bn_apply_stats")
+        ctx.save_for_backward(x, g, b, save)
+        ctx.slope, ctx.Rg = slope, Rg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        lib = _lib.load()
+        x, g, b, save = ctx.saved_tensors
+        R, C = x.shape
+        dy = dy.contiguous()
+        ws = _ws(x.device, 2 * lib.pf_bn_chunks(R) * C)
+        sums = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.pf_bn_bwd_sums(x.data_ptr(), dy.data_ptr(), R, C, g.data_ptr(), b.data_ptr(), ctx.slope, save.data_ptr(),
+                                      sums.data_ptr(), ws.data_ptr(), _stream()), "pf_bn_bwd_sums")
+        db, dg = sums[0].clone(), sums[1].clone()
+        dist.all_reduce(sums)
+        means = (sums / ctx.Rg).contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(lib.pf_bn_bwd_apply(x.data_ptr(), dy.data_ptr(), R, C, g.data_ptr(), b.data_ptr(), ctx.slope, save.data_ptr(),
+                                       means.data_ptr(), dx.data_ptr(), _stream()), "pf_bn_bwd_apply")
+        return dx, dg, db, None, None, None, None, None
+
+
+SYNC_BN = False          # set by TrainerModule(cfg.sync_batchnorm=True): BatchNorm statistics over all ranks
+
+
+def _sync_bn_active() -> bool:
+    if not SYNC_BN:
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def bn_lrelu(x: Tensor, bn: torch.nn.BatchNorm2d, slope: float) -> Tensor:
-    y = BnLreluFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope, bn.eps, bn.momentum)
+    fn = SyncBnLreluFn if _sync_bn_active() else BnLreluFn
+    y = fn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope, bn.eps, bn.momentum)
     with torch.no_grad():
         bn.num_batches_tracked += 1
     return y

@@ -26,7 +26,9 @@ except Exception:                        # pragma: no cover - not installed in t
 
 
 def default_cfg(**kw):
-    cfg = dict(net="UpsamplingFlow", learning_rate=1e-3, sched_patience=10, sched_factor=0.5, seed=2021)
+    # sync_batchnorm: BatchNorm statistics over ALL ranks (an extension: the reference trains on one GPU, where it is
+    # the same thing; default False = each rank normalises with its own shard, like DDP without SyncBatchNorm)
+    cfg = dict(net="UpsamplingFlow", learning_rate=1e-3, sched_patience=10, sched_factor=0.5, seed=2021, sync_batchnorm=False)
     cfg.update(kw)
     return SimpleNamespace(**cfg)
 
@@ -39,6 +41,8 @@ class TrainerModule(_Base):
         super().__init__()
         self.cfg = cfg or default_cfg()
         self.loss_mix = loss_mix
+        from . import train_ops
+        train_ops.SYNC_BN = bool(getattr(self.cfg, "sync_batchnorm", False))
         self.network = PointInterpFlow(pc_channel=3)
         self.emd_loss = EarthMoverDistance()
         self.chamfer_loss = ChamferCUDA()
