@@ -104,3 +104,16 @@ def test_cli_file_sharding_covers_every_file_once():
         parts = [shard_paths(files, r, world) for r in range(world)]
         assert sorted(sum(parts, [])) == sorted(files)
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_cnf_module_state_dict_matches_reference_census(golden_dir):
+    """The continuous model's parameter names / shapes / dtypes are those of the reference's pretrained CNF checkpoint
+    (census made by tools/make_golden.py from pretrain/puflow-x4-cnf-pu1k.pt)."""
+    import json
+    from puflow_amd.cnf import PointInterpFlow
+    with open(os.path.join(golden_dir, "state_dict_census_cnf.json")) as f:
+        census = json.load(f)
+    sd = PointInterpFlow(3).state_dict()
+    assert len(census) == 390 and [k for k, _, _ in census] == list(sd.keys())
+    for k, shape, dt in census:
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == dt, k

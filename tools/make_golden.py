@@ -135,6 +135,12 @@ def main():
     with open(os.path.join(gdir, "state_dict_census.json"), "w") as f:
         json.dump(census["puflow-x4-pu1k.pt"], f)
     print("census", len(census["puflow-x4-pu1k.pt"]))
+    # the continuous (CNF) checkpoint's key / shape list (its model cannot be RUN here - torchdiffeq - but its on-disk
+    # format can be read): pins puflow_amd.cnf.PointInterpFlow's state-dict surface
+    ref = torch.load(os.path.join(REF, "pretrain", "puflow-x4-cnf-pu1k.pt"), map_location="cpu")
+    with open(os.path.join(gdir, "state_dict_census_cnf.json"), "w") as f:
+        json.dump([[k, list(v.shape), str(v.dtype)] for k, v in ref.items()], f)
+    print("census cnf", len(ref))
 
 
 if __name__ == "__main__":
