@@ -1,15 +1,20 @@
 """CPU oracle for the CONTINUOUS (CNF) PU-Flow x4 variant.  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED.  The reference's continuous model (`/root/reference/modules/continuous/`) cannot be run
-here: it imports `torchdiffeq` (`cnf.py:3-4`), an un-vendored, un-pinned pip dependency
-(`docker/Dockerfile:43`) that is not installed and may not be stood in for.  What follows is therefore
+PARITY: the ODE right-hand side is PINNED, the ODE solver is UNPINNED.
+  * `odenet` / `rhs` (ODEnet, ConcatSquashLinear, ODEfunc.forward incl. the Hutchinson divergence and the noise
+    repetition of the inverse pass) are checked against golden vectors produced by the REFERENCE's own
+    `modules/continuous/odefunc.py` + `diffeq_layers.py`, which import without torchdiffeq
+    (tools/make_golden_cnf.py -> tests/golden/cnf_rhs.npz; tests/test_oracle_cnf.py, tests/test_gpu_cnf.py).
+  * The solver cannot be pinned: the reference's `cnf.py:3-4` imports `torchdiffeq`, an un-vendored, un-pinned pip
+    dependency (`docker/Dockerfile:43`) that is not installed and may not be stood in for, so `CNF`, `FlowBlock` and
+    the whole continuous `PointInterpFlow.forward` cannot be run here.  For those, what follows is
   * a restatement of the reference's own modules (file:line cited per function), and
   * a restatement FROM THE PUBLISHED ALGORITHM of torchdiffeq's adaptive `dopri5` (0.2.x line:
     Dormand-Prince 5(4) tableau with FSAL, Hairer's initial step, RMS norm over the flattened state tuple,
     step controller safety 0.9 / ifactor 10 / dfactor 0.2, 4th-order dense output at the end time,
     reverse time by negating t and f),
 anchored on the reference's call site (`cnf.py:97-113`: method dopri5, atol = rtol = 1e-5, states (x, logp, c)).
-No golden vector of the reference exists for this path; tests compare the HIP path against THIS file.
+No golden vector of the reference exists for the integrated path; tests compare the HIP path against THIS file.
 
 Shared with the discrete model (and pinned there): kNN, EdgeConv units, merge units, interpolation module
 (`continuous/interpflow.py:14` imports them from the discrete file) - taken from oracle/ref_cpu.py.

@@ -12,8 +12,9 @@ What runs where:
   * the adaptive step-size CONTROL of dopri5 (torchdiffeq semantics restated from its published algorithm, see
     oracle/cnf_ref.py header): a few host scalars per step - one device->host read of the error norm per step.
 
-Parity: UNPINNED against the reference (torchdiffeq is not installed and not vendored); the tests pin this path to
-oracle/cnf_ref.py, a from-text restatement.  Tolerance is the solver's own (atol = rtol = 1e-5).
+Parity: the right-hand side is pinned to the reference's own ODEfunc (tests/golden/cnf_rhs.npz); the solver is UNPINNED
+(torchdiffeq is not installed and not vendored) - the integrated path is tested against oracle/cnf_ref.py, a from-text
+restatement of dopri5.  Tolerance of the integrated path is the solver's own (atol = rtol = 1e-5).
 """
 from __future__ import annotations
 

@@ -106,3 +106,26 @@ def test_cli_continuous(tmp_path):
     assert out.shape == (2048, 3) and np.isfinite(out).all()
     d = O.pairwise_sqdist(torch.from_numpy(out)[None], torch.from_numpy(pts)[None]).min(-1)[0].sqrt()
     assert float(d.max()) < 0.5          # random weights: a sanity bound, the cloud stays around the input surface
+
+
+def test_rhs_kernel_matches_reference_golden(golden_dir):
+    """PINNED: `pf_cnf_rhs` against the REFERENCE's own ODEfunc.forward outputs (tools/make_golden_cnf.py)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "cnf_rhs.npz"))
+    sd = synth_cnf_state_dict(int(g["meta_seed"]))
+    net = _net(sd)
+    eng = net._engine(4)
+    for block, R in ((0, 1), (3, 1), (5, 4), (2, 4)):
+        tag = f"b{block}_R{R}"
+        y, c, e = (torch.from_numpy(g[f"{tag}_{k}"]) for k in ("y", "c", "e"))
+        B, NR, _ = y.shape
+        T = c.shape[0] * c.shape[1]
+        rows = B * NR
+        state = torch.cat([y.reshape(rows, 3), torch.zeros(rows, 1)], dim=-1).to(DEV)
+        ctx = eng.context(block, c.reshape(T, -1).to(DEV).contiguous())
+        out = torch.empty(rows, 4, device=DEV)
+        eng._rhs(block, state, state, [], 0.0, float(g[f"{tag}_t"]), 1.0, ctx, e.reshape(T, 3).to(DEV).contiguous(), out, None,
+                 rows, R)
+        out = out.cpu()
+        assert (out[:, :3] - torch.from_numpy(g[f"{tag}_dy"]).reshape(-1, 3)).abs().max() < 1e-5
+        assert (out[:, 3] - torch.from_numpy(g[f"{tag}_ndiv"]).reshape(-1)).abs().max() < 1e-5

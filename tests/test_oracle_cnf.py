@@ -71,3 +71,21 @@ def test_pack_cnf_block_layout():
         np.testing.assert_array_equal(rec[9872 + 256 + 4 * q:9872 + 256 + 4 * q + 3], g3[:, 0])
     np.testing.assert_array_equal(hb[0:64], sd[p + ".0._hyper_gate.bias"].numpy())
     assert not hb[64:128].any()                             # hyper_bias has no bias term (diffeq_layers.py:76)
+
+
+def test_rhs_matches_reference_golden(golden_dir):
+    """PINNED: the ODE right-hand side (ODEnet + Hutchinson divergence) against what the REFERENCE's own
+    `ODEfunc.forward` produced (tools/make_golden_cnf.py; odefunc.py / diffeq_layers.py import without torchdiffeq)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "cnf_rhs.npz"))
+    sd = synth_cnf_state_dict(int(g["meta_seed"]))
+    for block, R in ((0, 1), (3, 1), (5, 4), (2, 4)):
+        tag = f"b{block}_R{R}"
+        y, c, e = (torch.from_numpy(g[f"{tag}_{k}"]) for k in ("y", "c", "e"))
+        B, NR, _ = y.shape
+        cr = torch.repeat_interleave(c, R, dim=1).reshape(B * NR, -1)
+        er = torch.repeat_interleave(e, R, dim=1).reshape(B * NR, 3)
+        state = torch.cat([y.reshape(B * NR, 3), torch.zeros(B * NR, 1)], dim=-1)
+        out = C.rhs(sd, block, float(g[f"{tag}_t"]), state, cr, er)
+        assert (out[:, :3] - torch.from_numpy(g[f"{tag}_dy"]).reshape(-1, 3)).abs().max() < 2e-6
+        assert (out[:, 3] - torch.from_numpy(g[f"{tag}_ndiv"]).reshape(-1)).abs().max() < 2e-6
