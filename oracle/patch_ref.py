@@ -2,9 +2,13 @@
 
 Restates `modules/utils/patch.py:35-214` step by step.  The kernels it calls in the reference come from
 un-vendored, unpinned third-party packages (pointnet2_ops FPS, knn_cuda KNN, ChamferDistancePytorch;
-docker/Dockerfile:47-49, .gitmodules:1-3) and the reference has no tests for them: **parity unpinned** -
-the semantics are the ones stated in csrc/patch_ops.hip (FPS from index 0, first maximum; kNN by
-(distance, index); unfused fp32 squared distances)."""
+docker/Dockerfile:47-49, .gitmodules:1-3) and the reference has no tests for them.
+  * FPS: PINNED to the reference's own in-tree torch implementation of the same algorithm
+    (`modules/utils/fps.py::farthest_point_sampling`, used by `PatchHelper.merge_pc`, patch.py:162-165):
+    tests/golden/fps_ref.npz (tools/make_golden_patch.py) fixes the start index (0), the 1e10 initial distance, the
+    (dx^2 + dy^2) + dz^2 arithmetic and the first-maximum tie rule; `fps` below and `pf_fps` reproduce it exactly.
+  * large-K kNN, Chamfer-based outlier removal: **parity unpinned** - the semantics are the ones stated in
+    csrc/patch_ops.hip (kNN by (distance, index); unfused fp32 squared distances)."""
 from __future__ import annotations
 
 import torch

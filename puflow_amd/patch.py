@@ -86,6 +86,13 @@ class PatchHelper(object):
         return ops.gather_operation(patches.transpose(1, 2).contiguous(), idx)     # [B,3,npoint]
 
     # ---- patch.py:168-178
+    # ---- patch.py:162-165 (the reference uses its in-tree torch FPS here; same algorithm, see tests/golden/fps_ref.npz)
+    @staticmethod
+    def merge_pc(pc1: Tensor, pc2: Tensor, npoint: int) -> Tensor:
+        tmp = torch.cat([pc1, pc2], dim=1).contiguous()
+        idx = ops.furthest_point_sample(tmp, npoint).long()
+        return tmp[torch.arange(tmp.shape[0], device=tmp.device).view(-1, 1), idx]
+
     @staticmethod
     def normalize_pc(pc: Tensor):
         centroid = torch.mean(pc, dim=1, keepdim=True)

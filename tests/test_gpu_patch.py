@@ -29,6 +29,20 @@ def test_fps_bit_exact(B, N, npoint):
     assert got[:, 0].eq(0).all()
 
 
+def test_fps_matches_reference_torch_fps(golden_dir):
+    """PINNED: `pf_fps` (single-workgroup and cooperative kernels) against the reference's own in-tree torch FPS
+    (modules/utils/fps.py; tools/make_golden_patch.py), and PatchHelper.merge_pc (patch.py:162-165) built on it."""
+    from puflow_amd import ops
+    from puflow_amd.patch import PatchHelper
+    g = np.load(os.path.join(golden_dir, "fps_ref.npz"))
+    for tag in "abcde":
+        xyz, ref = torch.from_numpy(g[f"{tag}_xyz"]), torch.from_numpy(g[f"{tag}_idx"])
+        got = ops.furthest_point_sample(xyz.to(DEV), ref.shape[1])
+        assert torch.equal(got.cpu().long(), ref), tag
+    out = PatchHelper.merge_pc(torch.from_numpy(g["m_a"]).to(DEV), torch.from_numpy(g["m_b"]).to(DEV), 128)
+    assert torch.equal(out.cpu(), torch.from_numpy(g["m_out"]))
+
+
 @pytest.mark.parametrize("B,N,M,K", [(2, 2048, 32, 256), (1, 5000, 78, 256), (1, 300, 7, 300), (2, 1000, 5, 64)])
 def test_knn_large_and_KNN_surface(B, N, M, K):
     from puflow_amd import ops
