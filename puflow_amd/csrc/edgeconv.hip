@@ -310,6 +310,221 @@ int launch3(const EcArgs& a0, hipStream_t s) {
     return pf_last_launch_status();
 }
 
+// ---- "f16n": split-fp16 with a NATURAL-scale low half, one accumulator, conv_out with the operands swapped ----------
+// Arithmetic: x = hi + lo, hi = rne_f16(x), lo = rne_f16(x - hi) (no 2^11 scale: v_fma_mixlo/mixhi_f16 writes it straight into
+// the packed operand; gfx950's fp16 MFMA honours subnormal operands, so a small lo keeps an ABSOLUTE precision of 2^-25 in
+// the units the operand is stored in).  All three product terms (hi.hi, hi.lo, lo.hi) go into ONE fp32 accumulator: no second
+// accumulator, no fold.  To keep the subnormal floor far below fp32 rounding the host stores feature block u as 4^u x_u and the
+// weights of layer t on block u as 4^(t-u) W (packing.ec4_scales: exact powers of two, folded into the matrices and into the
+// rows of the P|Q table), so the accumulators of layer t hold 4^t v_t and LeakyReLU needs no rescale; conv_out holds 256 y.
+// conv_out runs with the operands swapped: an activation fragment is bit-for-bit also the A operand with the EDGES on the
+// MFMA rows (tools/probes/split_probe.hip), so D[edge][channel] puts a lane's 4 registers on 4 edges of one channel:
+// max over K = 16 is 2 in-lane max + a reduce-scatter over the 4 lane rows (v_permlane32_swap / v_permlane16_swap):
+// 28 VALU per point instead of 160.  Its accumulators are initialised with Q[j] alone (dword gathers, 64 B per 16 lanes);
+// P[i] is added once per channel after the max.  VALU per point: ~180 (edgeconv3_kernel<NS=2>: ~450).
+struct PfPairN { h8 h, l; };
+__device__ __forceinline__ unsigned pf_pk_f16(float a, float b) {
+    return __builtin_bit_cast(unsigned, (h2){(_Float16)a, (_Float16)b});          // v_cvt_pk_f16_f32 (RNE)
+}
+__device__ __forceinline__ PfPairN pf_pairn(f4 b0, f4 b1) {
+    const unsigned h0 = pf_pk_f16(b0.x, b0.y), h1 = pf_pk_f16(b0.z, b0.w), h2_ = pf_pk_f16(b1.x, b1.y), h3 = pf_pk_f16(b1.z, b1.w);
+    unsigned l0, l1, l2, l3;
+    // lo = fp16(x - hi) as fma(hi, -1, x); the trailing s_nop covers VALU write -> MFMA operand read (hipcc pads nothing
+    // for registers written inside an asm statement)
+    asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(h0), "v"(h1), "v"(h2_), "v"(h3), "v"(b0.x), "v"(b0.y), "v"(b0.z), "v"(b0.w), "v"(b1.x), "v"(b1.y), "v"(b1.z), "v"(b1.w));
+    PfPairN p;
+    p.h = __builtin_bit_cast(h8, (u4){h0, h1, h2_, h3});
+    p.l = __builtin_bit_cast(h8, (u4){l0, l1, l2, l3});
+    return p;
+}
+
+// reduce-scatter max steps: (a, b) -> lanes 0..31 get max over both halves of a, lanes 32..63 of b;  rows: the same
+// between odd and even 16-lane rows.  Inline asm because the builtin's two results are mis-paired by hipcc 7.2 once they
+// are bit-cast to float; the leading s_nop is the VALU write -> permlane read hazard.
+__device__ __forceinline__ float pf_rsmax32(float a, float b) {
+    unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
+}
+__device__ __forceinline__ float pf_rsmax16(float a, float b) {
+    unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
+}
+
+// acc[p][o] += W[o][cp] feat[p][cp] over CP block pairs, three fp16 MFMAs per pair into the one accumulator (small terms
+// first).  SWAP = false: D[channel][edge] (weights are the A operand);  SWAP = true: D[edge][channel].
+template <bool SWAP, int OB, int CP, int WCP, int D = 2, class WS, int P, int NIN>
+__device__ __forceinline__ void ec_mmn(const WS& ws, int frag0, const PfPairN (&feat)[P][NIN], f4 (&acc)[P][OB]) {
+    constexpr int NFRAG = OB * CP;
+    constexpr int DD = D < NFRAG ? D : NFRAG;
+    h8 wb[DD][2];
+#pragma unroll
+    for (int i = 0; i < DD; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wb[i][s] = ws.load(frag0 + (i / CP) * WCP + (i % CP), s);
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) {
+        const int ob = i / CP, cp = i % CP;
+        const h8 wh = wb[i % DD][0], wl = wb[i % DD][1];
+        if (i + DD < NFRAG) {
+            const int f = frag0 + ((i + DD) / CP) * WCP + ((i + DD) % CP);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) wb[i % DD][s] = ws.load(f, s);
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            f4 x = acc[p][ob];
+            if constexpr (SWAP) {
+                x = pf_mfma_f16(feat[p][cp].l, wh, x);
+                x = pf_mfma_f16(feat[p][cp].h, wl, x);
+                x = pf_mfma_f16(feat[p][cp].h, wh, x);
+            } else {
+                x = pf_mfma_f16(wh, feat[p][cp].l, x);
+                x = pf_mfma_f16(wl, feat[p][cp].h, x);
+                x = pf_mfma_f16(wh, feat[p][cp].h, x);
+            }
+            acc[p][ob] = x;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+constexpr float EC4_OUT_INV = 1.f / 256.f;       // conv_out accumulators hold 4^4 y (packing.ec4_scales)
+
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
+    constexpr int NCONV = 4, G = 32, S = 256, OBO = 8, OCH = 2, ODIM = 128;
+    constexpr int NWF = 2 * (NCONV * (NCONV - 1) / 2) + OBO * NCONV;      // 44 (ob, pair) fragments, 2 KiB each
+    constexpr int ROWB = 2 * S * 4;                                       // bytes per point of the P|Q table
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    __shared__ u4 wlds[NWF * 2 * 64];
+    for (int i = threadIdx.x; i < NWF * 2 * 64; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
+    __syncthreads();
+    const PfW2Lds ws{wlds, lane};
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pq), 0, 0x7fffffff, 0x00020000);
+    const int blkq = ((q & 1) << 1) | (q >> 1);                           // block a lane row ends up with (reduce-scatter)
+
+    for (int v = blockIdx.x; v < 8 * a.chunk; v += gridDim.x) {
+        const int tile = pf_xcd_tile(v, a.chunk);
+        if (tile >= a.ntiles) continue;
+        const int pt0 = (tile * NW + wave) * P;
+        int gP[P];                     // wave-uniform byte offset of point i's row
+        int vQ[P];                     // byte offset of Q[j_col] + this lane's 4 channels (growth layers, edges on columns)
+        int vO[P][4];                  // byte offset of Q_out[j_(4q+r)] + channel `col` (conv_out, edges on rows)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int g = pt0 + p;
+            g = g < a.T ? g : a.T - 1;
+            g = __builtin_amdgcn_readfirstlane(g);
+            const int bN = (g / a.N) * a.N;
+            gP[p] = g * ROWB;
+            const int jc = a.idx[(size_t)g * 16 + col];
+            const int4 j4 = *reinterpret_cast<const int4*>(a.idx + (size_t)g * 16 + 4 * q);
+            vQ[p] = (bN + jc) * ROWB + (S + 4 * q) * 4;
+            vO[p][0] = (bN + j4.x) * ROWB + (S + G * NCONV + col) * 4;
+            vO[p][1] = (bN + j4.y) * ROWB + (S + G * NCONV + col) * 4;
+            vO[p][2] = (bN + j4.z) * ROWB + (S + G * NCONV + col) * 4;
+            vO[p][3] = (bN + j4.w) * ROWB + (S + G * NCONV + col) * 4;
+        }
+        // growth layer t: P_t[i] + Q_t[j] for this lane's 4 channels of both 16-channel blocks
+        auto load_g = [&](int t, f4 (&dst)[P][2]) {
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int off = (G * t + 16 * ob) * 4;
+                    const f4 pv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * q, gP[p] + off, 0));
+                    const f4 qv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vQ[p], off, 0));
+                    dst[p][ob] = pv + qv;
+                }
+        };
+        // conv_out chunk: Q_out[j_(4q+r)][16 ob + col], r = 0..3 -> the four accumulator registers
+        auto load_o = [&](int ob0, f4 (&dst)[P][2]) {
+#pragma unroll
+            for (int o = 0; o < OCH; ++o)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[p][o][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vO[p][r], (ob0 + o) * 64, 0));
+        };
+        f4 ini[2][P][2];
+        load_g(0, ini[0]);
+        load_g(1, ini[1]);
+        PfPairN feat[P][NCONV];
+#pragma unroll
+        for (int p = 0; p < P; ++p) feat[p][0] = pf_pairn(pf_lrelu(ini[0][p][0], 0.05f), pf_lrelu(ini[0][p][1], 0.05f));
+        pf_static_for<1, NCONV>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t + 1 < NCONV) load_g(t + 1, ini[(t + 1) & 1]); else load_o(0, ini[(t + 1) & 1]);
+            f4 acc[P][2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p][ob] = ini[t & 1][p][ob];
+            ec_mmn<false, 2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, acc);
+#pragma unroll
+            for (int p = 0; p < P; ++p) feat[p][t] = pf_pairn(pf_lrelu(acc[p][0], 0.05f), pf_lrelu(acc[p][1], 0.05f));
+        });
+        constexpr int FO = 2 * (NCONV * (NCONV - 1) / 2);
+        float m[P][OBO];
+        pf_static_for<0, OBO / OCH>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int ob0 = c * OCH;
+            constexpr int st = NCONV + c;
+            if constexpr (c + 1 < OBO / OCH) load_o(ob0 + OCH, ini[(st + 1) & 1]);
+            f4 acc[P][OCH];
+#pragma unroll
+            for (int o = 0; o < OCH; ++o)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p][o] = ini[st & 1][p][o];
+            ec_mmn<true, OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, acc);
+#pragma unroll
+            for (int o = 0; o < OCH; ++o)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    m[p][ob0 + o] = fmaxf(fmaxf(acc[p][o].x, acc[p][o].y), fmaxf(acc[p][o].z, acc[p][o].w));
+        });
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            // lane row q now holds block blkq (o0) / 4 + blkq (o1), channel `col` of it
+            const float o0 = pf_rsmax16(pf_rsmax32(m[p][0], m[p][1]), pf_rsmax32(m[p][2], m[p][3]));
+            const float o1 = pf_rsmax16(pf_rsmax32(m[p][4], m[p][5]), pf_rsmax32(m[p][6], m[p][7]));
+            const int ch = 16 * blkq + col;
+            const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ch * 4, gP[p] + G * NCONV * 4, 0));
+            const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ch * 4, gP[p] + (G * NCONV + 64) * 4, 0));
+            if (pt0 + p < a.T) {
+                float* o = a.out + (size_t)(gP[p] / ROWB) * ODIM + ch;
+                o[0] = fmaf(o0, EC4_OUT_INV, p0);
+                o[64] = fmaf(o1, EC4_OUT_INV, p1);
+            }
+        }
+    }
+}
+
+template <int P, int NW>
+int launch4(const EcArgs& a0, hipStream_t s) {
+    EcArgs a = a0;
+    a.ntiles = (a.T + NW * P - 1) / (NW * P);
+    a.chunk = (a.ntiles + 7) / 8;
+    int grid = 8 * a.chunk;
+    if (grid > 256) grid = 256;                           // 88 KiB of LDS: one persistent workgroup per CU
+    hipLaunchKernelGGL((edgeconv4_kernel<P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    return pf_last_launch_status();
+}
+
 // ---- split-fp16 variant of the narrow units 0 / 1 (one 16-channel block per growth layer, four layers) ----
 // Two growth layers share one 32-channel MFMA step (a block pair); an odd layer count pairs with a zero block.
 // C3 (unit 0): the per-edge pre-activations of ALL S rows are one MFMA step against the folded edge table
@@ -522,6 +737,29 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
 #endif
                 default: return PF_ERR_UNSUPPORTED;
             }
+        case 7:                                   // units 2..5, split-fp16 natural-scale (packing: ec4_w; needs the SCALED P|Q table)
+            {
+                // the kernel addresses the P|Q table with 32-bit byte offsets: whole batch items per launch, < 2 GiB of table
+                const long long maxT = 0x7fffffffll / 2048;
+                if (N > maxT) return PF_ERR_UNSUPPORTED;
+                const int Bc = (int)(maxT / N);
+                for (int b0 = 0; b0 < B; b0 += Bc) {
+                    const int nb = B - b0 < Bc ? B - b0 : Bc;
+                    EcArgs c = a;
+                    c.pq = pq_or_xyz + (size_t)b0 * N * 512; c.idx = idx + (size_t)b0 * N * 16; c.out = out + (size_t)b0 * N * 128;
+                    c.T = nb * N;
+                    int rc;
+                    switch (variant) {
+                        case 0: rc = launch4<1, 16>(c, s); break;
+                        case 1: rc = launch4<2, 8>(c, s); break;
+                        case 2: rc = launch4<1, 8>(c, s); break;
+                        case 3: rc = launch4<2, 4>(c, s); break;
+                        default: return PF_ERR_UNSUPPORTED;
+                    }
+                    if (rc != PF_OK) return rc;
+                }
+                return PF_OK;
+            }
         case 5:                                   // unit 0, split-fp16 (packing: ec1h_w[0]; edge table inside wfrag)
             a.xyz = pq_or_xyz;
             return launch1h_v<32, true>(a, s, variant);
@@ -536,7 +774,7 @@ extern "C" int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, co
                            float* out, int B, int N, void* stream) {
     // shipped variants (tools/tune_edgeconv.py, MI355X): unit 0 -> (P=2, NW=8); unit 1 -> (1, 8);
     // units 2..5 -> (1, 16): one point per wave, 16 waves share the 88 KiB of LDS-resident weights.
-    static const int best[7] = {0, 2, 3, 0, 2, 0, 2};
-    if (cfg < 0 || cfg > 6) return PF_ERR_UNSUPPORTED;
+    static const int best[8] = {0, 2, 3, 0, 2, 0, 2, 0};
+    if (cfg < 0 || cfg > 7) return PF_ERR_UNSUPPORTED;
     return pf_edgeconv_tuned(cfg, best[cfg], pq_or_xyz, tab, idx, wfrag, out, B, N, stream);
 }

@@ -26,7 +26,8 @@ from .packing import COND_CHANNELS, FEAT_CHANNELS, GROWTH, NUM_BLOCKS, fold_stat
 
 _EC_CFG = [0, 1, 2, 2, 2, 2]
 _CHECK_FINITE = os.environ.get("PF_CHECK_FINITE", "0") == "1"      # debug aid: verify every eval forward is finite (syncs)
-_EC_SPLIT = {"bf16x3": (3, "ec3_w"), "f16x2": (4, "ec2h_w")}     # PF_EC_MODE -> (pf_edgeconv cfg, weight image)
+_EC_SPLIT = {"bf16x3": (3, "ec3_w"), "f16x2": (4, "ec2h_w"), "f16n": (7, "ec4_w")}   # PF_EC_MODE -> (pf_edgeconv cfg, weight image)
+_EC_VARIANT = {"bf16x3": "0", "f16x2": "2", "f16n": "0"}        # shipped launch shapes (tools/tune_edgeconv.py)
 
 
 # ----------------------------------------------------------------------------------------
@@ -128,11 +129,21 @@ class CondList(list):
 # HIP engine
 # ----------------------------------------------------------------------------------------
 class _Engine:
-    def __init__(self, sd, device: torch.device, upratio: int):
+    def __init__(self, sd, device: torch.device, upratio: int, ec_mode: Optional[str] = None):
         self.lib = _lib.load()
         self.device = device
         self.R = upratio
-        pk = pack_plan(fold_state_dict(sd, upratio))
+        # EdgeConv arithmetic of the 128-channel units (PF_EC_MODE), all within the same 1e-5 parity bar:
+        #   "f16n" (default)   split-fp16 with a natural-scale low half, one accumulator, conv_out with swapped operands
+        #                      (edgeconv4_kernel); needs |4^t x_t| < 65504 for growth layer t (|activation| < 1023)
+        #   "f16x2"            split-fp16 with a 2^11-scaled low half and a cross accumulator (edgeconv3_kernel<NS=2>)
+        #   "bf16x3"           3-term split-bf16 products, six bf16 MFMAs per step, fp32 exponent range
+        #   "f32"              v_mfma_f32_16x16x4_f32, bit-exact fp32 fma chain
+        # Out-of-range activations give inf/NaN, never a silently wrong number (PF_CHECK_FINITE=1 turns it into an error).
+        self.ec_mode = ec_mode or os.environ.get("PF_EC_MODE", "f16n")
+        if self.ec_mode not in ("f16n", "f16x2", "bf16x3", "f32"):
+            raise ValueError(f"unknown EdgeConv arithmetic mode {self.ec_mode!r}")
+        pk = pack_plan(fold_state_dict(sd, upratio), self.ec_mode)
         self.blob = torch.from_numpy(pk["blob"]).to(device)
         self.base = self.blob.data_ptr()
         self.ec_tab0 = pk["ec_tab0"]
@@ -140,14 +151,9 @@ class _Engine:
         self.ec3_w = pk["ec3_w"]
         self.ec2h_w = pk["ec2h_w"]
         self.ec1h_w = pk["ec1h_w"]
-        # EdgeConv arithmetic of the 128-channel units (PF_EC_MODE), all within the same 1e-5 parity bar:
-        #   "f16x2" (default)  2-term split-fp16 products, three fp16 MFMAs per 32-channel step (8e-7 from the exact
-        #                      kernel); needs |activation| < 65504 - beyond that the output is inf/NaN, never silently wrong
-        #   "bf16x3"           3-term split-bf16 products, six bf16 MFMAs per step (1.1e-6), fp32 exponent range
-        #   "f32"              v_mfma_f32_16x16x4_f32, bit-exact fp32 fma chain
-        self.ec_mode = os.environ.get("PF_EC_MODE", "f16x2")
-        # launch shape of edgeconv3_kernel (tuning knob; tools/tune_edgeconv.py): (P=1, NW=16) for f16x2
-        self.ec3_variant = int(os.environ.get("PF_EC3_VARIANT", "2" if self.ec_mode == "f16x2" else "0"))
+        self.ec4_w = pk["ec4_w"]
+        # launch shape of the split kernels (tuning knob; tools/tune_edgeconv.py)
+        self.ec3_variant = int(os.environ.get("PF_EC3_VARIANT", _EC_VARIANT.get(self.ec_mode, "0")))
         self.post = [_lib.offsets(o) for o in pk["post"]]
         self.flow = pk["flow"]
         self.interp_off = _lib.offsets(pk["interp"])
@@ -160,7 +166,7 @@ class _Engine:
         """Fused EdgeConv unit u -> h [T, odim] in the arithmetic PF_EC_MODE selects (pf_edgeconv cfg table:
         include/puflow_hip.h)."""
         lib = self.lib
-        if self.ec_mode == "f16x2" and u < 2:               # narrow units, edge table of unit 0 rides in the image
+        if self.ec_mode in ("f16x2", "f16n") and u < 2:     # narrow units, edge table of unit 0 rides in the image
             rc = lib.pf_edgeconv(5 + u, src, None, idx16.data_ptr(), self._p(self.ec1h_w[u]), h.data_ptr(), B, N, s)
         elif u >= 2 and self.ec_mode in _EC_SPLIT:
             cfg, wname = _EC_SPLIT[self.ec_mode]
@@ -284,6 +290,7 @@ class PointInterpFlow(nn.Module):
         self.flow_blocks = nn.ModuleList(
             [_FlowBlockParams(pc_channel, 64, COND_CHANNELS[i], i % 2 == 0) for i in range(NUM_BLOCKS)])
         self._engine_cache: Optional[_Engine] = None
+        self.ec_mode: Optional[str] = None       # EdgeConv arithmetic of the 128-channel units; None = $PF_EC_MODE or "f16n"
 
     # ---- plan cache ---------------------------------------------------------------------
     def invalidate_plan(self) -> None:
@@ -304,10 +311,10 @@ class PointInterpFlow(nn.Module):
     def _engine(self, upratio: int) -> _Engine:
         e = self._engine_cache
         dev = self.flow_blocks[0].actnorm.logs.device
-        if e is None or e.R != upratio or e.device != dev:
+        if e is None or e.R != upratio or e.device != dev or (self.ec_mode is not None and e.ec_mode != self.ec_mode):
             if dev.type != "cuda":
                 raise _lib.PuflowHipError("PointInterpFlow runs on the GPU only: move the module with .to('cuda')")
-            e = _Engine(self.state_dict(), dev, upratio)
+            e = _Engine(self.state_dict(), dev, upratio, self.ec_mode)
             self._engine_cache = e
         return e
 

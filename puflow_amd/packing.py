@@ -237,6 +237,60 @@ def frag_pack_f16x2(W: np.ndarray) -> np.ndarray:
     return res.reshape(-1).view(np.float32)
 
 
+def frag_pack_f16n(W: np.ndarray) -> np.ndarray:
+    """[OUT, IN] fp32 -> split-fp16 fragments with a NATURAL-scale low half, lo = fp16(W - hi) (subnormals kept), same
+    image layout as frag_pack_f16x2 ([OB][CP][hi / lo][64 lanes][8 fp16]).  For csrc/edgeconv.hip edgeconv4_kernel, where
+    all three product terms share one accumulator; the caller scales W by exact powers of two (ec4_scales) so that the
+    2^-25 absolute floor of a subnormal lo sits far below fp32 rounding."""
+    out, inn = W.shape
+    OB, CP = (out + 15) // 16, (inn + 31) // 32
+    Wp = np.zeros((OB * 16, CP * 32), dtype=np.float32)
+    Wp[:out, :inn] = W
+    if np.abs(Wp).max(initial=0.0) >= 65504.0:
+        raise ValueError("scaled weight magnitude exceeds the fp16 range of the f16n path; use PF_EC_MODE=bf16x3")
+    hi = Wp.astype(np.float16)
+    lo = (Wp - hi.astype(np.float32)).astype(np.float32).astype(np.float16)
+    lanes = np.arange(64)
+    row, q = lanes & 15, lanes >> 4
+    j = np.arange(8)
+    ch = np.where(j[None, :] < 4, 4 * q[:, None] + j[None, :], 16 + 4 * q[:, None] + (j[None, :] - 4))     # [64,8]
+    res = np.zeros((OB, CP, 2, 64, 8), dtype=np.uint16)
+    for si, part in enumerate((hi, lo)):
+        bits = part.view(np.uint16).reshape(OB, 16, CP, 32)
+        res[:, :, si] = bits[:, row[:, None], :, ch].transpose(2, 3, 0, 1)      # -> [OB,CP,64,8]
+    return res.reshape(-1).view(np.float32)
+
+
+EC4_STEP = 4.0        # activation scale ratio between consecutive growth layers of edgeconv4_kernel (csrc/edgeconv.hip)
+
+
+def ec4_scales(nconv: int = 4, g: int = 32, odim: int = 128):
+    """Power-of-two scale plan of edgeconv4_kernel for one 128-channel unit.
+    Feature block u is stored as a_u x_u with a_u = 4^u, so layer t's accumulators hold 4^t v_t and conv_out's 4^nconv y.
+    Returns (row_scale_P [S], row_scale_Q [S], a [nconv + 1]): multipliers of the rows of the P|Q table (the P rows of
+    conv_out stay unscaled: P_out is added after the max-pool, the kernel multiplies the pooled value by 4^-nconv)."""
+    a = EC4_STEP ** np.arange(nconv + 1)
+    S = g * nconv + odim
+    rp = np.ones(S); rq = np.ones(S)
+    for t in range(nconv):
+        rp[g * t:g * (t + 1)] = a[t]; rq[g * t:g * (t + 1)] = a[t]
+    rq[g * nconv:] = a[nconv]
+    return rp.astype(np.float32), rq.astype(np.float32), a.astype(np.float32)
+
+
+def ec4_weights(u: Dict[str, np.ndarray], nconv: int = 4, g: int = 32) -> np.ndarray:
+    """Growth matrices G1..G_nconv of a folded 128-channel unit in the f16n image: columns of feature block c of layer t
+    scaled by a_t / a_c (exact), then split hi / natural lo."""
+    _, _, a = ec4_scales(nconv, g, u[f"G{nconv}"].shape[0])
+    parts = []
+    for t in range(1, nconv + 1):
+        Gt = u[f"G{t}"].astype(np.float64).copy()
+        for c in range(t):
+            Gt[:, g * c:g * (c + 1)] *= a[t] / a[c]
+        parts.append(frag_pack_f16n(Gt.astype(np.float32)))
+    return np.concatenate(parts)
+
+
 def frag_unpack_f16x2(F: np.ndarray, out: int, inn: int) -> np.ndarray:
     """Inverse of frag_pack_f16x2 (tests): float64 hi + lo' / 2^11 of the [out, inn] matrix."""
     OB, CP = (out + 15) // 16, (inn + 31) // 32
@@ -338,8 +392,10 @@ def pack_flow_record(f: Dict[str, object]) -> np.ndarray:
     return rec
 
 
-def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
-    """-> {'blob': fp32 1-D array, 'ec_tab0', 'ec_w'[6], 'post'[6][12], 'flow', 'interp'[13], 'ld_const'}."""
+def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, object]:
+    """-> {'blob': fp32 1-D array, 'ec_tab0', 'ec_w'[6], 'post'[6][12], 'flow', 'interp'[13], 'ld_const'}.
+    ec_mode "f16n": the P|Q rows that feed the 128-channel units are scaled for edgeconv4_kernel (ec4_scales); the
+    other EdgeConv back-ends ("f16x2", "bf16x3", "f32") read an unscaled table."""
     B = _Blob()
     out: Dict[str, object] = {}
     units = plan["units"]
@@ -359,6 +415,8 @@ def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
     out["ec1h_w"] = ec1h + [None] * (NUM_BLOCKS - 2)
     out["ec3_w"] = [None, None] + [B.add(np.concatenate([frag_pack_bf16x3(units[i][f"G{t}"]) for t in range(1, 5)]))
                                    for i in range(2, NUM_BLOCKS)]
+    out["ec4_w"] = [None, None] + [B.add(ec4_weights(units[i])) for i in range(2, NUM_BLOCKS)]
+    out["ec_mode"] = ec_mode
     post = []
     for i in range(NUM_BLOCKS):
         m, f = plan["merges"][i], plan["flows"][i]
@@ -379,8 +437,14 @@ def pack_plan(plan: Dict[str, object]) -> Dict[str, object]:
         }
         if i + 1 < NUM_BLOCKS:
             nu = units[i + 1]
-            offs["PQ"] = B.add(frag_pack_f16x2(np.concatenate([nu["PA"], nu["QB"]], axis=0)))
-            offs["bPQ"] = B.add(np.concatenate([nu["pb"], np.zeros_like(nu["pb"])]))
+            Wpq = np.concatenate([nu["PA"], nu["QB"]], axis=0)
+            bpq = np.concatenate([nu["pb"], np.zeros_like(nu["pb"])])
+            if ec_mode == "f16n" and i + 1 >= 2:          # rows scaled by exact powers of two (edgeconv4_kernel)
+                rp, rq, _ = ec4_scales()
+                rs = np.concatenate([rp, rq])
+                Wpq, bpq = Wpq * rs[:, None], bpq * rs
+            offs["PQ"] = B.add(frag_pack_f16x2(Wpq))
+            offs["bPQ"] = B.add(bpq)
         else:
             offs["PQ"], offs["bPQ"] = 0, 0
         post.append([offs[k] for k in POST_SLOTS])

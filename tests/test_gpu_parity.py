@@ -140,20 +140,21 @@ def test_forward_matches_reference_golden(lib, golden_dir, name):
 
 
 def test_edgeconv_arithmetic_modes(lib):
-    """All EdgeConv arithmetic modes of the 128-channel units meet the parity bar: split-fp16 (default), split-bf16
-    and the bit-exact f32 MFMA kernel; they agree with each other to fp32 rounding."""
+    """All EdgeConv arithmetic modes of the 128-channel units meet the parity bar: split-fp16 with a natural-scale low
+    half (default), split-fp16 with a scaled low half, split-bf16 and the bit-exact f32 MFMA kernel; they agree with each
+    other to fp32 rounding."""
     sd = synth_state_dict(12)
     xyz = synth_patches(2, 512, seed=13)
     ref = O.forward(sd, xyz, 4, stages=True)
     net = _net(sd)
     outs = {}
-    for mode in ("f16x2", "bf16x3", "f32"):
-        eng = net._engine(4)
-        eng.ec_mode, eng.ec3_variant = mode, 0
+    for mode in ("f16n", "f16x2", "bf16x3", "f32"):
+        net.ec_mode = mode                                   # re-packs the plan (the P|Q row scales depend on the mode)
+        assert net._engine(4).ec_mode == mode
         st = net.forward_stages(xyz.to(DEV), 4)
         _check_stages(st, ref)
         outs[mode] = st
-    for mode in ("f16x2", "bf16x3"):
+    for mode in ("f16n", "f16x2", "bf16x3"):
         assert (outs["f32"]["x"] - outs[mode]["x"]).abs().max() < 5e-6
         assert (outs["f32"]["cs"][5] - outs[mode]["cs"][5]).abs().max() < 5e-6
 
@@ -169,9 +170,9 @@ def test_trained_style_dynamic_range(lib, seed):
     ref = O.forward(sd, xyz, 4, stages=True)
     assert max(h.abs().max() for h in ref["hs"]) > 100          # the regime this test is about
     net = _net(sd)
-    for mode in ("f16x2", "bf16x3", "f32"):
-        eng = net._engine(4)
-        eng.ec_mode, eng.ec3_variant = mode, 0
+    for mode in ("f16n", "f16x2", "bf16x3", "f32"):
+        net.ec_mode = mode
+        assert net._engine(4).ec_mode == mode
         st = net.forward_stages(xyz.to(DEV), 4)
         assert torch.equal(st["idx16"].cpu().long(), ref["idx16"])
         assert (st["x"].cpu() - ref["x"]).abs().max() < 1e-5
