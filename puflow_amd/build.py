@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # No reassociation is enabled; the exact-order kernels (kNN, Chamfer, EMD, FPS, training ops) keep default semantics.
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs; the AGPR form hipcc picks under pressure costs one
 # v_accvgpr_read per accumulator register before any VALU use (every layer here) and halves the occupancy.
-EXTRA_FLAGS = {s: ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] for s in ("edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip", "cnf.hip")}
+EXTRA_FLAGS = {s: ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=" + os.environ.get("PF_MFMA_VGPR_FORM", "1")] for s in ("edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip", "cnf.hip")}
 
 
 def _stale(target: str, deps) -> bool:

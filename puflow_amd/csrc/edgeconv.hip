@@ -364,21 +364,30 @@ __device__ __forceinline__ float pf_rsmax16(float a, float b) {
 
 // acc[p][o] += W[o][cp] feat[p][cp] over CP block pairs, three fp16 MFMAs per pair into the one accumulator (small terms
 // first).  SWAP = false: D[channel][edge] (weights are the A operand);  SWAP = true: D[edge][channel].
-template <bool SWAP, int OB, int CP, int WCP, int D = 2, class WS, int P, int NIN>
+#ifndef PF_EC4_DEPTH
+#define PF_EC4_DEPTH 2
+#endif
+#ifndef PF_EC4_CPMAJOR
+#define PF_EC4_CPMAJOR 0
+#endif
+template <bool SWAP, int OB, int CP, int WCP, int D = PF_EC4_DEPTH, class WS, int P, int NIN>
 __device__ __forceinline__ void ec_mmn(const WS& ws, int frag0, const PfPairN (&feat)[P][NIN], f4 (&acc)[P][OB]) {
     constexpr int NFRAG = OB * CP;
     constexpr int DD = D < NFRAG ? D : NFRAG;
+    // fragment walk: ob-major (one accumulator's whole chain, then the next) or cp-major (accumulators alternate)
+    auto OBI = [](int i) { return PF_EC4_CPMAJOR ? i % OB : i / CP; };
+    auto CPI = [](int i) { return PF_EC4_CPMAJOR ? i / OB : i % CP; };
     h8 wb[DD][2];
 #pragma unroll
     for (int i = 0; i < DD; ++i)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) wb[i][s] = ws.load(frag0 + (i / CP) * WCP + (i % CP), s);
+        for (int s = 0; s < 2; ++s) wb[i][s] = ws.load(frag0 + OBI(i) * WCP + CPI(i), s);
 #pragma unroll
     for (int i = 0; i < NFRAG; ++i) {
-        const int ob = i / CP, cp = i % CP;
+        const int ob = OBI(i), cp = CPI(i);
         const h8 wh = wb[i % DD][0], wl = wb[i % DD][1];
         if (i + DD < NFRAG) {
-            const int f = frag0 + ((i + DD) / CP) * WCP + ((i + DD) % CP);
+            const int f = frag0 + OBI(i + DD) * WCP + CPI(i + DD);
 #pragma unroll
             for (int s = 0; s < 2; ++s) wb[i % DD][s] = ws.load(f, s);
         }
@@ -396,13 +405,15 @@ __device__ __forceinline__ void ec_mmn(const WS& ws, int frag0, const PfPairN (&
             }
             acc[p][ob] = x;
         }
+#ifndef PF_EC4_NOSB
         __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 
 constexpr float EC4_OUT_INV = 1.f / 256.f;       // conv_out accumulators hold 4^4 y (packing.ec4_scales)
 
-template <int P, int NW>
+template <int P, int NW, int DBG = 0>      // DBG bit mask (-DPF_TUNING_VARIANTS timing builds only; wrong results): 1 no gathers, 2 no MFMAs, 4 no LDS weight reads
 __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
     constexpr int NCONV = 4, G = 32, S = 256, OBO = 8, OCH = 2, ODIM = 128;
     constexpr int NWF = 2 * (NCONV * (NCONV - 1) / 2) + OBO * NCONV;      // 44 (ob, pair) fragments, 2 KiB each
@@ -410,34 +421,58 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
     __shared__ u4 wlds[NWF * 2 * 64];
+    // P[i] (S floats, the same for all 16 edges of a point) is read ONCE per point as one 1-KiB wave load and staged in a
+    // per-wave LDS slot; the per-layer pieces come back as broadcast ds_reads.  Loading them per layer straight into the
+    // (edge, 4-channel) lane layout cost as many texture-addresser cycles as the Q gathers themselves (16 lanes fetching
+    // the same 16 bytes still take a full quad-lane slot each): 392 -> 272 TA cycles per point.
+    __shared__ f4 plds[NW * P][64];
     for (int i = threadIdx.x; i < NWF * 2 * 64; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
     __syncthreads();
-    const PfW2Lds ws{wlds, lane};
+    const PfW2Lds ws_lds{wlds, lane};
+    const auto ws = [&] { if constexpr ((DBG & 4) != 0) return EcWConst{lane}; else return ws_lds; }();
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pq), 0, 0x7fffffff, 0x00020000);
     const int blkq = ((q & 1) << 1) | (q >> 1);                           // block a lane row ends up with (reduce-scatter)
 
-    for (int v = blockIdx.x; v < 8 * a.chunk; v += gridDim.x) {
-        const int tile = pf_xcd_tile(v, a.chunk);
-        if (tile >= a.ntiles) continue;
-        const int pt0 = (tile * NW + wave) * P;
-        int gP[P];                     // wave-uniform byte offset of point i's row
-        int vQ[P];                     // byte offset of Q[j_col] + this lane's 4 channels (growth layers, edges on columns)
-        int vO[P][4];                  // byte offset of Q_out[j_(4q+r)] + channel `col` (conv_out, edges on rows)
+    // the tile walk skips the holes of the XCD-aware order; the NEXT tile's indices and P rows are fetched while the
+    // current tile computes (the idx -> address -> gather chain is otherwise exposed once per point)
+    const int vend = 8 * a.chunk;
+    auto next_valid = [&](int v) { while (v < vend && pf_xcd_tile(v, a.chunk) >= a.ntiles) v += gridDim.x; return v; };
+    struct Pre { int g[P]; int jc[P]; int4 j4[P]; f4 prow[P]; };
+    auto fetch = [&](int v, Pre& n) {
+        const int pt0 = (pf_xcd_tile(v < vend ? v : blockIdx.x, a.chunk) * NW + wave) * P;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             int g = pt0 + p;
             g = g < a.T ? g : a.T - 1;
             g = __builtin_amdgcn_readfirstlane(g);
-            const int bN = (g / a.N) * a.N;
-            gP[p] = g * ROWB;
-            const int jc = a.idx[(size_t)g * 16 + col];
-            const int4 j4 = *reinterpret_cast<const int4*>(a.idx + (size_t)g * 16 + 4 * q);
-            vQ[p] = (bN + jc) * ROWB + (S + 4 * q) * 4;
-            vO[p][0] = (bN + j4.x) * ROWB + (S + G * NCONV + col) * 4;
-            vO[p][1] = (bN + j4.y) * ROWB + (S + G * NCONV + col) * 4;
-            vO[p][2] = (bN + j4.z) * ROWB + (S + G * NCONV + col) * 4;
-            vO[p][3] = (bN + j4.w) * ROWB + (S + G * NCONV + col) * 4;
+            n.g[p] = g;
+            n.jc[p] = a.idx[(size_t)g * 16 + col];
+            n.j4[p] = *reinterpret_cast<const int4*>(a.idx + (size_t)g * 16 + 4 * q);
+            n.prow[p] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, g * ROWB, 0));
         }
+    };
+    int v = next_valid(blockIdx.x);
+    Pre cur;
+    if (v < vend) fetch(v, cur);
+    while (v < vend) {
+        const int pt0 = (pf_xcd_tile(v, a.chunk) * NW + wave) * P;
+        const int vn = next_valid(v + gridDim.x);
+        int vQ[P];                     // byte offset of Q[j_col] + this lane's 4 channels (growth layers, edges on columns)
+        int vO[P][4];                  // byte offset of Q_out[j_(4q+r)] + channel `col` (conv_out, edges on rows)
+        int gout[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int g = cur.g[p];
+            const int bN = (g / a.N) * a.N;
+            gout[p] = g;
+            plds[wave * P + p][lane] = cur.prow[p];
+            vQ[p] = (bN + cur.jc[p]) * ROWB + (S + 4 * q) * 4;
+            vO[p][0] = (bN + cur.j4[p].x) * ROWB + (S + G * NCONV + col) * 4;
+            vO[p][1] = (bN + cur.j4[p].y) * ROWB + (S + G * NCONV + col) * 4;
+            vO[p][2] = (bN + cur.j4[p].z) * ROWB + (S + G * NCONV + col) * 4;
+            vO[p][3] = (bN + cur.j4[p].w) * ROWB + (S + G * NCONV + col) * 4;
+        }
+        fetch(vn, cur);                // next tile (a harmless re-read of the first tile when there is none)
         // growth layer t: P_t[i] + Q_t[j] for this lane's 4 channels of both 16-channel blocks
         auto load_g = [&](int t, f4 (&dst)[P][2]) {
 #pragma unroll
@@ -445,11 +480,11 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int off = (G * t + 16 * ob) * 4;
-                    const f4 pv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * q, gP[p] + off, 0));
-                    const f4 qv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vQ[p], off, 0));
-                    dst[p][ob] = pv + qv;
+                    if constexpr (DBG & 1) { dst[p][ob] = pf_splat((float)(off + vQ[p]) * 1e-9f); continue; }
+                    dst[p][ob] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vQ[p], off, 0));
                 }
         };
+        auto p_g = [&](int p, int t, int ob) -> f4 { return plds[wave * P + p][(G * t + 16 * ob) / 4 + q]; };
         // conv_out chunk: Q_out[j_(4q+r)][16 ob + col], r = 0..3 -> the four accumulator registers
         auto load_o = [&](int ob0, f4 (&dst)[P][2]) {
 #pragma unroll
@@ -457,15 +492,18 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
 #pragma unroll
                 for (int p = 0; p < P; ++p)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (DBG & 1) { dst[p][o][r] = (float)(vO[p][r] + ob0 + o) * 1e-9f; continue; }
                         dst[p][o][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vO[p][r], (ob0 + o) * 64, 0));
+                    }
         };
         f4 ini[2][P][2];
         load_g(0, ini[0]);
         load_g(1, ini[1]);
         PfPairN feat[P][NCONV];
 #pragma unroll
-        for (int p = 0; p < P; ++p) feat[p][0] = pf_pairn(pf_lrelu(ini[0][p][0], 0.05f), pf_lrelu(ini[0][p][1], 0.05f));
+        for (int p = 0; p < P; ++p)
+            feat[p][0] = pf_pairn(pf_lrelu(ini[0][p][0] + p_g(p, 0, 0), 0.05f), pf_lrelu(ini[0][p][1] + p_g(p, 0, 1), 0.05f));
         pf_static_for<1, NCONV>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             if constexpr (t + 1 < NCONV) load_g(t + 1, ini[(t + 1) & 1]); else load_o(0, ini[(t + 1) & 1]);
@@ -473,10 +511,13 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[p][ob] = ini[t & 1][p][ob];
-            ec_mmn<false, 2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, acc);
+                for (int p = 0; p < P; ++p) acc[p][ob] = ini[t & 1][p][ob] + p_g(p, t, ob);
+            if constexpr (!(DBG & 2)) ec_mmn<false, 2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, acc);
 #pragma unroll
-            for (int p = 0; p < P; ++p) feat[p][t] = pf_pairn(pf_lrelu(acc[p][0], 0.05f), pf_lrelu(acc[p][1], 0.05f));
+            for (int p = 0; p < P; ++p) {
+                if constexpr (DBG & 8) { feat[p][t] = feat[p][0]; feat[p][t].h[0] += (_Float16)acc[p][0].x; continue; }
+                feat[p][t] = pf_pairn(pf_lrelu(acc[p][0], 0.05f), pf_lrelu(acc[p][1], 0.05f));
+            }
         });
         constexpr int FO = 2 * (NCONV * (NCONV - 1) / 2);
         float m[P][OBO];
@@ -490,7 +531,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
             for (int o = 0; o < OCH; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][o] = ini[st & 1][p][o];
-            ec_mmn<true, OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, acc);
+            if constexpr (!(DBG & 2)) ec_mmn<true, OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, acc);
 #pragma unroll
             for (int o = 0; o < OCH; ++o)
 #pragma unroll
@@ -503,25 +544,26 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
             const float o0 = pf_rsmax16(pf_rsmax32(m[p][0], m[p][1]), pf_rsmax32(m[p][2], m[p][3]));
             const float o1 = pf_rsmax16(pf_rsmax32(m[p][4], m[p][5]), pf_rsmax32(m[p][6], m[p][7]));
             const int ch = 16 * blkq + col;
-            const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ch * 4, gP[p] + G * NCONV * 4, 0));
-            const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ch * 4, gP[p] + (G * NCONV + 64) * 4, 0));
+            const float* pr = reinterpret_cast<const float*>(plds[wave * P + p]);
+            const float p0 = pr[G * NCONV + ch], p1 = pr[G * NCONV + 64 + ch];
             if (pt0 + p < a.T) {
-                float* o = a.out + (size_t)(gP[p] / ROWB) * ODIM + ch;
+                float* o = a.out + (size_t)gout[p] * ODIM + ch;
                 o[0] = fmaf(o0, EC4_OUT_INV, p0);
                 o[64] = fmaf(o1, EC4_OUT_INV, p1);
             }
         }
+        v = vn;
     }
 }
 
-template <int P, int NW>
+template <int P, int NW, int DBG = 0>
 int launch4(const EcArgs& a0, hipStream_t s) {
     EcArgs a = a0;
     a.ntiles = (a.T + NW * P - 1) / (NW * P);
     a.chunk = (a.ntiles + 7) / 8;
     int grid = 8 * a.chunk;
     if (grid > 256) grid = 256;                           // 88 KiB of LDS: one persistent workgroup per CU
-    hipLaunchKernelGGL((edgeconv4_kernel<P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((edgeconv4_kernel<P, NW, DBG>), dim3(grid), dim3(NW * 64), 0, s, a);
     return pf_last_launch_status();
 }
 
@@ -754,6 +796,15 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
                         case 1: rc = launch4<2, 8>(c, s); break;
                         case 2: rc = launch4<1, 8>(c, s); break;
                         case 3: rc = launch4<2, 4>(c, s); break;
+#ifdef PF_TUNING_VARIANTS                                     // ablation builds only: wrong results
+                        case 8: rc = launch4<1, 16, 1>(c, s); break;      // no gathers
+                        case 9: rc = launch4<1, 16, 2>(c, s); break;      // no MFMAs
+                        case 10: rc = launch4<1, 16, 4>(c, s); break;     // no LDS weight reads
+                        case 11: rc = launch4<1, 16, 5>(c, s); break;     // no gathers, no LDS weight reads
+                        case 12: rc = launch4<1, 16, 3>(c, s); break;     // no gathers, no MFMAs
+                        case 13: rc = launch4<1, 16, 6>(c, s); break;     // no MFMAs, no LDS reads: gathers + VALU only
+                        case 14: rc = launch4<1, 16, 13>(c, s); break;    // no gathers, no LDS reads, no growth epilogues (lrelu + split)
+#endif
                         default: return PF_ERR_UNSUPPORTED;
                     }
                     if (rc != PF_OK) return rc;

@@ -13,12 +13,12 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 #define VFMA(r) "v_fma_f32 %" #r ", %" #r ", %[k1], %[k2]\n\t"
 
-template <int SHAPE, int NV>   // SHAPE 16 or 32; NV VALU per MFMA gap (0..8)
+template <int SHAPE, int NV, int NACC = 4>   // SHAPE 16 or 32; NV VALU per MFMA gap (0..8); NACC accumulators in rotation
 __device__ __forceinline__ void body(h8 a, h8 b, f4 (&c)[4], f16v (&d)[2], float (&v)[8], float k1, float k2, int iters) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            if constexpr (SHAPE == 16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c[m]) : "v"(a), "v"(b));
+            if constexpr (SHAPE == 16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c[m % NACC]) : "v"(a), "v"(b));
             else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d[m & 1]) : "v"(a), "v"(b));
 #pragma unroll
             for (int j = 0; j < NV; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j]) : "v"(k1), "v"(k2));
@@ -27,7 +27,7 @@ __device__ __forceinline__ void body(h8 a, h8 b, f4 (&c)[4], f16v (&d)[2], float
 }
 
 // role: 0 = every wave runs MFMA+NV interleaved; 1 = even-numbered waves-on-SIMD run MFMA only, the others VALU only (4*NV per iter)
-template <int SHAPE, int NV, int ROLE>
+template <int SHAPE, int NV, int ROLE, int NACC = 4>
 __global__ __launch_bounds__(1024) void k(int iters, float* out, long long* cyc, long long* rt) {
     const int wave = threadIdx.x >> 6;
     h8 a, b;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(1024) void k(int iters, float* out, long long* cyc,
     __syncthreads();
     const long long r0 = __builtin_amdgcn_s_memrealtime();
     const long long t0 = __builtin_amdgcn_s_memtime();
-    if constexpr (ROLE == 0) body<SHAPE, NV>(a, b, c, d, v, k1, k2, iters);
+    if constexpr (ROLE == 0) body<SHAPE, NV, NACC>(a, b, c, d, v, k1, k2, iters);
     else {
         // waves are dealt to SIMDs cyclically; waves w and w+4 share a SIMD in an 8-wave workgroup
         if (wave < 4) body<SHAPE, 0>(a, b, c, d, v, k1, k2, iters);
@@ -61,12 +61,12 @@ __global__ __launch_bounds__(1024) void k(int iters, float* out, long long* cyc,
     if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * (blockDim.x >> 6) + wave] = t1 - t0; rt[blockIdx.x * (blockDim.x >> 6) + wave] = r1 - r0; }
 }
 
-template <int SHAPE, int NV, int ROLE>
+template <int SHAPE, int NV, int ROLE, int NACC = 4>
 void run(const char* what, int waves, float* d, long long* dc) {
     const int iters = 4000, grid = 256;
     long long* dr = dc + 256 * 16;
-    k<SHAPE, NV, ROLE><<<grid, waves * 64>>>(100, d, dc, dr);
-    k<SHAPE, NV, ROLE><<<grid, waves * 64>>>(iters, d, dc, dr);
+    k<SHAPE, NV, ROLE, NACC><<<grid, waves * 64>>>(100, d, dc, dr);
+    k<SHAPE, NV, ROLE, NACC><<<grid, waves * 64>>>(iters, d, dc, dr);
     (void)hipDeviceSynchronize();
     std::vector<long long> h(grid * waves), hr(grid * waves);
     (void)hipMemcpy(h.data(), dc, h.size() * 8, hipMemcpyDeviceToHost);
@@ -118,5 +118,12 @@ int main() {
     run<S, 6, 1>("MFMA wave | VALU wave on one SIMD", 8, d, dc);
     SWEEP(16)
     SWEEP(32)
+    // dependent accumulator chains of the 16x16x32 shape (every MFMA takes the previous one's D as C)
+    run<16, 0, 0, 1>("ONE accumulator chain, 1 wave/SIMD", 4, d, dc);
+    run<16, 0, 0, 2>("TWO accumulators alternating, 1 wave/SIMD", 4, d, dc);
+    run<16, 2, 0, 1>("ONE accumulator chain, 1 wave/SIMD", 4, d, dc);
+    run<16, 0, 0, 1>("ONE accumulator chain, 2 waves/SIMD", 8, d, dc);
+    run<16, 0, 0, 1>("ONE accumulator chain, 4 waves/SIMD", 16, d, dc);
+    run<16, 2, 0, 1>("ONE accumulator chain, 4 waves/SIMD", 16, d, dc);
     return 0;
 }

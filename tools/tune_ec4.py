@@ -43,12 +43,24 @@ ex, _, pqx, hx = unit_inputs("f16x2")
 print(f"unit 3 |h|max {float(h32.abs().max()):.2f}   f16n vs f32 max|d| {float((hn - h32).abs().max()):.3e}   "
       f"f16x2 vs f32 max|d| {float((hx - h32).abs().max()):.3e}", flush=True)
 
-cands = [("f16n v0 (P1,NW16)", 7, 0, en, pqn, "ec4_w"), ("f16n v1 (P2,NW8)", 7, 1, en, pqn, "ec4_w"),
-         ("f16n v2 (P1,NW8)", 7, 2, en, pqn, "ec4_w"), ("f16n v3 (P2,NW4)", 7, 3, en, pqn, "ec4_w"),
-         ("f16x2 v2 (P1,NW16) [r1]", 4, 2, ex, pqx, "ec2h_w")]
+cands = [("f16n v0 (P1,NW16)", 7, 0, en, pqn, "ec4_w", lib), ("f16n v1 (P2,NW8)", 7, 1, en, pqn, "ec4_w", lib),
+         ("f16n v2 (P1,NW8)", 7, 2, en, pqn, "ec4_w", lib), ("f16n v3 (P2,NW4)", 7, 3, en, pqn, "ec4_w", lib),
+         ("f16x2 v2 (P1,NW16) [r1]", 4, 2, ex, pqx, "ec2h_w", lib)]
+# side-by-side tuning builds: python tools/tune_ec4.py <tag> ...  loads libpuflow_hip_<tag>.so (puflow_amd.build.build(defines, tag))
+import ctypes
+for tag in sys.argv[1:]:
+    l = ctypes.CDLL(_lib.LIB_PATH.replace(".so", f"_{tag}.so"))
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(l, name); fn.restype, fn.argtypes = res, args
+    if tag == "abl":       # -DPF_TUNING_VARIANTS build: timing-only ablations of the (P1, NW16) shape
+        cands += [(f"[abl] {what}", 7, v, en, pqn, "ec4_w", l) for v, what in
+                  ((0, "full"), (8, "no gathers"), (9, "no MFMAs"), (10, "no LDS weight reads"), (11, "no gathers, no LDS reads"),
+                   (12, "no gathers, no MFMAs"), (13, "no MFMAs, no LDS reads"), (14, "no gathers, LDS reads, growth epilogues"))]
+        continue
+    cands += [(f"[{tag}] f16n v0 (P1,NW16)", 7, 0, en, pqn, "ec4_w", l), (f"[{tag}] f16n v1 (P2,NW8)", 7, 1, en, pqn, "ec4_w", l)]
 times = {c[0]: [] for c in cands}
 for rnd in range(8):
-    for name, cfg, v, e, pq, wname in cands:
+    for name, cfg, v, e, pq, wname, lib in cands:
         out = torch.empty_like(h32)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -59,7 +71,8 @@ for rnd in range(8):
         if rnd > 0:
             times[name].append(a.elapsed_time(b) / 5)
         if rnd == 0:
-            print(f"  {name}: max|d| vs f32 {float((out - h32).abs().max()):.3e}", flush=True)
+            if "[abl]" not in name or "full" in name:
+                print(f"  {name}: max|d| vs f32 {float((out - h32).abs().max()):.3e}", flush=True)
 for name, t in times.items():
     t = sorted(t)
-    print(f"{name:28s} min {t[0]:.4f} ms  med {t[len(t) // 2]:.4f} ms", flush=True)
+    print(f"{name:36s} min {t[0]:.4f} ms  med {t[len(t) // 2]:.4f} ms", flush=True)
