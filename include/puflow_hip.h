@@ -45,7 +45,9 @@ int pf_nn1(const float* p1, const float* p2, int B, int N, int M, float* dist_ou
  * cfg 3 / 4: units 2..5 on the bf16 / fp16 matrix pipe with split operands (wfrag = the bf16x3 / f16x2
  * image of the same weights; fp32-class results, see csrc/pf_mfma.h);
  * cfg 5 / 6: units 0 / 1 on the fp16 matrix pipe (wfrag = f16x2 image; unit 0's edge table rides at its end,
- * input = xyz [B*N,3], tab ignored).
+ * input = xyz [B*N,3], tab ignored);
+ * cfg 7: units 2..5, split-fp16 with a natural-scale low half (wfrag = packing.ec4_weights; the P|Q table must carry
+ * the row scales of packing.ec4_scales; csrc/edgeconv.hip edgeconv4_kernel) - the shipped default.
  * idx [B*N,16] int32 (index inside the batch item); wfrag = fragment-packed growth weights;
  * out [B*N, odim]. */
 int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, const int* idx, const float* wfrag, float* out,
@@ -84,9 +86,9 @@ int pf_logp(const float* z, const float* ld_pt, float ld_const, int B, int N, fl
 
 /* Interpolation module (interpflow.py:85-186), fused: kNN-8 context features -> weights ->
  * softmax_k -> weighted sum of neighbour latents.  idx16 [T,16] (first 8 columns used),
- * u_out [T*R,3] in the row order of g (row = n*R + r).  1 <= R <= 4 (the packed
- * weight blob must have been made for the same R: packing.pack_plan).
- * off[13]: float offsets into w (csrc/interp.hip header, packing.INTERP_SLOTS). */
+ * u_out [T*R,3] in the row order of g (row = n*R + r).  1 <= R <= 32 (r_max of WeightEstimationUnit,
+ * interpflow.py:142; R <= 4 runs the 4-row fast path, larger ratios all 32 rows of the last weight conv).
+ * off[15]: float offsets into w (csrc/interp.hip header, packing.INTERP_SLOTS); the blob does not depend on R. */
 int pf_interp(const float* xyz, const float* z, const int* idx16, const float* w, const long long* off, float* u_out,
               int B, int N, int R, void* stream);
 
@@ -212,9 +214,15 @@ int pf_dist_feature(const float* xyz, const int* idx, int B, int N, int K, float
  * the candidate exchange ring; overwritten either way). */
 int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, int* idx_out, void* stream);
 
+/* Layout of pf_fps's scratch when the cooperative kernel runs (return value 1; 0 = single-workgroup kernel, no ring):
+ * cloud b's ring starts at 64-bit word b * stride_words of `mind`; word `abort_word` of a ring is non-zero after the
+ * launch iff that cloud's workgroups gave up waiting for each other (bounded spin) - its idx_out row is then invalid. */
+int pf_fps_scratch_layout(int N, long long* stride_words, long long* abort_word);
+
 /* K nearest references of every query for large K (patch extraction, K = 256).  Replaces knn_cuda.KNN
- * (patch.py:33,107).  ref [B,N,3], query [B,M,3], K <= N <= 16384 -> idx_out [B,M,K] int32 ordered by
- * (distance, index); dist_out [B,M,K] squared L2 (nullable). */
+ * (patch.py:33,107).  ref [B,N,3], query [B,M,3], K <= N (any N; K <= 8192 when N > 16384: the references are then
+ * streamed through LDS in chunks) -> idx_out [B,M,K] int32 ordered by (distance, index); dist_out [B,M,K] squared L2
+ * (nullable). */
 int pf_knn_large(const float* ref, const float* query, int B, int N, int M, int K, int* idx_out, float* dist_out,
                  void* stream);
 

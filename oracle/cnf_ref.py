@@ -115,6 +115,10 @@ def dopri5(func: Callable[[float, Tensor], Tensor], y0: Tensor, t0: float, t1: f
         err = dt * err
         tol = atol + rtol * torch.maximum(y.abs(), y1.abs())
         ratio = rms(float(((err / tol) ** 2).sum().double()))
+        if not math.isfinite(ratio):                                    # torchdiffeq: NaN propagates / asserts
+            raise FloatingPointError(f"dopri5: non-finite error norm at t = {t:g}")
+        if not (t + dt > t):
+            raise FloatingPointError(f"dopri5: underflow in dt ({dt:g}) at t = {t:g}")
         accept = ratio <= 1.0
         if accept:
             mid = None

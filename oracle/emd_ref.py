@@ -15,6 +15,9 @@ Determinism rules chosen where the reference is racy:
   * GetMax: the reference lets ANY bidder whose increment is within 1e-6 of the maximum win
     (last writer, cu:188-191); here the winner of object o is the bidder with the largest
     increment, largest index among exact ties.
+  * non-finite predictions: when no object has a value above the -1e9 start (a NaN / inf prediction row) the point bids on
+    the object with its own index at the minimum increment eps (the reference would index best_i = -1, cu:133,176-178);
+    the NaN then shows in dist and the loss.
   * value arithmetic: `3.0 - sqrtf(.) - price` is evaluated in double (the literal 3.0 is a
     double in cu:146) and rounded to float once; squared distances are unfused fp32.
 """
@@ -52,6 +55,10 @@ def auction_one(x: np.ndarray, y: np.ndarray, eps: float, iters: int):
         v2 = v.copy()
         v2[np.arange(U.size), best_i] = f32(-1e9)
         better = np.maximum(v2.max(axis=1), f32(-1e9)) if n > 1 else np.full(U.size, f32(-1e9))
+        with np.errstate(invalid="ignore"):
+            none = ~(v > f32(-1e9)).any(axis=1)                      # NaN / inf prediction row: own index, minimum increment
+        best_i = np.where(none, U, best_i)
+        best = np.where(none, f32(0), best); better = np.where(none, f32(0), better)
         inc = ((best - better).astype(f32) + eps).astype(f32)       # cu:175
         # winner per object: largest (inc, i)
         order = np.lexsort((U, inc))                                # ascending by inc then by i

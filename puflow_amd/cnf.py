@@ -35,6 +35,7 @@ from .weights import state_dict_spec
 
 ATOL = RTOL = 1e-5                       # continuous/interpflow.py:28
 SAFETY, IFACTOR, DFACTOR, ORDER = 0.9, 10.0, 0.2, 5
+MAX_NUM_STEPS = 100000                   # step attempts per integration; a bound, never reached by a sane model
 DP_ALPHA = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
 DP_BETA = [
     [1 / 5],
@@ -113,7 +114,7 @@ class _CnfEngine:
         self.lib = _lib.load()
         self.device = device
         self.R = upratio
-        self.base = _Engine(_discrete_shell(sd), device, upratio)
+        self.base = _Engine(_discrete_shell(sd), device)
         self.rec, self.Hc, self.hb, self.T_end = [], [], [], []
         for i in range(NUM_BLOCKS):
             rec, Hc, hb, T_end = pack_cnf_block(sd, i)
@@ -199,6 +200,7 @@ class _CnfEngine:
         f0, f1 = K[0], K[6]
         t = t0
         last = None
+        attempts = 0
         while t1 > t:
             want_mid = t1 <= t + dt                            # this step would cover the end time: emit the mid-point too
             _lib.check(self.lib.pf_cnf_step(y.data_ptr(), f0.data_ptr(), float(t), float(dt), 1 if reverse else 0,
@@ -206,7 +208,17 @@ class _CnfEngine:
                                             f1.data_ptr(), tmp.data_ptr() if want_mid else None, RTOL, ATOL, rows, R,
                                             ws.data_ptr(), self.red.data_ptr(), self._stream()), "pf_cnf_step")
             self.nfe += 6
+            attempts += 1
             ratio = math.sqrt(float(self.red.item()) / n_tot)
+            # torchdiffeq raises here too ('underflow in dt', NaN propagates into dt): without these guards a NaN error
+            # norm makes every comparison False - no step is ever accepted and dt grows tenfold per attempt, forever
+            if not math.isfinite(ratio):
+                raise _lib.PuflowHipError(f"dopri5: non-finite error norm in block {i} at t = {t:g} (NaN / inf in the input, "
+                                          "the weights or the state)")
+            if not (t + dt > t):
+                raise _lib.PuflowHipError(f"dopri5: underflow in dt ({dt:g}) at t = {t:g}, block {i}")
+            if attempts > MAX_NUM_STEPS:
+                raise _lib.PuflowHipError(f"dopri5: more than {MAX_NUM_STEPS} step attempts in block {i}")
             if ratio <= 1.0:
                 self.accepted += 1
                 nxt = t + dt
@@ -306,7 +318,7 @@ class PointInterpFlow(nn.Module):
             ldj = ldj + st[:, 3].view(B, N).sum(1)
         z = p.view(B, N, 3)
         logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + math.log(2 * math.pi)), dim=(1, 2)) - ldj)
-        u = base.interp(xyz, z.contiguous(), idx16)                                   # [B, N*R, 3], row n*R + r
+        u = base.interp(xyz, z.contiguous(), idx16, upratio)                                   # [B, N*R, 3], row n*R + r
         # ---- g
         u = u.reshape(T * upratio, 3)
         for i in reversed(range(NUM_BLOCKS)):

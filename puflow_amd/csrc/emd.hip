@@ -103,6 +103,11 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(EmdArgs a) {
             for (int m = 1; m < 64; m <<= 1)
                 tri_merge(tbest, tbetter, tidx, __shfl_xor(tbest, m), __shfl_xor(tbetter, m), __shfl_xor(tidx, m));
             if (lane == 0) {
+                // a NaN / inf prediction row makes every value NaN or -inf: no `v > tbest` ever fires and the index stays at
+                // its sentinel.  Bid on a valid object (the point's own index) with the minimum increment instead of
+                // indexing out of bounds: the NaN then reaches dist and the loss, where TrainerModule.training_step's NaN
+                // guard (train_pu1k.py:71-73) handles it.  (The reference starts best_i at -1: a one-element underrun.)
+                if ((unsigned)tidx >= (unsigned)n) { tidx = i; tbest = tbetter = 0.f; }
                 const float inc = __fadd_rn(__fsub_rn(tbest, tbetter), a.eps);
                 bid[i] = tidx;
                 bid_inc[i] = inc;

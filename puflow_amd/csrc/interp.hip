@@ -18,7 +18,8 @@
 //   0 dtab [64 x e]        1 d_W3 [64 x 64]     2 d_b3 [64] f32      3 (W0a W6) [128 x 64]    4 reserved
 //   5 ectab [128 x e]      6 ec G1..G7 (16 pair fragments; layer t starts at fragment floor(t/2) * ceil(t/2))
 //   7 (W0b Gout) [128 x 128]   8 w1tab [128 x e] (bracket above)   9 w_W3 [64 x 128]  10 w_b3 [64] f32
-//   11 w_W6 [16 x 64] (R rows replicated per q group)   12 w_b6 [16] f32
+//   11 w_W6 [16 x 64] (rows 0..3 replicated per q group: the R <= 4 fast path)   12 w_b6 [16] f32
+//   13 w_W6 [32 x 64] all r_max = 32 rows (R > 4: WeightEstimationUnit supports up to 32, interpflow.py:142)   14 w_b6 [32] f32
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
@@ -38,12 +39,12 @@ struct InterpArgs {
     const float* z;      // [T,3]
     const int* idx;      // [T,16]  (first 8 used)
     const float* w;
-    long long off[13];
+    long long off[15];
     float* u;            // [T*R,3]  row = n*R + r
-    int T, N, ntiles, R;     // R = upsampling ratio actually written (1..4)
+    int T, N, ntiles, R;     // R = upsampling ratio actually written (1..4; BIG: 5..32)
 };
 
-template <int P, int NW>
+template <int P, int NW, bool BIG = false>     // BIG: upsampling ratios 5..32 (all 32 rows of the last weight conv)
 __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
     constexpr int R = 4;                 // rows computed (W6 is packed with 4 rows per q group); a.R <= 4 are stored
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
     const PfW2Lds wsDT{wl + L_DT * 128, lane}, wsET{wl + L_ET * 128, lane}, wsWT{wl + L_WT * 128, lane},
         wsD3{wl + L_D3 * 128, lane}, wsEC{wl + L_EC * 128, lane};
     const PfW2Buf wsD6(a.w + a.off[3], lane), wsW0(a.w + a.off[7], lane), wsW3(a.w + a.off[9], lane),
-        wsW6(a.w + a.off[11], lane);
+        wsW6(a.w + a.off[BIG ? 13 : 11], lane);
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int pt0 = (tile * NW + wave) * P * 2;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
         }
 
         // ---- rest of the weight unit: 128 -> 64 -> R
-        f4 w3[P][1];
+        f4 w3[P][BIG ? 2 : 1];
         {
             PfPair2 w1p[P][4];
 #pragma unroll
@@ -185,30 +186,58 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
                 w2p[p][1] = pf_pair2(pf_lrelu(w2[p][2], 0.01f), pf_lrelu(w2[p][3], 0.01f));
             }
 #pragma unroll
-            for (int p = 0; p < P; ++p) w3[p][0] = *reinterpret_cast<const f4*>(a.w + a.off[12] + 4 * q);
-            pf_mm2f<1, 2, 2>(wsW6, 0, w2p, 0, w3, 0);
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int ob = 0; ob < (BIG ? 2 : 1); ++ob) w3[p][ob] = pf_bias(a.w + a.off[BIG ? 14 : 12], ob, q);
+            pf_mm2f<(BIG ? 2 : 1), 2, 2>(wsW6, 0, w2p, 0, w3, 0);
         }
 
         // ---- softmax over the 8 neighbours (lanes k = 0..7 of the point), then weighted latent sum
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            float av[R];
+            if constexpr (BIG) {
+                // lane (k, q) owns rows 16 ob + 4 q + r of the weight tensor; every lane sums all three latent channels
+                float zj[3];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float x = w3[p][0][r];
-                float m = x;
-                m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
-                const float ex = expf(x - m);
-                float s = ex;
-                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-                av[r] = ex / s;
-            }
-            const float zj = a.z[(size_t)gj[p] * 3 + (q < 3 ? q : 0)];      // lane q handles latent channel q
+                for (int c = 0; c < 3; ++c) zj[c] = a.z[(size_t)gj[p] * 3 + c];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float s = av[r] * zj;
-                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-                if (ok[p] && k == 0 && q < 3 && r < a.R) a.u[((size_t)gi[p] * a.R + r) * 3 + q] = s;
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * ob + 4 * q + r;
+                        const float x = w3[p][ob][r];
+                        float m = x;
+                        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+                        const float ex = expf(x - m);
+                        float sm = ex;
+                        sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4);
+                        const float av = ex / sm;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            float s = av * zj[c];
+                            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+                            if (ok[p] && k == 0 && row < a.R) a.u[((size_t)gi[p] * a.R + row) * 3 + c] = s;
+                        }
+                    }
+            } else {
+                float av[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float x = w3[p][0][r];
+                    float m = x;
+                    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+                    const float ex = expf(x - m);
+                    float s = ex;
+                    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+                    av[r] = ex / s;
+                }
+                const float zj = a.z[(size_t)gj[p] * 3 + (q < 3 ? q : 0)];      // lane q handles latent channel q
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float s = av[r] * zj;
+                    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+                    if (ok[p] && k == 0 && q < 3 && r < a.R) a.u[((size_t)gi[p] * a.R + r) * 3 + q] = s;
+                }
             }
         }
     }
@@ -220,13 +249,14 @@ extern "C" int pf_interp(const float* xyz, const float* z, const int* idx16, con
                          float* u_out, int B, int N, int R, void* stream) {
     if (!xyz || !z || !idx16 || !w || !off || !u_out) return PF_ERR_NULL;
     if (B <= 0 || N < 8 || (long long)B * N > (1ll << 28)) return PF_ERR_SHAPE;
-    if (R < 1 || R > 4) return PF_ERR_UNSUPPORTED;
+    if (R < 1 || R > 32) return PF_ERR_UNSUPPORTED;          // r_max of WeightEstimationUnit (interpflow.py:142)
     constexpr int P = PF_INTERP_P, NW = PF_INTERP_NW;
     InterpArgs a{};
     a.xyz = xyz; a.z = z; a.idx = idx16; a.w = w; a.u = u_out; a.T = B * N; a.N = N; a.R = R;
-    for (int i = 0; i < 13; ++i) a.off[i] = off[i];
+    for (int i = 0; i < 15; ++i) a.off[i] = off[i];
     a.ntiles = (a.T + NW * P * 2 - 1) / (NW * P * 2);
     const int grid = a.ntiles < 256 ? a.ntiles : 256;         // persistent: 88 KiB of LDS = one workgroup per CU
-    hipLaunchKernelGGL((interp_kernel<P, NW>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, a);
+    if (R <= 4) hipLaunchKernelGGL((interp_kernel<P, NW, false>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((interp_kernel<P, NW, true>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, a);
     return pf_last_launch_status();
 }

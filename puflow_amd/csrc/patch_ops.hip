@@ -72,12 +72,11 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
 // step (agent-scope atomic loads) and reduces them.  The 64-bit word IS the whole message (coordinates are re-read
 // from the read-only input), so relaxed ordering suffices: no L2 write-back / invalidate per step, which is what an
 // acquire / release pair costs at agent scope on this chip.  No read-modify-write atomics, no counters: a slot is
-// "empty" while it is 0;
-// a workgroup clears its slot of step j+2 while it works on step j, which is safe because having read every
-// candidate of step j-1 proves that all workgroups are done reading step j-2.
+// "filled" when it carries the current step's 2-bit tag (the same slot held step j-4's word before): see the kernel.
 // Progress: blocks are dispatched in index order and a cloud's workgroups are contiguous, so the lowest
 // unfinished cloud always has all its workgroups resident; a bounded spin + abort flag guarantees the grid drains
-// even if that assumption were ever violated (the output is then garbage and ring[..] abort word is set).
+// even if that assumption were ever violated: the cloud's abort word is then set and its output is invalid -
+// pf_fps_scratch_layout tells the caller where that word is, puflow_amd.ops.furthest_point_sample checks it and raises.
 #ifndef PF_FPSC_T
 #define PF_FPSC_T 256
 #endif
@@ -142,18 +141,22 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop_kernel(const float* __restric
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
             unsigned long long* slot = ring + (j & 3) * FPSC_GMAX;
+            // word = distance bits << 32 | step tag (2 bits) | valid bit | ~index (29 bits).  The tag (j / 4) & 3 tells a
+            // word of THIS step from the one the same slot held four steps ago, so a consumer can never take a stale
+            // candidate whatever order two relaxed stores to different addresses become visible in (no slot clearing,
+            // no release / acquire); within a step every word carries the same tag, so the integer max is unchanged.
+            const unsigned long long tagv = ((unsigned long long)(((j >> 2) & 3) << 1) | 1ull) << 29;
             if (lane == 0) {
                 const unsigned long long key =
-                    bv < 0.f ? 1ull : (((unsigned long long)__float_as_uint(bv) << 32) | (unsigned)(~bi));
-                __hip_atomic_store(ring + ((j + 2) & 3) * FPSC_GMAX + g, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bv < 0.f ? tagv : (((unsigned long long)__float_as_uint(bv) << 32) | tagv | ((~(unsigned)bi) & 0x1fffffffu));
                 __hip_atomic_store(slot + g, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             unsigned long long k = 0;
             unsigned spins = 0;
             bool dead = false;
             for (;;) {
-                k = lane < G ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-                if (!__any(k == 0)) break;
+                k = lane < G ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tagv;
+                if (!__any((k & (7ull << 29)) != tagv)) break;
                 if (++spins > FPSC_SPIN_MAX || (spins % 1024 == 0 &&
                         __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { dead = true; break; }
             }
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop_kernel(const float* __restric
             if (lane >= G) k = 0;
             // every lane fetches ITS candidate's coordinates while the maximum is being reduced: the winner's are
             // then already in registers (one dependent L2 round trip less per step)
-            const int ci = (lane < G && !dead) ? (int)(~(unsigned)(k & 0xffffffffu)) : 0;
+            const int ci = (lane < G && !dead) ? (int)((~(unsigned)k) & 0x1fffffffu) : 0;
             const int cic = (unsigned)ci < (unsigned)N ? ci : 0;
             const float cx = p[cic * 3 + 0], cy = p[cic * 3 + 1], cz = p[cic * 3 + 2];
             unsigned long long kmax = k;
@@ -186,36 +189,47 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop_kernel(const float* __restric
     }
 }
 
-// ---- large-K kNN: one workgroup per query; all N keys (dist bits << 32 | index) bitonic-sorted in LDS
+// ---- large-K kNN: one workgroup per query; keys (dist bits << 32 | index) bitonic-sorted in LDS.
+// N <= 16384: all N keys in one sort.  Larger clouds (knn_cuda.KNN takes any N, patch.py:33,107): the references are
+// streamed in chunks; LDS holds the running best KP >= K keys in front of the chunk's keys, every pass sorts the
+// NP = 16384 keys and keeps the front.  Keys are distinct (the index is part of the key), so the result is the exact
+// (distance, index)-ordered top K whatever the chunking.
 constexpr int KS_T = 1024;
 constexpr int KS_NMAX = 16384;          // 128 KiB of 64-bit keys
+constexpr int KS_KMAX = 8192;           // chunked path: at least half of the LDS keys are fresh references per pass
 
 __global__ __launch_bounds__(KS_T) void knn_sort_kernel(const float* __restrict__ ref, const float* __restrict__ query,
-                                                       int N, int M, int K, int NP /*pow2 >= N*/, int* __restrict__ idx_out,
-                                                       float* __restrict__ dist_out) {
+                                                       int N, int M, int K, int NP /*pow2: keys sorted per pass*/,
+                                                       int KP /*0: single pass; else pow2 >= K kept between passes*/,
+                                                       int* __restrict__ idx_out, float* __restrict__ dist_out) {
     extern __shared__ unsigned long long keys[];
     const int b = blockIdx.y, q = blockIdx.x, tid = threadIdx.x;
     const float* r = ref + (size_t)b * N * 3;
     const float* qq = query + ((size_t)b * M + q) * 3;
     const float qx = qq[0], qy = qq[1], qz = qq[2];
-    for (int i = tid; i < NP; i += KS_T) {
-        unsigned long long key = ~0ull;
-        if (i < N) key = ((unsigned long long)__float_as_uint(sqd(qx, qy, qz, r[i * 3 + 0], r[i * 3 + 1], r[i * 3 + 2])) << 32) | (unsigned)i;
-        keys[i] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= NP; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < NP; i += KS_T) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a = keys[i], c = keys[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > c) == up) { keys[i] = c; keys[l] = a; }
-                }
-            }
-            __syncthreads();
+    const int C = NP - KP;                                              // fresh references per pass
+    for (int i = tid; i < KP; i += KS_T) keys[i] = ~0ull;
+    for (int c0 = 0; c0 < N; c0 += C) {
+        for (int i = tid; i < C; i += KS_T) {
+            const int j = c0 + i;
+            unsigned long long key = ~0ull;
+            if (j < N) key = ((unsigned long long)__float_as_uint(sqd(qx, qy, qz, r[j * 3 + 0], r[j * 3 + 1], r[j * 3 + 2])) << 32) | (unsigned)j;
+            keys[KP + i] = key;
         }
+        __syncthreads();
+        for (int k = 2; k <= NP; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < NP; i += KS_T) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long a = keys[i], c = keys[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > c) == up) { keys[i] = c; keys[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+    }
     for (int i = tid; i < K; i += KS_T) {
         const unsigned long long key = keys[i];
         idx_out[((size_t)b * M + q) * K + i] = (int)(key & 0xffffffffu);
@@ -224,6 +238,14 @@ __global__ __launch_bounds__(KS_T) void knn_sort_kernel(const float* __restrict_
 }
 
 }  // namespace
+
+// 1 when pf_fps runs the cooperative kernel for clouds of N points (its scratch row then holds the candidate ring):
+// stride_words = 64-bit words between the rings of consecutive clouds, abort_word = index of the abort word in a ring
+extern "C" int pf_fps_scratch_layout(int N, long long* stride_words, long long* abort_word) {
+    if (stride_words) *stride_words = ((long long)N / 2) & ~1ll;
+    if (abort_word) *abort_word = FPSC_RING;
+    return N >= 8192 && N <= FPSC_GMAX * 1024 * 8 ? 1 : 0;
+}
 
 // xyz [B,N,3] -> idx [B,npoint] int32; mind: [B,N] float scratch
 extern "C" int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, int* idx_out, void* stream) {
@@ -253,19 +275,25 @@ extern "C" int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, i
     return pf_last_launch_status();
 }
 
-// K nearest references of every query, K <= N <= 16384: idx [B,M,K] int32, dist [B,M,K] squared L2 (nullable)
+// K nearest references of every query, K <= N (K <= 8192 when N > 16384): idx [B,M,K] int32, dist [B,M,K] squared L2 (nullable)
 extern "C" int pf_knn_large(const float* ref, const float* query, int B, int N, int M, int K, int* idx_out,
                             float* dist_out, void* stream) {
     if (!ref || !query || !idx_out) return PF_ERR_NULL;
-    if (B <= 0 || N <= 0 || M <= 0 || K <= 0 || K > N || B > 65535) return PF_ERR_SHAPE;
-    if (N > KS_NMAX) return PF_ERR_UNSUPPORTED;
-    int np = 1;
-    while (np < N) np <<= 1;
+    if (B <= 0 || N <= 0 || M <= 0 || K <= 0 || K > N || B > 65535 || (long long)N * 3 > 0x7fffffffll) return PF_ERR_SHAPE;
+    int np = 1, kp = 0;
+    if (N <= KS_NMAX) {
+        while (np < N) np <<= 1;
+    } else {
+        if (K > KS_KMAX) return PF_ERR_UNSUPPORTED;
+        np = KS_NMAX;
+        kp = 1;
+        while (kp < K) kp <<= 1;
+    }
     const size_t lds = (size_t)np * 8;
     if (lds > 64 * 1024)        // idempotent opt-in to > 64 KiB of dynamic LDS (no state kept on our side)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             KS_NMAX * 8);
-    hipLaunchKernelGGL(knn_sort_kernel, dim3(M, B), dim3(KS_T), lds, (hipStream_t)stream, ref, query, N, M, K, np, idx_out,
-                       dist_out);
+    hipLaunchKernelGGL(knn_sort_kernel, dim3(M, B), dim3(KS_T), lds, (hipStream_t)stream, ref, query, N, M, K, np, kp,
+                       idx_out, dist_out);
     return pf_last_launch_status();
 }

@@ -129,10 +129,9 @@ class CondList(list):
 # HIP engine
 # ----------------------------------------------------------------------------------------
 class _Engine:
-    def __init__(self, sd, device: torch.device, upratio: int, ec_mode: Optional[str] = None):
+    def __init__(self, sd, device: torch.device, ec_mode: Optional[str] = None):
         self.lib = _lib.load()
         self.device = device
-        self.R = upratio
         # EdgeConv arithmetic of the 128-channel units (PF_EC_MODE), all within the same 1e-5 parity bar:
         #   "f16n" (default)   split-fp16 with a natural-scale low half, one accumulator, conv_out with swapped operands
         #                      (edgeconv4_kernel); needs |4^t x_t| < 65504 for growth layer t (|activation| < 1023)
@@ -143,7 +142,7 @@ class _Engine:
         self.ec_mode = ec_mode or os.environ.get("PF_EC_MODE", "f16n")
         if self.ec_mode not in ("f16n", "f16x2", "bf16x3", "f32"):
             raise ValueError(f"unknown EdgeConv arithmetic mode {self.ec_mode!r}")
-        pk = pack_plan(fold_state_dict(sd, upratio), self.ec_mode)
+        pk = pack_plan(fold_state_dict(sd), self.ec_mode)
         self.blob = torch.from_numpy(pk["blob"]).to(device)
         self.base = self.blob.data_ptr()
         self.ec_tab0 = pk["ec_tab0"]
@@ -222,11 +221,11 @@ class _Engine:
                                     lps.data_ptr(), logp.data_ptr(), s), "pf_logp")
         return z, ldj, logp
 
-    def interp(self, xyz: Tensor, z: Tensor, idx16: Tensor) -> Tensor:
+    def interp(self, xyz: Tensor, z: Tensor, idx16: Tensor, R: int) -> Tensor:
         B, N, _ = xyz.shape
-        u = torch.empty((B, N * self.R, 3), dtype=torch.float32, device=xyz.device)
+        u = torch.empty((B, N * R, 3), dtype=torch.float32, device=xyz.device)
         _lib.check(self.lib.pf_interp(xyz.data_ptr(), z.data_ptr(), idx16.data_ptr(), self.base, self.interp_off,
-                                      u.data_ptr(), B, N, self.R, self._stream()), "pf_interp")
+                                      u.data_ptr(), B, N, R, self._stream()), "pf_interp")
         return u
 
     def flow_g(self, u: Tensor, cp: Tensor, st: Tensor, R: int) -> Tensor:
@@ -238,7 +237,7 @@ class _Engine:
         return x
 
 
-    def profile_stages(self, xyz: Tensor, iters: int = 5) -> dict:
+    def profile_stages(self, xyz: Tensor, iters: int = 5, R: int = 4) -> dict:
         """Average ms per launch of each stage, timed with HIP events on the launch stream
         (torch's current stream IS the stream the kernels are enqueued on)."""
         B, N, _ = xyz.shape
@@ -266,8 +265,8 @@ class _Engine:
                     u, h.data_ptr(), self.base, self.post[u], None, st[u].data_ptr(), cp[u].data_ptr(),
                     pq.data_ptr() if u < 5 else None, T, s)))
             z, _, _ = timed("flow_f+logp", lambda: self.flow_f(xyz, cp, st))
-            u_ = timed("interp", lambda: self.interp(xyz, z, idx16))
-            timed("flow_g", lambda: self.flow_g(u_, cp, st, self.R))
+            u_ = timed("interp", lambda: self.interp(xyz, z, idx16, R))
+            timed("flow_g", lambda: self.flow_g(u_, cp, st, R))
         torch.cuda.synchronize()
         return {k: sum(a.elapsed_time(b) for a, b in v[1:]) / (len(v) - 1) for k, v in acc.items()}
 
@@ -293,8 +292,13 @@ class PointInterpFlow(nn.Module):
         self.ec_mode: Optional[str] = None       # EdgeConv arithmetic of the 128-channel units; None = $PF_EC_MODE or "f16n"
 
     # ---- plan cache ---------------------------------------------------------------------
+    # The packed plan is a function of the parameters / buffers.  It is dropped by load_state_dict(), .to() / _apply();
+    # entering train() mode only marks it as possibly stale: the next eval-mode use compares the tensors' version
+    # counters (every in-place update, e.g. an optimizer step or a BatchNorm running-stat update, bumps them) and
+    # re-packs only when something changed - so eval() / train() toggles around validation batches cost nothing.
     def invalidate_plan(self) -> None:
         self._engine_cache = None
+        self._plan_gen = getattr(self, "_plan_gen", 0) + 1
 
     def load_state_dict(self, *a, **kw):
         self.invalidate_plan()
@@ -305,17 +309,33 @@ class PointInterpFlow(nn.Module):
         return super()._apply(fn, *a, **kw)
 
     def train(self, mode: bool = True):
-        self.invalidate_plan()
+        if mode:
+            self._maybe_stale = True
         return super().train(mode)
 
-    def _engine(self, upratio: int) -> _Engine:
+    def _signature(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def _engine(self, upratio: int = 4) -> _Engine:
+        """The packed plan (it does not depend on the upsampling ratio; the argument is kept for callers of round 1)."""
         e = self._engine_cache
         dev = self.flow_blocks[0].actnorm.logs.device
-        if e is None or e.R != upratio or e.device != dev or (self.ec_mode is not None and e.ec_mode != self.ec_mode):
+        if e is not None and getattr(self, "_maybe_stale", False):
+            if self._signature() != e.signature:
+                self.invalidate_plan()
+                e = None
+            elif not self.training:
+                self._maybe_stale = False
+        if e is not None and (e.device != dev or (self.ec_mode is not None and e.ec_mode != self.ec_mode)):
+            self.invalidate_plan()
+            e = None
+        if e is None:
             if dev.type != "cuda":
                 raise _lib.PuflowHipError("PointInterpFlow runs on the GPU only: move the module with .to('cuda')")
-            e = _Engine(self.state_dict(), dev, upratio, self.ec_mode)
+            e = _Engine(self.state_dict(), dev, self.ec_mode)
+            e.signature = self._signature()
             self._engine_cache = e
+            self._maybe_stale = self.training
         return e
 
     def _check_mode(self):
@@ -382,7 +402,7 @@ class PointInterpFlow(nn.Module):
         idx16 = e.knn(xyz)
         _, cp, st = e.features(xyz, idx16, want_cs=False)
         z, _, logp = e.flow_f(xyz, cp, st)
-        u = e.interp(xyz, z, idx16)
+        u = e.interp(xyz, z, idx16, upratio)
         x = e.flow_g(u, cp, st, upratio)
         if _CHECK_FINITE and not bool(torch.isfinite(x).all() & torch.isfinite(logp)):
             # the split-fp16 kernels overflow to inf/NaN when an activation or weight leaves the fp16 range (65504):
@@ -400,7 +420,7 @@ class PointInterpFlow(nn.Module):
         idx16 = e.knn(xyz)
         cs, cp, st = e.features(xyz, idx16, want_cs=True)
         z, ldj, logp = e.flow_f(xyz, cp, st)
-        u = e.interp(xyz, z, idx16)
+        u = e.interp(xyz, z, idx16, upratio)
         x = e.flow_g(u, cp, st, upratio)
         B, N, _ = xyz.shape
         fz = u.view(B, N, upratio, 3).transpose(2, 3)
@@ -415,7 +435,10 @@ class PointInterpFlow(nn.Module):
         """The eval forward for a fixed [B, N, 3] shape captured in a hipGraph: ONE launch per call instead of 18, so the
         step no longer depends on host launch latency / jitter (8 ranks sharing one host).  Returns `run(xyz) -> (x, logp)`;
         the results live in static buffers that the next call overwrites (clone them to keep them) and are
-        bit-identical to `forward` (same kernels, same order)."""
+        bit-identical to `forward` (same kernels, same order).
+        The capture bakes device pointers into the packed weight blob: the callable keeps that plan alive, and refuses to
+        replay (PuflowHipError) once the module's weights changed or moved (load_state_dict, .to(), an optimizer step in
+        between) - capture again then."""
         self._check_mode()
         dev = self.flow_blocks[0].actnorm.logs.device
         static_in = torch.zeros((B, N, 3), dtype=torch.float32, device=dev)
@@ -424,16 +447,23 @@ class PointInterpFlow(nn.Module):
         with torch.cuda.stream(side):                      # warm-up outside capture: library load, plan packing
             self._forward_eval(static_in, upratio)
         torch.cuda.current_stream(dev).wait_stream(side)
+        engine = self._engine(upratio)                     # pinned: the graph reads this engine's blob
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out_x, out_logp = self._forward_eval(static_in, upratio)
+        if self._engine_cache is not engine:
+            raise _lib.PuflowHipError("the plan was re-packed during capture")
 
         def run(xyz: Tensor) -> Tuple[Tensor, Tensor]:
             if tuple(xyz.shape) != (B, N, 3):
                 raise ValueError(f"graph captured for {(B, N, 3)}, got {tuple(xyz.shape)}")
+            if self.training or self._engine(upratio) is not engine:
+                raise _lib.PuflowHipError("the captured graph is stale: the module's weights changed, moved or the module is "
+                                          "in train() mode - call graphed() again")
             static_in.copy_(xyz)
             graph.replay()
             return out_x, out_logp
 
-        run.graph = graph                                    # keep the capture alive with the callable
+        run.graph = graph                                    # keep the capture and its plan alive with the callable
+        run.engine = engine
         return run

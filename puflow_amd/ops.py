@@ -133,10 +133,25 @@ def furthest_point_sample(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
     lib = _lib.load()
     xyz = _f32c(xyz)
     B, N, _ = xyz.shape
-    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    idx = torch.zeros((B, npoint), dtype=torch.int32, device=xyz.device)
     mind = torch.empty((B, N), dtype=torch.float32, device=xyz.device)
     _lib.check(lib.pf_fps(xyz.data_ptr(), B, N, npoint, mind.data_ptr(), idx.data_ptr(), _stream()), "pf_fps")
+    _check_fps_abort(lib, mind, B, N)
     return idx
+
+
+def _check_fps_abort(lib, mind: torch.Tensor, B: int, N: int) -> None:
+    """The cooperative FPS kernel's workgroups wait for each other with a BOUNDED spin; a cloud whose workgroups gave up
+    has its abort word set and an invalid index row.  One small device -> host read per call (FPS itself is tens of ms)."""
+    import ctypes
+    stride, word = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    if not lib.pf_fps_scratch_layout(N, ctypes.byref(stride), ctypes.byref(word)):
+        return
+    words = mind.view(-1)[: (B * N) // 2 * 2].view(torch.int64)
+    pos = torch.arange(B, device=mind.device, dtype=torch.int64) * stride.value + word.value
+    if bool((words[pos] != 0).any()):
+        raise _lib.PuflowHipError("pf_fps: the cooperative kernel's workgroups timed out waiting for each other "
+                                  "(a cloud's workgroups were not co-resident); the sampled indices are invalid")
 
 
 def gather_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

@@ -144,7 +144,8 @@ def fold_state_dict(sd, upratio: int = 4) -> Dict[str, object]:
     W3, b3 = _fold_bn(sd, p + ".3", p + ".4")
     ip["w_W3"], ip["w_b3"] = W3.astype(np.float32), b3.astype(np.float32)
     W6 = _np(sd, p + ".6.weight"); W6 = W6.reshape(W6.shape[0], -1)
-    ip["w_W6"], ip["w_b6"] = W6[:upratio].astype(np.float32), _np(sd, p + ".6.bias")[:upratio].astype(np.float32)
+    # all r_max = 32 rows; a forward uses the first `upratio` of them (interpflow.py:180) - the plan does not depend on it
+    ip["w_W6"], ip["w_b6"] = W6.astype(np.float32), _np(sd, p + ".6.bias").astype(np.float32)
     # linear o linear folds around the 256-channel context (no nonlinearity between the producers' last conv and the
     # weight unit's first conv, interpflow.py:134,144):  W0.[d; e] with d = W6 d2 + b6 and e = Gout feat + (PA x_i + QB x_j + pb)
     W0d = ip["w_W0"].astype(np.float64)
@@ -315,7 +316,8 @@ def frag_unpack(F: np.ndarray, out: int, inn: int) -> np.ndarray:
 # Device blob: every folded matrix in kernel order + offset tables (float units, 64-aligned)
 # ---------------------------------------------------------------------------------------
 POST_SLOTS = ["M1", "b1", "M2", "H1", "S2", "bS2", "T2", "bT2", "ST4", "bST4", "PQ", "bPQ"]
-INTERP_SLOTS = ["dtab", "d_W3", "d_b3", "d_W6", "d_b6", "ectab", "ec_w", "w_W0", "w_b0", "w_W3", "w_b3", "w_W6", "w_b6"]
+INTERP_SLOTS = ["dtab", "d_W3", "d_b3", "d_W6", "d_b6", "ectab", "ec_w", "w_W0", "w_b0", "w_W3", "w_b3", "w_W6", "w_b6",
+                "w_W6full", "w_b6full"]
 FLOW_REC = 5360
 
 
@@ -452,12 +454,11 @@ def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, objec
     out["flow"] = B.add(np.concatenate([pack_flow_record(f) for f in plan["flows"]]))
     out["ld_const"] = float(sum(f["ld_const"] for f in plan["flows"]))
     ip = plan["interp"]
-    R = plan["upratio"]
-    W6r = np.zeros((16, 64), np.float32)
+    W6r = np.zeros((16, 64), np.float32)           # R <= 4 fast path: rows 0..3 replicated into every 4-row q group
     b6r = np.zeros(16, np.float32)
     for q in range(4):
-        W6r[4 * q:4 * q + R] = ip["w_W6"]
-        b6r[4 * q:4 * q + R] = ip["w_b6"]
+        W6r[4 * q:4 * q + 4] = ip["w_W6"][:4]
+        b6r[4 * q:4 * q + 4] = ip["w_b6"][:4]
     ec = ip["ec"]
     ft = ip["f_tab"]
     io = {   # matrices: f16x2 fragment images (csrc/interp.hip header lists the slots)
@@ -470,6 +471,7 @@ def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, objec
         "w_b0": B.add(_etab_frag(ft[:, 0:3], ft[:, 3:6], None, ft[:, 6] + ip["f_b0"])),   # W0b.(edge table) + b0 + W0a.b6
         "w_W3": B.add(frag_pack_f16x2(ip["w_W3"])), "w_b3": B.add(ip["w_b3"]),
         "w_W6": B.add(frag_pack_f16x2(W6r)), "w_b6": B.add(b6r),
+        "w_W6full": B.add(frag_pack_f16x2(ip["w_W6"])), "w_b6full": B.add(ip["w_b6"]),
     }
     out["interp"] = [io[k] for k in INTERP_SLOTS]
     out["blob"] = B.data()

@@ -68,13 +68,25 @@ class TrainerModule(_Base):
                                                                patience=self.cfg.sched_patience)
         return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "monitor": "CD"}}
 
-    def _losses(self, batch):
-        if len(batch) == 3:
+    @staticmethod
+    def _unpack(batch):
+        """The reference's two batch forms: the PU1K / PUGeo dict with a leading DataLoader dimension of 1
+        (train_pu1k.py:55-56: 'gt_dense_xyz_pl', 'input_sparse_xyz_pl', squeezed) and the PU-GAN tuple
+        (xyz_sparse, xyz_dense[, radius]) (train_pugan.py:55)."""
+        if isinstance(batch, dict):
+            xyz_sparse, xyz_dense = batch["input_sparse_xyz_pl"], batch["gt_dense_xyz_pl"]
+            radius = batch.get("up_ratio_pl", batch.get("pointclouds_radius"))
+        elif len(batch) == 3:
             xyz_sparse, xyz_dense, radius = batch
         else:
             (xyz_sparse, xyz_dense), radius = batch, None
-        xyz_sparse, xyz_dense = xyz_sparse.squeeze(0) if xyz_sparse.dim() == 4 else xyz_sparse, \
-            xyz_dense.squeeze(0) if xyz_dense.dim() == 4 else xyz_dense
+        if xyz_sparse.dim() == 4:
+            xyz_sparse, xyz_dense = xyz_sparse.squeeze(0), xyz_dense.squeeze(0)
+            radius = radius.squeeze(0) if radius is not None and radius.dim() == 2 else radius
+        return xyz_sparse, xyz_dense, radius
+
+    def _losses(self, batch):
+        xyz_sparse, xyz_dense, radius = self._unpack(batch)
         upratio = int(xyz_dense.shape[1] / xyz_sparse.shape[1])
         xyz_pred, logpx = self(xyz_sparse, upratio=upratio)
         if self.loss_mix == "pugan":
@@ -98,12 +110,13 @@ class TrainerModule(_Base):
 
     @torch.no_grad()
     def validation_step(self, batch, batch_idx=0):
-        xyz_sparse, xyz_dense = batch[0], batch[1]
+        xyz_sparse, xyz_dense, _ = self._unpack(batch)
         upratio = int(xyz_dense.shape[1] / xyz_sparse.shape[1])
         was = self.training
-        from .dist import broadcast_buffers
-        broadcast_buffers(self)                  # multi-rank: rank 0's BN running statistics, as DDP would have them
-        self.eval()
+        if batch_idx == 0:
+            from .dist import broadcast_buffers
+            broadcast_buffers(self)              # multi-rank: rank 0's BN running statistics, as DDP would have them
+        self.eval()                              # (the packed eval plan is re-used across validation batches: interpflow._engine)
         predict_x, logpx = self(xyz_sparse, upratio=upratio)
         cd = self.chamfer_loss2(predict_x, xyz_dense)
         self.train(was)
@@ -128,7 +141,9 @@ class TrainerModule(_Base):
             return                      # single process: the init happens inside the first real forward, as in the reference
         from .dist import broadcast_module
         with torch.no_grad():
-            sparse, dense = batch[0], batch[1]
+            sparse, dense, _ = self._unpack(batch)
+            # NB: this extra train-mode forward also moves the BatchNorm running statistics one momentum step further than
+            # a single-process run would (they are overwritten by rank 0's on the next broadcast_buffers)
             self(sparse, upratio=int(dense.shape[1] / sparse.shape[1]))
         broadcast_module(self)
 

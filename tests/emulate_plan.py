@@ -109,7 +109,7 @@ def forward(plan, xyz, idx16, stages=False):
         + d2 @ _t(ip["f_dW"]).T + feat @ _t(ip["f_eW"]).T
     w = _lrelu(w, 0.01)
     w = _lrelu(w @ _t(ip["w_W3"]).T + _t(ip["w_b3"]), 0.01)
-    w = w @ _t(ip["w_W6"]).T + _t(ip["w_b6"])                         # [B,N,8,R]
+    w = w @ _t(ip["w_W6"][:R]).T + _t(ip["w_b6"][:R])                 # [B,N,8,R]  (first R of the r_max = 32 rows)
     a = torch.softmax(w, dim=2)                                       # over k
     zj = _gather(z, idx8)                                             # [B,N,8,3]
     fz = torch.einsum("bnkc,bnkr->bncr", zj, a)                       # [B,N,3,R]

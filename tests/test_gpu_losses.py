@@ -90,3 +90,23 @@ def test_emd_quality_and_backward():
     np.testing.assert_allclose(xd.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-7)
     assert float(yd.grad.abs().sum()) == 0.0
     assert abs(float(loss) - float(d2.sum()) / 2.0) < 1e-4
+
+
+def test_emd_nan_prediction_row_is_loud_not_a_fault():
+    """A NaN prediction (an expected event in training: TrainerModule keeps the reference's NaN-loss guard,
+    train_pu1k.py:71-73) must come out as a NaN loss, not as an out-of-bounds bid index inside the auction."""
+    from puflow_amd.loss import EarthMoverDistance, emdFunction
+    n = 256
+    x, y = _unit_cube(2, n, 5), _unit_cube(2, n, 6)
+    x[1, 17] = float("nan")
+    x[1, 40, 1] = float("inf")
+    dist, ass = emdFunction.apply(x.to(DEV), y.to(DEV), 0.005, 50)
+    torch.cuda.synchronize()
+    ass, dist = ass.cpu().numpy(), dist.cpu().numpy()
+    assert ass.min() >= 0 and ass.max() < n                      # every index stays in range
+    assert np.isnan(dist[1, 17]) and not np.isfinite(dist[1, 40])
+    assert np.isfinite(dist[0]).all()                            # the clean sample is untouched
+    dref, aref = E.emd_forward(x.numpy(), y.numpy(), 0.005, 50)
+    assert (ass[0] == aref[0]).all() and (ass[1] == aref[1]).mean() > 0.99
+    loss = EarthMoverDistance()(x.to(DEV), y.to(DEV))
+    assert bool(torch.isnan(loss))

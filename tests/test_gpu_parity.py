@@ -182,8 +182,10 @@ def test_trained_style_dynamic_range(lib, seed):
             assert (st["cs"][i].cpu() - ref["cs"][i]).abs().max() < 1e-5 * max(1.0, float(ref["cs"][i].abs().max())), (mode, i)
 
 
-@pytest.mark.parametrize("R", [2, 3])
+@pytest.mark.parametrize("R", [1, 2, 3, 5, 8, 16, 32])
 def test_other_upsampling_ratios(lib, R):
+    """--up_ratio other than 4: R <= 4 runs the 4-row fast path of the interpolation kernel, larger ratios all r_max = 32
+    rows of the weight unit's last conv (interpflow.py:142,180); the packed plan is the same for every R."""
     sd = synth_state_dict(6)
     xyz = synth_patches(2, 256, seed=3)
     ref = O.forward(sd, xyz, R, stages=True)
@@ -296,3 +298,38 @@ def test_graphed_forward_is_bit_identical(lib):
         assert torch.equal(x_g, x_e) and torch.equal(lp_g, lp_e)
     with pytest.raises(ValueError):
         run(synth_patches(2, 256, seed=1).to(DEV))
+
+
+def test_graphed_forward_is_pinned_to_its_plan(lib):
+    """The captured graph bakes pointers into the packed weight blob: it must keep that blob alive across eval() /
+    train() toggles and allocator churn, replay bit-identically, and refuse to replay once the weights changed."""
+    sd = synth_state_dict(21)
+    xyz = synth_patches(2, 256, seed=22).to(DEV)
+    net = _net(sd)
+    x0, l0 = net(xyz, 4)
+    x0, l0 = x0.clone(), l0.clone()
+    run = net.graphed(2, 256, 4)
+    x1, l1 = run(xyz)
+    assert torch.equal(x1, x0) and torch.equal(l1, l0)
+    net.eval()                                             # used to drop the engine the graph points into
+    junk = [torch.randn(1 << 20, device=DEV) for _ in range(8)]      # allocator churn over any freed blob
+    del junk
+    torch.cuda.empty_cache()
+    x2, l2 = run(xyz)
+    assert torch.equal(x2, x0) and torch.equal(l2, l0)
+    e_before = net._engine(4)
+    net.train(); net.eval()                                # mode toggles alone do not re-pack
+    assert net._engine(4) is e_before
+    with torch.no_grad():
+        net.flow_blocks[0].actnorm.bias.add_(0.25)         # in-place weight update while in eval mode after a train() phase
+    net.train(); net.eval()
+    from puflow_amd._lib import PuflowHipError
+    with pytest.raises(PuflowHipError):
+        run(xyz)                                           # stale capture: loud, not a silent replay of old weights
+    x3, _ = net(xyz, 4)
+    assert not torch.equal(x3, x0)                         # the eager path picked the new weights up
+    run2 = net.graphed(2, 256, 4)
+    assert torch.equal(run2(xyz)[0], x3)
+    net.load_state_dict(sd)
+    with pytest.raises(PuflowHipError):
+        run2(xyz)

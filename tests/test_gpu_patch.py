@@ -108,3 +108,76 @@ def test_cli_end_to_end(tmp_path):
     cd_out = float(O.chamfer_distance_mean(torch.from_numpy(out)[None], torch.from_numpy(xin)[None]))
     cd_ref = float(O.chamfer_distance_mean(torch.from_numpy(ref)[None], torch.from_numpy(xin)[None]))
     assert abs(cd_out - cd_ref) < 0.02 * cd_ref
+
+
+def test_knn_large_streams_clouds_beyond_the_lds_limit():
+    """knn_cuda.KNN takes any N (patch.py:33,107): clouds of more than 16 384 points stream through LDS in chunks; the
+    result is still the exact (distance, index)-ordered top K."""
+    from puflow_amd import ops
+    N, M, K = 100000, 24, 256
+    ref_pts = synth_patches(1, N, seed=4242, surface=True)
+    ref_pts[0, 70000] = ref_pts[0, 11]                         # duplicate far apart in index: tie broken by index
+    qry = ref_pts[:, [0, 11, 5000, 16383, 16384, 16385, 32768, 70000, 99999] + list(range(100, 115))].clone()
+    d_ref, i_ref = O.knn_canonical(qry, ref_pts, K)
+    dist, idx = ops.KNN(k=K, transpose_mode=True)(ref_pts.to(DEV), qry.to(DEV))
+    assert torch.equal(idx.cpu(), i_ref) and torch.equal(dist.cpu(), d_ref)
+    # K above the chunked path's limit is refused loudly, not truncated
+    from puflow_amd._lib import PuflowHipError
+    with pytest.raises(PuflowHipError):
+        ops.KNN(k=9000, transpose_mode=True)(ref_pts.to(DEV), qry.to(DEV))
+
+
+def test_fps_abort_word_is_reported():
+    """A cooperative-FPS cloud whose workgroups timed out sets its abort word: the wrapper must raise, not hand out
+    the (invalid) index row."""
+    from puflow_amd import _lib, ops
+    lib = _lib.load()
+    B, N = 3, 10240
+    mind = torch.zeros((B, N), dtype=torch.float32, device=DEV)
+    ops._check_fps_abort(lib, mind, B, N)                        # clean: no exception
+    import ctypes
+    stride, word = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    assert lib.pf_fps_scratch_layout(N, ctypes.byref(stride), ctypes.byref(word)) == 1
+    mind.view(-1).view(torch.int64)[2 * stride.value + word.value] = 1
+    with pytest.raises(_lib.PuflowHipError):
+        ops._check_fps_abort(lib, mind, B, N)
+    assert lib.pf_fps_scratch_layout(2048, None, None) == 0      # single-workgroup kernel: no ring to check
+    ops._check_fps_abort(lib, mind[:, :2048].contiguous(), B, 2048)
+
+
+def test_pugan_5000_to_20000_pipeline():
+    """BASELINE configs[3]: one 5000-point cloud -> int(5000 / 256 * 4) = 78 patches of 256 -> 78 x 1280 = 99 840
+    candidates -> FPS 20 024 -> drop 24 outliers -> 20 000 points (patch.py:35-80,101; upsample.py:46-56).
+    Stage by stage against the oracle: patch extraction bit-exact, the network within 1e-5 of the CPU oracle on every
+    candidate, and - GIVEN the HIP candidates - the merge and the outlier removal bit-exact (the FPS merge is chaotic
+    in its input, so the final selection is compared on identical candidates, and end to end as coverage)."""
+    from puflow_amd.interpflow import PointInterpFlow
+    from puflow_amd.patch import PatchHelper
+    sd = synth_state_dict(31)
+    net = PointInterpFlow(3); net.load_state_dict(sd); net.set_to_initialized_state(); net = net.to(DEV).eval()
+    pc = synth_patches(1, 5000, seed=50) * 2.0 + 0.7
+    ph = PatchHelper(256, 4)
+    pcn, gc, gfd = PatchHelper.normalize_pc(pc.to(DEV))
+    patches = PatchHelper.extract_knn_patch(pcn, ph.knn, 256, 4)
+    assert tuple(patches.shape) == (1, 78, 256, 3)
+    assert torch.equal(patches.cpu(), P.extract_knn_patch(pcn.cpu(), 256, 4))
+    cand = PatchHelper.upsampling_patches(net, patches, 4)                          # [1, 78, 1280, 3]
+    assert tuple(cand.shape) == (1, 78, 1280, 3)
+    pn, pcen, pfd = P.normalize_pc(patches.cpu().reshape(78, 256, 3))
+    pred_ref, _ = O.forward(sd, pn, 4)
+    cand_ref = (torch.cat([pred_ref, pn], 1) * pfd + pcen).reshape(1, 78, 1280, 3)
+    assert (cand.cpu() - cand_ref).abs().max() < 1e-5
+    merged = PatchHelper.merge_patches(cand, 20024)                                 # [1, 3, 20024]
+    ref_m = P.merge_patches(cand.cpu(), 20024)
+    assert torch.equal(merged.transpose(1, 2).cpu(), ref_m)
+    den = (merged * gfd + gc.transpose(1, 2)).transpose(1, 2).contiguous()
+    out = PatchHelper.remove_outliers(den, pc.to(DEV), 24)
+    ref_o = P.remove_outliers(den.cpu(), pc, 24)
+    assert tuple(out.shape) == (1, 20000, 3) and torch.equal(out.cpu(), ref_o)
+    # the one-call pipeline gives the same cloud
+    e2e = PatchHelper.remove_outliers(ph.upsample(net, pc.to(DEV), npoint=20024, upratio=4), pc.to(DEV), 24)
+    assert torch.equal(e2e, out)
+    cd_out = float(O.chamfer_distance_mean(out.cpu(), pc))
+    ref_full = P.remove_outliers(P.merge_patches(cand_ref, 20024) * gfd.cpu() + gc.cpu(), pc, 24)
+    cd_ref = float(O.chamfer_distance_mean(ref_full, pc))
+    assert abs(cd_out - cd_ref) < 0.02 * cd_ref

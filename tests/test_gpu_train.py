@@ -170,3 +170,59 @@ def test_trainer_module_step_and_eval_roundtrip():
     sd = {k: v.detach().cpu() for k, v in tm.network.state_dict().items()}
     xr, lr = O.forward(sd, sparse.cpu(), 4)
     assert (x.cpu() - xr).abs().max() < 1e-5
+
+
+def test_training_step_at_the_real_batch_size_matches_the_oracle():
+    """BASELINE configs[2] shape: 32 patches of 256 -> 1024 points per rank.  The HIP train-mode forward + backward
+    against the train-mode oracle (oracle/ref_cpu.py::forward_train, itself pinned to the reference's own training
+    step at B = 4 by tests/golden/train_step.npz): x, logp, CD, loss and the gradient norm of every parameter."""
+    from puflow_amd import ops
+    from puflow_amd.interpflow import PointInterpFlow
+    B, N, R = 32, 256, 4
+    sd = synth_state_dict(77)
+    dense = synth_patches(B, N * R, seed=78)
+    sparse = dense[:, ::R].contiguous()
+    # oracle on CPU (autograd over the restatement)
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    xr, lr, _ = O.forward_train(sdr, sparse, R, actnorm_init=True)
+    cdr = _chamfer_cpu(xr, dense)
+    lossr = lr * 1e-4 + cdr * 1e-1
+    lossr.backward()
+    net = PointInterpFlow(3)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    x, logp = net(sparse.to(DEV), R)
+    cd, _ = ops.chamfer_distance(x, dense.to(DEV))
+    loss = logp * 1e-4 + cd * 1e-1
+    loss.backward()
+    assert (x.detach().cpu() - xr.detach()).abs().max() < 2e-5
+    np.testing.assert_allclose(float(logp), float(lr), rtol=1e-5)
+    np.testing.assert_allclose(float(cd), float(cdr), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(float(loss), float(lossr), rtol=1e-5)
+    params = dict(net.named_parameters())
+    ref_norm = {k: float(v.grad.norm()) for k, v in sdr.items() if v.requires_grad and v.grad is not None}
+    floor = 1e-5 * max(ref_norm.values())
+    assert len(ref_norm) > 150
+    for k, ref in ref_norm.items():
+        got = 0.0 if params[k].grad is None else float(params[k].grad.norm())
+        assert abs(got - ref) <= 3e-3 * ref + floor, (k, got, ref)
+
+
+def test_train_entry_runs_epochs_on_the_gpu(tmp_path):
+    """puflow_amd.train.train(): dict batches (the reference's PU1K form) from the synthetic data module, two epochs with
+    validation; the scheduler sees the CD, the losses are finite, weights move, ActNorm gets its first-batch init."""
+    from puflow_amd.data import SyntheticPatchData
+    from puflow_amd.train import train
+    from puflow_amd.trainer import default_cfg
+    kw = dict(num_point_patch=256, up_ratio=4, batch_size=4, device=DEV)
+    tr = SyntheticPatchData(num_patches=8, seed=1, **kw)
+    va = SyntheticPatchData(num_patches=4, seed=2, is_augment=False, **kw)
+    # EMD expects coordinates in about [0, 1]: shift the unit-ball patches
+    for d in (tr, va):
+        d.inp = d.inp * 0.5 + 0.5; d.gt = d.gt * 0.5 + 0.5; d.is_augment = False
+    mod, hist = train("Train", str(tmp_path / "x.ckpt"), None, default_cfg(sched_patience=0), tr, va, max_epochs=2,
+                      dataset="pu1k", device=DEV, log=None)
+    assert hist["epochs"] == 2 and len(hist["CD"]) == 2 and all(np.isfinite(hist["CD"])) and all(np.isfinite(hist["loss"]))
+    assert all(b.actnorm.is_inited for b in mod.network.flow_blocks)
+    assert not os.path.exists(str(tmp_path / "x-epoch2.ckpt"))                  # <= 10 epochs: not saved (train_pu1k.py:173)
+    assert mod.epoch == 2

@@ -38,7 +38,7 @@ def test_argument_validation_without_gpu(built_lib):
     assert lib.pf_knn(8, 8, 1, 16, 16, 17, 8, None, None) == -2        # K > M
     assert lib.pf_knn(8, 8, 1, 16, 16, 5, 8, None, None) == -3         # K not built
     assert lib.pf_edgeconv(99, 8, 8, 8, 8, 8, 1, 64, None) == -3
-    assert lib.pf_interp(8, 8, 8, 8, _lib.offsets([0] * 13), 8, 1, 64, 5, None) == -3
+    assert lib.pf_interp(8, 8, 8, 8, _lib.offsets([0] * 15), 8, 1, 64, 33, None) == -3
 
 
 def test_module_state_dict_matches_reference_census(golden_dir):

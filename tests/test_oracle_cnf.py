@@ -89,3 +89,13 @@ def test_rhs_matches_reference_golden(golden_dir):
         out = C.rhs(sd, block, float(g[f"{tag}_t"]), state, cr, er)
         assert (out[:, :3] - torch.from_numpy(g[f"{tag}_dy"]).reshape(-1, 3)).abs().max() < 2e-6
         assert (out[:, 3] - torch.from_numpy(g[f"{tag}_ndiv"]).reshape(-1)).abs().max() < 2e-6
+
+
+def test_dopri5_raises_on_nan_and_dt_underflow():
+    """torchdiffeq propagates a NaN error norm / asserts 't0 + dt > t0'; an unguarded restatement would spin forever
+    (every comparison with NaN is False: no step accepted, dt x10 per attempt)."""
+    import pytest as _pt
+    with _pt.raises(FloatingPointError):
+        C.dopri5(lambda t, y: y * float("nan"), torch.ones(4, 3), 0.0, 1.0)
+    with _pt.raises(FloatingPointError):
+        C.dopri5(lambda t, y: torch.ones_like(y) / (t - 0.5) ** 2, torch.ones(4, 3), 0.0, 1.0)     # pole at t = 0.5
