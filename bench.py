@@ -43,7 +43,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=32, help="patches per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="patches per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch patches per GPU; strong: --total-batch patches split over the ranks")
+    ap.add_argument("--total-batch", type=int, default=32, help="patches of the whole job under --scaling strong")
     ap.add_argument("--npoint", type=int, default=2048)
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = headline metric (BASELINE configs[1]); train = configs[2] training step (CD+EMD, RCCL all-reduce)")
@@ -56,6 +59,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.scaling == "strong":                     # fixed total work: the rank's contiguous shard of --total-batch patches
+        from puflow_amd.dist import shard_bounds
+        lo, hi = shard_bounds(args.total_batch, rank, world)
+        if hi - lo < 1:
+            raise SystemExit(f"--total-batch {args.total_batch} leaves rank {rank} of {world} without a patch")
+        args.batch = hi - lo
     # rehearsal knobs (one-GPU box): PF_BENCH_SINGLE_DEVICE=1 maps every rank to cuda:0 and PF_BENCH_BACKEND=gloo
     # replaces RCCL (two ranks cannot share one device under RCCL); the driver's multi-GPU runs use neither.
     if os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1":
@@ -116,7 +125,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
-    patches = world * args.batch * args.steps
+    patches = (args.total_batch if args.scaling == "strong" else world * args.batch) * args.steps
     value = patches / el
 
     out = None
@@ -129,47 +138,57 @@ def main():
         ec_fl = edgeconv_ref_flops(T, 128, 32, 4, 128)
         knn_ms = prof["knn"]
         knn_bytes = T * (3 * 4 + 16 * 4)               # 155 648 B per 2048-pt patch
-        if eng.ec_mode == "f16x2":
-            kname, peak = "edgeconv3_kernel<NCONV=4,ODIM=128,NS=2> (unit 3, split-fp16 on v_mfma_f32_16x16x32_f16)", BF16_MFMA_PEAK_TF
-            ec_exec = T * 132 * 16384.0                 # executed: 132 fp16 MFMAs (16x16x32) per point
-            basis = ("algorithmic = reference dense fp32 formulation (SURVEY 8d: 7.92 GFLOP per patch per unit), priced "
-                     "against the DENSE fp16/bf16 MFMA peak because the kernel runs on the fp16 pipe: fp32-equivalent results "
-                     "from 3 fp16 MFMA terms per product (2-way split, hi.hi + hi.lo + lo.hi), after the exact per-point P/Q "
-                     "fold (5.4x fewer MACs than the reference formulation); executed_* counts the fp16 MFMA flops actually issued")
-        elif eng.ec_mode == "bf16x3":
-            kname, peak = "edgeconv3_kernel<NCONV=4,ODIM=128> (unit 3, split-bf16 on v_mfma_f32_16x16x32_bf16)", BF16_MFMA_PEAK_TF
-            ec_exec = T * 264 * 16384.0                 # executed: 264 bf16 MFMAs (16x16x32) per point
-            basis = ("algorithmic = reference dense fp32 formulation (SURVEY 8d: 7.92 GFLOP per patch per unit), priced "
-                     "against the DENSE bf16 MFMA peak because the kernel runs on the bf16 pipe: fp32-equivalent results "
-                     "from 6 bf16 MFMA terms per product (3-way split), after the exact per-point P/Q fold (5.4x fewer "
-                     "MACs than the reference formulation); executed_* counts the bf16 MFMA flops actually issued")
-        else:
-            kname, peak = "edgeconv_kernel<GB=2,NCONV=4,ODIM=128> (unit 3, v_mfma_f32_16x16x4_f32)", FP32_MFMA_PEAK_TF
-            ec_exec = T * 352 * 2048.0                  # executed: 352 f32 MFMAs (16x16x4) per point
-            basis = ("algorithmic = reference dense formulation (SURVEY 8d: 7.92 GFLOP per patch per unit); frac > 1 because "
-                     "the kernel EXECUTES 5.4x fewer flops (exact per-point P/Q fold); executed_frac = MFMA utilisation")
+        # (kernel, pipe peak, MFMAs executed per point, flops per MFMA, MFMAs per point that are not split overhead)
+        KERNELS = {
+            "f16n": ("edgeconv4_kernel<P=1,NW=16> (units 2-5, split-fp16 natural-scale low half, v_mfma_f32_16x16x32_f16)",
+                     "edgeconv4_kernel", BF16_MFMA_PEAK_TF, 132, 16384.0, 44),
+            "f16x2": ("edgeconv3_kernel<NCONV=4,ODIM=128,NS=2> (units 2-5, split-fp16, v_mfma_f32_16x16x32_f16)",
+                      "edgeconv3_kernel", BF16_MFMA_PEAK_TF, 132, 16384.0, 44),
+            "bf16x3": ("edgeconv3_kernel<NCONV=4,ODIM=128,NS=3> (units 2-5, split-bf16, v_mfma_f32_16x16x32_bf16)",
+                       "edgeconv3_kernel", BF16_MFMA_PEAK_TF, 264, 16384.0, 44),
+            "f32": ("edgeconv_kernel<GB=2,NCONV=4,ODIM=128> (units 2-5, v_mfma_f32_16x16x4_f32)",
+                    "edgeconv_kernel<2, 4, 128", FP32_MFMA_PEAK_TF, 352, 2048.0, 352),
+        }
+        kname, kprefix, peak, n_mfma, fl_mfma, n_useful = KERNELS[eng.ec_mode]
+        ec_exec = T * n_mfma * fl_mfma                  # MFMA flops actually issued per launch
+        # roofline.frac = EXECUTED matrix flops / dense peak of the pipe the kernel runs on (= MFMA utilisation at the
+        # nominal 2.4 GHz; rocprof's SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE gives the same ratio at the clock held).
+        # The reference-formulation figure (2 x 16 x 120 832 MAC per point, 5.4x what the P/Q fold leaves to
+        # execute) is kept as algorithmic_vs_fp16_peak; useful_frac discounts the split overhead as well (one of the
+        # three fp16 MFMAs of a product is "the" product, the other two buy fp32 accuracy).
         roof = {"bound": "mfma", "kernel": kname,
-                "achieved": ec_fl / (ec_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": ec_fl / (ec_ms * 1e-3) / 1e12 / peak, "traffic": None,
-                "flops_basis": basis,
-                "executed_achieved": ec_exec / (ec_ms * 1e-3) / 1e12,
-                "executed_frac": ec_exec / (ec_ms * 1e-3) / 1e12 / peak,
+                "achieved": ec_exec / (ec_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": ec_exec / (ec_ms * 1e-3) / 1e12 / peak, "traffic": None,
+                "flops_basis": f"executed: {n_mfma} MFMAs x {int(fl_mfma)} flop per point x {T} points per launch; live HIP-event "
+                               "duration on the launch stream",
+                "useful_frac": ec_exec / (ec_ms * 1e-3) / 1e12 / peak * n_useful / n_mfma,
+                "algorithmic_tflops": ec_fl / (ec_ms * 1e-3) / 1e12,
+                "algorithmic_vs_fp16_peak": ec_fl / (ec_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF,
                 "avg_launch_ms": ec_ms}
-        # HBM traffic of the dominant kernel: PMC counters are collected offline with rocprofv3 (bench.py cannot
-        # run under --pmc and time itself); the committed summary of the same command is read back here.
+        # HBM traffic and the profiler's own duration of the dominant kernel: PMC counters are collected offline with
+        # rocprofv3 (bench.py cannot run under --pmc and time itself); the committed summary of the same command is read
+        # back here so that every number of this object can be recomputed from profiles/ alone.
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pmc = json.load(f)["kernels"]
-            pref = "edgeconv3_kernel" if eng.ec_mode in ("f16x2", "bf16x3") else "edgeconv_kernel<2, 4, 128"
-            key = [k for k in pmc if k.startswith(pref)][0]
-            roof["traffic"] = pmc[key]["hbm_bytes_per_launch"]
-            roof["traffic_note"] = ("bytes per launch at 32 x 2048 from profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE x2 "
-                                    "+ WRITE_SIZE); algorithmic HBM bytes per launch = PQ 134.2 MB + idx 4.2 MB + out 33.6 MB")
+            key = [k for k in pmc if k.startswith(kprefix)][0]
+            roof["traffic"] = pmc[key].get("hbm_bytes_per_launch")
+            roof["profile"] = {"file": "profiles/pmc_latest.json", "kernel": key, "avg_launch_ms": pmc[key].get("avg_us", 0.0) / 1e3,
+                               "mfma_util_pct": pmc[key].get("mfma_util_pct"), "shader_clock_ghz": pmc[key].get("shader_clock_ghz")}
+            roof["traffic_note"] = ("bytes per launch at 32 x 2048 (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction); "
+                                    "algorithmic HBM bytes per launch = PQ 134.2 MB + idx 4.2 MB + out 33.6 MB")
         except Exception:
             pass
-        extra = {"stage_ms": prof,
-                 "knn_hbm": {"achieved": knn_bytes / (knn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "note": "kNN is VALU/selection-bound by construction (216 flop/B)"},
+        # kNN: north_star asks for HBM GB/s; the kernel is VALU/selection-bound by construction (216 flop/B), so the VALU
+        # fraction is the meaningful roofline: pair evaluations x ~17 VALU lane-slots per pair (csrc/knn.hip) against
+        # 1024 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s
+        pair_evals = float(args.batch) * args.npoint * args.npoint
+        roof_knn = {"kernel": "knn4_kernel<16>", "bound": "valu", "avg_launch_ms": knn_ms,
+                    "hbm": {"achieved": knn_bytes / (knn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": knn_bytes / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    "valu": {"pair_evals": pair_evals, "lane_slots_per_pair": 17, "achieved": pair_evals * 17 / (knn_ms * 1e-3) / 1e12,
+                             "peak": 39.3, "unit": "T lane-ops/s", "frac": pair_evals * 17 / (knn_ms * 1e-3) / 1e12 / 39.3}}
+        extra = {"stage_ms": prof, "roofline_knn": roof_knn,
                  "model_algorithmic_tflops": model_ref_flops_per_patch() * value / world / 1e12}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -213,18 +232,19 @@ def main():
                                "logp_note": "logp is a batch mean; compared in tests on equal batches"}
         out = {"metric": "patches/sec x4 2048->8192 (PU1K discrete, eval)", "value": value, "unit": "patches/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                # the arithmetic the path computes in: fp32 values, each product as 2-term split-fp16 on the fp16 MFMA
                # with fp32 accumulation (PF_EC_MODE=f32: plain f32 MFMA in the 128-channel EdgeConv units)
-               "dtype": "f32 (split-fp16 MFMA products, fp32 accumulate)" if eng.ec_mode == "f16x2" else
+               "dtype": "f32 (split-fp16 MFMA products, fp32 accumulate)" if eng.ec_mode in ("f16n", "f16x2") else
                         ("f32 (split-bf16 EdgeConv, split-fp16 elsewhere)" if eng.ec_mode == "bf16x3" else
                          "f32 (f32 MFMA EdgeConv, split-fp16 elsewhere)"),
                "data": "synthetic",
                "config": {"workload": "BASELINE configs[1]: PU1K discrete x4 inference, 32 x 2048-pt patches per GPU "
                                       "(fp32-parity mode)", "arithmetic": "fp32 inputs, accumulators and results; the dense layers run as 2-term split-fp16 "
                           "products on the fp16 MFMA pipe (hi.hi + hi.lo + lo.hi, fp32-class accuracy: parity tests hold the "
-                          "same 1e-5 bar; PF_EC_MODE=bf16x3 / f32 select the split-bf16 / bit-exact f32 EdgeConv kernels)", "launch": "hipGraph replay (one launch per step)" if use_graph else "eager (18 launches per step)",
-                          "patches_per_gpu": args.batch, "npoint": args.npoint,
+                          "same 1e-5 bar; PF_EC_MODE=f16x2 / bf16x3 / f32 select the earlier split-fp16, the split-bf16 and the bit-exact f32 EdgeConv kernels)", "launch": "hipGraph replay (one launch per step)" if use_graph else "eager (18 launches per step)",
+                          "patches_per_gpu": args.batch, "total_batch": args.total_batch if args.scaling == "strong" else world * args.batch,
+                          "npoint": args.npoint,
                           "upratio": 4, "sharding": f"patch batch over {world} rank(s), no data-path collective"},
                "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)

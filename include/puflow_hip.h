@@ -58,10 +58,17 @@ int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, const int* id
 int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, const float* tab, const int* idx,
                       const float* wfrag, float* out, int B, int N, void* stream);
 
-/* Per-point stage after EdgeConv unit `unit` (0..5): FeatMergeUnit (interpflow.py:251-258), the
- * injector conditioner nets (coupling.py:132-134), coupling1's c-part and the next unit's PQ.
- * off[12] = float offsets into `w` of: M1,b1,M2,H1,S2,bS2,T2,bT2,ST4,bST4,PQ,bPQ.
- * c [T,cdim] (nullable), st [T,8], cp [T,64], pq_next [T,2S'] (NULL allowed for unit 5 only). */
+/* Per-point stages after EdgeConv unit `unit` (0..5).  off[13] = float offsets into the blob `w` of
+ * M1,b1,M2,H1,S2,bS2,T2,bT2,ST4,bST4,PQ,bPQ,scales (packing.POST_SLOTS; f16n fragment images + per-matrix 2^-sw).
+ *
+ * pf_pq_gemm (unit 0..4): next unit's per-point EdgeConv vectors  PQ' = Wpq h + bpq  -> pq_next [T, 2S']
+ *   (the exact per-point fold of the edge feature [x_i, x_j, x_j - x_i], interpflow.py:229-232; packing.fold_edgeconv).
+ * pf_cond (unit 0..5): FeatMergeUnit (interpflow.py:251-258), the injector conditioner nets (coupling.py:132-134,
+ *   interpflow.py:22-43) and coupling1's c-part: c [T,cdim] (nullable), st [T,8], cp [T,64].
+ * pf_post = both, one call per unit (pq_next may be NULL for unit 5 only). */
+int pf_pq_gemm(int unit, const float* h, const float* w, const long long* off, float* pq_next, int T, void* stream);
+int pf_cond(int unit, const float* h, const float* w, const long long* off, float* c, float* st, float* cp, int T,
+            void* stream);
 int pf_post(int unit, const float* h, const float* w, const long long* off, float* c, float* st, float* cp,
             float* pq_next, int T, void* stream);
 

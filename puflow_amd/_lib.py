@@ -23,6 +23,8 @@ SIGNATURES = {
                                   c_void_p]),
     "pf_post": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                         c_void_p]),
+    "pf_pq_gemm": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_int, c_void_p]),
+    "pf_cond": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pf_flow_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pf_flow_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pf_logp": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

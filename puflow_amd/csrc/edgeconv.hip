@@ -322,95 +322,6 @@ int launch3(const EcArgs& a0, hipStream_t s) {
 // max over K = 16 is 2 in-lane max + a reduce-scatter over the 4 lane rows (v_permlane32_swap / v_permlane16_swap):
 // 28 VALU per point instead of 160.  Its accumulators are initialised with Q[j] alone (dword gathers, 64 B per 16 lanes);
 // P[i] is added once per channel after the max.  VALU per point: ~180 (edgeconv3_kernel<NS=2>: ~450).
-struct PfPairN { h8 h, l; };
-__device__ __forceinline__ unsigned pf_pk_f16(float a, float b) {
-    return __builtin_bit_cast(unsigned, (h2){(_Float16)a, (_Float16)b});          // v_cvt_pk_f16_f32 (RNE)
-}
-__device__ __forceinline__ PfPairN pf_pairn(f4 b0, f4 b1) {
-    const unsigned h0 = pf_pk_f16(b0.x, b0.y), h1 = pf_pk_f16(b0.z, b0.w), h2_ = pf_pk_f16(b1.x, b1.y), h3 = pf_pk_f16(b1.z, b1.w);
-    unsigned l0, l1, l2, l3;
-    // lo = fp16(x - hi) as fma(hi, -1, x); the trailing s_nop covers VALU write -> MFMA operand read (hipcc pads nothing
-    // for registers written inside an asm statement)
-    asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "s_nop 1"
-        : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
-        : "v"(h0), "v"(h1), "v"(h2_), "v"(h3), "v"(b0.x), "v"(b0.y), "v"(b0.z), "v"(b0.w), "v"(b1.x), "v"(b1.y), "v"(b1.z), "v"(b1.w));
-    PfPairN p;
-    p.h = __builtin_bit_cast(h8, (u4){h0, h1, h2_, h3});
-    p.l = __builtin_bit_cast(h8, (u4){l0, l1, l2, l3});
-    return p;
-}
-
-// reduce-scatter max steps: (a, b) -> lanes 0..31 get max over both halves of a, lanes 32..63 of b;  rows: the same
-// between odd and even 16-lane rows.  Inline asm because the builtin's two results are mis-paired by hipcc 7.2 once they
-// are bit-cast to float; the leading s_nop is the VALU write -> permlane read hazard.
-__device__ __forceinline__ float pf_rsmax32(float a, float b) {
-    unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    return fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
-}
-__device__ __forceinline__ float pf_rsmax16(float a, float b) {
-    unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    return fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
-}
-
-// acc[p][o] += W[o][cp] feat[p][cp] over CP block pairs, three fp16 MFMAs per pair into the one accumulator (small terms
-// first).  SWAP = false: D[channel][edge] (weights are the A operand);  SWAP = true: D[edge][channel].
-#ifndef PF_EC4_DEPTH
-#define PF_EC4_DEPTH 2
-#endif
-#ifndef PF_EC4_CPMAJOR
-#define PF_EC4_CPMAJOR 0
-#endif
-template <bool SWAP, int OB, int CP, int WCP, int D = PF_EC4_DEPTH, class WS, int P, int NIN>
-__device__ __forceinline__ void ec_mmn(const WS& ws, int frag0, const PfPairN (&feat)[P][NIN], f4 (&acc)[P][OB]) {
-    constexpr int NFRAG = OB * CP;
-    constexpr int DD = D < NFRAG ? D : NFRAG;
-    // fragment walk: ob-major (one accumulator's whole chain, then the next) or cp-major (accumulators alternate)
-    auto OBI = [](int i) { return PF_EC4_CPMAJOR ? i % OB : i / CP; };
-    auto CPI = [](int i) { return PF_EC4_CPMAJOR ? i / OB : i % CP; };
-    h8 wb[DD][2];
-#pragma unroll
-    for (int i = 0; i < DD; ++i)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) wb[i][s] = ws.load(frag0 + OBI(i) * WCP + CPI(i), s);
-#pragma unroll
-    for (int i = 0; i < NFRAG; ++i) {
-        const int ob = OBI(i), cp = CPI(i);
-        const h8 wh = wb[i % DD][0], wl = wb[i % DD][1];
-        if (i + DD < NFRAG) {
-            const int f = frag0 + OBI(i + DD) * WCP + CPI(i + DD);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) wb[i % DD][s] = ws.load(f, s);
-        }
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            f4 x = acc[p][ob];
-            if constexpr (SWAP) {
-                x = pf_mfma_f16(feat[p][cp].l, wh, x);
-                x = pf_mfma_f16(feat[p][cp].h, wl, x);
-                x = pf_mfma_f16(feat[p][cp].h, wh, x);
-            } else {
-                x = pf_mfma_f16(wh, feat[p][cp].l, x);
-                x = pf_mfma_f16(wl, feat[p][cp].h, x);
-                x = pf_mfma_f16(wh, feat[p][cp].h, x);
-            }
-            acc[p][ob] = x;
-        }
-#ifndef PF_EC4_NOSB
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-}
-
 constexpr float EC4_OUT_INV = 1.f / 256.f;       // conv_out accumulators hold 4^4 y (packing.ec4_scales)
 
 template <int P, int NW, int DBG = 0>      // DBG bit mask (-DPF_TUNING_VARIANTS timing builds only; wrong results): 1 no gathers, 2 no MFMAs, 4 no LDS weight reads
@@ -512,7 +423,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
             for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][ob] = ini[t & 1][p][ob] + p_g(p, t, ob);
-            if constexpr (!(DBG & 2)) ec_mmn<false, 2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, acc);
+            if constexpr (!(DBG & 2)) pf_mmn<false, 2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, acc);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if constexpr (DBG & 8) { feat[p][t] = feat[p][0]; feat[p][t].h[0] += (_Float16)acc[p][0].x; continue; }
@@ -531,7 +442,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
             for (int o = 0; o < OCH; ++o)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][o] = ini[st & 1][p][o];
-            if constexpr (!(DBG & 2)) ec_mmn<true, OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, acc);
+            if constexpr (!(DBG & 2)) pf_mmn<true, OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, acc);
 #pragma unroll
             for (int o = 0; o < OCH; ++o)
 #pragma unroll

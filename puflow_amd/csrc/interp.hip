@@ -11,11 +11,12 @@
 // Every term that is affine in the edge's raw inputs e = (x_i, x_j, |x_i - x_j|, 1) - the distance encoder's first
 // layer, the EdgeConv pre-activations, the bracket above - is one MFMA step against an 8-column "edge table"
 // (e occupies 8 of the 32 k-slots).  Only the first R rows of the last weight conv are computed (interpflow.py:180).
-// Arithmetic: split-fp16 products (pf_mfma.h "f16x2"), fp32-class accuracy; 91 fragment pairs = 273 fp16 MFMAs
-// per tile where the unfolded f32 formulation needs 1216.
+// Arithmetic: split-fp16 products with a natural-scale low half (pf_mfma.h "f16n": one accumulator, no fold), fp32-class
+// accuracy; 91 fragment pairs = 273 fp16 MFMAs per tile where the unfolded f32 formulation needs 1216.  Matrices that
+// share an accumulator share a power-of-two scale (packing.INTERP_SCALES); the kernel multiplies by its inverse.
 //
 // Weight blob (float offsets in `off[]`, see puflow_amd/packing.py::INTERP_SLOTS); matrices are f16x2 fragment images:
-//   0 dtab [64 x e]        1 d_W3 [64 x 64]     2 d_b3 [64] f32      3 (W0a W6) [128 x 64]    4 reserved
+//   0 dtab [64 x e]        1 d_W3 [64 x 64]     2 d_b3 [64] f32      3 (W0a W6) [128 x 64]    4 scales [6] f32
 //   5 ectab [128 x e]      6 ec G1..G7 (16 pair fragments; layer t starts at fragment floor(t/2) * ceil(t/2))
 //   7 (W0b Gout) [128 x 128]   8 w1tab [128 x e] (bracket above)   9 w_W3 [64 x 128]  10 w_b3 [64] f32
 //   11 w_W6 [16 x 64] (rows 0..3 replicated per q group: the R <= 4 fast path)   12 w_b6 [16] f32
@@ -29,7 +30,7 @@
 #define PF_INTERP_P 1
 #endif
 #ifndef PF_INTERP_NW
-#define PF_INTERP_NW 8
+#define PF_INTERP_NW 12
 #endif
 
 namespace {
@@ -50,9 +51,9 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
     const int ps = col >> 3, k = col & 7;
-    // the small, latency-critical matrices (edge tables, d_W3, the 7-step growth chain) live in LDS for the whole
-    // persistent workgroup: 44 fragments x 2 KiB; the three big ones stream from L2 with a deep prefetch
-    constexpr int L_DT = 0, L_ET = 4, L_WT = 12, L_D3 = 20, L_EC = 28, L_END = 44;
+    // everything but the 64 KiB (W0b Gout) image lives in LDS for the whole persistent workgroup: 76 fragments x 2 KiB
+    // = 152 KiB (edge tables, d_W3, the 7-step growth chain, (W0a W6), w_W3); (W0b Gout) streams from L2, 4 fragments ahead
+    constexpr int L_DT = 0, L_ET = 4, L_WT = 12, L_D3 = 20, L_EC = 28, L_D6 = 44, L_W3 = 60, L_END = 76;
     __shared__ u4 wl[L_END * 128];
     {
         auto stage = [&](int f0, int nf, long long off) {
@@ -60,19 +61,22 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
             for (int i = threadIdx.x; i < nf * 128; i += blockDim.x) wl[f0 * 128 + i] = src[i];
         };
         stage(L_DT, 4, a.off[0]); stage(L_ET, 8, a.off[5]); stage(L_WT, 8, a.off[8]); stage(L_D3, 8, a.off[1]);
-        stage(L_EC, 16, a.off[6]);
+        stage(L_EC, 16, a.off[6]); stage(L_D6, 16, a.off[3]); stage(L_W3, 16, a.off[9]);
         __syncthreads();
     }
     const PfW2Lds wsDT{wl + L_DT * 128, lane}, wsET{wl + L_ET * 128, lane}, wsWT{wl + L_WT * 128, lane},
-        wsD3{wl + L_D3 * 128, lane}, wsEC{wl + L_EC * 128, lane};
-    const PfW2Buf wsD6(a.w + a.off[3], lane), wsW0(a.w + a.off[7], lane), wsW3(a.w + a.off[9], lane),
-        wsW6(a.w + a.off[BIG ? 13 : 11], lane);
+        wsD3{wl + L_D3 * 128, lane}, wsEC{wl + L_EC * 128, lane}, wsD6{wl + L_D6 * 128, lane}, wsW3{wl + L_W3 * 128, lane};
+    const PfW2BufD<4> wsW0(a.w + a.off[7], lane);
+    const PfW2BufD<2> wsW6(a.w + a.off[BIG ? 13 : 11], lane);
+
+    const float* sc = a.w + a.off[4];
+    const float iDT = sc[0], iD3 = sc[1], iW1 = sc[2], iEC = sc[3], iW3 = sc[4], iW6 = sc[5];
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int pt0 = (tile * NW + wave) * P * 2;
         int gi[P], gj[P];
         bool ok[P];
-        PfPair2 e[P][1];                 // raw edge inputs (x_i, x_j, |x_i - x_j|, 1) in k-slots 0..7 (lanes q = 0)
+        PfPairN e[P][1];                 // raw edge inputs (x_i, x_j, |x_i - x_j|, 1) in k-slots 0..7 (lanes q = 0)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int g = pt0 + p * 2 + ps;
@@ -89,58 +93,24 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
             const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(v0, v0), __fmul_rn(v1, v1)), __fmul_rn(v2, v2)));
             const f4 z4 = pf_splat(0.f);
             const f4 e0 = {xi[0], xi[1], xi[2], xj[0]}, e1 = {xj[1], xj[2], nrm, 1.f};
-            e[p][0] = pf_pair2(q == 0 ? e0 : z4, q == 0 ? e1 : z4);
-        }
-
-        // ---- distance encoder 10 -> 64 -> 64, then its (folded) contribution to the weight unit's first layer
-        f4 w1[P][8];
-        {
-            f4 d[P][4];
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int p = 0; p < P; ++p) d[p][cb] = pf_splat(0.f);
-            pf_mm2f<4, 1, 1>(wsDT, 0, e, 0, d, 0);
-            PfPair2 dp[P][2];
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                dp[p][0] = pf_pair2(pf_lrelu(d[p][0], 0.01f), pf_lrelu(d[p][1], 0.01f));
-                dp[p][1] = pf_pair2(pf_lrelu(d[p][2], 0.01f), pf_lrelu(d[p][3], 0.01f));
-            }
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int p = 0; p < P; ++p) d[p][cb] = pf_bias(a.w + a.off[2], cb, q);
-            pf_mm2f<4, 2, 2>(wsD3, 0, dp, 0, d, 0);
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                dp[p][0] = pf_pair2(pf_lrelu(d[p][0], 0.01f), pf_lrelu(d[p][1], 0.01f));
-                dp[p][1] = pf_pair2(pf_lrelu(d[p][2], 0.01f), pf_lrelu(d[p][3], 0.01f));
-            }
-            // w1 = [b0 + W0a b6 + W0b.(edge table)] e + (W0a W6) d2
-#pragma unroll
-            for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-                for (int p = 0; p < P; ++p) w1[p][ob] = pf_splat(0.f);
-            pf_mm2f<4, 1, 1>(wsWT, 0, e, 0, w1, 0);
-            pf_mm2f<4, 1, 1>(wsWT, 4, e, 0, w1, 4);
-            pf_mm2f<4, 2, 2>(wsD6, 0, dp, 0, w1, 0);
-            pf_mm2f<4, 2, 2>(wsD6, 8, dp, 0, w1, 4);
+            e[p][0] = pf_pairn(q == 0 ? e0 : z4, q == 0 ? e1 : z4);
         }
 
         // ---- EdgeConv growth features (C=3, g=16, 8 convs) on the same 8 neighbours; conv_out is folded into w1
+        // (first: its 8-layer dependent chain sets the tile's latency and needs the fewest live registers)
+        f4 w1[P][8];
         {
-            PfPair2 fp[P][4];
+            PfPairN fp[P][4];
             f4 last[P];
             {
                 f4 acc[P][1];
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][0] = pf_splat(0.f);
-                pf_mm2f<1, 1, 1>(wsET, 0, e, 0, acc, 0);                 // pre-activation from the raw inputs (edge table)
+                pf_mmn<false, 1, 1, 1>(wsET, 0, e, acc);                 // pre-activation from the raw inputs (edge table)
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    last[p] = pf_lrelu(acc[p][0], 0.05f);
-                    fp[p][0] = pf_pair2(last[p], pf_splat(0.f));
+                    last[p] = pf_lrelu(acc[p][0] * iEC, 0.05f);
+                    fp[p][0] = pf_pairn(last[p], pf_splat(0.f));
                 }
             }
             pf_static_for<1, 8>([&](auto tc) {
@@ -150,46 +120,86 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
                 f4 acc[P][1];
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p][0] = pf_splat(0.f);
-                pf_mm2f<1, 1, 1>(wsET, t, e, 0, acc, 0);
-                pf_mm2f<1, CPT, CPT>(wsEC, F0, fp, 0, acc, 0);
+                pf_mmn<false, 1, 1, 1>(wsET, t, e, acc);
+                pf_mmn<false, 1, CPT, CPT>(wsEC, F0, fp, acc);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    const f4 f = pf_lrelu(acc[p][0], 0.05f);
-                    if constexpr (t % 2 == 1) fp[p][t / 2] = pf_pair2(last[p], f);
-                    else fp[p][t / 2] = pf_pair2(f, pf_splat(0.f));
+                    const f4 f = pf_lrelu(acc[p][0] * iEC, 0.05f);
+                    if constexpr (t % 2 == 1) fp[p][t / 2] = pf_pairn(last[p], f);
+                    else fp[p][t / 2] = pf_pairn(f, pf_splat(0.f));
                     last[p] = f;
                 }
             });
-            pf_mm2f<4, 4, 4>(wsW0, 0, fp, 0, w1, 0);               // w1 += (W0b Gout) feat, two chunks of 4 output blocks
-            pf_mm2f<4, 4, 4>(wsW0, 16, fp, 0, w1, 4);
+            // w1 = [b0 + W0a b6 + W0b.(edge table)] e + (W0b Gout) feat
+#pragma unroll
+            for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+                for (int p = 0; p < P; ++p) w1[p][ob] = pf_splat(0.f);
+            pf_mmn<false, 4, 1, 1>(wsWT, 0, e, w1, 0, 0);
+            pf_mmn<false, 4, 1, 1>(wsWT, 4, e, w1, 0, 4);
+            pf_mmn<false, 4, 4, 4>(wsW0, 0, fp, w1, 0, 0);            // two chunks of 4 output blocks
+            pf_mmn<false, 4, 4, 4>(wsW0, 16, fp, w1, 0, 4);
+        }
+
+        // ---- distance encoder 10 -> 64 -> 64, then its (folded) contribution to the weight unit's first layer
+        {
+            f4 d[P][4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int p = 0; p < P; ++p) d[p][cb] = pf_splat(0.f);
+            pf_mmn<false, 4, 1, 1>(wsDT, 0, e, d);
+            PfPairN dp[P][2];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                dp[p][0] = pf_pairn(pf_lrelu(d[p][0] * iDT, 0.01f), pf_lrelu(d[p][1] * iDT, 0.01f));
+                dp[p][1] = pf_pairn(pf_lrelu(d[p][2] * iDT, 0.01f), pf_lrelu(d[p][3] * iDT, 0.01f));
+            }
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int p = 0; p < P; ++p) d[p][cb] = pf_bias(a.w + a.off[2], cb, q);
+            pf_mmn<false, 4, 2, 2>(wsD3, 0, dp, d);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                dp[p][0] = pf_pairn(pf_lrelu(d[p][0] * iD3, 0.01f), pf_lrelu(d[p][1] * iD3, 0.01f));
+                dp[p][1] = pf_pairn(pf_lrelu(d[p][2] * iD3, 0.01f), pf_lrelu(d[p][3] * iD3, 0.01f));
+            }
+            // w1 += (W0a W6) d2
+            pf_mmn<false, 4, 2, 2>(wsD6, 0, dp, w1, 0, 0);
+            pf_mmn<false, 4, 2, 2>(wsD6, 8, dp, w1, 0, 4);
         }
 
         // ---- rest of the weight unit: 128 -> 64 -> R
         f4 w3[P][BIG ? 2 : 1];
         {
-            PfPair2 w1p[P][4];
+            PfPairN w1p[P][4];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    w1p[p][c] = pf_pair2(pf_lrelu(w1[p][2 * c], 0.01f), pf_lrelu(w1[p][2 * c + 1], 0.01f));
+                    w1p[p][c] = pf_pairn(pf_lrelu(w1[p][2 * c] * iW1, 0.01f), pf_lrelu(w1[p][2 * c + 1] * iW1, 0.01f));
             f4 w2[P][4];
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
                 for (int p = 0; p < P; ++p) w2[p][ob] = pf_bias(a.w + a.off[10], ob, q);
-            pf_mm2f<4, 4, 4>(wsW3, 0, w1p, 0, w2, 0);
-            PfPair2 w2p[P][2];
+            pf_mmn<false, 4, 4, 4>(wsW3, 0, w1p, w2);
+            PfPairN w2p[P][2];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                w2p[p][0] = pf_pair2(pf_lrelu(w2[p][0], 0.01f), pf_lrelu(w2[p][1], 0.01f));
-                w2p[p][1] = pf_pair2(pf_lrelu(w2[p][2], 0.01f), pf_lrelu(w2[p][3], 0.01f));
+                w2p[p][0] = pf_pairn(pf_lrelu(w2[p][0] * iW3, 0.01f), pf_lrelu(w2[p][1] * iW3, 0.01f));
+                w2p[p][1] = pf_pairn(pf_lrelu(w2[p][2] * iW3, 0.01f), pf_lrelu(w2[p][3] * iW3, 0.01f));
             }
 #pragma unroll
             for (int p = 0; p < P; ++p)
 #pragma unroll
                 for (int ob = 0; ob < (BIG ? 2 : 1); ++ob) w3[p][ob] = pf_bias(a.w + a.off[BIG ? 14 : 12], ob, q);
-            pf_mm2f<(BIG ? 2 : 1), 2, 2>(wsW6, 0, w2p, 0, w3, 0);
+            pf_mmn<false, (BIG ? 2 : 1), 2, 2>(wsW6, 0, w2p, w3);
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int ob = 0; ob < (BIG ? 2 : 1); ++ob) w3[p][ob] = w3[p][ob] * iW6;
         }
 
         // ---- softmax over the 8 neighbours (lanes k = 0..7 of the point), then weighted latent sum
@@ -250,13 +260,14 @@ extern "C" int pf_interp(const float* xyz, const float* z, const int* idx16, con
     if (!xyz || !z || !idx16 || !w || !off || !u_out) return PF_ERR_NULL;
     if (B <= 0 || N < 8 || (long long)B * N > (1ll << 28)) return PF_ERR_SHAPE;
     if (R < 1 || R > 32) return PF_ERR_UNSUPPORTED;          // r_max of WeightEstimationUnit (interpflow.py:142)
-    constexpr int P = PF_INTERP_P, NW = PF_INTERP_NW;
+    constexpr int P = PF_INTERP_P, NW = PF_INTERP_NW, NWB = 8;      // the R > 4 variant needs more registers: 2 waves per SIMD
     InterpArgs a{};
     a.xyz = xyz; a.z = z; a.idx = idx16; a.w = w; a.u = u_out; a.T = B * N; a.N = N; a.R = R;
     for (int i = 0; i < 15; ++i) a.off[i] = off[i];
-    a.ntiles = (a.T + NW * P * 2 - 1) / (NW * P * 2);
-    const int grid = a.ntiles < 256 ? a.ntiles : 256;         // persistent: 88 KiB of LDS = one workgroup per CU
+    const int nw = R <= 4 ? NW : NWB;
+    a.ntiles = (a.T + nw * P * 2 - 1) / (nw * P * 2);
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;         // persistent: 152 KiB of LDS = one workgroup per CU
     if (R <= 4) hipLaunchKernelGGL((interp_kernel<P, NW, false>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((interp_kernel<P, NW, true>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((interp_kernel<P, NWB, true>), dim3(grid), dim3(NWB * 64), 0, (hipStream_t)stream, a);
     return pf_last_launch_status();
 }

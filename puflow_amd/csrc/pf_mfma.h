@@ -247,6 +247,18 @@ struct PfW2Lds {
     }
 };
 
+template <int DEPTH_>
+struct PfW2BufD {
+    static constexpr int DEPTH = DEPTH_;
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;           // lane * 16
+    __device__ __forceinline__ PfW2BufD(const void* p, int lane)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000)), voff(lane * 16) {}
+    __device__ __forceinline__ h8 load(int frag, int split) const {
+        return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (frag * 2 + split) * (PF_WAVE * 16), 0));
+    }
+};
+
 struct PfW2Buf {
     static constexpr int DEPTH = PF_MM2_DEPTH;   // L2 latency wants ~500 cycles of MFMA work in flight
     __amdgpu_buffer_rsrc_t rsrc;
@@ -318,6 +330,98 @@ __device__ __forceinline__ void pf_mm2f(const WS2& ws, int frag0, const PfPair2 
 #pragma unroll
         for (int o = 0; o < OB; ++o) acc[p][acc0 + o] = accm[p][o] + accx[p][o] * PF_LO_INV;
 }
+
+// ---- split-fp16 with a NATURAL-scale low half ("f16n"): one accumulator, no fold ----------------------------------
+// x = hi + lo, hi = rne_f16(x), lo = rne_f16(x - hi) written straight into the packed operand by v_fma_mixlo/mixhi_f16
+// (3 VALU per value pair instead of 9).  gfx950's fp16 MFMA honours subnormal operands, so a small lo keeps an ABSOLUTE
+// precision of 2^-25 in the units the operand is stored in; hosts keep that floor far below fp32 rounding by storing the
+// weights scaled by a power of two (packing.frag_pack_f16n: max |W'| in [2^13, 2^14)) and, where the range allows,
+// the activations too.  All three product terms (hi.hi, hi.lo, lo.hi) go into ONE fp32 accumulator.
+struct PfPairN { h8 h, l; };
+__device__ __forceinline__ unsigned pf_pk_f16(float a, float b) {
+    return __builtin_bit_cast(unsigned, (h2){(_Float16)a, (_Float16)b});          // v_cvt_pk_f16_f32 (RNE)
+}
+__device__ __forceinline__ PfPairN pf_pairn(f4 b0, f4 b1) {
+    const unsigned h0 = pf_pk_f16(b0.x, b0.y), h1 = pf_pk_f16(b0.z, b0.w), h2_ = pf_pk_f16(b1.x, b1.y), h3 = pf_pk_f16(b1.z, b1.w);
+    unsigned l0, l1, l2, l3;
+    // lo = fp16(x - hi) as fma(hi, -1, x); the trailing s_nop covers VALU write -> MFMA operand read (hipcc pads nothing
+    // for registers written inside an asm statement)
+    asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(h0), "v"(h1), "v"(h2_), "v"(h3), "v"(b0.x), "v"(b0.y), "v"(b0.z), "v"(b0.w), "v"(b1.x), "v"(b1.y), "v"(b1.z), "v"(b1.w));
+    PfPairN p;
+    p.h = __builtin_bit_cast(h8, (u4){h0, h1, h2_, h3});
+    p.l = __builtin_bit_cast(h8, (u4){l0, l1, l2, l3});
+    return p;
+}
+
+// reduce-scatter max steps: (a, b) -> lanes 0..31 get max over both halves of a, lanes 32..63 of b;  rows: the same
+// between odd and even 16-lane rows.  Inline asm because the builtin's two results are mis-paired by hipcc 7.2 once they
+// are bit-cast to float; the leading s_nop is the VALU write -> permlane read hazard.
+__device__ __forceinline__ float pf_rsmax32(float a, float b) {
+    unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
+}
+__device__ __forceinline__ float pf_rsmax16(float a, float b) {
+    unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
+}
+
+// acc[p][o] += W[o][cp] feat[p][cp] over CP block pairs, three fp16 MFMAs per pair into the one accumulator (small terms
+// first).  SWAP = false: D[channel][edge] (weights are the A operand);  SWAP = true: D[edge][channel].
+#ifndef PF_MMN_CPMAJOR
+#define PF_MMN_CPMAJOR 0
+#endif
+template <bool SWAP, int OB, int CP, int WCP, class WS, int P, int NIN, int NACC>
+__device__ __forceinline__ void pf_mmn(const WS& ws, int frag0, const PfPairN (&feat)[P][NIN], f4 (&acc)[P][NACC], int in0 = 0, int acc0 = 0) {
+    constexpr int D = WS::DEPTH;                  // fragments in flight: 2 from LDS, 8 behind buffer loads (L2 latency)
+    constexpr int NFRAG = OB * CP;
+    constexpr int DD = D < NFRAG ? D : NFRAG;
+    // fragment walk: ob-major (one accumulator's whole chain, then the next) or cp-major (accumulators alternate)
+    auto OBI = [](int i) { return PF_MMN_CPMAJOR ? i % OB : i / CP; };
+    auto CPI = [](int i) { return PF_MMN_CPMAJOR ? i / OB : i % CP; };
+    h8 wb[DD][2];
+#pragma unroll
+    for (int i = 0; i < DD; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wb[i][s] = ws.load(frag0 + OBI(i) * WCP + CPI(i), s);
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) {
+        const int ob = OBI(i), cp = CPI(i);
+        const h8 wh = wb[i % DD][0], wl = wb[i % DD][1];
+        if (i + DD < NFRAG) {
+            const int f = frag0 + OBI(i + DD) * WCP + CPI(i + DD);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) wb[i % DD][s] = ws.load(f, s);
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            f4 x = acc[p][acc0 + ob];
+            if constexpr (SWAP) {
+                x = pf_mfma_f16(feat[p][in0 + cp].l, wh, x);
+                x = pf_mfma_f16(feat[p][in0 + cp].h, wl, x);
+                x = pf_mfma_f16(feat[p][in0 + cp].h, wh, x);
+            } else {
+                x = pf_mfma_f16(wh, feat[p][in0 + cp].l, x);
+                x = pf_mfma_f16(wl, feat[p][in0 + cp].h, x);
+                x = pf_mfma_f16(wh, feat[p][in0 + cp].h, x);
+            }
+            acc[p][acc0 + ob] = x;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 
 // cooperative global -> LDS copy of `nf4` float4 by the whole workgroup (call before a __syncthreads)
 __device__ __forceinline__ void pf_stage_lds(f4* __restrict__ dst, const f4* __restrict__ src, int nf4) {

@@ -1,214 +1,304 @@
-// Per-point stage that follows each EdgeConv unit (one launch per unit):
-//   c   = W2 relu(W1 h + b1)                         FeatMergeUnit   (interpflow.py:251-258)
-//   (c itself is written only on request: W2 is folded into the first layers of the three nets below)
-//   s,t = LinearA1D_s(c), LinearA1D_t(c)             AffineInjectorLayer nets (coupling.py:132-134,
-//                                                    interpflow.py:22-43) - depend on c only, so they
-//                                                    are computed once per ORIGINAL point and shared by
-//                                                    f and by the R replicas of g
-//   cp  = W0[:, tdim:] c                             c-part of coupling1's first layer (interpflow.py:38-41)
-//   PQ' = Wpq h + bpq                                next unit's per-point EdgeConv vectors (packing.py)
-// MFMA columns = 16 points; all intermediates stay in registers (pf_mfma.h layout).  Arithmetic: split-fp16
-// products (pf_mfma.h "f16x2": three fp16 MFMAs per 32-channel step, fp32-class accuracy); weights arrive
-// pre-split from the host (packing.frag_pack_f16x2) and stream through buffer loads (they stay in L1/L2).
+// Per-point stages that follow each EdgeConv unit, as two kernels:
+//
+//   pf_pq_gemm   PQ' = Wpq h + bpq        next unit's per-point EdgeConv vectors P | Q (packing.py: the exact per-point fold
+//                                         of the edge feature [x_i, x_j, x_j - x_i], interpflow.py:229-232)
+//   pf_cond      c   = W2 relu(W1 h + b1)                     FeatMergeUnit   (interpflow.py:251-258)
+//                s,t = LinearA1D_s(c), LinearA1D_t(c)         AffineInjectorLayer nets (coupling.py:132-134,
+//                                                             interpflow.py:22-43): they depend on c only, so they are
+//                                                             computed once per ORIGINAL point, shared by f and the R replicas of g
+//                cp  = W0[:, tdim:] c                         c-part of coupling1's first layer (interpflow.py:38-41)
+//                (c itself is written only on request: W2 is folded into the first layers of the three nets)
+//
+// Arithmetic of both: split-fp16 products with a natural-scale low half (pf_mfma.h "f16n": three fp16 MFMAs per
+// 32-channel step into one fp32 accumulator); weights arrive pre-split and pre-scaled by a power of two per matrix
+// (packing.frag_pack_f16n_scaled), the kernels multiply by its inverse.
+//
+// pf_pq_gemm is the [2S x ODIM] x [ODIM x T] GEMM that produces 134 MB per launch at 32 x 2048 points: its roofline is
+// the HBM write.  Mapping: the WEIGHTS are register-resident (a wave owns 16 RB output rows for the whole launch: RB x CP
+// fragment pairs = 64 VGPRs at ODIM = 128), the POINTS stream: a round stages NT tiles of 16 points in LDS as ready-made
+// B operands (every wave converts 1 / NW of the round's tiles: fp32 -> (hi, lo) once per point, not once per consumer),
+// then every wave multiplies every tile by its rows.  LDS bytes per MFMA are half of what streaming the weights would
+// need, no weight byte is re-read from L2 after the prologue, and the operand split costs 1/16 of the VALU work.
+//
+// pf_cond keeps its 120 KiB of weights in LDS for the life of a persistent workgroup (one wave = 16 points).
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
 
-#ifndef PF_POST_P
-#define PF_POST_P 2
-#endif
-#ifndef PF_POST_NW
-#define PF_POST_NW 4
-#endif
-
 namespace {
 
-struct PostArgs {
+__device__ __forceinline__ h8 pf_ldw(const u4* p) { return __builtin_bit_cast(h8, *p); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct PqArgs {
+    const float* h;       // [T, ODIM]
+    const u4* w;          // f16n fragment image [ROWS/16][CP][hi / lo][64 lanes]
+    const float* bias;    // [ROWS]   true scale, added after the rescale
+    const float* scales;  // POST_SCALES: [6] = 2^-sw of the PQ matrix
+    float* pq;            // [T, ROWS]
+    int T, ntiles, NT, nrounds;
+};
+
+template <int ODIM, int ROWS, int NW>
+__global__ __launch_bounds__(NW * 64) void pq_gemm_kernel(PqArgs a) {
+    constexpr int HB = ODIM / 16, CP = (HB + 1) / 2, OBT = ROWS / 16, RB = OBT / NW, NTMAX = 16;
+    static_assert(OBT % NW == 0, "rows split evenly over the waves");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    __shared__ u4 bl[NTMAX][CP][2][64];
+    h8 wh[RB][CP], wl[RB][CP];
+    f4 bias[RB];
+#pragma unroll
+    for (int ob = 0; ob < RB; ++ob) {
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+            const u4* f = a.w + (size_t)(((wave * RB + ob) * CP + cp) * 2) * 64 + lane;
+            wh[ob][cp] = pf_ldw(f);
+            wl[ob][cp] = pf_ldw(f + 64);
+        }
+        bias[ob] = *reinterpret_cast<const f4*>(a.bias + (wave * RB + ob) * 16 + 4 * q);
+    }
+    const float inv = a.scales[6];
+    for (int round = blockIdx.x; round < a.nrounds; round += gridDim.x) {
+        const int tile0 = round * a.NT;
+        const int nt = a.ntiles - tile0 < a.NT ? a.ntiles - tile0 : a.NT;
+        // ---- stage: this wave converts tiles wave, wave + NW, ...
+        for (int t = wave; t < nt; t += NW) {
+            int pt = (tile0 + t) * 16 + col;
+            pt = pt < a.T ? pt : a.T - 1;
+            f4 hb[HB + (HB & 1)];
+#pragma unroll
+            for (int b = 0; b < HB; ++b) hb[b] = *reinterpret_cast<const f4*>(a.h + (size_t)pt * ODIM + b * 16 + 4 * q);
+            if constexpr (HB & 1) hb[HB] = pf_splat(0.f);
+#pragma unroll
+            for (int cp = 0; cp < CP; ++cp) {
+                const PfPairN p = pf_pairn(hb[2 * cp], hb[2 * cp + 1]);
+                bl[t][cp][0][lane] = __builtin_bit_cast(u4, p.h);
+                bl[t][cp][1][lane] = __builtin_bit_cast(u4, p.l);
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            f4 acc[RB];
+#pragma unroll
+            for (int ob = 0; ob < RB; ++ob) acc[ob] = pf_splat(0.f);
+#pragma unroll
+            for (int cp = 0; cp < CP; ++cp) {
+                const h8 fh = __builtin_bit_cast(h8, bl[t][cp][0][lane]), fl = __builtin_bit_cast(h8, bl[t][cp][1][lane]);
+#pragma unroll
+                for (int ob = 0; ob < RB; ++ob) {
+                    f4 x = acc[ob];
+                    x = pf_mfma_f16(wh[ob][cp], fl, x);
+                    x = pf_mfma_f16(wl[ob][cp], fh, x);
+                    x = pf_mfma_f16(wh[ob][cp], fh, x);
+                    acc[ob] = x;
+                }
+            }
+            const int pt = (tile0 + t) * 16 + col;
+            if (pt < a.T) {
+#pragma unroll
+                for (int ob = 0; ob < RB; ++ob) {
+                    f4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = fmaf(acc[ob][r], inv, bias[ob][r]);
+                    *reinterpret_cast<f4*>(a.pq + (size_t)pt * ROWS + (wave * RB + ob) * 16 + 4 * q) = o;
+                }
+            }
+        }
+        __syncthreads();                                   // the next round overwrites the staged tiles
+    }
+}
+
+template <int ODIM, int ROWS>
+int launch_pq(PqArgs a, hipStream_t s) {
+    constexpr int NW = 16;
+    a.ntiles = (a.T + 15) / 16;
+    // tiles per round: as many as LDS holds when there is plenty of work, fewer when that would leave CUs idle
+    int nt = a.ntiles / 256;
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+    a.NT = nt;
+    a.nrounds = (a.ntiles + nt - 1) / nt;
+    const int grid = a.nrounds < 256 ? a.nrounds : 256;    // one workgroup per CU (LDS, 16 waves)
+    hipLaunchKernelGGL((pq_gemm_kernel<ODIM, ROWS, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    return pf_last_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct CondArgs {
     const float* h;                       // [T, ODIM]
-    const f4* wM1; const float* b1;       // [ODIM/2, ODIM]
-    const f4* wM2;                        // [CDIM, ODIM/2]
-    const f4* wH1;                        // [192, ODIM/2]  rows: (s_W0 | t_W0 | c1_W0c) W2  (merge conv2 folded in)
-    const f4* wS2; const float* bS2;      // [64, 64]
-    const f4* wT2; const float* bT2;      // [64, 64]
-    const f4* wST4; const float* bST4;    // [16, 128]    rows 0-2: s_W4 on cols 0-63, rows 3-5: t_W4 on cols 64-127
-    const f4* wPQ; const float* bPQ;      // [2*SNEXT, ODIM]  (unused when SNEXT == 0)
+    const float* w;                       // blob base
+    long long off[13];                    // POST_SLOTS
     float* c;                             // [T, CDIM]   (nullable)
     float* st;                            // [T, 8]      s0 s1 s2 t0 t1 t2 - -
     float* cp;                            // [T, 64]
-    float* pq;                            // [T, 2*SNEXT]
     int T, ntiles;
 };
 
-template <int ODIM, int CDIM, int SNEXT, int P, int NW>
-__global__ __launch_bounds__(NW * 64) void post_kernel(PostArgs a) {
+__device__ __forceinline__ f4 pf_scale(f4 v, float k) { return v * k; }
+
+template <int ODIM, int CDIM, int NW>
+__global__ __launch_bounds__(NW * 64) void cond_kernel(CondArgs a) {
     constexpr int HB = ODIM / 16, MB = ODIM / 32, CB = CDIM / 16;
     constexpr int HP = (HB + 1) / 2, MP = (MB + 1) / 2;              // block pairs (32 input channels per MFMA step)
+    // LDS-resident fragment images: M1 | H1 | S2 | T2 | ST4   (2 KiB per fragment pair)
+    constexpr int F_M1 = 0, F_H1 = F_M1 + MB * HP, F_S2 = F_H1 + 12 * MP, F_T2 = F_S2 + 8, F_ST4 = F_T2 + 8, F_END = F_ST4 + 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
-    const PfW2Buf wsPQ(a.wPQ, lane), wsM1(a.wM1, lane), wsM2(a.wM2, lane), wsH1(a.wH1, lane), wsS2(a.wS2, lane),
-        wsT2(a.wT2, lane), wsST4(a.wST4, lane);
+    __shared__ u4 wl[F_END * 128];
+    {
+        auto stage = [&](int f0, int nf, long long off) {
+            const u4* src = reinterpret_cast<const u4*>(a.w + off);
+            for (int i = threadIdx.x; i < nf * 128; i += blockDim.x) wl[f0 * 128 + i] = src[i];
+        };
+        stage(F_M1, MB * HP, a.off[0]); stage(F_H1, 12 * MP, a.off[3]); stage(F_S2, 8, a.off[4]); stage(F_T2, 8, a.off[6]);
+        stage(F_ST4, 4, a.off[8]);
+        __syncthreads();
+    }
+    const PfW2Lds wsM1{wl + F_M1 * 128, lane}, wsH1{wl + F_H1 * 128, lane}, wsS2{wl + F_S2 * 128, lane},
+        wsT2{wl + F_T2 * 128, lane}, wsST4{wl + F_ST4 * 128, lane};
+    const PfW2BufD<2> wsM2(a.w + a.off[2], lane);      // only for the `cs` API output: shallow prefetch, few registers
+    const float* sc = a.w + a.off[12];
+    const float iM1 = sc[0], iM2 = sc[1], iH1 = sc[2], iS2 = sc[3], iT2 = sc[4], iST4 = sc[5];
+    const float* b1 = a.w + a.off[1];
+    const float* bS2 = a.w + a.off[5];
+    const float* bT2 = a.w + a.off[7];
+    const float* bST4 = a.w + a.off[9];
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int pt0 = (tile * NW + wave) * P * 16;
-        int pt[P];
-        bool ok[P];
-        PfPair2 hp[P][HP];
+        const int g = (tile * NW + wave) * 16 + col;
+        const bool ok = g < a.T;
+        const int pt = ok ? g : a.T - 1;
+        PfPairN hp[1][HP];
         {
-            f4 h[P][HB];
+            f4 h[HB + (HB & 1)];
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const int g = pt0 + p * 16 + col;
-                ok[p] = g < a.T;
-                pt[p] = ok[p] ? g : a.T - 1;
+            for (int b = 0; b < HB; ++b) h[b] = *reinterpret_cast<const f4*>(a.h + (size_t)pt * ODIM + b * 16 + 4 * q);
+            if constexpr (HB & 1) h[HB] = pf_splat(0.f);
 #pragma unroll
-                for (int b = 0; b < HB; ++b)
-                    h[p][b] = *reinterpret_cast<const f4*>(a.h + (size_t)pt[p] * ODIM + b * 16 + 4 * q);
-            }
-            pf_pairs2<HB>(h, 0, hp);
+            for (int c = 0; c < HP; ++c) hp[0][c] = pf_pairn(h[2 * c], h[2 * c + 1]);
         }
-
-        // ---- next unit's P|Q vectors
-        if constexpr (SNEXT > 0) {
-            pf_static_for<0, (2 * SNEXT) / 32>([&](auto cc) {
-                constexpr int ob0 = decltype(cc)::value * 2;
-#ifdef PF_POST_SYNC
-                if constexpr (decltype(cc)::value % PF_POST_SYNC == 0) __syncthreads();   // waves stream the weights in step -> L1 hits
-#endif
-                f4 acc[P][2];
-#pragma unroll
-                for (int o = 0; o < 2; ++o)
-#pragma unroll
-                    for (int p = 0; p < P; ++p) acc[p][o] = pf_bias(a.bPQ, ob0 + o, q);
-                pf_mm2f<2, HP, HP>(wsPQ, ob0 * HP, hp, 0, acc, 0);
-#pragma unroll
-                for (int o = 0; o < 2; ++o)
-#pragma unroll
-                    for (int p = 0; p < P; ++p)
-                        if (ok[p])
-                            *reinterpret_cast<f4*>(a.pq + (size_t)pt[p] * (2 * SNEXT) + (ob0 + o) * 16 + 4 * q) = acc[p][o];
-            });
-        }
-
-        // ---- merge MLP
-        PfPair2 mp[P][MP];
+        // ---- merge MLP: m = relu(W1 h + b1)
+        PfPairN mp[1][MP];
         {
-            f4 m[P][MB];
+            f4 m[1][MB + (MB & 1)];
 #pragma unroll
-            for (int o = 0; o < MB; ++o)
+            for (int o = 0; o < MB; ++o) m[0][o] = pf_bias(b1, o, q);
+            pf_mmn<false, MB, HP, HP>(wsM1, 0, hp, m);
 #pragma unroll
-                for (int p = 0; p < P; ++p) m[p][o] = pf_bias(a.b1, o, q);
-            pf_mm2f<MB, HP, HP>(wsM1, 0, hp, 0, m, 0);
+            for (int o = 0; o < MB; ++o) m[0][o] = pf_relu(pf_scale(m[0][o], iM1));
+            if constexpr (MB & 1) m[0][MB] = pf_splat(0.f);
 #pragma unroll
-            for (int o = 0; o < MB; ++o)
-#pragma unroll
-                for (int p = 0; p < P; ++p) m[p][o] = pf_relu(m[p][o]);
-            pf_pairs2<MB>(m, 0, mp);
+            for (int c = 0; c < MP; ++c) mp[0][c] = pf_pairn(m[0][2 * c], m[0][2 * c + 1]);
         }
-
         // c = W2 m is only materialised when the caller wants `cs` (feat_extract API): everything downstream of c
         // is linear in it, so the host folded W2 into those layers (H1 := [s_W0; t_W0; c1_W0c] W2, packing.pack_plan)
         if (a.c) {
-            f4 c[P][CB];
+            f4 c[1][CB];
 #pragma unroll
-            for (int o = 0; o < CB; ++o)
+            for (int o = 0; o < CB; ++o) c[0][o] = pf_splat(0.f);
+            pf_mmn<false, CB, MP, MP>(wsM2, 0, mp, c);
+            if (ok)
 #pragma unroll
-                for (int p = 0; p < P; ++p) c[p][o] = pf_splat(0.f);
-            pf_mm2f<CB, MP, MP>(wsM2, 0, mp, 0, c, 0);
-#pragma unroll
-            for (int o = 0; o < CB; ++o)
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    if (ok[p]) *reinterpret_cast<f4*>(a.c + (size_t)pt[p] * CDIM + o * 16 + 4 * q) = c[p][o];
+                for (int o = 0; o < CB; ++o)
+                    *reinterpret_cast<f4*>(a.c + (size_t)pt * CDIM + o * 16 + 4 * q) = pf_scale(c[0][o], iM2);
         }
-
         // ---- coupling1 c-part (rows 128..191 of H1), stored raw
         {
-            f4 acc[P][4];
+            f4 acc[1][4];
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
+            for (int o = 0; o < 4; ++o) acc[0][o] = pf_splat(0.f);
+            pf_mmn<false, 4, MP, MP>(wsH1, 8 * MP, mp, acc);
+            if (ok)
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[p][o] = pf_splat(0.f);
-            pf_mm2f<4, MP, MP>(wsH1, 8 * MP, mp, 0, acc, 0);
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    if (ok[p]) *reinterpret_cast<f4*>(a.cp + (size_t)pt[p] * 64 + o * 16 + 4 * q) = acc[p][o];
+                for (int o = 0; o < 4; ++o)
+                    *reinterpret_cast<f4*>(a.cp + (size_t)pt * 64 + o * 16 + 4 * q) = pf_scale(acc[0][o], iH1);
         }
-
         // ---- injector nets: hidden1 -> hidden2 for s (pairs 0..1) and t (pairs 2..3)
-        PfPair2 h2p[P][4];
+        PfPairN h2p[1][4];
         pf_static_for<0, 2>([&](auto nc) {
             constexpr int net = decltype(nc)::value;
-            f4 h1[P][4];
+            f4 h1[1][4];
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
+            for (int o = 0; o < 4; ++o) h1[0][o] = pf_splat(0.f);
+            pf_mmn<false, 4, MP, MP>(wsH1, (4 * net) * MP, mp, h1);
+            PfPairN h1p[1][2];
+            h1p[0][0] = pf_pairn(pf_lrelu(pf_scale(h1[0][0], iH1), 0.01f), pf_lrelu(pf_scale(h1[0][1], iH1), 0.01f));
+            h1p[0][1] = pf_pairn(pf_lrelu(pf_scale(h1[0][2], iH1), 0.01f), pf_lrelu(pf_scale(h1[0][3], iH1), 0.01f));
+            f4 h2[1][4];
 #pragma unroll
-                for (int p = 0; p < P; ++p) h1[p][o] = pf_splat(0.f);
-            pf_mm2f<4, MP, MP>(wsH1, (4 * net) * MP, mp, 0, h1, 0);
-            f4 h2[P][4];
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    h1[p][o] = pf_lrelu(h1[p][o], 0.01f);
-                    h2[p][o] = pf_bias(net == 0 ? a.bS2 : a.bT2, o, q);
-                }
-            PfPair2 h1p[P][2];
-            pf_pairs2<4>(h1, 0, h1p);
-            if constexpr (net == 0) pf_mm2f<4, 2, 2>(wsS2, 0, h1p, 0, h2, 0); else pf_mm2f<4, 2, 2>(wsT2, 0, h1p, 0, h2, 0);
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                h2p[p][2 * net + 0] = pf_pair2(pf_lrelu(h2[p][0], 0.01f), pf_lrelu(h2[p][1], 0.01f));
-                h2p[p][2 * net + 1] = pf_pair2(pf_lrelu(h2[p][2], 0.01f), pf_lrelu(h2[p][3], 0.01f));
-            }
+            for (int o = 0; o < 4; ++o) h2[0][o] = pf_bias(net == 0 ? bS2 : bT2, o, q);
+            if constexpr (net == 0) pf_mmn<false, 4, 2, 2>(wsS2, 0, h1p, h2); else pf_mmn<false, 4, 2, 2>(wsT2, 0, h1p, h2);
+            const float i2 = net == 0 ? iS2 : iT2;
+            h2p[0][2 * net + 0] = pf_pairn(pf_lrelu(pf_scale(h2[0][0], i2), 0.01f), pf_lrelu(pf_scale(h2[0][1], i2), 0.01f));
+            h2p[0][2 * net + 1] = pf_pairn(pf_lrelu(pf_scale(h2[0][2], i2), 0.01f), pf_lrelu(pf_scale(h2[0][3], i2), 0.01f));
         });
         {
-            f4 acc[P][1];
-#pragma unroll
-            for (int p = 0; p < P; ++p) acc[p][0] = pf_bias(a.bST4, 0, q);
-            pf_mm2f<1, 4, 4>(wsST4, 0, h2p, 0, acc, 0);
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-                if (ok[p] && q < 2) *reinterpret_cast<f4*>(a.st + (size_t)pt[p] * 8 + 4 * q) = acc[p][0];
+            f4 acc[1][1];
+            acc[0][0] = pf_bias(bST4, 0, q);
+            pf_mmn<false, 1, 4, 4>(wsST4, 0, h2p, acc);
+            if (ok && q < 2) *reinterpret_cast<f4*>(a.st + (size_t)pt * 8 + 4 * q) = pf_scale(acc[0][0], iST4);
         }
     }
 }
 
-template <int ODIM, int CDIM, int SNEXT>
-int launch(PostArgs a, hipStream_t s) {
-    constexpr int P = PF_POST_P, NW = PF_POST_NW;
-    a.ntiles = (a.T + NW * P * 16 - 1) / (NW * P * 16);
-    int grid = a.ntiles < 2048 ? a.ntiles : 2048;
-    hipLaunchKernelGGL((post_kernel<ODIM, CDIM, SNEXT, P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+template <int ODIM, int CDIM>
+int launch_cond(CondArgs a, hipStream_t s) {
+#ifndef PF_COND_NW
+#define PF_COND_NW 16
+#endif
+    constexpr int NW = PF_COND_NW;
+    a.ntiles = (a.T + NW * 16 - 1) / (NW * 16);
+    constexpr int lds = ((ODIM / 32) * ((ODIM / 16 + 1) / 2) + 12 * ((ODIM / 32 + 1) / 2) + 20) * 2048;
+    int per_cu = (160 * 1024) / lds;                       // persistent workgroups that fit one CU's LDS
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const int cap = 256 * per_cu;
+    const int grid = a.ntiles < cap ? a.ntiles : cap;
+    hipLaunchKernelGGL((cond_kernel<ODIM, CDIM, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
     return pf_last_launch_status();
 }
 
 }  // namespace
 
-// unit: 0..5 selects (ODIM, CDIM, SNEXT) = (32,32,128) (64,64,256) (128,128,256)x3 (128,128,0).
-// w: blob base; off[12]: float offsets of M1, b1, M2, H1, S2, bS2, T2, bT2, ST4, bST4, PQ, bPQ.
-extern "C" int pf_post(int unit, const float* h, const float* w, const long long* off, float* c, float* st, float* cp,
-                       float* pq_next, int T, void* stream) {
-    if (!h || !w || !off || !st || !cp) return PF_ERR_NULL;
+// unit: 0..4 selects (ODIM, ROWS) = (32, 256) (64, 512) (128, 512) x 3.  w: blob base; off[13]: POST_SLOTS.
+extern "C" int pf_pq_gemm(int unit, const float* h, const float* w, const long long* off, float* pq_next, int T, void* stream) {
+    if (!h || !w || !off || !pq_next) return PF_ERR_NULL;
     if (T <= 0) return PF_ERR_SHAPE;
-    PostArgs a{};
-    a.h = h;
-    a.wM1 = reinterpret_cast<const f4*>(w + off[0]); a.b1 = w + off[1];
-    a.wM2 = reinterpret_cast<const f4*>(w + off[2]);
-    a.wH1 = reinterpret_cast<const f4*>(w + off[3]);
-    a.wS2 = reinterpret_cast<const f4*>(w + off[4]); a.bS2 = w + off[5];
-    a.wT2 = reinterpret_cast<const f4*>(w + off[6]); a.bT2 = w + off[7];
-    a.wST4 = reinterpret_cast<const f4*>(w + off[8]); a.bST4 = w + off[9];
-    a.wPQ = reinterpret_cast<const f4*>(w + off[10]); a.bPQ = w + off[11];
-    a.c = c; a.st = st; a.cp = cp; a.pq = pq_next; a.T = T;
+    PqArgs a{};
+    a.h = h; a.w = reinterpret_cast<const u4*>(w + off[10]); a.bias = w + off[11]; a.scales = w + off[12]; a.pq = pq_next; a.T = T;
     hipStream_t s = (hipStream_t)stream;
-    if (unit < 5 && !pq_next) return PF_ERR_NULL;
     switch (unit) {
-        case 0: return launch<32, 32, 128>(a, s);
-        case 1: return launch<64, 64, 256>(a, s);
-        case 2: case 3: case 4: return launch<128, 128, 256>(a, s);
-        case 5: return launch<128, 128, 0>(a, s);
+        case 0: return launch_pq<32, 256>(a, s);
+        case 1: return launch_pq<64, 512>(a, s);
+        case 2: case 3: case 4: return launch_pq<128, 512>(a, s);
         default: return PF_ERR_UNSUPPORTED;
     }
+}
+
+// unit: 0..5 selects (ODIM, CDIM) = (32,32) (64,64) (128,128) x 4.
+extern "C" int pf_cond(int unit, const float* h, const float* w, const long long* off, float* c, float* st, float* cp,
+                       int T, void* stream) {
+    if (!h || !w || !off || !st || !cp) return PF_ERR_NULL;
+    if (T <= 0) return PF_ERR_SHAPE;
+    CondArgs a{};
+    a.h = h; a.w = w; a.c = c; a.st = st; a.cp = cp; a.T = T;
+    for (int i = 0; i < 13; ++i) a.off[i] = off[i];
+    hipStream_t s = (hipStream_t)stream;
+    switch (unit) {
+        case 0: return launch_cond<32, 32>(a, s);
+        case 1: return launch_cond<64, 64>(a, s);
+        case 2: case 3: case 4: case 5: return launch_cond<128, 128>(a, s);
+        default: return PF_ERR_UNSUPPORTED;
+    }
+}
+
+// Both stages of unit `unit` (the round-1 entry point, kept for callers that want one call per unit).
+extern "C" int pf_post(int unit, const float* h, const float* w, const long long* off, float* c, float* st, float* cp,
+                       float* pq_next, int T, void* stream) {
+    if (unit < 5) {
+        if (!pq_next) return PF_ERR_NULL;
+        const int rc = pf_pq_gemm(unit, h, w, off, pq_next, T, stream);
+        if (rc != PF_OK) return rc;
+    }
+    return pf_cond(unit, h, w, off, c, st, cp, T, stream);
 }

@@ -188,22 +188,26 @@ class _Engine:
         return idx
 
     def features(self, xyz: Tensor, idx16: Tensor, want_cs: bool):
-        """6x (EdgeConv -> per-point stage).  Returns cs (or None), cp [6,T,64], st [6,T,8]."""
+        """6x (EdgeConv -> next unit's P|Q GEMM), then the six conditioner stages (they only feed the flow kernels, so they
+        stay off the EdgeConv -> P|Q -> EdgeConv chain).  Returns cs (or None), cp [6,T,64], st [6,T,8]."""
         B, N, _ = xyz.shape
         T, dev, s = B * N, xyz.device, self._stream()
         cp = torch.empty((NUM_BLOCKS, T, 64), dtype=torch.float32, device=dev)
         st = torch.empty((NUM_BLOCKS, T, 8), dtype=torch.float32, device=dev)
         pq = torch.empty((T, 512), dtype=torch.float32, device=dev)
-        cs: List[Optional[Tensor]] = []
+        hs: List[Tensor] = []
         for u in range(NUM_BLOCKS):
-            odim = FEAT_CHANNELS[u + 1]
-            h = torch.empty((T, odim), dtype=torch.float32, device=dev)
+            h = torch.empty((T, FEAT_CHANNELS[u + 1]), dtype=torch.float32, device=dev)
             src = xyz.data_ptr() if u == 0 else pq.data_ptr()
             self._edgeconv(u, src, idx16, h, B, N, s)
+            if u + 1 < NUM_BLOCKS:
+                _lib.check(self.lib.pf_pq_gemm(u, h.data_ptr(), self.base, self.post[u], pq.data_ptr(), T, s), f"pf_pq_gemm[{u}]")
+            hs.append(h)
+        cs: List[Optional[Tensor]] = []
+        for u in range(NUM_BLOCKS):
             c = torch.empty((B, N, COND_CHANNELS[u]), dtype=torch.float32, device=dev) if want_cs else None
-            _lib.check(self.lib.pf_post(u, h.data_ptr(), self.base, self.post[u], c.data_ptr() if want_cs else None,
-                                        st[u].data_ptr(), cp[u].data_ptr(), pq.data_ptr() if u < 5 else None, T, s),
-                       f"pf_post[{u}]")
+            _lib.check(self.lib.pf_cond(u, hs[u].data_ptr(), self.base, self.post[u], c.data_ptr() if want_cs else None,
+                                        st[u].data_ptr(), cp[u].data_ptr(), T, s), f"pf_cond[{u}]")
             cs.append(c)
         return (cs if want_cs else None), cp, st
 
@@ -257,13 +261,17 @@ class _Engine:
             cp = torch.empty((NUM_BLOCKS, T, 64), dtype=torch.float32, device=dev)
             st = torch.empty((NUM_BLOCKS, T, 8), dtype=torch.float32, device=dev)
             pq = torch.empty((T, 512), dtype=torch.float32, device=dev)
+            hs = []
             for u in range(NUM_BLOCKS):
                 h = torch.empty((T, FEAT_CHANNELS[u + 1]), dtype=torch.float32, device=dev)
                 src = xyz.data_ptr() if u == 0 else pq.data_ptr()
                 timed(f"edgeconv{u}", lambda: self._edgeconv(u, src, idx16, h, B, N, s))
-                timed(f"post{u}", lambda: _lib.check(self.lib.pf_post(
-                    u, h.data_ptr(), self.base, self.post[u], None, st[u].data_ptr(), cp[u].data_ptr(),
-                    pq.data_ptr() if u < 5 else None, T, s)))
+                if u + 1 < NUM_BLOCKS:
+                    timed(f"pq{u}", lambda: _lib.check(self.lib.pf_pq_gemm(u, h.data_ptr(), self.base, self.post[u], pq.data_ptr(), T, s)))
+                hs.append(h)
+            for u in range(NUM_BLOCKS):
+                timed(f"cond{u}", lambda: _lib.check(self.lib.pf_cond(u, hs[u].data_ptr(), self.base, self.post[u], None,
+                                                                     st[u].data_ptr(), cp[u].data_ptr(), T, s)))
             z, _, _ = timed("flow_f+logp", lambda: self.flow_f(xyz, cp, st))
             u_ = timed("interp", lambda: self.interp(xyz, z, idx16, R))
             timed("flow_g", lambda: self.flow_g(u_, cp, st, R))

@@ -262,6 +262,21 @@ def frag_pack_f16n(W: np.ndarray) -> np.ndarray:
     return res.reshape(-1).view(np.float32)
 
 
+def f16n_scale(W: np.ndarray) -> float:
+    """Power of two that brings max |W| into [2^13, 2^14): the natural-scale low halves of (almost) all weights are then
+    normal fp16 numbers and the 2^-25 absolute floor of the rest is < 2^-38 of the largest weight."""
+    m = float(np.abs(W).max(initial=0.0))
+    if m == 0.0 or not np.isfinite(m):
+        return 1.0
+    return float(2.0 ** int(np.clip(13 - np.floor(np.log2(m)), -24, 40)))
+
+
+def frag_pack_f16n_scaled(W: np.ndarray):
+    """-> (f16n fragment image of W * 2^sw, 2^-sw as float32): the kernel multiplies its accumulators by the second."""
+    sc = f16n_scale(W)
+    return frag_pack_f16n((W.astype(np.float64) * sc).astype(np.float32)), np.float32(1.0 / sc)
+
+
 EC4_STEP = 4.0        # activation scale ratio between consecutive growth layers of edgeconv4_kernel (csrc/edgeconv.hip)
 
 
@@ -315,9 +330,11 @@ def frag_unpack(F: np.ndarray, out: int, inn: int) -> np.ndarray:
 # ---------------------------------------------------------------------------------------
 # Device blob: every folded matrix in kernel order + offset tables (float units, 64-aligned)
 # ---------------------------------------------------------------------------------------
-POST_SLOTS = ["M1", "b1", "M2", "H1", "S2", "bS2", "T2", "bT2", "ST4", "bST4", "PQ", "bPQ"]
-INTERP_SLOTS = ["dtab", "d_W3", "d_b3", "d_W6", "d_b6", "ectab", "ec_w", "w_W0", "w_b0", "w_W3", "w_b3", "w_W6", "w_b6",
+POST_SLOTS = ["M1", "b1", "M2", "H1", "S2", "bS2", "T2", "bT2", "ST4", "bST4", "PQ", "bPQ", "scales"]
+POST_SCALES = ["M1", "M2", "H1", "S2", "T2", "ST4", "PQ"]      # order of the 2^-sw factors in the "scales" slot
+INTERP_SLOTS = ["dtab", "d_W3", "d_b3", "d_W6", "scales", "ectab", "ec_w", "w_W0", "w_b0", "w_W3", "w_b3", "w_W6", "w_b6",
                 "w_W6full", "w_b6full"]
+INTERP_SCALES = ["dtab", "d_W3", "w1", "ec", "w_W3", "w_W6"]     # 2^-sw factors in the "scales" slot (csrc/interp.hip)
 FLOW_REC = 5360
 
 
@@ -352,6 +369,19 @@ def _edge_table(u: Dict[str, np.ndarray]) -> np.ndarray:
     t = np.zeros((S, 8), np.float32)
     t[:, 0:3], t[:, 3:6], t[:, 6] = u["PA"], u["QB"], u["pb"]
     return t
+
+
+def _etab_dense(xi: np.ndarray, xj: np.ndarray, nrm, const: np.ndarray) -> np.ndarray:
+    """'Edge table' as a dense [rows, 32] matrix (column map of _etab_frag)."""
+    rows = xi.shape[0]
+    W = np.zeros((rows, 32), np.float32)
+    W[:, 0:3] = xi
+    W[:, 3] = xj[:, 0]
+    W[:, 16:18] = xj[:, 1:3]
+    if nrm is not None:
+        W[:, 18] = nrm
+    W[:, 19] = const
+    return W
 
 
 def _etab_frag(xi: np.ndarray, xj: np.ndarray, nrm, const: np.ndarray) -> np.ndarray:
@@ -429,14 +459,18 @@ def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, objec
         ST4 = np.zeros((6, 128), np.float32)
         ST4[0:3, 0:64] = f["s_W4"]; ST4[3:6, 64:128] = f["t_W4"]
         bST4 = _pad_vec(np.concatenate([f["s_b4"], f["t_b4"]]), 16)
-        offs = {
-            # matrices: split-fp16 fragment images (csrc/pointwise.hip runs on the fp16 matrix pipe, f16x2 products)
-            "M1": B.add(frag_pack_f16x2(m["W1"])), "b1": B.add(_pad_vec(m["b1"], ((m["b1"].size + 15) // 16) * 16)),
-            "M2": B.add(frag_pack_f16x2(m["W2"])), "H1": B.add(frag_pack_f16x2(H1)),
-            "S2": B.add(frag_pack_f16x2(f["s_W2"])), "bS2": B.add(f["s_b2"]),
-            "T2": B.add(frag_pack_f16x2(f["t_W2"])), "bT2": B.add(f["t_b2"]),
-            "ST4": B.add(frag_pack_f16x2(ST4)), "bST4": B.add(bST4),
-        }
+        # matrices: f16n fragment images (natural-scale low half) of W * 2^sw with sw per matrix; biases are stored
+        # pre-multiplied by the same 2^sw (they initialise the accumulators) except bPQ, which is added after the
+        # rescale; "scales" holds the 2^-sw factors in POST_SCALES order (csrc/pointwise.hip)
+        inv = {}
+        def img(name, W):
+            im, inv[name] = frag_pack_f16n_scaled(W)
+            return B.add(im)
+        offs = {"M1": img("M1", m["W1"]), "M2": img("M2", m["W2"]), "H1": img("H1", H1),
+                "S2": img("S2", f["s_W2"]), "T2": img("T2", f["t_W2"]), "ST4": img("ST4", ST4)}
+        offs["b1"] = B.add(_pad_vec(m["b1"], ((m["b1"].size + 15) // 16) * 16) / inv["M1"])
+        offs["bS2"] = B.add(f["s_b2"] / inv["S2"]); offs["bT2"] = B.add(f["t_b2"] / inv["T2"])
+        offs["bST4"] = B.add(bST4 / inv["ST4"])
         if i + 1 < NUM_BLOCKS:
             nu = units[i + 1]
             Wpq = np.concatenate([nu["PA"], nu["QB"]], axis=0)
@@ -445,10 +479,11 @@ def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, objec
                 rp, rq, _ = ec4_scales()
                 rs = np.concatenate([rp, rq])
                 Wpq, bpq = Wpq * rs[:, None], bpq * rs
-            offs["PQ"] = B.add(frag_pack_f16x2(Wpq))
+            offs["PQ"] = img("PQ", Wpq)
             offs["bPQ"] = B.add(bpq)
         else:
-            offs["PQ"], offs["bPQ"] = 0, 0
+            offs["PQ"], offs["bPQ"], inv["PQ"] = 0, 0, np.float32(1.0)
+        offs["scales"] = B.add(_pad_vec(np.array([inv[k] for k in POST_SCALES], np.float32), 16))
         post.append([offs[k] for k in POST_SLOTS])
     out["post"] = post
     out["flow"] = B.add(np.concatenate([pack_flow_record(f) for f in plan["flows"]]))
@@ -461,17 +496,33 @@ def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, objec
         b6r[4 * q:4 * q + 4] = ip["w_b6"][:4]
     ec = ip["ec"]
     ft = ip["f_tab"]
-    io = {   # matrices: f16x2 fragment images (csrc/interp.hip header lists the slots)
-        "dtab": B.add(_etab_frag(ip["d_PA"], ip["d_QB"], ip["d_wn"], ip["d_b0"])),
-        "d_W3": B.add(frag_pack_f16x2(ip["d_W3"])), "d_b3": B.add(ip["d_b3"]),
-        "d_W6": B.add(frag_pack_f16x2(ip["f_dW"])), "d_b6": 0,                      # folded: W0a.W6 on d2; slot 4 reserved
-        "ectab": B.add(_etab_frag(ec["PA"][:128], ec["QB"][:128], None, ec["pb"][:128])),   # growth pre-activations
-        "ec_w": B.add(np.concatenate([frag_pack_f16x2(ec[f"G{t}"]) for t in range(1, 8)])),
-        "w_W0": B.add(frag_pack_f16x2(ip["f_eW"])),                                 # folded: W0b.Gout
-        "w_b0": B.add(_etab_frag(ft[:, 0:3], ft[:, 3:6], None, ft[:, 6] + ip["f_b0"])),   # W0b.(edge table) + b0 + W0a.b6
-        "w_W3": B.add(frag_pack_f16x2(ip["w_W3"])), "w_b3": B.add(ip["w_b3"]),
-        "w_W6": B.add(frag_pack_f16x2(W6r)), "w_b6": B.add(b6r),
-        "w_W6full": B.add(frag_pack_f16x2(ip["w_W6"])), "w_b6full": B.add(ip["w_b6"]),
+    # matrices: f16n fragment images (natural-scale low half) scaled by a power of two per GROUP of matrices that share
+    # an accumulator; biases that initialise accumulators are pre-multiplied by the group's 2^sw; "scales" = the 2^-sw
+    # factors in INTERP_SCALES order (csrc/interp.hip header lists the slots)
+    def grp(*mats):
+        sc = min(f16n_scale(m) for m in mats)
+        return sc, [frag_pack_f16n((m.astype(np.float64) * sc).astype(np.float32)) for m in mats]
+    dtab_d = _etab_dense(ip["d_PA"], ip["d_QB"], ip["d_wn"], ip["d_b0"])
+    ectab_d = _etab_dense(ec["PA"][:128], ec["QB"][:128], None, ec["pb"][:128])
+    w1tab_d = _etab_dense(ft[:, 0:3], ft[:, 3:6], None, ft[:, 6] + ip["f_b0"])     # W0b.(edge table) + b0 + W0a.b6
+    s_dt, (i_dt,) = grp(dtab_d)
+    s_d3, (i_d3,) = grp(ip["d_W3"])
+    s_w1, (i_w1t, i_d6, i_w0) = grp(w1tab_d, ip["f_dW"], ip["f_eW"])
+    ecG = [ec[f"G{t}"] for t in range(1, 8)]
+    s_ec, ec_imgs = grp(ectab_d, *ecG)
+    s_w3, (i_w3,) = grp(ip["w_W3"])
+    s_w6, (i_w6r, i_w6f) = grp(W6r, ip["w_W6"])
+    io = {
+        "dtab": B.add(i_dt), "d_W3": B.add(i_d3), "d_b3": B.add(ip["d_b3"] * s_d3),
+        "d_W6": B.add(i_d6),                                                        # folded: W0a.W6 on d2
+        "scales": B.add(_pad_vec(np.array([1 / s_dt, 1 / s_d3, 1 / s_w1, 1 / s_ec, 1 / s_w3, 1 / s_w6], np.float32), 16)),
+        "ectab": B.add(ec_imgs[0]),                                                 # growth pre-activations
+        "ec_w": B.add(np.concatenate(ec_imgs[1:])),
+        "w_W0": B.add(i_w0),                                                        # folded: W0b.Gout
+        "w_b0": B.add(i_w1t),
+        "w_W3": B.add(i_w3), "w_b3": B.add(ip["w_b3"] * s_w3),
+        "w_W6": B.add(i_w6r), "w_b6": B.add(b6r * s_w6),
+        "w_W6full": B.add(i_w6f), "w_b6full": B.add(ip["w_b6"] * s_w6),
     }
     out["interp"] = [io[k] for k in INTERP_SLOTS]
     out["blob"] = B.data()
