@@ -47,7 +47,8 @@ int pf_nn1(const float* p1, const float* p2, int B, int N, int M, float* dist_ou
  * cfg 5 / 6: units 0 / 1 on the fp16 matrix pipe (wfrag = f16x2 image; unit 0's edge table rides at its end,
  * input = xyz [B*N,3], tab ignored);
  * cfg 7: units 2..5, split-fp16 with a natural-scale low half (wfrag = packing.ec4_weights; the P|Q table must carry
- * the row scales of packing.ec4_scales; csrc/edgeconv.hip edgeconv4_kernel) - the shipped default.
+ * the row scales of packing.ec4_scales; csrc/edgeconv.hip edgeconv4_kernel) - the shipped default;
+ * cfg 8 / 9: units 0 / 1 in the same arithmetic (wfrag = packing ec1n_w; unit 1 reads the scaled P|Q table).
  * idx [B*N,16] int32 (index inside the batch item); wfrag = fragment-packed growth weights;
  * out [B*N, odim]. */
 int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, const int* idx, const float* wfrag, float* out,

@@ -599,6 +599,169 @@ int launch1h(const EcArgs& a0, hipStream_t s) {
     return pf_last_launch_status();
 }
 
+// ---- f16n variant of the narrow units 0 / 1 (same arithmetic and scale plan as edgeconv4_kernel) -------------------
+// Growth layers are 16 channels wide (unit 0: 8, zero-padded): two layers share one 32-channel MFMA step.  conv_out
+// runs with the operands swapped (edges on the MFMA rows) and a reduce-scatter max-pool; feature block t is stored as
+// 4^t x_t, the accumulators of layer t hold 4^t v_t, conv_out's 256 y (packing.ec1n_scales).
+// C3 (unit 0): every pre-activation is one MFMA step against the folded edge table (raw inputs e = (x_i, x_j, 1) in 8 of
+// the 32 k-slots); the same e registers are the B operand of the growth rows and the A operand of the conv_out rows.
+// PQ (unit 1): Q[j] gathers as accumulator initialisers, P[i] staged per wave in LDS (one load per point).
+// Fragments in LDS: G1 | G2 | G3 (2 pairs) | Gout (OBO x 2 pairs) | [C3: edge table, S/16 x 1 pair].
+template <int ODIM, bool C3, int P, int NW>
+__global__ __launch_bounds__(NW * 64) void edgeconv1n_kernel(EcArgs a) {
+    constexpr int NCONV = 4, S = 16 * NCONV + ODIM, SB = S / 16, OBO = ODIM / 16;
+    constexpr int FO = 4, FT = FO + OBO * 2, NWF = FT + (C3 ? SB : 0);
+    constexpr int ROWB = 2 * S * 4;                                       // bytes per point of the P|Q table (unit 1)
+    static_assert(OBO == 2 || OBO == 4, "reduce-scatter below is written for 2 or 4 output blocks");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    __shared__ u4 wlds[NWF * 128];
+    __shared__ float plds[C3 ? 1 : NW * P][C3 ? 1 : S];
+    for (int i = threadIdx.x; i < NWF * 128; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
+    __syncthreads();
+    const PfW2Lds ws{wlds, lane};
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(C3 ? a.xyz : a.pq), 0, 0x7fffffff, 0x00020000);
+
+    for (int v = blockIdx.x; v < 8 * a.chunk; v += gridDim.x) {
+        const int tile = pf_xcd_tile(v, a.chunk);
+        if (tile >= a.ntiles) continue;
+        const int pt0 = (tile * NW + wave) * P;
+        int gi[P], vQ[P], vO[P][4];
+        PfPairN e[P][1];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int g = pt0 + p;
+            g = g < a.T ? g : a.T - 1;
+            g = __builtin_amdgcn_readfirstlane(g);
+            gi[p] = g;
+            const int bN = (g / a.N) * a.N;
+            const int jc = bN + a.idx[(size_t)g * 16 + col];
+            if constexpr (C3) {
+                float xi[3], xj[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    xi[c] = a.xyz[(size_t)g * 3 + c];
+                    xj[c] = a.xyz[(size_t)jc * 3 + c];
+                }
+                const f4 z4 = pf_splat(0.f);
+                const f4 e0 = {xi[0], xi[1], xi[2], xj[0]}, e1 = {xj[1], xj[2], 0.f, 1.f};
+                e[p][0] = pf_pairn(q == 0 ? e0 : z4, q == 0 ? e1 : z4);
+            } else {
+                const int4 j4 = *reinterpret_cast<const int4*>(a.idx + (size_t)g * 16 + 4 * q);
+                vQ[p] = jc * ROWB + (S + 4 * q) * 4;
+                vO[p][0] = (bN + j4.x) * ROWB + (S + 16 * NCONV + col) * 4;
+                vO[p][1] = (bN + j4.y) * ROWB + (S + 16 * NCONV + col) * 4;
+                vO[p][2] = (bN + j4.z) * ROWB + (S + 16 * NCONV + col) * 4;
+                vO[p][3] = (bN + j4.w) * ROWB + (S + 16 * NCONV + col) * 4;
+                // P[i]: S floats, one coalesced load per point (lanes beyond S / 2 idle), staged for broadcast reads
+                if (lane * 2 < S) {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const f2 pv = *reinterpret_cast<const f2*>(a.pq + (size_t)g * (2 * S) + lane * 2);
+                    *reinterpret_cast<f2*>(&plds[wave * P + p][lane * 2]) = pv;
+                }
+            }
+        }
+        // growth pre-activation block t (this lane's 4 channels x its edge column), conv_out block (4 edges x its channel)
+        f4 pre[P][NCONV];
+        f4 outi[P][OBO];
+        if constexpr (C3) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+#pragma unroll
+                for (int b = 0; b < NCONV; ++b) pre[p][b] = pf_splat(0.f);
+#pragma unroll
+                for (int b = 0; b < OBO; ++b) outi[p][b] = pf_splat(0.f);
+            }
+            pf_mmn<false, NCONV, 1, 1>(ws, FT, e, pre);
+            pf_mmn<true, OBO, 1, 1>(ws, FT + NCONV, e, outi);
+        } else {
+#pragma unroll
+            for (int b = 0; b < NCONV; ++b)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    pre[p][b] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vQ[p], b * 64, 0));
+#pragma unroll
+            for (int b = 0; b < OBO; ++b)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        outi[p][b][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vO[p][r], b * 64, 0));
+#pragma unroll
+            for (int b = 0; b < NCONV; ++b)
+#pragma unroll
+                for (int p = 0; p < P; ++p) pre[p][b] += *reinterpret_cast<const f4*>(&plds[wave * P + p][16 * b + 4 * q]);
+        }
+
+        PfPairN fp[P][2];
+        f4 last[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            last[p] = pf_lrelu(pre[p][0], 0.05f);
+            fp[p][0] = pf_pairn(last[p], pf_splat(0.f));
+        }
+        pf_static_for<1, NCONV>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int CPT = (t + 1) / 2, F0 = (t / 2) * ((t + 1) / 2);
+            f4 acc[P][1];
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p][0] = pre[p][t];
+            pf_mmn<false, 1, CPT, CPT>(ws, F0, fp, acc);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const f4 f = pf_lrelu(acc[p][0], 0.05f);
+                if constexpr (t % 2 == 1) fp[p][t / 2] = pf_pairn(last[p], f);
+                else fp[p][t / 2] = pf_pairn(f, pf_splat(0.f));
+                last[p] = f;
+            }
+        });
+        pf_mmn<true, OBO, 2, 2>(ws, FO, fp, outi);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float m[OBO];
+#pragma unroll
+            for (int b = 0; b < OBO; ++b) m[b] = fmaxf(fmaxf(outi[p][b].x, outi[p][b].y), fmaxf(outi[p][b].z, outi[p][b].w));
+            float o;
+            int ch;
+            if constexpr (OBO == 4) {           // lane row q ends up with block {0, 2, 1, 3}[q]
+                o = pf_rsmax16(pf_rsmax32(m[0], m[1]), pf_rsmax32(m[2], m[3]));
+                ch = 16 * (((q & 1) << 1) | (q >> 1)) + col;
+            } else {                            // rows 0,1 hold block 0, rows 2,3 block 1 (both copies complete)
+                const float n = pf_rsmax32(m[0], m[1]);
+                o = pf_rsmax16(n, n);
+                ch = 16 * (q >> 1) + col;
+            }
+            float pv = 0.f;
+            if constexpr (!C3) pv = plds[wave * P + p][16 * NCONV + ch];
+            if (pt0 + p < a.T && (OBO == 4 || (q & 1) == 0))
+                a.out[(size_t)gi[p] * ODIM + ch] = fmaf(o, EC4_OUT_INV, pv);
+        }
+    }
+}
+
+template <int ODIM, bool C3, int P, int NW>
+int launch1n(const EcArgs& a0, hipStream_t s) {
+    EcArgs a = a0;
+    a.ntiles = (a.T + NW * P - 1) / (NW * P);
+    a.chunk = (a.ntiles + 7) / 8;
+    int grid = 8 * a.chunk;
+    const int cap = 256 * (32 / NW);                      // persistent: resident workgroups only (LDS < 40 KiB each)
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL((edgeconv1n_kernel<ODIM, C3, P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    return pf_last_launch_status();
+}
+
+template <int ODIM, bool C3>
+int launch1n_v(const EcArgs& a, hipStream_t s, int variant) {
+    switch (variant) {
+        case 0: return launch1n<ODIM, C3, 1, 8>(a, s);
+        case 1: return launch1n<ODIM, C3, 2, 8>(a, s);
+        case 2: return launch1n<ODIM, C3, 1, 16>(a, s);
+        case 3: return launch1n<ODIM, C3, 2, 4>(a, s);
+        default: return PF_ERR_UNSUPPORTED;
+    }
+}
+
 template <int ODIM, bool C3>
 int launch1h_v(const EcArgs& a, hipStream_t s, int variant) {
     switch (variant) {
@@ -722,6 +885,14 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
                 }
                 return PF_OK;
             }
+        case 8:                                   // unit 0, f16n (packing: ec1n_w[0]; scaled edge table inside wfrag)
+            a.xyz = pq_or_xyz;
+            if ((long long)B * N * 12 > 0x7fffffffll) return PF_ERR_SHAPE;
+            return launch1n_v<32, true>(a, s, variant);
+        case 9:                                   // unit 1, f16n (packing: ec1n_w[1]; needs the SCALED P|Q table of post 0)
+            a.pq = pq_or_xyz;
+            if ((long long)B * N * 1024 > 0x7fffffffll) return PF_ERR_SHAPE;      // 32-bit buffer offsets
+            return launch1n_v<64, false>(a, s, variant);
         case 5:                                   // unit 0, split-fp16 (packing: ec1h_w[0]; edge table inside wfrag)
             a.xyz = pq_or_xyz;
             return launch1h_v<32, true>(a, s, variant);
@@ -734,9 +905,9 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
 
 extern "C" int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, const int* idx, const float* wfrag,
                            float* out, int B, int N, void* stream) {
-    // shipped variants (tools/tune_edgeconv.py, MI355X): unit 0 -> (P=2, NW=8); unit 1 -> (1, 8);
+    // shipped variants (tools/tune_edgeconv.py / tune_ec4.py / PF_EC1N_VARIANT sweeps, MI355X): f16n units 0 / 1 -> (P=2, NW=8);
     // units 2..5 -> (1, 16): one point per wave, 16 waves share the 88 KiB of LDS-resident weights.
-    static const int best[8] = {0, 2, 3, 0, 2, 0, 2, 0};
-    if (cfg < 0 || cfg > 7) return PF_ERR_UNSUPPORTED;
+    static const int best[10] = {0, 2, 3, 0, 2, 0, 2, 0, 1, 1};
+    if (cfg < 0 || cfg > 9) return PF_ERR_UNSUPPORTED;
     return pf_edgeconv_tuned(cfg, best[cfg], pq_or_xyz, tab, idx, wfrag, out, B, N, stream);
 }

@@ -151,6 +151,8 @@ class _Engine:
         self.ec2h_w = pk["ec2h_w"]
         self.ec1h_w = pk["ec1h_w"]
         self.ec4_w = pk["ec4_w"]
+        self.ec1n_w = pk["ec1n_w"]
+        self.ec1_variant = [int(v) for v in os.environ.get("PF_EC1N_VARIANT", "1,1").split(",")]    # launch shapes of units 0, 1
         # launch shape of the split kernels (tuning knob; tools/tune_edgeconv.py)
         self.ec3_variant = int(os.environ.get("PF_EC3_VARIANT", _EC_VARIANT.get(self.ec_mode, "0")))
         self.post = [_lib.offsets(o) for o in pk["post"]]
@@ -165,7 +167,10 @@ class _Engine:
         """Fused EdgeConv unit u -> h [T, odim] in the arithmetic PF_EC_MODE selects (pf_edgeconv cfg table:
         include/puflow_hip.h)."""
         lib = self.lib
-        if self.ec_mode in ("f16x2", "f16n") and u < 2:     # narrow units, edge table of unit 0 rides in the image
+        if self.ec_mode == "f16n" and u < 2:                # narrow units on the natural-scale split (scaled P|Q table)
+            rc = lib.pf_edgeconv_tuned(8 + u, self.ec1_variant[u], src, None, idx16.data_ptr(), self._p(self.ec1n_w[u]),
+                                       h.data_ptr(), B, N, s)
+        elif self.ec_mode == "f16x2" and u < 2:             # narrow units, edge table of unit 0 rides in the image
             rc = lib.pf_edgeconv(5 + u, src, None, idx16.data_ptr(), self._p(self.ec1h_w[u]), h.data_ptr(), B, N, s)
         elif u >= 2 and self.ec_mode in _EC_SPLIT:
             cfg, wname = _EC_SPLIT[self.ec_mode]

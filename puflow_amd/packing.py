@@ -448,6 +448,17 @@ def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, objec
     out["ec3_w"] = [None, None] + [B.add(np.concatenate([frag_pack_bf16x3(units[i][f"G{t}"]) for t in range(1, 5)]))
                                    for i in range(2, NUM_BLOCKS)]
     out["ec4_w"] = [None, None] + [B.add(ec4_weights(units[i])) for i in range(2, NUM_BLOCKS)]
+    # f16n images of the narrow units 0 / 1 (csrc/edgeconv.hip edgeconv1n_kernel): G1 | G2 | G3 | Gout with the same
+    # 4^t activation-scale plan; unit 0 carries its edge table with the rows scaled like the P|Q rows of the other units
+    ec1n = []
+    for i in range(2):
+        parts = [ec4_weights(units[i], 4, 16)]
+        if i == 0:
+            rp, rq, _ = ec4_scales(4, 16, 32)
+            # C = 3: every pre-activation (conv_out's P part included) comes from the table, so all its rows take the Q scale
+            parts.append(frag_pack_f16n(_etab_dense(units[0]["PA"] * rq[:, None], units[0]["QB"] * rq[:, None], None, units[0]["pb"] * rq)))
+        ec1n.append(B.add(np.concatenate(parts)))
+    out["ec1n_w"] = ec1n + [None] * (NUM_BLOCKS - 2)
     out["ec_mode"] = ec_mode
     post = []
     for i in range(NUM_BLOCKS):
@@ -475,8 +486,8 @@ def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, objec
             nu = units[i + 1]
             Wpq = np.concatenate([nu["PA"], nu["QB"]], axis=0)
             bpq = np.concatenate([nu["pb"], np.zeros_like(nu["pb"])])
-            if ec_mode == "f16n" and i + 1 >= 2:          # rows scaled by exact powers of two (edgeconv4_kernel)
-                rp, rq, _ = ec4_scales()
+            if ec_mode == "f16n":                         # rows scaled by exact powers of two (edgeconv4 / edgeconv1n kernels)
+                rp, rq, _ = ec4_scales() if i + 1 >= 2 else ec4_scales(4, 16, 64)
                 rs = np.concatenate([rp, rq])
                 Wpq, bpq = Wpq * rs[:, None], bpq * rs
             offs["PQ"] = img("PQ", Wpq)
