@@ -139,6 +139,10 @@ int pf_emd_backward(const float* xyz1, const float* xyz2, float* gradxyz, const 
 long long pf_gemm_ws_floats(int M, int N, int K);
 int pf_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
             long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats, void* stream);
+/* pf_gemm with the matrix-pipe arithmetic chosen by the caller: 0 = f32 MFMA (what pf_gemm runs), 2 = split-fp16 (operands
+ * inside the fp16 range: forward GEMMs), 3 = split-bf16 (gradient operands); all fp32-class results. */
+int pf_gemm_ex(int arith, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
+               long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats, void* stream);
 
 /* BatchNorm2d(training) + LeakyReLU(slope) on x [R,C] (interpflow.py:205-206,216-217; eps 1e-5, momentum 0.1):
  * save [2][C] = batch mean, 1/sqrt(var+eps); running stats updated in place when non-NULL (unbiased variance).

@@ -39,6 +39,8 @@ SIGNATURES = {
     "pf_gemm_ws_floats": (c_longlong, [c_int, c_int, c_int]),
     "pf_gemm": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p,
                         c_int, c_int, c_int, c_void_p, c_longlong, c_void_p]),
+    "pf_gemm_ex": (c_int, [c_int, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p,
+                        c_int, c_int, c_int, c_void_p, c_longlong, c_void_p]),
     "pf_bn_chunks": (c_int, [c_longlong]),
     "pf_bn_lrelu_fwd": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

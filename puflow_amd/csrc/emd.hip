@@ -21,6 +21,7 @@ namespace {
 
 constexpr int EMD_THREADS = 1024;
 constexpr int EMD_NMAX_LDS = 4096;      // y + price resident in LDS up to this n (64 KiB)
+constexpr int EMD_NMAX_ALL = 2048;      // the WHOLE auction state resident in LDS up to this n (11 n words = 88 KiB)
 
 struct EmdArgs {
     const float* x;          // xyz1 [B,n,3] prediction
@@ -47,24 +48,34 @@ __device__ __forceinline__ void tri_merge(float& best, float& better, int& idx, 
     better = nbetter;
 }
 
-template <bool IN_LDS>
+// MODE 0: state in global memory; 1: y + price in LDS; 2: the whole state in LDS (n <= EMD_NMAX_ALL) - every phase of every
+// iteration then runs out of LDS: the 50 x 5 barrier-separated phases of a 1024-point auction were bound by the latency of
+// their global loads / atomics (72 us per iteration), not by the arithmetic.
+template <int MODE>
 __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(EmdArgs a) {
-    __shared__ float sy[IN_LDS ? 3 * EMD_NMAX_LDS : 3];
-    __shared__ float sprice[IN_LDS ? EMD_NMAX_LDS : 1];
+    constexpr bool IN_LDS = MODE >= 1, ALL = MODE == 2;
+    constexpr int NY = ALL ? EMD_NMAX_ALL : EMD_NMAX_LDS;
+    __shared__ float sy[IN_LDS ? 3 * NY : 3];
+    __shared__ float sprice[IN_LDS ? NY : 1];
+    __shared__ int sstate[ALL ? 7 * EMD_NMAX_ALL : 1];
     __shared__ int ucount;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.n;
     const size_t o0 = (size_t)b * n;
     const float* x = a.x + o0 * 3;
     const float* yg = a.y + o0 * 3;
-    int* assignment = a.assignment + o0;
-    int* assignment_inv = a.assignment_inv + o0;
+    int* assignment_g = a.assignment + o0;
+    int* assignment_inv_g = a.assignment_inv + o0;
     float* priceg = a.price + o0;
-    int* bid = a.bid + o0;
-    float* bid_inc = a.bid_inc + o0;
-    unsigned* maxb = a.max_inc_bits + o0;
-    int* max_idx = a.max_idx + o0;
-    int* ulist = a.unass_idx + o0;
+    int* assignment = ALL ? sstate : assignment_g;
+    int* assignment_inv = ALL ? sstate + EMD_NMAX_ALL : assignment_inv_g;
+    int* bid = ALL ? sstate + 2 * EMD_NMAX_ALL : a.bid + o0;
+    float* bid_inc = ALL ? reinterpret_cast<float*>(sstate + 3 * EMD_NMAX_ALL) : a.bid_inc + o0;
+    unsigned* maxb = ALL ? reinterpret_cast<unsigned*>(sstate + 4 * EMD_NMAX_ALL) : a.max_inc_bits + o0;
+    int* max_idx = ALL ? sstate + 5 * EMD_NMAX_ALL : a.max_idx + o0;
+    int* ulist = ALL ? sstate + 6 * EMD_NMAX_ALL : a.unass_idx + o0;
+    if (ALL)
+        for (int i = tid; i < n; i += EMD_THREADS) { assignment[i] = assignment_g[i]; assignment_inv[i] = assignment_inv_g[i]; }
 
     if (IN_LDS) {
         for (int i = tid; i < 3 * n; i += EMD_THREADS) sy[i] = yg[i];
@@ -150,6 +161,7 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(EmdArgs a) {
                     dz = __fsub_rn(x[i * 3 + 2], yy[k * 3 + 2]);
         a.dist[o0 + i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
         if (IN_LDS) priceg[i] = sprice[i];
+        if (ALL) { assignment_g[i] = k; assignment_inv_g[i] = assignment_inv[i]; }
     }
 }
 
@@ -177,8 +189,9 @@ extern "C" int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist,
     EmdArgs a{xyz1, xyz2, dist, assignment, assignment_inv, price, bid, bid_increments,
               reinterpret_cast<unsigned*>(max_increments), max_idx, unass_idx, n, iters, eps};
     hipStream_t s = (hipStream_t)stream;
-    if (n <= EMD_NMAX_LDS) hipLaunchKernelGGL(emd_auction_kernel<true>, dim3(B), dim3(EMD_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(emd_auction_kernel<false>, dim3(B), dim3(EMD_THREADS), 0, s, a);
+    if (n <= EMD_NMAX_ALL) hipLaunchKernelGGL(emd_auction_kernel<2>, dim3(B), dim3(EMD_THREADS), 0, s, a);
+    else if (n <= EMD_NMAX_LDS) hipLaunchKernelGGL(emd_auction_kernel<1>, dim3(B), dim3(EMD_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(emd_auction_kernel<0>, dim3(B), dim3(EMD_THREADS), 0, s, a);
     return pf_last_launch_status();
 }
 

@@ -124,6 +124,166 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
 }
 
+// ---- split-precision GEMM: the same tiles on the fp16 / bf16 matrix pipe ------------------------------------------
+// The f32 MFMA runs at 1/16 of the 16-bit rate; the big layer GEMMs above already sit near ITS roofline.  Here both
+// operands are split while they are staged into LDS ([row][k] images, k contiguous: one 16-B read per MFMA operand):
+//   NS = 2  x = hi + lo in fp16 (natural-scale low half, pf_mfma.h "f16n"): 3 MFMAs per 32-deep step - forward GEMMs
+//           (activations and weights are O(1e-3 .. 1e2): inside the fp16 range)
+//   NS = 3  x = hi + mid + lo in bf16: 6 MFMAs per step, fp32 exponent range - the GEMMs that take a gradient operand
+//           (dX = dY W, dW = dY^T X: gradients reach 1e-8 and would underflow an fp16 split)
+// Results are fp32-class (>= 22 significant bits per product, fp32 accumulation); 5.3x / 2.7x fewer MFMA cycles than f32.
+template <int NS> struct SplitT;
+template <> struct SplitT<2> { typedef _Float16 T; };
+template <> struct SplitT<3> { typedef __bf16 T; };
+
+template <int NS, int WAVES_M, int WAVES_N, int TM, int TN, bool VEC>
+__global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
+    typedef typename SplitT<NS>::T T;
+    typedef T T8 __attribute__((ext_vector_type(8)));
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16, BK = 32, LDK = BK + 8;   // row stride 80 B: 16-B aligned
+    __shared__ T As[NS][BM][LDK];
+    __shared__ T Bs[NS][BN][LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_lo = blockIdx.z * g.kchunk;
+    const int k_hi = min(g.K, k_lo + g.kchunk);
+    const bool a_kfast = g.sak == 1, b_kfast = g.sbk == 1;
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = pf_splat(0.f);
+    // one element -> its NS parts
+    auto split_store = [&](T* p0, long long part_stride, float x) {
+        if constexpr (NS == 2) {
+            const _Float16 h = (_Float16)x;
+            p0[0] = h;
+            p0[part_stride] = (_Float16)(x - (float)h);
+        } else {
+            const __bf16 h = (__bf16)x;
+            const float r1 = x - (float)h;
+            const __bf16 m = (__bf16)r1;
+            p0[0] = h;
+            p0[part_stride] = m;
+            p0[2 * part_stride] = (__bf16)(r1 - (float)m);
+        }
+    };
+    constexpr long long PSA = (long long)BM * LDK, PSB = (long long)BN * LDK;
+
+    for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
+        // ---- stage A [BM][BK] and B^T [BN][BK], converting on the way
+        for (int v = tid; v < BM * (BK / 4); v += 256) {
+            int r, k;
+            f4 x = pf_splat(0.f);
+            if (a_kfast) {                                      // 4 consecutive k of one row
+                r = v / (BK / 4); k = (v % (BK / 4)) * 4;
+                const int gm = m0 + r, gk = k0 + k;
+                if (gm < g.M) {
+                    if (VEC && gk + 3 < k_hi) x = *reinterpret_cast<const f4*>(g.A + gm * g.sam + gk);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (gk + e < k_hi) x[e] = g.A[gm * g.sam + (gk + e) * g.sak];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_store(&As[0][r][k + e], PSA, x[e]);
+            } else {                                            // 4 consecutive rows of one k
+                k = v / (BM / 4); r = (v % (BM / 4)) * 4;
+                const int gm = m0 + r, gk = k0 + k;
+                if (gk < k_hi) {
+                    if (VEC && gm + 3 < g.M) x = *reinterpret_cast<const f4*>(g.A + gk * g.sak + gm * g.sam);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (gm + e < g.M) x[e] = g.A[(gm + e) * g.sam + gk * g.sak];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_store(&As[0][r + e][k], PSA, x[e]);
+            }
+        }
+        for (int v = tid; v < BN * (BK / 4); v += 256) {
+            int n, k;
+            f4 x = pf_splat(0.f);
+            if (b_kfast) {                                      // 4 consecutive k of one column n
+                n = v / (BK / 4); k = (v % (BK / 4)) * 4;
+                const int gn = n0 + n, gk = k0 + k;
+                if (gn < g.N) {
+                    if (VEC && gk + 3 < k_hi) x = *reinterpret_cast<const f4*>(g.B + gn * g.sbn + gk);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (gk + e < k_hi) x[e] = g.B[(gk + e) * g.sbk + gn * g.sbn];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_store(&Bs[0][n][k + e], PSB, x[e]);
+            } else {                                            // 4 consecutive n of one k
+                k = v / (BN / 4); n = (v % (BN / 4)) * 4;
+                const int gn = n0 + n, gk = k0 + k;
+                if (gk < k_hi) {
+                    if (VEC && gn + 3 < g.N) x = *reinterpret_cast<const f4*>(g.B + gk * g.sbk + gn * g.sbn);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (gn + e < g.N) x[e] = g.B[gk * g.sbk + (gn + e) * g.sbn];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_store(&Bs[0][n + e][k], PSB, x[e]);
+            }
+        }
+        __syncthreads();
+        T8 a[NS][TM], b[NS][TN];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[s][i] = *reinterpret_cast<const T8*>(&As[s][(wm * TM + i) * 16 + (lane & 15)][8 * (lane >> 4)]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[s][j] = *reinterpret_cast<const T8*>(&Bs[s][(wn * TN + j) * 16 + (lane & 15)][8 * (lane >> 4)]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f4 x = acc[i][j];
+                if constexpr (NS == 2) {
+                    x = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i], b[1][j], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][i], b[0][j], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i], b[0][j], x, 0, 0, 0);
+                } else {
+                    x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][i], b[2][j], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2][i], b[0][j], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][i], b[1][j], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][i], b[1][j], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][i], b[0][j], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][i], b[0][j], x, 0, 0, 0);
+                }
+                acc[i][j] = x;
+            }
+        __syncthreads();
+    }
+    float* C = g.C + (long long)blockIdx.z * g.M * g.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + (wm * TM + i) * 16 + 4 * (lane >> 4) + r;
+                if (m < g.M && n < g.N) C[m * g.ldc + n] = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f);
+            }
+        }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+void gemm_split_launch(int ns, const GemmArgs& g, int split, bool vec, hipStream_t s) {
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, split);
+    if (ns == 2) {
+        if (vec) hipLaunchKernelGGL((gemm_split_kernel<2, WAVES_M, WAVES_N, TM, TN, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_split_kernel<2, WAVES_M, WAVES_N, TM, TN, false>), grid, dim3(256), 0, s, g);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_split_kernel<3, WAVES_M, WAVES_N, TM, TN, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_split_kernel<3, WAVES_M, WAVES_N, TM, TN, false>), grid, dim3(256), 0, s, g);
+    }
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 void gemm_launch(const GemmArgs& g, int split, bool vec, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
@@ -487,8 +647,11 @@ extern "C" long long pf_gemm_ws_floats(int M, int N, int K) {
     return split > 1 ? (long long)split * M * N : 0;
 }
 
-extern "C" int pf_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
-                       long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats, void* stream) {
+// arith: 0 = f32 MFMA (bit-exact fp32 fma chain), 2 = split-fp16 (forward GEMMs), 3 = split-bf16 (gradient operands)
+extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
+                          float* C, long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats,
+                          void* stream) {
+    if (arith != 0 && arith != 2 && arith != 3) return PF_ERR_UNSUPPORTED;
     if (!A || !B || !C) return PF_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return PF_ERR_SHAPE;
     const long long need = pf_gemm_ws_floats(M, N, K);
@@ -497,13 +660,28 @@ extern "C" int pf_gemm(const float* A, long long sam, long long sak, const float
     hipStream_t s = (hipStream_t)stream;
     const bool use_ws = split > 1;
     GemmArgs g{A, sam, sak, B, sbk, sbn, use_ws ? ws : C, use_ws ? (long long)N : ldc, use_ws ? nullptr : bias, M, N, K, 0};
-    g.kchunk = ((K + split - 1) / split + 15) / 16 * 16;
+    g.kchunk = ((K + split - 1) / split + 31) / 32 * 32;
     split = (K + g.kchunk - 1) / g.kchunk;
     // float4 path: the contiguous dimension of each operand must be 4-aligned in extent, stride and base
     auto al16 = [](const void* p) { return (reinterpret_cast<unsigned long long>(p) & 15ull) == 0; };
     const bool va = (sak == 1) ? (K % 4 == 0 && sam % 4 == 0 && g.kchunk % 4 == 0) : (sam == 1 && M % 4 == 0 && sak % 4 == 0);
     const bool vb = (sbn == 1) ? (N % 4 == 0 && sbk % 4 == 0) : (sbk == 1 && K % 4 == 0 && sbn % 4 == 0);
     const bool vec = va && vb && al16(A) && al16(B);
+    if (arith != 0) {
+        // float4 staging of the split kernel: 4 consecutive elements along each operand's contiguous dimension
+        const bool va2 = (sak == 1) ? (sam % 4 == 0) : (sam == 1 && sak % 4 == 0);
+        const bool vb2 = (sbk == 1) ? (sbn % 4 == 0) : (sbn == 1 && sbk % 4 == 0);
+        const bool vec2 = va2 && vb2 && al16(A) && al16(B) && (sak == 1 || sam == 1) && (sbk == 1 || sbn == 1);
+        switch (gemm_shape(M, N)) {
+            case 0: gemm_split_launch<2, 2, 4, 4>(arith, g, split, vec2, s); break;
+            case 1: gemm_split_launch<4, 1, 4, 1>(arith, g, split, vec2, s); break;
+            case 2: gemm_split_launch<4, 1, 4, 2>(arith, g, split, vec2, s); break;
+            case 3: gemm_split_launch<4, 1, 4, 4>(arith, g, split, vec2, s); break;
+            case 4: gemm_split_launch<1, 4, 1, 4>(arith, g, split, vec2, s); break;
+            case 5: gemm_split_launch<1, 4, 2, 4>(arith, g, split, vec2, s); break;
+            default: gemm_split_launch<1, 4, 4, 4>(arith, g, split, vec2, s); break;
+        }
+    } else
     switch (gemm_shape(M, N)) {
         case 0: gemm_launch<2, 2, 4, 4>(g, split, vec, s); break;
         case 1: gemm_launch<4, 1, 4, 1>(g, split, vec, s); break;
@@ -517,6 +695,11 @@ extern "C" int pf_gemm(const float* A, long long sam, long long sak, const float
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(((long long)M * N + 63) / 64)), dim3(256), 0, s, ws, C, bias, M,
                            N, ldc, split);
     return pf_last_launch_status();
+}
+
+extern "C" int pf_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
+                       long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats, void* stream) {
+    return pf_gemm_ex(0, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K, ws, ws_floats, stream);
 }
 
 // BatchNorm(train) + LeakyReLU forward on x [R,C].  save [2][C] = mean, invstd (out); running stats updated in place

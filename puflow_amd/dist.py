@@ -40,16 +40,50 @@ def gather_shards(x_local: torch.Tensor, total: int, rank: int, world: int) -> t
 
 
 class FlatGradBucket:
-    """All gradients of a module as ONE flat fp32 buffer -> a single all-reduce per step."""
+    """All gradients of a module as ONE flat fp32 buffer -> a single all-reduce per step.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    as_views=True (what the trainer uses): every parameter's `.grad` IS a view of the flat buffer, autograd accumulates
+    into it in place, `flat.zero_()` replaces `optimizer.zero_grad()`, and the all-reduce needs no packing copies at all.
+    (Do not call `zero_grad(set_to_none=True)` on such parameters: it would drop the views; `rebind()` restores them.)
+    as_views=False keeps the round-1 behaviour: gradients are copied in and out around the collective."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], as_views: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         p0 = self.params[0]
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+        self.as_views = as_views
+        if as_views:
+            self.rebind()
+
+    def rebind(self) -> None:
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            view = self.flat[o:o + n].view_as(p)
+            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+            p.grad = view
+            o += n
+
+    def views_intact(self) -> bool:
+        o = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                return False
+            o += p.numel()
+        return True
 
     def all_reduce_mean(self) -> None:
         """grad <- mean over ranks of grad (missing grads count as zero)."""
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        if self.as_views:
+            if not self.views_intact():
+                self.rebind()
+            if multi:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                self.flat.div_(dist.get_world_size())
+            return
         o = 0
         for p in self.params:
             n = p.numel()
@@ -58,7 +92,7 @@ class FlatGradBucket:
             else:
                 self.flat[o:o + n].copy_(p.grad.reshape(-1))
             o += n
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if multi:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
         o = 0

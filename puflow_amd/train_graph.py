@@ -1,0 +1,130 @@
+"""The training step as hipGraphs.
+
+An eager `TrainerModule.train_step` enqueues ~3 500 small kernels (one per autograd node of the un-fused training ops) and
+is bound by host launch latency, not by the GPU.  The shapes of a step are static (fixed batch, fixed patch sizes), so the
+whole step is captured once and replayed:
+
+  single process : ONE graph = zero grads -> forward -> loss -> backward -> clip -> Adam
+  world size > 1 : graph A = zero grads -> forward -> loss -> backward   (gradients land in ONE flat buffer: every
+                              parameter's .grad is a view of it, so the all-reduce needs no packing copies)
+                   eager    = one RCCL all-reduce of the flat 806 103-float buffer, / world size
+                   graph B = clip -> Adam
+
+Preconditions, all checked: the module is in train() mode with ActNorm initialised (the data-dependent first-batch init is a
+host-side branch - run one eager `train_step` first, `GraphedTrainStep` does it for you when needed), SyncBN off (its
+statistics all-reduce reads the row count on the host), Adam built with `capturable=True` (`make_capturable` converts an
+existing optimizer).  The learning rate lives in a device tensor: `set_lr()` (or a scheduler through `sync_lr()`) changes it
+without re-capturing.  Results are those of the eager step with the same kernels in the same order; the NaN-loss guard of
+the reference (train_pu1k.py:71-73) becomes a tensor select (trainer.training_step).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+
+def make_capturable(optimizer: torch.optim.Optimizer, device) -> torch.optim.Optimizer:
+    """Adam(capturable=True) with the learning rate and the step counters as device tensors (required for capture)."""
+    for g in optimizer.param_groups:
+        g["capturable"] = True
+        if not isinstance(g["lr"], Tensor):
+            g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=device)
+    for st in optimizer.state.values():
+        if "step" in st and isinstance(st["step"], Tensor) and st["step"].device.type != "cuda":
+            st["step"] = st["step"].to(device=device, dtype=torch.float32)
+    return optimizer
+
+
+class GraphedTrainStep:
+    def __init__(self, module, optimizer: torch.optim.Optimizer, batch, clip: float = 1e-2, warmup: int = 2):
+        from . import train_ops
+        from .dist import FlatGradBucket
+        if train_ops._sync_bn_active():
+            raise RuntimeError("graphed_train_step: SyncBN reads the global row count on the host; capture is not possible")
+        self.module, self.optimizer, self.clip = module, optimizer, clip
+        dev = next(module.parameters()).device
+        self.world = torch.distributed.get_world_size() if (torch.distributed.is_available() and
+                                                             torch.distributed.is_initialized()) else 1
+        make_capturable(optimizer, dev)
+        self.static = self._clone_batch(batch)
+        module.train()
+        # gradients as views of one flat buffer (zeroed inside the graph; autograd accumulates into the views in place)
+        self.bucket = FlatGradBucket(module.parameters(), as_views=True)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):               # ActNorm init, library loads, workspaces, Adam state
+                module._sync_actnorm_init(self.static)
+                self._fwd_bwd()
+                self._reduce()
+                self._update()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph_a = torch.cuda.CUDAGraph()
+        self.graph_b: Optional[torch.cuda.CUDAGraph] = None
+        if self.world == 1:
+            with torch.cuda.graph(self.graph_a):
+                self.loss = self._fwd_bwd()
+                self._update()
+        else:
+            with torch.cuda.graph(self.graph_a):
+                self.loss = self._fwd_bwd()
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+                self._update()
+
+    # ---- pieces (the same calls in warm-up, capture and - implicitly - replay)
+    @staticmethod
+    def _clone_batch(batch):
+        if isinstance(batch, dict):
+            return {k: (v.clone() if isinstance(v, Tensor) else v) for k, v in batch.items()}
+        return tuple(v.clone() if isinstance(v, Tensor) else v for v in batch)
+
+    def _copy_in(self, batch) -> None:
+        if isinstance(batch, dict):
+            for k, v in batch.items():
+                if isinstance(v, Tensor):
+                    self.static[k].copy_(v)
+        else:
+            for d, v in zip(self.static, batch):
+                if isinstance(v, Tensor):
+                    d.copy_(v)
+
+    def _fwd_bwd(self) -> Tensor:
+        self.bucket.flat.zero_()
+        loss = self.module.training_step(self.static, 0)
+        loss.backward()
+        return loss.detach()
+
+    def _reduce(self) -> None:
+        if self.world > 1:
+            torch.distributed.all_reduce(self.bucket.flat)
+            self.bucket.flat.div_(self.world)
+
+    def _update(self) -> None:
+        torch.nn.utils.clip_grad_norm_(self.bucket.params, self.clip, foreach=True)
+        self.optimizer.step()
+
+    # ---- public
+    def __call__(self, batch) -> Tensor:
+        self._copy_in(batch)
+        self.graph_a.replay()
+        if self.graph_b is not None:
+            self._reduce()
+            self.graph_b.replay()
+        return self.loss
+
+    def set_lr(self, lr: float) -> None:
+        for g in self.optimizer.param_groups:
+            if isinstance(g["lr"], Tensor):
+                g["lr"].fill_(float(lr))
+            else:                                           # a scheduler replaced the tensor by a float: restore the tensor
+                g["lr"] = torch.tensor(float(lr), dtype=torch.float32, device=self.bucket.flat.device)
+                raise RuntimeError("the captured learning-rate tensor was replaced; use sync_lr() after scheduler.step()")
+
+    def sync_lr(self, scheduler_lr_holder) -> None:
+        """After `scheduler.step(metric)` on a shadow optimizer / param-group list holding plain floats."""
+        for g, h in zip(self.optimizer.param_groups, scheduler_lr_holder):
+            g["lr"].fill_(float(h["lr"]))

@@ -43,13 +43,23 @@ def _ws(dev, n: int) -> Tensor:
     return t
 
 
-def _gemm(A: Tensor, sam: int, sak: int, Bm: Tensor, sbk: int, sbn: int, C: Tensor, ldc: int, bias, M: int, N: int, K: int):
+# Matrix-pipe arithmetic of the training GEMMs: "f32" (default) = every GEMM on the f32 MFMA (bit-exact fp32 fma chains);
+# "split" = forward GEMMs as split-fp16 products (3 fp16 MFMAs per 32-deep step), GEMMs with a gradient operand as
+# split-bf16 (6 bf16 MFMAs, fp32 exponent range) - csrc/train_ops.hip gemm_split_kernel.  Measured at 32 x (256 -> 1024):
+# the same step time (the layer GEMMs of this un-fused path are bound by staging and launch count, not by the MFMA rate:
+# profiles/r2_train), so the exact arithmetic stays the default; the gradient tests pass in both modes.
+_GEMM_MODE = os.environ.get("PF_TRAIN_GEMM", "f32")
+ARITH_FWD, ARITH_BWD = (2, 3) if _GEMM_MODE == "split" else (0, 0)
+
+
+def _gemm(A: Tensor, sam: int, sak: int, Bm: Tensor, sbk: int, sbn: int, C: Tensor, ldc: int, bias, M: int, N: int, K: int,
+          arith: int = 0):
     lib = _lib.load()
     need = lib.pf_gemm_ws_floats(M, N, K)
     ws = _ws(C.device, need) if need else None
-    _lib.check(lib.pf_gemm(A.data_ptr(), sam, sak, Bm.data_ptr(), sbk, sbn, C.data_ptr(), ldc,
-                           bias.data_ptr() if bias is not None else None, M, N, K,
-                           ws.data_ptr() if ws is not None else None, need, _stream()), "pf_gemm")
+    _lib.check(lib.pf_gemm_ex(arith, A.data_ptr(), sam, sak, Bm.data_ptr(), sbk, sbn, C.data_ptr(), ldc,
+                              bias.data_ptr() if bias is not None else None, M, N, K,
+                              ws.data_ptr() if ws is not None else None, need, _stream()), "pf_gemm")
 
 
 class LinearFn(Function):
@@ -63,7 +73,7 @@ class LinearFn(Function):
         R, Cin = x2.shape
         Cout = W.shape[0]
         y = torch.empty((R, Cout), dtype=torch.float32, device=x.device)
-        _gemm(x2, Cin, 1, W, 1, Cin, y, Cout, b, R, Cout, Cin)
+        _gemm(x2, Cin, 1, W, 1, Cin, y, Cout, b, R, Cout, Cin, ARITH_FWD)
         ctx.save_for_backward(x2, W)
         ctx.has_bias = b is not None
         ctx.shp = shp
@@ -78,11 +88,11 @@ class LinearFn(Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
-            _gemm(dy2, Cout, 1, W, Cin, 1, dx, Cin, None, R, Cin, Cout)
+            _gemm(dy2, Cout, 1, W, Cin, 1, dx, Cin, None, R, Cin, Cout, ARITH_BWD)
             dx = dx.view(ctx.shp)
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(W)
-            _gemm(dy2, 1, Cout, x2, Cin, 1, dW, Cin, None, Cout, Cin, R)
+            _gemm(dy2, 1, Cout, x2, Cin, 1, dW, Cin, None, Cout, Cin, R, ARITH_BWD)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             lib = _lib.load()
             db = torch.empty((Cout,), dtype=torch.float32, device=dy.device)
@@ -352,6 +362,15 @@ class SoftmaxWsumFn(Function):
         return dw, dzj, None
 
 
+def _det_inv3(W: Tensor):
+    """(det, inverse) of a 3x3 matrix in closed form (cross products), differentiable.  torch.slogdet / torch.inverse go
+    through a LAPACK-style solver that synchronises with the host, which a captured training step cannot do."""
+    r0, r1, r2 = W[0], W[1], W[2]
+    c0, c1, c2 = torch.linalg.cross(r1, r2), torch.linalg.cross(r2, r0), torch.linalg.cross(r0, r1)
+    det = torch.dot(r0, c0)
+    return det, torch.stack([c0, c1, c2], dim=1) / det
+
+
 def _colsum3(rows: Tensor) -> Tensor:
     """[R,3] -> [3] column sums (HIP, deterministic)."""
     lib = _lib.load()
@@ -598,7 +617,7 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
                 an.is_inited = True
         W = blk.permutate1.permutater.W
         y = linear(ActNormFn.apply(p, an.logs, an.bias, 0), W)     # einsum 'ij,bnj->bni' (permutate.py:118)
-        ld = (torch.sum(an.logs) + torch.slogdet(W)[1]) * N        # parameter-only scalars
+        ld = (torch.sum(an.logs) + torch.log(torch.abs(_det_inv3(W)[0]))) * N        # parameter-only scalars (permutate.py:119)
         td = 1 if i % 2 == 0 else 2
         o = cond_net(blk.coupling1.bias_net, torch.cat([y[..., :td], cs[i]], dim=-1))
         s = cond_net(blk.coupling2.scale_net, cs[i])
@@ -628,6 +647,6 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         td = 1 if i % 2 == 0 else 2
         o = cond_net(blk.coupling1.bias_net, torch.cat([v[..., :td], RepeatRowsFn.apply(cs[i], R)], dim=-1))
         W = blk.permutate1.permutater.W
-        u = linear(CoupleAddFn.apply(v, o, td), torch.inverse(W))  # permutate.py:123-124 (3x3 inverse: parameter-only)
+        u = linear(CoupleAddFn.apply(v, o, td), _det_inv3(W)[1])   # permutate.py:123-124 (3x3 inverse: parameter-only)
         u = ActNormFn.apply(u, blk.actnorm.logs, blk.actnorm.bias, 1)
     return u, logp

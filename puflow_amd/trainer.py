@@ -55,9 +55,14 @@ class TrainerModule(_Base):
 
     def log(self, name, value, **_kw):          # Lightning's self.log when running without Lightning
         if _Base is nn.Module:
-            self.logged[name] = float(value.detach()) if isinstance(value, Tensor) else float(value)
+            # kept as a (detached) device tensor: no device->host sync per logged value, readable inside a captured step;
+            # `logged_values()` converts on demand
+            self.logged[name] = value.detach() if isinstance(value, Tensor) else float(value)
         else:                                   # pragma: no cover
             super().log(name, value, **_kw)
+
+    def logged_values(self) -> dict:
+        return {k: float(v) for k, v in self.logged.items()}
 
     def forward(self, p: Tensor, **kwargs):
         return self.network(p, **kwargs)
@@ -103,9 +108,14 @@ class TrainerModule(_Base):
 
     def training_step(self, batch, batch_idx=0):
         loss = self._losses(batch)
-        if self.loss_mix != "pugan" and bool(torch.isnan(loss)):      # NaN guard, train_pu1k.py:71-73
-            print("loss is nan")
-            loss.data = torch.ones_like(loss) * 0.1
+        if self.loss_mix != "pugan":                                  # NaN guard, train_pu1k.py:71-73
+            if torch.cuda.is_current_stream_capturing():
+                # inside a captured step nothing may read the device: the same substitution as a tensor op (a NaN loss
+                # becomes the constant 0.1, whose gradient is zero instead of the reference's NaN gradients)
+                loss = torch.where(torch.isnan(loss), torch.full_like(loss, 0.1), loss)
+            elif bool(torch.isnan(loss)):
+                print("loss is nan")
+                loss.data = torch.ones_like(loss) * 0.1
         return loss
 
     @torch.no_grad()
@@ -147,16 +157,23 @@ class TrainerModule(_Base):
             self(sparse, upratio=int(dense.shape[1] / sparse.shape[1]))
         broadcast_module(self)
 
+    def graphed_train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2):
+        """`train_step` for a fixed batch shape captured in hipGraphs (puflow_amd/train_graph.py): returns
+        `step(batch) -> loss` that replays forward + backward (+ clip + Adam) with one launch instead of ~3 500."""
+        from .train_graph import GraphedTrainStep
+        return GraphedTrainStep(self, optimizer, batch, clip)
+
     def train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2) -> Tensor:
         self.train()
         self._sync_actnorm_init(batch)
-        optimizer.zero_grad(set_to_none=True)
+        if self._bucket is None or self._bucket.flat.device != next(self.parameters()).device:
+            self._bucket = FlatGradBucket(self.parameters(), as_views=True)      # .grad = views of ONE flat buffer
+        elif not self._bucket.views_intact():
+            self._bucket.rebind()
+        self._bucket.flat.zero_()                               # = optimizer.zero_grad(), one memset
         loss = self.training_step(batch, 0)
         loss.backward()
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            if self._bucket is None:
-                self._bucket = FlatGradBucket(self.parameters())
-            self._bucket.all_reduce_mean()                      # ONE 3.2 MB RCCL all-reduce per step
-        torch.nn.utils.clip_grad_norm_(self.parameters(), clip)
+        self._bucket.all_reduce_mean()                          # multi-rank: ONE 3.2 MB RCCL all-reduce, no packing copies
+        torch.nn.utils.clip_grad_norm_(self._bucket.params, clip)
         optimizer.step()
         return loss.detach()

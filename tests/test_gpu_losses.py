@@ -50,7 +50,7 @@ def test_chamfer_backward_matches_autograd():
 
 
 @pytest.mark.parametrize("B,n,eps,iters", [(2, 256, 0.005, 50), (3, 1024, 0.005, 50), (1, 1024, 0.002, 300),
-                                           (2, 192, 0.01, 7)])
+                                           (2, 192, 0.01, 7), (1, 3072, 0.005, 6), (1, 4608, 0.01, 4)])   # the last two: state (partly) in global memory
 def test_emd_matches_oracle(B, n, eps, iters):
     from puflow_amd.loss import emdFunction
     x, y = _unit_cube(B, n, 10 + n), _unit_cube(B, n, 20 + n)
