@@ -382,7 +382,7 @@ __device__ __forceinline__ float pf_rsmax16(float a, float b) {
 #ifndef PF_MMN_CPMAJOR
 #define PF_MMN_CPMAJOR 0
 #endif
-template <bool SWAP, int OB, int CP, int WCP, class WS, int P, int NIN, int NACC>
+template <bool SWAP, int OB, int CP, int WCP, bool FENCE = true, class WS, int P, int NIN, int NACC>
 __device__ __forceinline__ void pf_mmn(const WS& ws, int frag0, const PfPairN (&feat)[P][NIN], f4 (&acc)[P][NACC], int in0 = 0, int acc0 = 0) {
     constexpr int D = WS::DEPTH;                  // fragments in flight: 2 from LDS, 8 behind buffer loads (L2 latency)
     constexpr int NFRAG = OB * CP;
@@ -418,7 +418,7 @@ __device__ __forceinline__ void pf_mmn(const WS& ws, int frag0, const PfPairN (&
             }
             acc[p][acc0 + ob] = x;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);      // FENCE = false: the caller interleaves two streams itself
     }
 }
 
