@@ -72,6 +72,11 @@ int pf_cond(int unit, const float* h, const float* w, const long long* off, floa
             void* stream);
 int pf_post(int unit, const float* h, const float* w, const long long* off, float* c, float* st, float* cp,
             float* pq_next, int T, void* stream);
+/* pf_cond of all six units in ONE launch (the stages only feed the flow kernels, so they run after the EdgeConv chain):
+ * h[6] device pointers to the units' EdgeConv outputs (HOST array of device pointers), c[6] likewise (or NULL),
+ * st [6][T][8], cp [6][T][64], off[6*13]. */
+int pf_cond_all(const float* const* h, const float* w, const long long* off, float* const* c, float* st, float* cp, int T,
+                void* stream);
 
 /* Flow forward f: all 6 FlowBlock.forward in one launch.  Replaces PointInterpFlow.f /
  * FlowBlock.forward (modules/discrete/interpflow.py:302-313,:66-74; normalize.py:30-37,

@@ -24,6 +24,7 @@ SIGNATURES = {
     "pf_post": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                         c_void_p]),
     "pf_pq_gemm": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_int, c_void_p]),
+    "pf_cond_all": (c_int, [POINTER(c_void_p), c_void_p, POINTER(c_longlong), POINTER(c_void_p), c_void_p, c_void_p, c_int, c_void_p]),
     "pf_cond": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pf_flow_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pf_flow_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -136,15 +136,20 @@ struct CondArgs {
 
 __device__ __forceinline__ f4 pf_scale(f4 v, float k) { return v * k; }
 
+// body of the conditioner stage of one unit for the workgroup's tiles  tile0, tile0 + tstride, ... < a.ntiles;  wl: LDS for
+// the unit's fragment images (cond_lds_bytes<ODIM>())
+template <int ODIM>
+constexpr int cond_lds_bytes() { return ((ODIM / 32) * ((ODIM / 16 + 1) / 2) + 12 * ((ODIM / 32 + 1) / 2) + 20) * 2048; }
+
 template <int ODIM, int CDIM, int NW>
-__global__ __launch_bounds__(NW * 64) void cond_kernel(CondArgs a) {
+__device__ __forceinline__ void cond_body(const CondArgs& a, u4* wl, int tile0, int tstride) {
     constexpr int HB = ODIM / 16, MB = ODIM / 32, CB = CDIM / 16;
     constexpr int HP = (HB + 1) / 2, MP = (MB + 1) / 2;              // block pairs (32 input channels per MFMA step)
     // LDS-resident fragment images: M1 | H1 | S2 | T2 | ST4   (2 KiB per fragment pair)
     constexpr int F_M1 = 0, F_H1 = F_M1 + MB * HP, F_S2 = F_H1 + 12 * MP, F_T2 = F_S2 + 8, F_ST4 = F_T2 + 8, F_END = F_ST4 + 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
-    __shared__ u4 wl[F_END * 128];
+    static_assert(F_END * 2048 == cond_lds_bytes<ODIM>(), "LDS size formula");
     {
         auto stage = [&](int f0, int nf, long long off) {
             const u4* src = reinterpret_cast<const u4*>(a.w + off);
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void cond_kernel(CondArgs a) {
     const float* bT2 = a.w + a.off[7];
     const float* bST4 = a.w + a.off[9];
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = tile0; tile < a.ntiles; tile += tstride) {
         const int g = (tile * NW + wave) * 16 + col;
         const bool ok = g < a.T;
         const int pt = ok ? g : a.T - 1;
@@ -241,20 +246,58 @@ __global__ __launch_bounds__(NW * 64) void cond_kernel(CondArgs a) {
     }
 }
 
+#ifndef PF_COND_NW
+#define PF_COND_NW 12
+#endif
+constexpr int COND_NW = PF_COND_NW;
+
+template <int ODIM, int CDIM>
+__global__ __launch_bounds__(COND_NW * 64) void cond_kernel(CondArgs a) {
+    extern __shared__ u4 cond_lds[];
+    cond_body<ODIM, CDIM, COND_NW>(a, cond_lds, blockIdx.x, gridDim.x);
+}
+
+// All six units in ONE launch: workgroup -> (unit, slot) through `first[]` (units 0 / 1 are cheaper and get fewer workgroups).
+struct CondAllArgs { CondArgs u[6]; int first[7]; };
+
+__global__ __launch_bounds__(COND_NW * 64) void cond_all_kernel(CondAllArgs g) {
+    extern __shared__ u4 cond_lds[];
+    const int b = blockIdx.x;
+    int unit = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) unit += b >= g.first[i] ? 1 : 0;
+    const int slot = b - g.first[unit], n = g.first[unit + 1] - g.first[unit];
+    if (unit == 0) cond_body<32, 32, COND_NW>(g.u[0], cond_lds, slot, n);
+    else if (unit == 1) cond_body<64, 64, COND_NW>(g.u[1], cond_lds, slot, n);
+    else {
+        // the four 128-channel units share ONE inlined body: their argument records are selected with scalar moves
+        // (unit is workgroup-uniform), not by indexing the kernel-argument array (that would spill it to scratch)
+        CondArgs a = g.u[2];
+        if (unit == 3) a = g.u[3];
+        if (unit == 4) a = g.u[4];
+        if (unit == 5) a = g.u[5];
+        cond_body<128, 128, COND_NW>(a, cond_lds, slot, n);
+    }
+}
+
+template <class KERNEL>
+void cond_allow_lds(KERNEL k, int bytes) {
+    if (bytes > 64 * 1024)       // idempotent opt-in to > 64 KiB of dynamic LDS (no state kept on our side)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 template <int ODIM, int CDIM>
 int launch_cond(CondArgs a, hipStream_t s) {
-#ifndef PF_COND_NW
-#define PF_COND_NW 16
-#endif
-    constexpr int NW = PF_COND_NW;
+    constexpr int NW = COND_NW, lds = cond_lds_bytes<ODIM>();
     a.ntiles = (a.T + NW * 16 - 1) / (NW * 16);
-    constexpr int lds = ((ODIM / 32) * ((ODIM / 16 + 1) / 2) + 12 * ((ODIM / 32 + 1) / 2) + 20) * 2048;
     int per_cu = (160 * 1024) / lds;                       // persistent workgroups that fit one CU's LDS
-    if (per_cu > 4) per_cu = 4;
+    const int by_waves = 32 / NW;
+    if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     const int cap = 256 * per_cu;
     const int grid = a.ntiles < cap ? a.ntiles : cap;
-    hipLaunchKernelGGL((cond_kernel<ODIM, CDIM, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    cond_allow_lds(cond_kernel<ODIM, CDIM>, lds);
+    hipLaunchKernelGGL((cond_kernel<ODIM, CDIM>), dim3(grid), dim3(NW * 64), lds, s, a);
     return pf_last_launch_status();
 }
 
@@ -290,6 +333,32 @@ extern "C" int pf_cond(int unit, const float* h, const float* w, const long long
         case 2: case 3: case 4: case 5: return launch_cond<128, 128>(a, s);
         default: return PF_ERR_UNSUPPORTED;
     }
+}
+
+// The conditioner stages of all six units in one launch.  h[u]: unit u's EdgeConv output [T, odim_u]; c[u] nullable (all or
+// none); st [6][T][8], cp [6][T][64] unit-major as the flow kernels read them; off: 6 x 13 offsets (POST_SLOTS per unit).
+extern "C" int pf_cond_all(const float* const* h, const float* w, const long long* off, float* const* c, float* st, float* cp,
+                           int T, void* stream) {
+    if (!h || !w || !off || !st || !cp) return PF_ERR_NULL;
+    if (T <= 0) return PF_ERR_SHAPE;
+    CondAllArgs g{};
+    const int ntiles = (T + COND_NW * 16 - 1) / (COND_NW * 16);
+    // workgroups per unit: units 0 / 1 carry about half the work of a 128-channel unit; one workgroup per CU (LDS)
+    static const int share[6] = {32, 32, 48, 48, 48, 48};
+    g.first[0] = 0;
+    for (int u = 0; u < 6; ++u) {
+        if (!h[u]) return PF_ERR_NULL;
+        CondArgs& a = g.u[u];
+        a.h = h[u]; a.w = w; a.c = c ? c[u] : nullptr; a.st = st + (size_t)u * T * 8; a.cp = cp + (size_t)u * T * 64; a.T = T;
+        a.ntiles = ntiles;
+        for (int i = 0; i < 13; ++i) a.off[i] = off[u * 13 + i];
+        const int n = ntiles < share[u] ? ntiles : share[u];
+        g.first[u + 1] = g.first[u] + n;
+    }
+    constexpr int lds = cond_lds_bytes<128>();
+    cond_allow_lds(cond_all_kernel, lds);
+    hipLaunchKernelGGL(cond_all_kernel, dim3(g.first[6]), dim3(COND_NW * 64), lds, (hipStream_t)stream, g);
+    return pf_last_launch_status();
 }
 
 // Both stages of unit `unit` (the round-1 entry point, kept for callers that want one call per unit).

@@ -156,6 +156,7 @@ class _Engine:
         # launch shape of the split kernels (tuning knob; tools/tune_edgeconv.py)
         self.ec3_variant = int(os.environ.get("PF_EC3_VARIANT", _EC_VARIANT.get(self.ec_mode, "0")))
         self.post = [_lib.offsets(o) for o in pk["post"]]
+        self.post_all = _lib.offsets([v for o in pk["post"] for v in o])
         self.flow = pk["flow"]
         self.interp_off = _lib.offsets(pk["interp"])
         self.ld_const = pk["ld_const"]
@@ -208,13 +209,18 @@ class _Engine:
             if u + 1 < NUM_BLOCKS:
                 _lib.check(self.lib.pf_pq_gemm(u, h.data_ptr(), self.base, self.post[u], pq.data_ptr(), T, s), f"pf_pq_gemm[{u}]")
             hs.append(h)
-        cs: List[Optional[Tensor]] = []
-        for u in range(NUM_BLOCKS):
-            c = torch.empty((B, N, COND_CHANNELS[u]), dtype=torch.float32, device=dev) if want_cs else None
-            _lib.check(self.lib.pf_cond(u, hs[u].data_ptr(), self.base, self.post[u], c.data_ptr() if want_cs else None,
-                                        st[u].data_ptr(), cp[u].data_ptr(), T, s), f"pf_cond[{u}]")
-            cs.append(c)
+        cs: List[Optional[Tensor]] = [torch.empty((B, N, COND_CHANNELS[u]), dtype=torch.float32, device=dev) if want_cs else None
+                                      for u in range(NUM_BLOCKS)]
+        self._cond_all(hs, cs if want_cs else None, st, cp, T, s)
         return (cs if want_cs else None), cp, st
+
+    def _cond_all(self, hs, cs, st: Tensor, cp: Tensor, T: int, s) -> None:
+        """The six conditioner stages in one launch (pf_cond_all)."""
+        import ctypes
+        PtrArr = ctypes.c_void_p * NUM_BLOCKS
+        h_arr = PtrArr(*[h.data_ptr() for h in hs])
+        c_arr = PtrArr(*[c.data_ptr() for c in cs]) if cs is not None else None
+        _lib.check(self.lib.pf_cond_all(h_arr, self.base, self.post_all, c_arr, st.data_ptr(), cp.data_ptr(), T, s), "pf_cond_all")
 
     def flow_f(self, xyz: Tensor, cp: Tensor, st: Tensor):
         B, N, _ = xyz.shape
@@ -274,9 +280,7 @@ class _Engine:
                 if u + 1 < NUM_BLOCKS:
                     timed(f"pq{u}", lambda: _lib.check(self.lib.pf_pq_gemm(u, h.data_ptr(), self.base, self.post[u], pq.data_ptr(), T, s)))
                 hs.append(h)
-            for u in range(NUM_BLOCKS):
-                timed(f"cond{u}", lambda: _lib.check(self.lib.pf_cond(u, hs[u].data_ptr(), self.base, self.post[u], None,
-                                                                     st[u].data_ptr(), cp[u].data_ptr(), T, s)))
+            timed("cond_all", lambda: self._cond_all(hs, None, st, cp, T, s))
             z, _, _ = timed("flow_f+logp", lambda: self.flow_f(xyz, cp, st))
             u_ = timed("interp", lambda: self.interp(xyz, z, idx16, R))
             timed("flow_g", lambda: self.flow_g(u_, cp, st, R))
