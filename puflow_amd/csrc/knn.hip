@@ -207,22 +207,21 @@ __global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ 
 // work: at 32 x 2048 that kernel puts ONE wave on each SIMD, so nothing hides its readlane / LDS / dependent-issue stalls.
 // Candidate lists are per (wave, lane); wave 0 inserts them in wave order = increasing index, which keeps the
 // (distance, index) tie rule.  Overflow of any list -> exact scan of that query tile by wave 0.
-#ifndef PF_KNN4_W
-#define PF_KNN4_W 4
-#endif
-constexpr int KNN4_W = PF_KNN4_W; // waves per workgroup = reference slices (4 or 8)
-constexpr int KNN4_G = 32 / KNN4_W;   // strided minimum groups per slice
+// KNN4_W = waves per workgroup = reference slices: 4 when the grid fills the chip anyway (32 x 2048: 1024 workgroups), 8 or
+// 16 for small batches (4 x 2048: 128 workgroups of 16 waves instead of 4 - the kernel's latency is one wave's two sweeps
+// over its slice, so more, shorter slices cut it almost proportionally).  Same results for every split.
 #ifndef PF_KNN4_U
 #define PF_KNN4_U 32
 #endif
-constexpr int KNN4_U = PF_KNN4_U;     // references per unrolled chunk (multiple of KNN4_G)
-constexpr int KNN4_CAP = 32;      // per-(wave, lane) candidate list capacity
+constexpr int KNN4_U = PF_KNN4_U;     // references per unrolled chunk (a multiple of every KNN4_G)
 
-template <int K>
+template <int K, int KNN4_W>
 __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
                                                            int N, int M, int* __restrict__ idx_out,
                                                            float* __restrict__ dist_out) {
     static_assert(K <= 16, "threshold selection uses two 16-element sorted halves");
+    constexpr int KNN4_G = 32 / KNN4_W;                       // strided minimum groups per slice
+    constexpr int KNN4_CAP = 32;                              // per-(wave, lane) candidate list capacity (spatially ordered inputs put most candidates in one slice)
     __shared__ float gms[32][64];
     __shared__ unsigned short lst[KNN4_W][KNN4_CAP][64];
     __shared__ int cnts[KNN4_W][64];
@@ -358,14 +357,21 @@ extern "C" int pf_knn(const float* p1, const float* p2, int B, int N, int M, int
     if (!p1 || !p2 || !idx_out) return PF_ERR_NULL;
     if (B <= 0 || N <= 0 || M <= 0 || K <= 0 || K > M || B > 65535) return PF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (K <= 16 && M >= 1024 && M <= 65536) {          // two-sweep kernel, references split over 4 waves
-        dim3 g4((N + 63) / 64, B), b4(KNN4_W * 64);
+    if (K <= 16 && M >= 1024 && M <= 65536) {          // two-sweep kernel, references split over 4 / 8 / 16 waves
+        const dim3 g4((N + 63) / 64, B);
+        const long long wgs = (long long)g4.x * B;
+        const int W = wgs >= 1024 ? 4 : (wgs >= 384 ? 8 : 16);
+#define PF_KNN4_LAUNCH(KK)                                                                                              \
+        if (W == 4) hipLaunchKernelGGL((knn4_kernel<KK, 4>), g4, dim3(256), 0, s, p1, p2, N, M, idx_out, dist_out);         \
+        else if (W == 8) hipLaunchKernelGGL((knn4_kernel<KK, 8>), g4, dim3(512), 0, s, p1, p2, N, M, idx_out, dist_out);    \
+        else hipLaunchKernelGGL((knn4_kernel<KK, 16>), g4, dim3(1024), 0, s, p1, p2, N, M, idx_out, dist_out)
         switch (K) {
-            case 4:  hipLaunchKernelGGL(knn4_kernel<4>, g4, b4, 0, s, p1, p2, N, M, idx_out, dist_out); break;
-            case 8:  hipLaunchKernelGGL(knn4_kernel<8>, g4, b4, 0, s, p1, p2, N, M, idx_out, dist_out); break;
-            case 16: hipLaunchKernelGGL(knn4_kernel<16>, g4, b4, 0, s, p1, p2, N, M, idx_out, dist_out); break;
+            case 4:  PF_KNN4_LAUNCH(4); break;
+            case 8:  PF_KNN4_LAUNCH(8); break;
+            case 16: PF_KNN4_LAUNCH(16); break;
             default: return PF_ERR_UNSUPPORTED;
         }
+#undef PF_KNN4_LAUNCH
         return pf_last_launch_status();
     }
     if (K <= 16 && M >= 256 && M <= 65536) {           // two-sweep kernel (u16 candidate lists)

@@ -32,8 +32,10 @@ def _net(sd):
 # ------------------------------------------------------------------------------------- kNN
 @pytest.mark.parametrize("B,N,M,K", [(2, 256, 256, 16), (1, 2048, 2048, 16), (3, 100, 77, 8), (1, 65, 300, 4),
                                      (2, 130, 130, 32), (1, 16, 16, 16), (2, 1000, 5000, 16), (1, 3000, 2049, 8),
-                                     (1, 257, 4096, 16)])
+                                     (1, 257, 4096, 16), (8, 3072, 2048, 16), (32, 2048, 2048, 16), (4, 2048, 2048, 8)])
 def test_knn_bit_exact(lib, B, N, M, K):
+    """The two-sweep kernel splits the references over 16 / 8 / 4 waves for grids of < 384 / < 1024 / more workgroups
+    (the shapes above exercise all three), with the same results."""
     from puflow_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + N + K)
     p1 = torch.rand(B, N, 3, generator=g) * 2 - 1
