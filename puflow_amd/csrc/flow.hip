@@ -9,8 +9,9 @@
 // Host-side folds (puflow_amd/packing.py): actnorm o inv1x1 = one 3x3 affine (A, a0) and its
 // inverse (Ai, ai0); injector (s, t) and the c-part of coupling1's first layer (cp) come
 // precomputed per ORIGINAL point from pf_post.  What is left per row is the coupling MLP
-// 64 -> 64 -> (1|2): split-fp16 products on the fp16 MFMA (pf_mfma.h "f16x2", fp32-class accuracy),
-// 16 rows per column tile, 30 MFMAs per tile and block.
+// 64 -> 64 -> (1|2): split-fp16 products with a natural-scale low half on the fp16 MFMA (pf_mfma.h "f16n", fp32-class
+// accuracy; W2 / W4 arrive scaled by a power of two each, their biases pre-multiplied, the kernel multiplies by the
+// inverses), 16 rows per column tile, 30 MFMAs per tile and block.
 //
 // The chain of 6 blocks is latency-bound, not throughput-bound (per tile: 6 x [gather cp/st -> 64 VALU ->
 // 24 MFMA -> split -> 6 MFMA -> exp/affine]), so the kernel is built for occupancy and short latencies:
@@ -18,21 +19,21 @@
 // at <= 128 VGPRs (4 waves per SIMD), and the next block's cp / st rows are fetched while the current block computes.
 //
 // Per-block weight record (floats), stride FLOW_REC = 5360:
-//   [0,4096)    f16x2 image of W2 (4 ob x 2 pairs)      [4096,5120) f16x2 image of W4 (1 ob x 2 pairs; rows
+//   [0,4096)    f16n image of 2^s2 W2 (4 ob x 2 pairs)      [4096,5120) f16n image of 2^s4 W4 (1 ob x 2 pairs; rows
 //               replicated into every 4-row q group)
-//   [5120,5184) b2      [5184,5200) b4 (replicated likewise)      [5200,5328) W0h [64][2]
-//   [5328,5352) A(9) a0(3) Ai(9) ai0(3)   [5352,5360) pad
+//   [5120,5184) 2^s2 b2      [5184,5200) 2^s4 b4 (replicated likewise)      [5200,5328) W0h [64][2]
+//   [5328,5352) A(9) a0(3) Ai(9) ai0(3)   [5352] 2^-s2   [5353] 2^-s4   [5354,5360) pad
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
 
-// waves per workgroup: g (inverse) fits 128 VGPRs -> 16 waves; f keeps (s, t) live across the coupling net and needs a
-// few more registers -> 12 waves (170 VGPRs each)
+// waves per workgroup: both directions fit 128 VGPRs -> 16 waves (4 per SIMD) since the coupling nets run on the f16n
+// helpers (no cross accumulator)
 #ifndef PF_FLOW_NW
 #define PF_FLOW_NW 16
 #endif
 #ifndef PF_FLOW_NW_FWD
-#define PF_FLOW_NW_FWD 12
+#define PF_FLOW_NW_FWD 16
 #endif
 
 namespace {
@@ -71,7 +72,8 @@ __device__ __forceinline__ FlowCond flow_cond(const float* __restrict__ cp, cons
 template <int TD>
 __device__ __forceinline__ void coupling_net(const float* rec /*LDS*/, int lane, int q, const FlowCond& c,
                                              const float (&h1)[2], float (&o)[2]) {
-    PfPair2 hp[1][2];
+    PfPairN hp[1][2];
+    const float i2 = rec[5352], i4 = rec[5353];
     {
         f4 hid[4];
 #pragma unroll
@@ -87,20 +89,20 @@ __device__ __forceinline__ void coupling_net(const float* rec /*LDS*/, int lane,
             }
             hid[cb] = pf_lrelu(v, 0.01f);
         }
-        hp[0][0] = pf_pair2(hid[0], hid[1]);
-        hp[0][1] = pf_pair2(hid[2], hid[3]);
+        hp[0][0] = pf_pairn(hid[0], hid[1]);
+        hp[0][1] = pf_pairn(hid[2], hid[3]);
     }
     const PfW2Lds ws{reinterpret_cast<const u4*>(rec), lane};
     f4 h2[1][4];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) h2[0][ob] = pf_bias(rec + 5120, ob, q);
-    pf_mm2f<4, 2, 2>(ws, 0, hp, 0, h2, 0);
-    hp[0][0] = pf_pair2(pf_lrelu(h2[0][0], 0.01f), pf_lrelu(h2[0][1], 0.01f));
-    hp[0][1] = pf_pair2(pf_lrelu(h2[0][2], 0.01f), pf_lrelu(h2[0][3], 0.01f));
+    pf_mmn<false, 4, 2, 2>(ws, 0, hp, h2);
+    hp[0][0] = pf_pairn(pf_lrelu(h2[0][0] * i2, 0.01f), pf_lrelu(h2[0][1] * i2, 0.01f));
+    hp[0][1] = pf_pairn(pf_lrelu(h2[0][2] * i2, 0.01f), pf_lrelu(h2[0][3] * i2, 0.01f));
     f4 acc[1][1];
     acc[0][0] = *reinterpret_cast<const f4*>(rec + 5184 + 4 * q);
-    pf_mm2f<1, 2, 2>(ws, 8, hp, 0, acc, 0);
-    o[0] = acc[0][0].x; o[1] = acc[0][0].y;
+    pf_mmn<false, 1, 2, 2>(ws, 8, hp, acc);
+    o[0] = acc[0][0].x * i4; o[1] = acc[0][0].y * i4;
 }
 
 template <bool INV, int NW>

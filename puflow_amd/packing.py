@@ -321,6 +321,20 @@ def frag_unpack_f16x2(F: np.ndarray, out: int, inn: int) -> np.ndarray:
     return W.reshape(OB * 16, CP * 32)[:out, :inn]
 
 
+def frag_unpack_f16n(F: np.ndarray, out: int, inn: int) -> np.ndarray:
+    """Inverse of frag_pack_f16n (tests): float64 hi + lo of the [out, inn] matrix (still carrying the packer's scale)."""
+    OB, CP = (out + 15) // 16, (inn + 31) // 32
+    img = np.ascontiguousarray(F, dtype=np.float32).view(np.uint16).reshape(OB, CP, 2, 64, 8).view(np.float16).astype(np.float64)
+    val = img[:, :, 0] + img[:, :, 1]
+    lanes = np.arange(64)
+    row, q = lanes & 15, lanes >> 4
+    j = np.arange(8)
+    ch = np.where(j[None, :] < 4, 4 * q[:, None] + j[None, :], 16 + 4 * q[:, None] + (j[None, :] - 4))
+    W = np.zeros((OB, 16, CP, 32))
+    W[:, row[:, None], :, ch] = val.transpose(2, 3, 0, 1)
+    return W.reshape(OB * 16, CP * 32)[:out, :inn]
+
+
 def frag_unpack(F: np.ndarray, out: int, inn: int) -> np.ndarray:
     OB, CB = F.shape[0], F.shape[1]
     f = F.reshape(OB, CB, 4, 16, 4).transpose(0, 3, 1, 2, 4)
@@ -406,21 +420,24 @@ def _ec_frags(u: Dict[str, np.ndarray], nconv: int) -> np.ndarray:
 def pack_flow_record(f: Dict[str, object]) -> np.ndarray:
     """One 5360-float flow-block record (layout: csrc/flow.hip header)."""
     rec = np.zeros(FLOW_REC, np.float32)
-    rec[0:4096] = frag_pack_f16x2(f["c1_W2"])         # 4 ob x 2 pairs
+    img2, inv2 = frag_pack_f16n_scaled(f["c1_W2"])     # 4 ob x 2 pairs
+    rec[0:4096] = img2
     W4 = f["c1_W4"]                                   # [3-td, 64]
     W4r = np.zeros((16, 64), np.float32)
     b4r = np.zeros(16, np.float32)
     for q in range(4):
         W4r[4 * q:4 * q + W4.shape[0]] = W4
         b4r[4 * q:4 * q + W4.shape[0]] = f["c1_b4"]
-    rec[4096:5120] = frag_pack_f16x2(W4r)             # 1 ob x 2 pairs
-    rec[5120:5184] = f["c1_b2"]
-    rec[5184:5200] = b4r
+    img4, inv4 = frag_pack_f16n_scaled(W4r)           # 1 ob x 2 pairs
+    rec[4096:5120] = img4
+    rec[5120:5184] = f["c1_b2"] / inv2
+    rec[5184:5200] = b4r / inv4
     W0h = np.zeros((64, 2), np.float32)
     W0h[:, :f["tdim"]] = f["c1_W0h"]
     rec[5200:5328] = W0h.reshape(-1)
     rec[5328:5337] = f["A"].reshape(-1); rec[5337:5340] = f["a0"]
     rec[5340:5349] = f["Ai"].reshape(-1); rec[5349:5352] = f["ai0"]
+    rec[5352], rec[5353] = inv2, inv4
     return rec
 
 

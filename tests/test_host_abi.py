@@ -83,13 +83,17 @@ def test_pack_plan_layout():
     # unit 3 growth weights: G1 (2x2 frags) first
     g1 = frag_unpack(blob[pk["ec_w"][3]:pk["ec_w"][3] + 4 * 256].reshape(2, 2, 64, 4), 32, 32)
     np.testing.assert_array_equal(g1, plan["units"][3]["G1"])
-    # flow record: split-fp16 images of W2 then the replicated W4 rows; hi + lo' 2^-11 reproduces fp32 to ~2^-22
-    from puflow_amd.packing import frag_unpack_f16x2
+    # flow record: natural-scale split-fp16 images of 2^s W2 then the replicated 2^s W4 rows, with 2^-s stored behind:
+    # (hi + lo) 2^-s reproduces fp32 to ~2^-22 (the scale puts max |W| at 2^13: every lo that matters is a normal fp16)
+    from puflow_amd.packing import frag_unpack_f16n, frag_unpack_f16x2
     rec = blob[pk["flow"] + 2 * FLOW_REC: pk["flow"] + 3 * FLOW_REC]
     W2 = plan["flows"][2]["c1_W2"]
-    np.testing.assert_allclose(frag_unpack_f16x2(rec[:4096], 64, 64), W2, rtol=2.0 ** -21, atol=1e-12)
-    w4 = frag_unpack_f16x2(rec[4096:5120], 16, 64)
+    inv2, inv4 = float(rec[5352]), float(rec[5353])
+    assert np.log2(inv2) == np.round(np.log2(inv2)) and 2.0 ** 13 <= np.abs(W2).max() / inv2 < 2.0 ** 14
+    np.testing.assert_allclose(frag_unpack_f16n(rec[:4096], 64, 64) * inv2, W2, rtol=2.0 ** -21, atol=1e-12)
+    w4 = frag_unpack_f16n(rec[4096:5120], 16, 64) * inv4
     np.testing.assert_allclose(w4[4:6], plan["flows"][2]["c1_W4"], rtol=2.0 ** -21, atol=1e-12)
+    np.testing.assert_allclose(rec[5120:5184] * inv2, plan["flows"][2]["c1_b2"], rtol=1e-6)
     np.testing.assert_array_equal(rec[5328:5337].reshape(3, 3), plan["flows"][2]["A"])
     assert FLOW_REC == 5360 and rec.size == FLOW_REC
     # EdgeConv unit 3, split-fp16 image: G1 [32, 32] = 2 ob x 1 pair
