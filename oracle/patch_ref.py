@@ -19,20 +19,28 @@ Tensor = torch.Tensor
 
 
 def fps(xyz: Tensor, npoint: int) -> Tensor:
-    """[B,N,3] -> int64 [B,npoint]."""
+    """[B,N,3] -> int64 [B,npoint].  numpy on coordinate planes with preallocated temporaries (20 024 steps over 99 840
+    points in seconds); the arithmetic and its order are the pinned ones: fp32 (dx^2 + dy^2) + dz^2, running minimum,
+    first maximal value."""
+    import numpy as np
     B, N, _ = xyz.shape
-    out = torch.zeros(B, npoint, dtype=torch.int64)
+    out = np.zeros((B, npoint), np.int64)
     for b in range(B):
-        p = xyz[b].float()
-        mind = torch.full((N,), 1e10)
+        p = np.ascontiguousarray(xyz[b].detach().cpu().float().numpy())
+        px, py, pz = p[:, 0].copy(), p[:, 1].copy(), p[:, 2].copy()
+        mind = np.full(N, 1e10, np.float32)
+        t0, t1 = np.empty(N, np.float32), np.empty(N, np.float32)
         cur = 0
         for j in range(1, npoint):
-            d = p - p[cur]
-            dd = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
-            mind = torch.minimum(mind, dd)
-            cur = int(torch.argmax(mind))            # first maximal value
+            np.subtract(px, px[cur], out=t0); np.multiply(t0, t0, out=t0)
+            np.subtract(py, py[cur], out=t1); np.multiply(t1, t1, out=t1)
+            np.add(t0, t1, out=t0)
+            np.subtract(pz, pz[cur], out=t1); np.multiply(t1, t1, out=t1)
+            np.add(t0, t1, out=t0)
+            np.minimum(mind, t0, out=mind)
+            cur = int(np.argmax(mind))               # first maximal value
             out[b, j] = cur
-    return out
+    return torch.from_numpy(out)
 
 
 def normalize_pc(pc: Tensor):

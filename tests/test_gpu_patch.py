@@ -177,6 +177,7 @@ def test_pugan_5000_to_20000_pipeline():
     # the one-call pipeline gives the same cloud
     e2e = PatchHelper.remove_outliers(ph.upsample(net, pc.to(DEV), npoint=20024, upratio=4), pc.to(DEV), 24)
     assert torch.equal(e2e, out)
+    # coverage, end to end against the all-oracle pipeline (its own candidates, its own selection)
     cd_out = float(O.chamfer_distance_mean(out.cpu(), pc))
     ref_full = P.remove_outliers(P.merge_patches(cand_ref, 20024) * gfd.cpu() + gc.cpu(), pc, 24)
     cd_ref = float(O.chamfer_distance_mean(ref_full, pc))
