@@ -580,6 +580,16 @@ def cond_net(net, h: Tensor) -> Tensor:
     return linear(h, L[4].weight, L[4].bias)
 
 
+def cond_net_split(net, h1: Tensor, cpart: Tensor) -> Tensor:
+    """LinearA1D on cat[h1, c] with the c-columns of the bias-free first layer already applied: W0 [h1; c] = W0[:, :td] h1 +
+    cpart (interpflow.py:38-41).  cpart = W0[:, td:] c is per ORIGINAL point: f and the R replicas of g share one evaluation."""
+    L = net.layers
+    td = h1.shape[-1]
+    h = ActFn.apply(linear(h1, L[0].weight[:, :td]) + cpart, 0.01)
+    h = ActFn.apply(linear(h, L[2].weight, L[2].bias), 0.01)
+    return linear(h, L[4].weight, L[4].bias)
+
+
 def _mlp_bn(mlp, x: Tensor) -> Tensor:
     """Conv,BN,LReLU(.01),Conv,BN,LReLU,Conv on rows (DistanceEncoder / WeightEstimationUnit)."""
     x = bn_lrelu(linear(x, mlp[0].weight, mlp[0].bias), mlp[1], 0.01)
@@ -607,6 +617,8 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     # ---- f + log-likelihood
     p = xyz
     ldj = torch.zeros(B, device=xyz.device)
+    st_nets: List[Tuple[Tensor, Tensor]] = []                      # injector (s, t) per block: functions of cs[i] only, shared by f and g
+    cparts: List[Tensor] = []                                      # c-columns of coupling1's first layer, likewise
     for i in range(net.num_blocks):
         blk = net.flow_blocks[i]
         an = blk.actnorm
@@ -619,9 +631,11 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         y = linear(ActNormFn.apply(p, an.logs, an.bias, 0), W)     # einsum 'ij,bnj->bni' (permutate.py:118)
         ld = (torch.sum(an.logs) + torch.log(torch.abs(_det_inv3(W)[0]))) * N        # parameter-only scalars (permutate.py:119)
         td = 1 if i % 2 == 0 else 2
-        o = cond_net(blk.coupling1.bias_net, torch.cat([y[..., :td], cs[i]], dim=-1))
+        cparts.append(linear(cs[i], blk.coupling1.bias_net.layers[0].weight[:, td:]))
+        o = cond_net_split(blk.coupling1.bias_net, y[..., :td], cparts[i])
         s = cond_net(blk.coupling2.scale_net, cs[i])
         t = cond_net(blk.coupling2.bias_net, cs[i])
+        st_nets.append((s, t))
         p = CoupleInjectFn.apply(y, o, s, t, td)
         ldj = ldj + ld - BatchSumFn.apply(s, 0)
     z = p
@@ -641,11 +655,11 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     # ---- g (exact inverse); injector nets are evaluated per ORIGINAL point and replicated
     for i in reversed(range(net.num_blocks)):
         blk = net.flow_blocks[i]
-        s = RepeatRowsFn.apply(cond_net(blk.coupling2.scale_net, cs[i]), R)
-        t = RepeatRowsFn.apply(cond_net(blk.coupling2.bias_net, cs[i]), R)
+        s = RepeatRowsFn.apply(st_nets[i][0], R)                   # same nets, same input as in f: evaluated once (autograd sums both uses)
+        t = RepeatRowsFn.apply(st_nets[i][1], R)
         v = InjectInvFn.apply(u, s, t)
         td = 1 if i % 2 == 0 else 2
-        o = cond_net(blk.coupling1.bias_net, torch.cat([v[..., :td], RepeatRowsFn.apply(cs[i], R)], dim=-1))
+        o = cond_net_split(blk.coupling1.bias_net, v[..., :td], RepeatRowsFn.apply(cparts[i], R))
         W = blk.permutate1.permutater.W
         u = linear(CoupleAddFn.apply(v, o, td), _det_inv3(W)[1])   # permutate.py:123-124 (3x3 inverse: parameter-only)
         u = ActNormFn.apply(u, blk.actnorm.logs, blk.actnorm.bias, 1)
