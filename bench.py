@@ -272,12 +272,20 @@ def bench_train(args, world, rank, dev, dist):
         if world > 1:
             dist.barrier()
 
+    # the step is replayed from hipGraphs by default (forward + loss + backward [+ all-reduce between two graphs] + clip + Adam:
+    # same kernels, same order; PF_BENCH_GRAPH=0 times the eager launches)
+    step = lambda b: tm.train_step(b, opt)
+    if os.environ.get("PF_BENCH_GRAPH", "1") == "1":
+        try:
+            step = tm.graphed_train_step(batch, opt)
+        except Exception as ex:
+            print(f"[bench] training-step capture failed ({type(ex).__name__}: {ex}); timing the eager step", file=sys.stderr)
     for _ in range(args.warmup):
-        tm.train_step(batch, opt)
+        step(batch)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tm.train_step(batch, opt)
+        loss = step(batch)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
     t = torch.tensor([el], dtype=torch.float64, device=dev)

@@ -51,36 +51,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = pf_splat(0.f);
 
-    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
-        if (VEC) {
-            for (int v = tid; v < BM * 4; v += 256) {           // A tile: BM x 16 floats = BM*4 float4
-                f4 x = pf_splat(0.f);
-                if (a_kfast) {                                  // float4 = 4 consecutive k of one row
+    // VEC: the next K-step's operand tiles are fetched into registers while the current one is multiplied (the layer GEMMs
+    // are 2..32 K-steps long: with load -> barrier -> multiply -> barrier per step every step paid a full memory latency)
+    constexpr int NA = (BM * 4 + 255) / 256, NB = (BN * 4 + 255) / 256;
+    f4 ra[NA], rb[NB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * 256;
+            f4 x = pf_splat(0.f);
+            if (v < BM * 4) {
+                if (a_kfast) {
                     const int r = v >> 2, k = (v & 3) * 4;
                     const int gm = m0 + r, gk = k0 + k;
                     if (gm < g.M && gk < k_hi) x = *reinterpret_cast<const f4*>(g.A + gm * g.sam + gk);
-                    *reinterpret_cast<f4*>(&As[r][k]) = x;
-                } else {                                        // float4 = 4 consecutive rows of one k
+                } else {
                     const int k = v / (BM / 4), r = (v % (BM / 4)) * 4;
                     const int gm = m0 + r, gk = k0 + k;
                     if (gm < g.M && gk < k_hi) x = *reinterpret_cast<const f4*>(g.A + gk * g.sak + gm);
-                    As[r][k] = x.x; As[r + 1][k] = x.y; As[r + 2][k] = x.z; As[r + 3][k] = x.w;
                 }
             }
-            for (int v = tid; v < BN * 4; v += 256) {           // B tile: 16 x BN floats
-                f4 x = pf_splat(0.f);
-                if (b_nfast) {                                  // float4 = 4 consecutive n of one k
+            ra[i] = x;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int v = tid + i * 256;
+            f4 x = pf_splat(0.f);
+            if (v < BN * 4) {
+                if (b_nfast) {
                     const int k = v / (BN / 4), n = (v % (BN / 4)) * 4;
                     const int gn = n0 + n, gk = k0 + k;
                     if (gn < g.N && gk < k_hi) x = *reinterpret_cast<const f4*>(g.B + gk * g.sbk + gn);
-                    *reinterpret_cast<f4*>(&Bs[k][n]) = x;
-                } else {                                        // float4 = 4 consecutive k of one n
+                } else {
                     const int n = v >> 2, k = (v & 3) * 4;
                     const int gn = n0 + n, gk = k0 + k;
                     if (gn < g.N && gk < k_hi) x = *reinterpret_cast<const f4*>(g.B + gn * g.sbn + gk);
+                }
+            }
+            rb[i] = x;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * 256;
+            if (v < BM * 4) {
+                const f4 x = ra[i];
+                if (a_kfast) {
+                    const int r = v >> 2, k = (v & 3) * 4;
+                    *reinterpret_cast<f4*>(&As[r][k]) = x;
+                } else {
+                    const int k = v / (BM / 4), r = (v % (BM / 4)) * 4;
+                    As[r][k] = x.x; As[r + 1][k] = x.y; As[r + 2][k] = x.z; As[r + 3][k] = x.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int v = tid + i * 256;
+            if (v < BN * 4) {
+                const f4 x = rb[i];
+                if (b_nfast) {
+                    const int k = v / (BN / 4), n = (v % (BN / 4)) * 4;
+                    *reinterpret_cast<f4*>(&Bs[k][n]) = x;
+                } else {
+                    const int n = v >> 2, k = (v & 3) * 4;
                     Bs[k][n] = x.x; Bs[k + 1][n] = x.y; Bs[k + 2][n] = x.z; Bs[k + 3][n] = x.w;
                 }
             }
+        }
+    };
+    if (VEC) fetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+        if (VEC) {
+            stash();
         } else {
             for (int v = tid; v < BM * 16; v += 256) {
                 const int r = a_kfast ? (v >> 4) : (v % BM);
@@ -96,6 +140,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             }
         }
         __syncthreads();
+        if (VEC && k0 + 16 < k_hi) fetch(k0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float a[TM], b[TN];
