@@ -268,6 +268,21 @@ int pf_cnf_step(const float* y0, const float* f0, float t, float h, int reverse,
                 const float* rec, float* y1, float* f1, float* ymid, float rtol, float atol, int rows, int R, double* ws,
                 double* out, void* stream);
 
+/* n_attempts dopri5 step attempts with the step-size controller ON THE DEVICE (no host read between attempts).
+ * ctl: 16 doubles - [0] t [1] dt [2] t1 [3] n_tot (elements of the RMS norm) [4] cur (which of ya / yb, fa / fb is current)
+ * [5] done [6] accepted [7] rejected [8] nfe [9] status (0 ok, 1 non-finite error norm, 2 dt underflow) [10] reverse.
+ * The host initialises ctl and the current buffers, enqueues batches and reads `done` once per batch; `out` [rows,4] holds
+ * the state at t1 when done with status 0.  ws: >= 1024 doubles. */
+int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float* fb, const float* ctx, const float* e, const float* rec,
+                 float* out, float rtol, float atol, int rows, int R, int n_attempts, double* ws, void* stream);
+
+/* The start of that integration over [t0, t1] on the device: resets ctl, f0 = f(t0, y), torchdiffeq's
+ * `_select_initial_step` into ctl[1].  n_tot / extra_d0: elements of the RMS norm and what the state rows outside y add to
+ * |y0|^2.  ftmp: [rows,4] scratch; ws: >= 256 doubles; red: 3 doubles. */
+int pf_cnf_init(double* ctl, const float* y, float* f0, float* ftmp, const float* ctx, const float* e, const float* rec,
+                double t0, double t1, double n_tot, double extra_d0, int reverse, float rtol, float atol, int rows, int R,
+                double* ws, double* red, void* stream);
+
 /* out[i] = sum_{j<n_terms} w[j] * ptrs[j][i]   (n_terms <= 8; ptrs / w are HOST arrays).  Runge-Kutta solution,
  * mid-point and dense-output combinations of torchdiffeq's dopri5 (cnf.py:97-113 call site). */
 int pf_lincomb(const float* const* ptrs, const float* w, int n_terms, float* out, long long n, void* stream);

@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p, POINTER
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PF_LIB_PATH", os.path.join(_HERE, "libpuflow_hip.so"))   # override: tuning builds only
@@ -80,6 +80,10 @@ SIGNATURES = {
     "pf_dist_feature": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_fps": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_fps_scratch_layout": (c_int, [c_int, POINTER(c_longlong), POINTER(c_longlong)]),
+    "pf_cnf_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double,
+                            c_double, c_int, c_float, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pf_cnf_steps": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                             c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_knn_large": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_cnf_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_float), c_int, c_float, c_float, c_float, c_void_p, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

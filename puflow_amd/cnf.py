@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -125,6 +126,10 @@ class _CnfEngine:
         self.ws = torch.empty(256, dtype=torch.float64, device=device)
         self.ws1k = torch.empty(1024, dtype=torch.float64, device=device)
         self.red = torch.empty(1, dtype=torch.float64, device=device)
+        self.red3 = torch.empty(3, dtype=torch.float64, device=device)
+        self.ctl = torch.empty(16, dtype=torch.float64, device=device)       # dopri5 controller state (csrc/cnf.hip)
+        self.first_batch = int(os.environ.get("PF_CNF_FIRST_BATCH", "8"))    # step attempts enqueued before the first look
+        self.next_batch = int(os.environ.get("PF_CNF_NEXT_BATCH", "4"))
         self.nfe = 0
         self.accepted = 0
         self.rejected = 0
@@ -183,64 +188,44 @@ class _CnfEngine:
         y[:, :3] = x
         K = torch.empty((7, rows, 4), dtype=torch.float32, device=dev)
         y1 = torch.empty_like(y)
-        tmp = torch.empty_like(y)
         f1 = torch.empty_like(y)
-        # f0 and the initial step
-        self._rhs(i, y, K, [], 0.0, net_t(t0), sgn, ctx, e, K[0], None, rows, R)
-        d0 = math.sqrt((self._sumsq(y, None, y, None) + extra_d0) / n_tot)
-        d1 = math.sqrt(self._sumsq(K[0], None, y, None) / n_tot)
-        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
-        self._rhs(i, y, K, [1.0], h0, net_t(t0 + h0), sgn, ctx, e, f1, None, rows, R)
-        d2 = math.sqrt(self._sumsq(f1, K[0], y, None) / n_tot) / h0
-        h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / ORDER)
-        dt = min(100 * h0, h1)
+        # f0 and torchdiffeq's initial step size, on the device (csrc/cnf.hip: pf_cnf_init); the controller state follows
+        ctl = self.ctl
+        _lib.check(self.lib.pf_cnf_init(ctl.data_ptr(), y.data_ptr(), K[0].data_ptr(), f1.data_ptr(), ctx.data_ptr(),
+                                        e.data_ptr(), self.rec[i].data_ptr(), t0, t1, n_tot, float(extra_d0),
+                                        1 if reverse else 0, RTOL, ATOL, rows, R, self.ws.data_ptr(), self.red3.data_ptr(),
+                                        self._stream()), "pf_cnf_init")
 
-        # ---- adaptive steps: ONE launch per attempt (six fused stage evaluations), one host read of the error norm
-        ws = self.ws1k
+        # ---- adaptive steps: ONE launch per attempt (six fused stage evaluations) + a one-wave controller kernel; the
+        # accept / reject / next-dt decisions are taken on the device (csrc/cnf.hip: cnf_ctl_kernel), the host enqueues a batch
+        # of attempts and reads the controller state once per batch (attempts past the end of the integration are no-ops)
+        out = torch.empty_like(y)
         f0, f1 = K[0], K[6]
-        t = t0
-        last = None
         attempts = 0
-        while t1 > t:
-            want_mid = t1 <= t + dt                            # this step would cover the end time: emit the mid-point too
-            _lib.check(self.lib.pf_cnf_step(y.data_ptr(), f0.data_ptr(), float(t), float(dt), 1 if reverse else 0,
-                                            ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), y1.data_ptr(),
-                                            f1.data_ptr(), tmp.data_ptr() if want_mid else None, RTOL, ATOL, rows, R,
-                                            ws.data_ptr(), self.red.data_ptr(), self._stream()), "pf_cnf_step")
-            self.nfe += 6
-            attempts += 1
-            ratio = math.sqrt(float(self.red.item()) / n_tot)
-            # torchdiffeq raises here too ('underflow in dt', NaN propagates into dt): without these guards a NaN error
-            # norm makes every comparison False - no step is ever accepted and dt grows tenfold per attempt, forever
-            if not math.isfinite(ratio):
-                raise _lib.PuflowHipError(f"dopri5: non-finite error norm in block {i} at t = {t:g} (NaN / inf in the input, "
-                                          "the weights or the state)")
-            if not (t + dt > t):
-                raise _lib.PuflowHipError(f"dopri5: underflow in dt ({dt:g}) at t = {t:g}, block {i}")
+        batch = self.first_batch
+        while True:
+            _lib.check(self.lib.pf_cnf_steps(ctl.data_ptr(), y.data_ptr(), y1.data_ptr(), f0.data_ptr(), f1.data_ptr(),
+                                             ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), out.data_ptr(), RTOL, ATOL,
+                                             rows, R, batch, self.ws1k.data_ptr(), self._stream()), "pf_cnf_steps")
+            attempts += batch
+            st = ctl.cpu()                                      # the one device->host read per batch of attempts
+            if st[5] != 0:
+                break
             if attempts > MAX_NUM_STEPS:
                 raise _lib.PuflowHipError(f"dopri5: more than {MAX_NUM_STEPS} step attempts in block {i}")
-            if ratio <= 1.0:
-                self.accepted += 1
-                nxt = t + dt
-                if t1 <= nxt:                                  # dense output at the end time (quartic through y0, y_mid, y1)
-                    xx = (t1 - t) / dt
-                    x2, x3, x4 = xx * xx, xx ** 3, xx ** 4
-                    w = [-8 * x4 + 18 * x3 - 11 * x2 + 1, -8 * x4 + 14 * x3 - 5 * x2, 16 * x4 - 32 * x3 + 16 * x2,
-                         dt * (-2 * x4 + 5 * x3 - 4 * x2 + xx), dt * (2 * x4 - 3 * x3 + x2)]
-                    out = torch.empty_like(y)
-                    self._lincomb([y, y1, tmp, f0, f1], w, out)
-                    last = out
-                t = nxt
-                y, y1 = y1, y                                  # accepted state; FSAL: f1 is the next step's f0
-                f0, f1 = f1, f0
-            else:
-                self.rejected += 1
-            if ratio == 0:
-                dt = dt * IFACTOR
-            else:
-                dfac = 1.0 if ratio < 1 else DFACTOR
-                dt = dt * min(IFACTOR, max(SAFETY / ratio ** (1.0 / ORDER), dfac))
-        return last
+            batch = self.next_batch
+        t, dt = float(st[0]), float(st[1])
+        self.accepted += int(st[6])
+        self.rejected += int(st[7])
+        self.nfe += int(st[8])
+        # torchdiffeq raises here too ('underflow in dt', NaN propagates into dt): without these guards a NaN error norm
+        # makes every comparison False - no step is ever accepted and dt grows tenfold per attempt, forever
+        if st[9] == 1:
+            raise _lib.PuflowHipError(f"dopri5: non-finite error norm in block {i} at t = {t:g} (NaN / inf in the input, "
+                                      "the weights or the state)")
+        if st[9] == 2:
+            raise _lib.PuflowHipError(f"dopri5: underflow in dt ({dt:g}) at t = {t:g}, block {i}")
+        return out
 
 
 class PointInterpFlow(nn.Module):

@@ -28,6 +28,9 @@ constexpr int CNF_REC = 10160;
 constexpr int CNF_CTX = 288;
 constexpr int CNF_NW = 4;                 // waves per workgroup
 
+constexpr int CTL_T = 0, CTL_DT = 1, CTL_T1 = 2, CTL_NTOT = 3, CTL_CUR = 4, CTL_DONE = 5, CTL_ACC = 6, CTL_REJ = 7, CTL_NFE = 8,
+              CTL_STATUS = 9, CTL_REV = 10, CTL_H0 = 11, CTL_D1 = 12;   // device-side dopri5 state, see cnf_ctl_kernel
+
 struct CnfArgs {
     const float* y0;        // [rows,4] state at the start of the step
     const float* k;         // [7][rows][4] stage derivatives
@@ -42,6 +45,7 @@ struct CnfArgs {
     float* kout;            // [rows,4]
     float* yout;            // nullable: the stage state yi (the last stage's is the step's solution)
     int rows, R, ntiles;
+    const double* ctl;      // nullable: take h = ctl[CTL_H0] and t = +-(ctl[CTL_T] + h) from the device (initial-step probe)
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -165,6 +169,12 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_rhs_kernel(CnfArgs a) {
     const int col = lane & 15, q = lane >> 4;
     const CnfW w = cnf_stage_weights(wl, a.rec, CNF_NW * 64, lane);
     const size_t kstride = (size_t)a.rows * 4;
+    float h = a.h, t = a.t;
+    if (a.ctl) {
+        const double hd = a.ctl[CTL_H0], td = a.ctl[CTL_T] + hd;
+        h = (float)hd;
+        t = (float)(a.ctl[CTL_REV] != 0.0 ? -td : td);
+    }
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int g = (tile * CNF_NW + wave) * 16 + col;
         const bool ok = g < a.rows;
@@ -173,11 +183,11 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_rhs_kernel(CnfArgs a) {
         f4 y = *reinterpret_cast<const f4*>(a.y0 + (size_t)row * 4);
         for (int j = 0; j < a.ncoef; ++j) {
             const f4 kj = *reinterpret_cast<const f4*>(a.k + j * kstride + (size_t)row * 4);
-            y += kj * (a.h * a.coef[j]);
+            y += kj * (h * a.coef[j]);
         }
         if (a.yout && ok && q == 0) *reinterpret_cast<f4*>(a.yout + (size_t)row * 4) = y;
         const float* cx = a.ctx + (size_t)pt * CNF_CTX;
-        const f4 k = cnf_eval(w, q, y, a.t, a.sgn, cx, a.e[(size_t)pt * 3 + 0], a.e[(size_t)pt * 3 + 1],
+        const f4 k = cnf_eval(w, q, y, t, a.sgn, cx, a.e[(size_t)pt * 3 + 0], a.e[(size_t)pt * 3 + 1],
                               a.e[(size_t)pt * 3 + 2]);
         if (ok && q == 0) *reinterpret_cast<f4*>(a.kout + (size_t)row * 4) = k;
     }
@@ -271,6 +281,182 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_kernel(CnfStepArgs a) {
         for (int i = 0; i < CNF_NW; ++i) t += red[i];
         a.partial[blockIdx.x] = t;
     }
+}
+
+// ---- adaptive step control on the device ------------------------------------------------------------
+// The host-side dopri5 loop read the error norm after every step attempt (one device->host sync per attempt, ~60 per
+// forward).  Here the controller state lives in device memory and a one-thread kernel takes torchdiffeq's decisions
+// (accept / reject, next step size, end-time coverage: the same formulas as oracle/cnf_ref.py::dopri5 and the host loop in
+// puflow_amd/cnf.py); the step kernel reads (t, dt, which buffer is current) from that state and is a no-op once the
+// integration is done, so the host can enqueue a batch of attempts and look at the state once per batch.
+//   ctl (doubles): [0] t  [1] dt  [2] t1  [3] n_tot  [4] cur (0/1)  [5] done  [6] accepted  [7] rejected  [8] nfe
+//                  [9] status (0 ok, 1 non-finite error norm, 2 dt underflow)  [10] reverse (0/1)
+// The step that covers t1 writes the dense-output value at t1 (quartic through y0, y_mid, y1: torchdiffeq's interpolation)
+// straight into `out`; if that attempt is rejected a later covering attempt overwrites it.
+
+struct CnfDevArgs {
+    double* ctl;
+    float* yb[2];
+    float* fb[2];
+    const float* ctx; const float* e; const float* rec;
+    float* out;              // [rows,4] dense output at t1
+    double* partial;
+    float rtol, atol;
+    int rows, R, ntiles;
+};
+
+__global__ __launch_bounds__(CNF_NW * 64) void cnf_step_dev_kernel(CnfDevArgs a) {
+    __shared__ f4 wl[CNF_REC / 4];
+    __shared__ double red[CNF_NW];
+    if (a.ctl[CTL_DONE] != 0.0) return;                              // uniform over the grid
+    const int cur = (int)a.ctl[CTL_CUR];
+    const float t = (float)a.ctl[CTL_T], h = (float)a.ctl[CTL_DT];
+    const bool reverse = a.ctl[CTL_REV] != 0.0;
+    const float sgn = reverse ? -1.f : 1.f, tsign = sgn;
+    const bool cover = a.ctl[CTL_T1] <= a.ctl[CTL_T] + a.ctl[CTL_DT];
+    float wd[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cover) {                                                     // weights of (y0, y1, y_mid, dt f0, dt f1) at x = (t1 - t) / dt
+        const double x = (a.ctl[CTL_T1] - a.ctl[CTL_T]) / a.ctl[CTL_DT], x2 = x * x, x3 = x2 * x, x4 = x2 * x2, dt = a.ctl[CTL_DT];
+        wd[0] = (float)(-8 * x4 + 18 * x3 - 11 * x2 + 1); wd[1] = (float)(-8 * x4 + 14 * x3 - 5 * x2);
+        wd[2] = (float)(16 * x4 - 32 * x3 + 16 * x2);
+        wd[3] = (float)(dt * (-2 * x4 + 5 * x3 - 4 * x2 + x)); wd[4] = (float)(dt * (2 * x4 - 3 * x3 + x2));
+    }
+    const float* y0p = a.yb[cur];
+    const float* f0p = a.fb[cur];
+    float* y1p = a.yb[1 - cur];
+    float* f1p = a.fb[1 - cur];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    const CnfW w = cnf_stage_weights(wl, a.rec, CNF_NW * 64, lane);
+    constexpr float AL[6] = {1.f / 5, 3.f / 10, 4.f / 5, 8.f / 9, 1.f, 1.f};
+    constexpr float BE[6][6] = {
+        {1.f / 5, 0, 0, 0, 0, 0},
+        {3.f / 40, 9.f / 40, 0, 0, 0, 0},
+        {44.f / 45, -56.f / 15, 32.f / 9, 0, 0, 0},
+        {19372.f / 6561, -25360.f / 2187, 64448.f / 6561, -212.f / 729, 0, 0},
+        {9017.f / 3168, -355.f / 33, 46732.f / 5247, 49.f / 176, -5103.f / 18656, 0},
+        {35.f / 384, 0, 500.f / 1113, 125.f / 192, -2187.f / 6784, 11.f / 84}};
+    constexpr float CE[7] = {(float)(35. / 384 - 1951. / 21600), 0, (float)(500. / 1113 - 22642. / 50085),
+                             (float)(125. / 192 - 451. / 720), (float)(-2187. / 6784 + 12231. / 42400),
+                             (float)(11. / 84 - 649. / 6300), (float)(-1. / 60)};
+    constexpr float CM[7] = {(float)(6025192743. / 30085553152 / 2), 0, (float)(51252292925. / 65400821598 / 2),
+                             (float)(-2691868925. / 45128329728 / 2), (float)(187940372067. / 1594534317056 / 2),
+                             (float)(-1776094331. / 19743644256 / 2), (float)(11237099. / 235043384 / 2)};
+    double acc = 0.0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int g = (tile * CNF_NW + wave) * 16 + col;
+        const bool ok = g < a.rows;
+        const int row = ok ? g : a.rows - 1;
+        const int pt = row / a.R;
+        const f4 y0 = *reinterpret_cast<const f4*>(y0p + (size_t)row * 4);
+        const float* cx = a.ctx + (size_t)pt * CNF_CTX;
+        const float e0 = a.e[(size_t)pt * 3 + 0], e1 = a.e[(size_t)pt * 3 + 1], e2 = a.e[(size_t)pt * 3 + 2];
+        f4 k[7];
+        k[0] = *reinterpret_cast<const f4*>(f0p + (size_t)row * 4);
+        f4 yi = y0;
+        pf_static_for<0, 6>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f4 comb = k[0] * BE[s][0];
+#pragma unroll
+            for (int j = 1; j <= s; ++j) comb += k[j] * BE[s][j];
+            yi = y0 + comb * h;
+            k[s + 1] = cnf_eval(w, q, yi, tsign * (t + AL[s] * h), sgn, cx, e0, e1, e2);
+        });
+        f4 err = k[0] * CE[0];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) err += k[j] * CE[j];
+        err *= h;
+        if (ok && q == 0) {
+            *reinterpret_cast<f4*>(y1p + (size_t)row * 4) = yi;
+            *reinterpret_cast<f4*>(f1p + (size_t)row * 4) = k[6];
+            if (cover) {
+                f4 m = k[0] * CM[0];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) m += k[j] * CM[j];
+                const f4 ymid = y0 + m * h;
+                // the same term order as the host path's pf_lincomb: ((((w0 y0) + w1 y1) + w2 ymid) + w3 f0) + w4 f1, fused
+                f4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    o[c] = fmaf(wd[4], k[6][c], fmaf(wd[3], k[0][c], fmaf(wd[2], ymid[c], fmaf(wd[1], yi[c], fmaf(wd[0], y0[c], 0.f)))));
+                *reinterpret_cast<f4*>(a.out + (size_t)row * 4) = o;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float r = err[c] / (a.atol + a.rtol * fmaxf(fabsf(y0[c]), fabsf(yi[c])));
+                acc += (double)r * (double)r;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tt = 0.0;
+        for (int i = 0; i < CNF_NW; ++i) tt += red[i];
+        a.partial[blockIdx.x] = tt;
+    }
+}
+
+// one wave (lane 0 decides): torchdiffeq's `_adaptive_step` decisions on the error norm of the attempt just made
+__global__ void cnf_ctl_kernel(double* ctl, const double* partial, int nblocks) {
+    if (blockIdx.x != 0 || threadIdx.x >= 64 || ctl[CTL_DONE] != 0.0) return;
+    double sum = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) sum += partial[i];       // fixed order: deterministic
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
+    if (threadIdx.x != 0) return;
+    const double ratio = sqrt(sum / ctl[CTL_NTOT]);
+    const double t = ctl[CTL_T], dt = ctl[CTL_DT], t1 = ctl[CTL_T1];
+    ctl[CTL_NFE] += 6.0;
+    if (!(ratio == ratio) || ratio > 1.7e308) { ctl[CTL_STATUS] = 1.0; ctl[CTL_DONE] = 1.0; return; }
+    if (!(t + dt > t)) { ctl[CTL_STATUS] = 2.0; ctl[CTL_DONE] = 1.0; return; }
+    double tn = t;
+    if (ratio <= 1.0) {
+        ctl[CTL_ACC] += 1.0;
+        tn = t + dt;
+        ctl[CTL_T] = tn;
+        ctl[CTL_CUR] = 1.0 - ctl[CTL_CUR];                       // accepted state; FSAL: f1 becomes the next f0
+    } else {
+        ctl[CTL_REJ] += 1.0;
+    }
+    double ndt;
+    if (ratio == 0.0) ndt = dt * 10.0;
+    else {
+        const double dfac = ratio < 1.0 ? 1.0 : 0.2;
+        double fac = 0.9 / pow(ratio, 1.0 / 5.0);
+        fac = fac > dfac ? fac : dfac;
+        fac = fac < 10.0 ? fac : 10.0;
+        ndt = dt * fac;
+    }
+    ctl[CTL_DT] = ndt;
+    if (!(t1 > tn)) ctl[CTL_DONE] = 1.0;
+}
+
+// torchdiffeq's `_select_initial_step` (oracle/cnf_ref.py::dopri5, first lines) in two one-thread kernels around the
+// probe evaluation f(t0 + h0, y0 + h0 f0).  red: [0] sumsq(y0 / scale) [1] sumsq(f0 / scale) [2] sumsq((f1 - f0) / scale)
+__global__ void cnf_ctl_reset_kernel(double* ctl, double t0, double t1, double n_tot, double reverse) {
+    if (threadIdx.x < 16 && blockIdx.x == 0) {
+        const int i = threadIdx.x;
+        ctl[i] = i == CTL_T ? t0 : i == CTL_T1 ? t1 : i == CTL_NTOT ? n_tot : i == CTL_REV ? reverse : 0.0;
+    }
+}
+__global__ void cnf_init_a_kernel(double* ctl, const double* red, double extra_d0) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double n = ctl[CTL_NTOT];
+    const double d0 = sqrt((red[0] + extra_d0) / n), d1 = sqrt(red[1] / n);
+    ctl[CTL_H0] = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    ctl[CTL_D1] = d1;
+}
+__global__ void cnf_init_b_kernel(double* ctl, const double* red) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double h0 = ctl[CTL_H0], d1 = ctl[CTL_D1];
+    const double d2 = sqrt(red[2] / ctl[CTL_NTOT]) / h0;
+    const double dm = d1 > d2 ? d1 : d2;
+    const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? (1e-6 > h0 * 1e-3 ? 1e-6 : h0 * 1e-3) : pow(0.01 / dm, 1.0 / 5.0);
+    ctl[CTL_DT] = 100.0 * h0 < h1 ? 100.0 * h0 : h1;
+    ctl[CTL_NFE] = 2.0;
 }
 
 // ---- Runge-Kutta bookkeeping -----------------------------------------------------------------------
@@ -411,5 +597,58 @@ extern "C" int pf_cnf_step(const float* y0, const float* f0, float t, float h, i
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(cnf_step_kernel, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, ws, grid, out);
+    return pf_last_launch_status();
+}
+
+// `n_attempts` step attempts of the adaptive integration whose state is in `ctl` (layout above), enqueued back to back with
+// the device-side controller in between: no host synchronisation.  ya / yb and fa / fb: the two state and derivative buffers
+// ([rows,4]; ctl's `cur` says which one holds the current state), out: the solution at t1 once ctl's `done` is set with
+// status 0.  ws: >= 1024 doubles.
+extern "C" int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float* fb, const float* ctx, const float* e,
+                            const float* rec, float* out, float rtol, float atol, int rows, int R, int n_attempts, double* ws,
+                            void* stream) {
+    if (!ctl || !ya || !yb || !fa || !fb || !ctx || !e || !rec || !out || !ws) return PF_ERR_NULL;
+    if (rows <= 0 || R <= 0 || n_attempts <= 0) return PF_ERR_SHAPE;
+    CnfDevArgs a{};
+    a.ctl = ctl; a.yb[0] = ya; a.yb[1] = yb; a.fb[0] = fa; a.fb[1] = fb; a.ctx = ctx; a.e = e; a.rec = rec; a.out = out;
+    a.partial = ws; a.rtol = rtol; a.atol = atol; a.rows = rows; a.R = R;
+    a.ntiles = (rows + CNF_NW * 16 - 1) / (CNF_NW * 16);
+    const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n_attempts; ++i) {
+        hipLaunchKernelGGL(cnf_step_dev_kernel, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+        hipLaunchKernelGGL(cnf_ctl_kernel, dim3(1), dim3(64), 0, s, ctl, ws, grid);
+    }
+    return pf_last_launch_status();
+}
+
+// The start of an adaptive integration over [t0, t1] (solver time; the network sees -t when reverse), all on the device:
+// resets the controller state, f0 = f(t0, y) into `f0`, torchdiffeq's initial step size into ctl[1].  ftmp: [rows,4] scratch
+// for the probe evaluation.  n_tot: elements of the RMS norms (rows*4 + the log-density rows torchdiffeq integrates
+// alongside), extra_d0: what those extra rows add to the squared norm of y0.  ws: >= 256 doubles, red: 3 doubles.
+extern "C" int pf_cnf_init(double* ctl, const float* y, float* f0, float* ftmp, const float* ctx, const float* e,
+                           const float* rec, double t0, double t1, double n_tot, double extra_d0, int reverse, float rtol,
+                           float atol, int rows, int R, double* ws, double* red, void* stream) {
+    if (!ctl || !y || !f0 || !ftmp || !ctx || !e || !rec || !ws || !red) return PF_ERR_NULL;
+    if (rows <= 0 || R <= 0 || !(n_tot > 0.0)) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const float sgn = reverse ? -1.f : 1.f;
+    hipLaunchKernelGGL(cnf_ctl_reset_kernel, dim3(1), dim3(64), 0, s, ctl, t0, t1, n_tot, reverse ? 1.0 : 0.0);
+    int st = pf_cnf_rhs(y, nullptr, nullptr, 0, 0.f, (float)(reverse ? -t0 : t0), sgn, ctx, e, rec, f0, nullptr, rows, R, stream);
+    if (st) return st;
+    const long long n = (long long)rows * 4;
+    if ((st = pf_scaled_sumsq(y, nullptr, y, nullptr, nullptr, nullptr, 0, 0.f, rtol, atol, n, ws, red + 0, stream))) return st;
+    if ((st = pf_scaled_sumsq(f0, nullptr, y, nullptr, nullptr, nullptr, 0, 0.f, rtol, atol, n, ws, red + 1, stream))) return st;
+    hipLaunchKernelGGL(cnf_init_a_kernel, dim3(1), dim3(64), 0, s, ctl, red, extra_d0);
+    {
+        CnfArgs a{};
+        a.y0 = y; a.k = f0; a.ncoef = 1; a.coef[0] = 1.f; a.sgn = sgn; a.ctx = ctx; a.e = e; a.rec = rec;
+        a.kout = ftmp; a.yout = nullptr; a.rows = rows; a.R = R; a.ctl = ctl;
+        a.ntiles = (rows + CNF_NW * 16 - 1) / (CNF_NW * 16);
+        const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
+        hipLaunchKernelGGL(cnf_rhs_kernel, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+    }
+    if ((st = pf_scaled_sumsq(ftmp, f0, y, nullptr, nullptr, nullptr, 0, 0.f, rtol, atol, n, ws, red + 2, stream))) return st;
+    hipLaunchKernelGGL(cnf_init_b_kernel, dim3(1), dim3(64), 0, s, ctl, red);
     return pf_last_launch_status();
 }
