@@ -221,6 +221,44 @@ int pf_batch_sum_bwd(const float* x, const float* g, int B, long long M, int mod
 /* DistanceEncoder.distance_vec (interpflow.py:100-115): out [B*N*K,10] = [x_i, x_j, x_i - x_j, |x_i - x_j|] */
 int pf_dist_feature(const float* xyz, const int* idx, int B, int N, int K, float* out, void* stream);
 
+/* ---- one FeatureExtractUnit (EdgeConv dense block) of the training step, fused (csrc/train_fused.hip) ----
+ * Replaces FeatureExtractUnit.forward in train() mode and its autograd backward (modules/discrete/interpflow.py:190-248):
+ * edge feature -> [Conv2d 1x1 + BatchNorm2d(batch statistics) + LeakyReLU, dense concatenation] x nconv -> conv_out ->
+ * max over the K neighbours (pooling = 1) or the per-edge output (pooling = 0, the interpolation's feat_conv).
+ * T = B*N points, E = T*K edges (point-major rows), GT = growth*nconv, S = GT + odim.  growth in {8,16,32}, nconv <= 8,
+ * odim a multiple of 16 <= 128, GT <= 128, E a multiple of 16, pooling requires K == 16.
+ * The caller owns every buffer; those marked (kept) must survive from pf_ec_train_fwd to pf_ec_train_bwd. */
+typedef struct PfEcTrain {
+    int B, N, K, C, growth, nconv, odim, pooling;
+    float slope, eps, momentum;
+    const float* x;                 /* [T, C] */
+    const int* idx;                 /* [T, K] batch-local neighbour indices */
+    const float* W[9];              /* conv t [growth, 3C + growth t] (t < nconv), then conv_out [odim, 3C + GT] */
+    const float* bias[9];
+    const float* gamma[8]; const float* beta[8];
+    float* run_mean[8]; float* run_var[8];     /* nullable: running statistics, updated in place */
+    float* Wpq;                     /* (kept) [2S, C] folded edge-feature weights */
+    float* bpq;                     /* [2S] */
+    float* PQ;                      /* (kept) [T, 2S] */
+    float* Y;                       /* (kept) [E, GT] pre-BatchNorm outputs of the growth layers */
+    float* aff;                     /* (kept) [4][GT] scale, shift, batch mean, 1/std */
+    float* out;                     /* [T, odim] (pooling) or [E, odim] */
+    unsigned char* arg;             /* (kept) [T, odim] argmax over K (pooling) */
+    /* backward only */
+    const float* dout;              /* gradient of `out` */
+    float* dA;                      /* [E, GT] scratch */
+    float* dPQ;                     /* [T, 2S] scratch */
+    float* coef;                    /* [2][GT] scratch */
+    float* dWpq;                    /* [2S, C] scratch */
+    float* dx;                      /* [T, C], nullable */
+    float* dW[9]; float* dbias[9]; float* dgamma[8]; float* dbeta[8];
+    float* ws; long long ws_floats; /* >= pf_ec_train_ws_floats() */
+    double* stat;                   /* 1025 doubles of scratch (column-statistics accumulators) */
+} PfEcTrain;
+long long pf_ec_train_ws_floats(const PfEcTrain* p);
+int pf_ec_train_fwd(const PfEcTrain* p, void* stream);
+int pf_ec_train_bwd(const PfEcTrain* p, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Patch pipeline around the network (modules/utils/patch.py:35-214), csrc/patch_ops.hip
  * ------------------------------------------------------------------------------------------- */

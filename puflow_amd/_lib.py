@@ -12,6 +12,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PF_LIB_PATH", os.path.join(_HERE, "libpuflow_hip.so"))   # override: tuning builds only
 _lib = None
 
+class PfEcTrain(ctypes.Structure):
+    """include/puflow_hip.h: PfEcTrain (one EdgeConv unit of the training step)."""
+    _fields_ = [("B", c_int), ("N", c_int), ("K", c_int), ("C", c_int), ("growth", c_int), ("nconv", c_int), ("odim", c_int),
+                ("pooling", c_int), ("slope", c_float), ("eps", c_float), ("momentum", c_float),
+                ("x", c_void_p), ("idx", c_void_p), ("W", c_void_p * 9), ("bias", c_void_p * 9),
+                ("gamma", c_void_p * 8), ("beta", c_void_p * 8), ("run_mean", c_void_p * 8), ("run_var", c_void_p * 8),
+                ("Wpq", c_void_p), ("bpq", c_void_p), ("PQ", c_void_p), ("Y", c_void_p), ("aff", c_void_p), ("out", c_void_p),
+                ("arg", c_void_p), ("dout", c_void_p), ("dA", c_void_p), ("dPQ", c_void_p), ("coef", c_void_p),
+                ("dWpq", c_void_p), ("dx", c_void_p), ("dW", c_void_p * 9), ("dbias", c_void_p * 9),
+                ("dgamma", c_void_p * 8), ("dbeta", c_void_p * 8), ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/puflow_hip.h
 SIGNATURES = {
     "pf_version": (c_int, []),
@@ -80,6 +92,9 @@ SIGNATURES = {
     "pf_dist_feature": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_fps": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_fps_scratch_layout": (c_int, [c_int, POINTER(c_longlong), POINTER(c_longlong)]),
+    "pf_ec_train_ws_floats": (c_longlong, [c_void_p]),
+    "pf_ec_train_fwd": (c_int, [c_void_p, c_void_p]),
+    "pf_ec_train_bwd": (c_int, [c_void_p, c_void_p]),
     "pf_cnf_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double,
                             c_double, c_int, c_float, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_cnf_steps": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,

@@ -1,0 +1,826 @@
+// One FeatureExtractUnit (EdgeConv dense block) of the TRAINING step as a handful of launches.
+//
+// Reference: modules/discrete/interpflow.py:190-248 (FeatureExtractUnit.forward in train() mode: edge feature ->
+// [Conv2d 1x1 + BatchNorm2d (batch statistics) + LeakyReLU(0.05), dense concatenation] x nconv -> conv_out -> max over the K
+// neighbours) and the autograd backward PyTorch derives from it.  The un-fused path (train_ops.hip + train_ops.py) runs
+// this as ~170 launches per unit and step (GEMM, two-pass statistics, apply, concatenations, gradient adds); at
+// 32 x 256 points every one of those kernels is shorter than the gap between two launches, so the step was bound by the
+// NUMBER of launches.  Here a unit is 7 launches forward and ~12 backward:
+//
+//   forward   fold        Wp = W1 - W3, Wq = W2 + W3 of all convs -> Wpq [2S, C]   (the edge feature [x_i; x_j; x_j - x_i]
+//                         enters every conv only through P = Wp x_i (+ bias) and Q = Wq x_j: packing.fold_edgeconv)
+//             gemm        PQ [T, 2S] = x Wpq^T + bias                              (train_ops.hip: pf_gemm)
+//             layer t     Y[:, g t : g (t+1)] = P_t[i] + Q_t[j] + lrelu(bn(Y[:, :g t])) Wg_t^T   - the BatchNorm of the
+//                         EARLIER layers is applied on load (scale / shift per channel), this layer's pre-activation
+//                         output is stored and its column sums / sums of squares leave in the epilogue
+//                         (the workgroup that finishes last turns the sums into scale / shift / running statistics)
+//             out         conv_out on lrelu(bn(Y)) + P_out[i] + Q_out[j], max over the 16 edges of a point in the MFMA
+//                         accumulator layout (the [E, odim] tensor is never written), argmax kept for the backward
+//   backward  out         dA [E, GT] = dYout Wg_out, dYout generated from (dh, argmax) on load; epilogue: BatchNorm-backward
+//                         sums of the last growth layer
+//             layer t     (t = nconv-1 .. 1)  dy_t = BN-backward of dA[:, slice t] formed on load and stored in place;
+//                         dA[:, :g t] += dy_t Wg_t; epilogue: sums for layer t-1
+//             layer 0     dA[:, :g] -> dy_0 in place
+//             pq          dP[i] = sum_k dy, dQ[j] += dy (atomics), conv_out part from (dh, argmax)
+//             dw          all growth-weight gradients of the unit in ONE split-K launch: [S, GT] = dY^T lrelu(bn(Y))
+//             gemm x2     dx = dPQ Wpq, dWpq = dPQ^T x
+//             assemble    conv weight gradients [*, 3C + g t] from dWpq (un-folding) and the dw partial sums
+//
+// All matrix products are v_mfma_f32_16x16x4_f32 (exact fp32 fma chains).  Rows of every per-edge tensor are edges in
+// point-major order (e = i K + k), so a 16-row MFMA tile is one point's 16 neighbours (K = 16) or two points (K = 8).
+#include <hip/hip_runtime.h>
+#include "pf_api_internal.h"
+#include "pf_mfma.h"
+
+extern "C" int pf_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
+                       long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats, void* stream);
+extern "C" long long pf_gemm_ws_floats(int M, int N, int K);
+extern "C" int pf_colsum(const float* g, long long R, int C, float* out, float* ws, void* stream);
+extern "C" int pf_bn_chunks(long long R);
+
+namespace {
+
+constexpr int EC_GRID = 512;          // persistent workgroups of the per-edge kernels (2 per CU)
+
+__device__ __forceinline__ float lrelu1(float v, float s) { return fmaxf(v, v * s); }
+__device__ __forceinline__ f4 lrelu4(f4 z, float s) {
+    f4 r;
+    r.x = fmaxf(z.x, z.x * s); r.y = fmaxf(z.y, z.y * s); r.z = fmaxf(z.z, z.z * s); r.w = fmaxf(z.w, z.w * s);
+    return r;
+}
+__device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 c) {
+    c = pf_mfma(a.x, b.x, c); c = pf_mfma(a.y, b.y, c); c = pf_mfma(a.z, b.z, c); c = pf_mfma(a.w, b.w, c);
+    return c;
+}
+// B operand that makes mfma4(a, ident, c) add the A-layout tile `a` (lane (row, q) holds channels 4q..4q+3 of its row) to the
+// accumulator-layout tile c: the matrix pipe as a transposer for per-row gathered addends
+__device__ __forceinline__ f4 ident_b(int row, int q) {
+    f4 r;
+    r.x = 4 * q + 0 == row ? 1.f : 0.f; r.y = 4 * q + 1 == row ? 1.f : 0.f;
+    r.z = 4 * q + 2 == row ? 1.f : 0.f; r.w = 4 * q + 3 == row ? 1.f : 0.f;
+    return r;
+}
+
+// ---- column statistics without a second launch: every workgroup adds its column sums to 64 double accumulators, the
+// workgroup that arrives last turns them into the layer's constants and clears them for the next user.
+//   mode 1 (BatchNorm forward): sums of y, y^2 -> scale, shift, mean, 1/std (aff rows 0..3), running statistics
+//   mode 2 (BatchNorm backward): sums of dz, dz xhat -> their means (coef rows 0, 1), dbeta, dgamma
+struct StatFin {
+    double* acc;                      // [STAT_COPIES][64] + a counter word behind them; all zero between uses
+    int mode, g, col0, ld;
+    float* aff; const float* gamma; const float* beta; float* run_mean; float* run_var; float eps, momentum;
+    float* coef; float* dgamma; float* dbeta;
+    double R;
+};
+
+constexpr int STAT_COPIES = 16;       // workgroups spread their atomics over this many accumulator sets (same-address atomics serialise)
+
+// s0 / s1: this lane's sums for column (lane & 15) of each 16-column tile; `first`: the column that maps to statistics
+// column 0; ncol <= 32
+template <int NT>
+__device__ __forceinline__ void stat_flush(float (&s0)[NT], float (&s1)[NT], int first, int ncol, const StatFin& f, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s0[nt] += __shfl_xor(s0[nt], 16); s0[nt] += __shfl_xor(s0[nt], 32);
+        s1[nt] += __shfl_xor(s1[nt], 16); s1[nt] += __shfl_xor(s1[nt], 32);
+    }
+    if (lane < 16) {                                                  // red[wave][2][32]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = nt * 16 + lane - first;
+            if (c >= 0 && c < ncol) { red[wave * 64 + c] = s0[nt]; red[wave * 64 + 32 + c] = s1[nt]; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && (threadIdx.x & 31) < ncol) {
+        const float v = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+        unsafeAtomicAdd(f.acc + (blockIdx.x % STAT_COPIES) * 64 + threadIdx.x, (double)v);
+    }
+    // order the accumulator atomics before the arrival count WITHOUT a release fence: a device-scope fence writes the whole
+    // L2 back on this multi-die part (tens of microseconds per launch); the atomics themselves are performed at the coherent
+    // level, so waiting for their acknowledgement is enough
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* counter = reinterpret_cast<unsigned*>(f.acc + STAT_COPIES * 64);
+    if (threadIdx.x == 0) red[0] = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1.f : 0.f;
+    __syncthreads();
+    if (red[0] == 0.f) return;
+    const int c = threadIdx.x;
+    if (c < ncol) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int k = 0; k < STAT_COPIES; ++k) {
+            a0 += __hip_atomic_load(f.acc + k * 64 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a1 += __hip_atomic_load(f.acc + k * 64 + 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f.acc[k * 64 + c] = 0.0; f.acc[k * 64 + 32 + c] = 0.0;
+        }
+        if (f.mode == 1) {
+            const double mean = a0 / f.R;
+            double var = a1 / f.R - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = 1.0f / sqrtf((float)var + f.eps);
+            const float sc = f.gamma[c] * rstd;
+            f.aff[f.col0 + c] = sc;
+            f.aff[f.ld + f.col0 + c] = f.beta[c] - (float)mean * sc;
+            f.aff[2 * f.ld + f.col0 + c] = (float)mean;
+            f.aff[3 * f.ld + f.col0 + c] = rstd;
+            if (f.run_mean) {
+                f.run_mean[c] = (1.f - f.momentum) * f.run_mean[c] + f.momentum * (float)mean;
+                f.run_var[c] = (1.f - f.momentum) * f.run_var[c] + f.momentum * (float)(var * (f.R / (f.R - 1.0)));
+            }
+        } else {
+            f.coef[f.col0 + c] = (float)(a0 / f.R);
+            f.coef[f.ld + f.col0 + c] = (float)(a1 / f.R);
+            f.dbeta[c] = (float)a0;
+            f.dgamma[c] = (float)a1;
+        }
+    }
+    if (threadIdx.x == 0) *counter = 0u;
+}
+
+// ------------------------------------------------------------------------------------------------ forward, one conv
+// growth layer t (OUT = false): Y[:, col0 : col0 + g] = P_t[i] + Q_t[j] + lrelu(bn(Y[:, :kin])) W^T, statistics of the result
+// conv_out (OUT = true): the same product on all GT growth channels, then max over the 16 edges of a point (POOL) or the
+// per-edge rows
+struct EcFwdArgs {
+    float* Y; int ldy;               // [E, ldy] pre-BN outputs of the growth layers
+    const float* aff;                // [4][ldy]: scale, shift, mean, rstd of the finished layers
+    const float* W; int ldw;         // growth columns of this conv: W[c * ldw + u], c < nout, u < kin
+    const float* pq; int ldpq;       // [T, ldpq] = P (+ bias) | Q
+    int poff, qoff;                  // columns of this conv's P and Q
+    const int* idx;                  // [E] batch-local neighbour index
+    int N, K;
+    int kin, col0, nout;
+    int ntiles;                      // E / 16
+    float slope;
+    float* out; unsigned char* arg;  // conv_out only
+    StatFin fin;                     // growth layers only
+};
+
+template <int NT, bool OUT, bool POOL>
+__global__ __launch_bounds__(256) void ec_fwd_kernel(EcFwdArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float red[256];
+    const int kin16 = (a.kin + 15) & ~15, kp = kin16 + 4, KS = kin16 / 16;
+    float* Wl = lds;
+    float* al = lds + NT * 16 * kp;
+    float* bl = al + kin16;
+    for (int i = threadIdx.x; i < NT * 16 * kin16; i += 256) {
+        const int c = i / kin16, u = i % kin16;
+        Wl[c * kp + u] = (c < a.nout && u < a.kin) ? a.W[(size_t)c * a.ldw + u] : 0.f;
+    }
+    for (int i = threadIdx.x; i < kin16; i += 256) {
+        al[i] = i < a.kin ? a.aff[i] : 0.f;
+        bl[i] = i < a.kin ? a.aff[a.ldy + i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    const f4 ident = ident_b(row, q);
+    float s0[NT], s1[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) s0[nt] = s1[nt] = 0.f;
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
+        const long long e0 = (long long)tile * 16;
+        // all loads of the tile first: the growth-feature row of this lane's edge and its P[i] + Q[j] addend
+        const long long er = e0 + row;
+        const long long ir = er / a.K;
+        const long long jr = (ir / a.N) * a.N + a.idx[er];
+        const float* yrow = a.Y + er * a.ldy;
+        f4 yv[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            yv[ks] = pf_splat(0.f);
+            if (ks < KS && ks * 16 + 4 * q < a.kin) yv[ks] = *reinterpret_cast<const f4*>(yrow + ks * 16 + 4 * q);
+        }
+        f4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c4 = nt * 16 + 4 * q;
+            f4 ex = pf_splat(0.f);
+            if (c4 < a.nout)
+                ex = *reinterpret_cast<const f4*>(a.pq + ir * a.ldpq + a.poff + c4) +
+                     *reinterpret_cast<const f4*>(a.pq + jr * a.ldpq + a.qoff + c4);
+            acc[nt] = mfma4(ex, ident, pf_splat(0.f));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks < KS) {
+                const int u = ks * 16 + 4 * q;
+                f4 av = pf_splat(0.f);
+                if (u < a.kin)
+                    av = lrelu4(yv[ks] * *reinterpret_cast<const f4*>(al + u) + *reinterpret_cast<const f4*>(bl + u), a.slope);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = mfma4(av, *reinterpret_cast<const f4*>(Wl + (nt * 16 + row) * kp + u), acc[nt]);
+            }
+        }
+        if (!OUT) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = nt * 16 + row;
+                if (col < a.nout) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[nt][r];
+                        a.Y[(e0 + 4 * q + r) * a.ldy + a.col0 + col] = v;
+                        s0[nt] += v; s1[nt] = fmaf(v, v, s1[nt]);
+                    }
+                }
+            }
+        } else if (!POOL) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = nt * 16 + row;
+                if (col < a.nout)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a.out[(e0 + 4 * q + r) * a.nout + col] = acc[nt][r];
+            }
+        } else {                                                       // K = 16: the tile is point `tile`
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float best = acc[nt][0];
+                int bk = 4 * q;
+#pragma unroll
+                for (int r = 1; r < 4; ++r)
+                    if (acc[nt][r] > best) { best = acc[nt][r]; bk = 4 * q + r; }
+#pragma unroll
+                for (int m = 16; m < 64; m <<= 1) {
+                    const float ov = __shfl_xor(best, m);
+                    const int ok = __shfl_xor(bk, m);
+                    if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; }
+                }
+                const int col = nt * 16 + row;
+                if (q == 0 && col < a.nout) {
+                    a.out[(long long)tile * a.nout + col] = best;
+                    a.arg[(long long)tile * a.nout + col] = (unsigned char)bk;
+                }
+            }
+        }
+    }
+    if (!OUT) stat_flush<NT>(s0, s1, 0, a.nout, a.fin, red);
+}
+
+// ------------------------------------------------------------------------------------------------ backward through one conv
+// SRC 0: the conv is conv_out of a pooled unit: dYout[e, c] = dh[i, c] if argmax[i, c] == k else 0, formed on load
+// SRC 1: conv_out without pooling: dYout [E, kin] dense
+// SRC 2: growth conv t: dy = BatchNorm+LeakyReLU backward of dA[:, c0 : c0 + kin], formed on load AND stored back in place
+// result: dA[:, 0 : nout]  =  (SRC 2: +=)  dYsrc W      (W[c * ldw + u], c < kin, u < nout)
+// epilogue: BatchNorm-backward sums (sum dz, sum dz xhat) of the layer in columns [sc0, sc0 + sg), whose gradient is now final
+struct EcBwdArgs {
+    const float* dh; const unsigned char* arg;
+    const float* dyout;
+    float* dA; const float* Y; int ld;
+    const float* aff;                // [4][ld]
+    const float* coef;               // [2][ld]
+    int c0, kin;
+    const float* W; int ldw;
+    int nout;
+    int sc0, sg;
+    int ntiles;
+    float slope;
+    StatFin fin;
+};
+
+template <int NT, int SRC>
+__global__ __launch_bounds__(256) void ec_bwd_kernel(EcBwdArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float red[256];
+    const int kin16 = (a.kin + 15) & ~15, kp = kin16 + 4, KS = kin16 / 16;
+    float* Wt = lds;                                   // Wt[u][c]
+    float* cf = lds + NT * 16 * kp;                    // SRC 2: [6][kin16] scale, shift, mean, rstd, m1, m2 of the source layer
+    for (int i = threadIdx.x; i < NT * 16 * kin16; i += 256) {
+        const int c = i / (NT * 16), u = i % (NT * 16);            // consecutive threads: consecutive u (contiguous in W)
+        Wt[u * kp + c] = (c < a.kin && u < a.nout) ? a.W[(size_t)c * a.ldw + u] : 0.f;
+    }
+    if (SRC == 2) {
+        for (int i = threadIdx.x; i < kin16; i += 256) {
+            const bool ok = i < a.kin;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) cf[w * kin16 + i] = ok ? a.aff[w * a.ld + a.c0 + i] : 0.f;
+            cf[4 * kin16 + i] = ok ? a.coef[a.c0 + i] : 0.f;
+            cf[5 * kin16 + i] = ok ? a.coef[a.ld + a.c0 + i] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    float s0[NT], s1[NT], ssc[NT], ssh[NT], smu[NT], srs[NT];
+    bool scol[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s0[nt] = s1[nt] = 0.f;
+        const int col = nt * 16 + row;
+        scol[nt] = col >= a.sc0 && col < a.sc0 + a.sg;
+        ssc[nt] = scol[nt] ? a.aff[col] : 0.f;
+        ssh[nt] = scol[nt] ? a.aff[a.ld + col] : 0.f;
+        smu[nt] = scol[nt] ? a.aff[2 * a.ld + col] : 0.f;
+        srs[nt] = scol[nt] ? a.aff[3 * a.ld + col] : 0.f;
+    }
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
+        const long long e0 = (long long)tile * 16;
+        // the tile's loads first
+        f4 src[SRC == 2 ? 2 : 8];
+        f4 ysrc[SRC == 2 ? 2 : 1];
+        unsigned ag[SRC == 0 ? 8 : 1];
+#pragma unroll
+        for (int ks = 0; ks < (SRC == 2 ? 2 : 8); ++ks) {
+            const int c = ks * 16 + 4 * q;
+            src[ks] = pf_splat(0.f);
+            if (ks < KS && c < a.kin) {
+                if (SRC == 0) {
+                    src[ks] = *reinterpret_cast<const f4*>(a.dh + (long long)tile * a.kin + c);
+                    ag[ks] = *reinterpret_cast<const unsigned*>(a.arg + (long long)tile * a.kin + c);
+                } else if (SRC == 1) {
+                    src[ks] = *reinterpret_cast<const f4*>(a.dyout + (e0 + row) * a.kin + c);
+                } else {
+                    src[ks] = *reinterpret_cast<const f4*>(a.dA + (e0 + row) * a.ld + a.c0 + c);
+                    ysrc[ks] = *reinterpret_cast<const f4*>(a.Y + (e0 + row) * a.ld + a.c0 + c);
+                }
+            }
+        }
+        float old[NT][4];
+        if (SRC == 2) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = nt * 16 + row;
+                    old[nt][r] = col < a.nout ? a.dA[(e0 + 4 * q + r) * a.ld + col] : 0.f;
+                }
+        }
+        f4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = pf_splat(0.f);
+#pragma unroll
+        for (int ks = 0; ks < (SRC == 2 ? 2 : 8); ++ks) {
+            if (ks < KS) {
+                const int c = ks * 16 + 4 * q;
+                f4 av = pf_splat(0.f);
+                if (c < a.kin) {
+                    if (SRC == 0) {
+                        const f4 dv = src[ks];
+                        const unsigned g4 = ag[ks];
+                        av.x = (int)(g4 & 255u) == row ? dv.x : 0.f; av.y = (int)((g4 >> 8) & 255u) == row ? dv.y : 0.f;
+                        av.z = (int)((g4 >> 16) & 255u) == row ? dv.z : 0.f; av.w = (int)(g4 >> 24) == row ? dv.w : 0.f;
+                    } else if (SRC == 1) {
+                        av = src[ks];
+                    } else {
+                        const f4 d = src[ks], y = ysrc[ks];
+                        const f4 sc = *reinterpret_cast<const f4*>(cf + c), sh = *reinterpret_cast<const f4*>(cf + kin16 + c);
+                        const f4 mu = *reinterpret_cast<const f4*>(cf + 2 * kin16 + c), rs = *reinterpret_cast<const f4*>(cf + 3 * kin16 + c);
+                        const f4 m1 = *reinterpret_cast<const f4*>(cf + 4 * kin16 + c), m2 = *reinterpret_cast<const f4*>(cf + 5 * kin16 + c);
+                        const f4 z = y * sc + sh;
+                        const f4 xh = (y - mu) * rs;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const float dz = d[w] * (z[w] > 0.f ? 1.f : a.slope);
+                            av[w] = sc[w] * (dz - m1[w] - xh[w] * m2[w]);
+                        }
+                        *reinterpret_cast<f4*>(a.dA + (e0 + row) * a.ld + a.c0 + c) = av;
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = mfma4(av, *reinterpret_cast<const f4*>(Wt + (nt * 16 + row) * kp + c), acc[nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = nt * 16 + row;
+            if (col < a.nout) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long e = e0 + 4 * q + r;
+                    float v = acc[nt][r];
+                    if (SRC == 2) v += old[nt][r];
+                    a.dA[e * a.ld + col] = v;
+                    if (scol[nt]) {
+                        const float y = a.Y[e * a.ld + col];
+                        const float dz = v * (fmaf(y, ssc[nt], ssh[nt]) > 0.f ? 1.f : a.slope);
+                        s0[nt] += dz;
+                        s1[nt] = fmaf(dz, (y - smu[nt]) * srs[nt], s1[nt]);
+                    }
+                }
+            }
+        }
+    }
+    stat_flush<NT>(s0, s1, a.sc0, a.sg, a.fin, red);
+}
+
+// growth layer 0 has no growth input: only dA[:, 0:g] -> dy in place
+__global__ __launch_bounds__(256) void ec_bwd0_kernel(float* dA, const float* Y, int ld, const float* aff, const float* coef, int g,
+                                                      long long E, float slope) {
+    const int g4 = g / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < E * g4; i += (long long)gridDim.x * 256) {
+        const long long e = i / g4;
+        const int c = (int)(i % g4) * 4;
+        float* dp = dA + e * ld + c;
+        const f4 d = *reinterpret_cast<const f4*>(dp);
+        const f4 y = *reinterpret_cast<const f4*>(Y + e * ld + c);
+        f4 o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = aff[c + w], z = fmaf(y[w], sc, aff[ld + c + w]);
+            const float xh = (y[w] - aff[2 * ld + c + w]) * aff[3 * ld + c + w];
+            const float dz = d[w] * (z > 0.f ? 1.f : slope);
+            o[w] = sc * (dz - coef[c + w] - xh * coef[ld + c + w]);
+        }
+        *reinterpret_cast<f4*>(dp) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dPQ
+// dPQ [T, 2S]: P half written (sum over the K edges of a point), Q half accumulated with atomics (zeroed by the caller).
+// columns 0..GT-1: growth layers (dY = the in-place converted dA), GT..S-1: conv_out (pooled: from dh / argmax).
+struct EcPqBwdArgs {
+    const float* dY; int ld;         // [E, ld = GT]
+    const float* dh; const unsigned char* arg; const float* dyout; int pooled;
+    const int* idx;
+    int N, K, GT, odim, S;
+    long long T;
+    float* dPQ;                      // [T, 2S]
+};
+__global__ __launch_bounds__(256) void ec_pq_bwd_kernel(EcPqBwdArgs a) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < a.T * a.S; t += (long long)gridDim.x * 256) {
+        const long long i = t / a.S;
+        const int c = (int)(t % a.S);
+        const long long base = (i / a.N) * a.N;
+        float* dq = a.dPQ + a.S + c;
+        float sum = 0.f;
+        if (c < a.GT) {
+            for (int k = 0; k < a.K; ++k) {
+                const long long e = i * a.K + k;
+                const float v = a.dY[e * a.ld + c];
+                sum += v;
+                atomicAdd(dq + (base + a.idx[e]) * 2 * a.S, v);
+            }
+        } else if (a.pooled) {
+            const int co = c - a.GT;
+            sum = a.dh[i * a.odim + co];
+            const long long e = i * a.K + a.arg[i * a.odim + co];
+            atomicAdd(dq + (base + a.idx[e]) * 2 * a.S, sum);
+        } else {
+            const int co = c - a.GT;
+            for (int k = 0; k < a.K; ++k) {
+                const long long e = i * a.K + k;
+                const float v = a.dyout[e * a.odim + co];
+                sum += v;
+                atomicAdd(dq + (base + a.idx[e]) * 2 * a.S, v);
+            }
+        }
+        a.dPQ[i * 2 * a.S + c] = sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ growth-weight gradients
+// part[chunk][c][u] = sum over the chunk's edges of dYfull[e, c] * lrelu(bn(Y[e, u])), c < S (growth layers then conv_out),
+// u < GT.  K dimension = edges: both operands are channel-fast in memory, so a block of 32 edges is staged through LDS
+// (coalesced float4 loads, the activation / the pooled gradient formed once on the way) and the MFMA operands are read
+// from there edge-major.  blockIdx.y = 0: the conv_out rows; 1: the growth rows, whose output is block lower triangular
+// (layer t sees columns u < g t only) - the valid 16 x 16 tiles of either kind are dealt round-robin to the four waves.
+struct EcDwArgs {
+    const float* dY; const float* Y; int ld;
+    const float* aff;
+    const float* dh; const unsigned char* arg; const float* dyout; int pooled;
+    int g, GT, odim, S, K;
+    long long E; int chunk;
+    float slope;
+    float* part;
+    float* bpart;                    // [nchunk][S]: column sums of dYfull over the chunk (the conv bias gradients)
+};
+constexpr int DW_EB = 32, DW_SLOTS = 16;
+
+__global__ __launch_bounds__(256) void ec_dw_kernel(EcDwArgs a) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    const bool outrows = blockIdx.y == 0;
+    const int RA = outrows ? a.odim : a.GT;
+    const int lda = RA + 16, ldb = a.GT + 16;
+    float* As = lds;
+    float* Bs = lds + DW_EB * lda;
+    const int NT = a.GT / 16, NRT = RA / 16;
+    int rts[DW_SLOTS], cts[DW_SLOTS];
+    bool val[DW_SLOTS];
+#pragma unroll
+    for (int s = 0; s < DW_SLOTS; ++s) {
+        const int id = wave + 4 * s;
+        rts[s] = 0; cts[s] = 0; val[s] = false;
+        if (outrows) {
+            if (id < NRT * NT) { rts[s] = id / NT; cts[s] = id % NT; val[s] = true; }
+        } else {
+            int cum = 0;
+            for (int r = 0; r < NRT; ++r) {
+                const int last = r * 16 + 15;
+                const int n = ((last / a.g) * a.g + 15) / 16;                 // column tiles u < g * (layer of the tile's last row)
+                if (!val[s] && id < cum + n) { rts[s] = r; cts[s] = id - cum; val[s] = true; }
+                cum += n;
+            }
+        }
+    }
+    f4 acc[DW_SLOTS];
+#pragma unroll
+    for (int s = 0; s < DW_SLOTS; ++s) acc[s] = pf_splat(0.f);
+    const long long e_lo = (long long)blockIdx.x * a.chunk, e_hi = min(a.E, e_lo + a.chunk);
+    const int ra4 = RA / 4, gt4 = a.GT / 4;
+    float bsum = 0.f;
+    for (long long eb = e_lo; eb < e_hi; eb += DW_EB) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < DW_EB * ra4; i += 256) {
+            const int el = i / ra4, c = (i % ra4) * 4;
+            const long long e = eb + el;
+            f4 v = pf_splat(0.f);
+            if (e < e_hi) {
+                if (!outrows) v = *reinterpret_cast<const f4*>(a.dY + e * a.ld + c);
+                else if (a.pooled) {
+                    const long long ii = e / a.K;
+                    const int k = (int)(e % a.K);
+                    const f4 dv = *reinterpret_cast<const f4*>(a.dh + ii * a.odim + c);
+                    const unsigned g4 = *reinterpret_cast<const unsigned*>(a.arg + ii * a.odim + c);
+                    v.x = (int)(g4 & 255u) == k ? dv.x : 0.f; v.y = (int)((g4 >> 8) & 255u) == k ? dv.y : 0.f;
+                    v.z = (int)((g4 >> 16) & 255u) == k ? dv.z : 0.f; v.w = (int)(g4 >> 24) == k ? dv.w : 0.f;
+                } else v = *reinterpret_cast<const f4*>(a.dyout + e * a.odim + c);
+            }
+            *reinterpret_cast<f4*>(As + el * lda + c) = v;
+        }
+        for (int i = threadIdx.x; i < DW_EB * gt4; i += 256) {
+            const int el = i / gt4, c = (i % gt4) * 4;
+            const long long e = eb + el;
+            f4 v = pf_splat(0.f);
+            if (e < e_hi)
+                v = lrelu4(*reinterpret_cast<const f4*>(a.Y + e * a.ld + c) * *reinterpret_cast<const f4*>(a.aff + c) +
+                           *reinterpret_cast<const f4*>(a.aff + a.ld + c), a.slope);
+            *reinterpret_cast<f4*>(Bs + el * ldb + c) = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < RA)
+#pragma unroll 8
+            for (int el = 0; el < DW_EB; ++el) bsum += As[el * lda + threadIdx.x];
+#pragma unroll
+        for (int ks = 0; ks < DW_EB / 4; ++ks) {
+            const float* ar = As + (4 * ks + q) * lda + row;
+            const float* br = Bs + (4 * ks + q) * ldb + row;
+#pragma unroll
+            for (int s = 0; s < DW_SLOTS; ++s)
+                if (val[s]) acc[s] = pf_mfma(ar[rts[s] * 16], br[cts[s] * 16], acc[s]);
+        }
+    }
+    if (threadIdx.x < RA) a.bpart[(size_t)blockIdx.x * a.S + (outrows ? a.GT : 0) + threadIdx.x] = bsum;
+    float* out = a.part + ((size_t)blockIdx.x * a.S + (outrows ? a.GT : 0)) * a.GT;
+#pragma unroll
+    for (int s = 0; s < DW_SLOTS; ++s)
+        if (val[s])
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(rts[s] * 16 + 4 * q + r) * a.GT + cts[s] * 16 + row] = acc[s][r];
+}
+
+// ------------------------------------------------------------------------------------------------ weight folding / un-folding
+struct EcConvs {
+    const float* W[9]; const float* bias[9];
+    float* dW[9]; float* dbias[9];
+    int rows[9], rowoff[10], width[9];      // conv t: [rows, width = 3C + g t]; rowoff: first row in the S-row stacking
+    int nconvs, C, S, GT;
+};
+// Wpq [2S, C], bpq [2S] = (bias | 0)
+__global__ __launch_bounds__(256) void ec_fold_kernel(EcConvs cv, float* Wpq, float* bpq) {
+    const int total = cv.S * cv.C;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int srow = i / cv.C, col = i % cv.C;
+        int t = 0;
+        while (t + 1 < cv.nconvs && srow >= cv.rowoff[t + 1]) ++t;
+        const float* w = cv.W[t] + (size_t)(srow - cv.rowoff[t]) * cv.width[t];
+        Wpq[(size_t)srow * cv.C + col] = w[col] - w[2 * cv.C + col];
+        Wpq[(size_t)(cv.S + srow) * cv.C + col] = w[cv.C + col] + w[2 * cv.C + col];
+        if (col == 0) { bpq[srow] = cv.bias[t][srow - cv.rowoff[t]]; bpq[cv.S + srow] = 0.f; }
+    }
+}
+// dW_t[r, :] = [dWp | dWq | dWq - dWp | sum_chunks part[:, rowoff_t + r, :g t]],  dbias_t[r] = sum_chunks bpart[:, rowoff_t + r].
+// 64 consecutive elements per workgroup, the chunk sum split four ways (threadIdx.y) and joined through LDS.
+__global__ __launch_bounds__(256) void ec_assemble_kernel(EcConvs cv, const float* dWpq, const float* part, int nchunk,
+                                                          const float* bpart, int total) {
+    __shared__ double sh[4][64], shb[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    int t = 0, r = 0, col = 0, srow = 0;
+    bool ok = i < total, grow = false;
+    if (ok) {
+        int rem = i;
+        while (rem >= cv.rows[t] * cv.width[t]) { rem -= cv.rows[t] * cv.width[t]; ++t; }
+        r = rem / cv.width[t]; col = rem % cv.width[t];
+        srow = cv.rowoff[t] + r;
+        grow = col >= 3 * cv.C;
+    }
+    double s = 0.0, sb = 0.0;
+    if (ok && grow) {
+        const int u = col - 3 * cv.C;
+        for (int k = ty; k < nchunk; k += 4) s += (double)part[((size_t)k * cv.S + srow) * cv.GT + u];
+    }
+    if (ok && col == 0)
+        for (int k = ty; k < nchunk; k += 4) sb += (double)bpart[(size_t)k * cv.S + srow];
+    sh[ty][tx] = s; shb[ty][tx] = sb;
+    __syncthreads();
+    if (ty != 0 || !ok) return;
+    float v;
+    if (col < cv.C) v = dWpq[(size_t)srow * cv.C + col];
+    else if (col < 2 * cv.C) v = dWpq[(size_t)(cv.S + srow) * cv.C + col - cv.C];
+    else if (col < 3 * cv.C) v = dWpq[(size_t)(cv.S + srow) * cv.C + col - 2 * cv.C] - dWpq[(size_t)srow * cv.C + col - 2 * cv.C];
+    else v = (float)((sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]));
+    cv.dW[t][(size_t)r * cv.width[t] + col] = v;
+    if (col == 0) cv.dbias[t][r] = (float)((shb[0][tx] + shb[1][tx]) + (shb[2][tx] + shb[3][tx]));
+}
+
+template <typename KERNEL>
+void allow_lds(KERNEL k, size_t bytes) {
+    if (bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+struct Dims {
+    int T, GT, S, nconvs;
+    long long E;
+    int ntiles, grid, nchunk;
+};
+constexpr int EC_DW_CHUNK = 512;
+
+int ec_dims(const PfEcTrain* p, Dims& d) {
+    if (!p) return PF_ERR_NULL;
+    if (p->B <= 0 || p->N <= 0 || p->K <= 0 || p->C <= 0 || p->nconv < 1 || p->nconv > 8) return PF_ERR_SHAPE;
+    if (p->growth != 8 && p->growth != 16 && p->growth != 32) return PF_ERR_UNSUPPORTED;
+    if (p->odim % 16 != 0 || p->odim > 128 || p->odim < 16) return PF_ERR_UNSUPPORTED;
+    if (p->pooling && p->K != 16) return PF_ERR_UNSUPPORTED;
+    d.T = p->B * p->N;
+    d.GT = p->growth * p->nconv;
+    if (d.GT > 128 || d.GT % 16 != 0) return PF_ERR_UNSUPPORTED;
+    d.S = d.GT + p->odim;
+    d.nconvs = p->nconv + 1;
+    d.E = (long long)d.T * p->K;
+    if (d.E % 16 != 0 || d.E > (1ll << 30)) return PF_ERR_SHAPE;
+    d.ntiles = (int)(d.E / 16);
+    d.grid = (d.ntiles + 3) / 4 < EC_GRID ? (d.ntiles + 3) / 4 : EC_GRID;
+    d.nchunk = (int)((d.E + EC_DW_CHUNK - 1) / EC_DW_CHUNK);
+    return PF_OK;
+}
+EcConvs ec_convs(const PfEcTrain* p, const Dims& d) {
+    EcConvs cv{};
+    cv.nconvs = d.nconvs; cv.C = p->C; cv.S = d.S; cv.GT = d.GT;
+    int off = 0;
+    for (int t = 0; t < d.nconvs; ++t) {
+        cv.W[t] = p->W[t]; cv.bias[t] = p->bias[t]; cv.dW[t] = p->dW[t]; cv.dbias[t] = p->dbias[t];
+        cv.rows[t] = t < p->nconv ? p->growth : p->odim;
+        cv.width[t] = 3 * p->C + p->growth * t;
+        cv.rowoff[t] = off;
+        off += cv.rows[t];
+    }
+    cv.rowoff[d.nconvs] = off;
+    return cv;
+}
+long long gemm_ws_max(const PfEcTrain* p, const Dims& d) {
+    long long g1 = pf_gemm_ws_floats(2 * d.S, p->C, d.T), g2 = pf_gemm_ws_floats(d.T, p->C, 2 * d.S),
+              g3 = pf_gemm_ws_floats(d.T, 2 * d.S, p->C);
+    long long gm = g1 > g2 ? g1 : g2;
+    return gm > g3 ? gm : g3;
+}
+
+}  // namespace
+
+// floats of scratch for either direction: dw partials [nchunk][S][GT] + [nchunk][S] + split-K slabs of the point GEMMs
+extern "C" long long pf_ec_train_ws_floats(const PfEcTrain* p) {
+    Dims d;
+    if (ec_dims(p, d) != PF_OK) return -1;
+    return (long long)d.nchunk * d.S * (d.GT + 1) + gemm_ws_max(p, d);
+}
+
+extern "C" int pf_ec_train_fwd(const PfEcTrain* p, void* stream) {
+    Dims d;
+    int st = ec_dims(p, d);
+    if (st) return st;
+    if (!p->x || !p->idx || !p->Wpq || !p->bpq || !p->PQ || !p->Y || !p->aff || !p->out || !p->ws || !p->stat) return PF_ERR_NULL;
+    if (p->pooling && !p->arg) return PF_ERR_NULL;
+    for (int t = 0; t < d.nconvs; ++t)
+        if (!p->W[t] || !p->bias[t]) return PF_ERR_NULL;
+    for (int t = 0; t < p->nconv; ++t)
+        if (!p->gamma[t] || !p->beta[t]) return PF_ERR_NULL;
+    if (p->ws_floats < pf_ec_train_ws_floats(p)) return PF_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const EcConvs cv = ec_convs(p, d);
+    float* gws = p->ws + (long long)d.nchunk * d.S * (d.GT + 1);
+    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * (STAT_COPIES * 64 + 1), s);
+    hipLaunchKernelGGL(ec_fold_kernel, dim3((d.S * p->C + 255) / 256), dim3(256), 0, s, cv, p->Wpq, p->bpq);
+    st = pf_gemm(p->x, p->C, 1, p->Wpq, 1, p->C, p->PQ, 2 * d.S, p->bpq, d.T, 2 * d.S, p->C, gws,
+                 pf_gemm_ws_floats(d.T, 2 * d.S, p->C), stream);
+    if (st) return st;
+    const int g = p->growth;
+    EcFwdArgs a{};
+    a.Y = p->Y; a.ldy = d.GT; a.aff = p->aff; a.pq = p->PQ; a.ldpq = 2 * d.S; a.idx = p->idx; a.N = p->N; a.K = p->K;
+    a.ntiles = d.ntiles; a.slope = p->slope;
+    for (int t = 0; t < p->nconv; ++t) {
+        a.W = p->W[t] + 3 * p->C; a.ldw = cv.width[t]; a.poff = g * t; a.qoff = d.S + g * t;
+        a.kin = g * t; a.col0 = g * t; a.nout = g;
+        a.fin = StatFin{p->stat, 1, g, g * t, d.GT, p->aff, p->gamma[t], p->beta[t], p->run_mean[t], p->run_var[t], p->eps,
+                        p->momentum, nullptr, nullptr, nullptr, (double)d.E};
+        const int kin16 = (a.kin + 15) & ~15;
+        const int nt = g > 16 ? 2 : 1;
+        const size_t lds = sizeof(float) * ((size_t)nt * 16 * (kin16 + 4) + 2 * kin16);
+        if (nt == 2) hipLaunchKernelGGL((ec_fwd_kernel<2, false, false>), dim3(d.grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((ec_fwd_kernel<1, false, false>), dim3(d.grid), dim3(256), lds, s, a);
+    }
+    a.W = p->W[p->nconv] + 3 * p->C; a.ldw = cv.width[p->nconv]; a.poff = d.GT; a.qoff = d.S + d.GT;
+    a.kin = d.GT; a.col0 = 0; a.nout = p->odim; a.out = p->out; a.arg = p->arg; a.fin = StatFin{};
+    const int nto = p->odim / 16;
+    const size_t lds = sizeof(float) * ((size_t)(nto <= 2 ? 2 : (nto <= 4 ? 4 : 8)) * 16 * (d.GT + 4) + 2 * d.GT);
+#define PF_ECO(NT)                                                                                                        \
+    do {                                                                                                                  \
+        if (p->pooling) { allow_lds(ec_fwd_kernel<NT, true, true>, lds);                                                  \
+            hipLaunchKernelGGL((ec_fwd_kernel<NT, true, true>), dim3(d.grid), dim3(256), lds, s, a); }                    \
+        else { allow_lds(ec_fwd_kernel<NT, true, false>, lds);                                                            \
+            hipLaunchKernelGGL((ec_fwd_kernel<NT, true, false>), dim3(d.grid), dim3(256), lds, s, a); }                   \
+    } while (0)
+    if (nto <= 2) PF_ECO(2); else if (nto <= 4) PF_ECO(4); else PF_ECO(8);
+#undef PF_ECO
+    return pf_last_launch_status();
+}
+
+extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
+    Dims d;
+    int st = ec_dims(p, d);
+    if (st) return st;
+    if (!p->x || !p->idx || !p->Wpq || !p->PQ || !p->Y || !p->aff || !p->dout || !p->dA || !p->dPQ || !p->coef || !p->dWpq ||
+        !p->ws || !p->stat)
+        return PF_ERR_NULL;
+    if (p->pooling && !p->arg) return PF_ERR_NULL;
+    for (int t = 0; t < d.nconvs; ++t)
+        if (!p->W[t] || !p->dW[t] || !p->dbias[t]) return PF_ERR_NULL;
+    for (int t = 0; t < p->nconv; ++t)
+        if (!p->dgamma[t] || !p->dbeta[t]) return PF_ERR_NULL;
+    if (p->ws_floats < pf_ec_train_ws_floats(p)) return PF_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const EcConvs cv = ec_convs(p, d);
+    const int g = p->growth, nc = p->nconv;
+    float* dwpart = p->ws;
+    float* bpart = dwpart + (long long)d.nchunk * d.S * d.GT;
+    float* gws = bpart + (long long)d.nchunk * d.S;
+    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * (STAT_COPIES * 64 + 1), s);
+    (void)hipMemsetAsync(p->dPQ, 0, sizeof(float) * (size_t)d.T * 2 * d.S, s);
+
+    // ---- conv_out: dA = dYout Wg_out (+ sums of the last growth layer)
+    {
+        EcBwdArgs a{};
+        a.dh = p->dout; a.arg = p->arg; a.dyout = p->dout; a.dA = p->dA; a.Y = p->Y; a.ld = d.GT; a.aff = p->aff; a.coef = p->coef;
+        a.c0 = 0; a.kin = p->odim; a.W = p->W[nc] + 3 * p->C; a.ldw = cv.width[nc]; a.nout = d.GT;
+        a.sc0 = g * (nc - 1); a.sg = g; a.ntiles = d.ntiles; a.slope = p->slope;
+        a.fin = StatFin{p->stat, 2, g, g * (nc - 1), d.GT, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, p->coef,
+                        p->dgamma[nc - 1], p->dbeta[nc - 1], (double)d.E};
+        const int nt = d.GT / 16 <= 2 ? 2 : (d.GT / 16 <= 4 ? 4 : 8);
+        const size_t lds = sizeof(float) * ((size_t)nt * 16 * (((p->odim + 15) & ~15) + 4));
+#define PF_ECB(NT, SRC)                                                                                                   \
+    do { allow_lds(ec_bwd_kernel<NT, SRC>, lds);                                                                          \
+         hipLaunchKernelGGL((ec_bwd_kernel<NT, SRC>), dim3(d.grid), dim3(256), lds, s, a); } while (0)
+        if (p->pooling) { if (nt == 2) PF_ECB(2, 0); else if (nt == 4) PF_ECB(4, 0); else PF_ECB(8, 0); }
+        else { if (nt == 2) PF_ECB(2, 1); else if (nt == 4) PF_ECB(4, 1); else PF_ECB(8, 1); }
+    }
+    // ---- growth layers, last to first
+    for (int t = nc - 1; t >= 1; --t) {
+        EcBwdArgs a{};
+        a.dA = p->dA; a.Y = p->Y; a.ld = d.GT; a.aff = p->aff; a.coef = p->coef;
+        a.c0 = g * t; a.kin = g; a.W = p->W[t] + 3 * p->C; a.ldw = cv.width[t]; a.nout = g * t;
+        a.sc0 = g * (t - 1); a.sg = g; a.ntiles = d.ntiles; a.slope = p->slope;
+        a.fin = StatFin{p->stat, 2, g, g * (t - 1), d.GT, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, p->coef,
+                        p->dgamma[t - 1], p->dbeta[t - 1], (double)d.E};
+        const int nt16 = (a.nout + 15) / 16;
+        const int nt = nt16 <= 1 ? 1 : (nt16 <= 2 ? 2 : (nt16 <= 4 ? 4 : 8));
+        const int kin16 = (g + 15) & ~15;
+        const size_t lds = sizeof(float) * ((size_t)nt * 16 * (kin16 + 4) + 6 * kin16);
+        if (nt == 1) PF_ECB(1, 2); else if (nt == 2) PF_ECB(2, 2); else if (nt == 4) PF_ECB(4, 2); else PF_ECB(8, 2);
+#undef PF_ECB
+    }
+    {
+        const long long n = d.E * (g / 4);
+        hipLaunchKernelGGL(ec_bwd0_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s,
+                           p->dA, p->Y, d.GT, p->aff, p->coef, g, d.E, p->slope);
+    }
+    // ---- dPQ (+ bias column sums)
+    {
+        EcPqBwdArgs a{p->dA, d.GT, p->dout, p->arg, p->dout, p->pooling, p->idx, p->N, p->K, d.GT, p->odim, d.S, (long long)d.T,
+                      p->dPQ};
+        const long long n = (long long)d.T * d.S;
+        hipLaunchKernelGGL(ec_pq_bwd_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256), 0, s, a);
+    }
+    // ---- growth-weight gradients (partials), dx, dWpq
+    {
+        EcDwArgs a{p->dA, p->Y, d.GT, p->aff, p->dout, p->arg, p->dout, p->pooling, g, d.GT, p->odim, d.S, p->K, d.E, EC_DW_CHUNK,
+                   p->slope, dwpart, bpart};
+        const int ramax = p->odim > d.GT ? p->odim : d.GT;
+        const size_t lds = sizeof(float) * (size_t)DW_EB * ((ramax + 16) + (d.GT + 16));
+        hipLaunchKernelGGL(ec_dw_kernel, dim3(d.nchunk, 2), dim3(256), lds, s, a);
+    }
+    if (p->dx) {
+        st = pf_gemm(p->dPQ, 2 * d.S, 1, p->Wpq, p->C, 1, p->dx, p->C, nullptr, d.T, p->C, 2 * d.S, gws,
+                     pf_gemm_ws_floats(d.T, p->C, 2 * d.S), stream);
+        if (st) return st;
+    }
+    st = pf_gemm(p->dPQ, 1, 2 * d.S, p->x, p->C, 1, p->dWpq, p->C, nullptr, 2 * d.S, p->C, d.T, gws,
+                 pf_gemm_ws_floats(2 * d.S, p->C, d.T), stream);
+    if (st) return st;
+    int total = 0;
+    for (int t = 0; t < d.nconvs; ++t) total += cv.rows[t] * cv.width[t];
+    hipLaunchKernelGGL(ec_assemble_kernel, dim3((total + 63) / 64), dim3(256), 0, s, cv, p->dWpq, dwpart, d.nchunk, bpart, total);
+    return pf_last_launch_status();
+}

@@ -13,6 +13,7 @@ Activations are channels-last [rows, C] fp32 (rows = points or edges).
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import math
@@ -50,6 +51,19 @@ def _ws(dev, n: int) -> Tensor:
 # profiles/r2_train), so the exact arithmetic stays the default; the gradient tests pass in both modes.
 _GEMM_MODE = os.environ.get("PF_TRAIN_GEMM", "f32")
 ARITH_FWD, ARITH_BWD = (2, 3) if _GEMM_MODE == "split" else (0, 0)
+
+
+_STAT = {}
+
+
+def _stat(dev) -> Tensor:
+    """1025 doubles per (device, stream): the column-statistics accumulators of the fused training kernels."""
+    key = (dev, _stream())
+    t = _STAT.get(key)
+    if t is None:
+        t = torch.zeros(1025, dtype=torch.float64, device=dev)
+        _STAT[key] = t
+    return t
 
 
 def _gemm(A: Tensor, sam: int, sak: int, Bm: Tensor, sbk: int, sbn: int, C: Tensor, ldc: int, bias, M: int, N: int, K: int,
@@ -546,6 +560,8 @@ def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True) -> Tensor:
     and the gather's scatter-add - exact algebra, same results up to fp32 rounding."""
     if _UNFOLDED:
         return edgeconv_train_unfolded(p, x, idx, pooling)
+    if _FUSED and not _sync_bn_active():
+        return edgeconv_train_fused(p, x, idx, pooling)
     B, N, C = x.shape
     K = idx.shape[-1]
     convs = [seq[0] for seq in p.convs] + [p.conv_out]
@@ -570,6 +586,122 @@ def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True) -> Tensor:
     if not pooling:
         return y.contiguous()
     return MaxPoolKFn.apply(y.contiguous(), K).view(B, N, -1)
+
+
+class EdgeConvUnitFn(Function):
+    """One FeatureExtractUnit in train mode as ~11 launches forward / ~20 backward (csrc/train_fused.hip: the folded edge
+    feature, BatchNorm applied on load by the consumer of each layer, statistics in the GEMM epilogues, max-pool in the
+    accumulator layout).  Same function and gradients as `edgeconv_train` (interpflow.py:190-248), which stays as the
+    A/B reference (PF_TRAIN_FUSED=0) and as the SyncBN path."""
+
+    @staticmethod
+    def _desc(x, idx, cfg, Ws, bs, gammas, betas):
+        K, g, nconv, odim, pooling, slope, eps, momentum, rmeans, rvars = cfg
+        B, N, C = x.shape
+        d = _lib.PfEcTrain()
+        d.B, d.N, d.K, d.C, d.growth, d.nconv, d.odim, d.pooling = B, N, K, C, g, nconv, odim, int(pooling)
+        d.slope, d.eps, d.momentum = slope, eps, momentum
+        d.x, d.idx = x.data_ptr(), idx.data_ptr()
+        for t in range(nconv + 1):
+            d.W[t], d.bias[t] = Ws[t].data_ptr(), bs[t].data_ptr()
+        for t in range(nconv):
+            d.gamma[t], d.beta[t] = gammas[t].data_ptr(), betas[t].data_ptr()
+            d.run_mean[t] = rmeans[t].data_ptr() if rmeans[t] is not None else None
+            d.run_var[t] = rvars[t].data_ptr() if rvars[t] is not None else None
+        return d
+
+    @staticmethod
+    def forward(ctx, x, idx, cfg, *params):
+        lib = _lib.load()
+        K, g, nconv, odim, pooling = cfg[:5]
+        nc1 = nconv + 1
+        Ws = [w.contiguous() for w in params[:nc1]]
+        bs = [b.contiguous() for b in params[nc1:2 * nc1]]
+        gammas = [t.contiguous() for t in params[2 * nc1:2 * nc1 + nconv]]
+        betas = [t.contiguous() for t in params[2 * nc1 + nconv:]]
+        x = x.contiguous()
+        B, N, C = x.shape
+        T, E, GT = B * N, B * N * K, g * nconv
+        S = GT + odim
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        Wpq, bpq = torch.empty((2 * S, C), **f32), torch.empty((2 * S,), **f32)
+        PQ, Y, aff = torch.empty((T, 2 * S), **f32), torch.empty((E, GT), **f32), torch.empty((4, GT), **f32)
+        out = torch.empty((T if pooling else E, odim), **f32)
+        arg = torch.empty((T, odim), dtype=torch.uint8, device=dev) if pooling else None
+        d = EdgeConvUnitFn._desc(x, idx, cfg, Ws, bs, gammas, betas)
+        d.Wpq, d.bpq, d.PQ, d.Y, d.aff, d.out = (Wpq.data_ptr(), bpq.data_ptr(), PQ.data_ptr(), Y.data_ptr(), aff.data_ptr(),
+                                                 out.data_ptr())
+        d.arg = arg.data_ptr() if pooling else None
+        need = lib.pf_ec_train_ws_floats(ctypes.byref(d))
+        if need < 0:
+            raise _lib.PuflowHipError(f"pf_ec_train: unsupported unit shape (K={K}, growth={g}, nconv={nconv}, odim={odim})")
+        ws = _ws(dev, need)
+        d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
+        d.stat = _stat(dev).data_ptr()
+        _lib.check(lib.pf_ec_train_fwd(ctypes.byref(d), _stream()), "pf_ec_train_fwd")
+        ctx.cfg = cfg
+        ctx.has_arg = pooling
+        ctx.save_for_backward(x, idx, Wpq, PQ, Y, aff, *(() if arg is None else (arg,)), *Ws, *gammas)
+        return out.view(B, N, odim) if pooling else out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        cfg = ctx.cfg
+        K, g, nconv, odim, pooling = cfg[:5]
+        nc1 = nconv + 1
+        sv = list(ctx.saved_tensors)
+        x, idx, Wpq, PQ, Y, aff = sv[:6]
+        arg = sv[6] if ctx.has_arg else None
+        rest = sv[7 if ctx.has_arg else 6:]
+        Ws, gammas = rest[:nc1], rest[nc1:]
+        B, N, C = x.shape
+        T, E, GT = B * N, B * N * K, g * nconv
+        S = GT + odim
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dout = dout.contiguous()
+        d = EdgeConvUnitFn._desc(x, idx, cfg, Ws, Ws, gammas, gammas)      # biases / betas are not read by the backward
+        d.Wpq, d.PQ, d.Y, d.aff = Wpq.data_ptr(), PQ.data_ptr(), Y.data_ptr(), aff.data_ptr()
+        d.arg = arg.data_ptr() if arg is not None else None
+        d.dout = dout.data_ptr()
+        dA, dPQ = torch.empty((E, GT), **f32), torch.empty((T, 2 * S), **f32)
+        coef, dWpq = torch.empty((2, GT), **f32), torch.empty((2 * S, C), **f32)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dWs = [torch.empty_like(w) for w in Ws]
+        dbs = [torch.empty((w.shape[0],), **f32) for w in Ws]
+        dgs = [torch.empty((g,), **f32) for _ in range(nconv)]
+        dbe = [torch.empty((g,), **f32) for _ in range(nconv)]
+        d.dA, d.dPQ, d.coef, d.dWpq = dA.data_ptr(), dPQ.data_ptr(), coef.data_ptr(), dWpq.data_ptr()
+        d.dx = dx.data_ptr() if dx is not None else None
+        for t in range(nc1):
+            d.dW[t], d.dbias[t] = dWs[t].data_ptr(), dbs[t].data_ptr()
+        for t in range(nconv):
+            d.dgamma[t], d.dbeta[t] = dgs[t].data_ptr(), dbe[t].data_ptr()
+        need = lib.pf_ec_train_ws_floats(ctypes.byref(d))
+        ws = _ws(dev, need)
+        d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
+        d.stat = _stat(dev).data_ptr()
+        _lib.check(lib.pf_ec_train_bwd(ctypes.byref(d), _stream()), "pf_ec_train_bwd")
+        return (dx, None, None, *dWs, *dbs, *dgs, *dbe)
+
+
+_FUSED = os.environ.get("PF_TRAIN_FUSED", "1") != "0"
+
+
+def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True) -> Tensor:
+    convs = [seq[0] for seq in p.convs] + [p.conv_out]
+    bns = [seq[1] for seq in p.convs]
+    g, nconv, odim = convs[0].weight.shape[0], len(bns), p.conv_out.weight.shape[0]
+    cfg = (idx.shape[-1], g, nconv, odim, bool(pooling), 0.05, float(bns[0].eps), float(bns[0].momentum),
+           [bn.running_mean for bn in bns], [bn.running_var for bn in bns])
+    out = EdgeConvUnitFn.apply(x, idx, cfg, *[c.weight for c in convs], *[c.bias for c in convs],
+                               *[bn.weight for bn in bns], *[bn.bias for bn in bns])
+    with torch.no_grad():
+        for bn in bns:
+            bn.num_batches_tracked += 1
+    return out
 
 
 def cond_net(net, h: Tensor) -> Tensor:
