@@ -259,6 +259,33 @@ long long pf_ec_train_ws_floats(const PfEcTrain* p);
 int pf_ec_train_fwd(const PfEcTrain* p, void* stream);
 int pf_ec_train_bwd(const PfEcTrain* p, void* stream);
 
+/* ---- point-wise MLP of the training step (2 or 3 Linear layers, LeakyReLU / ReLU between them), fused (csrc/train_mlp.hip) ----
+ * Replaces LinearA1D (modules/discrete/interpflow.py:22-43, the conditioner of the coupling / injector layers) and
+ * FeatMergeUnit (interpflow.py:251-258) in train() mode together with their autograd backward.
+ * Input of layer 0 = cat[y[row, :td], c[row / cdiv, :cc]] (never materialised): td <= 3, cc a multiple of 16 <= 128,
+ * cdiv in {1,2,4,8,16} divides rows; hidden widths multiples of 16 <= 128; last width <= 128.
+ * W[l]: [width[l], in_l] row-major, in_0 = td + cc, in_l = width[l-1]; b[l] nullable. */
+typedef struct PfMlpTrain {
+    int rows, nl, td, ldy, cc, cdiv;
+    int width[3];
+    float slope[2];                 /* activation after layer 0 (and 1): max(x, slope x) */
+    const float* y;                 /* [rows, ldy], nullable when td == 0 */
+    const float* c;                 /* [rows / cdiv, cc] */
+    const float* W[3]; const float* b[3];
+    float* h[2];                    /* (kept) [rows, width[l]] activations after layer l < nl - 1 */
+    float* out;                     /* [rows, width[nl-1]] */
+    /* backward only */
+    const float* dout;
+    float* dz[2];                   /* [rows, width[l]] scratch */
+    float* dy;                      /* [rows, ldy] (columns >= td zeroed), nullable */
+    float* dc;                      /* [rows / cdiv, cc], nullable */
+    float* dW[3]; float* db[3];     /* db[l] nullable */
+    float* ws; long long ws_floats; /* >= pf_mlp_train_ws_floats() */
+} PfMlpTrain;
+long long pf_mlp_train_ws_floats(const PfMlpTrain* p);
+int pf_mlp_train_fwd(const PfMlpTrain* p, void* stream);
+int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Patch pipeline around the network (modules/utils/patch.py:35-214), csrc/patch_ops.hip
  * ------------------------------------------------------------------------------------------- */

@@ -24,6 +24,15 @@ class PfEcTrain(ctypes.Structure):
                 ("dgamma", c_void_p * 8), ("dbeta", c_void_p * 8), ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p)]
 
 
+class PfMlpTrain(ctypes.Structure):
+    """include/puflow_hip.h: PfMlpTrain (a 2/3-layer point-wise MLP of the training step)."""
+    _fields_ = [("rows", c_int), ("nl", c_int), ("td", c_int), ("ldy", c_int), ("cc", c_int), ("cdiv", c_int),
+                ("width", c_int * 3), ("slope", c_float * 2), ("y", c_void_p), ("c", c_void_p),
+                ("W", c_void_p * 3), ("b", c_void_p * 3), ("h", c_void_p * 2), ("out", c_void_p), ("dout", c_void_p),
+                ("dz", c_void_p * 2), ("dy", c_void_p), ("dc", c_void_p), ("dW", c_void_p * 3), ("db", c_void_p * 3),
+                ("ws", c_void_p), ("ws_floats", c_longlong)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/puflow_hip.h
 SIGNATURES = {
     "pf_version": (c_int, []),
@@ -92,6 +101,9 @@ SIGNATURES = {
     "pf_dist_feature": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_fps": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_fps_scratch_layout": (c_int, [c_int, POINTER(c_longlong), POINTER(c_longlong)]),
+    "pf_mlp_train_ws_floats": (c_longlong, [c_void_p]),
+    "pf_mlp_train_fwd": (c_int, [c_void_p, c_void_p]),
+    "pf_mlp_train_bwd": (c_int, [c_void_p, c_void_p]),
     "pf_ec_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_ec_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_ec_train_bwd": (c_int, [c_void_p, c_void_p]),

@@ -1,0 +1,449 @@
+// Point-wise MLPs of the TRAINING step (no BatchNorm) as one launch forward and three backward.
+//
+// Reference: modules/discrete/interpflow.py:22-43 (LinearA1D: Linear(no bias) - LeakyReLU - Linear - LeakyReLU - Linear, the
+// conditioner of every coupling / injector layer, interpflow.py:46-82) and interpflow.py:251-258 (FeatMergeUnit:
+// Linear - ReLU - Linear).  The un-fused path ran each of the ~30 evaluations per step as 6 launches forward and ~20
+// backward on [8192..32768, 64] activations - all launch latency.  Here:
+//
+//   forward   one kernel: the 2 or 3 layers chained in registers ("channel-major": output channels on the MFMA rows, 16 points
+//             on the columns, so a layer's accumulator tile IS the next layer's B operand - csrc/pf_mfma.h), hidden activations
+//             stored once for the backward
+//   backward  chain   dz_l = (W_l^T dz_{l+1}) * act'(h_l) layer by layer in registers, stored for the weight gradients;
+//                     input gradients: dy[:, :td] and dc (summed over the `cdiv` replicas of a conditioning row)
+//             dw      every layer's dW = dz^T a and db = sum dz in ONE split-K launch (blockIdx.y = layer; a block of rows
+//                     staged through LDS, K dimension = rows), partial sums per row chunk
+//             reduce  partial sums -> dW, db
+//
+// The first layer's input is cat[y[:, :td], c[row / cdiv]]: td <= 3 leading columns of a [rows, ldy] tensor (the coupling's
+// untouched coordinates) and cc conditioning channels shared by cdiv consecutive rows (the x`upratio` replicas in the
+// inverse pass) - neither the concatenation nor the replicated conditioning tensor exists in memory.
+// All products are v_mfma_f32_16x16x4_f32 (fp32 fma chains).
+#include <hip/hip_runtime.h>
+#include "pf_api_internal.h"
+#include "pf_mfma.h"
+
+namespace {
+
+constexpr int MLP_GRID = 512;
+constexpr int MLP_EB = 32, MLP_SLOTS = 9, MLP_CHUNK = 256;
+
+__device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 c) {
+    c = pf_mfma(a.x, b.x, c); c = pf_mfma(a.y, b.y, c); c = pf_mfma(a.z, b.z, c); c = pf_mfma(a.w, b.w, c);
+    return c;
+}
+__device__ __forceinline__ f4 lrelu4(f4 z, float s) {
+    f4 r;
+    r.x = fmaxf(z.x, z.x * s); r.y = fmaxf(z.y, z.y * s); r.z = fmaxf(z.z, z.z * s); r.w = fmaxf(z.w, z.w * s);
+    return r;
+}
+__host__ __device__ inline int up16(int v) { return (v + 15) & ~15; }
+
+struct MlpShape {
+    int wi[3], wo[3], wi16[3], wo16[3];   // MFMA part of layer l: wi[0] = cc
+    int in[3];                             // row length of W[l]: in[0] = td + cc
+};
+__host__ __device__ inline MlpShape mlp_shape(const PfMlpTrain& p) {
+    MlpShape s{};
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {                       // unrolled with constant indices: the arrays stay in registers
+        if (l < p.nl) {
+            s.wi[l] = l == 0 ? p.cc : p.width[l > 0 ? l - 1 : 0];
+            s.wo[l] = p.width[l];
+            s.wi16[l] = up16(s.wi[l]); s.wo16[l] = up16(s.wo[l]);
+            s.in[l] = l == 0 ? p.td + p.cc : p.width[l > 0 ? l - 1 : 0];
+        }
+    }
+    return s;
+}
+template <typename T>
+__host__ __device__ inline T sel3(const T (&a)[3], int l) { return l == 0 ? a[0] : (l == 1 ? a[1] : a[2]); }
+template <typename T>
+__host__ __device__ inline T sel2(const T (&a)[2], int l) { return l == 0 ? a[0] : a[1]; }
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int NL>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p, int ntiles) {
+    extern __shared__ float lds[];
+    const MlpShape sh = mlp_shape(p);
+    float* Wl[NL];
+    float* bl[NL];
+    float* ptr = lds;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) { Wl[l] = ptr; ptr += sh.wo16[l] * (sh.wi16[l] + 4); bl[l] = ptr; ptr += sh.wo16[l]; }
+    float* Wx = ptr;                                     // [wo16[0]][4]: the td leading columns of W[0]
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int ld = sh.wi16[l] + 4, off = l == 0 ? p.td : 0;
+        for (int i = threadIdx.x; i < sh.wo16[l] * sh.wi16[l]; i += 256) {
+            const int c = i / sh.wi16[l], u = i % sh.wi16[l];
+            Wl[l][c * ld + u] = (c < sh.wo[l] && u < sh.wi[l]) ? p.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
+        }
+        for (int i = threadIdx.x; i < sh.wo16[l]; i += 256) bl[l][i] = (p.b[l] && i < sh.wo[l]) ? p.b[l][i] : 0.f;
+    }
+    for (int i = threadIdx.x; i < sh.wo16[0] * 4; i += 256) {
+        const int c = i >> 2, j = i & 3;
+        Wx[i] = (c < sh.wo[0] && j < p.td) ? p.W[0][(size_t)c * sh.in[0] + j] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const long long p0 = (long long)tile * 16 + col;
+        const bool valid = p0 < p.rows;
+        const long long pr = valid ? p0 : p.rows - 1;
+        f4 act[8];
+        const float* crow = p.c + (pr / p.cdiv) * p.cc;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+            act[cb] = pf_splat(0.f);
+            if (cb * 16 < sh.wi16[0]) act[cb] = *reinterpret_cast<const f4*>(crow + cb * 16 + 4 * q);
+        }
+        float xv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < p.td) xv[j] = p.y[pr * p.ldy + j];
+        pf_static_for<0, NL>([&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            const int ld = sh.wi16[l] + 4;
+            f4 nxt[8];
+#pragma unroll
+            for (int ob = 0; ob < 8; ++ob) {
+                nxt[ob] = pf_splat(0.f);
+                if (ob * 16 < sh.wo16[l]) {
+                    f4 acc = *reinterpret_cast<const f4*>(bl[l] + ob * 16 + 4 * q);
+                    if (l == 0 && p.td > 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f4 wx = *reinterpret_cast<const f4*>(Wx + (ob * 16 + 4 * q + r) * 4);
+                            acc[r] += wx.x * xv[0] + wx.y * xv[1] + wx.z * xv[2];
+                        }
+                    }
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb)
+                        if (cb * 16 < sh.wi16[l])
+                            acc = mfma4(*reinterpret_cast<const f4*>(Wl[l] + (ob * 16 + col) * ld + cb * 16 + 4 * q), act[cb], acc);
+                    if (l < NL - 1) {
+                        constexpr int lh = l < 2 ? l : 1;
+                        acc = lrelu4(acc, p.slope[lh]);
+                        if (valid) *reinterpret_cast<f4*>(p.h[lh] + p0 * sh.wo[l] + ob * 16 + 4 * q) = acc;
+                        nxt[ob] = acc;
+                    } else if (valid) {
+                        if ((sh.wo[l] & 15) == 0) *reinterpret_cast<f4*>(p.out + p0 * sh.wo[l] + ob * 16 + 4 * q) = acc;
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int ch = ob * 16 + 4 * q + r;
+                                if (ch < sh.wo[l]) p.out[p0 * sh.wo[l] + ch] = acc[r];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int ob = 0; ob < 8; ++ob) act[ob] = nxt[ob];
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward, chain
+template <int NL>
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p, int ntiles) {
+    extern __shared__ float lds[];
+    const MlpShape sh = mlp_shape(p);
+    float* Wt[NL];                                       // Wt[l][u][c] = W[l][c][off + u]
+    float* ptr = lds;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) { Wt[l] = ptr; ptr += sh.wi16[l] * (sh.wo16[l] + 4); }
+    float* Wx = ptr;                                     // [wo16[0]][4]
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int ld = sh.wo16[l] + 4, off = l == 0 ? p.td : 0;
+        for (int i = threadIdx.x; i < sh.wo16[l] * sh.wi16[l]; i += 256) {
+            const int c = i / sh.wi16[l], u = i % sh.wi16[l];                 // consecutive threads: consecutive u (contiguous in W)
+            Wt[l][u * ld + c] = (c < sh.wo[l] && u < sh.wi[l]) ? p.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
+        }
+    }
+    for (int i = threadIdx.x; i < sh.wo16[0] * 4; i += 256) {
+        const int c = i >> 2, j = i & 3;
+        Wx[i] = (c < sh.wo[0] && j < p.td) ? p.W[0][(size_t)c * sh.in[0] + j] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const long long p0 = (long long)tile * 16 + col;
+        const bool valid = p0 < p.rows;
+        const long long pr = valid ? p0 : p.rows - 1;
+        f4 g[8];
+        {
+            const int w = sh.wo[NL - 1];
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                g[cb] = pf_splat(0.f);
+                if (cb * 16 < sh.wo16[NL - 1] && valid) {
+                    const int ch = cb * 16 + 4 * q;
+                    if ((w & 3) == 0) {
+                        if (ch < w) g[cb] = *reinterpret_cast<const f4*>(p.dout + p0 * w + ch);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (ch + r < w) g[cb][r] = p.dout[p0 * w + ch + r];
+                    }
+                }
+            }
+        }
+        pf_static_for<0, NL>([&](auto lc) {
+            constexpr int l = NL - 1 - decltype(lc)::value;
+            const int ld = sh.wo16[l] + 4;
+            if (l == 0 && p.td > 0) {                     // dy[:, j] = sum_c dz1[c] W0[c][j]
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb)
+                    if (cb * 16 < sh.wo16[0])
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f4 wx = *reinterpret_cast<const f4*>(Wx + (cb * 16 + 4 * q + r) * 4);
+                            s0 = fmaf(g[cb][r], wx.x, s0); s1 = fmaf(g[cb][r], wx.y, s1); s2 = fmaf(g[cb][r], wx.z, s2);
+                        }
+                s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
+                s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+                if (q == 0 && valid && p.dy) {
+                    const float sv[3] = {s0, s1, s2};
+                    for (int j = 0; j < p.ldy; ++j) p.dy[p0 * p.ldy + j] = (j < p.td && j < 3) ? sv[j < 3 ? j : 0] : 0.f;
+                }
+            }
+            f4 nxt[8];
+#pragma unroll
+            for (int ub = 0; ub < 8; ++ub) {
+                nxt[ub] = pf_splat(0.f);
+                if (ub * 16 < sh.wi16[l]) {
+                    f4 acc = pf_splat(0.f);
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb)
+                        if (cb * 16 < sh.wo16[l])
+                            acc = mfma4(*reinterpret_cast<const f4*>(Wt[l] + (ub * 16 + col) * ld + cb * 16 + 4 * q), g[cb], acc);
+                    if (l > 0) {
+                        constexpr int lm = l > 0 ? l - 1 : 0;
+                        const f4 hv = *reinterpret_cast<const f4*>(p.h[lm] + pr * sh.wi[l] + ub * 16 + 4 * q);
+                        const float sl = p.slope[lm];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] *= hv[r] > 0.f ? 1.f : sl;
+                        if (valid) *reinterpret_cast<f4*>(p.dz[lm] + p0 * sh.wi[l] + ub * 16 + 4 * q) = acc;
+                        nxt[ub] = acc;
+                    } else if (p.dc) {                    // sum over the cdiv replicas of a conditioning row: adjacent columns
+#pragma unroll
+                        for (int m = 1; m < 16; m <<= 1)
+                            if (m < p.cdiv) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[r] += __shfl_xor(acc[r], m);
+                            }
+                        if (valid && (col % p.cdiv) == 0)
+                            *reinterpret_cast<f4*>(p.dc + (p0 / p.cdiv) * p.cc + ub * 16 + 4 * q) = acc;
+                    }
+                }
+            }
+#pragma unroll
+            for (int ub = 0; ub < 8; ++ub) g[ub] = nxt[ub];
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward, weights
+// layer l = blockIdx.y: part[chunk][off_l + c * wb16 + u] = sum over the chunk's rows of dz_{l+1}[row, c] * a_l[row, u];
+// a_0 = [c[row / cdiv] (cc) | y[row, :td]], a_l = h[l-1]; bias partial sums behind the layer's weight block.
+struct MlpDwLayout {
+    int off[3], boff[3], wb16[3], total;
+};
+__host__ __device__ inline MlpDwLayout mlp_dw_layout(const PfMlpTrain& p, const MlpShape& sh) {
+    MlpDwLayout L{};
+    int o = 0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        if (l < p.nl) {
+            L.wb16[l] = l == 0 ? up16(p.cc + p.td) : sh.wi16[l];
+            L.off[l] = o; o += sh.wo16[l] * L.wb16[l];
+            L.boff[l] = o; o += sh.wo16[l];
+        }
+    }
+    L.total = o;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p, float* part) {
+    extern __shared__ float lds[];
+    const MlpShape sh = mlp_shape(p);
+    const MlpDwLayout L = mlp_dw_layout(p, sh);
+    const int l = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    const int RA = sel3(sh.wo16, l), RB = sel3(L.wb16, l);
+    const int lda = RA + 16, ldb = RB + 16;
+    float* As = lds;
+    float* Bs = lds + MLP_EB * lda;
+    const float* asrc = l == p.nl - 1 ? p.dout : sel2(p.dz, l);
+    const float* hsrc = l > 0 ? sel2(p.h, l - 1) : nullptr;
+    const int wa = sel3(sh.wo, l), wil = sel3(sh.wi, l);
+    const int offl = sel3(L.off, l), boffl = sel3(L.boff, l);
+    const int NT = RB / 16, NRT = RA / 16;
+    int rts[MLP_SLOTS], cts[MLP_SLOTS];
+    bool val[MLP_SLOTS];
+#pragma unroll
+    for (int s = 0; s < MLP_SLOTS; ++s) {
+        const int id = wave + 4 * s;
+        val[s] = id < NRT * NT;
+        rts[s] = val[s] ? id / NT : 0; cts[s] = val[s] ? id % NT : 0;
+    }
+    f4 acc[MLP_SLOTS];
+#pragma unroll
+    for (int s = 0; s < MLP_SLOTS; ++s) acc[s] = pf_splat(0.f);
+    const long long r_lo = (long long)blockIdx.x * MLP_CHUNK, r_hi = min((long long)p.rows, r_lo + MLP_CHUNK);
+    float bsum = 0.f;
+    for (long long rb = r_lo; rb < r_hi; rb += MLP_EB) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < MLP_EB * RA; i += 256) {
+            const int el = i / RA, c = i % RA;
+            const long long r = rb + el;
+            As[el * lda + c] = (r < r_hi && c < wa) ? asrc[r * wa + c] : 0.f;
+        }
+        for (int i = threadIdx.x; i < MLP_EB * RB; i += 256) {
+            const int el = i / RB, u = i % RB;
+            const long long r = rb + el;
+            float v = 0.f;
+            if (r < r_hi) {
+                if (l > 0) { if (u < wil) v = hsrc[r * wil + u]; }
+                else if (u < p.cc) v = p.c[(r / p.cdiv) * p.cc + u];
+                else if (u < p.cc + p.td) v = p.y[r * p.ldy + u - p.cc];
+            }
+            Bs[el * ldb + u] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < RA)
+#pragma unroll 8
+            for (int el = 0; el < MLP_EB; ++el) bsum += As[el * lda + threadIdx.x];
+#pragma unroll
+        for (int ks = 0; ks < MLP_EB / 4; ++ks) {
+            const float* ar = As + (4 * ks + q) * lda + row;
+            const float* br = Bs + (4 * ks + q) * ldb + row;
+#pragma unroll
+            for (int s = 0; s < MLP_SLOTS; ++s)
+                if (val[s]) acc[s] = pf_mfma(ar[rts[s] * 16], br[cts[s] * 16], acc[s]);
+        }
+    }
+    float* out = part + (size_t)blockIdx.x * L.total;
+    if (threadIdx.x < RA) out[boffl + threadIdx.x] = bsum;
+#pragma unroll
+    for (int s = 0; s < MLP_SLOTS; ++s)
+        if (val[s])
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[offl + (rts[s] * 16 + 4 * q + r) * RB + cts[s] * 16 + row] = acc[s][r];
+}
+
+// partial sums -> dW[l] [wo, in_l] (column j < td of layer 0 sits behind the cc conditioning columns in the partials), db[l]
+__global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(PfMlpTrain p, const float* part, int nchunk) {
+    const MlpShape sh = mlp_shape(p);
+    const MlpDwLayout L = mlp_dw_layout(p, sh);
+    int cnt[3] = {0, 0, 0};
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+        if (l < p.nl) cnt[l] = sh.wo[l] * (sh.in[l] + 1);
+    const int total = cnt[0] + cnt[1] + cnt[2];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int l = i < cnt[0] ? 0 : (i < cnt[0] + cnt[1] ? 1 : 2);
+        const int rem = i - (l > 0 ? cnt[0] : 0) - (l > 1 ? cnt[1] : 0);
+        const int inl = sel3(sh.in, l);
+        const int c = rem / (inl + 1), j = rem % (inl + 1);
+        int src;
+        if (j == inl) src = sel3(L.boff, l) + c;
+        else {
+            const int u = l == 0 ? (j < p.td ? p.cc + j : j - p.td) : j;
+            src = sel3(L.off, l) + c * sel3(L.wb16, l) + u;
+        }
+        double s = 0.0;
+        for (int k = 0; k < nchunk; ++k) s += (double)part[(size_t)k * L.total + src];
+        float* db = sel3(p.db, l);
+        if (j == inl) { if (db) db[c] = (float)s; }
+        else sel3(p.dW, l)[(size_t)c * inl + j] = (float)s;
+    }
+}
+
+template <typename KERNEL>
+void allow_lds(KERNEL k, size_t bytes) {
+    if (bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int mlp_check(const PfMlpTrain* p) {
+    if (!p) return PF_ERR_NULL;
+    if (p->rows <= 0 || (p->nl != 2 && p->nl != 3) || p->td < 0 || p->td > 3 || p->cdiv < 1) return PF_ERR_SHAPE;
+    if (p->cc < 16 || p->cc > 128 || p->cc % 16 != 0) return PF_ERR_UNSUPPORTED;
+    if (p->cdiv != 1 && p->cdiv != 2 && p->cdiv != 4 && p->cdiv != 8 && p->cdiv != 16) return PF_ERR_UNSUPPORTED;
+    if (p->rows % p->cdiv != 0) return PF_ERR_SHAPE;
+    for (int l = 0; l < p->nl; ++l) {
+        if (p->width[l] < 1 || p->width[l] > 128) return PF_ERR_UNSUPPORTED;
+        if (l < p->nl - 1 && p->width[l] % 16 != 0) return PF_ERR_UNSUPPORTED;
+        if (!p->W[l]) return PF_ERR_NULL;
+    }
+    if (p->td > 0 && (!p->y || p->ldy < p->td)) return PF_ERR_NULL;
+    if (!p->c) return PF_ERR_NULL;
+    return PF_OK;
+}
+
+}  // namespace
+
+extern "C" long long pf_mlp_train_ws_floats(const PfMlpTrain* p) {
+    if (mlp_check(p) != PF_OK) return -1;
+    const MlpShape sh = mlp_shape(*p);
+    const MlpDwLayout L = mlp_dw_layout(*p, sh);
+    const long long nchunk = (p->rows + MLP_CHUNK - 1) / MLP_CHUNK;
+    return nchunk * L.total;
+}
+
+extern "C" int pf_mlp_train_fwd(const PfMlpTrain* p, void* stream) {
+    int st = mlp_check(p);
+    if (st) return st;
+    if (!p->out) return PF_ERR_NULL;
+    for (int l = 0; l < p->nl - 1; ++l)
+        if (!p->h[l]) return PF_ERR_NULL;
+    const MlpShape sh = mlp_shape(*p);
+    size_t lds = 0;
+    for (int l = 0; l < p->nl; ++l) lds += (size_t)sh.wo16[l] * (sh.wi16[l] + 4) + sh.wo16[l];
+    lds = (lds + (size_t)sh.wo16[0] * 4) * sizeof(float);
+    const int ntiles = (p->rows + 15) / 16;
+    const int grid = (ntiles + 3) / 4 < MLP_GRID ? (ntiles + 3) / 4 : MLP_GRID;
+    hipStream_t s = (hipStream_t)stream;
+    if (p->nl == 2) { allow_lds(mlp_fwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<2>, dim3(grid), dim3(256), lds, s, *p, ntiles); }
+    else { allow_lds(mlp_fwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<3>, dim3(grid), dim3(256), lds, s, *p, ntiles); }
+    return pf_last_launch_status();
+}
+
+extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
+    int st = mlp_check(p);
+    if (st) return st;
+    if (!p->dout || !p->ws) return PF_ERR_NULL;
+    for (int l = 0; l < p->nl - 1; ++l)
+        if (!p->h[l] || !p->dz[l]) return PF_ERR_NULL;
+    for (int l = 0; l < p->nl; ++l)
+        if (!p->dW[l]) return PF_ERR_NULL;
+    if (p->ws_floats < pf_mlp_train_ws_floats(p)) return PF_ERR_WORKSPACE;
+    const MlpShape sh = mlp_shape(*p);
+    const MlpDwLayout L = mlp_dw_layout(*p, sh);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        size_t lds = 0;
+        for (int l = 0; l < p->nl; ++l) lds += (size_t)sh.wi16[l] * (sh.wo16[l] + 4);
+        lds = (lds + (size_t)sh.wo16[0] * 4) * sizeof(float);
+        const int ntiles = (p->rows + 15) / 16;
+        const int grid = (ntiles + 3) / 4 < MLP_GRID ? (ntiles + 3) / 4 : MLP_GRID;
+        if (p->nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, *p, ntiles); }
+        else { allow_lds(mlp_bwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(grid), dim3(256), lds, s, *p, ntiles); }
+    }
+    const int nchunk = (p->rows + MLP_CHUNK - 1) / MLP_CHUNK;
+    {
+        int ramax = 0, rbmax = 0;
+        for (int l = 0; l < p->nl; ++l) { ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l]; }
+        const size_t lds = sizeof(float) * (size_t)MLP_EB * ((ramax + 16) + (rbmax + 16));
+        hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(256), lds, s, *p, p->ws);
+    }
+    int total = 0;
+    for (int l = 0; l < p->nl; ++l) total += sh.wo[l] * (sh.in[l] + 1);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, *p, p->ws, nchunk);
+    return pf_last_launch_status();
+}

@@ -687,6 +687,90 @@ class EdgeConvUnitFn(Function):
         return (dx, None, None, *dWs, *dbs, *dgs, *dbe)
 
 
+class MlpFn(Function):
+    """2- or 3-layer point-wise MLP (LinearA1D / FeatMergeUnit, interpflow.py:22-43, 251-258) on cat[y[:, :td], c[row // cdiv]]:
+    one launch forward, three backward (csrc/train_mlp.hip).  wb = W0, b0, W1, b1[, W2, b2] (None for a missing bias)."""
+
+    @staticmethod
+    def _desc(y, c, td, cdiv, slopes, Ws, bs):
+        d = _lib.PfMlpTrain()
+        nl = len(Ws)
+        cc = c.shape[-1]
+        rows = c.numel() // cc * cdiv
+        d.rows, d.nl, d.td, d.cc, d.cdiv = rows, nl, td, cc, cdiv
+        d.ldy = y.shape[-1] if y is not None else 0
+        for l in range(nl):
+            d.width[l] = Ws[l].shape[0]
+            d.W[l] = Ws[l].data_ptr()
+            d.b[l] = bs[l].data_ptr() if bs[l] is not None else None
+        for l in range(nl - 1):
+            d.slope[l] = slopes[l]
+        d.y = y.data_ptr() if y is not None else None
+        d.c = c.data_ptr()
+        return d, rows
+
+    @staticmethod
+    def forward(ctx, y, c, td, cdiv, slopes, *wb):
+        lib = _lib.load()
+        Ws = [w.contiguous() for w in wb[0::2]]
+        bs = [b.contiguous() if b is not None else None for b in wb[1::2]]
+        y = y.contiguous() if (y is not None and td > 0) else None
+        c = c.contiguous()
+        d, rows = MlpFn._desc(y, c, td, cdiv, slopes, Ws, bs)
+        f32 = dict(dtype=torch.float32, device=c.device)
+        hs = [torch.empty((rows, Ws[l].shape[0]), **f32) for l in range(len(Ws) - 1)]
+        out = torch.empty((rows, Ws[-1].shape[0]), **f32)
+        for l, h in enumerate(hs):
+            d.h[l] = h.data_ptr()
+        d.out = out.data_ptr()
+        _lib.check(lib.pf_mlp_train_fwd(ctypes.byref(d), _stream()), "pf_mlp_train_fwd")
+        ctx.cfg = (td, cdiv, slopes, len(Ws), [b is not None for b in bs], y is not None)
+        ctx.save_for_backward(c, *hs, *Ws, *(() if y is None else (y,)))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        td, cdiv, slopes, nl, has_b, has_y = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        c, hs, Ws = sv[0], sv[1:nl], sv[nl:2 * nl]
+        y = sv[2 * nl] if has_y else None
+        dout = dout.contiguous()
+        d, rows = MlpFn._desc(y, c, td, cdiv, slopes, Ws, [None] * nl)
+        f32 = dict(dtype=torch.float32, device=c.device)
+        dzs = [torch.empty_like(h) for h in hs]
+        dy = torch.empty_like(y) if (has_y and ctx.needs_input_grad[0]) else None
+        dc = torch.empty_like(c) if ctx.needs_input_grad[1] else None
+        dWs = [torch.empty_like(w) for w in Ws]
+        dbs = [torch.empty((w.shape[0],), **f32) if has_b[l] else None for l, w in enumerate(Ws)]
+        for l in range(nl - 1):
+            d.h[l], d.dz[l] = hs[l].data_ptr(), dzs[l].data_ptr()
+        d.dout = dout.data_ptr()
+        d.dy = dy.data_ptr() if dy is not None else None
+        d.dc = dc.data_ptr() if dc is not None else None
+        for l in range(nl):
+            d.dW[l] = dWs[l].data_ptr()
+            d.db[l] = dbs[l].data_ptr() if dbs[l] is not None else None
+        need = lib.pf_mlp_train_ws_floats(ctypes.byref(d))
+        if need < 0:
+            raise _lib.PuflowHipError("pf_mlp_train: unsupported shape")
+        ws = _ws(c.device, need)
+        d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
+        _lib.check(lib.pf_mlp_train_bwd(ctypes.byref(d), _stream()), "pf_mlp_train_bwd")
+        grads = []
+        for l in range(nl):
+            grads += [dWs[l], dbs[l]]
+        return (dy, dc, None, None, None, *grads)
+
+
+def mlp_fused(y, c: Tensor, td: int, cdiv: int, slopes, layers) -> Tensor:
+    """layers: nn.Linear modules.  -> [rows, out]"""
+    wb = []
+    for lin in layers:
+        wb += [lin.weight, lin.bias]
+    return MlpFn.apply(y, c, td, cdiv, tuple(slopes), *wb)
+
+
 _FUSED = os.environ.get("PF_TRAIN_FUSED", "1") != "0"
 
 
@@ -710,6 +794,12 @@ def cond_net(net, h: Tensor) -> Tensor:
     h = ActFn.apply(linear(h, L[0].weight), 0.01)
     h = ActFn.apply(linear(h, L[2].weight, L[2].bias), 0.01)
     return linear(h, L[4].weight, L[4].bias)
+
+
+def cond_net_fused(net, y, c: Tensor, td: int, cdiv: int) -> Tensor:
+    """LinearA1D on cat[y[..., :td], c[row // cdiv]] in one launch (csrc/train_mlp.hip); -> [rows, dout]."""
+    L = net.layers
+    return mlp_fused(y, c, td, cdiv, (0.01, 0.01), [L[0], L[2], L[4]])
 
 
 def cond_net_split(net, h1: Tensor, cpart: Tensor) -> Tensor:
@@ -744,7 +834,10 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     for i in range(net.num_blocks):
         h = edgeconv_train(net.feat_convs[i], h, idx16)
         m = net.merge_convs[i]
-        cs.append(linear(ActFn.apply(linear(h, m.conv1.weight, m.conv1.bias), 0.0), m.conv2.weight))
+        if _FUSED:
+            cs.append(mlp_fused(None, h, 0, 1, (0.0,), [m.conv1, m.conv2]).view(B, N, -1))
+        else:
+            cs.append(linear(ActFn.apply(linear(h, m.conv1.weight, m.conv1.bias), 0.0), m.conv2.weight))
 
     # ---- f + log-likelihood
     p = xyz
@@ -763,10 +856,15 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         y = linear(ActNormFn.apply(p, an.logs, an.bias, 0), W)     # einsum 'ij,bnj->bni' (permutate.py:118)
         ld = (torch.sum(an.logs) + torch.log(torch.abs(_det_inv3(W)[0]))) * N        # parameter-only scalars (permutate.py:119)
         td = 1 if i % 2 == 0 else 2
-        cparts.append(linear(cs[i], blk.coupling1.bias_net.layers[0].weight[:, td:]))
-        o = cond_net_split(blk.coupling1.bias_net, y[..., :td], cparts[i])
-        s = cond_net(blk.coupling2.scale_net, cs[i])
-        t = cond_net(blk.coupling2.bias_net, cs[i])
+        if _FUSED:
+            o = cond_net_fused(blk.coupling1.bias_net, y, cs[i], td, 1).view(B, N, -1)
+            s = cond_net_fused(blk.coupling2.scale_net, None, cs[i], 0, 1).view(B, N, -1)
+            t = cond_net_fused(blk.coupling2.bias_net, None, cs[i], 0, 1).view(B, N, -1)
+        else:
+            cparts.append(linear(cs[i], blk.coupling1.bias_net.layers[0].weight[:, td:]))
+            o = cond_net_split(blk.coupling1.bias_net, y[..., :td], cparts[i])
+            s = cond_net(blk.coupling2.scale_net, cs[i])
+            t = cond_net(blk.coupling2.bias_net, cs[i])
         st_nets.append((s, t))
         p = CoupleInjectFn.apply(y, o, s, t, td)
         ldj = ldj + ld - BatchSumFn.apply(s, 0)
@@ -791,7 +889,10 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         t = RepeatRowsFn.apply(st_nets[i][1], R)
         v = InjectInvFn.apply(u, s, t)
         td = 1 if i % 2 == 0 else 2
-        o = cond_net_split(blk.coupling1.bias_net, v[..., :td], RepeatRowsFn.apply(cparts[i], R))
+        if _FUSED:
+            o = cond_net_fused(blk.coupling1.bias_net, v, cs[i], td, R).view(B, N * R, -1)
+        else:
+            o = cond_net_split(blk.coupling1.bias_net, v[..., :td], RepeatRowsFn.apply(cparts[i], R))
         W = blk.permutate1.permutater.W
         u = linear(CoupleAddFn.apply(v, o, td), _det_inv3(W)[1])   # permutate.py:123-124 (3x3 inverse: parameter-only)
         u = ActNormFn.apply(u, blk.actnorm.logs, blk.actnorm.bias, 1)

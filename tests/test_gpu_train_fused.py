@@ -97,3 +97,72 @@ def test_edgeconv_unit_fused_matches_unfused(cin, odim, growth, K, pooling, B):
     for (m_f, v_f), (m_u, v_u) in zip(st_f, st_u):
         _close(m_f, m_u, "running_mean", 1e-5)
         _close(v_f, v_u, "running_var", 1e-5)
+
+
+@pytest.mark.parametrize("kind,cc,td,cdiv,rows", [
+    ("merge", 32, 0, 1, 1024), ("merge", 128, 0, 1, 8192), ("cond", 32, 0, 1, 1000 * 1), ("cond", 128, 0, 1, 8192),
+    ("cond", 64, 1, 1, 1024), ("cond", 128, 2, 1, 8192), ("cond", 128, 1, 4, 4096), ("cond", 32, 2, 4, 32768)])
+def test_mlp_fused_matches_unfused(kind, cc, td, cdiv, rows):
+    """csrc/train_mlp.hip against the un-fused composition of the same layers (linear / LeakyReLU kernels + torch cat and
+    repeat_interleave): output, dy, dc and every weight / bias gradient."""
+    from puflow_amd import train_ops
+    from puflow_amd.interpflow import _CondNet, _MergeParams
+    torch.manual_seed(cc + td + cdiv)
+    T = rows // cdiv
+    c0 = torch.randn(T, cc, device="cuda")
+    y0 = torch.randn(rows, 3, device="cuda")
+    if kind == "merge":
+        net = _MergeParams(cc, cc).cuda()
+        layers, slopes = [net.conv1, net.conv2], (0.0,)
+        dout_w = cc
+    else:
+        net = _CondNet(td + cc, 64, 3 - td if td else 3).cuda()
+        for q in net.parameters():
+            if float(q.abs().max()) == 0:
+                q.data.normal_(0, 0.1)
+        L = net.layers
+        layers, slopes = [L[0], L[2], L[4]], (0.01, 0.01)
+        dout_w = 3 - td if td else 3
+    wout = torch.randn(rows, dout_w, device="cuda")
+    # rows with a hidden pre-activation within 1e-5 of the kink get no output gradient: there the two paths may legitimately
+    # land on different sides of it (derivative 1 vs slope), which is not an error of either
+    with torch.no_grad():
+        x = c0.repeat_interleave(cdiv, dim=0) if cdiv > 1 else c0
+        if td:
+            x = torch.cat([y0[:, :td], x], dim=1)
+        z = x @ layers[0].weight.t() + (layers[0].bias if layers[0].bias is not None else 0)
+        near = z.abs().min(dim=1).values < 1e-5
+        if len(layers) == 3:
+            z2 = torch.nn.functional.leaky_relu(z, slopes[0]) @ layers[1].weight.t() + layers[1].bias
+            near |= z2.abs().min(dim=1).values < 1e-5
+        wout[near] = 0.0
+        assert int(near.sum()) < 0.01 * rows
+
+    def run(fused):
+        for q in net.parameters():
+            q.grad = None
+        c = c0.clone().requires_grad_(True)
+        y = y0.clone().requires_grad_(True)
+        if fused:
+            out = train_ops.mlp_fused(y if td else None, c, td, cdiv, slopes, layers)
+        else:
+            x = c.repeat_interleave(cdiv, dim=0) if cdiv > 1 else c
+            if td:
+                x = torch.cat([y[:, :td], x], dim=1)
+            if kind == "merge":
+                out = train_ops.linear(train_ops.ActFn.apply(train_ops.linear(x, net.conv1.weight, net.conv1.bias), 0.0),
+                                       net.conv2.weight)
+            else:
+                out = train_ops.cond_net(net, x)
+        (out * wout).sum().backward()
+        return (out.detach().clone(), c.grad.clone(), y.grad.clone() if td else None,
+                {n: q.grad.clone() for n, q in net.named_parameters()})
+
+    o_f, dc_f, dy_f, g_f = run(True)
+    o_u, dc_u, dy_u, g_u = run(False)
+    _close(o_f, o_u, "output", 1e-5)
+    _close(dc_f, dc_u, "dc", 1e-4)
+    if td:
+        _close(dy_f, dy_u, "dy", 1e-4)
+    for n in g_u:
+        _close(g_f[n], g_u[n], n, 1e-4)
