@@ -226,7 +226,7 @@ int pf_dist_feature(const float* xyz, const int* idx, int B, int N, int K, float
  * edge feature -> [Conv2d 1x1 + BatchNorm2d(batch statistics) + LeakyReLU, dense concatenation] x nconv -> conv_out ->
  * max over the K neighbours (pooling = 1) or the per-edge output (pooling = 0, the interpolation's feat_conv).
  * T = B*N points, E = T*K edges (point-major rows), GT = growth*nconv, S = GT + odim.  growth in {8,16,32}, nconv <= 8,
- * odim a multiple of 16 <= 128, GT <= 128, E a multiple of 16, pooling requires K == 16.
+ * odim a multiple of 16 <= 128, GT in {32, 64, 128}, E a multiple of 16, pooling requires K == 16.
  * The caller owns every buffer; those marked (kept) must survive from pf_ec_train_fwd to pf_ec_train_bwd. */
 typedef struct PfEcTrain {
     int B, N, K, C, growth, nconv, odim, pooling;

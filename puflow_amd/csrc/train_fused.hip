@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void ec_pq_bwd_kernel(EcPqBwdArgs a) {
 // u < GT.  K dimension = edges: both operands are channel-fast in memory, so a block of 32 edges is staged through LDS
 // (coalesced float4 loads, the activation / the pooled gradient formed once on the way) and the MFMA operands are read
 // from there edge-major.  blockIdx.y = 0: the conv_out rows; 1: the growth rows, whose output is block lower triangular
-// (layer t sees columns u < g t only) - the valid 16 x 16 tiles of either kind are dealt round-robin to the four waves.
+// (layer t sees columns u < g t only) - structurally empty 16 x 16 tiles are skipped.
 struct EcDwArgs {
     const float* dY; const float* Y; int ld;
     const float* aff;
@@ -487,7 +487,7 @@ struct EcDwArgs {
     float* part;
     float* bpart;                    // [nchunk][S]: column sums of dYfull over the chunk (the conv bias gradients)
 };
-constexpr int DW_EB = 32, DW_SLOTS = 16;
+constexpr int DW_EB = 32;
 
 __global__ __launch_bounds__(256) void ec_dw_kernel(EcDwArgs a) {
     extern __shared__ float lds[];
@@ -497,79 +497,109 @@ __global__ __launch_bounds__(256) void ec_dw_kernel(EcDwArgs a) {
     const int lda = RA + 16, ldb = a.GT + 16;
     float* As = lds;
     float* Bs = lds + DW_EB * lda;
+    // tile (rt, ct) of the output block -> wave: WC = min(4, NT) waves side by side along the columns, 4 / WC groups of
+    // them along the rows; a wave owns column tiles ct_j = w % WC + WC j (j < 2) and row tiles rt_s = w / WC + (4 / WC) s
+    // (s < 8): per K-step it reads <= 2 B values and <= 8 A values from LDS for <= 16 MFMAs
     const int NT = a.GT / 16, NRT = RA / 16;
-    int rts[DW_SLOTS], cts[DW_SLOTS];
-    bool val[DW_SLOTS];
+    const int WC = NT < 4 ? NT : 4, rstep = 4 / WC, rbase = wave / WC;
+    int ctj[2];
+    bool cval[2];
 #pragma unroll
-    for (int s = 0; s < DW_SLOTS; ++s) {
-        const int id = wave + 4 * s;
-        rts[s] = 0; cts[s] = 0; val[s] = false;
-        if (outrows) {
-            if (id < NRT * NT) { rts[s] = id / NT; cts[s] = id % NT; val[s] = true; }
-        } else {
-            int cum = 0;
-            for (int r = 0; r < NRT; ++r) {
-                const int last = r * 16 + 15;
-                const int n = ((last / a.g) * a.g + 15) / 16;                 // column tiles u < g * (layer of the tile's last row)
-                if (!val[s] && id < cum + n) { rts[s] = r; cts[s] = id - cum; val[s] = true; }
-                cum += n;
-            }
+    for (int jc = 0; jc < 2; ++jc) { ctj[jc] = wave % WC + WC * jc; cval[jc] = ctj[jc] < NT; }
+    bool val[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int rt = rbase + rstep * s;
+        int ntn = NT;
+        if (!outrows) {
+            const int last = rt * 16 + 15;
+            ntn = ((last / a.g) * a.g + 15) / 16;                 // column tiles u < g * (layer of the tile's last row)
         }
-    }
-    f4 acc[DW_SLOTS];
 #pragma unroll
-    for (int s = 0; s < DW_SLOTS; ++s) acc[s] = pf_splat(0.f);
-    const long long e_lo = (long long)blockIdx.x * a.chunk, e_hi = min(a.E, e_lo + a.chunk);
+        for (int jc = 0; jc < 2; ++jc) val[s][jc] = rt < NRT && cval[jc] && ctj[jc] < ntn;
+    }
+    f4 acc[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { acc[s][0] = pf_splat(0.f); acc[s][1] = pf_splat(0.f); }
+    const int e_lo = blockIdx.x * a.chunk, e_hi = min((int)a.E, e_lo + a.chunk);      // E < 2^30: 32-bit edge indices
     const int ra4 = RA / 4, gt4 = a.GT / 4;
     float bsum = 0.f;
-    for (long long eb = e_lo; eb < e_hi; eb += DW_EB) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < DW_EB * ra4; i += 256) {
-            const int el = i / ra4, c = (i % ra4) * 4;
-            const long long e = eb + el;
+    // float4 staging units, thread t owns units t, t + 256, ... (fixed (edge, column) per unit); the next block's units are
+    // fetched into registers while the current block is multiplied
+    constexpr int UN = 4;                                // DW_EB * 128 / 4 / 256
+    int elA[UN], cA[UN], elB[UN], cB[UN];
+#pragma unroll
+    for (int n = 0; n < UN; ++n) {
+        const int k = threadIdx.x + 256 * n;
+        elA[n] = k / ra4; cA[n] = (k - elA[n] * ra4) * 4;
+        elB[n] = k / gt4; cB[n] = (k - elB[n] * gt4) * 4;
+    }
+    f4 ra[UN], rbv[UN];
+    auto fetch = [&](int eb) {
+#pragma unroll
+        for (int n = 0; n < UN; ++n) {
             f4 v = pf_splat(0.f);
-            if (e < e_hi) {
-                if (!outrows) v = *reinterpret_cast<const f4*>(a.dY + e * a.ld + c);
+            const int e = eb + elA[n], c = cA[n];
+            if (elA[n] < DW_EB && e < e_hi) {
+                if (!outrows) v = *reinterpret_cast<const f4*>(a.dY + (size_t)e * a.ld + c);
                 else if (a.pooled) {
-                    const long long ii = e / a.K;
-                    const int k = (int)(e % a.K);
-                    const f4 dv = *reinterpret_cast<const f4*>(a.dh + ii * a.odim + c);
-                    const unsigned g4 = *reinterpret_cast<const unsigned*>(a.arg + ii * a.odim + c);
+                    const int ii = e >> 4, k = e & 15;                          // pooled units have K = 16
+                    const f4 dv = *reinterpret_cast<const f4*>(a.dh + (size_t)ii * a.odim + c);
+                    const unsigned g4 = *reinterpret_cast<const unsigned*>(a.arg + (size_t)ii * a.odim + c);
                     v.x = (int)(g4 & 255u) == k ? dv.x : 0.f; v.y = (int)((g4 >> 8) & 255u) == k ? dv.y : 0.f;
                     v.z = (int)((g4 >> 16) & 255u) == k ? dv.z : 0.f; v.w = (int)(g4 >> 24) == k ? dv.w : 0.f;
-                } else v = *reinterpret_cast<const f4*>(a.dyout + e * a.odim + c);
+                } else v = *reinterpret_cast<const f4*>(a.dyout + (size_t)e * a.odim + c);
             }
-            *reinterpret_cast<f4*>(As + el * lda + c) = v;
+            ra[n] = v;
         }
-        for (int i = threadIdx.x; i < DW_EB * gt4; i += 256) {
-            const int el = i / gt4, c = (i % gt4) * 4;
-            const long long e = eb + el;
+#pragma unroll
+        for (int n = 0; n < UN; ++n) {
             f4 v = pf_splat(0.f);
-            if (e < e_hi)
-                v = lrelu4(*reinterpret_cast<const f4*>(a.Y + e * a.ld + c) * *reinterpret_cast<const f4*>(a.aff + c) +
+            const int e = eb + elB[n], c = cB[n];
+            if (elB[n] < DW_EB && e < e_hi)
+                v = lrelu4(*reinterpret_cast<const f4*>(a.Y + (size_t)e * a.ld + c) * *reinterpret_cast<const f4*>(a.aff + c) +
                            *reinterpret_cast<const f4*>(a.aff + a.ld + c), a.slope);
-            *reinterpret_cast<f4*>(Bs + el * ldb + c) = v;
+            rbv[n] = v;
+        }
+    };
+    fetch(e_lo);
+    for (int eb = e_lo; eb < e_hi; eb += DW_EB) {
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < UN; ++n) {
+            if (elA[n] < DW_EB) *reinterpret_cast<f4*>(As + elA[n] * lda + cA[n]) = ra[n];
+            if (elB[n] < DW_EB) *reinterpret_cast<f4*>(Bs + elB[n] * ldb + cB[n]) = rbv[n];
         }
         __syncthreads();
+        if (eb + DW_EB < e_hi) fetch(eb + DW_EB);
         if (threadIdx.x < RA)
 #pragma unroll 8
             for (int el = 0; el < DW_EB; ++el) bsum += As[el * lda + threadIdx.x];
 #pragma unroll
         for (int ks = 0; ks < DW_EB / 4; ++ks) {
-            const float* ar = As + (4 * ks + q) * lda + row;
+            const float* ar = As + (4 * ks + q) * lda + row + rbase * 16;
             const float* br = Bs + (4 * ks + q) * ldb + row;
+            const float b0 = cval[0] ? br[ctj[0] * 16] : 0.f, b1 = cval[1] ? br[ctj[1] * 16] : 0.f;
 #pragma unroll
-            for (int s = 0; s < DW_SLOTS; ++s)
-                if (val[s]) acc[s] = pf_mfma(ar[rts[s] * 16], br[cts[s] * 16], acc[s]);
+            for (int s = 0; s < 8; ++s) {
+                if (val[s][0] || val[s][1]) {
+                    const float av = ar[rstep * s * 16];
+                    if (val[s][0]) acc[s][0] = pf_mfma(av, b0, acc[s][0]);
+                    if (val[s][1]) acc[s][1] = pf_mfma(av, b1, acc[s][1]);
+                }
+            }
         }
     }
     if (threadIdx.x < RA) a.bpart[(size_t)blockIdx.x * a.S + (outrows ? a.GT : 0) + threadIdx.x] = bsum;
     float* out = a.part + ((size_t)blockIdx.x * a.S + (outrows ? a.GT : 0)) * a.GT;
 #pragma unroll
-    for (int s = 0; s < DW_SLOTS; ++s)
-        if (val[s])
+    for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(size_t)(rts[s] * 16 + 4 * q + r) * a.GT + cts[s] * 16 + row] = acc[s][r];
+        for (int jc = 0; jc < 2; ++jc)
+            if (val[s][jc])
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(size_t)((rbase + rstep * s) * 16 + 4 * q + r) * a.GT + ctj[jc] * 16 + row] = acc[s][jc][r];
 }
 
 // ------------------------------------------------------------------------------------------------ weight folding / un-folding
@@ -648,7 +678,7 @@ int ec_dims(const PfEcTrain* p, Dims& d) {
     if (p->pooling && p->K != 16) return PF_ERR_UNSUPPORTED;
     d.T = p->B * p->N;
     d.GT = p->growth * p->nconv;
-    if (d.GT > 128 || d.GT % 16 != 0) return PF_ERR_UNSUPPORTED;
+    if (d.GT != 32 && d.GT != 64 && d.GT != 128) return PF_ERR_UNSUPPORTED;
     d.S = d.GT + p->odim;
     d.nconvs = p->nconv + 1;
     d.E = (long long)d.T * p->K;

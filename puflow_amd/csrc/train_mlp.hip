@@ -25,7 +25,8 @@
 namespace {
 
 constexpr int MLP_GRID = 512;
-constexpr int MLP_EB = 32, MLP_SLOTS = 9, MLP_CHUNK = 256;
+constexpr int MLP_EB = 32, MLP_SLOTS = 9;
+__host__ inline int mlp_chunk(int rows) { return rows > 16384 ? 256 : 128; }      // rows per split-K chunk (multiple of MLP_EB)
 
 __device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 c) {
     c = pf_mfma(a.x, b.x, c); c = pf_mfma(a.y, b.y, c); c = pf_mfma(a.z, b.z, c); c = pf_mfma(a.w, b.w, c);
@@ -74,8 +75,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p, int ntiles) 
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         const int ld = sh.wi16[l] + 4, off = l == 0 ? p.td : 0;
+        const int sft = 31 - __clz(sh.wi16[l]);                          // wi16 is a power of two (16 .. 128)
         for (int i = threadIdx.x; i < sh.wo16[l] * sh.wi16[l]; i += 256) {
-            const int c = i / sh.wi16[l], u = i % sh.wi16[l];
+            const int c = i >> sft, u = i & (sh.wi16[l] - 1);
             Wl[l][c * ld + u] = (c < sh.wo[l] && u < sh.wi[l]) ? p.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
         }
         for (int i = threadIdx.x; i < sh.wo16[l]; i += 256) bl[l][i] = (p.b[l] && i < sh.wo[l]) ? p.b[l][i] : 0.f;
@@ -87,11 +89,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p, int ntiles) 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const long long p0 = (long long)tile * 16 + col;
+        const int p0 = tile * 16 + col;
         const bool valid = p0 < p.rows;
-        const long long pr = valid ? p0 : p.rows - 1;
+        const int pr = valid ? p0 : p.rows - 1;
         f4 act[8];
-        const float* crow = p.c + (pr / p.cdiv) * p.cc;
+        const float* crow = p.c + (size_t)(pr / p.cdiv) * p.cc;
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) {
             act[cb] = pf_splat(0.f);
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p, int ntiles) 
         float xv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            if (j < p.td) xv[j] = p.y[pr * p.ldy + j];
+            if (j < p.td) xv[j] = p.y[(size_t)pr * p.ldy + j];
         pf_static_for<0, NL>([&](auto lc) {
             constexpr int l = decltype(lc)::value;
             const int ld = sh.wi16[l] + 4;
@@ -124,15 +126,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p, int ntiles) 
                     if (l < NL - 1) {
                         constexpr int lh = l < 2 ? l : 1;
                         acc = lrelu4(acc, p.slope[lh]);
-                        if (valid) *reinterpret_cast<f4*>(p.h[lh] + p0 * sh.wo[l] + ob * 16 + 4 * q) = acc;
+                        if (valid) *reinterpret_cast<f4*>(p.h[lh] + (size_t)p0 * sh.wo[l] + ob * 16 + 4 * q) = acc;
                         nxt[ob] = acc;
                     } else if (valid) {
-                        if ((sh.wo[l] & 15) == 0) *reinterpret_cast<f4*>(p.out + p0 * sh.wo[l] + ob * 16 + 4 * q) = acc;
+                        if ((sh.wo[l] & 15) == 0) *reinterpret_cast<f4*>(p.out + (size_t)p0 * sh.wo[l] + ob * 16 + 4 * q) = acc;
                         else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int ch = ob * 16 + 4 * q + r;
-                                if (ch < sh.wo[l]) p.out[p0 * sh.wo[l] + ch] = acc[r];
+                                if (ch < sh.wo[l]) p.out[(size_t)p0 * sh.wo[l] + ch] = acc[r];
                             }
                         }
                     }
@@ -157,8 +159,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p, int ntiles) 
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         const int ld = sh.wo16[l] + 4, off = l == 0 ? p.td : 0;
+        const int sft = 31 - __clz(sh.wi16[l]);                          // wi16 is a power of two (16 .. 128)
         for (int i = threadIdx.x; i < sh.wo16[l] * sh.wi16[l]; i += 256) {
-            const int c = i / sh.wi16[l], u = i % sh.wi16[l];                 // consecutive threads: consecutive u (contiguous in W)
+            const int c = i >> sft, u = i & (sh.wi16[l] - 1);                // consecutive threads: consecutive u (contiguous in W)
             Wt[l][u * ld + c] = (c < sh.wo[l] && u < sh.wi[l]) ? p.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
         }
     }
@@ -169,9 +172,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p, int ntiles) 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const long long p0 = (long long)tile * 16 + col;
+        const int p0 = tile * 16 + col;
         const bool valid = p0 < p.rows;
-        const long long pr = valid ? p0 : p.rows - 1;
+        const int pr = valid ? p0 : p.rows - 1;
         f4 g[8];
         {
             const int w = sh.wo[NL - 1];
@@ -181,11 +184,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p, int ntiles) 
                 if (cb * 16 < sh.wo16[NL - 1] && valid) {
                     const int ch = cb * 16 + 4 * q;
                     if ((w & 3) == 0) {
-                        if (ch < w) g[cb] = *reinterpret_cast<const f4*>(p.dout + p0 * w + ch);
+                        if (ch < w) g[cb] = *reinterpret_cast<const f4*>(p.dout + (size_t)p0 * w + ch);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (ch + r < w) g[cb][r] = p.dout[p0 * w + ch + r];
+                            if (ch + r < w) g[cb][r] = p.dout[(size_t)p0 * w + ch + r];
                     }
                 }
             }
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p, int ntiles) 
                 s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
                 if (q == 0 && valid && p.dy) {
                     const float sv[3] = {s0, s1, s2};
-                    for (int j = 0; j < p.ldy; ++j) p.dy[p0 * p.ldy + j] = (j < p.td && j < 3) ? sv[j < 3 ? j : 0] : 0.f;
+                    for (int j = 0; j < p.ldy; ++j) p.dy[(size_t)p0 * p.ldy + j] = (j < p.td && j < 3) ? sv[j < 3 ? j : 0] : 0.f;
                 }
             }
             f4 nxt[8];
@@ -223,11 +226,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p, int ntiles) 
                             acc = mfma4(*reinterpret_cast<const f4*>(Wt[l] + (ub * 16 + col) * ld + cb * 16 + 4 * q), g[cb], acc);
                     if (l > 0) {
                         constexpr int lm = l > 0 ? l - 1 : 0;
-                        const f4 hv = *reinterpret_cast<const f4*>(p.h[lm] + pr * sh.wi[l] + ub * 16 + 4 * q);
+                        const f4 hv = *reinterpret_cast<const f4*>(p.h[lm] + (size_t)pr * sh.wi[l] + ub * 16 + 4 * q);
                         const float sl = p.slope[lm];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[r] *= hv[r] > 0.f ? 1.f : sl;
-                        if (valid) *reinterpret_cast<f4*>(p.dz[lm] + p0 * sh.wi[l] + ub * 16 + 4 * q) = acc;
+                        if (valid) *reinterpret_cast<f4*>(p.dz[lm] + (size_t)p0 * sh.wi[l] + ub * 16 + 4 * q) = acc;
                         nxt[ub] = acc;
                     } else if (p.dc) {                    // sum over the cdiv replicas of a conditioning row: adjacent columns
 #pragma unroll
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p, int ntiles) 
                                 for (int r = 0; r < 4; ++r) acc[r] += __shfl_xor(acc[r], m);
                             }
                         if (valid && (col % p.cdiv) == 0)
-                            *reinterpret_cast<f4*>(p.dc + (p0 / p.cdiv) * p.cc + ub * 16 + 4 * q) = acc;
+                            *reinterpret_cast<f4*>(p.dc + (size_t)(p0 / p.cdiv) * p.cc + ub * 16 + 4 * q) = acc;
                     }
                 }
             }
@@ -268,7 +271,7 @@ __host__ __device__ inline MlpDwLayout mlp_dw_layout(const PfMlpTrain& p, const 
     return L;
 }
 
-__global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p, float* part) {
+__global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p, float* part, int chunk) {
     extern __shared__ float lds[];
     const MlpShape sh = mlp_shape(p);
     const MlpDwLayout L = mlp_dw_layout(p, sh);
@@ -294,27 +297,65 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p, float* part) 
     f4 acc[MLP_SLOTS];
 #pragma unroll
     for (int s = 0; s < MLP_SLOTS; ++s) acc[s] = pf_splat(0.f);
-    const long long r_lo = (long long)blockIdx.x * MLP_CHUNK, r_hi = min((long long)p.rows, r_lo + MLP_CHUNK);
+    const int r_lo = blockIdx.x * chunk, r_hi = min(p.rows, r_lo + chunk);
     float bsum = 0.f;
-    for (long long rb = r_lo; rb < r_hi; rb += MLP_EB) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < MLP_EB * RA; i += 256) {
-            const int el = i / RA, c = i % RA;
-            const long long r = rb + el;
-            As[el * lda + c] = (r < r_hi && c < wa) ? asrc[r * wa + c] : 0.f;
-        }
-        for (int i = threadIdx.x; i < MLP_EB * RB; i += 256) {
-            const int el = i / RB, u = i % RB;
-            const long long r = rb + el;
-            float v = 0.f;
-            if (r < r_hi) {
-                if (l > 0) { if (u < wil) v = hsrc[r * wil + u]; }
-                else if (u < p.cc) v = p.c[(r / p.cdiv) * p.cc + u];
-                else if (u < p.cc + p.td) v = p.y[r * p.ldy + u - p.cc];
+    // staging in float4 units, thread t owns units t, t + 256, ...: (row, column) of each unit fixed for the whole kernel.
+    // The next block's units are fetched into registers while the current block is multiplied (the products are short:
+    // without this every block paid a full memory latency between two barriers)
+    constexpr int UA = 4, UB = 5;                       // MLP_EB * 128 / 4 / 256, MLP_EB * 144 / 4 / 256 rounded up
+    const int ra4 = RA / 4, rb4 = RB / 4;
+    int elA[UA], cA[UA], elB[UB], cB[UB];
+#pragma unroll
+    for (int n = 0; n < UA; ++n) { const int k = threadIdx.x + 256 * n; elA[n] = k / ra4; cA[n] = (k - elA[n] * ra4) * 4; }
+#pragma unroll
+    for (int n = 0; n < UB; ++n) { const int k = threadIdx.x + 256 * n; elB[n] = k / rb4; cB[n] = (k - elB[n] * rb4) * 4; }
+    const int dsh = 31 - __clz(p.cdiv);                 // cdiv is a power of two
+    f4 ra[UA], rbv[UB];
+    auto fetch = [&](int rb) {
+#pragma unroll
+        for (int n = 0; n < UA; ++n) {
+            f4 v = pf_splat(0.f);
+            const int r = rb + elA[n], c = cA[n];
+            if (elA[n] < MLP_EB && r < r_hi && c < wa) {
+                if ((wa & 3) == 0) v = *reinterpret_cast<const f4*>(asrc + (size_t)r * wa + c);
+                else {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        if (c + w < wa) v[w] = asrc[(size_t)r * wa + c + w];
+                }
             }
-            Bs[el * ldb + u] = v;
+            ra[n] = v;
         }
+#pragma unroll
+        for (int n = 0; n < UB; ++n) {
+            f4 v = pf_splat(0.f);
+            const int r = rb + elB[n], u = cB[n];
+            if (elB[n] < MLP_EB && r < r_hi) {
+                if (l > 0) { if (u < wil) v = *reinterpret_cast<const f4*>(hsrc + (size_t)r * wil + u); }
+                else if (u + 3 < p.cc) v = *reinterpret_cast<const f4*>(p.c + (size_t)(r >> dsh) * p.cc + u);
+                else {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int uu = u + w;
+                        if (uu < p.cc) v[w] = p.c[(size_t)(r >> dsh) * p.cc + uu];
+                        else if (uu < p.cc + p.td) v[w] = p.y[(size_t)r * p.ldy + uu - p.cc];
+                    }
+                }
+            }
+            rbv[n] = v;
+        }
+    };
+    fetch(r_lo);
+    for (int rb = r_lo; rb < r_hi; rb += MLP_EB) {
         __syncthreads();
+#pragma unroll
+        for (int n = 0; n < UA; ++n)
+            if (elA[n] < MLP_EB) *reinterpret_cast<f4*>(As + elA[n] * lda + cA[n]) = ra[n];
+#pragma unroll
+        for (int n = 0; n < UB; ++n)
+            if (elB[n] < MLP_EB) *reinterpret_cast<f4*>(Bs + elB[n] * ldb + cB[n]) = rbv[n];
+        __syncthreads();
+        if (rb + MLP_EB < r_hi) fetch(rb + MLP_EB);
         if (threadIdx.x < RA)
 #pragma unroll 8
             for (int el = 0; el < MLP_EB; ++el) bsum += As[el * lda + threadIdx.x];
@@ -345,23 +386,32 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(PfMlpTrain p, const 
     for (int l = 0; l < 3; ++l)
         if (l < p.nl) cnt[l] = sh.wo[l] * (sh.in[l] + 1);
     const int total = cnt[0] + cnt[1] + cnt[2];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int l = i < cnt[0] ? 0 : (i < cnt[0] + cnt[1] ? 1 : 2);
+    __shared__ double shr[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    const bool ok = i < total;
+    int l = 0, c = 0, j = 0, inl = 1, src = 0;
+    if (ok) {
+        l = i < cnt[0] ? 0 : (i < cnt[0] + cnt[1] ? 1 : 2);
         const int rem = i - (l > 0 ? cnt[0] : 0) - (l > 1 ? cnt[1] : 0);
-        const int inl = sel3(sh.in, l);
-        const int c = rem / (inl + 1), j = rem % (inl + 1);
-        int src;
+        inl = sel3(sh.in, l);
+        c = rem / (inl + 1); j = rem % (inl + 1);
         if (j == inl) src = sel3(L.boff, l) + c;
         else {
             const int u = l == 0 ? (j < p.td ? p.cc + j : j - p.td) : j;
             src = sel3(L.off, l) + c * sel3(L.wb16, l) + u;
         }
-        double s = 0.0;
-        for (int k = 0; k < nchunk; ++k) s += (double)part[(size_t)k * L.total + src];
-        float* db = sel3(p.db, l);
-        if (j == inl) { if (db) db[c] = (float)s; }
-        else sel3(p.dW, l)[(size_t)c * inl + j] = (float)s;
     }
+    double s = 0.0;
+    if (ok)
+        for (int k = ty; k < nchunk; k += 4) s += (double)part[(size_t)k * L.total + src];
+    shr[ty][tx] = s;
+    __syncthreads();
+    if (ty != 0 || !ok) return;
+    s = (shr[0][tx] + shr[1][tx]) + (shr[2][tx] + shr[3][tx]);
+    float* db = sel3(p.db, l);
+    if (j == inl) { if (db) db[c] = (float)s; }
+    else sel3(p.dW, l)[(size_t)c * inl + j] = (float)s;
 }
 
 template <typename KERNEL>
@@ -373,12 +423,12 @@ void allow_lds(KERNEL k, size_t bytes) {
 int mlp_check(const PfMlpTrain* p) {
     if (!p) return PF_ERR_NULL;
     if (p->rows <= 0 || (p->nl != 2 && p->nl != 3) || p->td < 0 || p->td > 3 || p->cdiv < 1) return PF_ERR_SHAPE;
-    if (p->cc < 16 || p->cc > 128 || p->cc % 16 != 0) return PF_ERR_UNSUPPORTED;
+    if (p->cc != 16 && p->cc != 32 && p->cc != 64 && p->cc != 128) return PF_ERR_UNSUPPORTED;
     if (p->cdiv != 1 && p->cdiv != 2 && p->cdiv != 4 && p->cdiv != 8 && p->cdiv != 16) return PF_ERR_UNSUPPORTED;
     if (p->rows % p->cdiv != 0) return PF_ERR_SHAPE;
     for (int l = 0; l < p->nl; ++l) {
         if (p->width[l] < 1 || p->width[l] > 128) return PF_ERR_UNSUPPORTED;
-        if (l < p->nl - 1 && p->width[l] % 16 != 0) return PF_ERR_UNSUPPORTED;
+        if (l < p->nl - 1 && p->width[l] != 16 && p->width[l] != 32 && p->width[l] != 64 && p->width[l] != 128) return PF_ERR_UNSUPPORTED;
         if (!p->W[l]) return PF_ERR_NULL;
     }
     if (p->td > 0 && (!p->y || p->ldy < p->td)) return PF_ERR_NULL;
@@ -392,7 +442,8 @@ extern "C" long long pf_mlp_train_ws_floats(const PfMlpTrain* p) {
     if (mlp_check(p) != PF_OK) return -1;
     const MlpShape sh = mlp_shape(*p);
     const MlpDwLayout L = mlp_dw_layout(*p, sh);
-    const long long nchunk = (p->rows + MLP_CHUNK - 1) / MLP_CHUNK;
+    const int chunk = mlp_chunk(p->rows);
+    const long long nchunk = (p->rows + chunk - 1) / chunk;
     return nchunk * L.total;
 }
 
@@ -435,15 +486,16 @@ extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
         if (p->nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, *p, ntiles); }
         else { allow_lds(mlp_bwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(grid), dim3(256), lds, s, *p, ntiles); }
     }
-    const int nchunk = (p->rows + MLP_CHUNK - 1) / MLP_CHUNK;
+    const int chunk = mlp_chunk(p->rows);
+    const int nchunk = (p->rows + chunk - 1) / chunk;
     {
         int ramax = 0, rbmax = 0;
         for (int l = 0; l < p->nl; ++l) { ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l]; }
         const size_t lds = sizeof(float) * (size_t)MLP_EB * ((ramax + 16) + (rbmax + 16));
-        hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(256), lds, s, *p, p->ws);
+        hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(256), lds, s, *p, p->ws, chunk);
     }
     int total = 0;
     for (int l = 0; l < p->nl; ++l) total += sh.wo[l] * (sh.in[l] + 1);
-    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, *p, p->ws, nchunk);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, *p, p->ws, nchunk);
     return pf_last_launch_status();
 }
