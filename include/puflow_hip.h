@@ -286,6 +286,25 @@ long long pf_mlp_train_ws_floats(const PfMlpTrain* p);
 int pf_mlp_train_fwd(const PfMlpTrain* p, void* stream);
 int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream);
 
+/* ---- element-wise half of a flow block in the training step, fused per direction (csrc/train_flow.hip) ----
+ * Replaces ActNorm / InvertibleConv1x1-style 3x3 linear / AffineCoupling / reverse permutation / AffineInjector of
+ * modules/discrete/interpflow.py:46-82 (normalize.py:28-54, permutate.py:77-124, coupling.py:55-137) in train() mode.
+ * partial: >= 256 * 15 floats of scratch; counter: one 32-bit word, zero between calls. */
+int pf_flow_params_fwd(const float* W, const float* logs, float n, float* Winv, float* ld, void* stream);
+int pf_flow_params_bwd(const float* Winv, const float* dWinv, const float* dld, float n, float* dW, float* dlogs, void* stream);
+int pf_flow_affine_fwd(const float* x, const float* o, int td, const float* logs, const float* bias, const float* M, int inv,
+                       long long R, float* y, void* stream);
+int pf_flow_affine_bwd(const float* x, const float* o, int td, const float* logs, const float* bias, const float* M, int inv,
+                       long long R, const float* dy, float* dx, float* dobuf, float* dlogs, float* dbias, float* dM,
+                       float* partial, unsigned* counter, void* stream);
+int pf_couple_inject2_fwd(const float* y, const float* o, const float* s, const float* t, int td, long long R, float* out,
+                          float* ssum, float* partial, unsigned* counter, void* stream);
+int pf_couple_inject2_bwd(const float* out, const float* dout, const float* dssum, const float* s, int td, long long R,
+                          float* dy, float* dobuf, float* ds, float* dt, void* stream);
+int pf_inject_inv2_fwd(const float* u, const float* s, const float* t, int Rr, long long R, float* v, void* stream);
+int pf_inject_inv2_bwd(const float* u, const float* s, const float* dv, int Rr, long long R, float* du, float* ds, float* dt,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Patch pipeline around the network (modules/utils/patch.py:35-214), csrc/patch_ops.hip
  * ------------------------------------------------------------------------------------------- */

@@ -101,6 +101,17 @@ SIGNATURES = {
     "pf_dist_feature": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_fps": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_fps_scratch_layout": (c_int, [c_int, POINTER(c_longlong), POINTER(c_longlong)]),
+    "pf_flow_params_fwd": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "pf_flow_params_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "pf_flow_affine_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
+    "pf_flow_affine_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_couple_inject2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
+    "pf_couple_inject2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
+    "pf_inject_inv2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
+    "pf_inject_inv2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_mlp_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_mlp_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_mlp_train_bwd": (c_int, [c_void_p, c_void_p]),

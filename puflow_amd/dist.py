@@ -42,10 +42,14 @@ def gather_shards(x_local: torch.Tensor, total: int, rank: int, world: int) -> t
 class FlatGradBucket:
     """All gradients of a module as ONE flat fp32 buffer -> a single all-reduce per step.
 
-    as_views=True (what the trainer uses): every parameter's `.grad` IS a view of the flat buffer, autograd accumulates
-    into it in place, `flat.zero_()` replaces `optimizer.zero_grad()`, and the all-reduce needs no packing copies at all.
-    (Do not call `zero_grad(set_to_none=True)` on such parameters: it would drop the views; `rebind()` restores them.)
-    as_views=False keeps the round-1 behaviour: gradients are copied in and out around the collective."""
+    as_views=False (what the trainer uses): the step starts with `.grad = None` for every parameter, so autograd hands the
+    gradient tensors of the backward kernels over as they are (no zero-fill, no accumulate kernel per parameter - at
+    ~230 parameter tensors those were ~230 launches per step, more than the collective costs).  `all_reduce_mean()` packs
+    them with ONE concatenation into the flat buffer, all-reduces it, and re-points every `.grad` at its slice of the
+    buffer (views: no copy back), which is what clipping and Adam then read.
+    as_views=True: every `.grad` IS a view of the flat buffer from the start and autograd accumulates in place (zero the
+    buffer with `flat.zero_()`; do not call `zero_grad(set_to_none=True)`, `rebind()` restores the views): no packing
+    copy at all, but one accumulate launch per parameter."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], as_views: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -74,36 +78,33 @@ class FlatGradBucket:
             o += p.numel()
         return True
 
+    def drop_grads(self) -> None:
+        """Start of a step in the packing mode: autograd will install fresh gradient tensors."""
+        for p in self.params:
+            p.grad = None
+
+    def pack(self) -> None:
+        """flat <- concatenation of all gradients (missing ones count as zero), ONE launch; `.grad` <- views of flat."""
+        torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params], out=self.flat)
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[o:o + n].view_as(p)
+            o += n
+
     def all_reduce_mean(self) -> None:
         """grad <- mean over ranks of grad (missing grads count as zero)."""
         multi = dist.is_initialized() and dist.get_world_size() > 1
         if self.as_views:
             if not self.views_intact():
                 self.rebind()
-            if multi:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-                self.flat.div_(dist.get_world_size())
-            return
-        o = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[o:o + n].zero_()
-            else:
-                self.flat[o:o + n].copy_(p.grad.reshape(-1))
-            o += n
+        else:
+            if not multi:
+                return                                  # single process: the gradients stay where autograd put them
+            self.pack()
         if multi:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
-        o = 0
-        for p in self.params:
-            n = p.numel()
-            g = self.flat[o:o + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            o += n
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:

@@ -5,10 +5,12 @@ is bound by host launch latency, not by the GPU.  The shapes of a step are stati
 whole step is captured once and replayed:
 
   single process : ONE graph = zero grads -> forward -> loss -> backward -> clip -> Adam
-  world size > 1 : graph A = zero grads -> forward -> loss -> backward   (gradients land in ONE flat buffer: every
-                              parameter's .grad is a view of it, so the all-reduce needs no packing copies)
+  world size > 1 : graph A = forward -> loss -> backward -> ONE concatenation of all gradients into a flat buffer
                    eager    = one RCCL all-reduce of the flat 806 103-float buffer, / world size
-                   graph B = clip -> Adam
+                   graph B = clip -> Adam   (every .grad is a view of the flat buffer by then)
+The step starts from `.grad = None`: autograd installs the backward kernels' output tensors as the gradients (inside a
+capture they live in the graph's pool, at fixed addresses), so there is neither a zero-fill nor an accumulate launch per
+parameter.
 
 Preconditions, all checked: the module is in train() mode with ActNorm initialised (the data-dependent first-batch init is a
 host-side branch - run one eager `train_step` first, `GraphedTrainStep` does it for you when needed), SyncBN off (its
@@ -50,8 +52,7 @@ class GraphedTrainStep:
         make_capturable(optimizer, dev)
         self.static = self._clone_batch(batch)
         module.train()
-        # gradients as views of one flat buffer (zeroed inside the graph; autograd accumulates into the views in place)
-        self.bucket = FlatGradBucket(module.parameters(), as_views=True)
+        self.bucket = FlatGradBucket(module.parameters())
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -93,9 +94,11 @@ class GraphedTrainStep:
                     d.copy_(v)
 
     def _fwd_bwd(self) -> Tensor:
-        self.bucket.flat.zero_()
+        self.bucket.drop_grads()
         loss = self.module.training_step(self.static, 0)
         loss.backward()
+        if self.world > 1:
+            self.bucket.pack()
         return loss.detach()
 
     def _reduce(self) -> None:

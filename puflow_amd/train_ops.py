@@ -687,6 +687,154 @@ class EdgeConvUnitFn(Function):
         return (dx, None, None, *dWs, *dbs, *dgs, *dbe)
 
 
+_COUNTER = {}
+
+
+def _counter(dev) -> Tensor:
+    """One zero-initialised 32-bit word per (device, stream): the arrival counter of the in-kernel grid reductions (reset by
+    the workgroup that uses it last)."""
+    key = (dev, _stream())
+    t = _COUNTER.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=dev)
+        _COUNTER[key] = t
+    return t
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class FlowParamsFn(Function):
+    """W [3,3], logs [...,3] -> (W^-1 [3,3], ld [1] = (sum(logs) + log|det W|) n): the parameter-only scalars of a flow block
+    (normalize.py:34-36, permutate.py:118-124) in one one-thread kernel instead of ~25 tiny torch launches."""
+
+    @staticmethod
+    def forward(ctx, W, logs, n):
+        lib = _lib.load()
+        W, lg = W.contiguous(), logs.reshape(3).contiguous()
+        Winv = torch.empty_like(W)
+        ld = torch.empty((1,), dtype=torch.float32, device=W.device)
+        _lib.check(lib.pf_flow_params_fwd(W.data_ptr(), lg.data_ptr(), float(n), Winv.data_ptr(), ld.data_ptr(), _stream()),
+                   "pf_flow_params_fwd")
+        ctx.save_for_backward(Winv)
+        ctx.n, ctx.lshape = float(n), logs.shape
+        return Winv, ld
+
+    @staticmethod
+    def backward(ctx, dWinv, dld):
+        lib = _lib.load()
+        (Winv,) = ctx.saved_tensors
+        dW = torch.empty_like(Winv)
+        dlogs = torch.empty((3,), dtype=torch.float32, device=Winv.device)
+        dWinv = dWinv.contiguous() if dWinv is not None else None
+        dld = dld.contiguous() if dld is not None else None
+        _lib.check(lib.pf_flow_params_bwd(Winv.data_ptr(), _ptr(dWinv), _ptr(dld), ctx.n, dW.data_ptr(), dlogs.data_ptr(),
+                                          _stream()), "pf_flow_params_bwd")
+        return dW, dlogs.view(ctx.lshape), None
+
+
+class FlowAffineFn(Function):
+    """inv=0: y = M (x e^logs + bias)  (ActNorm, then the 3x3 linear);  inv=1: y = (M [x_head, x_tail + o] - bias) e^-logs
+    (coupling shift, inverse linear, inverse ActNorm).  One launch each way; the 15 parameter-gradient sums are reduced
+    inside the backward kernel (csrc/train_flow.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, o, td, logs, bias, M, inv):
+        lib = _lib.load()
+        x = x.contiguous()
+        o = o.contiguous() if o is not None else None
+        lg, bs, M = logs.reshape(3).contiguous(), bias.reshape(3).contiguous(), M.contiguous()
+        R = x.numel() // 3
+        y = torch.empty_like(x)
+        _lib.check(lib.pf_flow_affine_fwd(x.data_ptr(), _ptr(o), td, lg.data_ptr(), bs.data_ptr(), M.data_ptr(), inv, R,
+                                          y.data_ptr(), _stream()), "pf_flow_affine_fwd")
+        ctx.save_for_backward(x, lg, bs, M, *(() if o is None else (o,)))
+        ctx.cfg = (td, inv, logs.shape, o is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        td, inv, pshape, has_o = ctx.cfg
+        sv = ctx.saved_tensors
+        x, lg, bs, M = sv[:4]
+        o = sv[4] if has_o else None
+        R = x.numel() // 3
+        dy = dy.contiguous()
+        dev = x.device
+        dx = torch.empty_like(x)
+        do = torch.empty_like(o) if has_o else None
+        dl, db = torch.empty((3,), dtype=torch.float32, device=dev), torch.empty((3,), dtype=torch.float32, device=dev)
+        dM = torch.empty_like(M)
+        ws = _ws(dev, 256 * 16)
+        _lib.check(lib.pf_flow_affine_bwd(x.data_ptr(), _ptr(o), td, lg.data_ptr(), bs.data_ptr(), M.data_ptr(), inv, R,
+                                          dy.data_ptr(), dx.data_ptr(), _ptr(do), dl.data_ptr(), db.data_ptr(), dM.data_ptr(),
+                                          ws.data_ptr(), _counter(dev).data_ptr(), _stream()), "pf_flow_affine_bwd")
+        return dx, do, None, dl.view(pshape), db.view(pshape), dM, None
+
+
+class CoupleInject2Fn(Function):
+    """CoupleInjectFn that also returns sum(s) (the injector's log-det term, coupling.py:137) from the same launch."""
+
+    @staticmethod
+    def forward(ctx, y, o, s, t, td):
+        lib = _lib.load()
+        y, o, s, t = y.contiguous(), o.contiguous(), s.contiguous(), t.contiguous()
+        R = y.numel() // 3
+        dev = y.device
+        out = torch.empty_like(y)
+        ssum = torch.empty((1,), dtype=torch.float32, device=dev)
+        ws = _ws(dev, 256 * 16)
+        _lib.check(lib.pf_couple_inject2_fwd(y.data_ptr(), o.data_ptr(), s.data_ptr(), t.data_ptr(), td, R, out.data_ptr(),
+                                             ssum.data_ptr(), ws.data_ptr(), _counter(dev).data_ptr(), _stream()),
+                   "pf_couple_inject2_fwd")
+        ctx.save_for_backward(out, s)
+        ctx.td, ctx.oshape = td, o.shape
+        return out, ssum
+
+    @staticmethod
+    def backward(ctx, dout, dssum):
+        lib = _lib.load()
+        out, s = ctx.saved_tensors
+        R = out.numel() // 3
+        dout = dout.contiguous()
+        dssum = dssum.contiguous() if dssum is not None else None
+        dy, ds, dt = torch.empty_like(out), torch.empty_like(s), torch.empty_like(s)
+        do = torch.empty(ctx.oshape, dtype=torch.float32, device=out.device)
+        _lib.check(lib.pf_couple_inject2_bwd(out.data_ptr(), dout.data_ptr(), _ptr(dssum), s.data_ptr(), ctx.td, R, dy.data_ptr(),
+                                             do.data_ptr(), ds.data_ptr(), dt.data_ptr(), _stream()), "pf_couple_inject2_bwd")
+        return dy, do, ds, dt, None
+
+
+class InjectInv2Fn(Function):
+    """v = reverse(u e^s + t) with s, t [T,3] of the ORIGINAL points and u [T*R,3]: the repeat_interleave of the reference
+    (interpflow.py:319) happens in the index, its backward (sum over the R rows) in the same kernel."""
+
+    @staticmethod
+    def forward(ctx, u, s, t, Rr):
+        lib = _lib.load()
+        u, s, t = u.contiguous(), s.contiguous(), t.contiguous()
+        R = u.numel() // 3
+        v = torch.empty_like(u)
+        _lib.check(lib.pf_inject_inv2_fwd(u.data_ptr(), s.data_ptr(), t.data_ptr(), Rr, R, v.data_ptr(), _stream()),
+                   "pf_inject_inv2_fwd")
+        ctx.save_for_backward(u, s)
+        ctx.Rr = Rr
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        lib = _lib.load()
+        u, s = ctx.saved_tensors
+        R = u.numel() // 3
+        dv = dv.contiguous()
+        du, ds, dt = torch.empty_like(u), torch.empty_like(s), torch.empty_like(s)
+        _lib.check(lib.pf_inject_inv2_bwd(u.data_ptr(), s.data_ptr(), dv.data_ptr(), ctx.Rr, R, du.data_ptr(), ds.data_ptr(),
+                                          dt.data_ptr(), _stream()), "pf_inject_inv2_bwd")
+        return du, ds, dt, None
+
+
 class MlpFn(Function):
     """2- or 3-layer point-wise MLP (LinearA1D / FeatMergeUnit, interpflow.py:22-43, 251-258) on cat[y[:, :td], c[row // cdiv]]:
     one launch forward, three backward (csrc/train_mlp.hip).  wb = W0, b0, W1, b1[, W2, b2] (None for a missing bias)."""
@@ -844,6 +992,9 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     ldj = torch.zeros(B, device=xyz.device)
     st_nets: List[Tuple[Tensor, Tensor]] = []                      # injector (s, t) per block: functions of cs[i] only, shared by f and g
     cparts: List[Tensor] = []                                      # c-columns of coupling1's first layer, likewise
+    winvs: List[Tensor] = []
+    lds: List[Tensor] = []
+    ssums: List[Tensor] = []
     for i in range(net.num_blocks):
         blk = net.flow_blocks[i]
         an = blk.actnorm
@@ -853,23 +1004,35 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
                 an.logs.data.copy_(-torch.log(torch.std(p.detach(), dim=(0, 1), keepdim=True) + 1e-6))
                 an.is_inited = True
         W = blk.permutate1.permutater.W
-        y = linear(ActNormFn.apply(p, an.logs, an.bias, 0), W)     # einsum 'ij,bnj->bni' (permutate.py:118)
-        ld = (torch.sum(an.logs) + torch.log(torch.abs(_det_inv3(W)[0]))) * N        # parameter-only scalars (permutate.py:119)
         td = 1 if i % 2 == 0 else 2
         if _FUSED:
+            Winv, ld = FlowParamsFn.apply(W, an.logs, float(N))    # W^-1 and (sum(logs) + log|det W|) N (permutate.py:119)
+            winvs.append(Winv)
+            lds.append(ld)
+            y = FlowAffineFn.apply(p, None, 0, an.logs, an.bias, W, 0)    # ActNorm + einsum 'ij,bnj->bni' (permutate.py:118)
             o = cond_net_fused(blk.coupling1.bias_net, y, cs[i], td, 1).view(B, N, -1)
             s = cond_net_fused(blk.coupling2.scale_net, None, cs[i], 0, 1).view(B, N, -1)
             t = cond_net_fused(blk.coupling2.bias_net, None, cs[i], 0, 1).view(B, N, -1)
-        else:
-            cparts.append(linear(cs[i], blk.coupling1.bias_net.layers[0].weight[:, td:]))
-            o = cond_net_split(blk.coupling1.bias_net, y[..., :td], cparts[i])
-            s = cond_net(blk.coupling2.scale_net, cs[i])
-            t = cond_net(blk.coupling2.bias_net, cs[i])
+            st_nets.append((s, t))
+            p, ssum = CoupleInject2Fn.apply(y, o, s, t, td)
+            ssums.append(ssum)
+            continue
+        y = linear(ActNormFn.apply(p, an.logs, an.bias, 0), W)     # einsum 'ij,bnj->bni' (permutate.py:118)
+        ld = (torch.sum(an.logs) + torch.log(torch.abs(_det_inv3(W)[0]))) * N        # parameter-only scalars (permutate.py:119)
+        cparts.append(linear(cs[i], blk.coupling1.bias_net.layers[0].weight[:, td:]))
+        o = cond_net_split(blk.coupling1.bias_net, y[..., :td], cparts[i])
+        s = cond_net(blk.coupling2.scale_net, cs[i])
+        t = cond_net(blk.coupling2.bias_net, cs[i])
         st_nets.append((s, t))
         p = CoupleInjectFn.apply(y, o, s, t, td)
         ldj = ldj + ld - BatchSumFn.apply(s, 0)
     z = p
-    logp = -torch.mean(BatchSumFn.apply(z, 1) + ldj)
+    if _FUSED:
+        # -mean_b(gauss_b + sum_i (ld_i - sum(s_i)[b])) with the batch mean taken once, over scalars: the same number as the
+        # reference's per-sample bookkeeping (interpflow.py:327-337, probs.py:73-93)
+        logp = -(BatchSumFn.apply(z, 1).mean() + torch.cat(lds).sum() - torch.cat(ssums).sum() / B)
+    else:
+        logp = -torch.mean(BatchSumFn.apply(z, 1) + ldj)
 
     # ---- interpolation
     ip = net.interp
@@ -885,14 +1048,16 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     # ---- g (exact inverse); injector nets are evaluated per ORIGINAL point and replicated
     for i in reversed(range(net.num_blocks)):
         blk = net.flow_blocks[i]
+        td = 1 if i % 2 == 0 else 2
+        if _FUSED:
+            v = InjectInv2Fn.apply(u, st_nets[i][0], st_nets[i][1], R)        # s, t of the original point: row // R
+            o = cond_net_fused(blk.coupling1.bias_net, v, cs[i], td, R).view(B, N * R, -1)
+            u = FlowAffineFn.apply(v, o, td, blk.actnorm.logs, blk.actnorm.bias, winvs[i], 1)    # permutate.py:123-124
+            continue
         s = RepeatRowsFn.apply(st_nets[i][0], R)                   # same nets, same input as in f: evaluated once (autograd sums both uses)
         t = RepeatRowsFn.apply(st_nets[i][1], R)
         v = InjectInvFn.apply(u, s, t)
-        td = 1 if i % 2 == 0 else 2
-        if _FUSED:
-            o = cond_net_fused(blk.coupling1.bias_net, v, cs[i], td, R).view(B, N * R, -1)
-        else:
-            o = cond_net_split(blk.coupling1.bias_net, v[..., :td], RepeatRowsFn.apply(cparts[i], R))
+        o = cond_net_split(blk.coupling1.bias_net, v[..., :td], RepeatRowsFn.apply(cparts[i], R))
         W = blk.permutate1.permutater.W
         u = linear(CoupleAddFn.apply(v, o, td), _det_inv3(W)[1])   # permutate.py:123-124 (3x3 inverse: parameter-only)
         u = ActNormFn.apply(u, blk.actnorm.logs, blk.actnorm.bias, 1)
