@@ -15,6 +15,7 @@
 // Arithmetic follows the reference text: value = float((3.0 - (double)sqrtf(d2)) - (double)price)
 // (the literal 3.0 in cu:146 is a double), d2 unfused fp32.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "pf_api_internal.h"
 
 namespace {
@@ -165,6 +166,149 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(EmdArgs a) {
     }
 }
 
+// ---- the same auction with G workgroups per sample ------------------------------------------------------------------
+// One workgroup per sample leaves 224 of 256 CUs idle at the training batch (32 x 1024 points), and while the prediction is
+// still far from the target most points stay unassigned for all 50 iterations: ~30 000 point-bids x 1024 objects per sample,
+// 3 ms on one CU.  Here a sample's points are split over G workgroups (consecutive block indices); ground truth and prices
+// are copied to LDS per iteration, bids of a workgroup's own points stay in its LDS, and only the per-object state that
+// other workgroups need (maximum increment, winner, owner, price, assignment) is global, accessed with agent-scope atomics.
+// Three grid barriers per iteration (after bidding, after the winner vote, after assignment): an arrival counter per sample,
+// thread 0 spins on it.  The per-object vote arrays are double-buffered by iteration parity, so an iteration's entries are
+// cleared during the NEXT iteration (by the workgroup that wrote them) instead of behind a fourth barrier.
+// Same arithmetic and tie rules as the single-workgroup kernel: identical assignment.
+// Progress: a sample's workgroups have consecutive indices and B * G <= the number of CUs, so they are co-resident; the spin
+// is bounded anyway (on timeout the sample's distances are written as NaN and the grid drains).
+constexpr int EMDC_NMAX = 2048;
+struct EmdCoopArgs {
+    const float* x; const float* y;
+    float* dist; int* assignment; int* assignment_inv; float* price;
+    unsigned* mb0; unsigned* mb1; int* mi0; int* mi1;     // [B,n] each: maximum increment bits / winner index, per parity
+    unsigned* sync;                                        // [B,n] zeroed by the host: [0] arrivals, [1],[2] unassigned count per parity
+    int n, iters, G;
+    float eps;
+};
+template <typename T>
+__device__ __forceinline__ T ald(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void ast(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
+    __shared__ float sy[3 * EMDC_NMAX];
+    __shared__ float sprice[EMDC_NMAX];
+    __shared__ int ulist[EMDC_NMAX], sbid[EMDC_NMAX], pbid[EMDC_NMAX];
+    __shared__ float sinc[EMDC_NMAX];
+    __shared__ int ucount, dead;
+    const int G = a.G, b = blockIdx.x / G, w = blockIdx.x % G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n;
+    const size_t o0 = (size_t)b * n;
+    const float* x = a.x + o0 * 3;
+    int* assignment = a.assignment + o0;
+    int* ainv = a.assignment_inv + o0;
+    float* price = a.price + o0;
+    unsigned* cnt = a.sync + o0;
+    const int i0 = (int)((long long)w * n / G), i1 = (int)((long long)(w + 1) * n / G);
+    unsigned nb = 0;
+    if (tid == 0) dead = 0;
+    auto barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ++nb;
+        if (tid == 0) {
+            atomicAdd(cnt, 1u);
+            const unsigned target = nb * (unsigned)G;
+            int budget = 1 << 22;
+            while (ald(cnt) < target && --budget > 0) __builtin_amdgcn_s_sleep(2);
+            if (budget <= 0) dead = 1;
+        }
+        __syncthreads();
+    };
+    for (int i = tid; i < 3 * n; i += EMD_THREADS) sy[i] = a.y[o0 * 3 + i];
+    for (int i = i0 + tid; i < i1; i += EMD_THREADS) {
+        ast(a.mb0 + o0 + i, 0u); ast(a.mb1 + o0 + i, 0u); ast(a.mi0 + o0 + i, -1); ast(a.mi1 + o0 + i, -1);
+    }
+    barrier();
+    int pU = 0;
+    for (int it = 0; it < a.iters && !dead; ++it) {
+        const bool last = it == a.iters - 1;
+        const int par = it & 1;
+        unsigned* mb = (par ? a.mb1 : a.mb0) + o0;
+        int* mi = (par ? a.mi1 : a.mi0) + o0;
+        unsigned* mbo = (par ? a.mb0 : a.mb1) + o0;
+        int* mio = (par ? a.mi0 : a.mi1) + o0;
+        for (int i = tid; i < n; i += EMD_THREADS) sprice[i] = ald(price + i);
+        if (tid == 0) ucount = 0;
+        __syncthreads();
+        for (int i = i0 + tid; i < i1; i += EMD_THREADS)
+            if (ald(assignment + i) == -1) ulist[atomicAdd(&ucount, 1)] = i;
+        __syncthreads();
+        const int U = ucount;
+        if (tid == 0 && U > 0) atomicAdd(cnt + 1 + par, (unsigned)U);
+        // ---- bid: one wave per unassigned point of this workgroup's slice
+        for (int u = wave; u < U; u += EMD_THREADS / 64) {
+            const int i = ulist[u];
+            const float x1 = x[i * 3 + 0], y1 = x[i * 3 + 1], z1 = x[i * 3 + 2];
+            float tbest = -1e9f, tbetter = -1e9f;
+            int tidx = 0x7fffffff;
+            for (int k = lane; k < n; k += 64) {
+                const float dx = __fsub_rn(sy[k * 3 + 0], x1), dy = __fsub_rn(sy[k * 3 + 1], y1),
+                            dz = __fsub_rn(sy[k * 3 + 2], z1);
+                const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                const float v = (float)((3.0 - (double)sqrtf(d2)) - (double)sprice[k]);
+                if (v > tbest) { tbetter = tbest; tbest = v; tidx = k; }
+                else if (v > tbetter) tbetter = v;
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1)
+                tri_merge(tbest, tbetter, tidx, __shfl_xor(tbest, m), __shfl_xor(tbetter, m), __shfl_xor(tidx, m));
+            if (lane == 0) {
+                if ((unsigned)tidx >= (unsigned)n) { tidx = i; tbest = tbetter = 0.f; }      // NaN / inf row: see the kernel above
+                const float inc = __fadd_rn(__fsub_rn(tbest, tbetter), a.eps);
+                sbid[u] = tidx;
+                sinc[u] = inc;
+                atomicMax(mb + tidx, __float_as_uint(inc));
+            }
+        }
+        barrier();
+        if (ald(cnt + 1 + par) == 0u) break;                     // nothing left to assign in the whole sample (uniform)
+        // ---- winner of each object: largest index among the bidders holding the exact maximum increment
+        for (int u = tid; u < U; u += EMD_THREADS) {
+            const int o = sbid[u];
+            if (__float_as_uint(sinc[u]) == ald(mb + o)) atomicMax(mi + o, ulist[u]);
+        }
+        barrier();
+        // ---- assign; clear the OTHER parity's entries this workgroup wrote in the previous iteration
+        for (int u = tid; u < U; u += EMD_THREADS) {
+            const int i = ulist[u], o = sbid[u];
+            if (last || ald(mi + o) == i) {
+                if (!last) {
+                    const int prev = ald(ainv + o);
+                    if (prev != -1) ast(assignment + prev, -1);
+                }
+                ast(ainv + o, i);
+                ast(assignment + i, o);
+                atomicAdd(price + o, sinc[u]);
+            }
+        }
+        for (int u = tid; u < pU; u += EMD_THREADS) { ast(mbo + pbid[u], 0u); ast(mio + pbid[u], -1); }
+        if (w == 0 && tid == 0) ast(cnt + 1 + (1 - par), 0u);
+        for (int u = tid; u < U; u += EMD_THREADS) pbid[u] = sbid[u];
+        pU = U;
+        barrier();
+    }
+    // ---- squared distance to the assigned ground-truth point (cu:217-226)
+    for (int i = i0 + tid; i < i1; i += EMD_THREADS) {
+        const int k = ald(assignment + i);
+        float d = __builtin_nanf("");
+        if (!dead && (unsigned)k < (unsigned)n) {
+            const float dx = __fsub_rn(x[i * 3 + 0], sy[k * 3 + 0]), dy = __fsub_rn(x[i * 3 + 1], sy[k * 3 + 1]),
+                        dz = __fsub_rn(x[i * 3 + 2], sy[k * 3 + 2]);
+            d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        }
+        a.dist[o0 + i] = d;
+    }
+}
+
 __global__ __launch_bounds__(256) void emd_grad_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                       const float* __restrict__ gdist, const int* __restrict__ idx,
                                                       float* __restrict__ gx, int n, long long total) {
@@ -189,6 +333,17 @@ extern "C" int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist,
     EmdArgs a{xyz1, xyz2, dist, assignment, assignment_inv, price, bid, bid_increments,
               reinterpret_cast<unsigned*>(max_increments), max_idx, unass_idx, n, iters, eps};
     hipStream_t s = (hipStream_t)stream;
+    // several workgroups per sample when the batch alone cannot fill the chip (all B * G of them must be co-resident)
+    int G = 1;
+    while (G < 16 && B * (2 * G) <= 256 && n / (2 * G) >= 64) G *= 2;
+    if (G >= 2 && n <= EMDC_NMAX && !getenv("PF_EMD_SINGLE")) {
+        if (hipMemsetAsync(unass_idx, 0, (size_t)B * n * sizeof(int), s) != hipSuccess) return PF_ERR_LAUNCH;
+        EmdCoopArgs c{xyz1, xyz2, dist, assignment, assignment_inv, price, reinterpret_cast<unsigned*>(max_increments),
+                      reinterpret_cast<unsigned*>(bid_increments), max_idx, bid, reinterpret_cast<unsigned*>(unass_idx), n, iters,
+                      G, eps};
+        hipLaunchKernelGGL(emd_coop_kernel, dim3(B * G), dim3(EMD_THREADS), 0, s, c);
+        return pf_last_launch_status();
+    }
     if (n <= EMD_NMAX_ALL) hipLaunchKernelGGL(emd_auction_kernel<2>, dim3(B), dim3(EMD_THREADS), 0, s, a);
     else if (n <= EMD_NMAX_LDS) hipLaunchKernelGGL(emd_auction_kernel<1>, dim3(B), dim3(EMD_THREADS), 0, s, a);
     else hipLaunchKernelGGL(emd_auction_kernel<0>, dim3(B), dim3(EMD_THREADS), 0, s, a);
