@@ -285,6 +285,11 @@ typedef struct PfMlpTrain {
 long long pf_mlp_train_ws_floats(const PfMlpTrain* p);
 int pf_mlp_train_fwd(const PfMlpTrain* p, void* stream);
 int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream);
+/* n <= 16 networks of the same depth in one launch per kernel (blockIdx.z = network), e.g. the scale / shift conditioners of
+ * all flow blocks, which depend only on the conditioning features.  dev_descs: n * sizeof(PfMlpTrain) bytes of device
+ * scratch. */
+int pf_mlp_train_fwd_batch(const PfMlpTrain* descs, int n, void* dev_descs, void* stream);
+int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_descs, void* stream);
 
 /* ---- element-wise half of a flow block in the training step, fused per direction (csrc/train_flow.hip) ----
  * Replaces ActNorm / InvertibleConv1x1-style 3x3 linear / AffineCoupling / reverse permutation / AffineInjector of

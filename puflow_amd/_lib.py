@@ -115,6 +115,8 @@ SIGNATURES = {
     "pf_mlp_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_mlp_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_mlp_train_bwd": (c_int, [c_void_p, c_void_p]),
+    "pf_mlp_train_fwd_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "pf_mlp_train_bwd_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "pf_ec_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_ec_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_ec_train_bwd": (c_int, [c_void_p, c_void_p]),

@@ -47,10 +47,21 @@ __device__ __forceinline__ void grid_sums(float (&v)[NV], float* partial, unsign
     if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1 : 0;
     __syncthreads();
     if (!last) return;
+    // fixed-order sum of the gridDim.x partials: 16 threads per value (one strided subset each), then a tree over the 16
+    __shared__ float fs[16][16];
+    {
+        const int vi = threadIdx.x & 15, sub = threadIdx.x >> 4;                 // NV <= 16
+        float s = 0.f;
+        if (vi < NV)
+            for (unsigned w = sub; w < gridDim.x; w += 16)
+                s += __hip_atomic_load(partial + (size_t)w * NV + vi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fs[sub][vi] = s;
+    }
+    __syncthreads();
     if (threadIdx.x < NV) {
         float s = 0.f;
-        for (unsigned w = 0; w < gridDim.x; ++w)
-            s += __hip_atomic_load(partial + (size_t)w * NV + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += fs[k][threadIdx.x];
         fin(threadIdx.x, s);
     }
     if (threadIdx.x == 0) *counter = 0u;

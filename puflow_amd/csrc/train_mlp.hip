@@ -26,7 +26,7 @@ namespace {
 
 constexpr int MLP_GRID = 512;
 constexpr int MLP_EB = 32, MLP_SLOTS = 9;
-__host__ inline int mlp_chunk(int rows) { return rows > 16384 ? 256 : 128; }      // rows per split-K chunk (multiple of MLP_EB)
+__host__ __device__ inline int mlp_chunk(int rows) { return rows > 16384 ? 256 : 128; }      // rows per split-K chunk (multiple of MLP_EB)
 
 __device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 c) {
     c = pf_mfma(a.x, b.x, c); c = pf_mfma(a.y, b.y, c); c = pf_mfma(a.z, b.z, c); c = pf_mfma(a.w, b.w, c);
@@ -63,8 +63,10 @@ __host__ __device__ inline T sel2(const T (&a)[2], int l) { return l == 0 ? a[0]
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int NL>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p, int ntiles) {
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
     extern __shared__ float lds[];
+    const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;             // batched launch: one network per blockIdx.z
+    const int ntiles = (p.rows + 15) / 16;
     const MlpShape sh = mlp_shape(p);
     float* Wl[NL];
     float* bl[NL];
@@ -148,8 +150,10 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p, int ntiles) 
 
 // ------------------------------------------------------------------------------------------------ backward, chain
 template <int NL>
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p, int ntiles) {
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
     extern __shared__ float lds[];
+    const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;
+    const int ntiles = (p.rows + 15) / 16;
     const MlpShape sh = mlp_shape(p);
     float* Wt[NL];                                       // Wt[l][u][c] = W[l][c][off + u]
     float* ptr = lds;
@@ -271,8 +275,12 @@ __host__ __device__ inline MlpDwLayout mlp_dw_layout(const PfMlpTrain& p, const 
     return L;
 }
 
-__global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p, float* part, int chunk) {
+__global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
     extern __shared__ float lds[];
+    const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;
+    const int chunk = mlp_chunk(p.rows);
+    if ((int)blockIdx.x * chunk >= p.rows || (int)blockIdx.y >= p.nl) return;
+    float* part = p.ws;
     const MlpShape sh = mlp_shape(p);
     const MlpDwLayout L = mlp_dw_layout(p, sh);
     const int l = blockIdx.y;
@@ -378,7 +386,10 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p, float* part, 
 }
 
 // partial sums -> dW[l] [wo, in_l] (column j < td of layer 0 sits behind the cc conditioning columns in the partials), db[l]
-__global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(PfMlpTrain p, const float* part, int nchunk) {
+__global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
+    const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;
+    const float* part = p.ws;
+    const int nchunk = (p.rows + mlp_chunk(p.rows) - 1) / mlp_chunk(p.rows);
     const MlpShape sh = mlp_shape(p);
     const MlpDwLayout L = mlp_dw_layout(p, sh);
     int cnt[3] = {0, 0, 0};
@@ -412,6 +423,14 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(PfMlpTrain p, const 
     float* db = sel3(p.db, l);
     if (j == inl) { if (db) db[c] = (float)s; }
     else sel3(p.dW, l)[(size_t)c * inl + j] = (float)s;
+}
+
+// descriptors of a batched launch travel as kernel arguments of this copy kernel (capturable in a hipGraph, no host copy)
+constexpr int MLP_BATCH_MAX = 16;
+struct MlpBatch { PfMlpTrain p[MLP_BATCH_MAX]; };
+__global__ __launch_bounds__(256) void mlp_desc_upload_kernel(MlpBatch b, unsigned* dst, int nwords) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(&b);
+    for (int i = threadIdx.x; i < nwords; i += 256) dst[i] = src[i];
 }
 
 template <typename KERNEL>
@@ -460,8 +479,8 @@ extern "C" int pf_mlp_train_fwd(const PfMlpTrain* p, void* stream) {
     const int ntiles = (p->rows + 15) / 16;
     const int grid = (ntiles + 3) / 4 < MLP_GRID ? (ntiles + 3) / 4 : MLP_GRID;
     hipStream_t s = (hipStream_t)stream;
-    if (p->nl == 2) { allow_lds(mlp_fwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<2>, dim3(grid), dim3(256), lds, s, *p, ntiles); }
-    else { allow_lds(mlp_fwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<3>, dim3(grid), dim3(256), lds, s, *p, ntiles); }
+    if (p->nl == 2) { allow_lds(mlp_fwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<2>, dim3(grid), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr); }
+    else { allow_lds(mlp_fwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<3>, dim3(grid), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr); }
     return pf_last_launch_status();
 }
 
@@ -483,8 +502,8 @@ extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
         lds = (lds + (size_t)sh.wo16[0] * 4) * sizeof(float);
         const int ntiles = (p->rows + 15) / 16;
         const int grid = (ntiles + 3) / 4 < MLP_GRID ? (ntiles + 3) / 4 : MLP_GRID;
-        if (p->nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, *p, ntiles); }
-        else { allow_lds(mlp_bwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(grid), dim3(256), lds, s, *p, ntiles); }
+        if (p->nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr); }
+        else { allow_lds(mlp_bwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(grid), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr); }
     }
     const int chunk = mlp_chunk(p->rows);
     const int nchunk = (p->rows + chunk - 1) / chunk;
@@ -492,10 +511,91 @@ extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
         int ramax = 0, rbmax = 0;
         for (int l = 0; l < p->nl; ++l) { ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l]; }
         const size_t lds = sizeof(float) * (size_t)MLP_EB * ((ramax + 16) + (rbmax + 16));
-        hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(256), lds, s, *p, p->ws, chunk);
+        hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr);
     }
     int total = 0;
     for (int l = 0; l < p->nl; ++l) total += sh.wo[l] * (sh.in[l] + 1);
-    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, *p, p->ws, nchunk);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, *p, (const PfMlpTrain*)nullptr);
+    return pf_last_launch_status();
+}
+
+// ---- batched launches: n <= 16 networks of the same depth (e.g. the scale / shift conditioners of all six flow blocks, which
+// depend only on the conditioning features) in ONE launch per kernel, blockIdx.z = network.  dev_descs: n * sizeof(PfMlpTrain)
+// bytes of device scratch (the descriptors are copied there by a kernel whose arguments they are).
+extern "C" int pf_mlp_train_fwd_batch(const PfMlpTrain* descs, int n, void* dev_descs, void* stream) {
+    if (!descs || !dev_descs) return PF_ERR_NULL;
+    if (n < 1 || n > MLP_BATCH_MAX) return PF_ERR_SHAPE;
+    size_t lds = 0;
+    int gmax = 1;
+    MlpBatch b{};
+    for (int k = 0; k < n; ++k) {
+        const PfMlpTrain* p = descs + k;
+        int st = mlp_check(p);
+        if (st) return st;
+        if (p->nl != descs[0].nl || !p->out) return PF_ERR_SHAPE;
+        for (int l = 0; l < p->nl - 1; ++l)
+            if (!p->h[l]) return PF_ERR_NULL;
+        const MlpShape sh = mlp_shape(*p);
+        size_t w = 0;
+        for (int l = 0; l < p->nl; ++l) w += (size_t)sh.wo16[l] * (sh.wi16[l] + 4) + sh.wo16[l];
+        w = (w + (size_t)sh.wo16[0] * 4) * sizeof(float);
+        lds = w > lds ? w : lds;
+        const int ntiles = (p->rows + 15) / 16;
+        const int g = (ntiles + 3) / 4 < MLP_GRID ? (ntiles + 3) / 4 : MLP_GRID;
+        gmax = g > gmax ? g : gmax;
+        b.p[k] = *p;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mlp_desc_upload_kernel, dim3(1), dim3(256), 0, s, b, (unsigned*)dev_descs, (int)(n * sizeof(PfMlpTrain) / 4));
+    const PfMlpTrain* dd = (const PfMlpTrain*)dev_descs;
+    if (descs[0].nl == 2) { allow_lds(mlp_fwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<2>, dim3(gmax, 1, n), dim3(256), lds, s, b.p[0], dd); }
+    else { allow_lds(mlp_fwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<3>, dim3(gmax, 1, n), dim3(256), lds, s, b.p[0], dd); }
+    return pf_last_launch_status();
+}
+
+extern "C" int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_descs, void* stream) {
+    if (!descs || !dev_descs) return PF_ERR_NULL;
+    if (n < 1 || n > MLP_BATCH_MAX) return PF_ERR_SHAPE;
+    size_t lds_b = 0, lds_w = 0;
+    int gmax = 1, cmax = 1, tmax = 1;
+    MlpBatch b{};
+    for (int k = 0; k < n; ++k) {
+        const PfMlpTrain* p = descs + k;
+        int st = mlp_check(p);
+        if (st) return st;
+        if (p->nl != descs[0].nl || !p->dout || !p->ws) return PF_ERR_NULL;
+        for (int l = 0; l < p->nl - 1; ++l)
+            if (!p->h[l] || !p->dz[l]) return PF_ERR_NULL;
+        for (int l = 0; l < p->nl; ++l)
+            if (!p->dW[l]) return PF_ERR_NULL;
+        if (p->ws_floats < pf_mlp_train_ws_floats(p)) return PF_ERR_WORKSPACE;
+        const MlpShape sh = mlp_shape(*p);
+        const MlpDwLayout L = mlp_dw_layout(*p, sh);
+        size_t w = 0;
+        for (int l = 0; l < p->nl; ++l) w += (size_t)sh.wi16[l] * (sh.wo16[l] + 4);
+        w = (w + (size_t)sh.wo16[0] * 4) * sizeof(float);
+        lds_b = w > lds_b ? w : lds_b;
+        int ramax = 0, rbmax = 0, total = 0;
+        for (int l = 0; l < p->nl; ++l) {
+            ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l];
+            total += sh.wo[l] * (sh.in[l] + 1);
+        }
+        const size_t w2 = sizeof(float) * (size_t)MLP_EB * ((ramax + 16) + (rbmax + 16));
+        lds_w = w2 > lds_w ? w2 : lds_w;
+        const int ntiles = (p->rows + 15) / 16;
+        const int g = (ntiles + 3) / 4 < MLP_GRID ? (ntiles + 3) / 4 : MLP_GRID;
+        gmax = g > gmax ? g : gmax;
+        const int nchunk = (p->rows + mlp_chunk(p->rows) - 1) / mlp_chunk(p->rows);
+        cmax = nchunk > cmax ? nchunk : cmax;
+        tmax = total > tmax ? total : tmax;
+        b.p[k] = *p;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mlp_desc_upload_kernel, dim3(1), dim3(256), 0, s, b, (unsigned*)dev_descs, (int)(n * sizeof(PfMlpTrain) / 4));
+    const PfMlpTrain* dd = (const PfMlpTrain*)dev_descs;
+    if (descs[0].nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(gmax, 1, n), dim3(256), lds_b, s, b.p[0], dd); }
+    else { allow_lds(mlp_bwd_kernel<3>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(gmax, 1, n), dim3(256), lds_b, s, b.p[0], dd); }
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(256), lds_w, s, b.p[0], dd);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(256), 0, s, b.p[0], dd);
     return pf_last_launch_status();
 }

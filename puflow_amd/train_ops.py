@@ -911,6 +911,99 @@ class MlpFn(Function):
         return (dy, dc, None, None, None, *grads)
 
 
+_DESC_BUF = {}
+
+
+def _desc_buf(dev) -> Tensor:
+    key = (dev, _stream())
+    t = _DESC_BUF.get(key)
+    if t is None:
+        t = torch.empty(16 * ctypes.sizeof(_lib.PfMlpTrain), dtype=torch.uint8, device=dev)
+        _DESC_BUF[key] = t
+    return t
+
+
+class CondNetBatchFn(Function):
+    """Several LinearA1D conditioners (first layer without bias, interpflow.py:22-43) that only read conditioning features -
+    the scale and shift nets of every flow block - in ONE launch forward and four backward (csrc/train_mlp.hip, batched
+    entry points).  apply(cidx, *cs, *[W0, W1, b1, W2, b2 per net]) -> one [rows, dout] tensor per net; cidx[k] = which of
+    the `cs` tensors net k reads."""
+
+    @staticmethod
+    def forward(ctx, cidx, *ts):
+        lib = _lib.load()
+        n = len(cidx)
+        ncs = len(ts) - 5 * n
+        cs = [c.contiguous() for c in ts[:ncs]]
+        prm = [w.contiguous() for w in ts[ncs:]]
+        descs = (_lib.PfMlpTrain * n)()
+        outs, hs = [], []
+        for k in range(n):
+            W0, W1, b1, W2, b2 = prm[5 * k:5 * k + 5]
+            d, rows = MlpFn._desc(None, cs[cidx[k]], 0, 1, (0.01, 0.01), [W0, W1, W2], [None, b1, b2])
+            f32 = dict(dtype=torch.float32, device=W0.device)
+            h = [torch.empty((rows, W0.shape[0]), **f32), torch.empty((rows, W1.shape[0]), **f32)]
+            out = torch.empty((rows, W2.shape[0]), **f32)
+            d.h[0], d.h[1], d.out = h[0].data_ptr(), h[1].data_ptr(), out.data_ptr()
+            descs[k] = d
+            outs.append(out)
+            hs += h
+        _lib.check(lib.pf_mlp_train_fwd_batch(descs, n, _desc_buf(cs[0].device).data_ptr(), _stream()), "pf_mlp_train_fwd_batch")
+        ctx.cidx, ctx.ncs = cidx, ncs
+        ctx.save_for_backward(*cs, *prm, *hs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        lib = _lib.load()
+        cidx, ncs = ctx.cidx, ctx.ncs
+        n = len(cidx)
+        sv = list(ctx.saved_tensors)
+        cs, prm, hs = sv[:ncs], sv[ncs:ncs + 5 * n], sv[ncs + 5 * n:]
+        dev = cs[0].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        descs = (_lib.PfMlpTrain * n)()
+        keep, grads, dcs = [], [], [[] for _ in range(ncs)]
+        need_tot = 0
+        for k in range(n):
+            W0, W1, b1, W2, b2 = prm[5 * k:5 * k + 5]
+            d, rows = MlpFn._desc(None, cs[cidx[k]], 0, 1, (0.01, 0.01), [W0, W1, W2], [None, None, None])
+            need_tot += lib.pf_mlp_train_ws_floats(ctypes.byref(d))
+        ws = _ws(dev, need_tot)
+        off = 0
+        for k in range(n):
+            W0, W1, b1, W2, b2 = prm[5 * k:5 * k + 5]
+            c = cs[cidx[k]]
+            d, rows = MlpFn._desc(None, c, 0, 1, (0.01, 0.01), [W0, W1, W2], [None, None, None])
+            dout = douts[k].contiguous() if douts[k] is not None else torch.zeros((rows, W2.shape[0]), **f32)
+            dz = [torch.empty_like(hs[2 * k]), torch.empty_like(hs[2 * k + 1])]
+            dc = torch.empty_like(c)
+            dW = [torch.empty_like(W0), torch.empty_like(W1), torch.empty_like(W2)]
+            db = [torch.empty_like(b1), torch.empty_like(b2)]
+            d.h[0], d.h[1], d.dz[0], d.dz[1] = hs[2 * k].data_ptr(), hs[2 * k + 1].data_ptr(), dz[0].data_ptr(), dz[1].data_ptr()
+            d.dout, d.dc = dout.data_ptr(), dc.data_ptr()
+            for l in range(3):
+                d.dW[l] = dW[l].data_ptr()
+            d.db[1], d.db[2] = db[0].data_ptr(), db[1].data_ptr()
+            need = lib.pf_mlp_train_ws_floats(ctypes.byref(d))
+            d.ws, d.ws_floats = ws.data_ptr() + 4 * off, need
+            off += need
+            descs[k] = d
+            keep += [dout, dz]
+            dcs[cidx[k]].append(dc)
+            grads += [dW[0], dW[1], db[0], dW[2], db[1]]
+        _lib.check(lib.pf_mlp_train_bwd_batch(descs, n, _desc_buf(dev).data_ptr(), _stream()), "pf_mlp_train_bwd_batch")
+        dc_out = []
+        for lst in dcs:
+            if not lst:
+                dc_out.append(None)
+            elif len(lst) == 1:
+                dc_out.append(lst[0])
+            else:
+                dc_out.append(torch.stack(lst).sum(0) if len(lst) > 2 else lst[0] + lst[1])
+        return (None, *dc_out, *grads)
+
+
 def mlp_fused(y, c: Tensor, td: int, cdiv: int, slopes, layers) -> Tensor:
     """layers: nn.Linear modules.  -> [rows, out]"""
     wb = []
@@ -987,6 +1080,17 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         else:
             cs.append(linear(ActFn.apply(linear(h, m.conv1.weight, m.conv1.bias), 0.0), m.conv2.weight))
 
+    # ---- injector nets (s, t) of every block: functions of cs[i] only - one batched launch (and shared by f and g)
+    st_all = None
+    if _FUSED:
+        prm = []
+        for blk in net.flow_blocks:
+            for cn in (blk.coupling2.scale_net, blk.coupling2.bias_net):
+                L = cn.layers
+                prm += [L[0].weight, L[2].weight, L[2].bias, L[4].weight, L[4].bias]
+        cidx = tuple(i for i in range(net.num_blocks) for _ in range(2))
+        st_all = CondNetBatchFn.apply(cidx, *cs, *prm)
+
     # ---- f + log-likelihood
     p = xyz
     ldj = torch.zeros(B, device=xyz.device)
@@ -1011,8 +1115,7 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
             lds.append(ld)
             y = FlowAffineFn.apply(p, None, 0, an.logs, an.bias, W, 0)    # ActNorm + einsum 'ij,bnj->bni' (permutate.py:118)
             o = cond_net_fused(blk.coupling1.bias_net, y, cs[i], td, 1).view(B, N, -1)
-            s = cond_net_fused(blk.coupling2.scale_net, None, cs[i], 0, 1).view(B, N, -1)
-            t = cond_net_fused(blk.coupling2.bias_net, None, cs[i], 0, 1).view(B, N, -1)
+            s, t = st_all[2 * i].view(B, N, -1), st_all[2 * i + 1].view(B, N, -1)
             st_nets.append((s, t))
             p, ssum = CoupleInject2Fn.apply(y, o, s, t, td)
             ssums.append(ssum)
