@@ -29,6 +29,7 @@
 // All matrix products are v_mfma_f32_16x16x4_f32 (exact fp32 fma chains).  Rows of every per-edge tensor are edges in
 // point-major order (e = i K + k), so a 16-row MFMA tile is one point's 16 neighbours (K = 16) or two points (K = 8).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "pf_api_internal.h"
 #include "pf_mfma.h"
 
@@ -165,9 +166,20 @@ __global__ __launch_bounds__(256) void ec_fwd_kernel(EcFwdArgs a) {
     float* Wl = lds;
     float* al = lds + NT * 16 * kp;
     float* bl = al + kin16;
-    for (int i = threadIdx.x; i < NT * 16 * kin16; i += 256) {
-        const int c = i / kin16, u = i % kin16;
-        Wl[c * kp + u] = (c < a.nout && u < a.kin) ? a.W[(size_t)c * a.ldw + u] : 0.f;
+    // 16 lanes along a weight row (coalesced, no division); a thread's <= 8 elements of a row are loaded together, then stored:
+    // a load -> store loop pays a full memory latency per element
+    for (int c = threadIdx.x >> 4; c < NT * 16; c += 16) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = (threadIdx.x & 15) + 16 * k;
+            v[k] = (u < kin16 && c < a.nout && u < a.kin) ? a.W[(size_t)c * a.ldw + u] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = (threadIdx.x & 15) + 16 * k;
+            if (u < kin16) Wl[c * kp + u] = v[k];
+        }
     }
     for (int i = threadIdx.x; i < kin16; i += 256) {
         al[i] = i < a.kin ? a.aff[i] : 0.f;
@@ -179,13 +191,20 @@ __global__ __launch_bounds__(256) void ec_fwd_kernel(EcFwdArgs a) {
     float s0[NT], s1[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) s0[nt] = s1[nt] = 0.f;
-    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
+    const int tile0 = blockIdx.x * 4 + wave;
+    int jnext = tile0 < a.ntiles ? a.idx[(long long)tile0 * 16 + row] : 0;
+    for (int tile = tile0; tile < a.ntiles; tile += gridDim.x * 4) {
         const long long e0 = (long long)tile * 16;
-        // all loads of the tile first: the growth-feature row of this lane's edge and its P[i] + Q[j] addend
-        const long long er = e0 + row;
-        const long long ir = er / a.K;
-        const long long jr = (ir / a.N) * a.N + a.idx[er];
-        const float* yrow = a.Y + er * a.ldy;
+        // all loads of the tile first: the growth-feature row of this lane's edge and its P[i] + Q[j] addend (the neighbour
+        // index was fetched during the previous tile: one dependent memory latency less per tile)
+        const int er = (int)e0 + row;
+        const int ir = er / a.K;
+        const long long jr = (long long)(ir / a.N) * a.N + jnext;
+        {
+            const int tn = tile + gridDim.x * 4;
+            if (tn < a.ntiles) jnext = a.idx[(long long)tn * 16 + row];
+        }
+        const float* yrow = a.Y + (size_t)er * a.ldy;
         f4 yv[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
@@ -198,8 +217,8 @@ __global__ __launch_bounds__(256) void ec_fwd_kernel(EcFwdArgs a) {
             const int c4 = nt * 16 + 4 * q;
             f4 ex = pf_splat(0.f);
             if (c4 < a.nout)
-                ex = *reinterpret_cast<const f4*>(a.pq + ir * a.ldpq + a.poff + c4) +
-                     *reinterpret_cast<const f4*>(a.pq + jr * a.ldpq + a.qoff + c4);
+                ex = *reinterpret_cast<const f4*>(a.pq + (size_t)ir * a.ldpq + a.poff + c4) +
+                     *reinterpret_cast<const f4*>(a.pq + (size_t)jr * a.ldpq + a.qoff + c4);
             acc[nt] = mfma4(ex, ident, pf_splat(0.f));
         }
 #pragma unroll
@@ -288,9 +307,15 @@ __global__ __launch_bounds__(256) void ec_bwd_kernel(EcBwdArgs a) {
     const int kin16 = (a.kin + 15) & ~15, kp = kin16 + 4, KS = kin16 / 16;
     float* Wt = lds;                                   // Wt[u][c]
     float* cf = lds + NT * 16 * kp;                    // SRC 2: [6][kin16] scale, shift, mean, rstd, m1, m2 of the source layer
-    for (int i = threadIdx.x; i < NT * 16 * kin16; i += 256) {
-        const int c = i / (NT * 16), u = i % (NT * 16);            // consecutive threads: consecutive u (contiguous in W)
-        Wt[u * kp + c] = (c < a.kin && u < a.nout) ? a.W[(size_t)c * a.ldw + u] : 0.f;
+    for (int c = threadIdx.x >> 4; c < kin16; c += 16) {                       // 16 lanes along a weight row (u): coalesced
+        float v[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int u = (threadIdx.x & 15) + 16 * k;
+            v[k] = (c < a.kin && u < a.nout) ? a.W[(size_t)c * a.ldw + u] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NT; ++k) Wt[((threadIdx.x & 15) + 16 * k) * kp + c] = v[k];
     }
     if (SRC == 2) {
         for (int i = threadIdx.x; i < kin16; i += 256) {
@@ -663,10 +688,12 @@ void allow_lds(KERNEL k, size_t bytes) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
 struct Dims {
     int T, GT, S, nconvs;
     long long E;
-    int ntiles, grid, nchunk;
+    int ntiles, grid, grid_light, nchunk;
 };
 constexpr int EC_DW_CHUNK = 512;
 
@@ -685,6 +712,9 @@ int ec_dims(const PfEcTrain* p, Dims& d) {
     if (d.E % 16 != 0 || d.E > (1ll << 30)) return PF_ERR_SHAPE;
     d.ntiles = (int)(d.E / 16);
     d.grid = (d.ntiles + 3) / 4 < EC_GRID ? (d.ntiles + 3) / 4 : EC_GRID;
+    // growth-layer kernels: measured (layer with 96 input channels, 131 072 edges) 44 / 30 / 29 / 41 us at 128 / 256 / 512 / 2048
+    // workgroups: beyond 2 per CU the fixed cost per workgroup (weight staging, 64 statistics atomics) outweighs the latency hiding
+    { const int gl = env_int("PF_EC_GRID_LIGHT", 512); d.grid_light = (d.ntiles + 3) / 4 < gl ? (d.ntiles + 3) / 4 : gl; }
     d.nchunk = (int)((d.E + EC_DW_CHUNK - 1) / EC_DW_CHUNK);
     return PF_OK;
 }
@@ -749,8 +779,8 @@ extern "C" int pf_ec_train_fwd(const PfEcTrain* p, void* stream) {
         const int kin16 = (a.kin + 15) & ~15;
         const int nt = g > 16 ? 2 : 1;
         const size_t lds = sizeof(float) * ((size_t)nt * 16 * (kin16 + 4) + 2 * kin16);
-        if (nt == 2) hipLaunchKernelGGL((ec_fwd_kernel<2, false, false>), dim3(d.grid), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((ec_fwd_kernel<1, false, false>), dim3(d.grid), dim3(256), lds, s, a);
+        if (nt == 2) hipLaunchKernelGGL((ec_fwd_kernel<2, false, false>), dim3(d.grid_light), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((ec_fwd_kernel<1, false, false>), dim3(d.grid_light), dim3(256), lds, s, a);
     }
     a.W = p->W[p->nconv] + 3 * p->C; a.ldw = cv.width[p->nconv]; a.poff = d.GT; a.qoff = d.S + d.GT;
     a.kin = d.GT; a.col0 = 0; a.nout = p->odim; a.out = p->out; a.arg = p->arg; a.fin = StatFin{};
@@ -802,7 +832,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         const size_t lds = sizeof(float) * ((size_t)nt * 16 * (((p->odim + 15) & ~15) + 4));
 #define PF_ECB(NT, SRC)                                                                                                   \
     do { allow_lds(ec_bwd_kernel<NT, SRC>, lds);                                                                          \
-         hipLaunchKernelGGL((ec_bwd_kernel<NT, SRC>), dim3(d.grid), dim3(256), lds, s, a); } while (0)
+         hipLaunchKernelGGL((ec_bwd_kernel<NT, SRC>), dim3(SRC == 2 ? d.grid_light : d.grid), dim3(256), lds, s, a); } while (0)
         if (p->pooling) { if (nt == 2) PF_ECB(2, 0); else if (nt == 4) PF_ECB(4, 0); else PF_ECB(8, 0); }
         else { if (nt == 2) PF_ECB(2, 1); else if (nt == 4) PF_ECB(4, 1); else PF_ECB(8, 1); }
     }

@@ -78,9 +78,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p0, const PfMlp
     for (int l = 0; l < NL; ++l) {
         const int ld = sh.wi16[l] + 4, off = l == 0 ? p.td : 0;
         const int sft = 31 - __clz(sh.wi16[l]);                          // wi16 is a power of two (16 .. 128)
-        for (int i = threadIdx.x; i < sh.wo16[l] * sh.wi16[l]; i += 256) {
-            const int c = i >> sft, u = i & (sh.wi16[l] - 1);
-            Wl[l][c * ld + u] = (c < sh.wo[l] && u < sh.wi[l]) ? p.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
+        // 8 loads in flight per thread, then 8 LDS stores: a load -> store loop pays a full memory latency per element
+        for (int i0 = threadIdx.x; i0 < sh.wo16[l] * sh.wi16[l]; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + 256 * k, c = i >> sft, u = i & (sh.wi16[l] - 1);
+                v[k] = (i < sh.wo16[l] * sh.wi16[l] && c < sh.wo[l] && u < sh.wi[l]) ? p.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + 256 * k, c = i >> sft, u = i & (sh.wi16[l] - 1);
+                if (i < sh.wo16[l] * sh.wi16[l]) Wl[l][c * ld + u] = v[k];
+            }
         }
         for (int i = threadIdx.x; i < sh.wo16[l]; i += 256) bl[l][i] = (p.b[l] && i < sh.wo[l]) ? p.b[l][i] : 0.f;
     }
@@ -164,9 +174,18 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p0, const PfMlp
     for (int l = 0; l < NL; ++l) {
         const int ld = sh.wo16[l] + 4, off = l == 0 ? p.td : 0;
         const int sft = 31 - __clz(sh.wi16[l]);                          // wi16 is a power of two (16 .. 128)
-        for (int i = threadIdx.x; i < sh.wo16[l] * sh.wi16[l]; i += 256) {
-            const int c = i >> sft, u = i & (sh.wi16[l] - 1);                // consecutive threads: consecutive u (contiguous in W)
-            Wt[l][u * ld + c] = (c < sh.wo[l] && u < sh.wi[l]) ? p.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
+        for (int i0 = threadIdx.x; i0 < sh.wo16[l] * sh.wi16[l]; i0 += 256 * 8) {   // consecutive threads: consecutive u (contiguous in W)
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + 256 * k, c = i >> sft, u = i & (sh.wi16[l] - 1);
+                v[k] = (i < sh.wo16[l] * sh.wi16[l] && c < sh.wo[l] && u < sh.wi[l]) ? p.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + 256 * k, c = i >> sft, u = i & (sh.wi16[l] - 1);
+                if (i < sh.wo16[l] * sh.wi16[l]) Wt[l][u * ld + c] = v[k];
+            }
         }
     }
     for (int i = threadIdx.x; i < sh.wo16[0] * 4; i += 256) {

@@ -345,10 +345,13 @@ inline int gemm_shape(int M, int N) {
     if (M <= 16) return 4;
     if (M <= 32) return 5;
     if (M <= 64) return 6;
+    // 128 x 128 tiles leave most CUs idle on the point-level GEMMs of the training step ([8192, 128..512] outputs: 64..256
+    // tiles, one 1-wave-per-SIMD workgroup per CU): 64 x 64 tiles there
+    if ((long long)((M + 127) / 128) * ((N + 127) / 128) < 1024) return 7;
     return 0;
 }
 inline void gemm_tile_dims(int shape, int& bm, int& bn) {
-    static const int d[7][2] = {{128, 128}, {256, 16}, {256, 32}, {256, 64}, {16, 256}, {32, 256}, {64, 256}};
+    static const int d[8][2] = {{128, 128}, {256, 16}, {256, 32}, {256, 64}, {16, 256}, {32, 256}, {64, 256}, {64, 64}};
     bm = d[shape][0]; bn = d[shape][1];
 }
 
@@ -724,6 +727,7 @@ extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sa
             case 3: gemm_split_launch<4, 1, 4, 4>(arith, g, split, vec2, s); break;
             case 4: gemm_split_launch<1, 4, 1, 4>(arith, g, split, vec2, s); break;
             case 5: gemm_split_launch<1, 4, 2, 4>(arith, g, split, vec2, s); break;
+            case 7: gemm_split_launch<2, 2, 2, 2>(arith, g, split, vec2, s); break;
             default: gemm_split_launch<1, 4, 4, 4>(arith, g, split, vec2, s); break;
         }
     } else
@@ -734,6 +738,7 @@ extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sa
         case 3: gemm_launch<4, 1, 4, 4>(g, split, vec, s); break;
         case 4: gemm_launch<1, 4, 1, 4>(g, split, vec, s); break;
         case 5: gemm_launch<1, 4, 2, 4>(g, split, vec, s); break;
+        case 7: gemm_launch<2, 2, 2, 2>(g, split, vec, s); break;
         default: gemm_launch<1, 4, 4, 4>(g, split, vec, s); break;
     }
     if (use_ws)

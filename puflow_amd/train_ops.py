@@ -1024,8 +1024,7 @@ def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True) -> Ten
     out = EdgeConvUnitFn.apply(x, idx, cfg, *[c.weight for c in convs], *[c.bias for c in convs],
                                *[bn.weight for bn in bns], *[bn.bias for bn in bns])
     with torch.no_grad():
-        for bn in bns:
-            bn.num_batches_tracked += 1
+        torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)          # one launch for the unit's counters
     return out
 
 
