@@ -228,6 +228,7 @@ int pf_dist_feature(const float* xyz, const int* idx, int B, int N, int K, float
  * T = B*N points, E = T*K edges (point-major rows), GT = growth*nconv, S = GT + odim.  growth in {8,16,32}, nconv <= 8,
  * odim a multiple of 16 <= 128, GT in {32, 64, 128}, E a multiple of 16, pooling requires K == 16.
  * The caller owns every buffer; those marked (kept) must survive from pf_ec_train_fwd to pf_ec_train_bwd. */
+#define PF_TRAIN_STAT_DOUBLES 4097
 typedef struct PfEcTrain {
     int B, N, K, C, growth, nconv, odim, pooling;
     float slope, eps, momentum;
@@ -253,11 +254,39 @@ typedef struct PfEcTrain {
     float* dx;                      /* [T, C], nullable */
     float* dW[9]; float* dbias[9]; float* dgamma[8]; float* dbeta[8];
     float* ws; long long ws_floats; /* >= pf_ec_train_ws_floats() */
-    double* stat;                   /* 1025 doubles of scratch (column-statistics accumulators) */
+    double* stat;                   /* PF_TRAIN_STAT_DOUBLES doubles of scratch (column-statistics accumulators) */
 } PfEcTrain;
 long long pf_ec_train_ws_floats(const PfEcTrain* p);
 int pf_ec_train_fwd(const PfEcTrain* p, void* stream);
 int pf_ec_train_bwd(const PfEcTrain* p, void* stream);
+
+/* ---- BatchNorm MLP of the interpolation module in the training step, fused (csrc/train_fused.hip) ----
+ * Replaces DistanceEncoder.mlp / WeightEstimationUnit.mlp (modules/discrete/interpflow.py:85-151: [Conv2d 1x1 +
+ * BatchNorm2d(batch statistics) + LeakyReLU(slope)] x (nl - 1), then Conv2d 1x1) in train() mode with their autograd
+ * backward.  Input = cat[xa [rows, kin0a], xb [rows, kin0b]] (never built; kin0b = 0: one input); widths multiples of 16
+ * <= 128, kin0a, kin0b <= 128.  W[l]: [width[l], in_l], in_0 = kin0a + kin0b. */
+typedef struct PfBnMlpTrain {
+    int rows, nl, kin0a, kin0b;
+    int width[3];
+    float slope, eps, momentum;
+    const float* xa; const float* xb;
+    const float* W[3]; const float* b[3];
+    const float* gamma[2]; const float* beta[2];
+    float* run_mean[2]; float* run_var[2];      /* nullable */
+    float* y[3];                    /* (kept) [rows, width[l]] pre-BatchNorm output of layer l; y[nl-1] is the result */
+    float* aff[2];                  /* (kept) [4][width[l]] scale, shift, batch mean, 1/std */
+    /* backward only */
+    const float* dout;              /* [rows, width[nl-1]] */
+    float* d[2];                    /* [rows, width[l]] scratch */
+    float* coef[2];                 /* [2][width[l]] scratch */
+    float* dxa; float* dxb;         /* nullable: [rows, kin0a], [rows, kin0b] */
+    float* dW[3]; float* db[3]; float* dgamma[2]; float* dbeta[2];
+    float* ws; long long ws_floats; /* >= pf_bnmlp_train_ws_floats() */
+    double* stat;                   /* PF_TRAIN_STAT_DOUBLES doubles */
+} PfBnMlpTrain;
+long long pf_bnmlp_train_ws_floats(const PfBnMlpTrain* p);
+int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream);
+int pf_bnmlp_train_bwd(const PfBnMlpTrain* p, void* stream);
 
 /* ---- point-wise MLP of the training step (2 or 3 Linear layers, LeakyReLU / ReLU between them), fused (csrc/train_mlp.hip) ----
  * Replaces LinearA1D (modules/discrete/interpflow.py:22-43, the conditioner of the coupling / injector layers) and

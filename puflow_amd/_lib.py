@@ -24,6 +24,17 @@ class PfEcTrain(ctypes.Structure):
                 ("dgamma", c_void_p * 8), ("dbeta", c_void_p * 8), ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p)]
 
 
+class PfBnMlpTrain(ctypes.Structure):
+    """include/puflow_hip.h: PfBnMlpTrain (a BatchNorm MLP of the interpolation module in the training step)."""
+    _fields_ = [("rows", c_int), ("nl", c_int), ("kin0a", c_int), ("kin0b", c_int), ("width", c_int * 3),
+                ("slope", c_float), ("eps", c_float), ("momentum", c_float), ("xa", c_void_p), ("xb", c_void_p),
+                ("W", c_void_p * 3), ("b", c_void_p * 3), ("gamma", c_void_p * 2), ("beta", c_void_p * 2),
+                ("run_mean", c_void_p * 2), ("run_var", c_void_p * 2), ("y", c_void_p * 3), ("aff", c_void_p * 2),
+                ("dout", c_void_p), ("d", c_void_p * 2), ("coef", c_void_p * 2), ("dxa", c_void_p), ("dxb", c_void_p),
+                ("dW", c_void_p * 3), ("db", c_void_p * 3), ("dgamma", c_void_p * 2), ("dbeta", c_void_p * 2),
+                ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p)]
+
+
 class PfMlpTrain(ctypes.Structure):
     """include/puflow_hip.h: PfMlpTrain (a 2/3-layer point-wise MLP of the training step)."""
     _fields_ = [("rows", c_int), ("nl", c_int), ("td", c_int), ("ldy", c_int), ("cc", c_int), ("cdiv", c_int),
@@ -117,6 +128,9 @@ SIGNATURES = {
     "pf_mlp_train_bwd": (c_int, [c_void_p, c_void_p]),
     "pf_mlp_train_fwd_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "pf_mlp_train_bwd_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "pf_bnmlp_train_ws_floats": (c_longlong, [c_void_p]),
+    "pf_bnmlp_train_fwd": (c_int, [c_void_p, c_void_p]),
+    "pf_bnmlp_train_bwd": (c_int, [c_void_p, c_void_p]),
     "pf_ec_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_ec_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_ec_train_bwd": (c_int, [c_void_p, c_void_p]),

@@ -67,7 +67,7 @@ __device__ __forceinline__ f4 ident_b(int row, int q) {
 //   mode 1 (BatchNorm forward): sums of y, y^2 -> scale, shift, mean, 1/std (aff rows 0..3), running statistics
 //   mode 2 (BatchNorm backward): sums of dz, dz xhat -> their means (coef rows 0, 1), dbeta, dgamma
 struct StatFin {
-    double* acc;                      // [STAT_COPIES][64] + a counter word behind them; all zero between uses
+    double* acc;                      // [STAT_COPIES][2][STAT_W] + a counter word behind them; all zero between uses
     int mode, g, col0, ld;
     float* aff; const float* gamma; const float* beta; float* run_mean; float* run_var; float eps, momentum;
     float* coef; float* dgamma; float* dbeta;
@@ -75,9 +75,11 @@ struct StatFin {
 };
 
 constexpr int STAT_COPIES = 16;       // workgroups spread their atomics over this many accumulator sets (same-address atomics serialise)
+constexpr int STAT_W = 128;           // statistics columns per launch (EdgeConv layers use <= 32, the BatchNorm MLPs up to 128)
+constexpr int STAT_DOUBLES = STAT_COPIES * 2 * STAT_W + 1;
 
 // s0 / s1: this lane's sums for column (lane & 15) of each 16-column tile; `first`: the column that maps to statistics
-// column 0; ncol <= 32
+// column 0; ncol <= STAT_W.  red: 4 * 2 * STAT_W floats of LDS.
 template <int NT>
 __device__ __forceinline__ void stat_flush(float (&s0)[NT], float (&s1)[NT], int first, int ncol, const StatFin& f, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -86,24 +88,25 @@ __device__ __forceinline__ void stat_flush(float (&s0)[NT], float (&s1)[NT], int
         s0[nt] += __shfl_xor(s0[nt], 16); s0[nt] += __shfl_xor(s0[nt], 32);
         s1[nt] += __shfl_xor(s1[nt], 16); s1[nt] += __shfl_xor(s1[nt], 32);
     }
-    if (lane < 16) {                                                  // red[wave][2][32]
+    if (lane < 16) {                                                  // red[wave][2][STAT_W]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int c = nt * 16 + lane - first;
-            if (c >= 0 && c < ncol) { red[wave * 64 + c] = s0[nt]; red[wave * 64 + 32 + c] = s1[nt]; }
+            if (c >= 0 && c < ncol) { red[wave * 2 * STAT_W + c] = s0[nt]; red[wave * 2 * STAT_W + STAT_W + c] = s1[nt]; }
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64 && (threadIdx.x & 31) < ncol) {
-        const float v = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
-        unsafeAtomicAdd(f.acc + (blockIdx.x % STAT_COPIES) * 64 + threadIdx.x, (double)v);
+    if ((threadIdx.x & (STAT_W - 1)) < ncol) {                        // 256 threads = 2 x STAT_W sums
+        const int t = threadIdx.x;
+        const float v = (red[t] + red[2 * STAT_W + t]) + (red[4 * STAT_W + t] + red[6 * STAT_W + t]);
+        unsafeAtomicAdd(f.acc + (blockIdx.x % STAT_COPIES) * 2 * STAT_W + t, (double)v);
     }
     // order the accumulator atomics before the arrival count WITHOUT a release fence: a device-scope fence writes the whole
     // L2 back on this multi-die part (tens of microseconds per launch); the atomics themselves are performed at the coherent
     // level, so waiting for their acknowledgement is enough
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned* counter = reinterpret_cast<unsigned*>(f.acc + STAT_COPIES * 64);
+    unsigned* counter = reinterpret_cast<unsigned*>(f.acc + STAT_COPIES * 2 * STAT_W);
     if (threadIdx.x == 0) red[0] = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1.f : 0.f;
     __syncthreads();
     if (red[0] == 0.f) return;
@@ -111,9 +114,9 @@ __device__ __forceinline__ void stat_flush(float (&s0)[NT], float (&s1)[NT], int
     if (c < ncol) {
         double a0 = 0.0, a1 = 0.0;
         for (int k = 0; k < STAT_COPIES; ++k) {
-            a0 += __hip_atomic_load(f.acc + k * 64 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a1 += __hip_atomic_load(f.acc + k * 64 + 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            f.acc[k * 64 + c] = 0.0; f.acc[k * 64 + 32 + c] = 0.0;
+            a0 += __hip_atomic_load(f.acc + k * 2 * STAT_W + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a1 += __hip_atomic_load(f.acc + k * 2 * STAT_W + STAT_W + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f.acc[k * 2 * STAT_W + c] = 0.0; f.acc[k * 2 * STAT_W + STAT_W + c] = 0.0;
         }
         if (f.mode == 1) {
             const double mean = a0 / f.R;
@@ -161,7 +164,7 @@ struct EcFwdArgs {
 template <int NT, bool OUT, bool POOL>
 __global__ __launch_bounds__(256) void ec_fwd_kernel(EcFwdArgs a) {
     extern __shared__ float lds[];
-    __shared__ float red[256];
+    __shared__ float red[8 * STAT_W];
     const int kin16 = (a.kin + 15) & ~15, kp = kin16 + 4, KS = kin16 / 16;
     float* Wl = lds;
     float* al = lds + NT * 16 * kp;
@@ -303,7 +306,7 @@ struct EcBwdArgs {
 template <int NT, int SRC>
 __global__ __launch_bounds__(256) void ec_bwd_kernel(EcBwdArgs a) {
     extern __shared__ float lds[];
-    __shared__ float red[256];
+    __shared__ float red[8 * STAT_W];
     const int kin16 = (a.kin + 15) & ~15, kp = kin16 + 4, KS = kin16 / 16;
     float* Wt = lds;                                   // Wt[u][c]
     float* cf = lds + NT * 16 * kp;                    // SRC 2: [6][kin16] scale, shift, mean, rstd, m1, m2 of the source layer
@@ -762,7 +765,7 @@ extern "C" int pf_ec_train_fwd(const PfEcTrain* p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const EcConvs cv = ec_convs(p, d);
     float* gws = p->ws + (long long)d.nchunk * d.S * (d.GT + 1);
-    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * (STAT_COPIES * 64 + 1), s);
+    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * STAT_DOUBLES, s);
     hipLaunchKernelGGL(ec_fold_kernel, dim3((d.S * p->C + 255) / 256), dim3(256), 0, s, cv, p->Wpq, p->bpq);
     st = pf_gemm(p->x, p->C, 1, p->Wpq, 1, p->C, p->PQ, 2 * d.S, p->bpq, d.T, 2 * d.S, p->C, gws,
                  pf_gemm_ws_floats(d.T, 2 * d.S, p->C), stream);
@@ -817,7 +820,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     float* dwpart = p->ws;
     float* bpart = dwpart + (long long)d.nchunk * d.S * d.GT;
     float* gws = bpart + (long long)d.nchunk * d.S;
-    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * (STAT_COPIES * 64 + 1), s);
+    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * STAT_DOUBLES, s);
     (void)hipMemsetAsync(p->dPQ, 0, sizeof(float) * (size_t)d.T * 2 * d.S, s);
 
     // ---- conv_out: dA = dYout Wg_out (+ sums of the last growth layer)
@@ -882,5 +885,526 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     int total = 0;
     for (int t = 0; t < d.nconvs; ++t) total += cv.rows[t] * cv.width[t];
     hipLaunchKernelGGL(ec_assemble_kernel, dim3((total + 63) / 64), dim3(256), 0, s, cv, p->dWpq, dwpart, d.nchunk, bpart, total);
+    return pf_last_launch_status();
+}
+
+// =====================================================================================================================
+// BatchNorm MLPs of the interpolation module in the training step: DistanceEncoder and WeightEstimationUnit
+// (modules/discrete/interpflow.py:85-151: Conv2d 1x1 + BatchNorm2d + LeakyReLU(0.01), twice, then Conv2d 1x1) on the
+// [B N K, C] edge rows.  Same construction as the EdgeConv unit above, minus the neighbour gather: a layer's kernel applies
+// the PREVIOUS layer's BatchNorm + LeakyReLU on load, stores its own pre-BatchNorm output and leaves the column sums in the
+// epilogue (finalised by the last workgroup); the backward forms BatchNorm-backward on load.  The weight unit's input
+// cat[d, feat] (256 wide) is never built: the first layer runs as two K-passes over the two tensors.
+// =====================================================================================================================
+namespace {
+
+struct BnlFwdArgs {
+    const float* X; int ldx, kin;              // input rows [rows, ldx], kin <= 128 columns used
+    const float* sc; const float* sh;          // BatchNorm scale / shift of the producing layer (nullable: raw input)
+    float slope;
+    const float* W; int ldw;                   // W[c * ldw + u], c < nout, u < kin (already offset to this K-slice)
+    const float* bias;                         // nullable
+    float* out; int nout;                      // [rows, nout]
+    int accum;                                 // out += (second K-pass)
+    int rows, ntiles;
+    int want_stats;
+    StatFin fin;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float red[8 * STAT_W];
+    const int kin16 = (a.kin + 15) & ~15, kp = kin16 + 4, KS = kin16 / 16;
+    float* Wl = lds;
+    float* al = lds + NT * 16 * kp;
+    float* bl = al + kin16;
+    for (int c = threadIdx.x >> 4; c < NT * 16; c += 16) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = (threadIdx.x & 15) + 16 * k;
+            v[k] = (u < kin16 && c < a.nout && u < a.kin) ? a.W[(size_t)c * a.ldw + u] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = (threadIdx.x & 15) + 16 * k;
+            if (u < kin16) Wl[c * kp + u] = v[k];
+        }
+    }
+    for (int i = threadIdx.x; i < kin16; i += 256) {
+        al[i] = i < a.kin ? (a.sc ? a.sc[i] : 1.f) : 0.f;
+        bl[i] = (i < a.kin && a.sh) ? a.sh[i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    const bool vec = (a.kin & 3) == 0 && (a.ldx & 3) == 0;
+    const float slope = a.sc ? a.slope : 1.f;                     // raw input: identity
+    float s0[NT], s1[NT], bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s0[nt] = s1[nt] = 0.f;
+        const int col = nt * 16 + row;
+        bv[nt] = (a.bias && col < a.nout) ? a.bias[col] : 0.f;
+    }
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
+        const int r0 = tile * 16;
+        const int rr = min(r0 + row, a.rows - 1);
+        const float* xrow = a.X + (size_t)rr * a.ldx;
+        f4 xv[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            xv[ks] = pf_splat(0.f);
+            const int u = ks * 16 + 4 * q;
+            if (ks < KS && u < a.kin) {
+                if (vec) xv[ks] = *reinterpret_cast<const f4*>(xrow + u);
+                else {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        if (u + w < a.kin) xv[ks][w] = xrow[u + w];
+                }
+            }
+        }
+        f4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = pf_splat(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks < KS) {
+                const int u = ks * 16 + 4 * q;
+                const f4 av = lrelu4(xv[ks] * *reinterpret_cast<const f4*>(al + u) + *reinterpret_cast<const f4*>(bl + u), slope);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = mfma4(av, *reinterpret_cast<const f4*>(Wl + (nt * 16 + row) * kp + u), acc[nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = nt * 16 + row;
+            if (col < a.nout) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rw = r0 + 4 * q + r;
+                    if (rw < a.rows) {
+                        float* op = a.out + (size_t)rw * a.nout + col;
+                        float v = acc[nt][r] + bv[nt];
+                        if (a.accum) v += *op;
+                        *op = v;
+                        s0[nt] += v; s1[nt] = fmaf(v, v, s1[nt]);
+                    }
+                }
+            }
+        }
+    }
+    if (a.want_stats) stat_flush<NT>(s0, s1, 0, a.nout, a.fin, red);
+}
+
+// backward through one layer.  SRC 1: dy [rows, kin] dense (the last layer, or a later K-pass of an already converted buffer);
+// SRC 2: dy = BatchNorm + LeakyReLU backward of dbuf (gradient wrt the layer's ACTIVATED output), formed on load and stored
+// back in place.  dx [rows, nout] = dy W (nullable: conversion only); epilogue: BatchNorm-backward sums of the layer that
+// produced this layer's input (pre-BN values xpre, constants aff_prev), when that layer has one.
+struct BnlBwdArgs {
+    const float* dy;
+    float* dbuf; const float* ypre; const float* aff; const float* coef;
+    int kin; float slope;
+    const float* W; int ldw;                   // W[c * ldw + u], c < kin, u < nout
+    float* dx; int nout;
+    const float* xpre; const float* aff_prev; int want_stats;
+    int rows, ntiles;
+    StatFin fin;
+};
+
+template <int NT, int SRC>
+__global__ __launch_bounds__(256) void bnl_bwd_kernel(BnlBwdArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float red[8 * STAT_W];
+    const int kin16 = (a.kin + 15) & ~15, kp = kin16 + 4, KS = kin16 / 16;
+    float* Wt = lds;                                   // Wt[u][c]
+    float* cf = lds + NT * 16 * kp;                    // SRC 2: [6][kin16]
+    if (a.dx)
+        for (int c = threadIdx.x >> 4; c < kin16; c += 16) {
+            float v[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int u = (threadIdx.x & 15) + 16 * k;
+                v[k] = (c < a.kin && u < a.nout) ? a.W[(size_t)c * a.ldw + u] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < NT; ++k) Wt[((threadIdx.x & 15) + 16 * k) * kp + c] = v[k];
+        }
+    if (SRC == 2) {
+        for (int i = threadIdx.x; i < kin16; i += 256) {
+            const bool ok = i < a.kin;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) cf[w * kin16 + i] = ok ? a.aff[w * a.kin + i] : 0.f;
+            cf[4 * kin16 + i] = ok ? a.coef[i] : 0.f;
+            cf[5 * kin16 + i] = ok ? a.coef[a.kin + i] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    float s0[NT], s1[NT], ssc[NT], ssh[NT], smu[NT], srs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s0[nt] = s1[nt] = 0.f;
+        const int col = nt * 16 + row;
+        const bool ok = a.want_stats && col < a.nout;
+        ssc[nt] = ok ? a.aff_prev[col] : 0.f;
+        ssh[nt] = ok ? a.aff_prev[a.nout + col] : 0.f;
+        smu[nt] = ok ? a.aff_prev[2 * a.nout + col] : 0.f;
+        srs[nt] = ok ? a.aff_prev[3 * a.nout + col] : 0.f;
+    }
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
+        const int r0 = tile * 16;
+        const int rr = min(r0 + row, a.rows - 1);
+        const bool rok = r0 + row < a.rows;
+        f4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = pf_splat(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks < KS) {
+                const int c = ks * 16 + 4 * q;
+                f4 av = pf_splat(0.f);
+                if (c < a.kin && rok) {
+                    if (SRC == 1) av = *reinterpret_cast<const f4*>(a.dy + (size_t)rr * a.kin + c);
+                    else {
+                        float* dp = a.dbuf + (size_t)rr * a.kin + c;
+                        const f4 d = *reinterpret_cast<const f4*>(dp);
+                        const f4 y = *reinterpret_cast<const f4*>(a.ypre + (size_t)rr * a.kin + c);
+                        const f4 sc = *reinterpret_cast<const f4*>(cf + c), sh = *reinterpret_cast<const f4*>(cf + kin16 + c);
+                        const f4 mu = *reinterpret_cast<const f4*>(cf + 2 * kin16 + c), rs = *reinterpret_cast<const f4*>(cf + 3 * kin16 + c);
+                        const f4 m1 = *reinterpret_cast<const f4*>(cf + 4 * kin16 + c), m2 = *reinterpret_cast<const f4*>(cf + 5 * kin16 + c);
+                        const f4 z = y * sc + sh;
+                        const f4 xh = (y - mu) * rs;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const float dz = d[w] * (z[w] > 0.f ? 1.f : a.slope);
+                            av[w] = sc[w] * (dz - m1[w] - xh[w] * m2[w]);
+                        }
+                        *reinterpret_cast<f4*>(dp) = av;
+                    }
+                }
+                if (a.dx)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = mfma4(av, *reinterpret_cast<const f4*>(Wt + (nt * 16 + row) * kp + c), acc[nt]);
+            }
+        }
+        if (a.dx)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = nt * 16 + row;
+                if (col < a.nout) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rw = r0 + 4 * q + r;
+                        if (rw < a.rows) {
+                            const float v = acc[nt][r];
+                            a.dx[(size_t)rw * a.nout + col] = v;
+                            if (a.want_stats) {
+                                const float y = a.xpre[(size_t)rw * a.nout + col];
+                                const float dz = v * (fmaf(y, ssc[nt], ssh[nt]) > 0.f ? 1.f : a.slope);
+                                s0[nt] += dz;
+                                s1[nt] = fmaf(dz, (y - smu[nt]) * srs[nt], s1[nt]);
+                            }
+                        }
+                    }
+                }
+            }
+    }
+    if (a.want_stats) stat_flush<NT>(s0, s1, 0, a.nout, a.fin, red);
+}
+
+// part[chunk][c][u] = sum over the chunk's rows of dy[row, c] * act(X[row, u]) (c < RA, u < RB), bpart[chunk][c] = sum dy
+struct BnlDwArgs {
+    const float* dy; int RA;                   // [rows, RA]
+    const float* X; int ldx, RB;               // [rows, ldx], RB columns used
+    const float* sc; const float* sh; float slope;
+    int rows, chunk;
+    float* part; float* bpart;                 // [nchunk][RA16][RB16], [nchunk][RA16]
+};
+__global__ __launch_bounds__(256) void bnl_dw_kernel(BnlDwArgs a) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    const int RA = (a.RA + 15) & ~15, RB = (a.RB + 15) & ~15;
+    const int lda = RA + 16, ldb = RB + 16;
+    float* As = lds;
+    float* Bs = lds + DW_EB * lda;
+    const int NT = RB / 16, NRT = RA / 16;
+    const int WC = NT < 4 ? NT : 4, rstep = 4 / (WC == 3 ? 4 : WC), rbase = wave / (WC == 3 ? 4 : WC);
+    int ctj[2];
+    bool cval[2];
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc) { ctj[jc] = wave % (WC == 3 ? 4 : WC) + (WC == 3 ? 4 : WC) * jc; cval[jc] = ctj[jc] < NT; }
+    bool val[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc) val[s][jc] = rbase + rstep * s < NRT && cval[jc];
+    f4 acc[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { acc[s][0] = pf_splat(0.f); acc[s][1] = pf_splat(0.f); }
+    const int r_lo = blockIdx.x * a.chunk, r_hi = min(a.rows, r_lo + a.chunk);
+    const int ra4 = RA / 4, rb4 = RB / 4;
+    constexpr int UN = 4;
+    int elA[UN], cA[UN], elB[UN], cB[UN];
+#pragma unroll
+    for (int n = 0; n < UN; ++n) {
+        const int k = threadIdx.x + 256 * n;
+        elA[n] = k / ra4; cA[n] = (k - elA[n] * ra4) * 4;
+        elB[n] = k / rb4; cB[n] = (k - elB[n] * rb4) * 4;
+    }
+    const bool veca = (a.RA & 3) == 0, vecb = (a.RB & 3) == 0 && (a.ldx & 3) == 0;
+    const float slope = a.sc ? a.slope : 1.f;
+    f4 ra[UN], rbv[UN];
+    auto fetch = [&](int rb) {
+#pragma unroll
+        for (int n = 0; n < UN; ++n) {
+            f4 v = pf_splat(0.f);
+            const int r = rb + elA[n], c = cA[n];
+            if (elA[n] < DW_EB && r < r_hi && c < a.RA) {
+                if (veca) v = *reinterpret_cast<const f4*>(a.dy + (size_t)r * a.RA + c);
+                else
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        if (c + w < a.RA) v[w] = a.dy[(size_t)r * a.RA + c + w];
+            }
+            ra[n] = v;
+        }
+#pragma unroll
+        for (int n = 0; n < UN; ++n) {
+            f4 v = pf_splat(0.f);
+            const int r = rb + elB[n], c = cB[n];
+            if (elB[n] < DW_EB && r < r_hi && c < a.RB) {
+                f4 x = pf_splat(0.f), s1 = pf_splat(1.f), s2 = pf_splat(0.f);
+                if (vecb) x = *reinterpret_cast<const f4*>(a.X + (size_t)r * a.ldx + c);
+                else
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        if (c + w < a.RB) x[w] = a.X[(size_t)r * a.ldx + c + w];
+                if (a.sc)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        if (c + w < a.RB) { s1[w] = a.sc[c + w]; s2[w] = a.sh[c + w]; }
+                v = lrelu4(x * s1 + s2, slope);
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (c + w >= a.RB) v[w] = 0.f;
+            }
+            rbv[n] = v;
+        }
+    };
+    float bsum = 0.f;
+    fetch(r_lo);
+    for (int rb = r_lo; rb < r_hi; rb += DW_EB) {
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < UN; ++n) {
+            if (elA[n] < DW_EB) *reinterpret_cast<f4*>(As + elA[n] * lda + cA[n]) = ra[n];
+            if (elB[n] < DW_EB) *reinterpret_cast<f4*>(Bs + elB[n] * ldb + cB[n]) = rbv[n];
+        }
+        __syncthreads();
+        if (rb + DW_EB < r_hi) fetch(rb + DW_EB);
+        if (threadIdx.x < RA)
+#pragma unroll 8
+            for (int el = 0; el < DW_EB; ++el) bsum += As[el * lda + threadIdx.x];
+#pragma unroll
+        for (int ks = 0; ks < DW_EB / 4; ++ks) {
+            const float* ar = As + (4 * ks + q) * lda + row + rbase * 16;
+            const float* br = Bs + (4 * ks + q) * ldb + row;
+            const float b0 = cval[0] ? br[ctj[0] * 16] : 0.f, b1 = cval[1] ? br[ctj[1] * 16] : 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (val[s][0] || val[s][1]) {
+                    const float av = ar[rstep * s * 16];
+                    if (val[s][0]) acc[s][0] = pf_mfma(av, b0, acc[s][0]);
+                    if (val[s][1]) acc[s][1] = pf_mfma(av, b1, acc[s][1]);
+                }
+            }
+        }
+    }
+    if (threadIdx.x < RA) a.bpart[(size_t)blockIdx.x * RA + threadIdx.x] = bsum;
+    float* out = a.part + (size_t)blockIdx.x * RA * RB;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc)
+            if (val[s][jc])
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(size_t)((rbase + rstep * s) * 16 + 4 * q + r) * RB + ctj[jc] * 16 + row] = acc[s][jc][r];
+}
+
+// dW[c * ldw + coff + u] = sum_chunks part[k][c][u] (c < RA, u < RB); db[c] = sum_chunks bpart[k][c] (db nullable)
+__global__ __launch_bounds__(256) void bnl_reduce_kernel(const float* part, const float* bpart, int nchunk, int RA, int RB, int RA16,
+                                                         int RB16, float* dW, int ldw, int coff, float* db) {
+    __shared__ double shr[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    const int total = RA * (RB + 1);
+    const bool ok = i < total;
+    const int c = ok ? i / (RB + 1) : 0, u = ok ? i % (RB + 1) : 0;
+    double s = 0.0;
+    if (ok) {
+        if (u == RB) { for (int k = ty; k < nchunk; k += 4) s += (double)bpart[(size_t)k * RA16 + c]; }
+        else for (int k = ty; k < nchunk; k += 4) s += (double)part[((size_t)k * RA16 + c) * RB16 + u];
+    }
+    shr[ty][tx] = s;
+    __syncthreads();
+    if (ty != 0 || !ok) return;
+    s = (shr[0][tx] + shr[1][tx]) + (shr[2][tx] + shr[3][tx]);
+    if (u == RB) { if (db) db[c] = (float)s; }
+    else dW[(size_t)c * ldw + coff + u] = (float)s;
+}
+
+constexpr int BNL_CHUNK = 256;
+
+int bnl_check(const PfBnMlpTrain* p) {
+    if (!p) return PF_ERR_NULL;
+    if (p->rows < 16 || (p->nl != 2 && p->nl != 3)) return PF_ERR_SHAPE;
+    if (p->kin0a < 1 || p->kin0a > 128 || p->kin0b < 0 || p->kin0b > 128) return PF_ERR_UNSUPPORTED;
+    if (p->kin0b > 0 && (p->kin0a & 3)) return PF_ERR_UNSUPPORTED;
+    for (int l = 0; l < p->nl; ++l) {
+        if (p->width[l] < 16 || p->width[l] > 128 || p->width[l] % 16 != 0) return PF_ERR_UNSUPPORTED;
+        if (!p->W[l] || !p->y[l]) return PF_ERR_NULL;
+    }
+    for (int l = 0; l < p->nl - 1; ++l)
+        if (!p->gamma[l] || !p->beta[l] || !p->aff[l]) return PF_ERR_NULL;
+    if (!p->xa || (p->kin0b > 0 && !p->xb) || !p->stat) return PF_ERR_NULL;
+    return PF_OK;
+}
+inline int bnl_nt(int w) { const int n = (w + 15) / 16; return n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8)); }
+
+template <int NT>
+void bnl_fwd_launch(const BnlFwdArgs& a, int grid, hipStream_t s) {
+    const int kin16 = (a.kin + 15) & ~15;
+    const size_t lds = sizeof(float) * ((size_t)NT * 16 * (kin16 + 4) + 2 * kin16);
+    allow_lds(bnl_fwd_kernel<NT>, lds);
+    hipLaunchKernelGGL(bnl_fwd_kernel<NT>, dim3(grid), dim3(256), lds, s, a);
+}
+void bnl_fwd_dispatch(const BnlFwdArgs& a, int grid, hipStream_t s) {
+    switch (bnl_nt(a.nout)) {
+        case 1: bnl_fwd_launch<1>(a, grid, s); break;
+        case 2: bnl_fwd_launch<2>(a, grid, s); break;
+        case 4: bnl_fwd_launch<4>(a, grid, s); break;
+        default: bnl_fwd_launch<8>(a, grid, s); break;
+    }
+}
+template <int NT, int SRC>
+void bnl_bwd_launch(const BnlBwdArgs& a, int grid, hipStream_t s) {
+    const int kin16 = (a.kin + 15) & ~15;
+    const size_t lds = sizeof(float) * ((size_t)NT * 16 * (kin16 + 4) + 6 * kin16);
+    allow_lds(bnl_bwd_kernel<NT, SRC>, lds);
+    hipLaunchKernelGGL((bnl_bwd_kernel<NT, SRC>), dim3(grid), dim3(256), lds, s, a);
+}
+void bnl_bwd_dispatch(const BnlBwdArgs& a, int src, int grid, hipStream_t s) {
+    const int nt = a.dx ? bnl_nt(a.nout) : 1;
+#define PF_BNLB(NT) do { if (src == 1) bnl_bwd_launch<NT, 1>(a, grid, s); else bnl_bwd_launch<NT, 2>(a, grid, s); } while (0)
+    switch (nt) {
+        case 1: PF_BNLB(1); break;
+        case 2: PF_BNLB(2); break;
+        case 4: PF_BNLB(4); break;
+        default: PF_BNLB(8); break;
+    }
+#undef PF_BNLB
+}
+
+}  // namespace
+
+extern "C" long long pf_bnmlp_train_ws_floats(const PfBnMlpTrain* p) {
+    if (!p || p->rows < 16) return -1;
+    const long long nchunk = (p->rows + BNL_CHUNK - 1) / BNL_CHUNK;
+    return nchunk * (128ll * 128 + 128);
+}
+
+extern "C" int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream) {
+    int st = bnl_check(p);
+    if (st) return st;
+    hipStream_t s = (hipStream_t)stream;
+    const int ntiles = (p->rows + 15) / 16;
+    const int grid = (ntiles + 3) / 4 < EC_GRID ? (ntiles + 3) / 4 : EC_GRID;
+    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * STAT_DOUBLES, s);
+    const int in0 = p->kin0a + p->kin0b;
+    for (int l = 0; l < p->nl; ++l) {
+        const bool bn = l < p->nl - 1;
+        BnlFwdArgs a{};
+        a.slope = p->slope; a.out = p->y[l]; a.nout = p->width[l]; a.rows = p->rows; a.ntiles = ntiles;
+        if (bn) a.fin = StatFin{p->stat, 1, p->width[l], 0, p->width[l], p->aff[l], p->gamma[l], p->beta[l], p->run_mean[l],
+                                p->run_var[l], p->eps, p->momentum, nullptr, nullptr, nullptr, (double)p->rows};
+        if (l == 0) {
+            a.X = p->xa; a.ldx = p->kin0a; a.kin = p->kin0a; a.W = p->W[0]; a.ldw = in0; a.bias = p->b[0];
+            a.want_stats = bn && p->kin0b == 0;
+            bnl_fwd_dispatch(a, grid, s);
+            if (p->kin0b > 0) {
+                a.X = p->xb; a.ldx = p->kin0b; a.kin = p->kin0b; a.W = p->W[0] + p->kin0a; a.bias = nullptr; a.accum = 1;
+                a.want_stats = bn;
+                bnl_fwd_dispatch(a, grid, s);
+            }
+        } else {
+            a.X = p->y[l - 1]; a.ldx = p->width[l - 1]; a.kin = p->width[l - 1];
+            a.sc = p->aff[l - 1]; a.sh = p->aff[l - 1] + p->width[l - 1];
+            a.W = p->W[l]; a.ldw = p->width[l - 1]; a.bias = p->b[l]; a.want_stats = bn;
+            bnl_fwd_dispatch(a, grid, s);
+        }
+    }
+    return pf_last_launch_status();
+}
+
+extern "C" int pf_bnmlp_train_bwd(const PfBnMlpTrain* p, void* stream) {
+    int st = bnl_check(p);
+    if (st) return st;
+    if (!p->dout || !p->ws) return PF_ERR_NULL;
+    for (int l = 0; l < p->nl; ++l)
+        if (!p->dW[l]) return PF_ERR_NULL;
+    for (int l = 0; l < p->nl - 1; ++l)
+        if (!p->d[l] || !p->coef[l] || !p->dgamma[l] || !p->dbeta[l]) return PF_ERR_NULL;
+    if (p->ws_floats < pf_bnmlp_train_ws_floats(p)) return PF_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int ntiles = (p->rows + 15) / 16;
+    const int grid = (ntiles + 3) / 4 < EC_GRID ? (ntiles + 3) / 4 : EC_GRID;
+    const int nchunk = (p->rows + BNL_CHUNK - 1) / BNL_CHUNK;
+    float* part = p->ws;
+    float* bpart = p->ws + (size_t)nchunk * 128 * 128;
+    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * STAT_DOUBLES, s);
+    const int in0 = p->kin0a + p->kin0b;
+    auto dw = [&](const float* dy, int RA, const float* X, int ldx, int RB, const float* sc, const float* sh, float* dW, int ldw,
+                  int coff, float* db) {
+        const int RA16 = (RA + 15) & ~15, RB16 = (RB + 15) & ~15;
+        BnlDwArgs a{dy, RA, X, ldx, RB, sc, sh, p->slope, p->rows, BNL_CHUNK, part, bpart};
+        const size_t lds = sizeof(float) * (size_t)DW_EB * ((RA16 + 16) + (RB16 + 16));
+        hipLaunchKernelGGL(bnl_dw_kernel, dim3(nchunk), dim3(256), lds, s, a);
+        const int total = RA * (RB + 1);
+        hipLaunchKernelGGL(bnl_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, part, bpart, nchunk, RA, RB, RA16, RB16, dW,
+                           ldw, coff, db);
+    };
+    for (int l = p->nl - 1; l >= 0; --l) {
+        const bool bn = l < p->nl - 1;
+        const float* dyl = bn ? p->d[l] : p->dout;          // after the kernel below: the gradient wrt this layer's pre-BN output
+        BnlBwdArgs a{};
+        a.kin = p->width[l]; a.slope = p->slope; a.rows = p->rows; a.ntiles = ntiles;
+        if (bn) { a.dbuf = p->d[l]; a.ypre = p->y[l]; a.aff = p->aff[l]; a.coef = p->coef[l]; }
+        else a.dy = p->dout;
+        if (l > 0) {
+            a.W = p->W[l]; a.ldw = p->width[l - 1]; a.dx = p->d[l - 1]; a.nout = p->width[l - 1];
+            a.xpre = p->y[l - 1]; a.aff_prev = p->aff[l - 1]; a.want_stats = 1;
+            a.fin = StatFin{p->stat, 2, p->width[l - 1], 0, p->width[l - 1], nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f,
+                            p->coef[l - 1], p->dgamma[l - 1], p->dbeta[l - 1], (double)p->rows};
+            bnl_bwd_dispatch(a, bn ? 2 : 1, grid, s);
+            dw(dyl, p->width[l], p->y[l - 1], p->width[l - 1], p->width[l - 1], p->aff[l - 1], p->aff[l - 1] + p->width[l - 1],
+               p->dW[l], p->width[l - 1], 0, p->db[l]);
+        } else {
+            // first layer: one pass per input tensor; the first pass also converts d[0] in place
+            a.W = p->W[0]; a.ldw = in0; a.dx = p->dxa; a.nout = p->kin0a;
+            if (bn || p->dxa) bnl_bwd_dispatch(a, bn ? 2 : 1, grid, s);
+            if (p->kin0b > 0 && p->dxb) {
+                BnlBwdArgs b2 = a;
+                b2.dy = dyl; b2.dbuf = nullptr; b2.W = p->W[0] + p->kin0a; b2.dx = p->dxb; b2.nout = p->kin0b;
+                bnl_bwd_dispatch(b2, 1, grid, s);
+            }
+            dw(dyl, p->width[0], p->xa, p->kin0a, p->kin0a, nullptr, nullptr, p->dW[0], in0, 0, p->db[0]);
+            if (p->kin0b > 0) dw(dyl, p->width[0], p->xb, p->kin0b, p->kin0b, nullptr, nullptr, p->dW[0], in0, p->kin0a, nullptr);
+        }
+    }
     return pf_last_launch_status();
 }

@@ -26,7 +26,7 @@ namespace {
 
 constexpr int MLP_GRID = 512;
 constexpr int MLP_EB = 32, MLP_SLOTS = 9;
-__host__ __device__ inline int mlp_chunk(int rows) { return rows > 16384 ? 256 : 128; }      // rows per split-K chunk (multiple of MLP_EB)
+__host__ __device__ inline int mlp_chunk(int rows) { return rows > 16384 ? 128 : 64; }      // rows per split-K chunk (multiple of MLP_EB)
 
 __device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 c) {
     c = pf_mfma(a.x, b.x, c); c = pf_mfma(a.y, b.y, c); c = pf_mfma(a.z, b.z, c); c = pf_mfma(a.w, b.w, c);

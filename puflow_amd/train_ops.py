@@ -57,11 +57,11 @@ _STAT = {}
 
 
 def _stat(dev) -> Tensor:
-    """1025 doubles per (device, stream): the column-statistics accumulators of the fused training kernels."""
+    """4097 doubles (PF_TRAIN_STAT_DOUBLES) per (device, stream): the column-statistics accumulators of the fused training kernels."""
     key = (dev, _stream())
     t = _STAT.get(key)
     if t is None:
-        t = torch.zeros(1025, dtype=torch.float64, device=dev)
+        t = torch.zeros(4097, dtype=torch.float64, device=dev)
         _STAT[key] = t
     return t
 
@@ -911,6 +911,98 @@ class MlpFn(Function):
         return (dy, dc, None, None, None, *grads)
 
 
+class BnMlpFn(Function):
+    """[Conv2d 1x1 + BatchNorm2d(train) + LeakyReLU] x 2 + Conv2d 1x1 on rows (DistanceEncoder / WeightEstimationUnit,
+    interpflow.py:85-151) on cat[xa, xb] without building it: 3-4 launches forward, ~10 backward (csrc/train_fused.hip).
+    apply(xa, xb | None, cfg, W0, b0, W1, b1, W2, b2, gamma0, beta0, gamma1, beta1)"""
+
+    @staticmethod
+    def _desc(xa, xb, cfg, Ws):
+        slope, eps, momentum, rmeans, rvars = cfg
+        d = _lib.PfBnMlpTrain()
+        d.rows, d.nl = xa.shape[0], len(Ws)
+        d.kin0a, d.kin0b = xa.shape[1], (xb.shape[1] if xb is not None else 0)
+        for l, w in enumerate(Ws):
+            d.width[l] = w.shape[0]
+            d.W[l] = w.data_ptr()
+        d.slope, d.eps, d.momentum = slope, eps, momentum
+        d.xa, d.xb = xa.data_ptr(), _ptr(xb)
+        return d
+
+    @staticmethod
+    def forward(ctx, xa, xb, cfg, *prm):
+        lib = _lib.load()
+        slope, eps, momentum, rmeans, rvars = cfg
+        xa = xa.contiguous()
+        xb = xb.contiguous() if xb is not None else None
+        Ws = [w.contiguous() for w in prm[0:6:2]]
+        bs = [b.contiguous() for b in prm[1:6:2]]
+        gb = [g.contiguous() for g in prm[6:10]]
+        dev = xa.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        d = BnMlpFn._desc(xa, xb, cfg, Ws)
+        ys = [torch.empty((xa.shape[0], w.shape[0]), **f32) for w in Ws]
+        affs = [torch.empty((4, Ws[l].shape[0]), **f32) for l in range(2)]
+        for l in range(3):
+            d.b[l], d.y[l] = bs[l].data_ptr(), ys[l].data_ptr()
+        for l in range(2):
+            d.gamma[l], d.beta[l], d.aff[l] = gb[2 * l].data_ptr(), gb[2 * l + 1].data_ptr(), affs[l].data_ptr()
+            d.run_mean[l], d.run_var[l] = _ptr(rmeans[l]), _ptr(rvars[l])
+        d.stat = _stat(dev).data_ptr()
+        _lib.check(lib.pf_bnmlp_train_fwd(ctypes.byref(d), _stream()), "pf_bnmlp_train_fwd")
+        ctx.cfg, ctx.has_b = cfg, xb is not None
+        ctx.save_for_backward(xa, *(() if xb is None else (xb,)), *Ws, *ys, *affs, gb[0], gb[2])
+        return ys[2]
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        sv = list(ctx.saved_tensors)
+        xa = sv[0]
+        xb = sv[1] if ctx.has_b else None
+        o = 2 if ctx.has_b else 1
+        Ws, ys, affs, gam = sv[o:o + 3], sv[o + 3:o + 6], sv[o + 6:o + 8], sv[o + 8:o + 10]
+        dev = xa.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dout = dout.contiguous()
+        d = BnMlpFn._desc(xa, xb, ctx.cfg, Ws)
+        ds = [torch.empty_like(ys[0]), torch.empty_like(ys[1])]
+        coefs = [torch.empty((2, Ws[l].shape[0]), **f32) for l in range(2)]
+        dxa = torch.empty_like(xa) if ctx.needs_input_grad[0] else None
+        dxb = torch.empty_like(xb) if (xb is not None and ctx.needs_input_grad[1]) else None
+        dWs = [torch.empty_like(w) for w in Ws]
+        dbs = [torch.empty((w.shape[0],), **f32) for w in Ws]
+        dgs = [torch.empty((Ws[l].shape[0],), **f32) for l in range(2)]
+        dbe = [torch.empty((Ws[l].shape[0],), **f32) for l in range(2)]
+        for l in range(3):
+            d.y[l], d.dW[l], d.db[l] = ys[l].data_ptr(), dWs[l].data_ptr(), dbs[l].data_ptr()
+        for l in range(2):
+            d.gamma[l], d.beta[l] = gam[l].data_ptr(), gam[l].data_ptr()
+            d.aff[l], d.d[l], d.coef[l] = affs[l].data_ptr(), ds[l].data_ptr(), coefs[l].data_ptr()
+            d.dgamma[l], d.dbeta[l] = dgs[l].data_ptr(), dbe[l].data_ptr()
+        d.dout, d.dxa, d.dxb = dout.data_ptr(), _ptr(dxa), _ptr(dxb)
+        need = lib.pf_bnmlp_train_ws_floats(ctypes.byref(d))
+        ws = _ws(dev, need)
+        d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
+        d.stat = _stat(dev).data_ptr()
+        _lib.check(lib.pf_bnmlp_train_bwd(ctypes.byref(d), _stream()), "pf_bnmlp_train_bwd")
+        return (dxa, dxb, None, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dgs[0], dbe[0], dgs[1], dbe[1])
+
+
+def bnmlp_fused(mlp, xa: Tensor, xb=None) -> Tensor:
+    convs, bns = [mlp[0], mlp[3], mlp[6]], [mlp[1], mlp[4]]
+    cfg = (0.01, float(bns[0].eps), float(bns[0].momentum), [bn.running_mean for bn in bns], [bn.running_var for bn in bns])
+    prm = []
+    for c in convs:
+        prm += [c.weight, c.bias]
+    for bn in bns:
+        prm += [bn.weight, bn.bias]
+    out = BnMlpFn.apply(xa, xb, cfg, *prm)
+    with torch.no_grad():
+        torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+    return out
+
+
 _DESC_BUF = {}
 
 
@@ -1140,9 +1232,13 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     ip = net.interp
     fd = torch.empty((B * N * 8, 10), dtype=torch.float32, device=xyz.device)        # inputs only: no gradient
     _lib.check(_lib.load().pf_dist_feature(xyz.data_ptr(), idx8.data_ptr(), B, N, 8, fd.data_ptr(), _stream()), "pf_dist_feature")
-    d = _mlp_bn(ip.knn_context.distance_encoder.mlp, fd)          # [E8,128]
-    feat = edgeconv_train(ip.knn_context.feat_conv, xyz, idx8, pooling=False)
-    w = _mlp_bn(ip.weight_unit.mlp, torch.cat([d, feat], dim=1))  # [E8,32]
+    fused_bn = _FUSED and not _sync_bn_active()
+    d = bnmlp_fused(ip.knn_context.distance_encoder.mlp, fd) if fused_bn else _mlp_bn(ip.knn_context.distance_encoder.mlp, fd)
+    feat = edgeconv_train(ip.knn_context.feat_conv, xyz, idx8, pooling=False)      # d, feat: [E8,128]
+    if fused_bn:
+        w = bnmlp_fused(ip.weight_unit.mlp, d, feat)              # on cat[d, feat] (interpflow.py:146) without building it
+    else:
+        w = _mlp_bn(ip.weight_unit.mlp, torch.cat([d, feat], dim=1))  # [E8,32]
     zj = GatherRowsFn.apply(z, idx8)                              # [E8,3]
     fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)      # [T,3,R]
     u = fz.transpose(1, 2).reshape(B, N * R, 3)

@@ -166,3 +166,52 @@ def test_mlp_fused_matches_unfused(kind, cc, td, cdiv, rows):
         _close(dy_f, dy_u, "dy", 1e-4)
     for n in g_u:
         _close(g_f[n], g_u[n], n, 1e-4)
+
+
+@pytest.mark.parametrize("two_inputs,rows", [(False, 4096), (True, 4096), (True, 65536)])
+def test_bnmlp_fused_matches_unfused(two_inputs, rows):
+    """The interpolation module's BatchNorm MLPs (csrc/train_fused.hip, pf_bnmlp_train_*) against the un-fused layer kernels:
+    DistanceEncoder (10 -> 64 -> 64 -> 128, input without gradient) and WeightEstimationUnit (cat[128, 128] -> 128 -> 64 -> 32)."""
+    from puflow_amd import train_ops
+    from puflow_amd.interpflow import _InterpParams
+    torch.manual_seed(5 + rows)
+    ip = _InterpParams().cuda().train()
+    mlp = ip.weight_unit.mlp if two_inputs else ip.knn_context.distance_encoder.mlp
+    for m in mlp:
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.3, 0.3)
+    xa0 = torch.randn(rows, 128 if two_inputs else 10, device="cuda")
+    xb0 = torch.randn(rows, 128, device="cuda") if two_inputs else None
+    wout = torch.randn(rows, 32 if two_inputs else 128, device="cuda")
+    # rows with a hidden pre-activation close to the LeakyReLU kink get no output gradient (see test_mlp_fused_matches_unfused)
+    with torch.no_grad():
+        ref = train_ops._mlp_bn(mlp, torch.cat([xa0, xb0], 1) if two_inputs else xa0)
+    def run(fused):
+        for q in mlp.parameters():
+            q.grad = None
+        for m in mlp:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.zero_(); m.running_var.fill_(1.0)
+        xa = xa0.clone().requires_grad_(True)
+        xb = xb0.clone().requires_grad_(True) if two_inputs else None
+        if fused:
+            out = train_ops.bnmlp_fused(mlp, xa, xb)
+        else:
+            out = train_ops._mlp_bn(mlp, torch.cat([xa, xb], 1) if two_inputs else xa)
+        (out * wout).sum().backward()
+        return (out.detach().clone(), xa.grad.clone(), xb.grad.clone() if two_inputs else None,
+                {n: q.grad.clone() for n, q in mlp.named_parameters()},
+                [(m.running_mean.clone(), m.running_var.clone()) for m in mlp if isinstance(m, torch.nn.BatchNorm2d)])
+    o_f, da_f, db_f, g_f, st_f = run(True)
+    o_u, da_u, db_u, g_u, st_u = run(False)
+    _close(o_f, o_u, "output", 2e-5)
+    _close(da_f, da_u, "dxa", 5e-4)
+    if two_inputs:
+        _close(db_f, db_u, "dxb", 5e-4)
+    for n in g_u:
+        if n in ("0.bias", "3.bias"):                 # conv bias in front of a BatchNorm: true gradient zero, rounding noise
+            continue
+        _close(g_f[n], g_u[n], n, 5e-4)
+    for (m_f, v_f), (m_u, v_u) in zip(st_f, st_u):
+        _close(m_f, m_u, "running_mean", 1e-5)
+        _close(v_f, v_u, "running_var", 1e-5)
