@@ -254,7 +254,8 @@ typedef struct PfEcTrain {
     float* dx;                      /* [T, C], nullable */
     float* dW[9]; float* dbias[9]; float* dgamma[8]; float* dbeta[8];
     float* ws; long long ws_floats; /* >= pf_ec_train_ws_floats() */
-    double* stat;                   /* PF_TRAIN_STAT_DOUBLES doubles of scratch (column-statistics accumulators) */
+    double* stat;                   /* PF_TRAIN_STAT_DOUBLES doubles (column-statistics accumulators): zeroed ONCE by the caller,
+                                       every kernel that uses them leaves them zero again */
 } PfEcTrain;
 long long pf_ec_train_ws_floats(const PfEcTrain* p);
 int pf_ec_train_fwd(const PfEcTrain* p, void* stream);
@@ -282,7 +283,7 @@ typedef struct PfBnMlpTrain {
     float* dxa; float* dxb;         /* nullable: [rows, kin0a], [rows, kin0b] */
     float* dW[3]; float* db[3]; float* dgamma[2]; float* dbeta[2];
     float* ws; long long ws_floats; /* >= pf_bnmlp_train_ws_floats() */
-    double* stat;                   /* PF_TRAIN_STAT_DOUBLES doubles */
+    double* stat;                   /* PF_TRAIN_STAT_DOUBLES doubles, zeroed once by the caller (see PfEcTrain) */
 } PfBnMlpTrain;
 long long pf_bnmlp_train_ws_floats(const PfBnMlpTrain* p);
 int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream);

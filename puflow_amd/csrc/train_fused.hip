@@ -669,7 +669,13 @@ __global__ __launch_bounds__(256) void ec_assemble_kernel(EcConvs cv, const floa
     double s = 0.0, sb = 0.0;
     if (ok && grow) {
         const int u = col - 3 * cv.C;
-        for (int k = ty; k < nchunk; k += 4) s += (double)part[((size_t)k * cv.S + srow) * cv.GT + u];
+        int k = ty;
+        for (; k + 12 < nchunk; k += 16) {                            // four loads in flight per thread
+            const float v0 = part[((size_t)k * cv.S + srow) * cv.GT + u], v1 = part[((size_t)(k + 4) * cv.S + srow) * cv.GT + u];
+            const float v2 = part[((size_t)(k + 8) * cv.S + srow) * cv.GT + u], v3 = part[((size_t)(k + 12) * cv.S + srow) * cv.GT + u];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; k < nchunk; k += 4) s += (double)part[((size_t)k * cv.S + srow) * cv.GT + u];
     }
     if (ok && col == 0)
         for (int k = ty; k < nchunk; k += 4) sb += (double)bpart[(size_t)k * cv.S + srow];
@@ -765,7 +771,6 @@ extern "C" int pf_ec_train_fwd(const PfEcTrain* p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const EcConvs cv = ec_convs(p, d);
     float* gws = p->ws + (long long)d.nchunk * d.S * (d.GT + 1);
-    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * STAT_DOUBLES, s);
     hipLaunchKernelGGL(ec_fold_kernel, dim3((d.S * p->C + 255) / 256), dim3(256), 0, s, cv, p->Wpq, p->bpq);
     st = pf_gemm(p->x, p->C, 1, p->Wpq, 1, p->C, p->PQ, 2 * d.S, p->bpq, d.T, 2 * d.S, p->C, gws,
                  pf_gemm_ws_floats(d.T, 2 * d.S, p->C), stream);
@@ -820,7 +825,6 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     float* dwpart = p->ws;
     float* bpart = dwpart + (long long)d.nchunk * d.S * d.GT;
     float* gws = bpart + (long long)d.nchunk * d.S;
-    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * STAT_DOUBLES, s);
     (void)hipMemsetAsync(p->dPQ, 0, sizeof(float) * (size_t)d.T * 2 * d.S, s);
 
     // ---- conv_out: dA = dYout Wg_out (+ sums of the last growth layer)
@@ -1248,7 +1252,15 @@ __global__ __launch_bounds__(256) void bnl_reduce_kernel(const float* part, cons
     double s = 0.0;
     if (ok) {
         if (u == RB) { for (int k = ty; k < nchunk; k += 4) s += (double)bpart[(size_t)k * RA16 + c]; }
-        else for (int k = ty; k < nchunk; k += 4) s += (double)part[((size_t)k * RA16 + c) * RB16 + u];
+        else {
+            int k = ty;
+            for (; k + 12 < nchunk; k += 16) {                        // four loads in flight per thread
+                const float v0 = part[((size_t)k * RA16 + c) * RB16 + u], v1 = part[((size_t)(k + 4) * RA16 + c) * RB16 + u];
+                const float v2 = part[((size_t)(k + 8) * RA16 + c) * RB16 + u], v3 = part[((size_t)(k + 12) * RA16 + c) * RB16 + u];
+                s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+            }
+            for (; k < nchunk; k += 4) s += (double)part[((size_t)k * RA16 + c) * RB16 + u];
+        }
     }
     shr[ty][tx] = s;
     __syncthreads();
@@ -1324,7 +1336,6 @@ extern "C" int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int ntiles = (p->rows + 15) / 16;
     const int grid = (ntiles + 3) / 4 < EC_GRID ? (ntiles + 3) / 4 : EC_GRID;
-    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * STAT_DOUBLES, s);
     const int in0 = p->kin0a + p->kin0b;
     for (int l = 0; l < p->nl; ++l) {
         const bool bn = l < p->nl - 1;
@@ -1366,7 +1377,6 @@ extern "C" int pf_bnmlp_train_bwd(const PfBnMlpTrain* p, void* stream) {
     const int nchunk = (p->rows + BNL_CHUNK - 1) / BNL_CHUNK;
     float* part = p->ws;
     float* bpart = p->ws + (size_t)nchunk * 128 * 128;
-    (void)hipMemsetAsync(p->stat, 0, sizeof(double) * STAT_DOUBLES, s);
     const int in0 = p->kin0a + p->kin0b;
     auto dw = [&](const float* dy, int RA, const float* X, int ldx, int RB, const float* sc, const float* sh, float* dW, int ldw,
                   int coff, float* db) {

@@ -434,7 +434,15 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(PfMlpTrain p0, const
     }
     double s = 0.0;
     if (ok)
-        for (int k = ty; k < nchunk; k += 4) s += (double)part[(size_t)k * L.total + src];
+    {
+        int k = ty;
+        for (; k + 12 < nchunk; k += 16) {                            // four loads in flight per thread
+            const float v0 = part[(size_t)k * L.total + src], v1 = part[(size_t)(k + 4) * L.total + src];
+            const float v2 = part[(size_t)(k + 8) * L.total + src], v3 = part[(size_t)(k + 12) * L.total + src];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; k < nchunk; k += 4) s += (double)part[(size_t)k * L.total + src];
+    }
     shr[ty][tx] = s;
     __syncthreads();
     if (ty != 0 || !ok) return;
