@@ -179,6 +179,11 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(EmdArgs a) {
 // Progress: a sample's workgroups have consecutive indices and B * G <= the number of CUs, so they are co-resident; the spin
 // is bounded anyway (on timeout the sample's distances are written as NaN and the grid drains).
 constexpr int EMDC_NMAX = 2048;
+// the barrier words are cleared by a kernel, not by hipMemsetAsync: inside a captured hipGraph a memset node was observed to
+// race with the kernel node that follows it (arrival counters cleared under the running auction -> missed barriers)
+__global__ __launch_bounds__(256) void emd_zero_kernel(unsigned* p, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0u;
+}
 struct EmdCoopArgs {
     const float* x; const float* y;
     float* dist; int* assignment; int* assignment_inv; float* price;
@@ -337,7 +342,7 @@ extern "C" int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist,
     int G = 1;
     while (G < 16 && B * (2 * G) <= 256 && n / (2 * G) >= 64) G *= 2;
     if (G >= 2 && n <= EMDC_NMAX && !getenv("PF_EMD_SINGLE")) {
-        if (hipMemsetAsync(unass_idx, 0, (size_t)B * n * sizeof(int), s) != hipSuccess) return PF_ERR_LAUNCH;
+        hipLaunchKernelGGL(emd_zero_kernel, dim3(64), dim3(256), 0, s, reinterpret_cast<unsigned*>(unass_idx), (long long)B * n);
         EmdCoopArgs c{xyz1, xyz2, dist, assignment, assignment_inv, price, reinterpret_cast<unsigned*>(max_increments),
                       reinterpret_cast<unsigned*>(bid_increments), max_idx, bid, reinterpret_cast<unsigned*>(unass_idx), n, iters,
                       G, eps};

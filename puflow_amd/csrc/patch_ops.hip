@@ -239,6 +239,12 @@ __global__ __launch_bounds__(KS_T) void knn_sort_kernel(const float* __restrict_
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void fps_zero_kernel(float* p, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0.f;
+}
+}  // namespace
+
 // 1 when pf_fps runs the cooperative kernel for clouds of N points (its scratch row then holds the candidate ring):
 // stride_words = 64-bit words between the rings of consecutive clouds, abort_word = index of the abort word in a ring
 extern "C" int pf_fps_scratch_layout(int N, long long* stride_words, long long* abort_word) {
@@ -260,7 +266,9 @@ extern "C" int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, i
         const int G = (N + FPSC_T * ppt - 1) / (FPSC_T * ppt);
         const long long stride = ((long long)N / 2) & ~1ll;                           // 64-bit words per cloud
         unsigned long long* ring = reinterpret_cast<unsigned long long*>(mind);
-        if (hipMemsetAsync(mind, 0, (size_t)B * N * sizeof(float), s) != hipSuccess) return PF_ERR_LAUNCH;
+        // cleared by a kernel, not hipMemsetAsync: a memset node inside a captured hipGraph was observed to race with the
+        // kernel node that follows it (csrc/emd.hip)
+        hipLaunchKernelGGL(fps_zero_kernel, dim3(256), dim3(256), 0, s, mind, (long long)B * N);
         const dim3 grid(B * G), block(FPSC_T);
         switch (ppt) {
             case 1: hipLaunchKernelGGL(fps_coop_kernel<1>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); break;

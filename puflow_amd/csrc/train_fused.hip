@@ -691,6 +691,10 @@ __global__ __launch_bounds__(256) void ec_assemble_kernel(EcConvs cv, const floa
     if (col == 0) cv.dbias[t][r] = (float)((shb[0][tx] + shb[1][tx]) + (shb[2][tx] + shb[3][tx]));
 }
 
+__global__ __launch_bounds__(256) void ec_zero_kernel(f4* p, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p[i] = pf_splat(0.f);
+}
+
 template <typename KERNEL>
 void allow_lds(KERNEL k, size_t bytes) {
     if (bytes > 64 * 1024)
@@ -825,7 +829,8 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     float* dwpart = p->ws;
     float* bpart = dwpart + (long long)d.nchunk * d.S * d.GT;
     float* gws = bpart + (long long)d.nchunk * d.S;
-    (void)hipMemsetAsync(p->dPQ, 0, sizeof(float) * (size_t)d.T * 2 * d.S, s);
+    // cleared by a kernel rather than hipMemsetAsync: see csrc/emd.hip (memset nodes inside a captured hipGraph)
+    hipLaunchKernelGGL(ec_zero_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<f4*>(p->dPQ), (long long)d.T * 2 * d.S / 4);
 
     // ---- conv_out: dA = dYout Wg_out (+ sums of the last growth layer)
     {
