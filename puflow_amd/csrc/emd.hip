@@ -322,6 +322,11 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(const float* __restrict__
     const long long b = t / n;
     const int j = idx[t];
     const float g = gdist[t] * 2.f;                               // cu:295
+    if ((unsigned)j >= (unsigned)n) {                             // an assignment that is not an index: loud, never out of bounds
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gx[t * 3 + c] = __builtin_nanf("");
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) gx[t * 3 + c] += g * (x[t * 3 + c] - y[(b * n + j) * 3 + c]);
 }
