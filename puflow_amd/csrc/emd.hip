@@ -172,8 +172,9 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(EmdArgs a) {
 // 3 ms on one CU.  Here a sample's points are split over G workgroups (consecutive block indices); ground truth and prices
 // are copied to LDS per iteration, bids of a workgroup's own points stay in its LDS, and only the per-object state that
 // other workgroups need (maximum increment, winner, owner, price, assignment) is global, accessed with agent-scope atomics.
-// Three grid barriers per iteration (after bidding, after the winner vote, after assignment): an arrival counter per sample,
-// thread 0 spins on it.  The per-object vote arrays are double-buffered by iteration parity, so an iteration's entries are
+// Grid barriers per iteration: after bidding, [after the winner vote,] after assignment - an arrival counter per sample,
+// thread 0 spins on it.  With 64-bit vote words (increment bits << 32 | bidder index, one atomic max) the vote phase and its
+// barrier are gone: two barriers per iteration.  The per-object vote arrays are double-buffered by iteration parity, so an iteration's entries are
 // cleared during the NEXT iteration (by the workgroup that wrote them) instead of behind a fourth barrier.
 // Same arithmetic and tie rules as the single-workgroup kernel: identical assignment.
 // Progress: a sample's workgroups have consecutive indices and B * G <= the number of CUs, so they are co-resident; the spin
@@ -188,6 +189,7 @@ struct EmdCoopArgs {
     const float* x; const float* y;
     float* dist; int* assignment; int* assignment_inv; float* price;
     unsigned* mb0; unsigned* mb1; int* mi0; int* mi1;     // [B,n] each: maximum increment bits / winner index, per parity
+    unsigned long long* k0; unsigned long long* k1;        // KEY64: [B,n] (increment bits << 32 | bidder) per parity, instead
     unsigned* sync;                                        // [B,n] zeroed by the host: [0] arrivals, [1],[2] unassigned count per parity
     int n, iters, G;
     float eps;
@@ -197,6 +199,7 @@ __device__ __forceinline__ T ald(const T* p) { return __hip_atomic_load(p, __ATO
 template <typename T>
 __device__ __forceinline__ void ast(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+template <bool KEY64>
 __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
     __shared__ float sy[3 * EMDC_NMAX];
     __shared__ float sprice[EMDC_NMAX];
@@ -230,17 +233,20 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
     };
     for (int i = tid; i < 3 * n; i += EMD_THREADS) sy[i] = a.y[o0 * 3 + i];
     for (int i = i0 + tid; i < i1; i += EMD_THREADS) {
-        ast(a.mb0 + o0 + i, 0u); ast(a.mb1 + o0 + i, 0u); ast(a.mi0 + o0 + i, -1); ast(a.mi1 + o0 + i, -1);
+        if (KEY64) { ast(a.k0 + o0 + i, 0ull); ast(a.k1 + o0 + i, 0ull); }
+        else { ast(a.mb0 + o0 + i, 0u); ast(a.mb1 + o0 + i, 0u); ast(a.mi0 + o0 + i, -1); ast(a.mi1 + o0 + i, -1); }
     }
     barrier();
     int pU = 0;
     for (int it = 0; it < a.iters && !dead; ++it) {
         const bool last = it == a.iters - 1;
         const int par = it & 1;
-        unsigned* mb = (par ? a.mb1 : a.mb0) + o0;
-        int* mi = (par ? a.mi1 : a.mi0) + o0;
-        unsigned* mbo = (par ? a.mb0 : a.mb1) + o0;
-        int* mio = (par ? a.mi0 : a.mi1) + o0;
+        unsigned* mb = KEY64 ? nullptr : (par ? a.mb1 : a.mb0) + o0;
+        int* mi = KEY64 ? nullptr : (par ? a.mi1 : a.mi0) + o0;
+        unsigned* mbo = KEY64 ? nullptr : (par ? a.mb0 : a.mb1) + o0;
+        int* mio = KEY64 ? nullptr : (par ? a.mi0 : a.mi1) + o0;
+        unsigned long long* key = KEY64 ? (par ? a.k1 : a.k0) + o0 : nullptr;
+        unsigned long long* keyo = KEY64 ? (par ? a.k0 : a.k1) + o0 : nullptr;
         for (int i = tid; i < n; i += EMD_THREADS) sprice[i] = ald(price + i);
         if (tid == 0) ucount = 0;
         __syncthreads();
@@ -271,21 +277,27 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
                 const float inc = __fadd_rn(__fsub_rn(tbest, tbetter), a.eps);
                 sbid[u] = tidx;
                 sinc[u] = inc;
-                atomicMax(mb + tidx, __float_as_uint(inc));
+                // KEY64: one 64-bit max decides the object's winner - largest increment (positive floats order like their
+                // bits), then largest bidder index: the vote phase and its barrier disappear
+                if (KEY64) atomicMax(key + tidx, ((unsigned long long)__float_as_uint(inc) << 32) | (unsigned)i);
+                else atomicMax(mb + tidx, __float_as_uint(inc));
             }
         }
         barrier();
         if (ald(cnt + 1 + par) == 0u) break;                     // nothing left to assign in the whole sample (uniform)
-        // ---- winner of each object: largest index among the bidders holding the exact maximum increment
-        for (int u = tid; u < U; u += EMD_THREADS) {
-            const int o = sbid[u];
-            if (__float_as_uint(sinc[u]) == ald(mb + o)) atomicMax(mi + o, ulist[u]);
+        if (!KEY64) {
+            // ---- winner of each object: largest index among the bidders holding the exact maximum increment
+            for (int u = tid; u < U; u += EMD_THREADS) {
+                const int o = sbid[u];
+                if (__float_as_uint(sinc[u]) == ald(mb + o)) atomicMax(mi + o, ulist[u]);
+            }
+            barrier();
         }
-        barrier();
         // ---- assign; clear the OTHER parity's entries this workgroup wrote in the previous iteration
         for (int u = tid; u < U; u += EMD_THREADS) {
             const int i = ulist[u], o = sbid[u];
-            if (last || ald(mi + o) == i) {
+            const bool won = KEY64 ? (int)(unsigned)(ald(key + o) & 0xffffffffull) == i : ald(mi + o) == i;
+            if (last || won) {
                 if (!last) {
                     const int prev = ald(ainv + o);
                     if (prev != -1) ast(assignment + prev, -1);
@@ -295,7 +307,10 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
                 atomicAdd(price + o, sinc[u]);
             }
         }
-        for (int u = tid; u < pU; u += EMD_THREADS) { ast(mbo + pbid[u], 0u); ast(mio + pbid[u], -1); }
+        for (int u = tid; u < pU; u += EMD_THREADS) {
+            if (KEY64) ast(keyo + pbid[u], 0ull);
+            else { ast(mbo + pbid[u], 0u); ast(mio + pbid[u], -1); }
+        }
         if (w == 0 && tid == 0) ast(cnt + 1 + (1 - par), 0u);
         for (int u = tid; u < U; u += EMD_THREADS) pbid[u] = sbid[u];
         pU = U;
@@ -349,9 +364,20 @@ extern "C" int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist,
     if (G >= 2 && n <= EMDC_NMAX && !getenv("PF_EMD_SINGLE")) {
         hipLaunchKernelGGL(emd_zero_kernel, dim3(64), dim3(256), 0, s, reinterpret_cast<unsigned*>(unass_idx), (long long)B * n);
         EmdCoopArgs c{xyz1, xyz2, dist, assignment, assignment_inv, price, reinterpret_cast<unsigned*>(max_increments),
-                      reinterpret_cast<unsigned*>(bid_increments), max_idx, bid, reinterpret_cast<unsigned*>(unass_idx), n, iters,
-                      G, eps};
-        hipLaunchKernelGGL(emd_coop_kernel, dim3(B * G), dim3(EMD_THREADS), 0, s, c);
+                      reinterpret_cast<unsigned*>(bid_increments), max_idx, bid, nullptr, nullptr,
+                      reinterpret_cast<unsigned*>(unass_idx), n, iters, G, eps};
+        // 64-bit vote words need two of the caller's [B,n] scratch arrays back to back (8-byte aligned): true when they are
+        // slices of one allocation, as puflow_amd.loss.emdFunction passes them; otherwise the three-barrier protocol
+        const size_t bn = (size_t)B * n;
+        const bool pair0 = bid_increments == max_increments + bn && (reinterpret_cast<size_t>(max_increments) & 7) == 0;
+        const bool pair1 = bid == max_idx + bn && (reinterpret_cast<size_t>(max_idx) & 7) == 0;
+        if (pair0 && pair1 && !getenv("PF_EMD_VOTE32")) {
+            c.k0 = reinterpret_cast<unsigned long long*>(max_increments);
+            c.k1 = reinterpret_cast<unsigned long long*>(max_idx);
+            // each array pair holds 2 B n 32-bit words = B n 64-bit words: sample b's keys at word offset b n
+            hipLaunchKernelGGL(emd_coop_kernel<true>, dim3(B * G), dim3(EMD_THREADS), 0, s, c);
+        } else
+            hipLaunchKernelGGL(emd_coop_kernel<false>, dim3(B * G), dim3(EMD_THREADS), 0, s, c);
         return pf_last_launch_status();
     }
     if (n <= EMD_NMAX_ALL) hipLaunchKernelGGL(emd_auction_kernel<2>, dim3(B), dim3(EMD_THREADS), 0, s, a);

@@ -21,10 +21,15 @@ class emdFunction(Function):
         xyz1 = ops._f32c(xyz1)
         xyz2 = ops._f32c(xyz2)
         dev = xyz1.device
-        f = lambda: torch.zeros(B, n, device=dev)
-        i = lambda v: torch.full((B, n), v, device=dev, dtype=torch.int32)
-        dist, price, bid_inc, max_inc = f(), f(), f(), f()
-        assignment, assignment_inv, bid, unass_idx, max_idx = i(-1), i(-1), i(0), i(0), i(0)
+        # inputs of the auction: price 0, assignment / inverse -1 (emd_module.py:45-56); everything else is scratch the kernel
+        # initialises itself - handed over as slices of ONE allocation, in the order (max_inc, bid_inc, max_idx, bid), so that
+        # the multi-workgroup kernel can use pairs of them as 64-bit vote words (csrc/emd.hip)
+        price = torch.zeros(B, n, device=dev)
+        assign2 = torch.full((2, B, n), -1, device=dev, dtype=torch.int32)
+        assignment, assignment_inv = assign2[0], assign2[1]
+        scratch = torch.empty((5, B, n), device=dev, dtype=torch.int32)
+        max_inc, bid_inc, max_idx, bid, unass_idx = scratch[0], scratch[1], scratch[2], scratch[3], scratch[4]
+        dist = torch.empty(B, n, device=dev)
         _lib.check(lib.pf_emd_forward(xyz1.data_ptr(), xyz2.data_ptr(), dist.data_ptr(), assignment.data_ptr(),
                                       price.data_ptr(), assignment_inv.data_ptr(), bid.data_ptr(), bid_inc.data_ptr(),
                                       max_inc.data_ptr(), unass_idx.data_ptr(), max_idx.data_ptr(), float(eps),
