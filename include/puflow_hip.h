@@ -340,6 +340,16 @@ int pf_inject_inv2_fwd(const float* u, const float* s, const float* t, int Rr, l
 int pf_inject_inv2_bwd(const float* u, const float* s, const float* dv, int Rr, long long R, float* du, float* ds, float* dt,
                        void* stream);
 
+/* ---- gradient clipping (L2 norm over all parameters) + Adam for the whole model in two launches (csrc/optim.hip) ----
+ * Replaces torch.nn.utils.clip_grad_norm_ (Lightning gradient_clip_val, train_pu1k.py:149) + torch.optim.Adam.step
+ * (train_pu1k.py:46).  flat_g / m / v: [numel] in the chunk table's flat layout; params: device array of parameter addresses;
+ * chunks: device int32 [nchunks][4] = (tensor id, offset in the tensor, length, offset in the flat buffers), no chunk crosses
+ * a tensor; lr, step: device scalars (step is incremented here, before use); partial: >= nchunks doubles; counter: one zero
+ * word (left zero); coef: 2 floats out (clip coefficient, gradient norm before clipping). */
+int pf_clip_adam(float* flat_g, float* m, float* v, float* const* params, const int* chunks, int nchunks, const float* lr,
+                 float* step, float beta1, float beta2, float eps, float max_norm, double* partial, unsigned* counter,
+                 float* coef, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Patch pipeline around the network (modules/utils/patch.py:35-214), csrc/patch_ops.hip
  * ------------------------------------------------------------------------------------------- */

@@ -92,14 +92,15 @@ class FlatGradBucket:
             p.grad = self.flat[o:o + n].view_as(p)
             o += n
 
-    def all_reduce_mean(self) -> None:
-        """grad <- mean over ranks of grad (missing grads count as zero)."""
+    def all_reduce_mean(self, always_pack: bool = False) -> None:
+        """grad <- mean over ranks of grad (missing grads count as zero).  always_pack: concatenate into the flat buffer in a
+        single process too (the fused optimizer reads the flat buffer)."""
         multi = dist.is_initialized() and dist.get_world_size() > 1
         if self.as_views:
             if not self.views_intact():
                 self.rebind()
         else:
-            if not multi:
+            if not multi and not always_pack:
                 return                                  # single process: the gradients stay where autograd put them
             self.pack()
         if multi:

@@ -4,7 +4,8 @@ An eager `TrainerModule.train_step` enqueues ~3 500 small kernels (one per autog
 is bound by host launch latency, not by the GPU.  The shapes of a step are static (fixed batch, fixed patch sizes), so the
 whole step is captured once and replayed:
 
-  single process : ONE graph = zero grads -> forward -> loss -> backward -> clip -> Adam
+  single process : ONE graph = forward -> loss -> backward -> [one concatenation of the gradients] -> clip + Adam (two fused
+                   launches with puflow_amd.optim.FusedClipAdam; PyTorch's capturable Adam costs ~550 per-tensor launches)
   world size > 1 : graph A = forward -> loss -> backward -> ONE concatenation of all gradients into a flat buffer
                    eager    = one RCCL all-reduce of the flat 806 103-float buffer, / world size
                    graph B = clip -> Adam   (every .grad is a view of the flat buffer by then)
@@ -49,7 +50,13 @@ class GraphedTrainStep:
         dev = next(module.parameters()).device
         self.world = torch.distributed.get_world_size() if (torch.distributed.is_available() and
                                                              torch.distributed.is_initialized()) else 1
-        make_capturable(optimizer, dev)
+        from .optim import FusedClipAdam
+        self.fused = isinstance(optimizer, FusedClipAdam)
+        if self.fused:
+            optimizer.param_groups[0]["max_norm"] = clip
+            optimizer.sync_lr()
+        else:
+            make_capturable(optimizer, dev)
         self.static = self._clone_batch(batch)
         module.train()
         self.bucket = FlatGradBucket(module.parameters())
@@ -107,6 +114,11 @@ class GraphedTrainStep:
             self.bucket.flat.div_(self.world)
 
     def _update(self) -> None:
+        if self.fused:                                      # clip + Adam as two launches on the flat gradient buffer
+            if self.world == 1:
+                self.bucket.pack()
+            self.optimizer.step_flat(self.bucket.flat)
+            return
         torch.nn.utils.clip_grad_norm_(self.bucket.params, self.clip, foreach=True)
         self.optimizer.step()
 
@@ -120,6 +132,10 @@ class GraphedTrainStep:
         return self.loss
 
     def set_lr(self, lr: float) -> None:
+        if self.fused:
+            self.optimizer.param_groups[0]["lr"] = float(lr)
+            self.optimizer.sync_lr()                        # the device scalar the captured kernels read
+            return
         for g in self.optimizer.param_groups:
             if isinstance(g["lr"], Tensor):
                 g["lr"].fill_(float(lr))
@@ -129,5 +145,8 @@ class GraphedTrainStep:
 
     def sync_lr(self, scheduler_lr_holder) -> None:
         """After `scheduler.step(metric)` on a shadow optimizer / param-group list holding plain floats."""
+        if self.fused:
+            self.set_lr(float(scheduler_lr_holder[0]["lr"]))
+            return
         for g, h in zip(self.optimizer.param_groups, scheduler_lr_holder):
             g["lr"].fill_(float(h["lr"]))

@@ -28,7 +28,8 @@ except Exception:                        # pragma: no cover - not installed in t
 def default_cfg(**kw):
     # sync_batchnorm: BatchNorm statistics over ALL ranks (an extension: the reference trains on one GPU, where it is
     # the same thing; default False = each rank normalises with its own shard, like DDP without SyncBatchNorm)
-    cfg = dict(net="UpsamplingFlow", learning_rate=1e-3, sched_patience=10, sched_factor=0.5, seed=2021, sync_batchnorm=False)
+    cfg = dict(net="UpsamplingFlow", learning_rate=1e-3, sched_patience=10, sched_factor=0.5, seed=2021, sync_batchnorm=False,
+               fused_optimizer=True)
     cfg.update(kw)
     return SimpleNamespace(**cfg)
 
@@ -68,7 +69,15 @@ class TrainerModule(_Base):
         return self.network(p, **kwargs)
 
     def configure_optimizers(self):
-        optimizer = torch.optim.Adam(self.parameters(), lr=self.cfg.learning_rate)
+        # Adam as in the reference (train_pu1k.py:46).  On the GPU the update and Lightning's gradient clipping run as two fused
+        # launches (puflow_amd/optim.py: same arithmetic as clip_grad_norm_ + torch.optim.Adam; cfg.fused_optimizer=False keeps
+        # torch.optim.Adam)
+        on_gpu = next(self.parameters()).is_cuda
+        if on_gpu and getattr(self.cfg, "fused_optimizer", True):
+            from .optim import FusedClipAdam
+            optimizer = FusedClipAdam(self.parameters(), lr=self.cfg.learning_rate, max_norm=1e-2)
+        else:
+            optimizer = torch.optim.Adam(self.parameters(), lr=self.cfg.learning_rate)
         scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, "min", factor=self.cfg.sched_factor, min_lr=1e-4,
                                                                patience=self.cfg.sched_patience)
         return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "monitor": "CD"}}
@@ -171,6 +180,12 @@ class TrainerModule(_Base):
         self._bucket.drop_grads()                               # = optimizer.zero_grad(set_to_none=True): no fill, no accumulate
         loss = self.training_step(batch, 0)
         loss.backward()
+        from .optim import FusedClipAdam
+        if isinstance(optimizer, FusedClipAdam):
+            self._bucket.all_reduce_mean(always_pack=True)      # ONE concatenation (+ ONE 3.2 MB RCCL all-reduce when multi-rank)
+            optimizer.param_groups[0]["max_norm"] = clip
+            optimizer.step_flat(self._bucket.flat)              # clip by the global norm + Adam: two launches
+            return loss.detach()
         self._bucket.all_reduce_mean()                          # multi-rank: ONE concatenation + ONE 3.2 MB RCCL all-reduce
         torch.nn.utils.clip_grad_norm_(self._bucket.params, clip, foreach=True)
         optimizer.step()

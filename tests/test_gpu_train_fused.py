@@ -215,3 +215,31 @@ def test_bnmlp_fused_matches_unfused(two_inputs, rows):
     for (m_f, v_f), (m_u, v_u) in zip(st_f, st_u):
         _close(m_f, m_u, "running_mean", 1e-5)
         _close(v_f, v_u, "running_var", 1e-5)
+
+
+def test_fused_clip_adam_matches_torch():
+    """csrc/optim.hip against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on the same gradients, five steps, with a
+    learning-rate change in between (what ReduceLROnPlateau does)."""
+    from puflow_amd.optim import FusedClipAdam
+    torch.manual_seed(3)
+    shapes = [(64, 129), (64,), (3, 3), (1, 1, 3), (128, 384, 1, 1), (5000,), (4097,)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    fa = FusedClipAdam(pa, lr=1e-3, max_norm=1e-2)
+    tb = torch.optim.Adam(pb, lr=1e-3)
+    for it in range(5):
+        grads = [torch.randn_like(p) * (10.0 if it % 2 == 0 else 1e-4) for p in pa]     # clipped and un-clipped steps
+        if it == 3:
+            fa.param_groups[0]["lr"] = 5e-4
+            tb.param_groups[0]["lr"] = 5e-4
+        for p, q, g in zip(pa, pb, grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        fa.step()
+        norm = torch.nn.utils.clip_grad_norm_(pb, 1e-2)
+        tb.step()
+        assert abs(float(fa.coef[1]) - float(norm)) <= 1e-5 * float(norm)
+        for p, q in zip(pa, pb):
+            assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max())), (it, p.shape)
+    sd = fa.state_dict()
+    fa.load_state_dict(sd)
+    assert float(fa.step_t) == 5.0
