@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = headline metric (BASELINE configs[1]); train = configs[2] training step (CD+EMD, RCCL all-reduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reduced", action="store_true",
+                    help="skip the secondary reduced-precision line (a child process on libpuflow_hip_f16.so)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
 
@@ -230,12 +232,16 @@ def main():
                                "max_rel_err_log_det": ld_rel, "cd_build_vs_oracle": cd_bo,
                                "abs_cd_diff_vs_common_target": cd_diff,
                                "logp_note": "logp is a batch mean; compared in tests on equal batches"}
+        reduced_lib = os.environ.get("PF_LIB_PATH", "").endswith("_f16.so")
+        if world == 1 and not args.no_cpu_baseline and not args.no_reduced and not reduced_lib:
+            extra["reduced_precision"] = reduced_precision_line(args)
         out = {"metric": "patches/sec x4 2048->8192 (PU1K discrete, eval)", "value": value, "unit": "patches/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                # the arithmetic the path computes in: fp32 values, each product as 2-term split-fp16 on the fp16 MFMA
                # with fp32 accumulation (PF_EC_MODE=f32: plain f32 MFMA in the 128-channel EdgeConv units)
-               "dtype": "f32 (split-fp16 MFMA products, fp32 accumulate)" if eng.ec_mode in ("f16n", "f16x2") else
+               "dtype": "f16 operands (ONE fp16 MFMA product per step, fp32 accumulate): reduced-precision throughput build" if reduced_lib else
+                        "f32 (split-fp16 MFMA products, fp32 accumulate)" if eng.ec_mode in ("f16n", "f16x2") else
                         ("f32 (split-bf16 EdgeConv, split-fp16 elsewhere)" if eng.ec_mode == "bf16x3" else
                          "f32 (f32 MFMA EdgeConv, split-fp16 elsewhere)"),
                "data": "synthetic",
@@ -251,6 +257,34 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def reduced_precision_line(args):
+    """BASELINE configs[1] also names a bf16 / fp16 run: the same workload on `libpuflow_hip_f16.so` (one fp16 MFMA product
+    per 32-channel step instead of the three of the fp32-parity arithmetic; operands rounded to fp16, fp32 accumulation),
+    measured in a CHILD process (the library is chosen at load time) and judged by Chamfer distance against the CPU oracle.
+    A secondary line - never `value`."""
+    import subprocess
+    from puflow_amd.build import LIB_F16
+    if not os.path.exists(LIB_F16):
+        return {"skipped": "libpuflow_hip_f16.so not built (python -m puflow_amd.build)"}
+    env = dict(os.environ, PF_LIB_PATH=LIB_F16)
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(min(args.steps, 100)), "--warmup", str(min(args.warmup, 10)),
+           "--batch", str(args.batch), "--npoint", str(args.npoint), "--cpu-seconds", "3", "--no-reduced"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+    except Exception as ex:                                                  # the headline must not depend on this leg
+        return {"failed": f"{type(ex).__name__}: {ex}"[:200]}
+    par = d.get("parity", {})
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+            "library": "puflow_amd/libpuflow_hip_f16.so (-DPF_MMN_TERMS=1)",
+            "max_abs_dx_vs_fp32_oracle": par.get("max_abs_dx_vs_oracle"),
+            "cd_build_vs_fp32_oracle": par.get("cd_build_vs_oracle"),
+            "abs_cd_diff_vs_common_target": par.get("abs_cd_diff_vs_common_target"),
+            "knn_idx_exact_match_rate": par.get("knn_idx_exact_match_rate"),
+            "note": "same kernels, launches and weights as the headline; only the number of fp16 products per step differs"}
 
 
 def bench_train(args, world, rank, dev, dist):

@@ -25,19 +25,30 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") -> str:
-    """defines/tag: build a tuning variant `libpuflow_hip_<tag>.so` with extra -D flags (tools/tune_*.py)."""
+# sources whose arithmetic the reduced-precision throughput build changes (they include pf_mfma.h's split-fp16 products)
+F16_SOURCES = ("edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip")
+LIB_F16 = LIB.replace(".so", "_f16.so")
+
+
+def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "", only=None) -> str:
+    """defines/tag: build a variant `libpuflow_hip_<tag>.so` with extra -D flags (tools/tune_*.py, build_f16()).
+    only: recompile just these sources with the flags and link them with the main build's objects for the rest."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     lib = LIB if not tag else LIB.replace(".so", f"_{tag}.so")
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "puflow_hip.h"))
     objdir = os.path.join(HERE, "build" + (f"_{tag}" if tag else ""))
+    maindir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for s in srcs:
-        o = os.path.join(objdir, os.path.basename(s).replace(".hip", ".o"))
+        base = os.path.basename(s)
+        if only is not None and base not in only:
+            objs.append(os.path.join(maindir, base.replace(".hip", ".o")))       # shared with the main build
+            continue
+        o = os.path.join(objdir, base.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + [f"-D{d}" for d in defines] + ["-c", s, "-o", o]
@@ -55,6 +66,14 @@ def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") 
     return lib
 
 
+def build_f16(force: bool = False, verbose: bool = True) -> str:
+    """The reduced-precision throughput library: one fp16 product per 32-channel step instead of three (PF_MMN_TERMS=1)."""
+    build(force=False, verbose=verbose)                                   # the objects it shares
+    return build(force=force, verbose=verbose, defines=["PF_MMN_TERMS=1"], tag="f16", only=F16_SOURCES)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_f16(force="--force" in sys.argv)
     print(LIB)
+    print(LIB_F16)

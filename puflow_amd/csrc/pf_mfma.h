@@ -382,6 +382,12 @@ __device__ __forceinline__ float pf_rsmax16(float a, float b) {
 #ifndef PF_MMN_CPMAJOR
 #define PF_MMN_CPMAJOR 0
 #endif
+// Products per 32-channel step: 3 = split-fp16 with the natural-scale low half (hi*lo + lo*hi + hi*hi: fp32-grade results,
+// the parity mode and the default); 1 = hi*hi only - plain fp16 operands, fp32 accumulation: the reduced-precision THROUGHPUT
+// build (`libpuflow_hip_f16.so`, BASELINE configs[1] "bf16/fp16" line; judged by Chamfer distance, never the headline)
+#ifndef PF_MMN_TERMS
+#define PF_MMN_TERMS 3
+#endif
 template <bool SWAP, int OB, int CP, int WCP, bool FENCE = true, class WS, int P, int NIN, int NACC>
 __device__ __forceinline__ void pf_mmn(const WS& ws, int frag0, const PfPairN (&feat)[P][NIN], f4 (&acc)[P][NACC], int in0 = 0, int acc0 = 0) {
     constexpr int D = WS::DEPTH;                  // fragments in flight: 2 from LDS, 8 behind buffer loads (L2 latency)
@@ -408,12 +414,16 @@ __device__ __forceinline__ void pf_mmn(const WS& ws, int frag0, const PfPairN (&
         for (int p = 0; p < P; ++p) {
             f4 x = acc[p][acc0 + ob];
             if constexpr (SWAP) {
-                x = pf_mfma_f16(feat[p][in0 + cp].l, wh, x);
-                x = pf_mfma_f16(feat[p][in0 + cp].h, wl, x);
+                if constexpr (PF_MMN_TERMS == 3) {
+                    x = pf_mfma_f16(feat[p][in0 + cp].l, wh, x);
+                    x = pf_mfma_f16(feat[p][in0 + cp].h, wl, x);
+                }
                 x = pf_mfma_f16(feat[p][in0 + cp].h, wh, x);
             } else {
-                x = pf_mfma_f16(wh, feat[p][in0 + cp].l, x);
-                x = pf_mfma_f16(wl, feat[p][in0 + cp].h, x);
+                if constexpr (PF_MMN_TERMS == 3) {
+                    x = pf_mfma_f16(wh, feat[p][in0 + cp].l, x);
+                    x = pf_mfma_f16(wl, feat[p][in0 + cp].h, x);
+                }
                 x = pf_mfma_f16(wh, feat[p][in0 + cp].h, x);
             }
             acc[p][acc0 + ob] = x;

@@ -88,8 +88,10 @@ __global__ __launch_bounds__(NW * 64) void pq_gemm_kernel(PqArgs a) {
 #pragma unroll
                 for (int ob = 0; ob < RB; ++ob) {
                     f4 x = acc[ob];
-                    x = pf_mfma_f16(wh[ob][cp], fl, x);
-                    x = pf_mfma_f16(wl[ob][cp], fh, x);
+                    if constexpr (PF_MMN_TERMS == 3) {
+                        x = pf_mfma_f16(wh[ob][cp], fl, x);
+                        x = pf_mfma_f16(wl[ob][cp], fh, x);
+                    }
                     x = pf_mfma_f16(wh[ob][cp], fh, x);
                     acc[ob] = x;
                 }

@@ -23,3 +23,18 @@ def test_bench_train_fresh_process(graph):
     assert rec["unit"] == "patches/s" and rec["value"] > 0 and rec["steps"] == 4
     assert rec["loss"] == rec["loss"] and abs(rec["loss"]) < 1e3          # finite, sane
     assert "capture failed" not in out.stderr
+
+
+def test_bench_reduced_precision_line():
+    """`python bench.py`: the headline stays the fp32-parity arithmetic; the secondary single-term fp16 line (a child process on
+    libpuflow_hip_f16.so) is present, faster, bit-exact in kNN and within Chamfer-distance noise of the fp32 oracle."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--cpu-seconds", "2"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["dtype"].startswith("f32") and rec["parity"]["max_abs_dx_vs_oracle"] < 1e-5
+    red = rec["reduced_precision"]
+    assert "value" in red, red
+    assert red["dtype"].startswith("f16") and red["knn_idx_exact_match_rate"] == 1.0
+    assert red["max_abs_dx_vs_fp32_oracle"] < 5e-3 and red["cd_build_vs_fp32_oracle"] < 1e-6
+    assert red["value"] > 0.9 * rec["value"]
