@@ -256,7 +256,11 @@ typedef struct PfEcTrain {
     float* ws; long long ws_floats; /* >= pf_ec_train_ws_floats() */
     double* stat;                   /* PF_TRAIN_STAT_DOUBLES doubles (column-statistics accumulators): zeroed ONCE by the caller,
                                        every kernel that uses them leaves them zero again */
+    const int* csr_off; const int* csr_edge;   /* backward, nullable: transposed neighbour lists (pf_knn_csr) - the neighbour
+                                       scatter-add of dQ then runs as a gather without float atomics */
 } PfEcTrain;
+/* transposed neighbour lists of idx [B*N, K]: off [T+1], edge [T*K]; cnt: T ints (4-aligned size) of scratch */
+int pf_knn_csr(const int* idx, int B, int N, int K, int* off, int* edge, int* cnt, void* stream);
 long long pf_ec_train_ws_floats(const PfEcTrain* p);
 int pf_ec_train_fwd(const PfEcTrain* p, void* stream);
 int pf_ec_train_bwd(const PfEcTrain* p, void* stream);

@@ -499,6 +499,73 @@ __global__ __launch_bounds__(256) void ec_pq_bwd_kernel(EcPqBwdArgs a) {
     }
 }
 
+// The same without atomics, given the transposed neighbour lists (built once per step, pf_knn_csr): in-edges of point j are
+// csr_edge[csr_off[j] .. csr_off[j+1]).  dQ[j] = sum over them (plain loads, coalesced over the channels), dP as above; the
+// caller need not clear dPQ.
+struct EcPqCsrArgs {
+    EcPqBwdArgs b;
+    const int* off; const int* edge;
+};
+__global__ __launch_bounds__(256) void ec_pq_bwd_csr_kernel(EcPqCsrArgs a) {
+    const EcPqBwdArgs& b = a.b;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < b.T * b.S; t += (long long)gridDim.x * 256) {
+        const int i = (int)(t / b.S);
+        const int c = (int)(t % b.S);
+        const int lo = a.off[i], hi = a.off[i + 1];
+        float sum = 0.f, q = 0.f;
+        if (c < b.GT) {
+            for (int k = 0; k < b.K; ++k) sum += b.dY[((size_t)i * b.K + k) * b.ld + c];
+            for (int n = lo; n < hi; ++n) q += b.dY[(size_t)a.edge[n] * b.ld + c];
+        } else if (b.pooled) {
+            const int co = c - b.GT;
+            sum = b.dh[(size_t)i * b.odim + co];
+            for (int n = lo; n < hi; ++n) {
+                const int e = a.edge[n], ii = e / b.K, k = e - ii * b.K;
+                if (b.arg[(size_t)ii * b.odim + co] == k) q += b.dh[(size_t)ii * b.odim + co];
+            }
+        } else {
+            const int co = c - b.GT;
+            for (int k = 0; k < b.K; ++k) sum += b.dyout[((size_t)i * b.K + k) * b.odim + co];
+            for (int n = lo; n < hi; ++n) q += b.dyout[(size_t)a.edge[n] * b.odim + co];
+        }
+        b.dPQ[(size_t)i * 2 * b.S + c] = sum;
+        b.dPQ[(size_t)i * 2 * b.S + b.S + c] = q;
+    }
+}
+
+// transposed neighbour lists of idx [T, K] (batch-local indices, N points per sample): count -> scan -> fill
+__global__ __launch_bounds__(256) void csr_count_kernel(const int* idx, int N, int K, long long E, int* cnt) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long long)gridDim.x * 256) {
+        const long long i = e / K;
+        atomicAdd(cnt + (i / N) * N + idx[e], 1);
+    }
+}
+// exclusive scan of cnt[T] -> off[T+1] by ONE workgroup of 1024 threads (T <= a few 100 k); cnt is left as the running fill cursor
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int* cnt, int T, int* off) {
+    __shared__ int part[1024];
+    const int per = (T + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(T, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += cnt[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int i = lo; i < hi; ++i) { const int c = cnt[i]; off[i] = run; cnt[i] = run; run += c; }
+    if (threadIdx.x == 1023) off[T] = part[1023];
+}
+__global__ __launch_bounds__(256) void csr_fill_kernel(const int* idx, int N, int K, long long E, int* cursor, int* edge) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long long)gridDim.x * 256) {
+        const long long i = e / K;
+        edge[atomicAdd(cursor + (i / N) * N + idx[e], 1)] = (int)e;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ growth-weight gradients
 // part[chunk][c][u] = sum over the chunk's edges of dYfull[e, c] * lrelu(bn(Y[e, u])), c < S (growth layers then conv_out),
 // u < GT.  K dimension = edges: both operands are channel-fast in memory, so a block of 32 edges is staged through LDS
@@ -761,6 +828,22 @@ extern "C" long long pf_ec_train_ws_floats(const PfEcTrain* p) {
     return (long long)d.nchunk * d.S * (d.GT + 1) + gemm_ws_max(p, d);
 }
 
+// transposed neighbour lists: off [T+1], edge [T*K] (edge ids e = i K + k grouped by the point they point AT), cnt [T] scratch.
+// Built once per step and shared by every unit that uses the same idx (pf_ec_train_bwd: csr_off / csr_edge).
+extern "C" int pf_knn_csr(const int* idx, int B, int N, int K, int* off, int* edge, int* cnt, void* stream) {
+    if (!idx || !off || !edge || !cnt) return PF_ERR_NULL;
+    if (B <= 0 || N <= 0 || K <= 0 || (long long)B * N > (1ll << 26)) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = B * N;
+    const long long E = (long long)T * K;
+    const unsigned g = (unsigned)((E + 255) / 256 > 2048 ? 2048 : (E + 255) / 256);
+    hipLaunchKernelGGL(ec_zero_kernel, dim3(64), dim3(256), 0, s, reinterpret_cast<f4*>(cnt), (long long)(T + 3) / 4);
+    hipLaunchKernelGGL(csr_count_kernel, dim3(g), dim3(256), 0, s, idx, N, K, E, cnt);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, T, off);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(g), dim3(256), 0, s, idx, N, K, E, cnt, edge);
+    return pf_last_launch_status();
+}
+
 extern "C" int pf_ec_train_fwd(const PfEcTrain* p, void* stream) {
     Dims d;
     int st = ec_dims(p, d);
@@ -829,8 +912,10 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     float* dwpart = p->ws;
     float* bpart = dwpart + (long long)d.nchunk * d.S * d.GT;
     float* gws = bpart + (long long)d.nchunk * d.S;
+    const bool csr = p->csr_off && p->csr_edge;
     // cleared by a kernel rather than hipMemsetAsync: see csrc/emd.hip (memset nodes inside a captured hipGraph)
-    hipLaunchKernelGGL(ec_zero_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<f4*>(p->dPQ), (long long)d.T * 2 * d.S / 4);
+    if (!csr)
+        hipLaunchKernelGGL(ec_zero_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<f4*>(p->dPQ), (long long)d.T * 2 * d.S / 4);
 
     // ---- conv_out: dA = dYout Wg_out (+ sums of the last growth layer)
     {
@@ -873,7 +958,9 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         EcPqBwdArgs a{p->dA, d.GT, p->dout, p->arg, p->dout, p->pooling, p->idx, p->N, p->K, d.GT, p->odim, d.S, (long long)d.T,
                       p->dPQ};
         const long long n = (long long)d.T * d.S;
-        hipLaunchKernelGGL(ec_pq_bwd_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256), 0, s, a);
+        const dim3 grid((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256));
+        if (csr) hipLaunchKernelGGL(ec_pq_bwd_csr_kernel, grid, dim3(256), 0, s, EcPqCsrArgs{a, p->csr_off, p->csr_edge});
+        else hipLaunchKernelGGL(ec_pq_bwd_kernel, grid, dim3(256), 0, s, a);
     }
     // ---- growth-weight gradients (partials), dx, dWpq
     {

@@ -549,7 +549,7 @@ def edgeconv_train_unfolded(p, x: Tensor, idx: Tensor, pooling: bool = True) -> 
     return MaxPoolKFn.apply(y, K).view(B, N, -1)
 
 
-def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True) -> Tensor:
+def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None) -> Tensor:
     """FeatureExtractUnit in train mode (interpflow.py:234-248). x [B,N,C]; returns [B,N,odim] or [B*N*K, odim].
 
     Same algebra as the inference path's edge-feature fold (packing.fold_edgeconv): every conv of the dense block sees
@@ -561,7 +561,7 @@ def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True) -> Tensor:
     if _UNFOLDED:
         return edgeconv_train_unfolded(p, x, idx, pooling)
     if _FUSED and not _sync_bn_active():
-        return edgeconv_train_fused(p, x, idx, pooling)
+        return edgeconv_train_fused(p, x, idx, pooling, csr)
     B, N, C = x.shape
     K = idx.shape[-1]
     convs = [seq[0] for seq in p.convs] + [p.conv_out]
@@ -596,7 +596,7 @@ class EdgeConvUnitFn(Function):
 
     @staticmethod
     def _desc(x, idx, cfg, Ws, bs, gammas, betas):
-        K, g, nconv, odim, pooling, slope, eps, momentum, rmeans, rvars = cfg
+        K, g, nconv, odim, pooling, slope, eps, momentum, rmeans, rvars = cfg[:10]
         B, N, C = x.shape
         d = _lib.PfEcTrain()
         d.B, d.N, d.K, d.C, d.growth, d.nconv, d.odim, d.pooling = B, N, K, C, g, nconv, odim, int(pooling)
@@ -683,6 +683,9 @@ class EdgeConvUnitFn(Function):
         ws = _ws(dev, need)
         d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
         d.stat = _stat(dev).data_ptr()
+        csr = cfg[10] if len(cfg) > 10 else None
+        if csr is not None:                                   # transposed neighbour lists: dQ as a gather, no float atomics
+            d.csr_off, d.csr_edge = csr[0].data_ptr(), csr[1].data_ptr()
         _lib.check(lib.pf_ec_train_bwd(ctypes.byref(d), _stream()), "pf_ec_train_bwd")
         return (dx, None, None, *dWs, *dbs, *dgs, *dbe)
 
@@ -1107,12 +1110,27 @@ def mlp_fused(y, c: Tensor, td: int, cdiv: int, slopes, layers) -> Tensor:
 _FUSED = os.environ.get("PF_TRAIN_FUSED", "1") != "0"
 
 
-def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True) -> Tensor:
+def knn_csr(idx: Tensor):
+    """Transposed neighbour lists of idx [B,N,K] int32 (batch-local): (off [T+1], edge [T*K]) - for every point the edges that
+    point AT it.  Built once per step (4 small launches) and shared by all EdgeConv units on the same idx: their backward then
+    gathers dQ instead of scatter-adding it with float atomics."""
+    B, N, K = idx.shape
+    T = B * N
+    dev = idx.device
+    off = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    edge = torch.empty(T * K, dtype=torch.int32, device=dev)
+    cnt = torch.empty((T + 3) // 4 * 4, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().pf_knn_csr(idx.data_ptr(), B, N, K, off.data_ptr(), edge.data_ptr(), cnt.data_ptr(), _stream()),
+               "pf_knn_csr")
+    return off, edge
+
+
+def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None) -> Tensor:
     convs = [seq[0] for seq in p.convs] + [p.conv_out]
     bns = [seq[1] for seq in p.convs]
     g, nconv, odim = convs[0].weight.shape[0], len(bns), p.conv_out.weight.shape[0]
     cfg = (idx.shape[-1], g, nconv, odim, bool(pooling), 0.05, float(bns[0].eps), float(bns[0].momentum),
-           [bn.running_mean for bn in bns], [bn.running_var for bn in bns])
+           [bn.running_mean for bn in bns], [bn.running_var for bn in bns], csr)
     out = EdgeConvUnitFn.apply(x, idx, cfg, *[c.weight for c in convs], *[c.bias for c in convs],
                                *[bn.weight for bn in bns], *[bn.bias for bn in bns])
     with torch.no_grad():
@@ -1159,12 +1177,15 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     R = upratio
     idx16, _ = ops.knn_idx32(xyz, xyz, 16)
     idx8 = idx16[..., :8].contiguous()
+    fused_ec = _FUSED and not _sync_bn_active()
+    csr16 = knn_csr(idx16) if fused_ec else None
+    csr8 = knn_csr(idx8) if fused_ec else None
 
     # ---- feature extractor
     cs: List[Tensor] = []
     h = xyz
     for i in range(net.num_blocks):
-        h = edgeconv_train(net.feat_convs[i], h, idx16)
+        h = edgeconv_train(net.feat_convs[i], h, idx16, csr=csr16)
         m = net.merge_convs[i]
         if _FUSED:
             cs.append(mlp_fused(None, h, 0, 1, (0.0,), [m.conv1, m.conv2]).view(B, N, -1))
@@ -1234,7 +1255,7 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     _lib.check(_lib.load().pf_dist_feature(xyz.data_ptr(), idx8.data_ptr(), B, N, 8, fd.data_ptr(), _stream()), "pf_dist_feature")
     fused_bn = _FUSED and not _sync_bn_active()
     d = bnmlp_fused(ip.knn_context.distance_encoder.mlp, fd) if fused_bn else _mlp_bn(ip.knn_context.distance_encoder.mlp, fd)
-    feat = edgeconv_train(ip.knn_context.feat_conv, xyz, idx8, pooling=False)      # d, feat: [E8,128]
+    feat = edgeconv_train(ip.knn_context.feat_conv, xyz, idx8, pooling=False, csr=csr8)      # d, feat: [E8,128]
     if fused_bn:
         w = bnmlp_fused(ip.weight_unit.mlp, d, feat)              # on cat[d, feat] (interpflow.py:146) without building it
     else:

@@ -166,11 +166,11 @@ class TrainerModule(_Base):
             self(sparse, upratio=int(dense.shape[1] / sparse.shape[1]))
         broadcast_module(self)
 
-    def graphed_train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2):
+    def graphed_train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2, warmup: int = 2):
         """`train_step` for a fixed batch shape captured in hipGraphs (puflow_amd/train_graph.py): returns
         `step(batch) -> loss` that replays forward + backward (+ clip + Adam) with one launch instead of ~3 500."""
         from .train_graph import GraphedTrainStep
-        return GraphedTrainStep(self, optimizer, batch, clip)
+        return GraphedTrainStep(self, optimizer, batch, clip, warmup)
 
     def train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2) -> Tensor:
         self.train()

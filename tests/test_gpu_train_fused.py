@@ -30,7 +30,8 @@ def _run(p, x, idx, pooling, fused, wout):
     old = train_ops._FUSED
     train_ops._FUSED = fused
     try:
-        out = fn(p, x, idx, pooling)
+        # fused == "csr": the neighbour scatter-add of the backward as a gather over the transposed lists
+        out = fn(p, x, idx, pooling, train_ops.knn_csr(idx)) if fused == "csr" else fn(p, x, idx, pooling)
     finally:
         train_ops._FUSED = old
     (out * wout.view_as(out)).sum().backward()
@@ -86,6 +87,12 @@ def test_edgeconv_unit_fused_matches_unfused(cin, odim, growth, K, pooling, B):
         assert namb < 0.01 * wout.numel()
     o_f, dx_f, g_f, st_f = _run(p, x, idx, pooling, True, wout)
     o_u, dx_u, g_u, st_u = _run(p, x, idx, pooling, False, wout)
+    o_c, dx_c, g_c, _ = _run(p, x, idx, pooling, "csr", wout)
+    _close(dx_c, dx_u, "dx (csr gather)")
+    for n in g_u:
+        if not (n.endswith("0.bias") and "convs" in n):
+            _close(g_c[n], g_u[n], n + " (csr gather)")
+
     _close(o_f, o_u, "output", 2e-5)
     _close(dx_f, dx_u, "dx")
     for n in g_u:
