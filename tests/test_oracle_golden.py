@@ -67,3 +67,29 @@ def test_state_dict_census(golden_dir):
         assert list(sd[k].shape) == shape and str(sd[k].dtype) == dt
     nparam = sum(v.numel() for k, v in sd.items() if v.dtype == torch.float32 and "running" not in k)
     assert nparam == 806103
+
+
+def _load_pretrained(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pretrained_pu1k.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    return g, sd
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_oracle_matches_reference_with_pretrained_weights(golden_dir, case):
+    """The reference's own module with its own TRAINED checkpoint (pretrain/puflow-x4-pu1k.pt, tools/make_golden_pretrained.py):
+    the oracle reproduces x, z, the interpolated latent, log-det and log-likelihood on trained-scale activations too."""
+    torch.set_num_threads(1)
+    g, sd = _load_pretrained(golden_dir)
+    B, N, seed = (int(v) for v in g[f"{case}/meta"])
+    xyz = synth_patches(B, N, seed=seed, surface=True)
+    st = O.forward(sd, xyz, 4, stages=True)
+    assert np.array_equal(st["idx16"].numpy(), g[f"{case}/idx16"].astype(np.int64))
+    np.testing.assert_allclose(st["x"].numpy(), g[f"{case}/x"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(st["z"].numpy(), g[f"{case}/z"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(st["fz"].numpy(), g[f"{case}/fz"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(st["ldj"].numpy(), g[f"{case}/ldj"], rtol=2e-6)
+    np.testing.assert_allclose(float(st["logp"]), float(g[f"{case}/logp"]), rtol=2e-6)
+    for i in (0, 5):
+        n = g[f"{case}/cs{i}"].shape[-1]
+        np.testing.assert_allclose(st["cs"][i].numpy()[..., :n], g[f"{case}/cs{i}"], rtol=0, atol=1e-5)
