@@ -309,9 +309,13 @@ struct CnfDevArgs {
     int rows, R, ntiles;
 };
 
+// CTX_LDS (inverse direction, R >= 4 rows per original point): the context rows of the workgroup's 64 / R points are copied
+// to LDS once per tile and all six stage evaluations read them there - each evaluation re-read 1 152 B per row from L2 before
+template <bool CTX_LDS>
 __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_dev_kernel(CnfDevArgs a) {
     __shared__ f4 wl[CNF_REC / 4];
     __shared__ double red[CNF_NW];
+    __shared__ f4 sctx[CTX_LDS ? 16 * CNF_CTX / 4 : 1];
     if (a.ctl[CTL_DONE] != 0.0) return;                              // uniform over the grid
     const int cur = (int)a.ctl[CTL_CUR];
     const float t = (float)a.ctl[CTL_T], h = (float)a.ctl[CTL_DT];
@@ -354,6 +358,19 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_dev_kernel(CnfDevArgs a)
         const int pt = row / a.R;
         const f4 y0 = *reinterpret_cast<const f4*>(y0p + (size_t)row * 4);
         const float* cx = a.ctx + (size_t)pt * CNF_CTX;
+        if (CTX_LDS) {
+            const int ppw = CNF_NW * 16 / a.R;                     // points of this workgroup's tile (<= 16)
+            const long long p0 = (long long)tile * ppw;
+            const long long npts = ((long long)a.rows + a.R - 1) / a.R;
+            __syncthreads();                                       // every wave is done with the previous tile's rows
+            for (int i = threadIdx.x; i < ppw * (CNF_CTX / 4); i += CNF_NW * 64) {
+                const long long pp = p0 + i / (CNF_CTX / 4);
+                sctx[i] = reinterpret_cast<const f4*>(a.ctx)[(pp < npts ? pp : npts - 1) * (CNF_CTX / 4) + i % (CNF_CTX / 4)];
+            }
+            __syncthreads();
+            const long long pl = pt - p0;                            // a clamped out-of-range lane may point past the tile
+            cx = reinterpret_cast<const float*>(sctx) + (size_t)(pl < 0 ? 0 : (pl >= ppw ? ppw - 1 : pl)) * CNF_CTX;
+        }
         const float e0 = a.e[(size_t)pt * 3 + 0], e1 = a.e[(size_t)pt * 3 + 1], e2 = a.e[(size_t)pt * 3 + 2];
         f4 k[7];
         k[0] = *reinterpret_cast<const f4*>(f0p + (size_t)row * 4);
@@ -620,7 +637,9 @@ extern "C" int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float*
     const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < n_attempts; ++i) {
-        hipLaunchKernelGGL(cnf_step_dev_kernel, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+        // context rows through LDS when a tile's 64 rows belong to <= 16 whole points
+        if (R >= 4 && (CNF_NW * 16) % R == 0) hipLaunchKernelGGL(cnf_step_dev_kernel<true>, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+        else hipLaunchKernelGGL(cnf_step_dev_kernel<false>, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
         hipLaunchKernelGGL(cnf_ctl_kernel, dim3(1), dim3(64), 0, s, ctl, ws, grid);
     }
     return pf_last_launch_status();
