@@ -36,8 +36,6 @@
 extern "C" int pf_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
                        long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats, void* stream);
 extern "C" long long pf_gemm_ws_floats(int M, int N, int K);
-extern "C" int pf_colsum(const float* g, long long R, int C, float* out, float* ws, void* stream);
-extern "C" int pf_bn_chunks(long long R);
 
 namespace {
 
