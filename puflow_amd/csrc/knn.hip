@@ -205,8 +205,8 @@ __global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ 
 // A workgroup owns 64 queries (lane = query in every wave); wave w scans reference quarter w.  Same 32 group
 // minima (8 strided groups per quarter), same tau, same candidates - but 4x the waves of knn2_kernel for the same
 // work: at 32 x 2048 that kernel puts ONE wave on each SIMD, so nothing hides its readlane / LDS / dependent-issue stalls.
-// Candidate lists are per (wave, lane); wave 0 inserts them in wave order = increasing index, which keeps the
-// (distance, index) tie rule.  Overflow of any list -> exact scan of that query tile by wave 0.
+// Candidate lists are per (wave, lane); all waves then merge them by rank in (distance, index) order (a query at a time, a
+// candidate per lane).  Overflow of any list -> exact scan of that query tile by wave 0.
 // KNN4_W = waves per workgroup = reference slices: 4 when the grid fills the chip anyway (32 x 2048: 1024 workgroups), 8 or
 // 16 for small batches (4 x 2048: 128 workgroups of 16 waves instead of 4 - the kernel's latency is one wave's two sweeps
 // over its slice, so more, shorter slices cut it almost proportionally).  Same results for every split.
@@ -292,30 +292,99 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
     for (int j = jfull; j < je; ++j) visit(j);
     cnts[wave][lane] = cnt;
     __syncthreads();
-    if (wave != 0) return;
-
-    float bd[K];
-    int bi[K];
-    bool over = false;
+    if constexpr (KNN4_W == 4) {
+        // 4 slices (the grid fills the chip by itself): wave 0 inserts the lists in slice order = increasing index into per-lane
+        // top-K registers.  Measured against the rank merge below at 32 x 2048: 0.124 vs 0.137 ms - 16 queries per wave, one
+        // after the other, cost more than one wave's inserts
+        if (wave != 0) return;
+        float bd[K];
+        int bi[K];
+        bool over = false;
 #pragma unroll
-    for (int w = 0; w < KNN4_W; ++w) over |= cnts[w][lane] > KNN4_CAP;
-    if (__any(over)) {
-        exact_scan<K>(qx, qy, qz, r, M, bd, bi);      // heavy ties: redo this query tile exactly (rare)
-    } else {
+        for (int w = 0; w < KNN4_W; ++w) over |= cnts[w][lane] > KNN4_CAP;
+        if (__any(over)) {
+            exact_scan<K>(qx, qy, qz, r, M, bd, bi);      // heavy ties: redo this query tile exactly (rare)
+        } else {
 #pragma unroll
-        for (int i = 0; i < K; ++i) { bd[i] = __builtin_inff(); bi[i] = -1; }
-        for (int w = 0; w < KNN4_W; ++w) {
-            const int cw = cnts[w][lane];
-            for (int s = 0; __any(s < cw); ++s) {
-                if (s < cw) {
-                    const int j = lst[w][s][lane];
-                    const float d = sqdist(qx, qy, qz, r[j * 3 + 0], r[j * 3 + 1], r[j * 3 + 2]);
-                    topk_insert<K>(bd, bi, d, j);
+            for (int i = 0; i < K; ++i) { bd[i] = __builtin_inff(); bi[i] = -1; }
+            for (int w = 0; w < KNN4_W; ++w) {
+                const int cw = cnts[w][lane];
+                for (int s = 0; __any(s < cw); ++s) {
+                    if (s < cw) {
+                        const int j = lst[w][s][lane];
+                        const float d = sqdist(qx, qy, qz, r[j * 3 + 0], r[j * 3 + 1], r[j * 3 + 2]);
+                        topk_insert<K>(bd, bi, d, j);
+                    }
                 }
             }
         }
+        if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
+        return;
     }
-    if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
+    // ---- 8 or 16 slices (small batches).  Every wave sees every list length: the overflow decision is the same in all of them
+    bool over = false;
+    int ctot = 0;
+#pragma unroll
+    for (int w = 0; w < KNN4_W; ++w) { over |= cnts[w][lane] > KNN4_CAP; ctot += cnts[w][lane]; }
+    if (__any(over || ctot > 64)) {                  // heavy ties: wave 0 redoes this query tile exactly (rare)
+        if (wave != 0) return;
+        float bd[K];
+        int bi[K];
+        exact_scan<K>(qx, qy, qz, r, M, bd, bi);
+        if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
+        return;
+    }
+    // merge by RANK, all waves: wave w takes queries [w 64/W, (w+1) 64/W), one query at a time with a candidate per lane
+    // (more than 64 candidates of one query count as heavy ties: exact path above).  rank = number of candidates that precede
+    // this one in (distance, index) order; the candidates of rank < K are the answer, written straight to their position.
+    // (Wave 0 inserting 8 or 16 lists alone was most of the kernel there: 0.081 -> 0.039 ms at 4 x 2048.)
+    constexpr int QPW = 64 / KNN4_W;
+    // phase 1, all of the wave's queries: this lane's candidate of each query and its distance (the loads of the QPW queries
+    // are independent: issued together, one memory latency instead of QPW)
+    int jq[QPW], cq[QPW];
+    float dq[QPW];
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+        const int ql = wave * QPW + t;                                    // query (= lane index in every wave), uniform
+        cq[t] = __builtin_amdgcn_readlane(ctot, ql);
+        int j0 = 0x7fffffff, acc = 0;
+#pragma unroll
+        for (int w = 0; w < KNN4_W; ++w) {
+            const int cw = cnts[w][ql];
+            const int s0 = lane - acc;
+            if (s0 >= 0 && s0 < cw) j0 = lst[w][s0][ql];
+            acc += cw;
+        }
+        jq[t] = j0;
+    }
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+        const int ql = wave * QPW + t;
+        const float ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qx), ql));
+        const float ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qy), ql));
+        const float az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qz), ql));
+        const int jj = lane < cq[t] ? jq[t] : 0;
+        const float d = sqdist(ax, ay, az, r[(size_t)jj * 3 + 0], r[(size_t)jj * 3 + 1], r[(size_t)jj * 3 + 2]);
+        dq[t] = lane < cq[t] ? d : __builtin_inff();
+    }
+    // phase 2: ranks
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+        const int ql = wave * QPW + t;
+        const int nq = blockIdx.x * 64 + ql;
+        if (nq >= N) break;                                               // uniform
+        const int C = cq[t];
+        const float d0 = dq[t];
+        const int j0 = jq[t];
+        const size_t row = (size_t)b * N + nq;
+        int r0 = 0;                                                       // C <= 64: a candidate per lane
+        for (int c = 0; c < C; ++c) {
+            const float dc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), c));
+            const int jc = __builtin_amdgcn_readlane(j0, c);
+            r0 += (dc < d0 || (dc == d0 && jc < j0)) ? 1 : 0;
+        }
+        if (lane < C && r0 < K) { idx_out[row * K + r0] = j0; if (dist_out) dist_out[row * K + r0] = d0; }
+    }
 }
 
 // K = 1: nearest neighbour distance + index (first minimum wins ties).
