@@ -43,6 +43,7 @@ def model_specific_args() -> argparse.ArgumentParser:
     p.add_argument("--checkpoint_path", default=None)
     p.add_argument("--begin_checkpoint", default=None)
     p.add_argument("--sync_batchnorm", action="store_true")
+    p.add_argument("--graph", action="store_true", help="replay the training step from a hipGraph per batch shape")
     return p
 
 
@@ -53,17 +54,34 @@ def _dist():
     return 0, 1
 
 
+def _batch_key(batch):
+    vals = batch.values() if isinstance(batch, dict) else batch
+    return tuple(tuple(v.shape) for v in vals if isinstance(v, torch.Tensor))
+
+
 def fit(module: TrainerModule, train_data: Iterable, val_data: Optional[Iterable], max_epochs: int,
-        clip: float = 1e-2, log=print) -> dict:
-    """The epoch loop of `pl.Trainer.fit` for this module.  Returns {'epochs', 'lr' (per epoch), 'CD' (per epoch)}."""
+        clip: float = 1e-2, log=print, graph: bool = False) -> dict:
+    """The epoch loop of `pl.Trainer.fit` for this module.  Returns {'epochs', 'lr' (per epoch), 'CD' (per epoch)}.
+    graph=True (GPU, fused optimizer): every batch shape is captured once as a hipGraph (`TrainerModule.graphed_train_step`;
+    the capture's single warm-up step is that batch's optimisation step) and replayed for the batches that follow."""
     opt_cfg = module.configure_optimizers()
     optimizer, scheduler = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
     hist = {"epochs": 0, "lr": [], "CD": [], "loss": []}
     rank, _ = _dist()
+    graphs = {}
+    use_graph = graph and next(module.parameters()).is_cuda
     for epoch in range(max_epochs):
         module.train()
         last = None
         for bi, batch in enumerate(train_data):
+            if use_graph:
+                key = _batch_key(batch)
+                if key not in graphs:
+                    graphs[key] = module.graphed_train_step(batch, optimizer, clip, warmup=1)
+                    last = graphs[key].warmup_loss
+                else:
+                    last = graphs[key](batch)
+                continue
             last = module.train_step(batch, optimizer, clip)
         hist["loss"].append(float(last) if last is not None else float("nan"))
         if val_data is not None:
@@ -85,7 +103,8 @@ def fit(module: TrainerModule, train_data: Iterable, val_data: Optional[Iterable
 
 def train(phase: str = "Train", checkpoint_path: Optional[str] = None, begin_checkpoint: Optional[str] = None, cfg=None,
           train_data: Optional[Iterable] = None, val_data: Optional[Iterable] = None, max_epochs: int = 100,
-          dataset: str = "pu1k", device: Optional[str] = None, log=print, module: Optional[TrainerModule] = None):
+          dataset: str = "pu1k", device: Optional[str] = None, log=print, module: Optional[TrainerModule] = None,
+          graph: bool = False):
     """Reference signature `train(phase, checkpoint_path, begin_checkpoint)` (train_pu1k.py:124); the keyword arguments
     replace what the reference hard-codes (datamodule, trainer_config).  Returns (module, history)."""
     cfg = cfg or default_cfg()
@@ -99,7 +118,7 @@ def train(phase: str = "Train", checkpoint_path: Optional[str] = None, begin_che
             module.network.set_to_initialized_state()
         if train_data is None:
             raise ValueError("train(): no training data (pass train_data or use the CLI's --data / --synthetic)")
-        hist = fit(module, train_data, val_data, max_epochs, log=log)
+        hist = fit(module, train_data, val_data, max_epochs, log=log, graph=graph)
         rank, _ = _dist()
         if checkpoint_path is not None and hist["epochs"] == max_epochs and max_epochs > 10 and rank == 0:
             save_path = checkpoint_path.replace(".ckpt", f"-epoch{max_epochs}.ckpt")
@@ -129,7 +148,8 @@ def main(argv=None) -> None:
     else:
         tr = patch_data_from_file(a.data, up_ratio=4, **kw)
         va = patch_data_from_file(a.data, up_ratio=4, num_batches=a.val_batches, **{**kw, "is_augment": False})
-    train("Train", a.checkpoint_path or DEFAULT_CKPT[a.dataset], a.begin_checkpoint, cfg, tr, va, a.max_epochs, a.dataset, dev)
+    train("Train", a.checkpoint_path or DEFAULT_CKPT[a.dataset], a.begin_checkpoint, cfg, tr, va, a.max_epochs, a.dataset, dev,
+          graph=a.graph)
 
 
 if __name__ == "__main__":

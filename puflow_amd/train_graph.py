@@ -65,7 +65,7 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):
             for _ in range(max(warmup, 1)):               # ActNorm init, library loads, workspaces, Adam state
                 module._sync_actnorm_init(self.static)
-                self._fwd_bwd()
+                self.warmup_loss = self._fwd_bwd()        # these ARE optimisation steps on `batch` (the fit loop counts them)
                 self._reduce()
                 self._update()
         torch.cuda.current_stream(dev).wait_stream(side)
@@ -124,6 +124,8 @@ class GraphedTrainStep:
 
     # ---- public
     def __call__(self, batch) -> Tensor:
+        if self.fused:
+            self.optimizer.sync_lr()                      # a scheduler may have edited param_groups[0]["lr"] since the last call
         self._copy_in(batch)
         self.graph_a.replay()
         if self.graph_b is not None:

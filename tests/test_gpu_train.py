@@ -228,6 +228,27 @@ def test_train_entry_runs_epochs_on_the_gpu(tmp_path):
     assert mod.epoch == 2
 
 
+def test_train_entry_with_graph_replay(tmp_path):
+    """train(..., graph=True): each batch shape is captured once (its single warm-up step is that batch's optimisation step)
+    and replayed afterwards; the scheduler's learning-rate change reaches the captured kernels; same bookkeeping as the eager
+    loop."""
+    from puflow_amd.data import SyntheticPatchData
+    from puflow_amd.optim import FusedClipAdam
+    from puflow_amd.train import train
+    from puflow_amd.trainer import default_cfg
+    kw = dict(num_point_patch=256, up_ratio=4, batch_size=4, device=DEV)
+    tr = SyntheticPatchData(num_patches=12, seed=1, **kw)
+    va = SyntheticPatchData(num_patches=4, seed=2, is_augment=False, **kw)
+    for d in (tr, va):
+        d.inp = d.inp * 0.5 + 0.5; d.gt = d.gt * 0.5 + 0.5; d.is_augment = False
+    cfg = default_cfg(sched_patience=0, sched_factor=0.5, learning_rate=1e-3)
+    mod, hist = train("Train", str(tmp_path / "x.ckpt"), None, cfg, tr, va, max_epochs=3, dataset="pu1k", device=DEV, log=None,
+                      graph=True)
+    assert hist["epochs"] == 3 and all(np.isfinite(hist["CD"])) and all(np.isfinite(hist["loss"]))
+    assert all(b.actnorm.is_inited for b in mod.network.flow_blocks) and mod.epoch == 3
+    assert len(hist["lr"]) == 3 and hist["lr"][-1] <= hist["lr"][0]
+
+
 def test_graphed_train_step_follows_the_eager_trajectory():
     """TrainerModule.graphed_train_step: forward + loss + backward + clip + Adam replayed from a hipGraph (same kernels, same
     order as the eager step).  Its constructor runs `warmup` eager steps (ActNorm init, optimizer state) before the capture,
