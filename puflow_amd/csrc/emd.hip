@@ -177,8 +177,10 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(EmdArgs a) {
 // barrier are gone: two barriers per iteration.  The per-object vote arrays are double-buffered by iteration parity, so an iteration's entries are
 // cleared during the NEXT iteration (by the workgroup that wrote them) instead of behind a fourth barrier.
 // Same arithmetic and tie rules as the single-workgroup kernel: identical assignment.
-// Progress: a sample's workgroups have consecutive indices and B * G <= the number of CUs, so they are co-resident; the spin
-// is bounded anyway (on timeout the sample's distances are written as NaN and the grid drains).
+// Progress: a sample's workgroups have consecutive indices and B * G <= the number of CUs, so they are co-resident when the
+// process has the GPU to itself (one process per GPU, the deployment this targets); the spin is bounded anyway - on timeout the
+// sample's distances are written as NaN and the grid drains.  Two processes sharing one GPU with full-size batches can starve
+// each other's barriers (seen in a 2-rank rehearsal on one device): use PF_EMD_SINGLE=1 there.
 constexpr int EMDC_NMAX = 2048;
 // the barrier words are cleared by a kernel, not by hipMemsetAsync: inside a captured hipGraph a memset node was observed to
 // race with the kernel node that follows it (arrival counters cleared under the running auction -> missed barriers)
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
         if (tid == 0) {
             atomicAdd(cnt, 1u);
             const unsigned target = nb * (unsigned)G;
-            int budget = 1 << 22;
+            int budget = 1 << 18;                       // ~0.2 s: a barrier normally completes in microseconds
             while (ald(cnt) < target && --budget > 0) __builtin_amdgcn_s_sleep(2);
             if (budget <= 0) dead = 1;
         }
