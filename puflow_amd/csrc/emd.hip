@@ -361,8 +361,10 @@ extern "C" int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist,
               reinterpret_cast<unsigned*>(max_increments), max_idx, unass_idx, n, iters, eps};
     hipStream_t s = (hipStream_t)stream;
     // several workgroups per sample when the batch alone cannot fill the chip (all B * G of them must be co-resident)
+    int ncu = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     int G = 1;
-    while (G < 16 && B * (2 * G) <= 256 && n / (2 * G) >= 64) G *= 2;
+    while (G < 16 && B * (2 * G) <= ncu && n / (2 * G) >= 64) G *= 2;          // one workgroup per CU at most: co-resident
     if (G >= 2 && n <= EMDC_NMAX && !getenv("PF_EMD_SINGLE")) {
         hipLaunchKernelGGL(emd_zero_kernel, dim3(64), dim3(256), 0, s, reinterpret_cast<unsigned*>(unass_idx), (long long)B * n);
         EmdCoopArgs c{xyz1, xyz2, dist, assignment, assignment_inv, price, reinterpret_cast<unsigned*>(max_increments),
