@@ -1367,10 +1367,10 @@ int bnl_check(const PfBnMlpTrain* p) {
     if (p->rows < 16 || (p->nl != 2 && p->nl != 3)) return PF_ERR_SHAPE;
     if (p->kin0a < 1 || p->kin0a > 128 || p->kin0b < 0 || p->kin0b > 128) return PF_ERR_UNSUPPORTED;
     if (p->kin0b > 0 && (p->kin0a & 3)) return PF_ERR_UNSUPPORTED;
-    for (int l = 0; l < p->nl; ++l) {
+    for (int l = 0; l < p->nl; ++l)
         if (p->width[l] < 16 || p->width[l] > 128 || p->width[l] % 16 != 0) return PF_ERR_UNSUPPORTED;
+    for (int l = 0; l < p->nl; ++l)
         if (!p->W[l] || !p->y[l]) return PF_ERR_NULL;
-    }
     for (int l = 0; l < p->nl - 1; ++l)
         if (!p->gamma[l] || !p->beta[l] || !p->aff[l]) return PF_ERR_NULL;
     if (!p->xa || (p->kin0b > 0 && !p->xb) || !p->stat) return PF_ERR_NULL;

@@ -41,6 +41,58 @@ def test_argument_validation_without_gpu(built_lib):
     assert lib.pf_interp(8, 8, 8, 8, _lib.offsets([0] * 15), 8, 1, 64, 33, None) == -3
 
 
+def test_training_entry_points_validate_their_descriptors(built_lib):
+    """The fused training entry points (PfEcTrain / PfMlpTrain / PfBnMlpTrain descriptors, the flow-block ops, the fused
+    optimizer, the neighbour-list transpose) reject incomplete or unsupported descriptors before any launch."""
+    import ctypes
+    from puflow_amd import _lib
+    lib = _lib.load()
+    ec = _lib.PfEcTrain()
+    assert lib.pf_ec_train_ws_floats(ctypes.byref(ec)) == -1                      # all-zero shape
+    ec.B, ec.N, ec.K, ec.C, ec.growth, ec.nconv, ec.odim, ec.pooling = 2, 64, 16, 32, 16, 4, 64, 1
+    assert lib.pf_ec_train_ws_floats(ctypes.byref(ec)) > 0
+    assert lib.pf_ec_train_fwd(ctypes.byref(ec), None) == -1                      # no buffers
+    ec.growth = 12
+    assert lib.pf_ec_train_ws_floats(ctypes.byref(ec)) == -1                      # growth must be 8 / 16 / 32
+    ec.growth, ec.K = 16, 8
+    assert lib.pf_ec_train_fwd(ctypes.byref(ec), None) == -3                      # pooled units need K = 16
+    ec.K, ec.nconv = 16, 3
+    assert lib.pf_ec_train_fwd(ctypes.byref(ec), None) == -3                      # growth * nconv must be 32 / 64 / 128
+    assert lib.pf_ec_train_fwd(None, None) == -1 and lib.pf_ec_train_bwd(None, None) == -1
+    m = _lib.PfMlpTrain()
+    assert lib.pf_mlp_train_ws_floats(ctypes.byref(m)) == -1
+    m.rows, m.nl, m.td, m.cc, m.cdiv = 64, 3, 1, 48, 1
+    m.width[0], m.width[1], m.width[2] = 64, 64, 2
+    assert lib.pf_mlp_train_fwd(ctypes.byref(m), None) == -3                      # cc must be 16 / 32 / 64 / 128
+    m.cc = 64
+    assert lib.pf_mlp_train_fwd(ctypes.byref(m), None) == -1                      # weights missing
+    m.cdiv = 3
+    assert lib.pf_mlp_train_fwd(ctypes.byref(m), None) == -3                      # replica count must be a power of two <= 16
+    assert lib.pf_mlp_train_fwd_batch(None, 2, None, None) == -1
+    bm = _lib.PfBnMlpTrain()
+    assert lib.pf_bnmlp_train_ws_floats(ctypes.byref(bm)) == -1
+    bm.rows, bm.nl, bm.kin0a, bm.kin0b = 256, 3, 10, 0
+    bm.width[0], bm.width[1], bm.width[2] = 64, 64, 100
+    assert lib.pf_bnmlp_train_fwd(ctypes.byref(bm), None) == -3                   # widths are multiples of 16
+    assert lib.pf_flow_affine_fwd(None, None, 1, None, None, None, 0, 10, None, None) == -1
+    assert lib.pf_flow_affine_fwd(8, None, 5, 8, 8, 8, 0, 10, 8, None) == -2      # td out of range
+    assert lib.pf_couple_inject2_fwd(8, 8, 8, 8, 0, 10, 8, 8, 8, 8, None) == -2   # td must be 1 or 2
+    assert lib.pf_inject_inv2_fwd(8, 8, 8, 4, 10, 8, None) == -2                  # rows not a multiple of the replica count
+    assert lib.pf_clip_adam(None, None, None, None, None, 4, None, None, 0.9, 0.999, 1e-8, 1e-2, None, None, None, None) == -1
+    assert lib.pf_knn_csr(None, 1, 16, 4, None, None, None, None) == -1
+    assert lib.pf_knn_csr(8, 0, 16, 4, 8, 8, 8, None) == -2
+    assert lib.pf_cnf_steps(None, None, None, None, None, None, None, None, None, 1e-5, 1e-5, 16, 1, 1, None, None) == -1
+
+
+def test_reduced_precision_library_has_the_same_surface(built_lib):
+    """libpuflow_hip_f16.so (bench.py's secondary line) exports every symbol of the main library."""
+    import ctypes
+    from puflow_amd import _lib, build
+    f16 = ctypes.CDLL(build.build_f16(verbose=False))
+    for name in _lib.SIGNATURES:
+        assert hasattr(f16, name), name
+
+
 def test_module_state_dict_matches_reference_census(golden_dir):
     import json
     from puflow_amd.interpflow import PointInterpFlow
