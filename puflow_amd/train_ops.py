@@ -560,7 +560,7 @@ def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None) ->
     and the gather's scatter-add - exact algebra, same results up to fp32 rounding."""
     if _UNFOLDED:
         return edgeconv_train_unfolded(p, x, idx, pooling)
-    if _FUSED and not _sync_bn_active():
+    if _FUSED and not _sync_bn_active() and _ec_fused_supported(p, x, idx, pooling):
         return edgeconv_train_fused(p, x, idx, pooling, csr)
     B, N, C = x.shape
     K = idx.shape[-1]
@@ -1123,6 +1123,15 @@ def knn_csr(idx: Tensor):
     _lib.check(_lib.load().pf_knn_csr(idx.data_ptr(), B, N, K, off.data_ptr(), edge.data_ptr(), cnt.data_ptr(), _stream()),
                "pf_knn_csr")
     return off, edge
+
+
+def _ec_fused_supported(p, x: Tensor, idx: Tensor, pooling: bool) -> bool:
+    """Shapes the fused unit kernels are built for (csrc/train_fused.hip: ec_dims); anything else takes the per-op path."""
+    g, nconv, odim = p.convs[0][0].weight.shape[0], len(p.convs), p.conv_out.weight.shape[0]
+    B, N, _ = x.shape
+    K = idx.shape[-1]
+    return (g in (8, 16, 32) and 1 <= nconv <= 8 and g * nconv in (32, 64, 128) and odim % 16 == 0 and 16 <= odim <= 128
+            and (B * N * K) % 16 == 0 and (K == 16 or not pooling))
 
 
 def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None) -> Tensor:
