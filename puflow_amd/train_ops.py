@@ -1158,6 +1158,8 @@ def cond_net(net, h: Tensor) -> Tensor:
 def cond_net_fused(net, y, c: Tensor, td: int, cdiv: int) -> Tensor:
     """LinearA1D on cat[y[..., :td], c[row // cdiv]] in one launch (csrc/train_mlp.hip); -> [rows, dout]."""
     L = net.layers
+    if cdiv not in (1, 2, 4, 8, 16):                   # the kernel shares a conditioning row between 2^k replicas only
+        c, cdiv = RepeatRowsFn.apply(c, cdiv), 1
     return mlp_fused(y, c, td, cdiv, (0.01, 0.01), [L[0], L[2], L[4]])
 
 

@@ -288,3 +288,31 @@ def test_training_forward_backward_on_an_odd_patch_size():
     v = np.sort(np.array(list(errs.values())))
     worst = max(errs, key=errs.get)
     assert np.median(v) < 1e-3 and v[int(0.9 * len(v))] < 2e-2 and v[-1] < 0.5, (float(np.median(v)), float(v[int(0.9 * len(v))]), worst, errs[worst])
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_training_forward_backward_other_up_ratios(R):
+    """Up-ratios other than 4 in train mode (the reference's interpolation supports any R <= r_max): a power of two shares the
+    conditioning row in the kernel, any other ratio goes through a materialised repeat - fused path against per-op path."""
+    from puflow_amd import train_ops
+    from puflow_amd.interpflow import PointInterpFlow
+    from puflow_amd.weights import synth_patches, synth_state_dict
+    xyz = synth_patches(2, 128, seed=4).cuda()
+
+    def run(fused):
+        net = PointInterpFlow(3); net.load_state_dict(synth_state_dict(6)); net = net.cuda().train()
+        old = train_ops._FUSED
+        train_ops._FUSED = fused
+        try:
+            u, logp = train_ops.forward_train(net, xyz, R)
+            (u.square().mean() + 1e-4 * logp).backward()
+        finally:
+            train_ops._FUSED = old
+        g = net.flow_blocks[3].coupling1.bias_net.layers[2].weight.grad.clone()
+        return u.detach(), float(logp), g
+
+    u_f, l_f, g_f = run(True)
+    u_u, l_u, g_u = run(False)
+    assert u_f.shape == (2, 128 * R, 3)
+    assert (u_f - u_u).abs().max() < 2e-5 and abs(l_f - l_u) < 1e-5 * abs(l_u)
+    assert float((g_f - g_u).abs().max()) < 2e-2 * float(g_u.abs().max())
