@@ -365,9 +365,15 @@ int pf_clip_adam(float* flat_g, float* m, float* v, float* const* params, const 
 int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, int* idx_out, void* stream);
 
 /* Layout of pf_fps's scratch when the cooperative kernel runs (return value 1; 0 = single-workgroup kernel, no ring):
- * cloud b's ring starts at 64-bit word b * stride_words of `mind`; word `abort_word` of a ring is non-zero after the
- * launch iff that cloud's workgroups gave up waiting for each other (bounded spin) - its idx_out row is then invalid. */
+ * cloud b's ring starts at 64-bit word b * stride_words of `mind`; word `abort_word` of a ring is the cloud's status after
+ * the launch: 0 = every step completed; 1 = its workgroups gave up waiting for each other (bounded spin); 2 = it never
+ * finished (or never got its workgroups).  Non-zero = that cloud's idx_out row is invalid. */
 int pf_fps_scratch_layout(int N, long long* stride_words, long long* abort_word);
+
+/* PatchHelper.normalize_pc (modules/utils/patch.py:168-178): centroid = mean over the N points, x - centroid, divided by the
+ * largest norm.  x, out [B,N,3] (out may alias x), centroid [B,3], fdist [B].  One workgroup per cloud with a fixed
+ * summation order: a cloud's result does not depend on B. */
+int pf_normalize_pc(const float* x, int B, int N, float* out, float* centroid, float* fdist, void* stream);
 
 /* K nearest references of every query for large K (patch extraction, K = 256).  Replaces knn_cuda.KNN
  * (patch.py:33,107).  ref [B,N,3], query [B,M,3], K <= N (any N; K <= 8192 when N > 16384: the references are then

@@ -142,6 +142,7 @@ SIGNATURES = {
     "pf_cnf_steps": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                              c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_knn_large": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pf_normalize_pc": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_cnf_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_float), c_int, c_float, c_float, c_float, c_void_p, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pf_cnf_step": (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

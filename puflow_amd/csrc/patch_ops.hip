@@ -66,39 +66,81 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
 // The single-workgroup kernel above re-reads 16 B per point from L2 on every one of the npoint sequential steps
 // (99 840 points -> 1.6 MB per step through ONE CU's 64 B/clk texture path: 19 us per step, 388 ms for the CLI's
 // 99 840 -> 20 024 merge, 99.7 % of its per-cloud GPU time).  Here a cloud is split over G <= 32 workgroups
-// (<= 8 points per thread), a step is: local arg-max in registers -> one 64-bit candidate per workgroup
+// (<= 32 points per thread), a step is: local arg-max in registers -> one 64-bit candidate per WAVE
 // (distance bits << 32 | ~index, so an integer max is "farthest, then smallest index") published with an
-// agent-scope atomic store into a 4-deep ring of G slots -> wave 0 of every workgroup polls the G slots of the
+// agent-scope atomic store into a 4-deep ring of G x 4 slots -> wave 0 of every workgroup polls the slots of the
 // step (agent-scope atomic loads) and reduces them.  The 64-bit word IS the whole message (coordinates are re-read
 // from the read-only input), so relaxed ordering suffices: no L2 write-back / invalidate per step, which is what an
 // acquire / release pair costs at agent scope on this chip.  No read-modify-write atomics, no counters: a slot is
 // "filled" when it carries the current step's 2-bit tag (the same slot held step j-4's word before): see the kernel.
 // Progress: blocks are dispatched in index order and a cloud's workgroups are contiguous, so the lowest
-// unfinished cloud always has all its workgroups resident; a bounded spin + abort flag guarantees the grid drains
-// even if that assumption were ever violated: the cloud's abort word is then set and its output is invalid -
+// unfinished cloud always has all its workgroups resident; a bounded spin + abort guarantees the grid drains
+// even if that assumption were ever violated.  A cloud's status word is 0 only after all of its steps completed -
 // pf_fps_scratch_layout tells the caller where that word is, puflow_amd.ops.furthest_point_sample checks it and raises.
 #ifndef PF_FPSC_T
 #define PF_FPSC_T 256
 #endif
 constexpr int FPSC_T = PF_FPSC_T;
 constexpr int FPSC_GMAX = 32;
-constexpr int FPSC_RING = 4 * FPSC_GMAX;                 // 64-bit words per cloud (+1 abort word)
+constexpr int FPSC_SLOTS = FPSC_GMAX * (FPSC_T / 64);    // one slot per wave of a cloud
+constexpr int FPSC_RING = 4 * FPSC_SLOTS;                // 64-bit words per cloud, then the status word
+static_assert(FPSC_SLOTS <= 128, "a lane polls two slots");
 constexpr unsigned FPSC_SPIN_MAX = 1u << 24;
+// status word of a cloud (ring[FPSC_RING]): 2 = not finished (set by fps_init_kernel), 1 = aborted, 0 = complete
+constexpr unsigned long long FPSC_ST_DONE = 0ull, FPSC_ST_ABORT = 1ull, FPSC_ST_INIT = 2ull;
 
+__device__ __forceinline__ unsigned long long fps_ld(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fps_st(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave-wide reductions without LDS traffic: rotate-reduce inside the 16-lane rows (DPP row_ror), then the four row results
+// through SGPRs.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = max(v, dpp_i<0x128>(v)); v = max(v, dpp_i<0x124>(v)); v = max(v, dpp_i<0x122>(v)); v = max(v, dpp_i<0x121>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)dpp_i<0x128>((int)v)); v = max(v, (unsigned)dpp_i<0x124>((int)v));
+    v = max(v, (unsigned)dpp_i<0x122>((int)v)); v = max(v, (unsigned)dpp_i<0x121>((int)v));
+    return max(max((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
+               max((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
+// A step: every WAVE reduces its own points in registers (DPP) and publishes one 64-bit word (distance bits << 32 | tag |
+// ~index: an integer max is "farthest, then smallest index") into its slot of a 4-deep ring; wave 0 of every workgroup reads
+// the G x 4 slots of the step (two per lane), reduces them and hands the winner's coordinates to the other waves through LDS
+// (double-buffered: ONE barrier per step).  Measured on the CLI's merge (99 840 -> 20 024, 25 workgroups), per step:
+//   one word per workgroup, shuffles through LDS, two barriers (round 2's first version)   2.86 us
+//   one word per wave, every wave reads all slots itself (no barrier at all)               2.95-3.1 us  (100 readers of the
+//                                                                          same lines: the reads get in each other's way)
+//   one word per wave, wave 0 reads (this kernel)                                          2.2-2.3 us
+//   the same with the workgroup's four words merged in LDS first (25 slots)                2.56 us
+//   ... waiting for the OWN slots only (wrong results, timing experiment)                  1.65 us  = what the store -> load
+//                                                                          round trip through the fabric leaves of a step
+// Tried and dropped: all workgroups of a cloud on one XCD (8x oversubscribed grid, HW_REG_XCC_ID, claim counter) - agent-scope
+// atomics bypass the XCD's L2 wherever the peers run (2.5 us), workgroup-scope loads are served by the CU's own L1 and never
+// see the peers' stores, and an L1 invalidate (buffer_inv sc1) per read costs 6.3 us per step; two staggered reads in flight
+// (2.37 us); s_sleep between reads (no change); touching the whole cloud once per XCD before the loop (-0.06 us).
 template <int PPT>
 __global__ __launch_bounds__(FPSC_T) void fps_coop_kernel(const float* __restrict__ xyz, int N, int npoint, int G,
                                                           unsigned long long* __restrict__ ringbuf, long long ring_stride,
                                                           int* __restrict__ out) {
-    __shared__ float sv[FPSC_T / 64];
-    __shared__ int si[FPSC_T / 64];
-    __shared__ int s_cur;
-    __shared__ float s_lx, s_ly, s_lz;
+    constexpr int NW = FPSC_T / 64;
+    __shared__ float s_l[2][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / G, g = blockIdx.x % G;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* p = xyz + (size_t)b * N * 3;
-    unsigned long long* ring = ringbuf + (size_t)b * ring_stride;       // [4][FPSC_GMAX] + abort word
+    unsigned long long* ring = ringbuf + (size_t)b * ring_stride;       // [4][FPSC_SLOTS] + status word
     unsigned long long* abort_w = ring + FPSC_RING;
     int* o = out + (size_t)b * npoint;
+    const int S = G * NW;                                               // slots = waves of the cloud (<= 128: two per lane)
 
     float px[PPT], py[PPT], pz[PPT], md[PPT];
     int pi[PPT];
@@ -111,7 +153,6 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop_kernel(const float* __restric
         px[k] = p[ic * 3 + 0]; py[k] = p[ic * 3 + 1]; pz[k] = p[ic * 3 + 2];
         md[k] = in ? 1e10f : -1.f;                                      // padding can never be the farthest point
     }
-    int cur = 0;
     if (g == 0 && tid == 0) o[0] = 0;
     float lx = p[0], ly = p[1], lz = p[2];
     for (int j = 1; j < npoint; ++j) {
@@ -123,70 +164,56 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop_kernel(const float* __restric
             md[k] = d;
             if (d > best) { best = d; besti = pi[k]; }
         }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const float ov = __shfl_xor(best, m);
-            const int oi = __shfl_xor(besti, m);
-            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        // distances are >= 0 or the -1 of padding: their bit patterns order like signed integers
+        const int vb = __float_as_int(best);
+        const int vmax = wave_max_i32(vb);
+        const unsigned imin = ~wave_max_u32(vb == vmax ? ~(unsigned)besti : 0u);      // smallest index among the maxima
+        unsigned long long* slot = ring + (j & 3) * FPSC_SLOTS;
+        // word = distance bits << 32 | step tag (2 bits) | valid bit | ~index (29 bits).  The tag (j / 4) & 3 tells a
+        // word of THIS step from the one the same slot held four steps ago, so a consumer can never take a stale
+        // candidate whatever order two relaxed stores to different addresses become visible in (no slot clearing,
+        // no release / acquire); within a step every word carries the same tag, so the integer max is unchanged.
+        const unsigned tag = ((unsigned)(((j >> 2) & 3) << 1) | 1u) << 29;
+        if (lane == 0) {
+            const unsigned long long key =
+                vmax < 0 ? (unsigned long long)tag : (((unsigned long long)(unsigned)vmax << 32) | tag | ((~imin) & 0x1fffffffu));
+            fps_st(slot + g * NW + wave, key);
         }
-        if (lane == 0) { sv[wave] = best; si[wave] = besti; }
-        __syncthreads();
         if (wave == 0) {
-            float bv = lane < FPSC_T / 64 ? sv[lane] : -1.f;
-            int bi = lane < FPSC_T / 64 ? si[lane] : 0x7fffffff;
-#pragma unroll
-            for (int m = 1; m < FPSC_T / 64; m <<= 1) {
-                const float ov = __shfl_xor(bv, m);
-                const int oi = __shfl_xor(bi, m);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            unsigned long long* slot = ring + (j & 3) * FPSC_GMAX;
-            // word = distance bits << 32 | step tag (2 bits) | valid bit | ~index (29 bits).  The tag (j / 4) & 3 tells a
-            // word of THIS step from the one the same slot held four steps ago, so a consumer can never take a stale
-            // candidate whatever order two relaxed stores to different addresses become visible in (no slot clearing,
-            // no release / acquire); within a step every word carries the same tag, so the integer max is unchanged.
-            const unsigned long long tagv = ((unsigned long long)(((j >> 2) & 3) << 1) | 1ull) << 29;
-            if (lane == 0) {
-                const unsigned long long key =
-                    bv < 0.f ? tagv : (((unsigned long long)__float_as_uint(bv) << 32) | tagv | ((~(unsigned)bi) & 0x1fffffffu));
-                __hip_atomic_store(slot + g, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            unsigned long long k = 0;
+            unsigned long long k0, k1;
             unsigned spins = 0;
             bool dead = false;
             for (;;) {
-                k = lane < G ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tagv;
-                if (!__any((k & (7ull << 29)) != tagv)) break;
-                if (++spins > FPSC_SPIN_MAX || (spins % 1024 == 0 &&
-                        __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { dead = true; break; }
+                k0 = lane < S ? fps_ld(slot + lane) : (unsigned long long)tag;
+                k1 = lane + 64 < S ? fps_ld(slot + lane + 64) : (unsigned long long)tag;
+                if (!__any(((unsigned)k0 & (7u << 29)) != tag || ((unsigned)k1 & (7u << 29)) != tag)) break;
+                if (++spins > FPSC_SPIN_MAX || (spins % 1024 == 0 && fps_ld(abort_w) == FPSC_ST_ABORT)) { dead = true; break; }
             }
-            if (dead) {
-                if (lane == 0) __hip_atomic_store(abort_w, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                k = 1ull;                                             // drain: every later step aborts at once too
-            }
-            if (lane >= G) k = 0;
-            // every lane fetches ITS candidate's coordinates while the maximum is being reduced: the winner's are
-            // then already in registers (one dependent L2 round trip less per step)
-            const int ci = (lane < G && !dead) ? (int)((~(unsigned)k) & 0x1fffffffu) : 0;
-            const int cic = (unsigned)ci < (unsigned)N ? ci : 0;
-            const float cx = p[cic * 3 + 0], cy = p[cic * 3 + 1], cz = p[cic * 3 + 2];
-            unsigned long long kmax = k;
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                const unsigned long long ok = __shfl_xor(kmax, m);
-                kmax = ok > kmax ? ok : kmax;
-            }
-            if (k == kmax && lane < G) {                              // keys are distinct (the index is part of the key)
-                s_cur = dead ? -1 : ci;
-                s_lx = cx; s_ly = cy; s_lz = cz;
+            if (dead) {                                                     // uniform over the wave
+                if (lane == 0) { fps_st(abort_w, FPSC_ST_ABORT); s_l[j & 1][3] = -1.f; }
+            } else {
+                const unsigned long long km = k0 > k1 ? k0 : k1;
+                // every lane fetches ITS candidate's coordinates while the maximum is being reduced: the winner's are then
+                // already in registers (one dependent L2 round trip less per step)
+                const unsigned ci = (~(unsigned)km) & 0x1fffffffu;
+                const unsigned cic = ci < (unsigned)N ? ci : 0u;
+                const float cx = p[cic * 3 + 0], cy = p[cic * 3 + 1], cz = p[cic * 3 + 2];
+                const unsigned hi = (unsigned)(km >> 32), lo = (unsigned)km;
+                const unsigned hmax = wave_max_u32(hi);
+                const unsigned lmax = wave_max_u32(hi == hmax ? lo : 0u);
+                const int wl = __builtin_ctzll(__ballot(hi == hmax && lo == lmax));       // keys are distinct: one lane matches
+                if (lane == wl) { s_l[j & 1][0] = cx; s_l[j & 1][1] = cy; s_l[j & 1][2] = cz; s_l[j & 1][3] = 1.f; }
+                if (g == 0 && lane == 0) o[j] = (int)((~lmax) & 0x1fffffffu);
             }
         }
+        // s_l is double-buffered: wave 0 rewrites this step's half only after the NEXT step's barrier, which every wave
+        // reaches after it has read the half here
         __syncthreads();
-        cur = s_cur;
-        lx = s_lx; ly = s_ly; lz = s_lz;
-        if (cur < 0) break;                                             // uniform over the workgroup: aborted
-        if (g == 0 && tid == 0) o[j] = cur;
+        lx = s_l[j & 1][0]; ly = s_l[j & 1][1]; lz = s_l[j & 1][2];
+        if (s_l[j & 1][3] < 0.f) return;                                  // uniform over the workgroup: aborted
     }
+    // every step of this cloud completed (a step completes only when all of its waves published): mark the row valid
+    if (g == 0 && tid == 0) fps_st(abort_w, FPSC_ST_DONE);
 }
 
 // ---- large-K kNN: one workgroup per query; keys (dist bits << 32 | index) bitonic-sorted in LDS.
@@ -237,11 +264,69 @@ __global__ __launch_bounds__(KS_T) void knn_sort_kernel(const float* __restrict_
     }
 }
 
+// ---- normalize_pc (modules/utils/patch.py:168-178): centroid = mean over the points, pc - centroid, divided by the largest
+// norm.  One workgroup per cloud / patch with a FIXED summation order (thread t adds points t, t + 256, ... in order, then a
+// binary tree over the 256 partial sums), so a cloud's result does not depend on how many clouds share the launch - torch's
+// mean picks its reduction tree from the whole tensor shape.  All arithmetic unfused fp32, IEEE sqrt and division.
+constexpr int NRM_T = 256;
+__global__ __launch_bounds__(NRM_T) void normalize_pc_kernel(const float* __restrict__ x, int N, float* __restrict__ out,
+                                                             float* __restrict__ centroid, float* __restrict__ fdist) {
+#pragma clang fp contract(off)
+    __shared__ float red[3][NRM_T];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = x + (size_t)b * N * 3;
+    float* o = out + (size_t)b * N * 3;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int i = tid; i < N; i += NRM_T) {
+        sx = __fadd_rn(sx, p[i * 3 + 0]); sy = __fadd_rn(sy, p[i * 3 + 1]); sz = __fadd_rn(sz, p[i * 3 + 2]);
+    }
+    red[0][tid] = sx; red[1][tid] = sy; red[2][tid] = sz;
+    __syncthreads();
+    for (int s = NRM_T / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[0][tid] = __fadd_rn(red[0][tid], red[0][tid + s]);
+            red[1][tid] = __fadd_rn(red[1][tid], red[1][tid + s]);
+            red[2][tid] = __fadd_rn(red[2][tid], red[2][tid + s]);
+        }
+        __syncthreads();
+    }
+    const float cx = __fdiv_rn(red[0][0], (float)N), cy = __fdiv_rn(red[1][0], (float)N), cz = __fdiv_rn(red[2][0], (float)N);
+    __syncthreads();
+    float m = 0.f;
+    for (int i = tid; i < N; i += NRM_T) {
+        const float dx = __fsub_rn(p[i * 3 + 0], cx), dy = __fsub_rn(p[i * 3 + 1], cy), dz = __fsub_rn(p[i * 3 + 2], cz);
+        m = fmaxf(m, __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))));
+    }
+    red[0][tid] = m;
+    __syncthreads();
+    for (int s = NRM_T / 2; s > 0; s >>= 1) {
+        if (tid < s) red[0][tid] = fmaxf(red[0][tid], red[0][tid + s]);
+        __syncthreads();
+    }
+    const float fd = red[0][0];
+    for (int i = tid; i < N; i += NRM_T) {
+        o[i * 3 + 0] = __fdiv_rn(__fsub_rn(p[i * 3 + 0], cx), fd);
+        o[i * 3 + 1] = __fdiv_rn(__fsub_rn(p[i * 3 + 1], cy), fd);
+        o[i * 3 + 2] = __fdiv_rn(__fsub_rn(p[i * 3 + 2], cz), fd);
+    }
+    if (tid == 0) {
+        centroid[b * 3 + 0] = cx; centroid[b * 3 + 1] = cy; centroid[b * 3 + 2] = cz;
+        fdist[b] = fd;
+    }
+}
+
 }  // namespace
 
 namespace {
-__global__ __launch_bounds__(256) void fps_zero_kernel(float* p, long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0.f;
+// clears the scratch rows and sets every cloud's status word to "not finished"
+__global__ __launch_bounds__(256) void fps_init_kernel(float* p, long long n, int B, long long stride_words) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = 0.f;
+        const long long w = i >> 1;                                       // 64-bit word index
+        if ((i & 1) == 0 && stride_words > 0 && w % stride_words == FPSC_RING && w / stride_words < B)
+            v = __uint_as_float((unsigned)FPSC_ST_INIT);                  // low half of the status word
+        p[i] = v;
+    }
 }
 }  // namespace
 
@@ -268,7 +353,7 @@ extern "C" int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, i
         unsigned long long* ring = reinterpret_cast<unsigned long long*>(mind);
         // cleared by a kernel, not hipMemsetAsync: a memset node inside a captured hipGraph was observed to race with the
         // kernel node that follows it (csrc/emd.hip)
-        hipLaunchKernelGGL(fps_zero_kernel, dim3(256), dim3(256), 0, s, mind, (long long)B * N);
+        hipLaunchKernelGGL(fps_init_kernel, dim3(256), dim3(256), 0, s, mind, (long long)B * N, B, stride);
         const dim3 grid(B * G), block(FPSC_T);
         switch (ppt) {
             case 1: hipLaunchKernelGGL(fps_coop_kernel<1>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); break;
@@ -303,5 +388,13 @@ extern "C" int pf_knn_large(const float* ref, const float* query, int B, int N, 
                             KS_NMAX * 8);
     hipLaunchKernelGGL(knn_sort_kernel, dim3(M, B), dim3(KS_T), lds, (hipStream_t)stream, ref, query, N, M, K, np, kp,
                        idx_out, dist_out);
+    return pf_last_launch_status();
+}
+
+// normalize_pc (patch.py:168-178) of B clouds / patches: x [B,N,3] -> out [B,N,3] (may alias x), centroid [B,3], fdist [B]
+extern "C" int pf_normalize_pc(const float* x, int B, int N, float* out, float* centroid, float* fdist, void* stream) {
+    if (!x || !out || !centroid || !fdist) return PF_ERR_NULL;
+    if (B <= 0 || N <= 0 || (long long)N * 3 > 0x7fffffffll) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(normalize_pc_kernel, dim3(B), dim3(NRM_T), 0, (hipStream_t)stream, x, N, out, centroid, fdist);
     return pf_last_launch_status();
 }

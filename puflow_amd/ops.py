@@ -141,8 +141,9 @@ def furthest_point_sample(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
 
 
 def _check_fps_abort(lib, mind: torch.Tensor, B: int, N: int) -> None:
-    """The cooperative FPS kernel's workgroups wait for each other with a BOUNDED spin; a cloud whose workgroups gave up
-    has its abort word set and an invalid index row.  One small device -> host read per call (FPS itself is tens of ms)."""
+    """The cooperative FPS kernel's workgroups wait for each other with a BOUNDED spin.  A cloud's status word is 0 only when
+    all of its steps completed (2 = never finished / never started, 1 = its workgroups gave up waiting): anything else means
+    an invalid index row.  One small device -> host read per call (FPS itself is tens of ms)."""
     import ctypes
     stride, word = ctypes.c_longlong(0), ctypes.c_longlong(0)
     if not lib.pf_fps_scratch_layout(N, ctypes.byref(stride), ctypes.byref(word)):
@@ -150,8 +151,22 @@ def _check_fps_abort(lib, mind: torch.Tensor, B: int, N: int) -> None:
     words = mind.view(-1)[: (B * N) // 2 * 2].view(torch.int64)
     pos = torch.arange(B, device=mind.device, dtype=torch.int64) * stride.value + word.value
     if bool((words[pos] != 0).any()):
-        raise _lib.PuflowHipError("pf_fps: the cooperative kernel's workgroups timed out waiting for each other "
-                                  "(a cloud's workgroups were not co-resident); the sampled indices are invalid")
+        raise _lib.PuflowHipError("pf_fps: the cooperative kernel did not complete every cloud (its workgroups timed out "
+                                  "waiting for each other or were never co-resident); the sampled indices are invalid")
+
+
+def normalize_pc(pc: torch.Tensor):
+    """PatchHelper.normalize_pc (modules/utils/patch.py:168-178) on the GPU: pc [B,N,3] -> (normalised [B,N,3],
+    centroid [B,1,3], furthest distance [B,1,1]).  Fixed summation order per cloud: independent of the batch size."""
+    lib = _lib.load()
+    pc = _f32c(pc)
+    B, N, _ = pc.shape
+    out = torch.empty_like(pc)
+    cen = torch.empty((B, 1, 3), dtype=torch.float32, device=pc.device)
+    fd = torch.empty((B, 1, 1), dtype=torch.float32, device=pc.device)
+    _lib.check(lib.pf_normalize_pc(pc.data_ptr(), B, N, out.data_ptr(), cen.data_ptr(), fd.data_ptr(), _stream()),
+               "pf_normalize_pc")
+    return out, cen, fd
 
 
 def gather_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

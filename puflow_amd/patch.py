@@ -95,6 +95,8 @@ class PatchHelper(object):
 
     @staticmethod
     def normalize_pc(pc: Tensor):
+        if pc.is_cuda and pc.dim() == 3 and pc.shape[-1] == 3:
+            return ops.normalize_pc(pc)          # fixed summation order: a cloud's result does not depend on the batch
         centroid = torch.mean(pc, dim=1, keepdim=True)
         pc = pc - centroid
         dist = torch.sum(pc ** 2, dim=-1, keepdim=True).sqrt()
@@ -115,7 +117,7 @@ class PatchHelper(object):
     def remove_outliers(sr: Tensor, lr: Tensor, num_outliers: int) -> Tensor:
         (B, N, _), device = sr.shape, sr.device
         dist1, _, _, _ = ops.chamfer_3DDist()(sr, lr)
-        idx_outliers = torch.argsort(dist1, dim=-1, descending=True)[:, :num_outliers]
+        idx_outliers = torch.argsort(dist1, dim=-1, descending=True, stable=True)[:, :num_outliers]
         idxb = torch.arange(B, device=device).view(-1, 1)
         keep = torch.ones((B, N), dtype=torch.int32, device=device)
         keep[idxb, idx_outliers] = 0

@@ -22,7 +22,8 @@ def _worker(rank, world, port, q):
         torch.manual_seed(100 + rank)                       # ranks start with DIFFERENT weights
         net = PointInterpFlow(3)
         D.broadcast_module(net, src=0)
-        w = net.merge_convs[2].conv1.weight.detach().clone()
+        # numpy, not a tensor: a tensor crosses the queue as a shared-memory file that disappears when this process exits
+        w = net.merge_convs[2].conv1.weight.detach().clone().numpy()
         # shards cover the batch exactly once
         total = 37
         lo, hi = D.shard_bounds(total, rank, world)
@@ -59,7 +60,7 @@ def test_two_rank_gloo():
     (r0, lo0, hi0, ok0, w0, g0, n0, t0, rm0), (r1, lo1, hi1, ok1, w1, g1, n1, t1, rm1) = res
     assert rm0 == rm1 == 1.0                                     # buffers follow rank 0
     assert (lo0, hi0, lo1, hi1) == (0, 19, 19, 37) and ok0 and ok1
-    assert torch.equal(w0, w1)                                   # broadcast made the weights identical
+    assert (w0 == w1).all()                                      # broadcast made the weights identical
     assert n0 == n1 == 806103                                    # the whole model is one 3.2 MB bucket
     assert g0 == g1 == [1.5, 0.0]                                # mean of (1, 2); absent grads count as zero
     assert t0 == t1 == 2.0

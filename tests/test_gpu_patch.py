@@ -110,6 +110,29 @@ def test_cli_end_to_end(tmp_path):
     assert abs(cd_out - cd_ref) < 0.02 * cd_ref
 
 
+def test_cli_batches_files_without_changing_any_cloud(tmp_path):
+    """The CLI passes consecutive files of equal point count through the pipeline together (`cloud_batch`): every output
+    file must be byte for byte what the one-file-at-a-time run (the reference's loop, upsample.py:42-57) writes, whatever
+    the grouping - equal sizes batched, a different size in between, a batch limit that splits a run."""
+    from puflow_amd import upsample as U
+    src = tmp_path / "in"
+    src.mkdir()
+    sizes = {"a.xyz": 1024, "b.xyz": 1024, "c.xyz": 768, "d.xyz": 1024, "e.xyz": 1024, "f.xyz": 1024}
+    for k, (name, n) in enumerate(sizes.items()):
+        np.savetxt(src / name, (synth_patches(1, n, seed=40 + k)[0] * 2.0 - 0.5).numpy(), fmt="%.6f")
+    sd = synth_state_dict(9)
+    paths = [str(src / name) for name in sizes]
+    outs = {}
+    for cb in (1, 2, 8):
+        dst = tmp_path / f"out{cb}"
+        dst.mkdir()
+        U.upsampling(paths, str(dst), None, up_ratio=4, num_outlier=24, num_patch=256, seed=2021, state_dict=sd, cloud_batch=cb)
+        outs[cb] = {name: (dst / name).read_bytes() for name in sizes}
+        assert all(len(v) > 0 for v in outs[cb].values())
+    assert outs[2] == outs[1] and outs[8] == outs[1]
+    assert np.loadtxt(tmp_path / "out8" / "c.xyz").shape == (768 * 4, 3)
+
+
 def test_knn_large_streams_clouds_beyond_the_lds_limit():
     """knn_cuda.KNN takes any N (patch.py:33,107): clouds of more than 16 384 points stream through LDS in chunks; the
     result is still the exact (distance, index)-ordered top K."""
@@ -138,9 +161,18 @@ def test_fps_abort_word_is_reported():
     import ctypes
     stride, word = ctypes.c_longlong(0), ctypes.c_longlong(0)
     assert lib.pf_fps_scratch_layout(N, ctypes.byref(stride), ctypes.byref(word)) == 1
-    mind.view(-1).view(torch.int64)[2 * stride.value + word.value] = 1
-    with pytest.raises(_lib.PuflowHipError):
-        ops._check_fps_abort(lib, mind, B, N)
+    for status in (1, 2):                                        # 1 = gave up waiting, 2 = never finished (initial value)
+        mind.zero_()
+        mind.view(-1).view(torch.int64)[2 * stride.value + word.value] = status
+        with pytest.raises(_lib.PuflowHipError):
+            ops._check_fps_abort(lib, mind, B, N)
+    # a real run leaves every cloud's status at 0 ("all steps completed")
+    pts = synth_patches(B, N, seed=77).to(DEV)
+    idx = torch.zeros((B, 64), dtype=torch.int32, device=DEV)
+    _lib.check(lib.pf_fps(pts.data_ptr(), B, N, 64, mind.data_ptr(), idx.data_ptr(), None), "pf_fps")
+    torch.cuda.synchronize()
+    words = mind.view(-1).view(torch.int64)
+    assert all(int(words[b * stride.value + word.value]) == 0 for b in range(B))
     assert lib.pf_fps_scratch_layout(2048, None, None) == 0      # single-workgroup kernel: no ring to check
     ops._check_fps_abort(lib, mind[:, :2048].contiguous(), B, 2048)
 

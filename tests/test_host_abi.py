@@ -173,3 +173,20 @@ def test_cnf_module_state_dict_matches_reference_census(golden_dir):
     assert len(census) == 390 and [k for k, _, _ in census] == list(sd.keys())
     for k, shape, dt in census:
         assert list(sd[k].shape) == shape and str(sd[k].dtype) == dt, k
+
+
+def test_save_xyz_writes_the_bytes_of_savetxt(tmp_path):
+    """upsample.py:57 writes with np.savetxt(fmt='%.6f'); the CLI's one-call writer must produce the same file."""
+    import numpy as np
+    from puflow_amd.upsample import save_xyz
+    rng = np.random.default_rng(3)
+    a = ((rng.random((5000, 3)) - 0.5) * 7.0).astype(np.float32)
+    a[0] = [0.0, -0.0, 1e-7]
+    a[1] = [123456.789, -1e-3, 0.9999995]
+    np.savetxt(tmp_path / "ref.xyz", a, fmt="%.6f")
+    save_xyz(tmp_path / "got.xyz", a)
+    assert (tmp_path / "got.xyz").read_bytes() == (tmp_path / "ref.xyz").read_bytes()
+    one = a[:1]
+    np.savetxt(tmp_path / "ref1.xyz", one, fmt="%.6f")
+    save_xyz(tmp_path / "got1.xyz", one)
+    assert (tmp_path / "got1.xyz").read_bytes() == (tmp_path / "ref1.xyz").read_bytes()
