@@ -375,6 +375,12 @@ int pf_fps_scratch_layout(int N, long long* stride_words, long long* abort_word)
  * summation order: a cloud's result does not depend on B. */
 int pf_normalize_pc(const float* x, int B, int N, float* out, float* centroid, float* fdist, void* stream);
 
+/* Text format of the CLI's output clouds (HOST memory, no GPU work): the bytes np.savetxt(path, cloud, fmt='%.6f') writes
+ * (modules/discrete/upsample.py:57) - rows of c "%.6f" values separated by one blank, '\n' after every row.  pts [n,c]
+ * float32; out must hold pf_format_xyz_bound(n, c) bytes.  Returns the bytes written or a negative PF_ERR_* code. */
+long long pf_format_xyz_bound(long long n, int c);
+long long pf_format_xyz(const float* pts, long long n, int c, char* out, long long cap);
+
 /* K nearest references of every query for large K (patch extraction, K = 256).  Replaces knn_cuda.KNN
  * (patch.py:33,107).  ref [B,N,3], query [B,M,3], K <= N (any N; K <= 8192 when N > 16384: the references are then
  * streamed through LDS in chunks) -> idx_out [B,M,K] int32 ordered by (distance, index); dist_out [B,M,K] squared L2

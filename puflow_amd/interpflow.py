@@ -128,8 +128,28 @@ class CondList(list):
 # ----------------------------------------------------------------------------------------
 # HIP engine
 # ----------------------------------------------------------------------------------------
+def _host_state_dict(sd):
+    """The state dict on the host with ONE device -> host copy per dtype (the weight folding reads ~400 small tensors: taken
+    one at a time from the GPU that is ~400 synchronising copies, 0.09 s of the 0.19 s a plan takes to build)."""
+    out, groups = {}, {}
+    for k, v in sd.items():
+        v = v.detach()
+        if v.is_cuda:
+            groups.setdefault(v.dtype, []).append((k, v))
+        else:
+            out[k] = v
+    for dt, items in groups.items():
+        flat = torch.cat([v.reshape(-1) for _, v in items]).cpu()
+        pos = 0
+        for k, v in items:
+            out[k] = flat[pos:pos + v.numel()].reshape(v.shape)
+            pos += v.numel()
+    return {k: out[k] for k in sd}
+
+
 class _Engine:
     def __init__(self, sd, device: torch.device, ec_mode: Optional[str] = None):
+        sd = _host_state_dict(sd)
         self.lib = _lib.load()
         self.device = device
         # EdgeConv arithmetic of the 128-channel units (PF_EC_MODE), all within the same 1e-5 parity bar:

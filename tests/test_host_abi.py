@@ -176,13 +176,27 @@ def test_cnf_module_state_dict_matches_reference_census(golden_dir):
 
 
 def test_save_xyz_writes_the_bytes_of_savetxt(tmp_path):
-    """upsample.py:57 writes with np.savetxt(fmt='%.6f'); the CLI's one-call writer must produce the same file."""
+    """upsample.py:57 writes with np.savetxt(fmt='%.6f'); the library's formatter (pf_format_xyz) must produce the same file:
+    random clouds, values on and next to rounding ties of the 6th decimal, negative values that round to zero, large and
+    tiny magnitudes, non-finite values."""
     import numpy as np
     from puflow_amd.upsample import save_xyz
     rng = np.random.default_rng(3)
-    a = ((rng.random((5000, 3)) - 0.5) * 7.0).astype(np.float32)
+    a = ((rng.random((20000, 3)) - 0.5) * 7.0).astype(np.float32)
     a[0] = [0.0, -0.0, 1e-7]
     a[1] = [123456.789, -1e-3, 0.9999995]
+    a[2] = [-4e-7, -5e-7, -6e-7]
+    a[3] = [0.5, 0.25, 0.125]                                  # exact binary fractions
+    a[4] = [2.5e-6, 3.5e-6, -2.5e-6]
+    a[5] = [1e9, -3.9e9, 4.1e9]                                # around the fast path's limit
+    a[6] = [3.4e38, -1e20, 1e-30]
+    a[7] = [np.inf, -np.inf, np.nan]
+    a[8] = [-np.nan, np.float32(-0.0), np.float32(1.17549435e-38)]
+    ties = (np.arange(0, 3000, dtype=np.float64) + 0.5) * 1e-6           # nearest float32 of k + 0.5 millionths
+    a[100:1100] = ties.astype(np.float32).reshape(1000, 3)
+    a[1100:2100] = np.nextafter(ties.astype(np.float32), np.float32(1)).reshape(1000, 3)
+    a[2100:3100] = -np.nextafter(ties.astype(np.float32), np.float32(0)).reshape(1000, 3)
+    a[3100:4100] = (rng.integers(0, 2 ** 22, (1000, 3)) / 2.0 ** 16).astype(np.float32)   # exact ties of the 6th decimal exist here: k / 65536
     np.savetxt(tmp_path / "ref.xyz", a, fmt="%.6f")
     save_xyz(tmp_path / "got.xyz", a)
     assert (tmp_path / "got.xyz").read_bytes() == (tmp_path / "ref.xyz").read_bytes()
@@ -190,3 +204,7 @@ def test_save_xyz_writes_the_bytes_of_savetxt(tmp_path):
     np.savetxt(tmp_path / "ref1.xyz", one, fmt="%.6f")
     save_xyz(tmp_path / "got1.xyz", one)
     assert (tmp_path / "got1.xyz").read_bytes() == (tmp_path / "ref1.xyz").read_bytes()
+    d = a[:50].astype(np.float64) * 1.000000123                # not float32: the pure-Python path
+    np.savetxt(tmp_path / "ref2.xyz", d, fmt="%.6f")
+    save_xyz(tmp_path / "got2.xyz", d)
+    assert (tmp_path / "got2.xyz").read_bytes() == (tmp_path / "ref2.xyz").read_bytes()

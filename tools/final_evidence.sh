@@ -21,4 +21,7 @@ timeout -k 10 200 python3 tools/train_breakdown.py 2>&1 | grep -v "Warn\|warn" >
 find "$OUT/train_trace" -name "*kernel_trace.csv" -delete
 timeout -k 10 200 python3 tools/time_cnf.py > "$OUT/time_cnf.txt" 2>&1; head -4 "$OUT/time_cnf.txt"
 timeout -k 10 200 python3 tools/stage_times.py > "$OUT/stage_times.txt" 2>&1; tail -15 "$OUT/stage_times.txt"
+timeout -k 10 200 python3 tools/time_fps.py 2>&1 | grep "B=" > "$OUT/time_fps.txt"; for b in 16 32; do timeout -k 10 100 python3 tools/time_fps.py 99840 20024 $b 2>&1 | grep "B=" >> "$OUT/time_fps.txt"; done; cat "$OUT/time_fps.txt"
+timeout -k 10 200 python3 tools/time_patch.py 2>&1 | grep -v amdgpu.ids > "$OUT/time_patch.txt"; cat "$OUT/time_patch.txt"
+timeout -k 10 300 python3 tools/time_cli.py 5000 64 2>&1 | grep -v amdgpu.ids > "$OUT/time_cli.txt"; cat "$OUT/time_cli.txt"
 echo "evidence $TAG complete"

@@ -17,7 +17,7 @@ with tempfile.TemporaryDirectory() as tmp:
     for k in range(F):
         np.savetxt(os.path.join(src, f"cloud{k:03d}.xyz"), synth_patches(1, N, seed=100 + k)[0].numpy(), fmt="%.6f")
     paths = sorted(os.path.join(src, f) for f in os.listdir(src))
-    for cb in (1, 1, 4, 8, 16):
+    for cb in (1, 1, 8, 16, 32):
         dst = os.path.join(tmp, f"out{cb}"); os.makedirs(dst, exist_ok=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
