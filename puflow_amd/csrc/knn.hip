@@ -205,8 +205,15 @@ __global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ 
 // A workgroup owns 64 queries (lane = query in every wave); wave w scans reference quarter w.  Same 32 group
 // minima (8 strided groups per quarter), same tau, same candidates - but 4x the waves of knn2_kernel for the same
 // work: at 32 x 2048 that kernel puts ONE wave on each SIMD, so nothing hides its readlane / LDS / dependent-issue stalls.
-// Candidate lists are per (wave, lane); all waves then merge them by rank in (distance, index) order (a query at a time, a
+// Candidate lists are per (wave, lane).  4 slices: every wave reduces its own list to a sorted top K, wave 0 merges the four
+// sorted lists of each query; 8 / 16 slices: all waves merge the lists by rank in (distance, index) order (a query at a time, a
 // candidate per lane).  Overflow of any list -> exact scan of that query tile by wave 0.
+// Where the time goes at 32 x 2048, K = 16 (tools/tune_knn.py, ablation builds): sweep A + threshold 29 us = the VALU bound of
+// its 8.5 operations per pair; sweep B 42 us (the same arithmetic + the divergent appends: almost every group of four
+// references is a candidate for SOME lane of the wave); selection 21 us (it was 42 us when wave 0 inserted all four lists
+// alone).  Tried and dropped: a 3-fma filter distance |r|^2 - 2 q.r from a per-reference table for both sweeps, widened by a
+// rounding bound so that the exact answer survives (built, bit-exact on all tests): 4.5 instead of 8.5 operations per pair,
+// but the kernel gained 2 us and the table kernel cost 3.5.
 // KNN4_W = waves per workgroup = reference slices: 4 when the grid fills the chip anyway (32 x 2048: 1024 workgroups), 8 or
 // 16 for small batches (4 x 2048: 128 workgroups of 16 waves instead of 4 - the kernel's latency is one wave's two sweeps
 // over its slice, so more, shorter slices cut it almost proportionally).  Same results for every split.
@@ -232,6 +239,11 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
     const float* q = p1 + ((size_t)b * N + (live ? n : N - 1)) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float* __restrict__ r = p2 + (size_t)b * M * 3;
+    // distance to reference j (wave-uniform j: scalar loads, SGPR operands)
+    auto fdist = [&](int j) {
+        const float* rr = r + (size_t)j * 3;
+        return sqdist(qx, qy, qz, rr[0], rr[1], rr[2]);
+    };
     const int mq = ((M + KNN4_W * 64 - 1) / (KNN4_W * 64)) * 64;      // slice length, multiple of 64
     const int jb = wave * mq, je = min(jb + mq, M);                   // this wave's references [jb, je)
     const int jfull = jb + ((je - jb) > 0 ? ((je - jb) / KNN4_U) * KNN4_U : 0);   // end of the unguarded chunks
@@ -245,18 +257,12 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
         for (int g = 0; g < KNN4_G; ++g) gm[g] = __builtin_inff();
         for (int j0 = jb; j0 < jfull; j0 += KNN4_U) {
 #pragma unroll
-            for (int c = 0; c < KNN4_U; ++c) {
-                const float* rr = r + (size_t)(j0 + c) * 3;
-                gm[c % KNN4_G] = fminf(gm[c % KNN4_G], sqdist(qx, qy, qz, rr[0], rr[1], rr[2]));
-            }
+            for (int c = 0; c < KNN4_U; ++c) gm[c % KNN4_G] = fminf(gm[c % KNN4_G], fdist(j0 + c));
         }
         for (int j0 = jfull; j0 < je; j0 += KNN4_G) {                   // tail: uniform guards, same group order
 #pragma unroll
             for (int g = 0; g < KNN4_G; ++g)
-                if (j0 + g < je) {
-                    const float* rr = r + (size_t)(j0 + g) * 3;
-                    gm[g] = fminf(gm[g], sqdist(qx, qy, qz, rr[0], rr[1], rr[2]));
-                }
+                if (j0 + g < je) gm[g] = fminf(gm[g], fdist(j0 + g));
         }
 #pragma unroll
         for (int g = 0; g < KNN4_G; ++g) gms[wave * KNN4_G + g][lane] = gm[g];
@@ -275,52 +281,112 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
         for (int i = 1; i < K; ++i) tau = fmaxf(tau, fminf(ha[i], hb[K - 1 - i]));
     }
 
+#if defined(PF_KNN_ABL) && PF_KNN_ABL == 2          // timing-only build: sweep A + threshold only
+    if (wave == 0 && live) idx_out[((size_t)b * N + n) * K] = __float_as_int(tau);
+    return;
+#endif
     // ---- sweep B: collect this slice's candidates with d <= tau (in index order)
     int cnt = 0;
-    auto visit = [&](int j) {
-        const float* rr = r + (size_t)j * 3;
-        const float d = sqdist(qx, qy, qz, rr[0], rr[1], rr[2]);
+    auto take = [&](float d, int j) {
         if (d <= tau) {
             if (cnt < KNN4_CAP) lst[wave][cnt][lane] = (unsigned short)j;
             ++cnt;
         }
     };
     for (int j0 = jb; j0 < jfull; j0 += KNN4_U) {
+        // all distances of the chunk first (straight-line code: the scalar loads of the references are issued together),
+        // then the rarely taken appends - with the branch right behind every distance each reference paid its own
+        // scalar-load latency
+        float dd[KNN4_U];
 #pragma unroll
-        for (int c = 0; c < KNN4_U; ++c) visit(j0 + c);
+        for (int c = 0; c < KNN4_U; ++c) dd[c] = fdist(j0 + c);
+#pragma unroll
+        for (int c = 0; c < KNN4_U; c += 4) {                               // ~1 % of the references pass: test four at a time
+            if (fminf(fminf(dd[c], dd[c + 1]), fminf(dd[c + 2], dd[c + 3])) <= tau) {
+                take(dd[c], j0 + c); take(dd[c + 1], j0 + c + 1); take(dd[c + 2], j0 + c + 2); take(dd[c + 3], j0 + c + 3);
+            }
+        }
     }
-    for (int j = jfull; j < je; ++j) visit(j);
+    for (int j = jfull; j < je; ++j) take(fdist(j), j);
     cnts[wave][lane] = cnt;
+#if defined(PF_KNN_ABL) && PF_KNN_ABL == 1          // timing-only build (tools/tune_knn.py): no merge
     __syncthreads();
+    if (wave == 0 && live) idx_out[((size_t)b * N + n) * K] = cnt;
+    return;
+#endif
     if constexpr (KNN4_W == 4) {
-        // 4 slices (the grid fills the chip by itself): wave 0 inserts the lists in slice order = increasing index into per-lane
-        // top-K registers.  Measured against the rank merge below at 32 x 2048: 0.124 vs 0.137 ms - 16 queries per wave, one
-        // after the other, cost more than one wave's inserts
+        // 4 slices (the grid fills the chip by itself).  Every wave first reduces ITS OWN list to a sorted top K (exact
+        // distances, inserted in list order = increasing index; the next candidate's coordinates are fetched while the current
+        // one is inserted), then wave 0 merges the four sorted lists of every query (lane) - 16 steps of "smallest head".
+        // Before: wave 0 alone inserted all four lists, list after list, while three waves idled: 42 of the kernel's 112 us at
+        // 32 x 2048 (tools/tune_knn.py); one pass over each lane's concatenated lists: 31 us.  (The rank merge of the
+        // 8 / 16-slice path measured slower here: 16 queries per wave, one after the other.)
+        static_assert(KNN4_CAP * 2 >= K * 4, "a wave's list region is reused for its K sorted distances");
+        __shared__ unsigned short sidx[4][K][64];
+        float (*sdst)[64] = reinterpret_cast<float (*)[64]>(&lst[wave][0][0]);      // own region: only this wave reads lst[wave]
+        {
+            float bd[K];
+            int bi[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) { bd[i] = __builtin_inff(); bi[i] = 0xffff; }
+            const int cme = cnt < KNN4_CAP ? cnt : KNN4_CAP;
+            int j = cme > 0 ? (int)lst[wave][0][lane] : 0;
+            float rx = r[j * 3 + 0], ry = r[j * 3 + 1], rz = r[j * 3 + 2];
+            for (int t = 0; __any(t < cme); ++t) {
+                const int jn = t + 1 < cme ? (int)lst[wave][t + 1][lane] : 0;
+                const float nx = r[jn * 3 + 0], ny = r[jn * 3 + 1], nz = r[jn * 3 + 2];
+                if (t < cme) topk_insert<K>(bd, bi, sqdist(qx, qy, qz, rx, ry, rz), j);
+                j = jn; rx = nx; ry = ny; rz = nz;
+            }
+            // all lanes of the wave are past their last list read (the loop above is wave-uniform): overwrite the region
+#pragma unroll
+            for (int i = 0; i < K; ++i) { sdst[i][lane] = bd[i]; sidx[wave][i][lane] = (unsigned short)bi[i]; }
+        }
+        __syncthreads();
         if (wave != 0) return;
         float bd[K];
         int bi[K];
-        bool over = false;
-#pragma unroll
-        for (int w = 0; w < KNN4_W; ++w) over |= cnts[w][lane] > KNN4_CAP;
-        if (__any(over)) {
+        if (__any(cnts[0][lane] > KNN4_CAP || cnts[1][lane] > KNN4_CAP || cnts[2][lane] > KNN4_CAP || cnts[3][lane] > KNN4_CAP)) {
             exact_scan<K>(qx, qy, qz, r, M, bd, bi);      // heavy ties: redo this query tile exactly (rare)
         } else {
+            // heads of the four lists (list w = slice w = lower indices first: on equal distances the lower list wins)
+            float hd[4];
+            int hi[4], hp[4];
 #pragma unroll
-            for (int i = 0; i < K; ++i) { bd[i] = __builtin_inff(); bi[i] = -1; }
-            for (int w = 0; w < KNN4_W; ++w) {
-                const int cw = cnts[w][lane];
-                for (int s = 0; __any(s < cw); ++s) {
-                    if (s < cw) {
-                        const int j = lst[w][s][lane];
-                        const float d = sqdist(qx, qy, qz, r[j * 3 + 0], r[j * 3 + 1], r[j * 3 + 2]);
-                        topk_insert<K>(bd, bi, d, j);
-                    }
+            for (int w = 0; w < 4; ++w) {
+                hd[w] = reinterpret_cast<const float (*)[64]>(&lst[w][0][0])[0][lane];
+                hi[w] = sidx[w][0][lane];
+                hp[w] = 1;
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                int wm = 0;
+                float dm = hd[0];
+#pragma unroll
+                for (int w = 1; w < 4; ++w)
+                    if (hd[w] < dm) { dm = hd[w]; wm = w; }      // strict: ties stay with the lower slice = lower index
+                int im = hi[0];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) im = wm == w ? hi[w] : im;
+                bd[i] = dm; bi[i] = im;
+                // advance list wm (its entries past the end are +inf / 0xffff: never chosen before a finite head)
+                int pm = hp[0];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) pm = wm == w ? hp[w] : pm;
+                const int pc = pm < K ? pm : K - 1;
+                const float nd = pm < K ? reinterpret_cast<const float (*)[64]>(&lst[wm][0][0])[pc][lane] : __builtin_inff();
+                const int ni = sidx[wm][pc][lane];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const bool m = wm == w;
+                    hd[w] = m ? nd : hd[w]; hi[w] = m ? ni : hi[w]; hp[w] = m ? pm + 1 : hp[w];
                 }
             }
         }
         if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
         return;
     }
+    __syncthreads();
     // ---- 8 or 16 slices (small batches).  Every wave sees every list length: the overflow decision is the same in all of them
     bool over = false;
     int ctot = 0;

@@ -86,6 +86,46 @@ def test_knn_heavy_ties_two_sweep_kernel(lib, mode):
         assert torch.equal(i.cpu(), i_ref) and torch.equal(d.cpu(), d_ref)
 
 
+@pytest.mark.parametrize("mode", ["offset", "far_offset", "tiny", "huge", "lattice", "clusters", "line"])
+def test_knn_two_sweep_kernel_on_hard_clouds(lib, mode):
+    """M >= 1024 runs knn4_kernel (threshold sweep, candidate lists, per-slice top K, 4-way merge of the slices): clouds far
+    from the origin, tiny / huge scales, lattices and duplicate clusters (ties at the K-th distance, list overflow -> exact
+    path), collinear points must give the oracle's result bit for bit."""
+    from puflow_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, M = 2, 1536
+    p = torch.rand(B, M, 3, generator=g) * 2 - 1
+    if mode == "offset":
+        p = p + torch.tensor([3.0, -2.0, 5.0])
+    elif mode == "far_offset":
+        p = p * 0.05 + torch.tensor([100.0, 250.0, -80.0])
+    elif mode == "tiny":
+        p = p * 1e-4
+    elif mode == "huge":
+        p = p * 3e4
+    elif mode == "lattice":
+        p = torch.round(p * 6) / 6                                           # 13^3 sites for 1536 points: many exact ties
+    elif mode == "clusters":
+        c = torch.rand(B, 40, 3, generator=g)
+        p = c[:, torch.randint(0, 40, (M,), generator=g)] + 1e-3 * torch.rand(B, M, 3, generator=g)
+        p[0, 200:260] = p[0, 0]                                              # 61 exact copies of one point
+    elif mode == "line":
+        t = torch.rand(B, M, 1, generator=g)
+        p = t * torch.tensor([1.0, 2.0, -0.5]) + 0.25
+    q = p[:, :700].contiguous()
+    for K in (4, 8, 16):
+        d_ref, i_ref = O.knn_canonical(q, p, K)
+        i, d = ops.knn_idx32(q.to(DEV), p.to(DEV), K, want_dist=True)
+        assert torch.equal(i.cpu().long(), i_ref) and torch.equal(d.cpu(), d_ref), (mode, K)
+    # and with enough workgroups for the 4-slice variant (its per-slice top K + merge): B x ceil(N / 64) >= 1024
+    pb = p[:1].repeat(24, 1, 1) + torch.arange(24).view(24, 1, 1) * (0.37 if mode != "huge" else 37.0)
+    pb = pb[:, torch.randperm(M, generator=g)].contiguous() if mode in ("lattice", "clusters") else pb
+    qb = torch.cat([pb, pb[:, :1536]], dim=1)[:, :2752].contiguous()          # 24 x 43 workgroups = 1032
+    d_ref, i_ref = O.knn_canonical(qb, pb, 16)
+    i, d = ops.knn_idx32(qb.to(DEV), pb.to(DEV), 16, want_dist=True)
+    assert torch.equal(i.cpu().long(), i_ref) and torch.equal(d.cpu(), d_ref), mode
+
+
 def test_nn1_first_minimum(lib):
     from puflow_amd import _lib
     x = synth_patches(2, 300, seed=5, surface=False)
