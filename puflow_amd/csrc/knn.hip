@@ -208,12 +208,13 @@ __global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ 
 // Candidate lists are per (wave, lane).  4 slices: every wave reduces its own list to a sorted top K, wave 0 merges the four
 // sorted lists of each query; 8 / 16 slices: all waves merge the lists by rank in (distance, index) order (a query at a time, a
 // candidate per lane).  Overflow of any list -> exact scan of that query tile by wave 0.
-// Where the time goes at 32 x 2048, K = 16 (tools/tune_knn.py, ablation builds): sweep A + threshold 29 us = the VALU bound of
-// its 8.5 operations per pair; sweep B 42 us (the same arithmetic + the divergent appends: almost every group of four
-// references is a candidate for SOME lane of the wave); selection 21 us (it was 42 us when wave 0 inserted all four lists
-// alone).  Tried and dropped: a 3-fma filter distance |r|^2 - 2 q.r from a per-reference table for both sweeps, widened by a
-// rounding bound so that the exact answer survives (built, bit-exact on all tests): 4.5 instead of 8.5 operations per pair,
-// but the kernel gained 2 us and the table kernel cost 3.5.
+// Where the time goes at 32 x 2048, K = 16 (tools/tune_knn.py, ablation builds): sweep A + threshold 23 us = the VALU bound of
+// its 6.5 operations per pair (29 us with the exact 8-operation distance in the sweeps: they now run on a fused FILTER
+// distance with a proven margin, see fdist below); sweep B 41 us (the same arithmetic + the divergent appends: almost every
+// group of four references is a candidate for SOME lane of the wave); selection 14-20 us (42 us when wave 0 inserted all four
+// lists alone).  Tried and dropped: a 3-fma filter |r|^2 - 2 q.r from a per-reference (x, y, z, |r|^2) table, widened by an
+// absolute rounding bound (built, bit-exact on all tests): 4.5 operations per pair, but 16-byte table rows need 128 SGPRs
+// per 32-reference chunk - the kernel gained 2 us and the table kernel cost 3.5.
 // KNN4_W = waves per workgroup = reference slices: 4 when the grid fills the chip anyway (32 x 2048: 1024 workgroups), 8 or
 // 16 for small batches (4 x 2048: 128 workgroups of 16 waves instead of 4 - the kernel's latency is one wave's two sweeps
 // over its slice, so more, shorter slices cut it almost proportionally).  Same results for every split.
@@ -239,10 +240,16 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
     const float* q = p1 + ((size_t)b * N + (live ? n : N - 1)) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float* __restrict__ r = p2 + (size_t)b * M * 3;
-    // distance to reference j (wave-uniform j: scalar loads, SGPR operands)
+    // FILTER distance to reference j (wave-uniform j: scalar loads, SGPR operands) for the two sweeps: the same rounded
+    // differences as the exact distance, summed with two fmas - 6 operations instead of 8.  Both are sums of three non-negative
+    // terms with at most 3 roundings each, so filter = exact x (1 +- 7u), u = 2^-24.  Sweep A's tau (K-th smallest group minimum
+    // of the filter) therefore bounds the exact K-th neighbour distance by tau (1 + 8u), and every reference of the exact answer,
+    // ties included, has a filter distance <= tau (1 + 16u): sweep B keeps filter <= tau (1 + 2^-19) + 1e-37 (twice that; the
+    // absolute term covers subnormal distances).  The answer is computed from EXACT distances of the survivors.
     auto fdist = [&](int j) {
         const float* rr = r + (size_t)j * 3;
-        return sqdist(qx, qy, qz, rr[0], rr[1], rr[2]);
+        const float dx = qx - rr[0], dy = qy - rr[1], dz = qz - rr[2];
+        return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     };
     const int mq = ((M + KNN4_W * 64 - 1) / (KNN4_W * 64)) * 64;      // slice length, multiple of 64
     const int jb = wave * mq, je = min(jb + mq, M);                   // this wave's references [jb, je)
@@ -279,13 +286,14 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
         tau = fminf(ha[0], hb[K - 1]);
 #pragma unroll
         for (int i = 1; i < K; ++i) tau = fmaxf(tau, fminf(ha[i], hb[K - 1 - i]));
+        tau = fmaf(tau, 1.9073486328125e-6f, tau) + 1e-37f;            // filter -> exact margin (see fdist)
     }
 
 #if defined(PF_KNN_ABL) && PF_KNN_ABL == 2          // timing-only build: sweep A + threshold only
     if (wave == 0 && live) idx_out[((size_t)b * N + n) * K] = __float_as_int(tau);
     return;
 #endif
-    // ---- sweep B: collect this slice's candidates with d <= tau (in index order)
+    // ---- sweep B: collect this slice's candidates with filter distance <= tau (in index order)
     int cnt = 0;
     auto take = [&](float d, int j) {
         if (d <= tau) {
