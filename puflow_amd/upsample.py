@@ -49,7 +49,12 @@ def save_xyz(path, points: np.ndarray) -> None:
 @torch.no_grad()
 def upsampling(data_paths: List[str], target_path: str, checkpoint_path: str, up_ratio: int, num_outlier: int,
                num_patch: int, num_upsampling: int = None, seed=None, state_dict=None, network_cls=PointInterpFlow,
-               cloud_batch: int = 16):
+               cloud_batch: int = None):
+    # The continuous model integrates all patches of a pass with ONE adaptive step sequence (the error norm is taken over the
+    # whole batch, cnf.py:97-113), so a cloud's result depends on what shares its pass: it keeps the reference's one file at a
+    # time unless asked otherwise.  The discrete model's patches never interact.
+    if cloud_batch is None:
+        cloud_batch = 16 if network_cls is PointInterpFlow else 1
     if seed is not None:
         np.random.seed(seed)
         torch.random.manual_seed(seed)
@@ -111,8 +116,9 @@ def main(argv=None, network_cls=PointInterpFlow):
     parser.add_argument("--up_ratio", type=int, help="upsampling ratio", default=4)
     parser.add_argument("--num_patch", type=int, help="number of point in each patch", default=256)
     parser.add_argument("--num_out", type=int, default=None, help="number of point of output point cloud")
-    parser.add_argument("--cloud_batch", type=int, default=16,
-                        help="(not in the reference) files of equal point count that share one pass; 1 = one file at a time")
+    parser.add_argument("--cloud_batch", type=int, default=None,
+                        help="(not in the reference) files of equal point count that share one pass; 1 = one file at a time "
+                             "(default: 16 for the discrete model, 1 for the continuous one)")
     args = parser.parse_args(argv)
     os.makedirs(args.target, exist_ok=True)            # exist_ok: several ranks may race to create it
     data_paths = []
