@@ -213,8 +213,8 @@ __global__ __launch_bounds__(KNN2_T) void knn2_kernel(const float* __restrict__ 
 // distance with a proven margin, see fdist below); sweep B 41 us (the same arithmetic + the divergent appends: almost every
 // group of four references is a candidate for SOME lane of the wave); selection 14-20 us (42 us when wave 0 inserted all four
 // lists alone).  Tried and dropped: a 3-fma filter |r|^2 - 2 q.r from a per-reference (x, y, z, |r|^2) table, widened by an
-// absolute rounding bound (built, bit-exact on all tests): 4.5 operations per pair, but 16-byte table rows need 128 SGPRs
-// per 32-reference chunk - the kernel gained 2 us and the table kernel cost 3.5.
+// absolute rounding bound (built twice, bit-exact on all tests): 4.5 operations per pair on paper, but slower than the fused
+// filter at every chunk size tried (sweep A alone 33-39 us with 8 / 16 / 32 references per chunk against 22.5 us).
 // KNN4_W = waves per workgroup = reference slices: 4 when the grid fills the chip anyway (32 x 2048: 1024 workgroups), 8 or
 // 16 for small batches (4 x 2048: 128 workgroups of 16 waves instead of 4 - the kernel's latency is one wave's two sweeps
 // over its slice, so more, shorter slices cut it almost proportionally).  Same results for every split.
