@@ -1156,11 +1156,12 @@ def cond_net(net, h: Tensor) -> Tensor:
 
 
 def cond_net_fused(net, y, c: Tensor, td: int, cdiv: int) -> Tensor:
-    """LinearA1D on cat[y[..., :td], c[row // cdiv]] in one launch (csrc/train_mlp.hip); -> [rows, dout]."""
-    L = net.layers
+    """LinearA1D on cat[y[..., :td], c[row // cdiv]] in one launch (csrc/train_mlp.hip); -> [rows, dout].
+    net: the LinearA1D module, or its three linear layers (weight / bias holders) as a list."""
+    L = net if isinstance(net, (list, tuple)) else [net.layers[0], net.layers[2], net.layers[4]]
     if cdiv not in (1, 2, 4, 8, 16):                   # the kernel shares a conditioning row between 2^k replicas only
         c, cdiv = RepeatRowsFn.apply(c, cdiv), 1
-    return mlp_fused(y, c, td, cdiv, (0.01, 0.01), [L[0], L[2], L[4]])
+    return mlp_fused(y, c, td, cdiv, (0.01, 0.01), L)
 
 
 def cond_net_split(net, h1: Tensor, cpart: Tensor) -> Tensor:
@@ -1178,6 +1179,69 @@ def _mlp_bn(mlp, x: Tensor) -> Tensor:
     x = bn_lrelu(linear(x, mlp[0].weight, mlp[0].bias), mlp[1], 0.01)
     x = bn_lrelu(linear(x, mlp[3].weight, mlp[3].bias), mlp[4], 0.01)
     return linear(x, mlp[6].weight, mlp[6].bias)
+
+
+class ParamFanFn(torch.autograd.Function):
+    """Identity on parameters that are used several times in one forward: `uses[i]` aliases of params[i].  Autograd sums the
+    gradients of a tensor's uses with one small add launch per extra use - 54 of them per step for the flow blocks'
+    parameters (ActNorm, W, the coupling net: f and g share them).  Here the sums of ALL parameters are two multi-tensor
+    launches in this node's backward."""
+
+    @staticmethod
+    def forward(ctx, uses, *params):
+        ctx.uses = uses
+        outs = []
+        for p, u in zip(params, uses):
+            outs += [p.view_as(p) for _ in range(u)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        groups, k = [], 0
+        for u in ctx.uses:
+            groups.append([g for g in grads[k:k + u] if g is not None])
+            k += u
+        acc = [gs[0] if gs else None for gs in groups]
+        for level in range(1, max(ctx.uses)):
+            sel = [i for i, gs in enumerate(groups) if len(gs) > level]
+            if sel:
+                summed = torch._foreach_add([acc[i] for i in sel], [groups[i][level] for i in sel])
+                for i, t in zip(sel, summed):
+                    acc[i] = t
+        return (None, *acc)
+
+
+class _Lin:
+    """weight / bias holder with the attribute names of nn.Linear (for mlp_fused on parameter aliases)."""
+    __slots__ = ("weight", "bias")
+
+    def __init__(self, weight, bias=None):
+        self.weight, self.bias = weight, bias
+
+
+_FAN = os.environ.get("PF_TRAIN_FAN", "1") != "0"
+
+
+def _flow_param_aliases(net):
+    """Per flow block: aliases of the parameters f and g share (ParamFanFn) - dict of lists indexed by use."""
+    plist = []
+    for blk in net.flow_blocks:
+        L = blk.coupling1.bias_net.layers
+        plist += [(blk.actnorm.logs, 3), (blk.actnorm.bias, 2), (blk.permutate1.permutater.W, 2), (L[0].weight, 2),
+                  (L[2].weight, 2), (L[2].bias, 2), (L[4].weight, 2), (L[4].bias, 2)]
+    if _FAN:
+        flat = list(ParamFanFn.apply(tuple(u for _, u in plist), *[p for p, _ in plist]))
+    else:
+        flat = [p for p, u in plist for _ in range(u)]
+    out, k = [], 0
+    for _ in net.flow_blocks:
+        a = {}
+        for name, u in (("logs", 3), ("bias", 2), ("W", 2), ("w0", 2), ("w2", 2), ("b2", 2), ("w4", 2), ("b4", 2)):
+            a[name] = flat[k:k + u]
+            k += u
+        a["net"] = [[_Lin(a["w0"][j]), _Lin(a["w2"][j], a["b2"][j]), _Lin(a["w4"][j], a["b4"][j])] for j in range(2)]
+        out.append(a)
+    return out
 
 
 def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
@@ -1222,6 +1286,7 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     winvs: List[Tensor] = []
     lds: List[Tensor] = []
     ssums: List[Tensor] = []
+    alias = _flow_param_aliases(net) if _FUSED else None          # aliases share the parameters' storage (ActNorm init below)
     for i in range(net.num_blocks):
         blk = net.flow_blocks[i]
         an = blk.actnorm
@@ -1233,11 +1298,12 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         W = blk.permutate1.permutater.W
         td = 1 if i % 2 == 0 else 2
         if _FUSED:
-            Winv, ld = FlowParamsFn.apply(W, an.logs, float(N))    # W^-1 and (sum(logs) + log|det W|) N (permutate.py:119)
+            al = alias[i]
+            Winv, ld = FlowParamsFn.apply(al["W"][0], al["logs"][0], float(N))    # W^-1 and (sum(logs) + log|det W|) N (permutate.py:119)
             winvs.append(Winv)
             lds.append(ld)
-            y = FlowAffineFn.apply(p, None, 0, an.logs, an.bias, W, 0)    # ActNorm + einsum 'ij,bnj->bni' (permutate.py:118)
-            o = cond_net_fused(blk.coupling1.bias_net, y, cs[i], td, 1).view(B, N, -1)
+            y = FlowAffineFn.apply(p, None, 0, al["logs"][1], al["bias"][0], al["W"][1], 0)    # ActNorm + einsum 'ij,bnj->bni' (permutate.py:118)
+            o = cond_net_fused(al["net"][0], y, cs[i], td, 1).view(B, N, -1)
             s, t = st_all[2 * i].view(B, N, -1), st_all[2 * i + 1].view(B, N, -1)
             st_nets.append((s, t))
             p, ssum = CoupleInject2Fn.apply(y, o, s, t, td)
@@ -1281,8 +1347,9 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         td = 1 if i % 2 == 0 else 2
         if _FUSED:
             v = InjectInv2Fn.apply(u, st_nets[i][0], st_nets[i][1], R)        # s, t of the original point: row // R
-            o = cond_net_fused(blk.coupling1.bias_net, v, cs[i], td, R).view(B, N * R, -1)
-            u = FlowAffineFn.apply(v, o, td, blk.actnorm.logs, blk.actnorm.bias, winvs[i], 1)    # permutate.py:123-124
+            al = alias[i]
+            o = cond_net_fused(al["net"][1], v, cs[i], td, R).view(B, N * R, -1)
+            u = FlowAffineFn.apply(v, o, td, al["logs"][2], al["bias"][1], winvs[i], 1)    # permutate.py:123-124
             continue
         s = RepeatRowsFn.apply(st_nets[i][0], R)                   # same nets, same input as in f: evaluated once (autograd sums both uses)
         t = RepeatRowsFn.apply(st_nets[i][1], R)
