@@ -33,6 +33,31 @@ def test_chamfer_forward(B, N, M):
     np.testing.assert_allclose(per.cpu().numpy(), O.chamfer_distance_per_sample(x, y).numpy(), rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("mode", ["lattice", "duplicates", "far_offset", "tiny", "ragged"])
+def test_chamfer_nearest_neighbour_on_hard_clouds(mode):
+    """pf_nn1 screens four references at a time with a fused filter distance and computes exact distances only for groups
+    that can lower the running minimum: ties (first minimum = lowest index must win), exact duplicates, clouds far from the
+    origin, tiny scales and reference counts that are not a multiple of the chunk must match the oracle bit for bit."""
+    from puflow_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, N, M = 2, 700, 1111 if mode == "ragged" else 1024
+    x = torch.rand(B, N, 3, generator=g) * 2 - 1
+    y = torch.rand(B, M, 3, generator=g) * 2 - 1
+    if mode == "lattice":
+        x, y = torch.round(x * 4) / 4, torch.round(y * 4) / 4               # 9^3 sites: many equal distances and zeros
+    elif mode == "duplicates":
+        y[:, 500:600] = y[:, 17:18]                                         # 101 copies of one reference
+        x[:, :50] = y[:, 17:18]                                             # queries exactly on it: distance 0, index 17
+    elif mode == "far_offset":
+        x, y = x * 0.01 + 300.0, y * 0.01 + 300.0
+    elif mode == "tiny":
+        x, y = x * 1e-18, y * 1e-18                                         # squared distances ~1e-36: near the subnormals
+    d1r, i1r, d2r, i2r = O.chamfer_nn(x, y)
+    d1, d2, i1, i2 = ops.chamfer_3DDist()(x.to(DEV), y.to(DEV))
+    assert torch.equal(d1.cpu(), d1r) and torch.equal(d2.cpu(), d2r)
+    assert torch.equal(i1.cpu().long(), i1r) and torch.equal(i2.cpu().long(), i2r)
+
+
 def test_chamfer_backward_matches_autograd():
     from puflow_amd import ops
     x = synth_patches(2, 300, seed=1, surface=False).requires_grad_(True)
