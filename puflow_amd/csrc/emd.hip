@@ -45,8 +45,8 @@ struct EmdArgs {
 // lane's own second).  This is the fold of the pairwise merge
 //     take (obest, oidx) if obest > best or (obest == best and oidx < idx);  better = max(min(best, obest), max(better, obetter))
 // over the lanes (a total order: value descending, index ascending; lanes hold distinct indices), done
-// with DPP row rotates + 4 readlanes per reduction instead of 18 dependent ds_bpermute shuffles.  (Measured: 0.87 -> 0.85 ms for
-// a far-off 32 x 1024 prediction, tools/time_emd.py - a bid is bound by its 16 objects per lane x ~26 operations, not by this.)
+// with DPP row rotates + 4 readlanes per reduction instead of 18 dependent ds_bpermute shuffles.  (No measurable change of the 0.87 ms a
+// far-off 32 x 1024 prediction takes, tools/time_emd.py: a bid is bound by its 16 objects per lane x ~26 operations.)
 template <int CTRL>
 __device__ __forceinline__ float emd_dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
