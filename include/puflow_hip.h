@@ -381,6 +381,12 @@ int pf_normalize_pc(const float* x, int B, int N, float* out, float* centroid, f
 long long pf_format_xyz_bound(long long n, int c);
 long long pf_format_xyz(const float* pts, long long n, int c, char* out, long long cap);
 
+/* Reader for the CLI's input clouds (HOST memory): the values np.loadtxt(path, dtype=np.float32) returns (upsample.py:42) for
+ * whitespace-separated numeric text ('#' comments, blank lines skipped, double parse then rounded to float32).  text[len]
+ * must be 0.  Returns the number of values written (rows x *ncols) or a negative PF_ERR_* code (UNSUPPORTED: a token that is
+ * not a number - fall back to numpy; SHAPE: ragged rows; WORKSPACE: out too small). */
+long long pf_parse_xyz(const char* text, long long len, float* out, long long cap, int* ncols);
+
 /* K nearest references of every query for large K (patch extraction, K = 256).  Replaces knn_cuda.KNN
  * (patch.py:33,107).  ref [B,N,3], query [B,M,3], K <= N (any N; K <= 8192 when N > 16384: the references are then
  * streamed through LDS in chunks) -> idx_out [B,M,K] int32 ordered by (distance, index); dist_out [B,M,K] squared L2

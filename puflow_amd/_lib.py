@@ -145,6 +145,7 @@ SIGNATURES = {
     "pf_normalize_pc": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_format_xyz_bound": (c_longlong, [c_longlong, c_int]),
     "pf_format_xyz": (c_longlong, [c_void_p, c_longlong, c_int, c_void_p, c_longlong]),
+    "pf_parse_xyz": (c_longlong, [c_void_p, c_longlong, c_void_p, c_longlong, POINTER(c_int)]),
     "pf_cnf_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_float), c_int, c_float, c_float, c_float, c_void_p, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pf_cnf_step": (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

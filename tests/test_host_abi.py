@@ -208,3 +208,46 @@ def test_save_xyz_writes_the_bytes_of_savetxt(tmp_path):
     np.savetxt(tmp_path / "ref2.xyz", d, fmt="%.6f")
     save_xyz(tmp_path / "got2.xyz", d)
     assert (tmp_path / "got2.xyz").read_bytes() == (tmp_path / "ref2.xyz").read_bytes()
+
+
+def test_load_xyz_reads_what_loadtxt_reads(tmp_path):
+    """upsample.py:42 reads with np.loadtxt(dtype=float32); the library's parser (pf_parse_xyz: fast path for plain decimals,
+    strtod for the rest) must return the same float32 bits - signs, leading / trailing dots, exponents, long digit strings,
+    nan / inf, comments, blank lines - and hand anything it does not understand to numpy."""
+    import random
+    import numpy as np
+    from puflow_amd.upsample import load_xyz
+    random.seed(5)
+    toks = []
+    for _ in range(30000):
+        k = random.random()
+        digits = lambda a, b: "".join(random.choice("0123456789") for _ in range(random.randint(a, b)))
+        if k < 0.5:
+            t = "%s%d.%s" % (random.choice(["", "-", "+"]), random.randint(0, 999), digits(0, 14))
+        elif k < 0.7:
+            t = "%s%d.%s" % (random.choice(["", "-"]), random.randint(0, 9), digits(10, 25))
+        elif k < 0.85:
+            t = "%.6e" % ((random.random() - 0.5) * 10 ** random.randint(-30, 30))
+        elif k < 0.9:
+            t = str(random.randint(-10 ** 9, 10 ** 9))
+        elif k < 0.95:
+            t = "." + digits(1, 9)
+        else:
+            t = random.choice(["nan", "inf", "-inf", "1e5", "-0.0", "0", "5.", "-.5", "123456789012345", "0.000001"])
+        toks.append(t)
+    rows = ["\t".join(toks[i:i + 3]) if i % 5 == 0 else "  ".join(toks[i:i + 3]) for i in range(0, len(toks), 3)]
+    text = "# header\n" + "\n".join(r + ("   # note" if i % 7 == 0 else "") for i, r in enumerate(rows)) + "\n\n"
+    (tmp_path / "a.xyz").write_text(text)
+    ref = np.loadtxt(tmp_path / "a.xyz", dtype=np.float32)
+    got = load_xyz(tmp_path / "a.xyz")
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()                      # bit for bit, -0.0 and NaN included
+    (tmp_path / "b.xyz").write_text("1.5 2.5 3.5\n")                              # a single row: 1-d, like loadtxt
+    assert load_xyz(tmp_path / "b.xyz").shape == np.loadtxt(tmp_path / "b.xyz", dtype=np.float32).shape == (3,)
+    (tmp_path / "c.xyz").write_text("1,2,3\n4,5,6\n")                            # not whitespace-separated: numpy's call
+    import pytest
+    with pytest.raises(ValueError):
+        load_xyz(tmp_path / "c.xyz")
+    (tmp_path / "d.xyz").write_text("1 2 3\n4 5\n")                              # ragged: numpy raises
+    with pytest.raises(ValueError):
+        load_xyz(tmp_path / "d.xyz")
