@@ -34,7 +34,7 @@ BN_EPS = 1e-5
 
 
 def _np(sd, k):
-    return sd[k].detach().cpu().double().numpy()
+    return sd[k].detach().cpu().numpy().astype(np.float64)      # numpy's cast: a torch .double() per tensor was half of the fold
 
 
 def _fold_bn(sd, conv: str, bn: str):
@@ -208,7 +208,8 @@ def frag_pack_bf16x3(W: np.ndarray) -> np.ndarray:
     res = np.zeros((OB, CP, 3, 64, 8), dtype=np.uint16)
     for si, part in enumerate((hi, mid, lo)):
         bits = (part.view(np.uint32) >> 16).astype(np.uint16).reshape(OB, 16, CP, 32)
-        res[:, :, si] = bits[:, row[:, None], :, ch].transpose(2, 3, 0, 1)      # -> [OB,CP,64,8]
+        # lane = 16 q + row holds k = 16 h + 4 q + jj at slot j = 4 h + jj: a pure axis permutation of [OB,row,CP,h,q,jj]
+        res[:, :, si] = bits.reshape(OB, 16, CP, 2, 4, 4).transpose(0, 2, 4, 1, 3, 5).reshape(OB, CP, 64, 8)
     return res.reshape(-1).view(np.float32)
 
 
@@ -234,7 +235,8 @@ def frag_pack_f16x2(W: np.ndarray) -> np.ndarray:
     res = np.zeros((OB, CP, 2, 64, 8), dtype=np.uint16)
     for si, part in enumerate((hi, lo)):
         bits = part.view(np.uint16).reshape(OB, 16, CP, 32)
-        res[:, :, si] = bits[:, row[:, None], :, ch].transpose(2, 3, 0, 1)      # -> [OB,CP,64,8]
+        # lane = 16 q + row holds k = 16 h + 4 q + jj at slot j = 4 h + jj: a pure axis permutation of [OB,row,CP,h,q,jj]
+        res[:, :, si] = bits.reshape(OB, 16, CP, 2, 4, 4).transpose(0, 2, 4, 1, 3, 5).reshape(OB, CP, 64, 8)
     return res.reshape(-1).view(np.float32)
 
 
@@ -258,7 +260,8 @@ def frag_pack_f16n(W: np.ndarray) -> np.ndarray:
     res = np.zeros((OB, CP, 2, 64, 8), dtype=np.uint16)
     for si, part in enumerate((hi, lo)):
         bits = part.view(np.uint16).reshape(OB, 16, CP, 32)
-        res[:, :, si] = bits[:, row[:, None], :, ch].transpose(2, 3, 0, 1)      # -> [OB,CP,64,8]
+        # lane = 16 q + row holds k = 16 h + 4 q + jj at slot j = 4 h + jj: a pure axis permutation of [OB,row,CP,h,q,jj]
+        res[:, :, si] = bits.reshape(OB, 16, CP, 2, 4, 4).transpose(0, 2, 4, 1, 3, 5).reshape(OB, CP, 64, 8)
     return res.reshape(-1).view(np.float32)
 
 
