@@ -5,6 +5,7 @@
 // oracle/patch_ref.py:  FPS starts at index 0, squared distances are unfused fp32
 // ((dx*dx)+(dy*dy))+(dz*dz), the farthest point is the FIRST maximum (smallest index);
 // kNN is ordered by (distance, index) like pf_knn.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
 
@@ -216,6 +217,150 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop_kernel(const float* __restric
     if (g == 0 && tid == 0) fps_st(abort_w, FPSC_ST_DONE);
 }
 
+// ---- two samples per exchange ------------------------------------------------------------------------------------------
+// A step of fps_coop_kernel is ~0.4 us of arithmetic and ~1.8 us of waiting for the words to cross the fabric.  Here every wave
+// publishes its TWO best points (keys K_a > K_b), so a round knows the global best c1 AND the best of the rest c2.  After c1
+// has been added, every min-distance can only shrink, i.e. every key can only fall; points nobody published lie below their
+// wave's K_b, which lies below K2 = key(c2).  So if c2 itself is not touched by c1 - d(c2, c1) >= md(c2), computed exactly as
+// the update would - c2 is still the largest key after the update: it IS the next sample of the sequential algorithm (keys are
+// distinct, so ties are decided exactly as there: farthest, then smallest index), and the round emits both.  Otherwise it
+// emits c1 alone, as before.  Every workgroup takes the same decision from the same words.  Bit-identical output.
+constexpr int FPSC_SLOTS2 = 2 * FPSC_SLOTS;
+constexpr int FPSC_RING2 = 4 * FPSC_SLOTS2;              // status word of the two-sample kernel's ring
+
+__device__ __forceinline__ unsigned long long fps_key(int vbits, unsigned idx, unsigned tag) {
+    return vbits < 0 ? (unsigned long long)tag : (((unsigned long long)(unsigned)vbits << 32) | tag | ((~idx) & 0x1fffffffu));
+}
+__device__ __forceinline__ unsigned long long u64max(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned long long u64min(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {       // two 32-bit passes: high word, then low
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned hmax = wave_max_u32(hi);
+    const unsigned lmax = wave_max_u32(hi == hmax ? lo : 0u);
+    return ((unsigned long long)hmax << 32) | lmax;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPSC_T) void fps_coop2_kernel(const float* __restrict__ xyz, int N, int npoint, int G,
+                                                           unsigned long long* __restrict__ ringbuf, long long ring_stride,
+                                                           int* __restrict__ out) {
+    constexpr int NW = FPSC_T / 64;
+    __shared__ float s_l[2][8];                                         // c1 xyz, c2 xyz, accepted-2 flag, alive flag
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const float* p = xyz + (size_t)b * N * 3;
+    unsigned long long* ring = ringbuf + (size_t)b * ring_stride;       // [4][FPSC_SLOTS2] + status word
+    unsigned long long* abort_w = ring + FPSC_RING2;
+    int* o = out + (size_t)b * npoint;
+    const int S2 = 2 * G * NW;                                          // words per round (<= 256: four per lane)
+
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    int pi[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int i = (g * PPT + k) * FPSC_T + tid;                     // increasing in k: first maximum = smallest index
+        pi[k] = i;
+        const bool in = i < N;
+        const int ic = in ? i : N - 1;
+        px[k] = p[ic * 3 + 0]; py[k] = p[ic * 3 + 1]; pz[k] = p[ic * 3 + 2];
+        md[k] = in ? 1e10f : -1.f;                                      // padding can never be the farthest point
+    }
+    if (g == 0 && tid == 0) o[0] = 0;
+    float l1x = p[0], l1y = p[1], l1z = p[2], l2x = 0.f, l2y = 0.f, l2z = 0.f;
+    bool have2 = false;
+    int j = 1;
+    for (int r = 0; j < npoint; ++r) {
+        // update with the sample(s) of the previous round; per-lane best two by (distance, then smaller index)
+        float b1 = -1.f, b2 = -1.f;
+        int i1 = 0x7fffffff, i2 = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            float d = fminf(md[k], sqd(px[k], py[k], pz[k], l1x, l1y, l1z));
+            if (have2) d = fminf(d, sqd(px[k], py[k], pz[k], l2x, l2y, l2z));
+            md[k] = d;
+            const bool gt1 = d > b1, gt2 = d > b2;                      // indices grow with k: strict comparisons keep the smaller
+            b2 = gt1 ? b1 : (gt2 ? d : b2);
+            i2 = gt1 ? i1 : (gt2 ? pi[k] : i2);
+            b1 = gt1 ? d : b1;
+            i1 = gt1 ? pi[k] : i1;
+        }
+        // the wave's best two (distances are >= 0 or the -1 of padding: their bit patterns order like signed integers)
+        const int vb = __float_as_int(b1);
+        const int vmax = wave_max_i32(vb);
+        const unsigned imin = ~wave_max_u32(vb == vmax ? ~(unsigned)i1 : 0u);
+        const bool mine = vb == vmax && (unsigned)i1 == imin;           // the lane that holds the wave's best
+        const int cb = mine ? __float_as_int(b2) : vb;
+        const unsigned ci = mine ? (unsigned)i2 : (unsigned)i1;
+        const int v2 = wave_max_i32(cb);
+        const unsigned i2m = ~wave_max_u32(cb == v2 ? ~ci : 0u);
+        unsigned long long* slot = ring + (r & 3) * FPSC_SLOTS2;
+        const unsigned tag = ((unsigned)(((r >> 2) & 3) << 1) | 1u) << 29;      // see fps_coop_kernel
+        if (lane == 0) {
+            fps_st(slot + 2 * (g * NW + wave), fps_key(vmax, imin, tag));
+            fps_st(slot + 2 * (g * NW + wave) + 1, fps_key(v2, i2m, tag));
+        }
+        if (wave == 0) {
+            unsigned long long k[4];
+            unsigned spins = 0;
+            bool dead = false;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    k[t] = lane + 64 * t < S2 ? fps_ld(slot + lane + 64 * t) : (unsigned long long)tag;
+                    ok = ok && ((unsigned)k[t] & (7u << 29)) == tag;
+                }
+                if (!__any(!ok)) break;
+                if (++spins > FPSC_SPIN_MAX || (spins % 1024 == 0 && fps_ld(abort_w) == FPSC_ST_ABORT)) { dead = true; break; }
+            }
+            if (dead) {                                                     // uniform over the wave
+                if (lane == 0) { fps_st(abort_w, FPSC_ST_ABORT); s_l[r & 1][7] = -1.f; }
+            } else {
+                // this lane's best two of its four words, then the wave's best two
+                const unsigned long long a0 = u64max(k[0], k[1]), a1 = u64min(k[0], k[1]);
+                const unsigned long long c0 = u64max(k[2], k[3]), c1m = u64min(k[2], k[3]);
+                const unsigned long long f1 = u64max(a0, c0);
+                const unsigned long long f2 = u64max(u64min(a0, c0), a0 > c0 ? a1 : c1m);
+                // both candidates' coordinates are fetched while the maxima are reduced
+                const unsigned q1 = (~(unsigned)f1) & 0x1fffffffu, q2 = (~(unsigned)f2) & 0x1fffffffu;
+                const unsigned q1c = q1 < (unsigned)N ? q1 : 0u, q2c = q2 < (unsigned)N ? q2 : 0u;
+                const float ax = p[q1c * 3 + 0], ay = p[q1c * 3 + 1], az = p[q1c * 3 + 2];
+                const float bx = p[q2c * 3 + 0], by = p[q2c * 3 + 1], bz = p[q2c * 3 + 2];
+                const unsigned long long K1 = wave_max_u64(f1);
+                const bool own1 = f1 == K1;                                  // keys are distinct: one lane
+                const unsigned long long K2 = wave_max_u64(own1 ? f2 : f1);
+                const int w1 = __builtin_ctzll(__ballot(own1));
+                const bool own2 = (own1 ? f2 : f1) == K2;
+                const int w2 = __builtin_ctzll(__ballot(own2));
+                const bool k2_second = w2 == w1;                             // K2 is the second word of the lane that owns K1
+                auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+                const float c1x = rl(ax, w1), c1y = rl(ay, w1), c1z = rl(az, w1);
+                const float c2x = k2_second ? rl(bx, w2) : rl(ax, w2), c2y = k2_second ? rl(by, w2) : rl(ay, w2),
+                            c2z = k2_second ? rl(bz, w2) : rl(az, w2);
+                const unsigned idx1 = (~(unsigned)K1) & 0x1fffffffu, idx2 = (~(unsigned)K2) & 0x1fffffffu;
+                // c2 follows c1 at once iff adding c1 leaves its min-distance (the high word of K2) untouched
+                const float md2 = __uint_as_float((unsigned)(K2 >> 32));
+                const bool two = j + 1 < npoint && idx2 < (unsigned)N && idx1 < (unsigned)N && sqd(c2x, c2y, c2z, c1x, c1y, c1z) >= md2;
+                if (lane == 0) {
+                    float* sl = s_l[r & 1];
+                    sl[0] = c1x; sl[1] = c1y; sl[2] = c1z; sl[3] = c2x; sl[4] = c2y; sl[5] = c2z;
+                    sl[6] = two ? 1.f : 0.f; sl[7] = 1.f;
+                    if (g == 0) { o[j] = (int)idx1; if (two) o[j + 1] = (int)idx2; }
+                }
+            }
+        }
+        // s_l is double-buffered (see fps_coop_kernel): one barrier per round
+        __syncthreads();
+        const float* sl = s_l[r & 1];
+        if (sl[7] < 0.f) return;                                          // uniform over the workgroup: aborted
+        l1x = sl[0]; l1y = sl[1]; l1z = sl[2]; l2x = sl[3]; l2y = sl[4]; l2z = sl[5];
+        have2 = sl[6] > 0.f;
+        j += have2 ? 2 : 1;
+    }
+    if (g == 0 && tid == 0) fps_st(abort_w, FPSC_ST_DONE);
+}
+
 // ---- large-K kNN: one workgroup per query; keys (dist bits << 32 | index) bitonic-sorted in LDS.
 // N <= 16384: all N keys in one sort.  Larger clouds (knn_cuda.KNN takes any N, patch.py:33,107): the references are
 // streamed in chunks; LDS holds the running best KP >= K keys in front of the chunk's keys, every pass sorts the
@@ -319,11 +464,11 @@ __global__ __launch_bounds__(NRM_T) void normalize_pc_kernel(const float* __rest
 
 namespace {
 // clears the scratch rows and sets every cloud's status word to "not finished"
-__global__ __launch_bounds__(256) void fps_init_kernel(float* p, long long n, int B, long long stride_words) {
+__global__ __launch_bounds__(256) void fps_init_kernel(float* p, long long n, int B, long long stride_words, int status_word) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         float v = 0.f;
         const long long w = i >> 1;                                       // 64-bit word index
-        if ((i & 1) == 0 && stride_words > 0 && w % stride_words == FPSC_RING && w / stride_words < B)
+        if ((i & 1) == 0 && stride_words > 0 && w % stride_words == status_word && w / stride_words < B)
             v = __uint_as_float((unsigned)FPSC_ST_INIT);                  // low half of the status word
         p[i] = v;
     }
@@ -332,9 +477,15 @@ __global__ __launch_bounds__(256) void fps_init_kernel(float* p, long long n, in
 
 // 1 when pf_fps runs the cooperative kernel for clouds of N points (its scratch row then holds the candidate ring):
 // stride_words = 64-bit words between the rings of consecutive clouds, abort_word = index of the abort word in a ring
+// two samples per exchange (fps_coop2_kernel) unless PF_FPS_ROUND2=0; read once: pf_fps and pf_fps_scratch_layout must agree
+static bool fps_two() {
+    static const bool two = [] { const char* e = getenv("PF_FPS_ROUND2"); return !(e && e[0] == '0'); }();
+    return two;
+}
+
 extern "C" int pf_fps_scratch_layout(int N, long long* stride_words, long long* abort_word) {
     if (stride_words) *stride_words = ((long long)N / 2) & ~1ll;
-    if (abort_word) *abort_word = FPSC_RING;
+    if (abort_word) *abort_word = fps_two() ? FPSC_RING2 : FPSC_RING;
     return N >= 8192 && N <= FPSC_GMAX * 1024 * 8 ? 1 : 0;
 }
 
@@ -353,15 +504,20 @@ extern "C" int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, i
         unsigned long long* ring = reinterpret_cast<unsigned long long*>(mind);
         // cleared by a kernel, not hipMemsetAsync: a memset node inside a captured hipGraph was observed to race with the
         // kernel node that follows it (csrc/emd.hip)
-        hipLaunchKernelGGL(fps_init_kernel, dim3(256), dim3(256), 0, s, mind, (long long)B * N, B, stride);
+        hipLaunchKernelGGL(fps_init_kernel, dim3(256), dim3(256), 0, s, mind, (long long)B * N, B, stride,
+                           fps_two() ? FPSC_RING2 : FPSC_RING);
         const dim3 grid(B * G), block(FPSC_T);
+#define PF_FPS_LAUNCH(PPT)                                                                                                  \
+        if (fps_two()) hipLaunchKernelGGL(fps_coop2_kernel<PPT>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); \
+        else hipLaunchKernelGGL(fps_coop_kernel<PPT>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out)
         switch (ppt) {
-            case 1: hipLaunchKernelGGL(fps_coop_kernel<1>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); break;
-            case 4: hipLaunchKernelGGL(fps_coop_kernel<4>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); break;
-            case 8: hipLaunchKernelGGL(fps_coop_kernel<8>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); break;
-            case 16: hipLaunchKernelGGL(fps_coop_kernel<16>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); break;
-            default: hipLaunchKernelGGL(fps_coop_kernel<32>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); break;
+            case 1: PF_FPS_LAUNCH(1); break;
+            case 4: PF_FPS_LAUNCH(4); break;
+            case 8: PF_FPS_LAUNCH(8); break;
+            case 16: PF_FPS_LAUNCH(16); break;
+            default: PF_FPS_LAUNCH(32); break;
         }
+#undef PF_FPS_LAUNCH
         return pf_last_launch_status();
     }
     hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(FPS_T), 0, s, xyz, N, npoint, mind, idx_out);
