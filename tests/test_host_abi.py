@@ -251,3 +251,32 @@ def test_load_xyz_reads_what_loadtxt_reads(tmp_path):
     (tmp_path / "d.xyz").write_text("1 2 3\n4 5\n")                              # ragged: numpy raises
     with pytest.raises(ValueError):
         load_xyz(tmp_path / "d.xyz")
+
+
+def test_param_fan_sums_the_gradients_of_every_use():
+    """train_ops.ParamFanFn hands out aliases of parameters that several autograd nodes use (f and g share the flow blocks'
+    parameters) and sums their gradients in its own backward: the result must be what autograd's per-use accumulation gives -
+    including a parameter with three uses, an unused alias (no gradient) and in-place initialisation through `.data` after the
+    aliases were taken (ActNorm's data-dependent init)."""
+    import torch
+    from puflow_amd.train_ops import ParamFanFn
+    torch.manual_seed(0)
+    a = torch.randn(3, 4, requires_grad=True)
+    b = torch.randn(5, requires_grad=True)
+    c = torch.randn(2, 2, requires_grad=True)
+    x = torch.randn(4)
+
+    def loss(a0, a1, a2, b0, b1, c0, c1):
+        return (a0 @ x).sum() + (a1 * a1).sum() * 0.5 + (a2.sum() ** 2) + (b0 * 3).sum() + b1.pow(3).sum() + c0.trace()   # c1 unused
+
+    al = ParamFanFn.apply((3, 2, 2), a, b, c)
+    assert len(al) == 7 and all(t.shape == p.shape for t, p in zip(al, (a, a, a, b, b, c, c)))
+    with torch.no_grad():
+        b.data.mul_(2.0)                                    # aliases are views: they see the new values
+    loss(*al).backward()
+    got = [p.grad.clone() for p in (a, b, c)]
+    for p in (a, b, c):
+        p.grad = None
+    loss(a, a, a, b, b, c, c).backward()
+    for g, p in zip(got, (a, b, c)):
+        assert torch.allclose(g, p.grad, rtol=1e-6, atol=1e-6)
