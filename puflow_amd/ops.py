@@ -117,6 +117,17 @@ def history_chamfer_distance(p1, p2):
     return _ChamferFn.apply(p1, p2)
 
 
+def nearest_distance(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """dist1 of chamfer_3DDist alone: squared distance of every point of x [B,N,3] to its nearest point of y [B,M,3] -> [B,N]
+    (pf_nn1; PatchHelper.remove_outliers uses only this half, modules/utils/patch.py:199-203)."""
+    lib = _lib.load()
+    x, y = _f32c(x), _f32c(y)
+    B, N, _ = x.shape
+    d1 = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    _lib.check(lib.pf_nn1(x.data_ptr(), y.data_ptr(), B, N, y.shape[1], d1.data_ptr(), None, _stream()), "pf_nn1")
+    return d1
+
+
 class chamfer_3DDist:
     """ChamferDistancePytorch surface used by PatchHelper.remove_outliers (modules/utils/patch.py:199-203)."""
 

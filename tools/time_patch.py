@@ -42,4 +42,4 @@ with torch.no_grad():
     M = pred.shape[1] * pred.shape[2]
     timed(f"fps merge {M}->{N * 4 + 24}... ", lambda: PatchHelper.merge_patches(pred, N * 4))
     cloud = pred.reshape(B, M, 3)[:, :N * 4].contiguous()
-    timed("chamfer_3DDist (outliers)", lambda: ops.chamfer_3DDist()(cloud, cloud))
+    timed("nearest distance (outliers)", lambda: ops.nearest_distance(cloud, pc))
