@@ -222,8 +222,9 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop_kernel(const float* __restric
 // publishes its TWO best points (keys K_a > K_b), so a round knows the global best c1 AND the best of the rest c2.  After c1
 // has been added, every min-distance can only shrink, i.e. every key can only fall; points nobody published lie below their
 // wave's K_b, which lies below K2 = key(c2).  So if c2 itself is not touched by c1 - d(c2, c1) >= md(c2), computed exactly as
-// the update would - c2 is still the largest key after the update: it IS the next sample of the sequential algorithm (keys are
-// distinct, so ties are decided exactly as there: farthest, then smallest index), and the round emits both.  Otherwise it
+// the update would - and md(c2) > 0, so that c2 also stays above c1's own new key (0, index of c1) - c2 is still the largest
+// key after the update: it IS the next sample of the sequential algorithm (keys are distinct, so ties are decided exactly as
+// there: farthest, then smallest index), and the round emits both.  Otherwise it
 // emits c1 alone, as before.  Every workgroup takes the same decision from the same words.  Bit-identical output; on the CLI's
 // merge (99 840 -> 20 024) 1.59 samples per round: 46.0 -> 30.4 ms per cloud.
 constexpr int FPSC_SLOTS2 = 2 * FPSC_SLOTS;
@@ -342,7 +343,10 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop2_kernel(const float* __restri
                 const unsigned idx1 = (~(unsigned)K1) & 0x1fffffffu, idx2 = (~(unsigned)K2) & 0x1fffffffu;
                 // c2 follows c1 at once iff adding c1 leaves its min-distance (the high word of K2) untouched
                 const float md2 = __uint_as_float((unsigned)(K2 >> 32));
-                const bool two = j + 1 < npoint && idx2 < (unsigned)N && idx1 < (unsigned)N && sqd(c2x, c2y, c2z, c1x, c1y, c1z) >= md2;
+                // (md2 > 0: once every min-distance is 0 - more samples than distinct points - c1 keeps the largest key
+                // (0, smallest index) after it has been added, and the sequential algorithm picks it again, not c2)
+                const bool two = j + 1 < npoint && idx2 < (unsigned)N && idx1 < (unsigned)N && md2 > 0.f &&
+                                 sqd(c2x, c2y, c2z, c1x, c1y, c1z) >= md2;
                 if (lane == 0) {
                     float* sl = s_l[r & 1];
                     sl[0] = c1x; sl[1] = c1y; sl[2] = c1z; sl[3] = c2x; sl[4] = c2y; sl[5] = c2z;

@@ -29,6 +29,20 @@ def test_fps_bit_exact(B, N, npoint):
     assert got[:, 0].eq(0).all()
 
 
+@pytest.mark.parametrize("sites,N,npoint", [(3, 8736, 617), (5, 11684, 2428), (9, 10000, 900), (2, 9000, 40)])
+def test_fps_on_lattices_and_past_the_last_distinct_point(sites, N, npoint):
+    """Cooperative FPS on lattice clouds: thousands of exact ties, and (first two cases) more samples than distinct points -
+    once every min-distance is 0 the sequential algorithm keeps returning the smallest index.  The two-samples-per-exchange
+    kernel once emitted (0, 1, 0, 1, ...) there: after c1 is added its own key stays the largest when everything is 0, so a
+    second sample needs md > 0 (found by tools/stress_exact.py)."""
+    from puflow_amd import ops
+    g = torch.Generator().manual_seed(sites * 1000 + N)
+    xyz = torch.round((torch.rand(2, N, 3, generator=g) * 2 - 1) * sites) / sites
+    ref = P.fps(xyz, npoint)
+    got = ops.furthest_point_sample(xyz.to(DEV), npoint)
+    assert torch.equal(got.cpu().long(), ref)
+
+
 def test_fps_matches_reference_torch_fps(golden_dir):
     """PINNED: `pf_fps` (single-workgroup and cooperative kernels) against the reference's own in-tree torch FPS
     (modules/utils/fps.py; tools/make_golden_patch.py), and PatchHelper.merge_pc (patch.py:162-165) built on it."""
