@@ -40,8 +40,12 @@ while time.time() < t_end:
     # ---- kNN: (B, N, M) chosen so that all of W = 4 / 8 / 16 and the M < 1024 kernels come up
     B = int(torch.randint(1, 5, (1,), generator=g)); M = int(torch.randint(64, 3000, (1,), generator=g))
     N = int(torch.randint(10, 1500, (1,), generator=g)); K = [4, 8, 16][int(torch.randint(0, 3, (1,), generator=g))]
-    if int(torch.randint(0, 4, (1,), generator=g)) == 0:
+    pick = int(torch.randint(0, 6, (1,), generator=g))
+    if pick == 0:
         B, N = 18, int(torch.randint(3600, 4000, (1,), generator=g))                  # >= 1024 workgroups: the 4-slice variant
+        M = int(torch.randint(1024, 1400, (1,), generator=g))
+    elif pick == 1:
+        B, N = 8, int(torch.randint(3100, 4000, (1,), generator=g))                   # 384 .. 1023 workgroups: 8 slices
         M = int(torch.randint(1024, 1400, (1,), generator=g))
     p = cloud(B, M, kind); q = p[:, :N].contiguous() if N <= M and int(torch.randint(0, 2, (1,), generator=g)) else cloud(B, N, kind)
     d_ref, i_ref = O.knn_canonical(q, p, min(K, M))
