@@ -2,7 +2,7 @@
 """GPU box: randomised bit-exactness stress of the selection kernels against the CPU oracle - kNN (all slice counts, K, tie
 structures), nearest neighbour (Chamfer), cooperative FPS (one- and two-sample exchange paths are both taken inside one run:
 whether a round emits two samples depends on the data).  Not part of the test-suite (minutes of CPU oracle time); run once
-after a change to csrc/knn.hip or csrc/patch_ops.hip:   python tools/stress_exact.py [seconds]"""
+after a change to csrc/knn.hip or csrc/patch_ops.hip:   python tools/stress_exact.py [seconds] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ from oracle import ref_cpu as O, patch_ref as P
 from puflow_amd import ops
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
-g = torch.Generator().manual_seed(20261004)
+g = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
 DEV = "cuda"
 
 
