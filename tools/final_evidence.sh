@@ -14,7 +14,10 @@ timeout -k 10 300 python3 bench.py --mode train --steps 20 --warmup 5 > "$OUT/be
 timeout -k 10 600 bash tools/profile_gpu.sh $TAG/pmc > "$OUT/profile_gpu.log" 2>&1; tail -2 "$OUT/profile_gpu.log"
 for B in 4 8 16 32; do
   timeout -k 10 120 python3 bench.py --scaling strong --total-batch $B --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=%d' % $B, d['value'], d['unit'], d['ms_per_step'], 'ms/step')"
-done > "$OUT/batch_sweep.txt"; cat "$OUT/batch_sweep.txt"
+done > "$OUT/batch_sweep.txt"
+for B in 4 8 16 32; do
+  timeout -k 10 120 python3 bench.py --scaling strong --total-batch $B --pipeline 3 --steps 60 --warmup 6 --no-cpu-baseline --no-reduced 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=%d, 3 steps in flight' % $B, d['value'], d['unit'], d['ms_per_step'], 'ms/step')"
+done >> "$OUT/batch_sweep.txt"; cat "$OUT/batch_sweep.txt"
 timeout -k 10 200 python3 tools/time_train.py > "$OUT/time_train.txt" 2>&1; cat "$OUT/time_train.txt"
 timeout -k 10 200 python3 tools/train_breakdown.py 2>&1 | grep -v "Warn\|warn" > "$OUT/train_breakdown.txt"; cat "$OUT/train_breakdown.txt"
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_trace" -o tr -- python3 $ROOT/tools/prof_train.py > "$OUT/train_trace.log" 2>&1)
