@@ -38,3 +38,19 @@ def test_bench_reduced_precision_line():
     assert red["dtype"].startswith("f16") and red["knn_idx_exact_match_rate"] == 1.0
     assert red["max_abs_dx_vs_fp32_oracle"] < 5e-3 and red["cd_build_vs_fp32_oracle"] < 1e-6
     assert red["value"] > 0.9 * rec["value"]
+    # secondary two-steps-in-flight figure: present, same work per step, not slower than ~the headline
+    pl = rec["pipelined"]
+    assert pl["steps_in_flight"] == 2 and pl["value"] > 0.9 * rec["value"]
+
+
+def test_bench_pipeline_option_small_batch():
+    """`--pipeline 3 --scaling strong --total-batch 4`: three captured graphs on three streams; the JSON line keeps the contract
+    (steps, unit) and the results of every graph are the ones of the single-graph run (parity block)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scaling", "strong", "--total-batch", "4", "--pipeline", "3",
+                          "--steps", "30", "--warmup", "3", "--cpu-seconds", "1", "--no-reduced"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["steps"] == 30 and rec["unit"] == "patches/s" and rec["scaling"] == "strong" and rec["value"] > 0
+    assert "3 steps in flight" in rec["config"]["launch"] and "pipelined" not in rec
+    assert rec["parity"]["max_abs_dx_vs_oracle"] < 1e-5 and rec["parity"]["knn_idx_exact_match_rate"] == 1.0
