@@ -351,7 +351,13 @@ class PointInterpFlow(nn.Module):
         return super().train(mode)
 
     def _signature(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        """What the packed eval plan was built from: address and version counter of every parameter / buffer.  Writers that
+        go around torch's version counters must bump them (torch._C._increment_version): the fused optimizer
+        (optim.FusedClipAdam.step_flat) and a replayed training graph (train_graph.GraphedTrainStep.__call__) do; a
+        train-mode forward, whose fused kernels update the BatchNorm running statistics through raw pointers, counts itself
+        in `_train_forwards`."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers())) + \
+            (getattr(self, "_train_forwards", 0),)
 
     def _engine(self, upratio: int = 4) -> _Engine:
         """The packed plan (it does not depend on the upsampling ratio; the argument is kept for callers of round 1)."""
@@ -428,6 +434,7 @@ class PointInterpFlow(nn.Module):
             from .train_ops import forward_train
             if not xyz.is_cuda:
                 raise _lib.PuflowHipError("input must be a GPU tensor (no CPU fallback)")
+            self._train_forwards = getattr(self, "_train_forwards", 0) + 1     # running statistics change: the eval plan is stale
             return forward_train(self, xyz, upratio)
         with torch.no_grad():
             return self._forward_eval(xyz, upratio)

@@ -72,6 +72,9 @@ class FusedClipAdam(torch.optim.Optimizer):
                                          float(g["eps"]), float(g["max_norm"]), self._partial.data_ptr(),
                                          self._counter.data_ptr(), self.coef.data_ptr(),
                                          torch.cuda.current_stream().cuda_stream), "pf_clip_adam")
+        # the kernel writes the parameters through raw pointers: tell torch (autograd's saved-tensor checks, and the packed
+        # eval plan of PointInterpFlow, which is keyed on the version counters)
+        torch._C._increment_version(self.params)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -131,6 +131,11 @@ class GraphedTrainStep:
         if self.graph_b is not None:
             self._reduce()
             self.graph_b.replay()
+        # a replay updates parameters and BatchNorm running statistics without passing through torch's version counters:
+        # bump them, or a later eval forward would keep a packed plan of the OLD weights (interpflow._signature)
+        if getattr(self, "_written", None) is None:
+            self._written = list(self.module.parameters()) + list(self.module.buffers())
+        torch._C._increment_version(self._written)
         return self.loss
 
     def set_lr(self, lr: float) -> None:

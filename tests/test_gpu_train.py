@@ -172,6 +172,48 @@ def test_trainer_module_step_and_eval_roundtrip():
     assert (x.cpu() - xr).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_eval_after_training_sees_the_new_weights(graph):
+    """The eval path runs from a packed plan cached on the module.  The fused optimizer, a replayed training graph and the
+    fused BatchNorm kernels write parameters / running statistics through raw pointers: the plan must still be rebuilt (an eval
+    forward BEFORE training caches a plan; validation between epochs once kept returning the same CD)."""
+    from puflow_amd.trainer import TrainerModule, default_cfg
+    torch.manual_seed(0)
+    tm = TrainerModule(default_cfg(learning_rate=1e-3), loss_mix="pugan")
+    tm.network.load_state_dict(synth_state_dict(22))
+    tm = tm.to(DEV)
+    opt = tm.configure_optimizers()["optimizer"]
+    dense01 = ((synth_patches(4, 1024, seed=6) + 1) / 2).to(DEV)
+    sparse = dense01[:, ::4].contiguous()
+    batch = (sparse, dense01, torch.ones(4, device=DEV))
+    tm.network.set_to_initialized_state()
+    tm.eval()
+    x0, _ = tm.network(sparse, 4)                                   # caches the plan of the initial weights
+    x0 = x0.clone()
+    tm.train()
+    if graph:
+        step = tm.graphed_train_step(batch, opt, warmup=1)
+        for _ in range(3):
+            step(batch)
+    else:
+        for _ in range(3):
+            tm.train_step(batch, opt)
+    cd1 = float(tm.validation_step((sparse, dense01))["CD"])         # eval inside, back to train()
+    if graph:
+        step(batch)
+    else:
+        tm.train_step(batch, opt)
+    cd2 = float(tm.validation_step((sparse, dense01))["CD"])
+    assert cd1 != cd2                                                # another step, another validation value
+    tm.eval()
+    x1, _ = tm.network(sparse, 4)
+    sd = {k: v.detach().cpu() for k, v in tm.network.state_dict().items()}
+    xr, _ = O.forward(sd, sparse.cpu(), 4)
+    err, moved = float((x1.cpu() - xr).abs().max()), float((x1 - x0).abs().max())
+    assert err < 1e-5, (err, moved)                                  # the CURRENT weights and running statistics
+    assert moved > 1e-4, moved                                       # and not the ones cached before training
+
+
 def test_training_step_at_the_real_batch_size_matches_the_oracle():
     """BASELINE configs[2] shape: 32 patches of 256 -> 1024 points per rank.  The HIP train-mode forward + backward
     against the train-mode oracle (oracle/ref_cpu.py::forward_train, itself pinned to the reference's own training

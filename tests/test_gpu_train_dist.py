@@ -19,7 +19,10 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # PF_EMD_SINGLE: the two ranks SHARE one GPU here; the cooperative EMD auction assumes the process has the device to itself
+    # (its workgroups wait for each other: two such kernels at once can starve each other's barriers - csrc/emd.hip).  One
+    # workgroup per sample is the documented setting for shared devices; with one GPU per rank it is not needed.
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PF_EMD_SINGLE="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from puflow_amd.optim import FusedClipAdam
