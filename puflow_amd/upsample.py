@@ -82,7 +82,13 @@ def upsampling(data_paths: List[str], target_path: str, checkpoint_path: str, up
     # One process per GPU (torchrun): every rank upsamples its own files - clouds are independent, so the CLI shards
     # by file with no collective at all (BASELINE configs[3]); a plain `python -m puflow_amd.upsample` is rank 0 of 1.
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    data_paths = shard_paths(data_paths, rank, world)
+    # The per-file shuffle is drawn from the process RNG in file order (upsample.py:43), so a file's result depends on the
+    # files before it.  Under sharding every rank therefore walks the WHOLE sorted list and draws (and discards) the shuffles
+    # of the other ranks' files: each file gets exactly the result of a one-process run, whatever the number of ranks.  The
+    # list is sorted in every case (the reference takes os.walk's order, which depends on the file system: its outputs are
+    # reproducible only on one machine).
+    all_paths = sorted(data_paths)
+    mine = set(shard_paths(data_paths, rank, world))
     device = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)}")
     network = network_cls(3)
     network.load_state_dict(state_dict if state_dict is not None else torch.load(checkpoint_path, map_location="cpu"))
@@ -115,10 +121,13 @@ def upsampling(data_paths: List[str], target_path: str, checkpoint_path: str, up
         pending.clear()
 
     with ThreadPoolExecutor(max_workers=1) as pool:
-        for path in data_paths:
+        for path in all_paths:
             _, file_name = os.path.split(path)
             pt_input = torch.from_numpy(load_xyz(path)).unsqueeze(0)
-            pt_input = pt_input[:, torch.randperm(pt_input.shape[1])].contiguous()
+            perm = torch.randperm(pt_input.shape[1])
+            if path not in mine:
+                continue                                            # another rank's file: only the RNG draw is replayed
+            pt_input = pt_input[:, perm].contiguous()
             if pending and (pending[0][1].shape[1] != pt_input.shape[1] or len(pending) >= max(int(cloud_batch), 1)):
                 flush(pool)
             pending.append((file_name, pt_input))

@@ -147,6 +147,33 @@ def test_cli_batches_files_without_changing_any_cloud(tmp_path):
     assert np.loadtxt(tmp_path / "out8" / "c.xyz").shape == (768 * 4, 3)
 
 
+def test_cli_sharding_over_ranks_does_not_change_any_cloud(tmp_path, monkeypatch):
+    """Under torchrun the CLI shards the (sorted) file list over the ranks.  A file's shuffle comes from the process RNG in
+    file order (upsample.py:43), so every rank replays the draws of the files it skips: each file must come out byte for byte
+    as in the one-process run - here ranks 0 and 1 of 2 are run one after the other through the environment variables the
+    CLI reads."""
+    from puflow_amd import upsample as U
+    src = tmp_path / "in"
+    src.mkdir()
+    names = ["b.xyz", "a.xyz", "d.xyz", "c.xyz", "e.xyz"]                     # created out of order: the list is sorted
+    for k, name in enumerate(names):
+        np.savetxt(src / name, (synth_patches(1, 1024 if k != 3 else 768, seed=60 + k)[0] * 1.5).numpy(), fmt="%.6f")
+    sd = synth_state_dict(9)
+    paths = [str(src / n) for n in names]
+
+    def run(tag, rank, world):
+        dst = tmp_path / tag
+        dst.mkdir(exist_ok=True)
+        monkeypatch.setenv("RANK", str(rank)); monkeypatch.setenv("WORLD_SIZE", str(world))
+        U.upsampling(paths, str(dst), None, up_ratio=4, num_outlier=24, num_patch=256, seed=2021, state_dict=sd)
+        return {p.name: p.read_bytes() for p in dst.iterdir()}
+
+    one = run("one", 0, 1)
+    r0, r1 = run("two", 0, 2), run("two", 1, 2)                                # both ranks write into the same directory
+    assert set(one) == set(names) and set(r1) == set(names)
+    assert r1 == one
+
+
 def test_knn_large_streams_clouds_beyond_the_lds_limit():
     """knn_cuda.KNN takes any N (patch.py:33,107): clouds of more than 16 384 points stream through LDS in chunks; the
     result is still the exact (distance, index)-ordered top K."""
