@@ -60,11 +60,17 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has made no GPU call
+        # yet (importing torch does not initialise the device) and makes none: it only waits for the children.
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...` "
+                         f"(or leave WORLD_SIZE unset and bench.py starts the ranks itself)")
     if args.scaling == "strong":                     # fixed total work: the rank's contiguous shard of --total-batch patches
         from puflow_amd.dist import shard_bounds
         lo, hi = shard_bounds(args.total_batch, rank, world)
@@ -178,7 +184,7 @@ def main():
         eng = net._engine(4)
         prof = eng.profile_stages(xyz, iters=5)
         T = args.batch * args.npoint
-        ec_ms = prof["edgeconv3"]                       # C=128 unit: avg ms per launch
+        ec_ms = prof["edgeconv5"]                       # C=128 unit (the last one: never fused with a P|Q GEMM): avg ms per launch
         ec_fl = edgeconv_ref_flops(T, 128, 32, 4, 128)
         knn_ms = prof["knn"]
         knn_bytes = T * (3 * 4 + 16 * 4)               # 155 648 B per 2048-pt patch
@@ -306,6 +312,29 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: run the same command line under torch.distributed.run as N
+    FRESH child processes (one rank per GPU, RCCL), started before this process has touched the GPU - no exec of a process
+    that initialised the device, no fork after it.  Rank 0's JSON line passes through on stdout; the exit code is the
+    launcher's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+    return 0
 
 
 def reduced_precision_line(args):

@@ -40,24 +40,30 @@ int pf_nn1(const float* p1, const float* p2, int B, int N, int M, float* dist_ou
 
 /* Fused EdgeConv dense block + max-pool over K=16 neighbours, eval mode.
  * Replaces FeatureExtractUnit.forward (modules/discrete/interpflow.py:190-248).
- * cfg 0: unit 0 (input = xyz [B*N,3], `tab` = [96,8] folded edge table);
- * cfg 1: unit 1, cfg 2: units 2..5 (input = PQ [B*N, 2S] per-point vectors, tab ignored);
- * cfg 3 / 4: units 2..5 on the bf16 / fp16 matrix pipe with split operands (wfrag = the bf16x3 / f16x2
- * image of the same weights; fp32-class results, see csrc/pf_mfma.h);
- * cfg 5 / 6: units 0 / 1 on the fp16 matrix pipe (wfrag = f16x2 image; unit 0's edge table rides at its end,
- * input = xyz [B*N,3], tab ignored);
- * cfg 7: units 2..5, split-fp16 with a natural-scale low half (wfrag = packing.ec4_weights; the P|Q table must carry
- * the row scales of packing.ec4_scales; csrc/edgeconv.hip edgeconv4_kernel) - the shipped default;
- * cfg 8 / 9: units 0 / 1 in the same arithmetic (wfrag = packing ec1n_w; unit 1 reads the scaled P|Q table).
+ * cfg 7: units 2..5, cfg 8 / 9: units 0 / 1 - the PRODUCT arithmetic: split-fp16 with a natural-scale low half on
+ * v_mfma_f32_16x16x32_f16 (fp32-class results, csrc/pf_mfma.h); wfrag = packing.ec4_weights / ec1n_w (unit 0's edge table
+ * rides at the end of its image, input = xyz [B*N,3]); units 1..5 read the P|Q table [B*N, 2S] with the row scales of
+ * packing.ec4_scales (csrc/edgeconv.hip edgeconv4_kernel / edgeconv1n_kernel);
+ * cfg 0 / 1 / 2: unit 0 (input = xyz, `tab` = [96,8] folded edge table), unit 1, units 2..5 on the exact-fp32 kernel
+ * (v_mfma_f32_16x16x4_f32, unscaled P|Q table): the in-library A/B reference the parity tests compare the product with;
+ * cfg 3..6 (round-1 split-bf16 / scaled split-fp16 generations) are gone: PF_ERR_UNSUPPORTED.
  * idx [B*N,16] int32 (index inside the batch item); wfrag = fragment-packed growth weights;
  * out [B*N, odim]. */
 int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, const int* idx, const float* wfrag, float* out,
                 int B, int N, void* stream);
 
-/* Same as pf_edgeconv with an explicit tuning variant (points per wave / waves per workgroup);
- * variant 0 is what pf_edgeconv ships.  Used by tools/tune_edgeconv.py for in-process A/B timing. */
+/* Same as pf_edgeconv with an explicit launch shape (points per wave / waves per workgroup).  The default build carries
+ * only the shape pf_edgeconv ships per cfg (anything else: PF_ERR_UNSUPPORTED); a -DPF_TUNING_VARIANTS build adds the
+ * alternatives and the timing-only ablation instantiations for tools/tune_ec4.py. */
 int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, const float* tab, const int* idx,
                       const float* wfrag, float* out, int B, int N, void* stream);
+
+/* EdgeConv unit `unit` (0..4, product arithmetic) AND the next unit's P|Q vectors: out [B*N, odim] as pf_edgeconv, pq_next
+ * [B*N, rows] as pf_pq_gemm(unit, out, ...) - bit-identical to that pair.  fuse: -1 = one launch when B*N <= 16 384 (the GEMM
+ * runs on each 16-point workgroup tile inside the EdgeConv kernel), otherwise the two kernels; 0 = never; 1 = always.
+ * w: weight blob base, off[13]: POST_SLOTS offsets of unit `unit`. */
+int pf_edgeconv_pq(int unit, const float* pq_or_xyz, const int* idx, const float* wfrag, float* out, const float* w,
+                   const long long* off, float* pq_next, int B, int N, int fuse, void* stream);
 
 /* Per-point stages after EdgeConv unit `unit` (0..5).  off[13] = float offsets into the blob `w` of
  * M1,b1,M2,H1,S2,bS2,T2,bT2,ST4,bST4,PQ,bPQ,scales (packing.POST_SLOTS; f16n fragment images + per-matrix 2^-sw).
@@ -97,6 +103,13 @@ int pf_flow_inv(const float* u, const float* cp, const float* st, const float* w
 int pf_logp(const float* z, const float* ld_pt, float ld_const, int B, int N, float* ldj, float* lpsum, float* logp,
             void* stream);
 
+/* pf_flow_fwd + pf_logp in ONE launch (the workgroup that finishes last reduces the wave tiles' sums per batch item, in a
+ * fixed order): outputs as those two.  ws: pf_flow_fwd_logp_ws_floats(B, N) floats, ZERO before the first call and left
+ * reusable by the kernel; one workspace per stream in flight.  N % 16 != 0 runs the two launches. */
+long long pf_flow_fwd_logp_ws_floats(int B, int N);
+int pf_flow_fwd_logp(const float* xyz, const float* cp, const float* st, const float* w, float* z, float* ld_pt,
+                     float ld_const, int B, int N, float* ldj, float* lpsum, float* logp, float* ws, void* stream);
+
 /* Interpolation module (interpflow.py:85-186), fused: kNN-8 context features -> weights ->
  * softmax_k -> weighted sum of neighbour latents.  idx16 [T,16] (first 8 columns used),
  * u_out [T*R,3] in the row order of g (row = n*R + r).  1 <= R <= 32 (r_max of WeightEstimationUnit,
@@ -127,6 +140,17 @@ int pf_chamfer_bwd(const float* x, const float* y, const int* idx1, const int* i
 int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist, int* assignment, float* price,
                    int* assignment_inv, int* bid, float* bid_increments, float* max_increments, int* unass_idx,
                    int* max_idx, float eps, int iters, int B, int n, void* stream);
+
+/* pf_emd_forward with the launch decision and the failure report made explicit.
+ * groups: workgroups per sample.  0 = chosen here from the device: the multi-workgroup auction waits on grid barriers, so it
+ * runs only when hipOccupancyMaxActiveBlocksPerMultiprocessor(kernel) x CU count says all B*G workgroups are resident at once
+ * (G = largest power of two <= 16 that fits, >= 64 points per workgroup), otherwise one workgroup per sample; 1 = always one
+ * workgroup per sample (no inter-workgroup waits: the setting for a GPU shared between processes); g > 1 = at most g.
+ * status: nullable device word; += 1 per sample whose barrier timed out (that sample's dist is NaN).  The caller reads it
+ * at its next synchronisation point (puflow_amd.loss.check_emd_status raises). */
+int pf_emd_forward_ex(const float* xyz1, const float* xyz2, float* dist, int* assignment, float* price,
+                      int* assignment_inv, int* bid, float* bid_increments, float* max_increments, int* unass_idx,
+                      int* max_idx, float eps, int iters, int B, int n, int groups, unsigned* status, void* stream);
 
 /* Auction EMD backward.  Replaces emd.backward (emd.cpp:21-24 -> emd_cuda.cu:284-316):
  * gradxyz [B,n,3] += 2 graddist (xyz1 - xyz2[idx]); gradient wrt xyz2 is zero (emd_module.py:68-72). */

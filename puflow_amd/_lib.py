@@ -53,6 +53,8 @@ SIGNATURES = {
     "pf_edgeconv": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pf_edgeconv_tuned": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_void_p]),
+    "pf_edgeconv_pq": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_int, c_int, c_int,
+                               c_void_p]),
     "pf_post": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                         c_void_p]),
     "pf_pq_gemm": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_int, c_void_p]),
@@ -60,6 +62,9 @@ SIGNATURES = {
     "pf_cond": (c_int, [c_int, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pf_flow_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pf_flow_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pf_flow_fwd_logp_ws_floats": (c_longlong, [c_int, c_int]),
+    "pf_flow_fwd_logp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
     "pf_logp": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_interp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_int, c_int, c_int,
                           c_void_p]),
@@ -68,6 +73,7 @@ SIGNATURES = {
     "pf_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_int, c_void_p]),
     "pf_emd_forward": (c_int, [c_void_p] * 11 + [c_float, c_int, c_int, c_int, c_void_p]),
+    "pf_emd_forward_ex": (c_int, [c_void_p] * 11 + [c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_emd_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pf_gemm_ws_floats": (c_longlong, [c_int, c_int, c_int]),
     "pf_gemm": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p,

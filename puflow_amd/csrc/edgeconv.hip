@@ -24,7 +24,75 @@ struct EcArgs {
     int N;               // points per batch item
     int chunk;           // ceil(ntiles / 8) for the XCD-aware tile order
     int ntiles;          // workgroup tiles
+    // fused next-unit P|Q GEMM (PQF kernels, small batches): the arguments of pointwise.hip pq_gemm_kernel
+    const u4* pqf_w;     // f16n fragment image [ROWS/16][CP][hi / lo][64 lanes]
+    const float* pqf_bias;
+    const float* pqf_scales;
+    float* pqf_out;      // [T, ROWS]
 };
+
+// ---- the next unit's P|Q vectors from inside the producing EdgeConv kernel (small batches) --------------------------------
+// At 4 x 2048 points pf_pq_gemm is a 12 us launch for 2 us of work (weight prologue, staging, drain); here the 16 points a
+// workgroup has just finished become one MFMA column tile: every wave leaves its points' pooled features in LDS as ready-made
+// B operands (fp32 -> hi / natural lo, the split of pf_pairn), one barrier, then every wave multiplies the tile by ITS rows of
+// the [ROWS x ODIM] matrix (fragments straight from L2: 16 KiB per wave and tile - fine for a few tiles per workgroup, too
+// much L2 traffic next to the Q gathers at 32 x 2048, where the separate HBM-bound kernel stays).  Products, order and
+// rescale are those of pq_gemm_kernel: the table is bit-identical.  hb: [2 parities][CP][hi / lo][64 lanes] x 16 B.
+template <int ODIM>
+__device__ __forceinline__ void pqf_stage(u4* hb, int ch, int pt, float v) {
+    _Float16* h = reinterpret_cast<_Float16*>(hb);
+    const int cp = ch >> 5, j = ((ch >> 4) & 1) * 4 + (ch & 3), slot = 16 * ((ch & 15) >> 2) + pt;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    h[((cp * 2 + 0) * 64 + slot) * 8 + j] = hi;
+    h[((cp * 2 + 1) * 64 + slot) * 8 + j] = lo;
+}
+
+template <int ODIM, int ROWS, int NW>
+__device__ __forceinline__ void pqf_gemm(const EcArgs& a, const u4* hb, int wave_u, int lane, int pt0_tile) {
+    constexpr int CP = ODIM / 32, RB = ROWS / 16 / NW;
+    static_assert(ODIM % 32 == 0 && ROWS % (16 * NW) == 0, "rows split evenly over the waves");
+    const int col = lane & 15, q = lane >> 4;
+    const PfW2BufD<RB * CP> ws(a.pqf_w, lane);
+    h8 wh[RB][CP], wl[RB][CP];
+#pragma unroll
+    for (int ob = 0; ob < RB; ++ob)
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+            wh[ob][cp] = ws.load((wave_u * RB + ob) * CP + cp, 0);
+            wl[ob][cp] = ws.load((wave_u * RB + ob) * CP + cp, 1);
+        }
+    const float inv = a.pqf_scales[6];
+    f4 acc[RB];
+#pragma unroll
+    for (int ob = 0; ob < RB; ++ob) acc[ob] = pf_splat(0.f);
+#pragma unroll
+    for (int cp = 0; cp < CP; ++cp) {
+        const h8 fh = __builtin_bit_cast(h8, hb[(cp * 2 + 0) * 64 + lane]), fl = __builtin_bit_cast(h8, hb[(cp * 2 + 1) * 64 + lane]);
+#pragma unroll
+        for (int ob = 0; ob < RB; ++ob) {
+            f4 x = acc[ob];
+            if constexpr (PF_MMN_TERMS == 3) {
+                x = pf_mfma_f16(wh[ob][cp], fl, x);
+                x = pf_mfma_f16(wl[ob][cp], fh, x);
+            }
+            x = pf_mfma_f16(wh[ob][cp], fh, x);
+            acc[ob] = x;
+        }
+    }
+    const int pt = pt0_tile + col;
+    if (pt < a.T) {
+#pragma unroll
+        for (int ob = 0; ob < RB; ++ob) {
+            const f4 bias = *reinterpret_cast<const f4*>(a.pqf_bias + (wave_u * RB + ob) * 16 + 4 * q);
+            f4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaf(acc[ob][r], inv, bias[r]);
+            *reinterpret_cast<f4*>(a.pqf_out + (size_t)pt * ROWS + (wave_u * RB + ob) * 16 + 4 * q) = o;
+        }
+    }
+}
+
 
 template <int GB, int NCONV, int ODIM, bool C3, int P, int NW>
 __global__ __launch_bounds__(NW * 64) void edgeconv_kernel(EcArgs a) {
@@ -163,24 +231,7 @@ __global__ __launch_bounds__(NW * 64) void edgeconv_kernel(EcArgs a) {
     }
 }
 
-// ---- split-precision variants of the 128-channel units (GB = 2: one growth layer = one 32-channel block pair) ----
-// Same data flow as edgeconv_kernel; growth features are kept as pre-split B operands, the weights come pre-split
-// from the host.  NS = 3: split-bf16 (hi, mid, lo; six MFMAs per pair; packing.frag_pack_bf16x3);
-// NS = 2: split-fp16 (hi, lo' = lo * 2^11; three MFMAs per pair into a main and a cross accumulator;
-// packing.frag_pack_f16x2).  Accuracy of both: fp32-class (tests compare to the oracle with the same 1e-5 bar).
-// MFMA cycles per point: 264 x 16 (NS = 3) or 132 x 16 (NS = 2) instead of 352 x 32 for the f32 pipe.
-template <int NS> struct EcSplit;
-template <> struct EcSplit<3> {
-    using Pair = PfPair;
-    using WLds = PfW3Lds;
-    static __device__ __forceinline__ Pair make(f4 a, f4 b) { return pf_pair(a, b); }
-};
-template <> struct EcSplit<2> {
-    using Pair = PfPair2;
-    using WLds = PfW2Lds;
-    static __device__ __forceinline__ Pair make(f4 a, f4 b) { return pf_pair2(a, b); }
-};
-
+// timing-only weight source of the -DPF_TUNING_VARIANTS ablation builds (edgeconv4_kernel DBG & 4)
 struct EcWConst {                                             // DBG & 4 (timing-only builds): weights without memory traffic
     static constexpr int DEPTH = 2;
     int lane;
@@ -189,126 +240,6 @@ struct EcWConst {                                             // DBG & 4 (timing
         return (h8){x, x, x, x, x, x, x, x};
     }
 };
-
-// acc[p][0..OB) += W feat over CP pairs, in the arithmetic of the split
-template <int NS, int OB, int CP, int WCP, class WS, class Pair, int P, int NIN>
-__device__ __forceinline__ void ec_mm(const WS& ws, int frag0, const Pair (&feat)[P][NIN], f4 (&acc)[P][OB]) {
-    if constexpr (NS == 3) {
-        pf_mm3<OB, CP, WCP>(ws, frag0, feat, 0, acc, 0);
-    } else {
-        f4 accx[P][OB];
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int o = 0; o < OB; ++o) accx[p][o] = pf_splat(0.f);
-        pf_mm2<OB, CP, WCP>(ws, frag0, feat, 0, acc, accx, 0);
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int o = 0; o < OB; ++o) acc[p][o] += accx[p][o] * PF_LO_INV;
-    }
-}
-
-template <int NCONV, int ODIM, int P, int NW, int DBG = 0, int NS = 3>   // DBG bit mask (timing-only builds): 1 no gathers, 2 no MFMAs, 4 no LDS weight reads, 8 no max-pool
-__global__ __launch_bounds__(NW * 64) void edgeconv3_kernel(EcArgs a) {
-    constexpr int G = 32, S = G * NCONV + ODIM, OBO = ODIM / 16, OCH = 2;
-    constexpr int NWF = 2 * (NCONV * (NCONV - 1) / 2) + OBO * NCONV;      // (ob, pair) fragments, NS KiB each
-    using SP = EcSplit<NS>;
-    using Pair = typename SP::Pair;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 15, q = lane >> 4;
-    __shared__ u4 wlds[NWF * NS * 64];
-    for (int i = threadIdx.x; i < NWF * NS * 64; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
-    __syncthreads();
-    const typename SP::WLds ws_lds{wlds, lane};
-    const auto ws = [&] { if constexpr ((DBG & 4) != 0) return EcWConst{lane}; else return ws_lds; }();
-
-    for (int v = blockIdx.x; v < 8 * a.chunk; v += gridDim.x) {
-        const int tile = pf_xcd_tile(v, a.chunk);
-        if (tile >= a.ntiles) continue;
-        const int pt0 = (tile * NW + wave) * P;
-        int gi[P], gj[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            int g = pt0 + p;
-            g = g < a.T ? g : a.T - 1;
-            gi[p] = g;
-            gj[p] = (g / a.N) * a.N + a.idx[(size_t)g * 16 + col];
-        }
-        auto init = [&](int p, int off) -> f4 {
-            if constexpr (DBG & 1) return pf_splat((float)(off + gi[p]) * 1e-6f);
-            const f4 pv = *reinterpret_cast<const f4*>(a.pq + (size_t)gi[p] * (2 * S) + off);
-            const f4 qv = *reinterpret_cast<const f4*>(a.pq + (size_t)gj[p] * (2 * S) + S + off);
-            return pv + qv;
-        };
-        f4 ini[2][P][2];
-        auto load_init = [&](int row0, f4 (&dst)[P][2]) {
-#pragma unroll
-            for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                for (int p = 0; p < P; ++p) dst[p][ob] = init(p, row0 + ob * 16 + 4 * q);
-        };
-        load_init(0, ini[0]);
-        load_init(G, ini[1]);
-        Pair feat[P][NCONV];
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-            feat[p][0] = SP::make(pf_lrelu(ini[0][p][0], 0.05f), pf_lrelu(ini[0][p][1], 0.05f));
-        pf_static_for<1, NCONV>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            load_init(G * (t + 1), ini[(t + 1) & 1]);                 // next growth layer, or conv_out chunk 0
-            f4 acc[P][2];
-#pragma unroll
-            for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                for (int p = 0; p < P; ++p) acc[p][ob] = ini[t & 1][p][ob];
-            if constexpr (!(DBG & 2)) ec_mm<NS, 2, t, t>(ws, 2 * (t * (t - 1) / 2), feat, acc);
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-                feat[p][t] = SP::make(pf_lrelu(acc[p][0], 0.05f), pf_lrelu(acc[p][1], 0.05f));
-        });
-        constexpr int FO = 2 * (NCONV * (NCONV - 1) / 2);
-        f4 sel[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) sel[p] = pf_splat(0.f);
-        pf_static_for<0, OBO / OCH>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int ob0 = c * OCH;
-            constexpr int st = NCONV + c;
-            if constexpr (c + 1 < OBO / OCH) load_init(G * NCONV + (ob0 + OCH) * 16, ini[(st + 1) & 1]);
-            f4 acc[P][OCH];
-#pragma unroll
-            for (int o = 0; o < OCH; ++o)
-#pragma unroll
-                for (int p = 0; p < P; ++p) acc[p][o] = ini[st & 1][p][o];
-            if constexpr (!(DBG & 2)) ec_mm<NS, OCH, NCONV, NCONV>(ws, FO + ob0 * NCONV, feat, acc);
-#pragma unroll
-            for (int o = 0; o < OCH; ++o)
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    f4 m;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m[r] = (DBG & 8) ? acc[p][o][r] : pf_rowmax16(acc[p][o][r]);
-                    if (col == ob0 + o) sel[p] = m;
-                }
-        });
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-            if (col < OBO && pt0 + p < a.T)
-                *reinterpret_cast<f4*>(a.out + (size_t)gi[p] * ODIM + col * 16 + 4 * q) = sel[p];
-    }
-}
-
-template <int P, int NW, int DBG = 0, int NS = 3>
-int launch3(const EcArgs& a0, hipStream_t s) {
-    EcArgs a = a0;
-    a.ntiles = (a.T + NW * P - 1) / (NW * P);
-    a.chunk = (a.ntiles + 7) / 8;
-    int grid = 8 * a.chunk;
-    if (grid > 256) grid = 256;                           // 132 / 88 KiB of LDS: one persistent workgroup per CU
-    hipLaunchKernelGGL((edgeconv3_kernel<4, 128, P, NW, DBG, NS>), dim3(grid), dim3(NW * 64), 0, s, a);
-    return pf_last_launch_status();
-}
 
 // ---- "f16n": split-fp16 with a NATURAL-scale low half, one accumulator, conv_out with the operands swapped ----------
 // Arithmetic: x = hi + lo, hi = rne_f16(x), lo = rne_f16(x - hi) (no 2^11 scale: v_fma_mixlo/mixhi_f16 writes it straight into
@@ -321,11 +252,12 @@ int launch3(const EcArgs& a0, hipStream_t s) {
 // MFMA rows (tools/probes/split_probe.hip), so D[edge][channel] puts a lane's 4 registers on 4 edges of one channel:
 // max over K = 16 is 2 in-lane max + a reduce-scatter over the 4 lane rows (v_permlane32_swap / v_permlane16_swap):
 // 28 VALU per point instead of 160.  Its accumulators are initialised with Q[j] alone (dword gathers, 64 B per 16 lanes);
-// P[i] is added once per channel after the max.  VALU per point: ~180 (edgeconv3_kernel<NS=2>: ~450).
+// P[i] is added once per channel after the max.  VALU per point: ~180 (round 1 split-fp16 kernel: ~450).
 constexpr float EC4_OUT_INV = 1.f / 256.f;       // conv_out accumulators hold 4^4 y (packing.ec4_scales)
 
-template <int P, int NW, int DBG = 0>      // DBG bit mask (-DPF_TUNING_VARIANTS timing builds only; wrong results): 1 no gathers, 2 no MFMAs, 4 no LDS weight reads
+template <int P, int NW, int DBG = 0, bool PQF = false>      // DBG bit mask (-DPF_TUNING_VARIANTS timing builds only; wrong results): 1 no gathers, 2 no MFMAs, 4 no LDS weight reads;  PQF: + the next unit's P|Q vectors (pqf_gemm)
 __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
+    static_assert(!PQF || NW * P == 16, "the fused P|Q GEMM takes a workgroup tile of 16 points as one MFMA column tile");
     constexpr int NCONV = 4, G = 32, S = 256, OBO = 8, OCH = 2, ODIM = 128;
     constexpr int NWF = 2 * (NCONV * (NCONV - 1) / 2) + OBO * NCONV;      // 44 (ob, pair) fragments, 2 KiB each
     constexpr int ROWB = 2 * S * 4;                                       // bytes per point of the P|Q table
@@ -337,6 +269,8 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
     // (edge, 4-channel) lane layout cost as many texture-addresser cycles as the Q gathers themselves (16 lanes fetching
     // the same 16 bytes still take a full quad-lane slot each): 392 -> 272 TA cycles per point.
     __shared__ f4 plds[NW * P][64];
+    __shared__ u4 hb[PQF ? 2 * (ODIM / 32) * 2 * 64 : 1];                 // PQF: the tile's pooled features as B operands, per tile parity
+    int parity = 0;
     for (int i = threadIdx.x; i < NWF * 2 * 64; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
     __syncthreads();
     const PfW2Lds ws_lds{wlds, lane};
@@ -457,145 +391,38 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
             const int ch = 16 * blkq + col;
             const float* pr = reinterpret_cast<const float*>(plds[wave * P + p]);
             const float p0 = pr[G * NCONV + ch], p1 = pr[G * NCONV + 64 + ch];
+            const float h0 = fmaf(o0, EC4_OUT_INV, p0), h1 = fmaf(o1, EC4_OUT_INV, p1);
             if (pt0 + p < a.T) {
                 float* o = a.out + (size_t)gout[p] * ODIM + ch;
-                o[0] = fmaf(o0, EC4_OUT_INV, p0);
-                o[64] = fmaf(o1, EC4_OUT_INV, p1);
+                o[0] = h0;
+                o[64] = h1;
             }
+            if constexpr (PQF) {
+                u4* hbt = hb + parity * ((ODIM / 32) * 2 * 64);
+                pqf_stage<ODIM>(hbt, ch, wave * P + p, h0);
+                pqf_stage<ODIM>(hbt, ch + 64, wave * P + p, h1);
+            }
+        }
+        if constexpr (PQF) {
+            // one barrier per tile: the staging buffer alternates, and a wave reaches the barrier of tile t + 1 only after it
+            // has finished reading tile t's buffer - which tile t + 2 overwrites
+            __syncthreads();
+            pqf_gemm<ODIM, 2 * S, NW>(a, hb + parity * ((ODIM / 32) * 2 * 64), __builtin_amdgcn_readfirstlane(wave), lane,
+                                      pf_xcd_tile(v, a.chunk) * NW * P);
+            parity ^= 1;
         }
         v = vn;
     }
 }
 
-template <int P, int NW, int DBG = 0>
+template <int P, int NW, int DBG = 0, bool PQF = false>
 int launch4(const EcArgs& a0, hipStream_t s) {
     EcArgs a = a0;
     a.ntiles = (a.T + NW * P - 1) / (NW * P);
     a.chunk = (a.ntiles + 7) / 8;
     int grid = 8 * a.chunk;
     if (grid > 256) grid = 256;                           // 88 KiB of LDS: one persistent workgroup per CU
-    hipLaunchKernelGGL((edgeconv4_kernel<P, NW, DBG>), dim3(grid), dim3(NW * 64), 0, s, a);
-    return pf_last_launch_status();
-}
-
-// ---- split-fp16 variant of the narrow units 0 / 1 (one 16-channel block per growth layer, four layers) ----
-// Two growth layers share one 32-channel MFMA step (a block pair); an odd layer count pairs with a zero block.
-// C3 (unit 0): the per-edge pre-activations of ALL S rows are one MFMA step against the folded edge table
-// (raw inputs e = (x_i, x_j, 1) in 8 of the 32 k-slots, packing._etab_frag) instead of 7 VALU fmas per row.
-// PQ (unit 1): P[i] + Q[j] gathers, all S rows issued at the top of the tile.
-// Fragments in LDS: G1 | G2 | G3 (2 pairs) | Gout (OBO x 2 pairs) | [C3: edge table, S/16 x 1 pair].
-template <int ODIM, bool C3, int P, int NW>
-__global__ __launch_bounds__(NW * 64) void edgeconv1h_kernel(EcArgs a) {
-    constexpr int NCONV = 4, S = 16 * NCONV + ODIM, SB = S / 16, OBO = ODIM / 16, OCH = 2;
-    constexpr int FO = 4, FT = FO + OBO * 2, NWF = FT + (C3 ? SB : 0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 15, q = lane >> 4;
-    __shared__ u4 wlds[NWF * 128];
-    for (int i = threadIdx.x; i < NWF * 128; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
-    __syncthreads();
-    const PfW2Lds ws{wlds, lane};
-
-    for (int v = blockIdx.x; v < 8 * a.chunk; v += gridDim.x) {
-        const int tile = pf_xcd_tile(v, a.chunk);
-        if (tile >= a.ntiles) continue;
-        const int pt0 = (tile * NW + wave) * P;
-        int gi[P], gj[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            int g = pt0 + p;
-            g = g < a.T ? g : a.T - 1;
-            gi[p] = g;
-            gj[p] = (g / a.N) * a.N + a.idx[(size_t)g * 16 + col];
-        }
-        f4 pre[P][SB];                       // P[i] + Q[j] (+ bias) of every stacked row, this lane's 4 channels per block
-        if constexpr (C3) {
-            PfPair2 e[P][1];
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                float xi[3], xj[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    xi[c] = a.xyz[(size_t)gi[p] * 3 + c];
-                    xj[c] = a.xyz[(size_t)gj[p] * 3 + c];
-                }
-                const f4 z4 = pf_splat(0.f);
-                const f4 e0 = {xi[0], xi[1], xi[2], xj[0]}, e1 = {xj[1], xj[2], 0.f, 1.f};
-                e[p][0] = pf_pair2(q == 0 ? e0 : z4, q == 0 ? e1 : z4);
-#pragma unroll
-                for (int b = 0; b < SB; ++b) pre[p][b] = pf_splat(0.f);
-            }
-            pf_mm2f<SB, 1, 1>(ws, FT, e, 0, pre, 0);
-        } else {
-#pragma unroll
-            for (int b = 0; b < SB; ++b)
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const f4 pv = *reinterpret_cast<const f4*>(a.pq + (size_t)gi[p] * (2 * S) + b * 16 + 4 * q);
-                    const f4 qv = *reinterpret_cast<const f4*>(a.pq + (size_t)gj[p] * (2 * S) + S + b * 16 + 4 * q);
-                    pre[p][b] = pv + qv;
-                }
-        }
-
-        PfPair2 fp[P][2];
-        f4 last[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            last[p] = pf_lrelu(pre[p][0], 0.05f);
-            fp[p][0] = pf_pair2(last[p], pf_splat(0.f));
-        }
-        pf_static_for<1, NCONV>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            constexpr int CPT = (t + 1) / 2, F0 = (t / 2) * ((t + 1) / 2);
-            f4 acc[P][1];
-#pragma unroll
-            for (int p = 0; p < P; ++p) acc[p][0] = pre[p][t];
-            pf_mm2f<1, CPT, CPT>(ws, F0, fp, 0, acc, 0);
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const f4 f = pf_lrelu(acc[p][0], 0.05f);
-                if constexpr (t % 2 == 1) fp[p][t / 2] = pf_pair2(last[p], f);
-                else fp[p][t / 2] = pf_pair2(f, pf_splat(0.f));
-                last[p] = f;
-            }
-        });
-
-        f4 sel[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) sel[p] = pf_splat(0.f);
-        pf_static_for<0, OBO / OCH>([&](auto cc) {
-            constexpr int ob0 = decltype(cc)::value * OCH;
-            f4 acc[P][OCH];
-#pragma unroll
-            for (int o = 0; o < OCH; ++o)
-#pragma unroll
-                for (int p = 0; p < P; ++p) acc[p][o] = pre[p][NCONV + ob0 + o];
-            pf_mm2f<OCH, 2, 2>(ws, FO + ob0 * 2, fp, 0, acc, 0);
-#pragma unroll
-            for (int o = 0; o < OCH; ++o)
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    f4 m;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m[r] = pf_rowmax16(acc[p][o][r]);
-                    if (col == ob0 + o) sel[p] = m;
-                }
-        });
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-            if (col < OBO && pt0 + p < a.T)
-                *reinterpret_cast<f4*>(a.out + (size_t)gi[p] * ODIM + col * 16 + 4 * q) = sel[p];
-    }
-}
-
-template <int ODIM, bool C3, int P, int NW>
-int launch1h(const EcArgs& a0, hipStream_t s) {
-    EcArgs a = a0;
-    a.ntiles = (a.T + NW * P - 1) / (NW * P);
-    a.chunk = (a.ntiles + 7) / 8;
-    int grid = 8 * a.chunk;
-    const int cap = 256 * (32 / NW);                      // persistent: resident workgroups only (LDS < 32 KiB each)
-    if (grid > cap) grid = cap;
-    hipLaunchKernelGGL((edgeconv1h_kernel<ODIM, C3, P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((edgeconv4_kernel<P, NW, DBG, PQF>), dim3(grid), dim3(NW * 64), 0, s, a);
     return pf_last_launch_status();
 }
 
@@ -607,9 +434,11 @@ int launch1h(const EcArgs& a0, hipStream_t s) {
 // the 32 k-slots); the same e registers are the B operand of the growth rows and the A operand of the conv_out rows.
 // PQ (unit 1): Q[j] gathers as accumulator initialisers, P[i] staged per wave in LDS (one load per point).
 // Fragments in LDS: G1 | G2 | G3 (2 pairs) | Gout (OBO x 2 pairs) | [C3: edge table, S/16 x 1 pair].
-template <int ODIM, bool C3, int P, int NW>
+template <int ODIM, bool C3, int P, int NW, bool PQF = false>      // PQF: + the next unit's P|Q vectors (pqf_gemm; ROWS = 256 after unit 0, 512 after unit 1)
 __global__ __launch_bounds__(NW * 64) void edgeconv1n_kernel(EcArgs a) {
+    static_assert(!PQF || NW * P == 16, "the fused P|Q GEMM takes a workgroup tile of 16 points as one MFMA column tile");
     constexpr int NCONV = 4, S = 16 * NCONV + ODIM, SB = S / 16, OBO = ODIM / 16;
+    constexpr int PQ_ROWS = ODIM == 32 ? 256 : 512;
     constexpr int FO = 4, FT = FO + OBO * 2, NWF = FT + (C3 ? SB : 0);
     constexpr int ROWB = 2 * S * 4;                                       // bytes per point of the P|Q table (unit 1)
     static_assert(OBO == 2 || OBO == 4, "reduce-scatter below is written for 2 or 4 output blocks");
@@ -617,6 +446,8 @@ __global__ __launch_bounds__(NW * 64) void edgeconv1n_kernel(EcArgs a) {
     const int col = lane & 15, q = lane >> 4;
     __shared__ u4 wlds[NWF * 128];
     __shared__ float plds[C3 ? 1 : NW * P][C3 ? 1 : S];
+    __shared__ u4 hb[PQF ? 2 * (ODIM / 32) * 2 * 64 : 1];
+    int parity = 0;
     for (int i = threadIdx.x; i < NWF * 128; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
     __syncthreads();
     const PfW2Lds ws{wlds, lane};
@@ -733,13 +564,22 @@ __global__ __launch_bounds__(NW * 64) void edgeconv1n_kernel(EcArgs a) {
             }
             float pv = 0.f;
             if constexpr (!C3) pv = plds[wave * P + p][16 * NCONV + ch];
+            const float hv = fmaf(o, EC4_OUT_INV, pv);
             if (pt0 + p < a.T && (OBO == 4 || (q & 1) == 0))
-                a.out[(size_t)gi[p] * ODIM + ch] = fmaf(o, EC4_OUT_INV, pv);
+                a.out[(size_t)gi[p] * ODIM + ch] = hv;
+            if constexpr (PQF) {
+                if (OBO == 4 || (q & 1) == 0) pqf_stage<ODIM>(hb + parity * ((ODIM / 32) * 2 * 64), ch, wave * P + p, hv);
+            }
+        }
+        if constexpr (PQF) {
+            __syncthreads();                       // one per tile (alternating staging buffer: see edgeconv4_kernel)
+            pqf_gemm<ODIM, PQ_ROWS, NW>(a, hb + parity * ((ODIM / 32) * 2 * 64), __builtin_amdgcn_readfirstlane(wave), lane, tile * NW * P);
+            parity ^= 1;
         }
     }
 }
 
-template <int ODIM, bool C3, int P, int NW>
+template <int ODIM, bool C3, int P, int NW, bool PQF = false>
 int launch1n(const EcArgs& a0, hipStream_t s) {
     EcArgs a = a0;
     a.ntiles = (a.T + NW * P - 1) / (NW * P);
@@ -747,29 +587,22 @@ int launch1n(const EcArgs& a0, hipStream_t s) {
     int grid = 8 * a.chunk;
     const int cap = 256 * (32 / NW);                      // persistent: resident workgroups only (LDS < 40 KiB each)
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL((edgeconv1n_kernel<ODIM, C3, P, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((edgeconv1n_kernel<ODIM, C3, P, NW, PQF>), dim3(grid), dim3(NW * 64), 0, s, a);
     return pf_last_launch_status();
 }
 
+// Launch shapes (points per wave P, waves per workgroup NW).  The default build carries ONE shape per kernel - the shipped
+// one (tools/tune_edgeconv.py / tune_ec4.py sweeps on MI355X); -DPF_TUNING_VARIANTS adds the alternatives and the timing-only
+// ablation instantiations (DBG != 0: wrong results) for the tuning tools.
 template <int ODIM, bool C3>
 int launch1n_v(const EcArgs& a, hipStream_t s, int variant) {
     switch (variant) {
+        case 1: return launch1n<ODIM, C3, 2, 8>(a, s);                  // shipped
+#ifdef PF_TUNING_VARIANTS
         case 0: return launch1n<ODIM, C3, 1, 8>(a, s);
-        case 1: return launch1n<ODIM, C3, 2, 8>(a, s);
         case 2: return launch1n<ODIM, C3, 1, 16>(a, s);
         case 3: return launch1n<ODIM, C3, 2, 4>(a, s);
-        default: return PF_ERR_UNSUPPORTED;
-    }
-}
-
-template <int ODIM, bool C3>
-int launch1h_v(const EcArgs& a, hipStream_t s, int variant) {
-    switch (variant) {
-        case 0: return launch1h<ODIM, C3, 2, 8>(a, s);
-        case 1: return launch1h<ODIM, C3, 1, 8>(a, s);
-        case 2: return launch1h<ODIM, C3, 1, 16>(a, s);
-        case 3: return launch1h<ODIM, C3, 2, 4>(a, s);
-        case 4: return launch1h<ODIM, C3, 4, 4>(a, s);
+#endif
         default: return PF_ERR_UNSUPPORTED;
     }
 }
@@ -792,22 +625,35 @@ int launch_v(const EcArgs& a0, hipStream_t s) {
     return pf_last_launch_status();
 }
 
+// the exact-fp32 reference kernel: shipped shape of unit class GB/ODIM = (1, 32): (2, 8); (1, 64): (1, 8); (2, 128): (1, 16)
 template <int GB, int NCONV, int ODIM, bool C3>
 int launch(const EcArgs& a, hipStream_t s, int variant) {
+    constexpr int BEST = ODIM == 32 ? 0 : (ODIM == 64 ? 2 : 3);
+    if (variant == BEST) {
+        if constexpr (BEST == 0) return launch_v<GB, NCONV, ODIM, C3, 2, 8>(a, s);
+        else if constexpr (BEST == 2) return launch_v<GB, NCONV, ODIM, C3, 1, 8>(a, s);
+        else return launch_v<GB, NCONV, ODIM, C3, 1, 16>(a, s);
+    }
+#ifdef PF_TUNING_VARIANTS
     switch (variant) {
-        case 0: return launch_v<GB, NCONV, ODIM, C3, 2, 8>(a, s);       // default
+        case 0: return launch_v<GB, NCONV, ODIM, C3, 2, 8>(a, s);
         case 1: return launch_v<GB, NCONV, ODIM, C3, 2, 4>(a, s);
         case 2: return launch_v<GB, NCONV, ODIM, C3, 1, 8>(a, s);
         case 3: return launch_v<GB, NCONV, ODIM, C3, 1, 16>(a, s);
-        default: return PF_ERR_UNSUPPORTED;
+        default: break;
     }
+#endif
+    return PF_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-// cfg: 0 = unit 0 (C=3, g=8 padded to 16, 4 convs, odim 32; C3 table variant)
-//      1 = unit 1 (g=16, odim 64)    2 = units 2..5 (g=32, odim 128)
-// variant: tuning knob (points per wave P, waves per workgroup NW); 0 = shipped default.
+// cfg 0 / 1 / 2: the exact-fp32 kernel (v_mfma_f32_16x16x4_f32; the in-library A/B reference) on unit 0 (C=3, g=8 padded to 16,
+//                odim 32; needs `tab`), unit 1 (g=16, odim 64), units 2..5 (g=32, odim 128); UNSCALED P|Q table
+// cfg 7 / 8 / 9: the product arithmetic (split-fp16 with a natural-scale low half): units 2..5 (packing: ec4_w), unit 0
+//                (ec1n_w[0], edge table inside wfrag), unit 1 (ec1n_w[1]); SCALED P|Q table (packing.ec4_scales)
+// (cfg 3..6 were the round-1 split-bf16 / scaled split-fp16 generations: removed, see the git history)
+// variant: launch shape; pf_edgeconv() passes the shipped one.
 extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, const float* tab, const int* idx,
                                  const float* wfrag, float* out, int B, int N, void* stream) {
     if (!pq_or_xyz || !idx || !wfrag || !out) return PF_ERR_NULL;
@@ -822,38 +668,7 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
             return launch<1, 4, 32, true>(a, s, variant);
         case 1: a.pq = pq_or_xyz; return launch<1, 4, 64, false>(a, s, variant);
         case 2: a.pq = pq_or_xyz; return launch<2, 4, 128, false>(a, s, variant);
-        case 3:                                   // units 2..5, split-bf16 weights (packing: ec3_w)
-            a.pq = pq_or_xyz;
-            switch (variant) {
-                case 0: return launch3<2, 8>(a, s);
-                case 1: return launch3<1, 8>(a, s);
-                case 2: return launch3<1, 16>(a, s);
-#ifdef PF_TUNING_VARIANTS                                     // ablation builds only (tools/tune_edgeconv.py --ablate): wrong results
-                case 8: return launch3<1, 16, 1>(a, s);      // no gathers
-                case 9: return launch3<1, 16, 2>(a, s);      // no MFMAs
-#endif
-                default: return PF_ERR_UNSUPPORTED;
-            }
-        case 4:                                   // units 2..5, split-fp16 weights (packing: ec2h_w)
-            a.pq = pq_or_xyz;
-            switch (variant) {
-                case 0: return launch3<2, 8, 0, 2>(a, s);
-                case 1: return launch3<1, 8, 0, 2>(a, s);
-                case 2: return launch3<1, 16, 0, 2>(a, s);
-                case 3: return launch3<2, 4, 0, 2>(a, s);
-                case 4: return launch3<4, 4, 0, 2>(a, s);
-#ifdef PF_TUNING_VARIANTS                                     // ablation builds only: wrong results
-                case 8: return launch3<1, 16, 1, 2>(a, s);      // no gathers
-                case 9: return launch3<1, 16, 2, 2>(a, s);      // no MFMAs
-                case 10: return launch3<1, 16, 4, 2>(a, s);     // no LDS weight reads
-                case 11: return launch3<1, 16, 8, 2>(a, s);     // no max-pool
-                case 12: return launch3<1, 16, 5, 2>(a, s);     // no gathers, no LDS weight reads
-                case 13: return launch3<1, 16, 13, 2>(a, s);    // ... and no max-pool: MFMA + split only
-                case 14: return launch3<1, 16, 15, 2>(a, s);    // nothing but the split / lrelu VALU work
-#endif
-                default: return PF_ERR_UNSUPPORTED;
-            }
-        case 7:                                   // units 2..5, split-fp16 natural-scale (packing: ec4_w; needs the SCALED P|Q table)
+        case 7:
             {
                 // the kernel addresses the P|Q table with 32-bit byte offsets: whole batch items per launch, < 2 GiB of table
                 const long long maxT = 0x7fffffffll / 2048;
@@ -866,11 +681,11 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
                     c.T = nb * N;
                     int rc;
                     switch (variant) {
-                        case 0: rc = launch4<1, 16>(c, s); break;
+                        case 0: rc = launch4<1, 16>(c, s); break;          // shipped
+#ifdef PF_TUNING_VARIANTS
                         case 1: rc = launch4<2, 8>(c, s); break;
                         case 2: rc = launch4<1, 8>(c, s); break;
                         case 3: rc = launch4<2, 4>(c, s); break;
-#ifdef PF_TUNING_VARIANTS                                     // ablation builds only: wrong results
                         case 8: rc = launch4<1, 16, 1>(c, s); break;      // no gathers
                         case 9: rc = launch4<1, 16, 2>(c, s); break;      // no MFMAs
                         case 10: rc = launch4<1, 16, 4>(c, s); break;     // no LDS weight reads
@@ -885,29 +700,54 @@ extern "C" int pf_edgeconv_tuned(int cfg, int variant, const float* pq_or_xyz, c
                 }
                 return PF_OK;
             }
-        case 8:                                   // unit 0, f16n (packing: ec1n_w[0]; scaled edge table inside wfrag)
+        case 8:
             a.xyz = pq_or_xyz;
             if ((long long)B * N * 12 > 0x7fffffffll) return PF_ERR_SHAPE;
             return launch1n_v<32, true>(a, s, variant);
-        case 9:                                   // unit 1, f16n (packing: ec1n_w[1]; needs the SCALED P|Q table of post 0)
+        case 9:
             a.pq = pq_or_xyz;
             if ((long long)B * N * 1024 > 0x7fffffffll) return PF_ERR_SHAPE;      // 32-bit buffer offsets
             return launch1n_v<64, false>(a, s, variant);
-        case 5:                                   // unit 0, split-fp16 (packing: ec1h_w[0]; edge table inside wfrag)
-            a.xyz = pq_or_xyz;
-            return launch1h_v<32, true>(a, s, variant);
-        case 6:                                   // unit 1, split-fp16 (packing: ec1h_w[1])
-            a.pq = pq_or_xyz;
-            return launch1h_v<64, false>(a, s, variant);
         default: return PF_ERR_UNSUPPORTED;
     }
 }
 
 extern "C" int pf_edgeconv(int cfg, const float* pq_or_xyz, const float* tab, const int* idx, const float* wfrag,
                            float* out, int B, int N, void* stream) {
-    // shipped variants (tools/tune_edgeconv.py / tune_ec4.py / PF_EC1N_VARIANT sweeps, MI355X): f16n units 0 / 1 -> (P=2, NW=8);
-    // units 2..5 -> (1, 16): one point per wave, 16 waves share the 88 KiB of LDS-resident weights.
-    static const int best[10] = {0, 2, 3, 0, 2, 0, 2, 0, 1, 1};
-    if (cfg < 0 || cfg > 9) return PF_ERR_UNSUPPORTED;
+    // shipped launch shapes: f32 reference (2,8) / (1,8) / (1,16); f16n units 0 / 1 -> (P=2, NW=8); units 2..5 -> (1, 16): one
+    // point per wave, 16 waves share the 88 KiB of LDS-resident weights
+    static const int best[10] = {0, 2, 3, -1, -1, -1, -1, 0, 1, 1};
+    if (cfg < 0 || cfg > 9 || best[cfg] < 0) return PF_ERR_UNSUPPORTED;
     return pf_edgeconv_tuned(cfg, best[cfg], pq_or_xyz, tab, idx, wfrag, out, B, N, stream);
+}
+
+// EdgeConv unit `unit` (0..4) in the product arithmetic AND the next unit's P|Q vectors: out [B*N, odim] as pf_edgeconv (cfg 8 /
+// 9 / 7), pq_next [B*N, rows] as pf_pq_gemm(unit, out, ...) - bit-identical to that pair of calls.  Small batches run both in
+// ONE launch (the fused epilogue above: a 16-point workgroup tile is one MFMA column tile of the GEMM); larger ones as the two
+// kernels (the P|Q GEMM is HBM-write-bound there and its weights would compete with the Q gathers for L2 bandwidth).
+// w: blob base, off[13]: POST_SLOTS of unit `unit` (packing.py).
+extern "C" int pf_pq_gemm(int unit, const float* h, const float* w, const long long* off, float* pq_next, int T, void* stream);
+
+extern "C" int pf_edgeconv_pq(int unit, const float* pq_or_xyz, const int* idx, const float* wfrag, float* out, const float* w,
+                              const long long* off, float* pq_next, int B, int N, int fuse, void* stream) {
+    if (!pq_or_xyz || !idx || !wfrag || !out || !w || !off || !pq_next) return PF_ERR_NULL;
+    if (unit < 0 || unit > 4) return PF_ERR_UNSUPPORTED;
+    if (B <= 0 || N < 16 || (long long)B * N > (1ll << 30)) return PF_ERR_SHAPE;
+    const long long T = (long long)B * N;
+    // fuse: 0 = never, 1 = always (when the shape allows), -1 = by size: up to 16 384 points (8 tiles per workgroup)
+    const bool fits32 = unit == 0 ? T * 12 <= 0x7fffffffll : (unit == 1 ? T * 1024 <= 0x7fffffffll : T * 2048 <= 0x7fffffffll);
+    const bool fused = fits32 && (fuse == 1 || (fuse < 0 && T <= 16384));
+    const int cfg = unit == 0 ? 8 : (unit == 1 ? 9 : 7);
+    if (!fused) {
+        const int rc = pf_edgeconv(cfg, pq_or_xyz, nullptr, idx, wfrag, out, B, N, stream);
+        return rc != PF_OK ? rc : pf_pq_gemm(unit, out, w, off, pq_next, (int)T, stream);
+    }
+    EcArgs a{};
+    a.idx = idx; a.wg = reinterpret_cast<const f4*>(wfrag); a.out = out; a.T = (int)T; a.N = N;
+    a.pqf_w = reinterpret_cast<const u4*>(w + off[10]); a.pqf_bias = w + off[11]; a.pqf_scales = w + off[12]; a.pqf_out = pq_next;
+    hipStream_t s = (hipStream_t)stream;
+    if (unit == 0) { a.xyz = pq_or_xyz; return launch1n<32, true, 2, 8, true>(a, s); }
+    a.pq = pq_or_xyz;
+    if (unit == 1) return launch1n<64, false, 2, 8, true>(a, s);
+    return launch4<1, 16, 0, true>(a, s);
 }

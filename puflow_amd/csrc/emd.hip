@@ -15,7 +15,6 @@
 // Arithmetic follows the reference text: value = float((3.0 - (double)sqrtf(d2)) - (double)price)
 // (the literal 3.0 in cu:146 is a double), d2 unfused fp32.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include "pf_api_internal.h"
 
 namespace {
@@ -200,10 +199,11 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(EmdArgs a) {
 // barrier are gone: two barriers per iteration.  The per-object vote arrays are double-buffered by iteration parity, so an iteration's entries are
 // cleared during the NEXT iteration (by the workgroup that wrote them) instead of behind a fourth barrier.
 // Same arithmetic and tie rules as the single-workgroup kernel: identical assignment.
-// Progress: a sample's workgroups have consecutive indices and B * G <= the number of CUs, so they are co-resident when the
-// process has the GPU to itself (one process per GPU, the deployment this targets); the spin is bounded anyway - on timeout the
-// sample's distances are written as NaN and the grid drains.  Two processes sharing one GPU with full-size batches can starve
-// each other's barriers (seen in a 2-rank rehearsal on one device): use PF_EMD_SINGLE=1 there.
+// Progress: the host launches this kernel only when the device can hold all B * G workgroups at once (pf_emd_forward_ex:
+// occupancy of this kernel x CU count); the spin is bounded anyway - on timeout the sample's distances are written as NaN,
+// the status word counts the sample and the grid drains.  Two PROCESSES sharing one GPU with full-size batches can still starve
+// each other's barriers (the occupancy query knows nothing about the other process; seen in a 2-rank rehearsal on one
+// device): such callers pass groups = 1 (loss.EarthMoverDistance(groups=1)), and a starved run is reported, not silent.
 constexpr int EMDC_NMAX = 2048;
 // the barrier words are cleared by a kernel, not by hipMemsetAsync: inside a captured hipGraph a memset node was observed to
 // race with the kernel node that follows it (arrival counters cleared under the running auction -> missed barriers)
@@ -216,6 +216,7 @@ struct EmdCoopArgs {
     unsigned* mb0; unsigned* mb1; int* mi0; int* mi1;     // [B,n] each: maximum increment bits / winner index, per parity
     unsigned long long* k0; unsigned long long* k1;        // KEY64: [B,n] (increment bits << 32 | bidder) per parity, instead
     unsigned* sync;                                        // [B,n] zeroed by the host: [0] arrivals, [1],[2] unassigned count per parity
+    unsigned* status;                                      // nullable: [0] += 1 for every sample whose grid barrier timed out
     int n, iters, G;
     float eps;
 };
@@ -350,6 +351,9 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
         }
         a.dist[o0 + i] = d;
     }
+    // a timed-out barrier is REPORTED (one count per sample; the host raises at its next synchronisation point), the NaN
+    // distances above only keep a consumer from using the partial assignment silently
+    if (dead && w == 0 && tid == 0 && a.status) atomicAdd(a.status, 1u);
 }
 
 __global__ __launch_bounds__(256) void emd_grad_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -371,32 +375,49 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist, int* assignment, float* price,
-                              int* assignment_inv, int* bid, float* bid_increments, float* max_increments,
-                              int* unass_idx, int* max_idx, float eps, int iters, int B, int n, void* stream) {
+// groups: workgroups per sample of the multi-workgroup auction - 0 = choose from the device (below), 1 = the one-workgroup
+// kernel (always safe: no inter-workgroup waits), g > 1 = at most g.  status: nullable device word; the multi-workgroup
+// kernel adds 1 to it for every sample whose grid barrier timed out (such a sample's distances are NaN).
+// The multi-workgroup kernel waits on grid barriers, so ALL its B * G workgroups must be resident at once.  That is decided
+// here from what the device can hold for THIS kernel - hipOccupancyMaxActiveBlocksPerMultiprocessor (its LDS / VGPR / wave
+// footprint) x the CU count - not assumed: G is the largest power of two with B * G <= resident capacity (and at most one
+// workgroup per CU, and >= 64 points per workgroup); if not even G = 2 fits, the one-workgroup kernel runs.  A caller that
+// knows the device is shared with other processes passes groups = 1 (or a smaller cap).
+extern "C" int pf_emd_forward_ex(const float* xyz1, const float* xyz2, float* dist, int* assignment, float* price,
+                                 int* assignment_inv, int* bid, float* bid_increments, float* max_increments,
+                                 int* unass_idx, int* max_idx, float eps, int iters, int B, int n, int groups,
+                                 unsigned* status, void* stream) {
     if (!xyz1 || !xyz2 || !dist || !assignment || !price || !assignment_inv || !bid || !bid_increments ||
         !max_increments || !unass_idx || !max_idx)
         return PF_ERR_NULL;
-    if (B <= 0 || n <= 0 || iters <= 0 || n > (1 << 20)) return PF_ERR_SHAPE;
+    if (B <= 0 || n <= 0 || iters <= 0 || n > (1 << 20) || groups < 0) return PF_ERR_SHAPE;
     EmdArgs a{xyz1, xyz2, dist, assignment, assignment_inv, price, bid, bid_increments,
               reinterpret_cast<unsigned*>(max_increments), max_idx, unass_idx, n, iters, eps};
     hipStream_t s = (hipStream_t)stream;
-    // several workgroups per sample when the batch alone cannot fill the chip (all B * G of them must be co-resident)
-    int ncu = 256, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    // 64-bit vote words need two of the caller's [B,n] scratch arrays back to back (8-byte aligned): true when they are
+    // slices of one allocation, as puflow_amd.loss.emdFunction passes them; otherwise the three-barrier protocol
+    const size_t bn = (size_t)B * n;
+    const bool pair0 = bid_increments == max_increments + bn && (reinterpret_cast<size_t>(max_increments) & 7) == 0;
+    const bool pair1 = bid == max_idx + bn && (reinterpret_cast<size_t>(max_idx) & 7) == 0;
+    const bool key64 = pair0 && pair1;
     int G = 1;
-    while (G < 16 && B * (2 * G) <= ncu && n / (2 * G) >= 64) G *= 2;          // one workgroup per CU at most: co-resident
-    if (G >= 2 && n <= EMDC_NMAX && !getenv("PF_EMD_SINGLE")) {
+    if (groups != 1 && n <= EMDC_NMAX) {
+        int ncu = 0, dev = 0, per_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const hipError_t oc = key64
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, emd_coop_kernel<true>, EMD_THREADS, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, emd_coop_kernel<false>, EMD_THREADS, 0);
+        if (oc != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        const long long resident = per_cu >= 1 ? (long long)ncu : 0;        // one workgroup per CU at most: each wants a whole CU's issue slots
+        const int cap = groups > 1 ? groups : 16;
+        while (2 * G <= cap && (long long)B * (2 * G) <= resident && n / (2 * G) >= 64) G *= 2;
+    }
+    if (G >= 2) {
         hipLaunchKernelGGL(emd_zero_kernel, dim3(64), dim3(256), 0, s, reinterpret_cast<unsigned*>(unass_idx), (long long)B * n);
         EmdCoopArgs c{xyz1, xyz2, dist, assignment, assignment_inv, price, reinterpret_cast<unsigned*>(max_increments),
                       reinterpret_cast<unsigned*>(bid_increments), max_idx, bid, nullptr, nullptr,
-                      reinterpret_cast<unsigned*>(unass_idx), n, iters, G, eps};
-        // 64-bit vote words need two of the caller's [B,n] scratch arrays back to back (8-byte aligned): true when they are
-        // slices of one allocation, as puflow_amd.loss.emdFunction passes them; otherwise the three-barrier protocol
-        const size_t bn = (size_t)B * n;
-        const bool pair0 = bid_increments == max_increments + bn && (reinterpret_cast<size_t>(max_increments) & 7) == 0;
-        const bool pair1 = bid == max_idx + bn && (reinterpret_cast<size_t>(max_idx) & 7) == 0;
-        if (pair0 && pair1 && !getenv("PF_EMD_VOTE32")) {
+                      reinterpret_cast<unsigned*>(unass_idx), status, n, iters, G, eps};
+        if (key64) {
             c.k0 = reinterpret_cast<unsigned long long*>(max_increments);
             c.k1 = reinterpret_cast<unsigned long long*>(max_idx);
             // each array pair holds 2 B n 32-bit words = B n 64-bit words: sample b's keys at word offset b n
@@ -409,6 +430,14 @@ extern "C" int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist,
     else if (n <= EMD_NMAX_LDS) hipLaunchKernelGGL(emd_auction_kernel<1>, dim3(B), dim3(EMD_THREADS), 0, s, a);
     else hipLaunchKernelGGL(emd_auction_kernel<0>, dim3(B), dim3(EMD_THREADS), 0, s, a);
     return pf_last_launch_status();
+}
+
+// the reference's emd.forward argument list (emd.cpp:14-31): workgroups per sample chosen from the device, no status word
+extern "C" int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist, int* assignment, float* price,
+                              int* assignment_inv, int* bid, float* bid_increments, float* max_increments,
+                              int* unass_idx, int* max_idx, float eps, int iters, int B, int n, void* stream) {
+    return pf_emd_forward_ex(xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments, max_increments,
+                             unass_idx, max_idx, eps, iters, B, n, 0, nullptr, stream);
 }
 
 extern "C" int pf_emd_backward(const float* xyz1, const float* xyz2, float* gradxyz, const float* graddist,

@@ -52,6 +52,13 @@ struct FlowArgs {
     int R;               // replicas (1 for fwd)
     int rows;            // T*R
     int ntiles;
+    // fwd with the log-likelihood folded in (pf_flow_fwd_logp; N % 16 == 0): every wave leaves the sums of its 16 rows, the
+    // workgroup that finishes last reduces them per batch item in a fixed order
+    float* part;         // [2][rows / 16]: sum of ld_pt, sum of -0.5 (z^2 + log 2 pi) over a wave tile; nullable = no fold
+    unsigned* counter;   // arrival counter behind the partials (zero between launches)
+    float* ldj; float* lps; float* logp;      // [B], [B], [1]
+    float ld_const;
+    int B, N;
 };
 
 struct FlowCond { f4 cp[4]; f4 s0, s1; };        // one block's conditioning of one row: cp [64] (this lane's 16), s|t [8]
@@ -169,16 +176,85 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(FlowArgs a) {
             a.out[(size_t)row * 3 + 2] = v[2];
             if (!INV) a.ld_pt[row] = ld;
         }
+        if constexpr (!INV) {
+            if (a.part) {
+                // sums over the 16 rows of this wave tile (rows % 16 == 0: the tile is all valid or all padding, and it
+                // lies inside one batch item), fixed butterfly order; written with an agent-scope store (the reader sits
+                // on another XCD: its L2 is not coherent with ours)
+                float sl = ld;
+                float sz = -0.5f * (v[0] * v[0] + LOG2PI_F) + -0.5f * (v[1] * v[1] + LOG2PI_F) + -0.5f * (v[2] * v[2] + LOG2PI_F);
+                sl += __shfl_xor(sl, 1); sz += __shfl_xor(sz, 1);
+                sl += __shfl_xor(sl, 2); sz += __shfl_xor(sz, 2);
+                sl += __shfl_xor(sl, 4); sz += __shfl_xor(sz, 4);
+                sl += __shfl_xor(sl, 8); sz += __shfl_xor(sz, 8);
+                if (ok && lane == 0) {
+                    const int wt = g >> 4;
+                    __hip_atomic_store(a.part + wt, sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.part + (a.rows >> 4) + wt, sz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+    if constexpr (!INV) {
+        if (!a.part) return;
+        // ---- log-likelihood: the workgroup that arrives last reduces the wave-tile sums per batch item (probs.py:73-75,
+        // interpflow.py:339-345), a fixed order whichever workgroup that is.  No release fence (it would write the whole L2
+        // back, tens of microseconds): the partials are agent-scope stores, waiting for their acknowledgement orders them
+        // before the arrival count (the same protocol as train_fused.hip stat_flush).
+        __shared__ float sa[NW * 64], sb[NW * 64];
+        __shared__ int is_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) is_last = atomicAdd(a.counter, 1u) == gridDim.x - 1 ? 1 : 0;
+        __syncthreads();
+        if (!is_last) return;
+        const int tid = threadIdx.x, NT = NW * 64;
+        const int per = a.N >> 4, half = a.rows >> 4;
+        float tot = 0.f;
+        for (int b = 0; b < a.B; ++b) {
+            float accl = 0.f, accz = 0.f;
+            for (int i = tid; i < per; i += NT) {
+                accl += __hip_atomic_load(a.part + b * per + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                accz += __hip_atomic_load(a.part + half + b * per + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            sa[tid] = accl; sb[tid] = accz;
+            __syncthreads();
+            for (int st = NT / 2; st > 0; st >>= 1) {
+                if (tid < st) { sa[tid] += sa[tid + st]; sb[tid] += sb[tid + st]; }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                const float l = sa[0] + a.ld_const * (float)a.N;
+                a.ldj[b] = l;
+                a.lps[b] = sb[0] + l;
+                tot += sb[0] + l;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            *a.logp = -tot / (float)a.B;
+            __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        }
     }
 }
 
-template <bool INV>
-int launch(FlowArgs a, hipStream_t s) {
-    constexpr int NW = INV ? PF_FLOW_NW : PF_FLOW_NW_FWD;
+// Waves per workgroup: 16 when that still gives every CU a tile; small batches take 8 or 4, so that the (latency-bound)
+// chain of a tile runs on more CUs at once - the 126 KiB weight prologue per workgroup is the price, paid in parallel.
+template <bool INV, int NW>
+int launch_nw(FlowArgs a, hipStream_t s) {
     a.ntiles = (a.rows + NW * 16 - 1) / (NW * 16);
     const int grid = a.ntiles < 256 ? a.ntiles : 256;          // persistent: 126 KiB of LDS = one workgroup per CU
     hipLaunchKernelGGL((flow_kernel<INV, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
     return pf_last_launch_status();
+}
+
+template <bool INV>
+int launch(FlowArgs a, hipStream_t s) {
+    constexpr int NWMAX = INV ? PF_FLOW_NW : PF_FLOW_NW_FWD;
+    const int wt = (a.rows + 15) / 16;                          // wave tiles
+    if (wt >= 200 * NWMAX) return launch_nw<INV, NWMAX>(a, s);
+    if (wt >= 200 * 8) return launch_nw<INV, 8>(a, s);
+    return launch_nw<INV, 4>(a, s);
 }
 
 // one workgroup per batch item: deterministic tree sums
@@ -222,6 +298,28 @@ extern "C" int pf_flow_fwd(const float* xyz, const float* cp, const float* st, c
     if (T <= 0) return PF_ERR_SHAPE;
     FlowArgs a{};
     a.in = xyz; a.cp = cp; a.st = st; a.w = w; a.out = z; a.ld_pt = ld_pt; a.T = T; a.R = 1; a.rows = T;
+    return launch<false>(a, (hipStream_t)stream);
+}
+
+// pf_flow_fwd + pf_logp in ONE launch: z, ld_pt as pf_flow_fwd; ldj [B], lpsum [B], logp [1] as pf_logp (the sums run in a
+// different - still fixed - order than pf_logp's: equal to it within fp32 rounding, identical from run to run).
+// ws: 2 * ceil(B N / 16) floats + 1 word, ZERO before the first call (the kernel leaves the counter word zero again).
+// N % 16 != 0: the two-launch path (a wave tile would straddle batch items).
+extern "C" long long pf_flow_fwd_logp_ws_floats(int B, int N) { return 2ll * (((long long)B * N + 15) / 16) + 4; }
+
+extern "C" int pf_flow_fwd_logp(const float* xyz, const float* cp, const float* st, const float* w, float* z, float* ld_pt,
+                                float ld_const, int B, int N, float* ldj, float* lpsum, float* logp, float* ws, void* stream) {
+    if (!xyz || !cp || !st || !w || !z || !ld_pt || !ldj || !lpsum || !logp || !ws) return PF_ERR_NULL;
+    if (B <= 0 || N <= 0 || (long long)B * N > (1ll << 30)) return PF_ERR_SHAPE;
+    const int T = B * N;
+    if (N % 16 != 0) {
+        const int rc = pf_flow_fwd(xyz, cp, st, w, z, ld_pt, T, stream);
+        return rc != PF_OK ? rc : pf_logp(z, ld_pt, ld_const, B, N, ldj, lpsum, logp, stream);
+    }
+    FlowArgs a{};
+    a.in = xyz; a.cp = cp; a.st = st; a.w = w; a.out = z; a.ld_pt = ld_pt; a.T = T; a.R = 1; a.rows = T;
+    a.part = ws; a.counter = reinterpret_cast<unsigned*>(ws + 2 * (T / 16));
+    a.ldj = ldj; a.lps = lpsum; a.logp = logp; a.ld_const = ld_const; a.B = B; a.N = N;
     return launch<false>(a, (hipStream_t)stream);
 }
 

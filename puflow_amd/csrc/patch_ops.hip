@@ -482,11 +482,13 @@ __global__ __launch_bounds__(256) void fps_init_kernel(float* p, long long n, in
 
 // 1 when pf_fps runs the cooperative kernel for clouds of N points (its scratch row then holds the candidate ring):
 // stride_words = 64-bit words between the rings of consecutive clouds, abort_word = index of the abort word in a ring
-// two samples per exchange (fps_coop2_kernel) unless PF_FPS_ROUND2=0; read once: pf_fps and pf_fps_scratch_layout must agree
-static bool fps_two() {
-    static const bool two = [] { const char* e = getenv("PF_FPS_ROUND2"); return !(e && e[0] == '0'); }();
-    return two;
-}
+// two samples per exchange (fps_coop2_kernel, the shipped kernel); -DPF_FPS_ONE_SAMPLE builds the one-sample kernel instead
+// (tools/time_fps.py A/B) - a compile-time choice: pf_fps and pf_fps_scratch_layout must agree
+#ifdef PF_FPS_ONE_SAMPLE
+static constexpr bool fps_two() { return false; }
+#else
+static constexpr bool fps_two() { return true; }
+#endif
 
 extern "C" int pf_fps_scratch_layout(int N, long long* stride_words, long long* abort_word) {
     if (stride_words) *stride_words = ((long long)N / 2) & ~1ll;

@@ -96,105 +96,7 @@ __device__ __forceinline__ void pf_mm(const WS& ws, int frag0, const f4 (&in)[P]
     }
 }
 
-// ---- split-bf16 ("bf16x3") path: fp32 accuracy on the bf16 matrix pipe -------------------------
-// x = hi + mid + lo with three bf16 terms (3 x 8 mantissa bits = fp32's 24); a product keeps the six
-// largest cross terms (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; dropped terms < 2^-24 relative).
-// v_mfma_f32_16x16x32_bf16 runs 16 cycles for 16x16x32 (f32 16x16x4: 32 cycles for 16x16x4), so six of them
-// replace eight f32 MFMAs at 3/8 of the cycles.
-// K-slot <-> channel map of one 32-channel step (a PAIR of 16-channel blocks b0,b1): lane (q = l>>4) holds
-// k = 8q + j, j < 4 -> channel 16 b0 + 4q + j, j >= 4 -> channel 16 b1 + 4q + (j-4): exactly the two float4
-// accumulator registers the lane already owns, so layers still chain without moving data.
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-
-typedef unsigned int u3 __attribute__((ext_vector_type(3)));
-
-__device__ __forceinline__ unsigned pf_cvt_pk(float a, float b) {
-    bf2 t = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, t);
-}
-__device__ __forceinline__ float pf_lo16(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float pf_hi16(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-// two fp32 values -> packed (hi, mid, lo) bf16 pairs.  Everything stays an SSA value (ext vectors, no structs with
-// addressable members): an earlier struct-based version made hipcc bounce the pieces through scratch / LDS.
-__device__ __forceinline__ u3 pf_split_pair(float a, float b) {
-    const unsigned ph = pf_cvt_pk(a, b);
-    const float ra = a - pf_lo16(ph), rb = b - pf_hi16(ph);
-    const unsigned pm = pf_cvt_pk(ra, rb);
-    const float sa = ra - pf_lo16(pm), sb = rb - pf_hi16(pm);
-    return (u3){ph, pm, pf_cvt_pk(sa, sb)};
-}
-
-// B operands (hi / mid / lo) of one block pair (two 16-channel blocks b0, b1 = 8 k-slots per lane)
-struct PfPair { bf8 h, m, l; };
-__device__ __forceinline__ PfPair pf_pair(f4 b0, f4 b1) {
-    const u3 s0 = pf_split_pair(b0.x, b0.y), s1 = pf_split_pair(b0.z, b0.w);
-    const u3 s2 = pf_split_pair(b1.x, b1.y), s3 = pf_split_pair(b1.z, b1.w);
-    PfPair p;
-    p.h = __builtin_bit_cast(bf8, (u4){s0.x, s1.x, s2.x, s3.x});
-    p.m = __builtin_bit_cast(bf8, (u4){s0.y, s1.y, s2.y, s3.y});
-    p.l = __builtin_bit_cast(bf8, (u4){s0.z, s1.z, s2.z, s3.z});
-    return p;
-}
-
-__device__ __forceinline__ f4 pf_mfma_bf16(bf8 a, bf8 b, f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-
-// weights: [frag][3 splits][64 lanes] x 16 B in LDS
-struct PfW3Lds {
-    const u4* base;
-    int lane;
-    __device__ __forceinline__ bf8 load(int frag, int split) const {
-        return __builtin_bit_cast(bf8, base[(frag * 3 + split) * PF_WAVE + lane]);
-    }
-};
-
-// same image read from global memory through a buffer descriptor (small matrices that stay in L1/L2)
-struct PfW3Buf {
-    __amdgpu_buffer_rsrc_t rsrc;
-    int voff;           // lane * 16
-    __device__ __forceinline__ PfW3Buf(const void* p, int lane)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000)), voff(lane * 16) {}
-    __device__ __forceinline__ bf8 load(int frag, int split) const {
-        return __builtin_bit_cast(bf8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (frag * 3 + split) * (PF_WAVE * 16), 0));
-    }
-};
-
-// acc[p][acc0+ob] += W[ob][cp] * in[p][in0+cp]  over block PAIRS cp < CP (six bf16 MFMAs per pair, small terms first).
-// The next fragment's three weight reads are issued before the current fragment's MFMAs (double buffer).
-template <int OB, int CP, int WCP, class WS3, int P, int NIN, int NACC>
-__device__ __forceinline__ void pf_mm3(const WS3& ws, int frag0, const PfPair (&in)[P][NIN], int in0,
-                                       f4 (&acc)[P][NACC], int acc0) {
-    constexpr int NFRAG = OB * CP;
-    bf8 wb[2][3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) wb[0][s] = ws.load(frag0, s);
-#pragma unroll
-    for (int i = 0; i < NFRAG; ++i) {
-        const int ob = i / CP, cp = i % CP;
-        if (i + 1 < NFRAG) {
-            const int f = frag0 + ((i + 1) / CP) * WCP + ((i + 1) % CP);
-#pragma unroll
-            for (int s = 0; s < 3; ++s) wb[(i + 1) & 1][s] = ws.load(f, s);
-        }
-        const bf8 wh = wb[i & 1][0], wm = wb[i & 1][1], wl = wb[i & 1][2];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            f4 a = acc[p][acc0 + ob];
-            a = pf_mfma_bf16(wh, in[p][in0 + cp].l, a);
-            a = pf_mfma_bf16(wl, in[p][in0 + cp].h, a);
-            a = pf_mfma_bf16(wm, in[p][in0 + cp].m, a);
-            a = pf_mfma_bf16(wh, in[p][in0 + cp].m, a);
-            a = pf_mfma_bf16(wm, in[p][in0 + cp].h, a);
-            a = pf_mfma_bf16(wh, in[p][in0 + cp].h, a);
-            acc[p][acc0 + ob] = a;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 // ---- split-fp16 ("f16x2") path: fp32 accuracy in THREE fp16 MFMAs per 32-channel step ---------------
 // x = hi + lo' * 2^-11 with hi = rne_f16(x) and lo' = rne_f16((x - hi) * 2^11): x - hi is exact in fp32 and at most
@@ -203,7 +105,7 @@ __device__ __forceinline__ void pf_mm3(const WS3& ws, int frag0, const PfPair (&
 // hi.hi in the main accumulator and hi.lo' + lo'.hi in a second one that is folded in as  acc + accx * 2^-11;
 // the dropped lo.lo term is < 2^-24 relative.  gfx950's fp16 MFMA honours subnormal operands (probed), so tiny
 // values degrade gracefully.  Range: |x| must stay below 65504 (fp16 max) - activations of this network are O(1..100);
-// beyond it the result is inf/NaN (loud), and PF_EC_MODE=bf16x3 / f32 remain available.
+// beyond it the result is inf/NaN (loud).  Used by csrc/cnf.hip; the eval kernels of the discrete path moved to the natural-scale variant below.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));

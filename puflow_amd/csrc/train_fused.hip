@@ -766,8 +766,6 @@ void allow_lds(KERNEL k, size_t bytes) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
-
 struct Dims {
     int T, GT, S, nconvs;
     long long E;
@@ -792,7 +790,7 @@ int ec_dims(const PfEcTrain* p, Dims& d) {
     d.grid = (d.ntiles + 3) / 4 < EC_GRID ? (d.ntiles + 3) / 4 : EC_GRID;
     // growth-layer kernels: measured (layer with 96 input channels, 131 072 edges) 44 / 30 / 29 / 41 us at 128 / 256 / 512 / 2048
     // workgroups: beyond 2 per CU the fixed cost per workgroup (weight staging, 64 statistics atomics) outweighs the latency hiding
-    { const int gl = env_int("PF_EC_GRID_LIGHT", 512); d.grid_light = (d.ntiles + 3) / 4 < gl ? (d.ntiles + 3) / 4 : gl; }
+    d.grid_light = d.grid;
     d.nchunk = (int)((d.E + EC_DW_CHUNK - 1) / EC_DW_CHUNK);
     return PF_OK;
 }

@@ -490,12 +490,38 @@ __global__ __launch_bounds__(256) void colstat_final_kernel(const float* __restr
     }
 }
 
+// BatchNorm backward: the two column sums once, written unscaled to (dbeta, dgamma) and scaled by 1/R to sums[2][C] - one
+// launch, no device-to-device copy nodes (a copy node that reads `sums` right before a kernel node that overwrites it is a
+// write-after-read across a memcpy -> kernel edge of a captured graph; the per-op path is captured whenever it is taken)
+__global__ __launch_bounds__(256) void colstat_final_bwd_kernel(const float* __restrict__ partial, int nchunk, int C, float inv_r,
+                                                               float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                               float* __restrict__ sums) {
+    __shared__ float sh[4][64];
+    const int l = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
+    for (int w = 0; w < 2; ++w) {
+        float s = 0.f;
+        if (c < C)
+            for (int k = part; k < nchunk; k += 4) s += partial[((long long)k * 2 + w) * C + c];
+        sh[part][l] = s;
+        __syncthreads();
+        if (part == 0 && c < C) {
+            const float t = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+            (w == 0 ? dbeta : dgamma)[c] = t * 1.0f;
+            sums[w * C + c] = t * inv_r;
+        }
+        __syncthreads();
+    }
+}
+
+// save[0..C) = mean (copied by the kernel: no copy node), save[C..2C) = 1/sqrt(var_b + eps); running statistics (nullable)
 __global__ void bn_finish_kernel(const float* __restrict__ var_b, int C, float eps, float momentum, float unbias,
                                  const float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
-                                 float* __restrict__ run_var) {
+                                 float* __restrict__ run_var, float* __restrict__ mean_out) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
     invstd[c] = 1.0f / sqrtf(var_b[c] + eps);
+    if (mean_out && mean_out != mean) mean_out[c] = mean[c];
     if (run_mean) {
         run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[c];
         run_var[c] = (1.f - momentum) * run_var[c] + momentum * (var_b[c] * unbias);
@@ -772,7 +798,7 @@ extern "C" int pf_bn_lrelu_fwd(const float* x, long long R, int C, const float* 
     colstat_launch<1>(x, nullptr, save, nullptr, nullptr, nullptr, 0.f, R, C, nchunk, rows_per, partial, s);
     hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(256), 0, s, partial, nchunk, C, 1, 1.0f / (float)R, var_b);
     hipLaunchKernelGGL(bn_finish_kernel, gc, dim3(64), 0, s, var_b, C, eps, momentum, (float)R / (float)(R - 1), save, save + C,
-                       run_mean, run_var);
+                       run_mean, run_var, (float*)nullptr);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, save, save + C, gamma, beta, slope, R * C, C, y);
     return pf_last_launch_status();
 }
@@ -790,10 +816,7 @@ extern "C" int pf_bn_lrelu_bwd(const float* x, const float* dy, long long R, int
     float* sums = ws + (long long)2 * nchunk * C;          // [2][C]: sum dz, sum dz*xhat
     dim3 gc((C + 63) / 64);
     colstat_launch<2>(x, dy, save, save + C, gamma, beta, slope, R, C, nchunk, rows_per, partial, s);
-    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(256), 0, s, partial, nchunk, C, 2, 1.0f, sums);
-    (void)hipMemcpyAsync(dbeta, sums, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
-    (void)hipMemcpyAsync(dgamma, sums + C, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
-    hipLaunchKernelGGL(colstat_final_kernel, gc, dim3(256), 0, s, partial, nchunk, C, 2, 1.0f / (float)R, sums);
+    hipLaunchKernelGGL(colstat_final_bwd_kernel, gc, dim3(256), 0, s, partial, nchunk, C, 1.0f / (float)R, dbeta, dgamma, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, dy, save, save + C, gamma, beta, sums, slope,
                        R * C, C, dx);
     return pf_last_launch_status();
@@ -822,9 +845,8 @@ extern "C" int pf_bn_apply_stats(const float* x, long long R, int C, const float
     if (!x || !mean || !var_b || !gamma || !beta || !y || !save) return PF_ERR_NULL;
     if (R <= 0 || C <= 0) return PF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemcpyAsync(save, mean, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, var_b, C, eps, momentum, unbias, save, save + C,
-                       run_mean, run_var);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, var_b, C, eps, momentum, unbias, mean, save + C,
+                       run_mean, run_var, save);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(R * C)), dim3(256), 0, s, x, save, save + C, gamma, beta, slope, R * C, C, y);
     return pf_last_launch_status();
 }

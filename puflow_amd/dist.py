@@ -108,12 +108,29 @@ class FlatGradBucket:
             self.flat.div_(dist.get_world_size())
 
 
+def _broadcast_tensors(tensors, src: int) -> None:
+    """One broadcast per dtype (the tensors of a dtype packed into a flat buffer) instead of one per tensor; the values are
+    written back with in-place copies under no_grad, which bump the tensors' version counters - a packed eval plan keyed on
+    them (interpflow._signature) therefore sees the new values (writes through `.data` would not)."""
+    groups = {}
+    for t in tensors:
+        groups.setdefault((t.dtype, t.device), []).append(t)
+    with torch.no_grad():
+        for ts in groups.values():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src)
+            pos = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[pos:pos + n].view_as(t))
+                pos += n
+
+
 def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
     """Same weights / buffers on every rank (e.g. after ActNorm's data-dependent init on rank 0)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    _broadcast_tensors(list(module.parameters()) + list(module.buffers()), src)
 
 
 def broadcast_buffers(module: torch.nn.Module, src: int = 0) -> None:
@@ -122,8 +139,7 @@ def broadcast_buffers(module: torch.nn.Module, src: int = 0) -> None:
     authoritative before anything reads them in eval mode (validation, checkpoints)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    for t in module.buffers():
-        dist.broadcast(t.data, src=src)
+    _broadcast_tensors(list(module.buffers()), src)
 
 
 def max_over_ranks(value: float, device) -> float:

@@ -26,8 +26,6 @@ from .packing import COND_CHANNELS, FEAT_CHANNELS, GROWTH, NUM_BLOCKS, fold_stat
 
 _EC_CFG = [0, 1, 2, 2, 2, 2]
 _CHECK_FINITE = os.environ.get("PF_CHECK_FINITE", "0") == "1"      # debug aid: verify every eval forward is finite (syncs)
-_EC_SPLIT = {"bf16x3": (3, "ec3_w"), "f16x2": (4, "ec2h_w"), "f16n": (7, "ec4_w")}   # PF_EC_MODE -> (pf_edgeconv cfg, weight image)
-_EC_VARIANT = {"bf16x3": "0", "f16x2": "2", "f16n": "0"}        # shipped launch shapes (tools/tune_edgeconv.py)
 
 
 # ----------------------------------------------------------------------------------------
@@ -152,51 +150,38 @@ class _Engine:
         sd = _host_state_dict(sd)
         self.lib = _lib.load()
         self.device = device
-        # EdgeConv arithmetic of the 128-channel units (PF_EC_MODE), all within the same 1e-5 parity bar:
-        #   "f16n" (default)   split-fp16 with a natural-scale low half, one accumulator, conv_out with swapped operands
-        #                      (edgeconv4_kernel); needs |4^t x_t| < 65504 for growth layer t (|activation| < 1023)
-        #   "f16x2"            split-fp16 with a 2^11-scaled low half and a cross accumulator (edgeconv3_kernel<NS=2>)
-        #   "bf16x3"           3-term split-bf16 products, six bf16 MFMAs per step, fp32 exponent range
-        #   "f32"              v_mfma_f32_16x16x4_f32, bit-exact fp32 fma chain
-        # Out-of-range activations give inf/NaN, never a silently wrong number (PF_CHECK_FINITE=1 turns it into an error).
-        self.ec_mode = ec_mode or os.environ.get("PF_EC_MODE", "f16n")
-        if self.ec_mode not in ("f16n", "f16x2", "bf16x3", "f32"):
+        # EdgeConv arithmetic (PointInterpFlow.ec_mode), both within the same 1e-5 parity bar:
+        #   "f16n" (default, the product)  split-fp16 with a natural-scale low half, one accumulator, conv_out with swapped
+        #                      operands (edgeconv4_kernel / edgeconv1n_kernel); needs |4^t x_t| < 65504 for growth layer t
+        #                      (|activation| < 1023); out-of-range activations give inf/NaN, never a silently wrong number
+        #   "f32"              v_mfma_f32_16x16x4_f32, bit-exact fp32 fma chain: the in-library A/B reference of the tests
+        self.ec_mode = ec_mode or "f16n"
+        if self.ec_mode not in ("f16n", "f32"):
             raise ValueError(f"unknown EdgeConv arithmetic mode {self.ec_mode!r}")
         pk = pack_plan(fold_state_dict(sd), self.ec_mode)
         self.blob = torch.from_numpy(pk["blob"]).to(device)
         self.base = self.blob.data_ptr()
         self.ec_tab0 = pk["ec_tab0"]
         self.ec_w = pk["ec_w"]
-        self.ec3_w = pk["ec3_w"]
-        self.ec2h_w = pk["ec2h_w"]
-        self.ec1h_w = pk["ec1h_w"]
         self.ec4_w = pk["ec4_w"]
         self.ec1n_w = pk["ec1n_w"]
-        self.ec1_variant = [int(v) for v in os.environ.get("PF_EC1N_VARIANT", "1,1").split(",")]    # launch shapes of units 0, 1
-        # launch shape of the split kernels (tuning knob; tools/tune_edgeconv.py)
-        self.ec3_variant = int(os.environ.get("PF_EC3_VARIANT", _EC_VARIANT.get(self.ec_mode, "0")))
         self.post = [_lib.offsets(o) for o in pk["post"]]
         self.post_all = _lib.offsets([v for o in pk["post"] for v in o])
         self.flow = pk["flow"]
         self.interp_off = _lib.offsets(pk["interp"])
         self.ld_const = pk["ld_const"]
+        self._logp_ws = {}
+        self.fuse_pq = -1          # pf_edgeconv_pq: -1 = fuse the P|Q GEMM into the EdgeConv launch for small batches, 0 never, 1 always
 
     def _p(self, off: int) -> int:
         return self.base + 4 * off
 
     def _edgeconv(self, u: int, src: int, idx16: Tensor, h: Tensor, B: int, N: int, s) -> None:
-        """Fused EdgeConv unit u -> h [T, odim] in the arithmetic PF_EC_MODE selects (pf_edgeconv cfg table:
-        include/puflow_hip.h)."""
+        """Fused EdgeConv unit u -> h [T, odim] in the engine's arithmetic (pf_edgeconv cfg table: include/puflow_hip.h)."""
         lib = self.lib
-        if self.ec_mode == "f16n" and u < 2:                # narrow units on the natural-scale split (scaled P|Q table)
-            rc = lib.pf_edgeconv_tuned(8 + u, self.ec1_variant[u], src, None, idx16.data_ptr(), self._p(self.ec1n_w[u]),
-                                       h.data_ptr(), B, N, s)
-        elif self.ec_mode == "f16x2" and u < 2:             # narrow units, edge table of unit 0 rides in the image
-            rc = lib.pf_edgeconv(5 + u, src, None, idx16.data_ptr(), self._p(self.ec1h_w[u]), h.data_ptr(), B, N, s)
-        elif u >= 2 and self.ec_mode in _EC_SPLIT:
-            cfg, wname = _EC_SPLIT[self.ec_mode]
-            rc = lib.pf_edgeconv_tuned(cfg, self.ec3_variant, src, None, idx16.data_ptr(),
-                                       self._p(getattr(self, wname)[u]), h.data_ptr(), B, N, s)
+        if self.ec_mode == "f16n":
+            w = self.ec1n_w[u] if u < 2 else self.ec4_w[u]
+            rc = lib.pf_edgeconv(8 + u if u < 2 else 7, src, None, idx16.data_ptr(), self._p(w), h.data_ptr(), B, N, s)
         else:
             tab = self._p(self.ec_tab0) if u == 0 else None
             rc = lib.pf_edgeconv(_EC_CFG[u], src, tab, idx16.data_ptr(), self._p(self.ec_w[u]), h.data_ptr(), B, N, s)
@@ -222,12 +207,23 @@ class _Engine:
         st = torch.empty((NUM_BLOCKS, T, 8), dtype=torch.float32, device=dev)
         pq = torch.empty((T, 512), dtype=torch.float32, device=dev)
         hs: List[Tensor] = []
+        # units read their P|Q table while the next one's is written: two tables, alternating (the fused kernel reads and writes
+        # tables in the same launch; the two-kernel path would get by with one)
+        pq2 = torch.empty((T, 512), dtype=torch.float32, device=dev)
         for u in range(NUM_BLOCKS):
             h = torch.empty((T, FEAT_CHANNELS[u + 1]), dtype=torch.float32, device=dev)
-            src = xyz.data_ptr() if u == 0 else pq.data_ptr()
-            self._edgeconv(u, src, idx16, h, B, N, s)
-            if u + 1 < NUM_BLOCKS:
-                _lib.check(self.lib.pf_pq_gemm(u, h.data_ptr(), self.base, self.post[u], pq.data_ptr(), T, s), f"pf_pq_gemm[{u}]")
+            src = xyz.data_ptr() if u == 0 else (pq if u % 2 else pq2).data_ptr()
+            nxt = pq2 if u % 2 else pq
+            if u + 1 == NUM_BLOCKS:
+                self._edgeconv(u, src, idx16, h, B, N, s)
+            elif self.ec_mode == "f16n":
+                # EdgeConv u + the next unit's P|Q vectors: one launch for small batches, two kernels otherwise (pf_edgeconv_pq)
+                w = self.ec1n_w[u] if u < 2 else self.ec4_w[u]
+                _lib.check(self.lib.pf_edgeconv_pq(u, src, idx16.data_ptr(), self._p(w), h.data_ptr(), self.base, self.post[u],
+                                                   nxt.data_ptr(), B, N, self.fuse_pq, s), f"pf_edgeconv_pq[{u}]")
+            else:
+                self._edgeconv(u, src, idx16, h, B, N, s)
+                _lib.check(self.lib.pf_pq_gemm(u, h.data_ptr(), self.base, self.post[u], nxt.data_ptr(), T, s), f"pf_pq_gemm[{u}]")
             hs.append(h)
         cs: List[Optional[Tensor]] = [torch.empty((B, N, COND_CHANNELS[u]), dtype=torch.float32, device=dev) if want_cs else None
                                       for u in range(NUM_BLOCKS)]
@@ -242,18 +238,27 @@ class _Engine:
         c_arr = PtrArr(*[c.data_ptr() for c in cs]) if cs is not None else None
         _lib.check(self.lib.pf_cond_all(h_arr, self.base, self.post_all, c_arr, st.data_ptr(), cp.data_ptr(), T, s), "pf_cond_all")
 
-    def flow_f(self, xyz: Tensor, cp: Tensor, st: Tensor):
+    def logp_ws(self, B: int, N: int, dev) -> Tensor:
+        """A zeroed workspace of pf_flow_fwd_logp (wave-tile sums + the arrival counter the kernel leaves at zero)."""
+        return torch.zeros((int(self.lib.pf_flow_fwd_logp_ws_floats(B, N)),), dtype=torch.float32, device=dev)
+
+    def flow_f(self, xyz: Tensor, cp: Tensor, st: Tensor, ws: Optional[Tensor] = None):
         B, N, _ = xyz.shape
         T, dev, s = B * N, xyz.device, self._stream()
         z = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
         ld_pt = torch.empty((T,), dtype=torch.float32, device=dev)
-        _lib.check(self.lib.pf_flow_fwd(xyz.data_ptr(), cp.data_ptr(), st.data_ptr(), self._p(self.flow),
-                                        z.data_ptr(), ld_pt.data_ptr(), T, s), "pf_flow_fwd")
         ldj = torch.empty((B,), dtype=torch.float32, device=dev)
         lps = torch.empty((B,), dtype=torch.float32, device=dev)
         logp = torch.empty((), dtype=torch.float32, device=dev)
-        _lib.check(self.lib.pf_logp(z.data_ptr(), ld_pt.data_ptr(), self.ld_const, B, N, ldj.data_ptr(),
-                                    lps.data_ptr(), logp.data_ptr(), s), "pf_logp")
+        # flow f and the log-likelihood in one launch
+        if ws is None:                                      # eager calls: one per shape and stream (a captured graph brings its own)
+            key = (B, N, s)
+            ws = self._logp_ws.get(key)
+            if ws is None:
+                ws = self._logp_ws[key] = self.logp_ws(B, N, dev)
+        _lib.check(self.lib.pf_flow_fwd_logp(xyz.data_ptr(), cp.data_ptr(), st.data_ptr(), self._p(self.flow), z.data_ptr(),
+                                             ld_pt.data_ptr(), self.ld_const, B, N, ldj.data_ptr(), lps.data_ptr(), logp.data_ptr(),
+                                             ws.data_ptr(), s), "pf_flow_fwd_logp")
         return z, ldj, logp
 
     def interp(self, xyz: Tensor, z: Tensor, idx16: Tensor, R: int) -> Tensor:
@@ -293,12 +298,20 @@ class _Engine:
             st = torch.empty((NUM_BLOCKS, T, 8), dtype=torch.float32, device=dev)
             pq = torch.empty((T, 512), dtype=torch.float32, device=dev)
             hs = []
+            pq2 = torch.empty((T, 512), dtype=torch.float32, device=dev)
+            fused = self.ec_mode == "f16n" and (self.fuse_pq == 1 or (self.fuse_pq < 0 and T <= 16384))
             for u in range(NUM_BLOCKS):
                 h = torch.empty((T, FEAT_CHANNELS[u + 1]), dtype=torch.float32, device=dev)
-                src = xyz.data_ptr() if u == 0 else pq.data_ptr()
-                timed(f"edgeconv{u}", lambda: self._edgeconv(u, src, idx16, h, B, N, s))
-                if u + 1 < NUM_BLOCKS:
-                    timed(f"pq{u}", lambda: _lib.check(self.lib.pf_pq_gemm(u, h.data_ptr(), self.base, self.post[u], pq.data_ptr(), T, s)))
+                src = xyz.data_ptr() if u == 0 else (pq if u % 2 else pq2).data_ptr()
+                nxt = pq2 if u % 2 else pq
+                if fused and u + 1 < NUM_BLOCKS:
+                    w = self.ec1n_w[u] if u < 2 else self.ec4_w[u]
+                    timed(f"edgeconv{u}+pq", lambda: _lib.check(self.lib.pf_edgeconv_pq(
+                        u, src, idx16.data_ptr(), self._p(w), h.data_ptr(), self.base, self.post[u], nxt.data_ptr(), B, N, 1, s)))
+                else:
+                    timed(f"edgeconv{u}", lambda: self._edgeconv(u, src, idx16, h, B, N, s))
+                    if u + 1 < NUM_BLOCKS:
+                        timed(f"pq{u}", lambda: _lib.check(self.lib.pf_pq_gemm(u, h.data_ptr(), self.base, self.post[u], nxt.data_ptr(), T, s)))
                 hs.append(h)
             timed("cond_all", lambda: self._cond_all(hs, None, st, cp, T, s))
             z, _, _ = timed("flow_f+logp", lambda: self.flow_f(xyz, cp, st))
@@ -326,15 +339,17 @@ class PointInterpFlow(nn.Module):
         self.flow_blocks = nn.ModuleList(
             [_FlowBlockParams(pc_channel, 64, COND_CHANNELS[i], i % 2 == 0) for i in range(NUM_BLOCKS)])
         self._engine_cache: Optional[_Engine] = None
-        self.ec_mode: Optional[str] = None       # EdgeConv arithmetic of the 128-channel units; None = $PF_EC_MODE or "f16n"
+        self.sync_batchnorm = False              # train-mode forward: BatchNorm statistics over all ranks (an argument, not a global)
+        self.ec_mode: Optional[str] = None       # EdgeConv arithmetic: None / "f16n" = the product, "f32" = the exact A/B reference kernel
 
     # ---- plan cache ---------------------------------------------------------------------
-    # The packed plan is a function of the parameters / buffers.  It is dropped by load_state_dict(), .to() / _apply();
-    # entering train() mode only marks it as possibly stale: the next eval-mode use compares the tensors' version
-    # counters (every in-place update, e.g. an optimizer step or a BatchNorm running-stat update, bumps them) and
-    # re-packs only when something changed - so eval() / train() toggles around validation batches cost nothing.
+    # The packed plan is a function of the parameters / buffers.  It is dropped by load_state_dict(), .to() / _apply(); every
+    # use compares the tensors' addresses and version counters (every in-place update, e.g. an optimizer step or a BatchNorm
+    # running-stat update, bumps them) and re-packs only when something changed - so eval() / train() toggles around
+    # validation batches cost nothing.
     def invalidate_plan(self) -> None:
         self._engine_cache = None
+        self._sig_tensors = None
         self._plan_gen = getattr(self, "_plan_gen", 0) + 1
 
     def load_state_dict(self, *a, **kw):
@@ -345,30 +360,30 @@ class PointInterpFlow(nn.Module):
         self.invalidate_plan()
         return super()._apply(fn, *a, **kw)
 
-    def train(self, mode: bool = True):
-        if mode:
-            self._maybe_stale = True
-        return super().train(mode)
-
     def _signature(self):
-        """What the packed eval plan was built from: address and version counter of every parameter / buffer.  Writers that
-        go around torch's version counters must bump them (torch._C._increment_version): the fused optimizer
-        (optim.FusedClipAdam.step_flat) and a replayed training graph (train_graph.GraphedTrainStep.__call__) do; a
-        train-mode forward, whose fused kernels update the BatchNorm running statistics through raw pointers, counts itself
-        in `_train_forwards`."""
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers())) + \
-            (getattr(self, "_train_forwards", 0),)
+        """What the packed eval plan was built from: the version counter of every parameter / buffer (and their addresses,
+        taken when the tensor list is (re)built: _apply() / load_state_dict() drop it).  Compared on EVERY use of the plan -
+        ~400 attribute reads, tens of microseconds - so in-place edits are seen in eval mode too.  Writers that go around
+        torch's version counters must bump them (torch._C._increment_version): the fused optimizer
+        (optim.FusedClipAdam.step_flat) and a replayed training graph (train_graph.GraphedTrainStep.__call__) do,
+        dist.broadcast_* write with in-place copies; a train-mode forward, whose fused kernels update the BatchNorm running
+        statistics through raw pointers, counts itself in `_train_forwards`.  (A write through `.data` is invisible to any
+        such check: use `with torch.no_grad(): p.copy_(...)`.)"""
+        ts = getattr(self, "_sig_tensors", None)
+        if ts is None:
+            ts = self._sig_tensors = list(self.parameters()) + list(self.buffers())
+            self._sig_addr = tuple(t.data_ptr() for t in ts)
+        return (self._sig_addr, tuple([t._version for t in ts]), getattr(self, "_train_forwards", 0))
 
     def _engine(self, upratio: int = 4) -> _Engine:
         """The packed plan (it does not depend on the upsampling ratio; the argument is kept for callers of round 1)."""
         e = self._engine_cache
         dev = self.flow_blocks[0].actnorm.logs.device
-        if e is not None and getattr(self, "_maybe_stale", False):
-            if self._signature() != e.signature:
-                self.invalidate_plan()
-                e = None
-            elif not self.training:
-                self._maybe_stale = False
+        # always compared (a ~400-tuple, cheap against a forward): in-place edits in eval mode, or writes through `.data`
+        # that a caller followed with torch._C._increment_version, are seen at the next use
+        if e is not None and self._signature() != e.signature:
+            self.invalidate_plan()
+            e = None
         if e is not None and (e.device != dev or (self.ec_mode is not None and e.ec_mode != self.ec_mode)):
             self.invalidate_plan()
             e = None
@@ -378,7 +393,6 @@ class PointInterpFlow(nn.Module):
             e = _Engine(self.state_dict(), dev, self.ec_mode)
             e.signature = self._signature()
             self._engine_cache = e
-            self._maybe_stale = self.training
         return e
 
     def _check_mode(self):
@@ -439,13 +453,13 @@ class PointInterpFlow(nn.Module):
         with torch.no_grad():
             return self._forward_eval(xyz, upratio)
 
-    def _forward_eval(self, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
+    def _forward_eval(self, xyz: Tensor, upratio: int, ws: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         self._check_mode()
         xyz = self._prep(xyz)
         e = self._engine(upratio)
         idx16 = e.knn(xyz)
         _, cp, st = e.features(xyz, idx16, want_cs=False)
-        z, _, logp = e.flow_f(xyz, cp, st)
+        z, _, logp = e.flow_f(xyz, cp, st, ws)
         u = e.interp(xyz, z, idx16, upratio)
         x = e.flow_g(u, cp, st, upratio)
         if _CHECK_FINITE and not bool(torch.isfinite(x).all() & torch.isfinite(logp)):
@@ -490,11 +504,12 @@ class PointInterpFlow(nn.Module):
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                      # warm-up outside capture: library load, plan packing
             self._forward_eval(static_in, upratio)
+            ws = self._engine(upratio).logp_ws(B, N, dev)  # this graph's own log-likelihood workspace (graphs may replay concurrently)
         torch.cuda.current_stream(dev).wait_stream(side)
         engine = self._engine(upratio)                     # pinned: the graph reads this engine's blob
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            out_x, out_logp = self._forward_eval(static_in, upratio)
+            out_x, out_logp = self._forward_eval(static_in, upratio, ws)
         if self._engine_cache is not engine:
             raise _lib.PuflowHipError("the plan was re-packed during capture")
 
@@ -508,6 +523,7 @@ class PointInterpFlow(nn.Module):
             graph.replay()
             return out_x, out_logp
 
-        run.graph = graph                                    # keep the capture and its plan alive with the callable
+        run.graph = graph                                    # keep the capture, its plan and its workspace alive with the callable
         run.engine = engine
+        run.ws = ws
         return run

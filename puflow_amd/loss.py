@@ -10,11 +10,37 @@ from torch.autograd import Function
 from . import _lib, ops
 
 
+_EMD_STATUS = {}          # device -> int32[2] word the multi-workgroup auction counts timed-out samples in
+
+
+def _emd_status(dev: torch.device) -> Tensor:
+    t = _EMD_STATUS.get(dev)
+    if t is None:
+        t = _EMD_STATUS[dev] = torch.zeros(2, dtype=torch.int32, device=dev)
+    return t
+
+
+def check_emd_status(device=None) -> None:
+    """Raise if a multi-workgroup EMD auction timed out on a grid barrier since the last check (its workgroups were not
+    co-resident, e.g. another process on the same GPU held the CUs): the affected samples' distances are NaN.  Reads one
+    device word (a synchronisation): called where the host synchronises anyway - never inside a graph capture."""
+    for dev, t in list(_EMD_STATUS.items()):
+        if device is not None and torch.device(device) != dev:
+            continue
+        n = int(t[0].item())
+        if n:
+            t.zero_()
+            raise _lib.PuflowHipError(f"pf_emd_forward: {n} sample(s) of a multi-workgroup auction timed out on a grid barrier "
+                                      "(workgroups not co-resident - is the GPU shared with another process?); their "
+                                      "distances are NaN.  Use EarthMoverDistance(groups=1) on a shared device")
+
+
 class emdFunction(Function):
-    """metric/emd/emd_module.py:31-72.  Unlike the reference there is no n % 1024 / B <= 512 limit."""
+    """metric/emd/emd_module.py:31-72.  Unlike the reference there is no n % 1024 / B <= 512 limit.
+    groups: workgroups per sample (0 = chosen from the device's occupancy for the kernel, 1 = one workgroup per sample)."""
 
     @staticmethod
-    def forward(ctx, xyz1, xyz2, eps, iters):
+    def forward(ctx, xyz1, xyz2, eps, iters, groups=0):
         lib = _lib.load()
         B, n, _ = xyz1.size()
         assert n == xyz2.size(1) and B == xyz2.size(0)
@@ -30,10 +56,11 @@ class emdFunction(Function):
         scratch = torch.empty((5, B, n), device=dev, dtype=torch.int32)
         max_inc, bid_inc, max_idx, bid, unass_idx = scratch[0], scratch[1], scratch[2], scratch[3], scratch[4]
         dist = torch.empty(B, n, device=dev)
-        _lib.check(lib.pf_emd_forward(xyz1.data_ptr(), xyz2.data_ptr(), dist.data_ptr(), assignment.data_ptr(),
-                                      price.data_ptr(), assignment_inv.data_ptr(), bid.data_ptr(), bid_inc.data_ptr(),
-                                      max_inc.data_ptr(), unass_idx.data_ptr(), max_idx.data_ptr(), float(eps),
-                                      int(iters), B, n, ops._stream()), "pf_emd_forward")
+        _lib.check(lib.pf_emd_forward_ex(xyz1.data_ptr(), xyz2.data_ptr(), dist.data_ptr(), assignment.data_ptr(),
+                                         price.data_ptr(), assignment_inv.data_ptr(), bid.data_ptr(), bid_inc.data_ptr(),
+                                         max_inc.data_ptr(), unass_idx.data_ptr(), max_idx.data_ptr(), float(eps),
+                                         int(iters), B, n, int(groups), _emd_status(dev).data_ptr(), ops._stream()),
+                   "pf_emd_forward")
         ctx.save_for_backward(xyz1, xyz2, assignment)
         ctx.mark_non_differentiable(assignment)
         return dist, assignment
@@ -47,24 +74,29 @@ class emdFunction(Function):
         g1 = torch.zeros_like(xyz1)
         _lib.check(lib.pf_emd_backward(xyz1.data_ptr(), xyz2.data_ptr(), g1.data_ptr(), graddist.data_ptr(),
                                        assignment.data_ptr(), B, n, ops._stream()), "pf_emd_backward")
-        return g1, torch.zeros_like(xyz2), None, None
+        return g1, torch.zeros_like(xyz2), None, None, None
 
 
 class emdModule(nn.Module):
     def forward(self, input1, input2, eps, iters):
         return emdFunction.apply(input1, input2, eps, iters)
 
+    check_status = staticmethod(check_emd_status)
+
 
 class EarthMoverDistance(nn.Module):
     """metric/loss.py:18-29."""
 
-    def __init__(self, eps=0.005, iters=50):
+    def __init__(self, eps=0.005, iters=50, groups=0):
         super().__init__()
         self.eps = eps
         self.iters = iters
+        self.groups = groups        # workgroups per sample of the auction: 0 = from the device, 1 = shared-device safe
+
+    check_status = staticmethod(check_emd_status)
 
     def forward(self, preds, gts, **kwargs):
-        loss, _ = emdFunction.apply(preds, gts, self.eps, self.iters)
+        loss, _ = emdFunction.apply(preds, gts, self.eps, self.iters, self.groups)
         if kwargs.get("radius") is not None:
             loss = loss / kwargs.get("radius").view(-1, 1)
         return torch.sum(loss)

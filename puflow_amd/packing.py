@@ -181,51 +181,20 @@ def frag_pack(W: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(f.transpose(0, 2, 3, 1, 4)).reshape(OB, CB, 64, 4)
 
 
-def _bf16_round(x: np.ndarray) -> np.ndarray:
-    """fp32 -> nearest-even bf16, returned as fp32 (exactly representable)."""
-    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
-    return r.astype(np.uint32).view(np.float32)
-
-
-def frag_pack_bf16x3(W: np.ndarray) -> np.ndarray:
-    """[OUT, IN] fp32 -> split-bf16 A-operand fragments of v_mfma_f32_16x16x32_bf16, as a float32-typed byte
-    image [OB][CP][3 splits hi/mid/lo][64 lanes][8 bf16] (csrc/pf_mfma.h 'split-bf16 path').
-    Lane l (row = l & 15, q = l >> 4), element j of block pair cp: channel 32 cp + 4q + j (j < 4) or
-    32 cp + 16 + 4q + (j - 4) (j >= 4)."""
-    out, inn = W.shape
-    OB, CP = (out + 15) // 16, (inn + 31) // 32
-    Wp = np.zeros((OB * 16, CP * 32), dtype=np.float32)
-    Wp[:out, :inn] = W
-    hi = _bf16_round(Wp)
-    r1 = (Wp - hi).astype(np.float32)
-    mid = _bf16_round(r1)
-    lo = _bf16_round((r1 - mid).astype(np.float32))
-    lanes = np.arange(64)
-    row, q = lanes & 15, lanes >> 4
-    j = np.arange(8)
-    ch = np.where(j[None, :] < 4, 4 * q[:, None] + j[None, :], 16 + 4 * q[:, None] + (j[None, :] - 4))     # [64,8]
-    res = np.zeros((OB, CP, 3, 64, 8), dtype=np.uint16)
-    for si, part in enumerate((hi, mid, lo)):
-        bits = (part.view(np.uint32) >> 16).astype(np.uint16).reshape(OB, 16, CP, 32)
-        # lane = 16 q + row holds k = 16 h + 4 q + jj at slot j = 4 h + jj: a pure axis permutation of [OB,row,CP,h,q,jj]
-        res[:, :, si] = bits.reshape(OB, 16, CP, 2, 4, 4).transpose(0, 2, 4, 1, 3, 5).reshape(OB, CP, 64, 8)
-    return res.reshape(-1).view(np.float32)
-
-
 F16_LO_SCALE = 2048.0
 
 
 def frag_pack_f16x2(W: np.ndarray) -> np.ndarray:
     """[OUT, IN] fp32 -> split-fp16 A-operand fragments of v_mfma_f32_16x16x32_f16, as a float32-typed byte
     image [OB][CP][2 splits hi / lo'][64 lanes][8 fp16], lo' = fp16((W - hi) * 2^11) (csrc/pf_mfma.h
-    'split-fp16 path').  Same lane / K-slot map as frag_pack_bf16x3."""
+    'split-fp16 path'; the continuous model's weight records).  Lane l (row = l & 15, q = l >> 4), element j of block pair
+    cp: channel 32 cp + 4q + j (j < 4) or 32 cp + 16 + 4q + (j - 4) (j >= 4)."""
     out, inn = W.shape
     OB, CP = (out + 15) // 16, (inn + 31) // 32
     Wp = np.zeros((OB * 16, CP * 32), dtype=np.float32)
     Wp[:out, :inn] = W
     if np.abs(Wp).max(initial=0.0) >= 65504.0:
-        raise ValueError("weight magnitude exceeds the fp16 range of the f16x2 path; use PF_EC_MODE=bf16x3")
+        raise ValueError("weight magnitude exceeds the fp16 range of the f16x2 path; use ec_mode='f32'")
     hi = Wp.astype(np.float16)
     lo = ((Wp - hi.astype(np.float32)).astype(np.float32) * np.float32(F16_LO_SCALE)).astype(np.float16)
     lanes = np.arange(64)
@@ -250,7 +219,7 @@ def frag_pack_f16n(W: np.ndarray) -> np.ndarray:
     Wp = np.zeros((OB * 16, CP * 32), dtype=np.float32)
     Wp[:out, :inn] = W
     if np.abs(Wp).max(initial=0.0) >= 65504.0:
-        raise ValueError("scaled weight magnitude exceeds the fp16 range of the f16n path; use PF_EC_MODE=bf16x3")
+        raise ValueError("scaled weight magnitude exceeds the fp16 range of the f16n path; use ec_mode='f32'")
     hi = Wp.astype(np.float16)
     lo = (Wp - hi.astype(np.float32)).astype(np.float32).astype(np.float16)
     lanes = np.arange(64)
@@ -446,27 +415,15 @@ def pack_flow_record(f: Dict[str, object]) -> np.ndarray:
 
 def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, object]:
     """-> {'blob': fp32 1-D array, 'ec_tab0', 'ec_w'[6], 'post'[6][12], 'flow', 'interp'[13], 'ld_const'}.
-    ec_mode "f16n": the P|Q rows that feed the 128-channel units are scaled for edgeconv4_kernel (ec4_scales); the
-    other EdgeConv back-ends ("f16x2", "bf16x3", "f32") read an unscaled table."""
+    ec_mode "f16n" (the product): the P|Q rows are scaled for edgeconv4_kernel / edgeconv1n_kernel (ec4_scales);
+    "f32" (the exact-fp32 A/B reference kernel) reads an unscaled table."""
+    if ec_mode not in ("f16n", "f32"):
+        raise ValueError(f"unknown EdgeConv arithmetic mode {ec_mode!r}")
     B = _Blob()
     out: Dict[str, object] = {}
     units = plan["units"]
     out["ec_tab0"] = B.add(_edge_table(units[0]))
     out["ec_w"] = [B.add(_ec_frags(units[i], 4)) for i in range(NUM_BLOCKS)]
-    # split-bf16 weight image of the 128-channel units (csrc/edgeconv.hip edgeconv3_kernel); None for units 0,1
-    out["ec2h_w"] = [None, None] + [B.add(np.concatenate([frag_pack_f16x2(units[i][f"G{t}"]) for t in range(1, 5)]))
-                                    for i in range(2, NUM_BLOCKS)]
-    # split-fp16 images of the narrow units 0 / 1 (csrc/edgeconv.hip edgeconv1h_kernel): G1 | G2 | G3 | Gout,
-    # unit 0 additionally carries its folded edge table (raw inputs -> all S pre-activations) as S/16 fragments
-    ec1h = []
-    for i in range(2):
-        parts = [frag_pack_f16x2(units[i][f"G{t}"]) for t in range(1, 5)]
-        if i == 0:
-            parts.append(_etab_frag(units[0]["PA"], units[0]["QB"], None, units[0]["pb"]))
-        ec1h.append(B.add(np.concatenate(parts)))
-    out["ec1h_w"] = ec1h + [None] * (NUM_BLOCKS - 2)
-    out["ec3_w"] = [None, None] + [B.add(np.concatenate([frag_pack_bf16x3(units[i][f"G{t}"]) for t in range(1, 5)]))
-                                   for i in range(2, NUM_BLOCKS)]
     out["ec4_w"] = [None, None] + [B.add(ec4_weights(units[i])) for i in range(2, NUM_BLOCKS)]
     # f16n images of the narrow units 0 / 1 (csrc/edgeconv.hip edgeconv1n_kernel): G1 | G2 | G3 | Gout with the same
     # 4^t activation-scale plan; unit 0 carries its edge table with the rows scaled like the P|Q rows of the other units

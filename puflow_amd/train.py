@@ -84,6 +84,8 @@ def fit(module: TrainerModule, train_data: Iterable, val_data: Optional[Iterable
                 continue
             last = module.train_step(batch, optimizer, clip)
         hist["loss"].append(float(last) if last is not None else float("nan"))
+        if next(module.parameters()).is_cuda:
+            module.check_device_status()          # end of epoch, the host just synchronised: EMD barrier time-outs raise, NaN substitutions are printed
         if val_data is not None:
             outs = [module.validation_step(b, i) for i, b in enumerate(val_data)]
             cd = module.validation_epoch_end(outs)["CD"]

@@ -44,7 +44,7 @@ class GraphedTrainStep:
     def __init__(self, module, optimizer: torch.optim.Optimizer, batch, clip: float = 1e-2, warmup: int = 2):
         from . import train_ops
         from .dist import FlatGradBucket
-        if train_ops._sync_bn_active():
+        if getattr(getattr(module, "network", module), "sync_batchnorm", False) and train_ops._multi_rank():
             raise RuntimeError("graphed_train_step: SyncBN reads the global row count on the host; capture is not possible")
         self.module, self.optimizer, self.clip = module, optimizer, clip
         dev = next(module.parameters()).device
@@ -59,6 +59,9 @@ class GraphedTrainStep:
             make_capturable(optimizer, dev)
         self.static = self._clone_batch(batch)
         module.train()
+        if hasattr(module, "_nan_subs") and (module._nan_subs is None or module._nan_subs.device != dev):
+            module._nan_subs = torch.zeros((), dtype=torch.int64, device=dev)     # NaN losses replaced inside the capture
+        self.calls = 0
         self.bucket = FlatGradBucket(module.parameters())
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -136,7 +139,17 @@ class GraphedTrainStep:
         if getattr(self, "_written", None) is None:
             self._written = list(self.module.parameters()) + list(self.module.buffers())
         torch._C._increment_version(self._written)
+        self.calls += 1
+        if self.calls % self.CHECK_EVERY == 0:
+            self.check()
         return self.loss
+
+    CHECK_EVERY = 64          # replays between two reads of the device status words (each read is a synchronisation)
+
+    def check(self) -> int:
+        """A timed-out EMD barrier raises; returns the NaN losses replaced since the last check (trainer.check_device_status)."""
+        fn = getattr(self.module, "check_device_status", None)
+        return fn() if fn is not None else 0
 
     def set_lr(self, lr: float) -> None:
         if self.fused:

@@ -211,14 +211,31 @@ class SyncBnLreluFn(Function):
         return dx, dg, db, None, None, None, None, None
 
 
-SYNC_BN = False          # set by TrainerModule(cfg.sync_batchnorm=True): BatchNorm statistics over all ranks
+# BatchNorm statistics over all ranks: an ARGUMENT of the forward, not process state - `forward_train` takes it from the
+# module (`PointInterpFlow.sync_batchnorm`, set from `cfg.sync_batchnorm`) and holds it in this context variable for the
+# duration of that call; `sync_bn(True)` is the same scope for callers of the single ops (tests)
+import contextlib
+import contextvars
+
+_SYNC_BN: contextvars.ContextVar = contextvars.ContextVar("puflow_sync_bn", default=False)
+
+
+@contextlib.contextmanager
+def sync_bn(on: bool):
+    tok = _SYNC_BN.set(bool(on))
+    try:
+        yield
+    finally:
+        _SYNC_BN.reset(tok)
+
+
+def _multi_rank() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def _sync_bn_active() -> bool:
-    if not SYNC_BN:
-        return False
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return bool(_SYNC_BN.get()) and _multi_rank()
 
 
 def bn_lrelu(x: Tensor, bn: torch.nn.BatchNorm2d, slope: float) -> Tensor:
@@ -1246,6 +1263,11 @@ def _flow_param_aliases(net):
 
 def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     """PointInterpFlow.forward in train() mode (interpflow.py:327-337) with gradients."""
+    with sync_bn(getattr(net, "sync_batchnorm", False)):
+        return _forward_train(net, xyz, upratio)
+
+
+def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     from . import ops
     xyz = xyz.detach().contiguous().float()
     B, N, _ = xyz.shape

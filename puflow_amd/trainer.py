@@ -29,7 +29,7 @@ def default_cfg(**kw):
     # sync_batchnorm: BatchNorm statistics over ALL ranks (an extension: the reference trains on one GPU, where it is
     # the same thing; default False = each rank normalises with its own shard, like DDP without SyncBatchNorm)
     cfg = dict(net="UpsamplingFlow", learning_rate=1e-3, sched_patience=10, sched_factor=0.5, seed=2021, sync_batchnorm=False,
-               fused_optimizer=True)
+               fused_optimizer=True, emd_workgroups=0)
     cfg.update(kw)
     return SimpleNamespace(**cfg)
 
@@ -42,10 +42,12 @@ class TrainerModule(_Base):
         super().__init__()
         self.cfg = cfg or default_cfg()
         self.loss_mix = loss_mix
-        from . import train_ops
-        train_ops.SYNC_BN = bool(getattr(self.cfg, "sync_batchnorm", False))
         self.network = PointInterpFlow(pc_channel=3)
-        self.emd_loss = EarthMoverDistance()
+        self.network.sync_batchnorm = bool(getattr(self.cfg, "sync_batchnorm", False))     # an argument of its train-mode forward
+        # cfg.emd_workgroups: workgroups per sample of the EMD auction (0 = chosen from the device, 1 = safe on a GPU that is
+        # shared with other processes: no inter-workgroup waits; csrc/emd.hip)
+        self.emd_loss = EarthMoverDistance(groups=int(getattr(self.cfg, "emd_workgroups", 0)))
+        self._nan_subs: Optional[Tensor] = None       # device counter: NaN losses replaced inside captured steps
         self.chamfer_loss = ChamferCUDA()
         self.chamfer_loss2 = ChamferCUDA2()
         self.epoch = 0
@@ -121,7 +123,11 @@ class TrainerModule(_Base):
             if torch.cuda.is_current_stream_capturing():
                 # inside a captured step nothing may read the device: the same substitution as a tensor op (a NaN loss
                 # becomes the constant 0.1, whose gradient is zero instead of the reference's NaN gradients)
-                loss = torch.where(torch.isnan(loss), torch.full_like(loss, 0.1), loss)
+                bad = torch.isnan(loss)
+                if self._nan_subs is None or self._nan_subs.device != loss.device:
+                    raise RuntimeError("capture a training step through graphed_train_step (it allocates the NaN counter)")
+                self._nan_subs += bad                 # counted on the device; check_device_status() reports it
+                loss = torch.where(bad, torch.full_like(loss, 0.1), loss)
             elif bool(torch.isnan(loss)):
                 print("loss is nan")
                 loss.data = torch.ones_like(loss) * 0.1
@@ -161,10 +167,31 @@ class TrainerModule(_Base):
         from .dist import broadcast_module
         with torch.no_grad():
             sparse, dense, _ = self._unpack(batch)
-            # NB: this extra train-mode forward also moves the BatchNorm running statistics one momentum step further than
-            # a single-process run would (they are overwritten by rank 0's on the next broadcast_buffers)
+            # this extra train-mode forward exists for ActNorm only: the BatchNorm buffers (running statistics, batch
+            # counters) are put back afterwards, so the first real step leaves them exactly where a single-process run does
+            bufs = list(self.network.buffers())
+            keep = [b.clone() for b in bufs]
             self(sparse, upratio=int(dense.shape[1] / sparse.shape[1]))
+            for b, k in zip(bufs, keep):
+                b.copy_(k)
         broadcast_module(self)
+
+    def check_device_status(self, raise_on_nan: bool = False) -> int:
+        """What the device recorded since the last call, read at a point where the host synchronises anyway (end of an eager
+        step, every few replays of a captured one, end of an epoch): a timed-out EMD grid barrier raises PuflowHipError; the
+        number of NaN losses a CAPTURED step replaced by the reference's constant 0.1 (train_pu1k.py:71-73) is returned (and
+        printed, like the reference's `loss is nan`)."""
+        from .loss import check_emd_status
+        check_emd_status(next(self.parameters()).device)
+        n = 0
+        if self._nan_subs is not None:
+            n = int(self._nan_subs.item())
+            if n:
+                self._nan_subs.zero_()
+                print(f"loss is nan ({n} captured step(s): replaced by 0.1, zero gradient)")
+                if raise_on_nan:
+                    raise RuntimeError(f"{n} training step(s) produced a NaN loss")
+        return n
 
     def graphed_train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2, warmup: int = 2):
         """`train_step` for a fixed batch shape captured in hipGraphs (puflow_amd/train_graph.py): returns
@@ -185,8 +212,10 @@ class TrainerModule(_Base):
             self._bucket.all_reduce_mean(always_pack=True)      # ONE concatenation (+ ONE 3.2 MB RCCL all-reduce when multi-rank)
             optimizer.param_groups[0]["max_norm"] = clip
             optimizer.step_flat(self._bucket.flat)              # clip by the global norm + Adam: two launches
-            return loss.detach()
-        self._bucket.all_reduce_mean()                          # multi-rank: ONE concatenation + ONE 3.2 MB RCCL all-reduce
-        torch.nn.utils.clip_grad_norm_(self._bucket.params, clip, foreach=True)
-        optimizer.step()
+        else:
+            self._bucket.all_reduce_mean()                      # multi-rank: ONE concatenation + ONE 3.2 MB RCCL all-reduce
+            torch.nn.utils.clip_grad_norm_(self._bucket.params, clip, foreach=True)
+            optimizer.step()
+        if not torch.cuda.is_current_stream_capturing() and loss.is_cuda:
+            self.check_device_status()                          # eager step: one word read (the NaN guard above read the loss already)
         return loss.detach()

@@ -54,3 +54,24 @@ def test_bench_pipeline_option_small_batch():
     assert rec["steps"] == 30 and rec["unit"] == "patches/s" and rec["scaling"] == "strong" and rec["value"] > 0
     assert "3 steps in flight" in rec["config"]["launch"] and "pipelined" not in rec
     assert rec["parity"]["max_abs_dx_vs_oracle"] < 1e-5 and rec["parity"]["knn_idx_exact_match_rate"] == 1.0
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) must run TWO ranks - fresh child processes
+    under torch.distributed.run, started before the parent touches the GPU - and report n_gpus = 2, not a silent one-rank
+    run.  Rehearsal knobs of the one-GPU box: both ranks on cuda:0, gloo instead of RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PF_BENCH_SINGLE_DEVICE="1", PF_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "4", "--steps", "10", "--warmup", "2",
+                          "--no-pipelined"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["total_batch"] == 8 and rec["value"] > 0
+    assert rec["cpu_baseline"] is None                        # N = 1 only
+    assert "launching" in out.stderr
+    # a launcher environment that disagrees with --gpus is an error, not a mislabeled run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr

@@ -135,3 +135,24 @@ def test_emd_nan_prediction_row_is_loud_not_a_fault():
     assert (ass[0] == aref[0]).all() and (ass[1] == aref[1]).mean() > 0.99
     loss = EarthMoverDistance()(x.to(DEV), y.to(DEV))
     assert bool(torch.isnan(loss))
+
+
+def test_emd_groups_argument_and_status_word():
+    """pf_emd_forward_ex: groups = 0 (chosen from the device's occupancy for the kernel), 1 (one workgroup per sample) and a
+    cap give the same assignment (same arithmetic and tie rules); a clean run leaves the status word at 0 and
+    check_emd_status() silent; a word that was bumped raises once and is cleared."""
+    from puflow_amd import _lib
+    from puflow_amd.loss import _emd_status, check_emd_status, emdFunction
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(4, 1024, 3, generator=g).cuda()
+    y = torch.rand(4, 1024, 3, generator=g).cuda()
+    outs = [emdFunction.apply(x, y, 0.005, 50, grp) for grp in (0, 1, 4)]
+    for d, a in outs[1:]:
+        assert torch.equal(a, outs[0][1]) and torch.equal(d, outs[0][0])
+    check_emd_status()                                       # nothing timed out
+    st = _emd_status(x.device)
+    assert int(st[0]) == 0
+    st[0] = 2
+    with pytest.raises(_lib.PuflowHipError):
+        check_emd_status()
+    check_emd_status()                                       # cleared by the report

@@ -27,12 +27,12 @@ def _data():
 def _run(x, w, gamma, beta, sync):
     from puflow_amd import train_ops as T
     dev = "cuda:0"
-    T.SYNC_BN = sync
     bn = torch.nn.BatchNorm2d(48).to(dev)
     with torch.no_grad():
         bn.weight.copy_(gamma); bn.bias.copy_(beta)
     xd = x.to(dev).requires_grad_(True)
-    y = T.bn_lrelu(xd, bn, 0.05)
+    with T.sync_bn(sync):
+        y = T.bn_lrelu(xd, bn, 0.05)
     loss = (y * w.to(dev)).mean()
     loss.backward()
     return (y.detach().cpu(), xd.grad.cpu(), bn.weight.grad.cpu(), bn.bias.grad.cpu(), bn.running_mean.cpu(), bn.running_var.cpu())

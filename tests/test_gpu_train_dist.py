@@ -19,10 +19,10 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    # PF_EMD_SINGLE: the two ranks SHARE one GPU here; the cooperative EMD auction assumes the process has the device to itself
-    # (its workgroups wait for each other: two such kernels at once can starve each other's barriers - csrc/emd.hip).  One
-    # workgroup per sample is the documented setting for shared devices; with one GPU per rank it is not needed.
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PF_EMD_SINGLE="1")
+    # The two ranks SHARE one GPU here.  The EMD auction picks its workgroups per sample from the device's occupancy for the
+    # kernel (csrc/emd.hip pf_emd_forward_ex): 2 samples x 16 workgroups per rank, 64 of 256 CUs for both ranks together -
+    # co-resident; a timed-out grid barrier would be REPORTED by train_step (loss.check_emd_status), not hidden in a NaN.
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from puflow_amd.optim import FusedClipAdam
@@ -63,3 +63,66 @@ def test_two_rank_train_step_keeps_parameters_identical():
     assert np.array_equal(w0, w1), float(np.abs(w0 - w1).max())
     from puflow_amd.weights import synth_state_dict
     assert np.abs(w0).sum() > 0 and w0.shape[0] == 806103
+
+
+# ---- first multi-rank step: ActNorm's data-dependent init needs one extra forward; the BatchNorm buffers must not see it
+def _bn_buffers(tm):
+    return {k: v.detach().cpu().numpy().copy() for k, v in tm.network.named_buffers()
+            if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+
+
+def _make_tm(dev, sync):
+    from puflow_amd.trainer import TrainerModule, default_cfg
+    from puflow_amd.weights import synth_state_dict
+    tm = TrainerModule(default_cfg(learning_rate=1e-3, sync_batchnorm=sync), loss_mix="pugan")
+    tm.network.load_state_dict(synth_state_dict(21))
+    for b in tm.network.flow_blocks:
+        b.actnorm.is_inited = False                       # a fresh model: the first step runs the data-dependent init
+    return tm.to(dev)
+
+
+def _worker_bn(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from puflow_amd.weights import synth_patches
+        dev = "cuda:0"
+        dense = ((synth_patches(4, 1024, seed=11) + 1) / 2)[2 * rank:2 * rank + 2].to(dev)
+        batch = (dense[:, ::4].contiguous(), dense, torch.ones(2, device=dev))
+        tm = _make_tm(dev, True)
+        opt = tm.configure_optimizers()["optimizer"]
+        loss = float(tm.train_step(batch, opt))
+        q.put((rank, loss, _bn_buffers(tm)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_first_multi_rank_step_leaves_batchnorm_buffers_like_one_process():
+    """Two ranks with global-batch BatchNorm statistics (cfg.sync_batchnorm) against ONE process on the concatenated batch:
+    after the first step - which includes the extra ActNorm-init forward on every rank - running means / variances agree to
+    fp32 rounding and the batch counters are equal (the init forward's BatchNorm side effects are undone)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    from puflow_amd.weights import synth_patches
+    dev = "cuda:0"
+    dense = ((synth_patches(4, 1024, seed=11) + 1) / 2).to(dev)
+    tm = _make_tm(dev, False)
+    opt = tm.configure_optimizers()["optimizer"]
+    tm.train_step((dense[:, ::4].contiguous(), dense, torch.ones(4, device=dev)), opt)
+    one = _bn_buffers(tm)
+    for rank, loss, bufs in res:
+        assert np.isfinite(loss)
+        assert bufs.keys() == one.keys() and len(one) == 3 * 36            # 36 BatchNorm layers
+        for k, v in one.items():
+            if k.endswith("num_batches_tracked"):
+                assert int(bufs[k]) == int(v), (k, bufs[k], v)              # ONE step counted, not two
+            else:
+                np.testing.assert_allclose(bufs[k], v, rtol=2e-5, atol=2e-6, err_msg=f"rank {rank} {k}")

@@ -137,7 +137,7 @@ def test_pack_plan_layout():
     np.testing.assert_array_equal(g1, plan["units"][3]["G1"])
     # flow record: natural-scale split-fp16 images of 2^s W2 then the replicated 2^s W4 rows, with 2^-s stored behind:
     # (hi + lo) 2^-s reproduces fp32 to ~2^-22 (the scale puts max |W| at 2^13: every lo that matters is a normal fp16)
-    from puflow_amd.packing import frag_unpack_f16n, frag_unpack_f16x2
+    from puflow_amd.packing import frag_unpack_f16n
     rec = blob[pk["flow"] + 2 * FLOW_REC: pk["flow"] + 3 * FLOW_REC]
     W2 = plan["flows"][2]["c1_W2"]
     inv2, inv4 = float(rec[5352]), float(rec[5353])
@@ -148,9 +148,11 @@ def test_pack_plan_layout():
     np.testing.assert_allclose(rec[5120:5184] * inv2, plan["flows"][2]["c1_b2"], rtol=1e-6)
     np.testing.assert_array_equal(rec[5328:5337].reshape(3, 3), plan["flows"][2]["A"])
     assert FLOW_REC == 5360 and rec.size == FLOW_REC
-    # EdgeConv unit 3, split-fp16 image: G1 [32, 32] = 2 ob x 1 pair
-    g1h = frag_unpack_f16x2(blob[pk["ec2h_w"][3]:pk["ec2h_w"][3] + 2 * 512], 32, 32)
-    np.testing.assert_allclose(g1h, plan["units"][3]["G1"], rtol=2.0 ** -21, atol=1e-12)
+    # EdgeConv unit 3, f16n image: G1 [32, 32] = 2 ob x 1 pair, columns scaled by a_1 / a_0 = 4 (packing.ec4_scales)
+    g1n = frag_unpack_f16n(blob[pk["ec4_w"][3]:pk["ec4_w"][3] + 2 * 512], 32, 32)
+    np.testing.assert_allclose(g1n / 4.0, plan["units"][3]["G1"], rtol=2.0 ** -21, atol=2.0 ** -26)      # natural-scale lo: absolute floor 2^-25 of the stored (x4) value
+    with pytest.raises(ValueError):
+        pack_plan(plan, "bf16x3")
 
 
 def test_cli_file_sharding_covers_every_file_once():
