@@ -48,8 +48,9 @@ def main():
                     help="weak: --batch patches per GPU; strong: --total-batch patches split over the ranks")
     ap.add_argument("--total-batch", type=int, default=32, help="patches of the whole job under --scaling strong")
     ap.add_argument("--npoint", type=int, default=2048)
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
-                    help="infer = headline metric (BASELINE configs[1]); train = configs[2] training step (CD+EMD, RCCL all-reduce)")
+    ap.add_argument("--mode", choices=["infer", "train", "cnf"], default="infer",
+                    help="infer = headline metric (BASELINE configs[1]); train = configs[2] training step (CD+EMD, RCCL all-reduce); "
+                         "cnf = configs[4] continuous (CNF) x4 inference, dopri5 on the device")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="steps in flight: P > 1 replays P captured graphs round-robin on P streams (independent batches overlap; "
                          "pays off when one batch cannot fill the chip, e.g. --scaling strong at 4 patches per GPU)")
@@ -58,6 +59,9 @@ def main():
     ap.add_argument("--no-reduced", action="store_true",
                     help="skip the secondary reduced-precision line (a child process on libpuflow_hip_f16.so)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--cnf-dynamics", type=float, default=5.0,
+                    help="--mode cnf: scale of the synthetic ODE nets (1 = random init: a trivial ODE; the default makes dopri5 work "
+                         "like on the reference's pretrained checkpoint)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -97,6 +101,8 @@ def main():
 
     if args.mode == "train":
         return bench_train(args, world, rank, dev, dist)
+    if args.mode == "cnf":
+        return bench_cnf(args, world, rank, dev, dist)
 
     sd = synth_state_dict(2021)
     net = PointInterpFlow(3)
@@ -365,18 +371,37 @@ def reduced_precision_line(args):
             "note": "same kernels, launches and weights as the headline; only the number of fp16 products per step differs"}
 
 
+def _ncpu():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("PF_CPU_THREADS", "16"))))
+
+
+# executed MACs per EDGE of one 128-channel EdgeConv unit's backward (pf_ec_train_bwd, C = 128, g = 32, 4 growth layers,
+# odim 128; csrc/train_fused.hip): conv_out dA 128 x 128, growth dA 32 x (32 + 64 + 96), all weight gradients
+# [S, GT] = 6144 + 128 x 128, and the two P|Q GEMMs (dx, dWpq: 2 x 512 x 128 per POINT = / 16 per edge)
+EC_BWD_MAC_PER_EDGE = 128 * 128 + 32 * (32 + 64 + 96) + (32 * (32 + 64 + 96) + 128 * 128) + 2 * 512 * 128 // 16
+
+
 def bench_train(args, world, rank, dev, dist):
     """BASELINE configs[2]: training step on 32 x (256 -> 1024) patches per GPU, loss 1e-4 logp + 5e-2 EMD(eps .005,
     50 it) + 1e-1 CD (train_pugan.py:59-61), grad all-reduce (one 3.2 MB RCCL bucket), clip 1e-2, Adam 1e-3."""
     from puflow_amd.trainer import TrainerModule, default_cfg
     from puflow_amd.weights import synth_patches, synth_state_dict
     from puflow_amd.dist import broadcast_module
-    tm = TrainerModule(default_cfg(learning_rate=1e-3), loss_mix="pugan")
-    tm.network.load_state_dict(synth_state_dict(2021))
+    # rehearsal on one GPU (several ranks share the device): one EMD workgroup per sample - the multi-workgroup auction's grid
+    # barriers assume this process's workgroups are co-resident (csrc/emd.hip)
+    shared = os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1" and world > 1
+    tm = TrainerModule(default_cfg(learning_rate=1e-3, emd_workgroups=1 if shared else 0), loss_mix="pugan")
+    sd = synth_state_dict(2021)
+    tm.network.load_state_dict(sd)
     tm = tm.to(dev)
     broadcast_module(tm)
     opt = tm.configure_optimizers()["optimizer"]
-    dense = ((synth_patches(args.batch, 1024, seed=2021 + rank) + 1) / 2).to(dev)      # [0,1] for the EMD
+    dense_cpu = (synth_patches(args.batch, 1024, seed=2021 + rank) + 1) / 2                # [0,1] for the EMD
+    dense = dense_cpu.to(dev)
     sparse = dense[:, ::4].contiguous()
     batch = (sparse, dense, torch.ones(args.batch, device=dev))
 
@@ -387,9 +412,11 @@ def bench_train(args, world, rank, dev, dist):
     # the step is replayed from hipGraphs by default (forward + loss + backward [+ all-reduce between two graphs] + clip + Adam:
     # same kernels, same order; PF_BENCH_GRAPH=0 times the eager launches)
     step = lambda b: tm.train_step(b, opt)
+    graphed = False
     if os.environ.get("PF_BENCH_GRAPH", "1") == "1":
         try:
             step = tm.graphed_train_step(batch, opt)
+            graphed = True
         except Exception as ex:
             print(f"[bench] training-step capture failed ({type(ex).__name__}: {ex}); timing the eager step", file=sys.stderr)
     for _ in range(args.warmup):
@@ -400,11 +427,42 @@ def bench_train(args, world, rank, dev, dist):
         loss = step(batch)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    tm.check_device_status()                      # EMD barrier time-outs raise, NaN substitutions of the captured steps are printed
     t = torch.tensor([el], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.destroy_process_group()
     el = float(t.item())
+    roof = cpu = None
+    if rank == 0:
+        # ---- dominant launch group, timed live: HIP events around every C-ABI call of three EAGER steps (the same kernels
+        # the graph replays).  The step is ~440 launches of 5 - 100 us; the largest share belongs to the backward of the
+        # 128-channel EdgeConv units (pf_ec_train_bwd: conv_out / growth dA, one split-K launch for all weight gradients, the
+        # neighbour scatter, two P|Q GEMMs), priced against the fp32 matrix pipe it runs on (v_mfma_f32_16x16x4_f32).
+        from puflow_amd._prof import profile_calls
+        with profile_calls() as prof:
+            for _ in range(3):
+                tm.train_step(batch, opt)
+            torch.cuda.synchronize()
+        tab = prof.table()
+        calls_ms = {k: v[1] / 3 for k, v in sorted(tab.items(), key=lambda kv: -kv[1][1])[:8]}
+        evs = prof.events.get("pf_ec_train_bwd", [])
+        ms = sorted(a.elapsed_time(b) for a, b in evs)
+        if ms:
+            big = ms[len(ms) // 2:]                                        # 7 units per step: the upper half are the four 128-channel ones
+            ec_ms = sum(big) / len(big)
+            E = args.batch * 256 * 16
+            flops = 2.0 * EC_BWD_MAC_PER_EDGE * E
+            roof = {"bound": "mfma", "kernel": "pf_ec_train_bwd of a 128-channel EdgeConv unit (csrc/train_fused.hip: ec_bwd_kernel x4, "
+                                             "ec_pq_bwd_kernel, ec_dw_kernel, two gemm_kernel, ec_assemble_kernel)",
+                    "achieved": flops / (ec_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": flops / (ec_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None, "avg_launch_ms": ec_ms,
+                    "flops_basis": f"executed: {EC_BWD_MAC_PER_EDGE} MAC per edge x {E} edges per call (all products on "
+                                   "v_mfma_f32_16x16x4_f32); live HIP-event duration of the call's launches on the launch stream",
+                    "calls_ms_per_step": calls_ms}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = train_cpu_baseline(sd, dense_cpu, args.cpu_seconds)
+    if world > 1:
+        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "training patches/sec (256->1024 patches, CD+EMD loss, grad all-reduce)",
                           "value": world * args.batch * args.steps / el, "unit": "patches/s", "n_gpus": world,
@@ -412,8 +470,165 @@ def bench_train(args, world, rank, dev, dist):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "synthetic", "loss": float(loss),
                           "config": {"workload": "BASELINE configs[2]: discrete x4 training step, 32 x (256->1024) patches per GPU",
-                                     "loss": "1e-4 logp + 5e-2 EMD(eps .005, 50 it) + 1e-1 CD", "optimizer": "Adam 1e-3, clip 1e-2"}}),
-              flush=True)
+                                     "loss": "1e-4 logp + 5e-2 EMD(eps .005, 50 it) + 1e-1 CD", "optimizer": "Adam 1e-3, clip 1e-2",
+                                     "launch": "hipGraph replay" if graphed else "eager",
+                                     "patches_per_gpu": args.batch, "sharding": f"patch batch over {world} rank(s); one RCCL "
+                                     "all-reduce of the flat 806 103-float gradient per step"},
+                          "roofline": roof, "cpu_baseline": cpu}), flush=True)
+
+
+def train_cpu_baseline(sd, dense_cpu, seconds):
+    """The training step of the CPU oracle (oracle/ref_cpu.py::forward_train under autograd + Chamfer + the numpy auction of
+    oracle/emd_ref.py with the assignment frozen, loss and backward; no optimizer update) on 2 patches, repeated for about
+    `seconds`."""
+    import numpy as np
+    from oracle import emd_ref, ref_cpu as O
+    ncpu = _ncpu()
+    torch.set_num_threads(ncpu)
+    bs = 2
+    dense = dense_cpu[:bs].contiguous()
+    sparse = dense[:, ::4].contiguous()
+
+    def one():
+        sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+        x, logp, _ = O.forward_train(sdr, sparse, 4, actnorm_init=False)
+        d1, _, d2, _ = O.chamfer_nn(x, dense)
+        cd = d1.mean(1).mean() + d2.mean(1).mean()
+        _, assign = emd_ref.emd_forward(x.detach().numpy(), dense.numpy(), 0.005, 50)
+        tgt = torch.gather(dense, 1, torch.from_numpy(np.asarray(assign)).long().clamp_min(0).unsqueeze(-1).expand(-1, -1, 3))
+        emd = ((x - tgt) ** 2).sum()
+        loss = logp * 1e-4 + emd * 5e-2 + cd * 1e-1
+        loss.backward()
+        return float(loss)
+
+    one()
+    n, t1 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        if time.perf_counter() - t1 > seconds:
+            break
+    cel = time.perf_counter() - t1
+    return {"value": bs * n / cel, "unit": "patches/s", "cores": ncpu, "kind": "port",
+            "sample": f"{n} training steps (forward + CD + EMD + backward, no optimizer update) of {bs} x (256 -> 1024)-pt patches, "
+                      "fp32 torch-CPU oracle (oracle/ref_cpu.py::forward_train, oracle/emd_ref.py)"}
+
+
+# MFMAs per 16-row tile and right-hand-side evaluation of the continuous model (csrc/cnf.hip: 64 -> 64 forward, its transpose
+# for the Hutchinson vector-Jacobian product, 64 -> 3): 24 + 24 + 6 split-fp16 products
+CNF_MFMA_PER_EVAL = 54
+
+
+def bench_cnf(args, world, rank, dev, dist):
+    """BASELINE configs[4]: continuous (CNF) x4 inference, 32 x 2048-pt patches per GPU; every flow block is an ODE
+    integrated by dopri5 (atol = rtol = 1e-5) with the step-size controller on the device.  Random-init weights make a
+    trivial ODE (168 evaluations, no rejected step); `synth_cnf_state_dict(dynamics=...)` scales the ODE nets so that the
+    solver works as hard as on the reference's pretrained checkpoint (462 evaluations, 62 accepted / 11
+    rejected steps) - the evaluation / accept / reject counts of the timed forward are part of the line."""
+    from puflow_amd.cnf import PointInterpFlow as CnfFlow
+    from puflow_amd.weights import synth_cnf_state_dict, synth_patches
+    from puflow_amd import _lib
+    sd = synth_cnf_state_dict(2021, dynamics=args.cnf_dynamics)
+    net = CnfFlow(3)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    B, N = args.batch, args.npoint
+    xyz_cpu = synth_patches(B, N, seed=2021 + rank)
+    xyz = xyz_cpu.to(dev)
+    torch.manual_seed(0)
+    noise_cpu = [torch.randn(B, N, 3) for _ in range(6)]
+    noise = [n.to(dev) for n in noise_cpu]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        net(xyz, 4, noise=noise)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x, logp = net(xyz, 4, noise=noise)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    stats = dict(net.last_stats)
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    roof = cpu = None
+    extra = {}
+    if rank == 0:
+        # ---- dominant kernel: one dopri5 step attempt (cnf_step kernel: six fused right-hand-side evaluations) on the R-times
+        # replicated rows of the inverse pass; live HIP events over 20 launches through the C ABI
+        import ctypes
+        eng = net._engine(4)
+        rows = B * N * 4
+        y0 = torch.randn(rows, 4, device=dev) * 0.3
+        f0 = torch.randn(rows, 4, device=dev) * 0.1
+        ctx = torch.randn(B * N, 288, device=dev) * 0.3
+        e = noise[0].reshape(B * N, 3).contiguous()
+        y1, f1, ym = torch.empty_like(y0), torch.empty_like(y0), torch.empty_like(y0)
+        ws = torch.zeros(2048, dtype=torch.float64, device=dev)
+        outd = torch.zeros(4, dtype=torch.float64, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        lib = _lib.load()
+
+        def attempt():
+            _lib.check(lib.pf_cnf_step(y0.data_ptr(), f0.data_ptr(), 0.1, 0.05, 1, ctx.data_ptr(), e.data_ptr(), eng.rec[2].data_ptr(),
+                                       y1.data_ptr(), f1.data_ptr(), ym.data_ptr(), 1e-5, 1e-5, rows, 4, ws.data_ptr(),
+                                       outd.data_ptr(), s), "pf_cnf_step")
+        for _ in range(3):
+            attempt()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            attempt()
+        b.record(); torch.cuda.synchronize()
+        st_ms = a.elapsed_time(b) / 20
+        flops = rows / 16 * 6 * CNF_MFMA_PER_EVAL * 16384.0
+        roof = {"bound": "mfma", "kernel": "cnf_step kernel (csrc/cnf.hip: one Dormand-Prince step attempt = six fused right-hand-side "
+                                         "evaluations incl. the Hutchinson vector-Jacobian product), inverse pass, rows = 4 B N",
+                "achieved": flops / (st_ms * 1e-3) / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": flops / (st_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, "traffic": None, "avg_launch_ms": st_ms,
+                "flops_basis": f"executed: 6 evaluations x {CNF_MFMA_PER_EVAL} fp16 MFMAs x 16384 flop per 16-row tile, {rows} rows per launch; "
+                               "live HIP-event duration on the launch stream",
+                "note": "the evaluation is bound by its 32 tanh + 32 sigmoid per lane on the transcendental unit, not by the matrix pipe "
+                        "(DESIGN section 9): the MFMA fraction is reported because the contract asks for one of hbm | mfma"}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cnf_ref
+            ncpu = _ncpu()
+            torch.set_num_threads(ncpu)
+            bs = 1
+            xs, ns = xyz_cpu[:bs], [n[:bs] for n in noise_cpu]
+            n_run, t1 = 0, time.perf_counter()
+            while True:
+                ref = cnf_ref.forward(sd, xs, 4, noise=ns, stages=True)
+                n_run += 1
+                if time.perf_counter() - t1 > args.cpu_seconds:
+                    break
+            cel = time.perf_counter() - t1
+            cpu = {"value": bs * n_run / cel, "unit": "patches/s", "cores": ncpu, "kind": "port",
+                   "sample": f"{n_run} forwards of {bs} x {N}-pt patch, fp32 torch-CPU oracle (oracle/cnf_ref.py: from-text dopri5)"}
+            got = net(xyz[:bs], 4, noise=[n[:bs] for n in noise], stages=True)
+            extra["parity"] = {"max_abs_dx_vs_oracle": float((got["x"].cpu() - ref["x"]).abs().max()),
+                               "nfe": [int(got["nfe"]), int(ref["nfe"])], "accepted": [int(got["accepted"]), int(ref["accepted"])],
+                               "rejected": [int(got["rejected"]), int(ref["rejected"])],
+                               "note": "HIP vs oracle on the same patch and Hutchinson vectors; the solver's own tolerance is 1e-5 per "
+                                       "integration, 12 chained integrations"}
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        out = {"metric": "patches/sec x4 2048->8192 (PU1K continuous CNF, eval)", "value": world * B * args.steps / el, "unit": "patches/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32 (split-fp16 MFMA products, fp32 accumulate; solver state fp32, norms f64)", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[4]: continuous CNF x4 inference, 32 x 2048-pt patches per GPU",
+                          "solver": "dopri5, atol = rtol = 1e-5, controller on the device", "ode_dynamics_scale": args.cnf_dynamics,
+                          "solver_work": stats, "patches_per_gpu": B, "npoint": N},
+               "roofline": roof, "cpu_baseline": cpu}
+        out.update(extra)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -36,8 +36,9 @@ struct EcArgs {
 // workgroup has just finished become one MFMA column tile: every wave leaves its points' pooled features in LDS as ready-made
 // B operands (fp32 -> hi / natural lo, the split of pf_pairn), one barrier, then every wave multiplies the tile by ITS rows of
 // the [ROWS x ODIM] matrix (fragments straight from L2: 16 KiB per wave and tile - fine for a few tiles per workgroup, too
-// much L2 traffic next to the Q gathers at 32 x 2048, where the separate HBM-bound kernel stays).  Products, order and
-// rescale are those of pq_gemm_kernel: the table is bit-identical.  hb: [2 parities][CP][hi / lo][64 lanes] x 16 B.
+// much L2 traffic next to the Q gathers at 32 x 2048, where the separate HBM-bound kernel stays).  Up to PQF_NT tiles are
+// staged before the GEMM runs (one weight fetch and its L2 latency per flush, not per tile).  Products, order and rescale
+// are those of pq_gemm_kernel: the table is bit-identical.  hb: [PQF_NT tiles][CP][hi / lo][64 lanes] x 16 B.
 template <int ODIM>
 __device__ __forceinline__ void pqf_stage(u4* hb, int ch, int pt, float v) {
     _Float16* h = reinterpret_cast<_Float16*>(hb);
@@ -48,51 +49,74 @@ __device__ __forceinline__ void pqf_stage(u4* hb, int ch, int pt, float v) {
     h[((cp * 2 + 1) * 64 + slot) * 8 + j] = lo;
 }
 
+constexpr int PQF_NT = 4;      // workgroup tiles staged before the GEMM runs on them (its weights come from L2 once per flush)
+
 template <int ODIM, int ROWS, int NW>
-__device__ __forceinline__ void pqf_gemm(const EcArgs& a, const u4* hb, int wave_u, int lane, int pt0_tile) {
+__device__ __forceinline__ void pqf_gemm(const EcArgs& a, const u4* hb, int nst, const int (&tpt)[PQF_NT], int wave_u, int lane) {
     constexpr int CP = ODIM / 32, RB = ROWS / 16 / NW;
     static_assert(ODIM % 32 == 0 && ROWS % (16 * NW) == 0, "rows split evenly over the waves");
+    // weight fragments of OBW of this wave's RB 16-row blocks are fetched together: all of them in the 8-wave kernels (256
+    // VGPRs per wave: one L2 latency per flush), one block at a time in the 16-wave kernel (128 VGPRs, none to spare)
+    constexpr int OBW = NW <= 8 ? RB : 1;
     const int col = lane & 15, q = lane >> 4;
-    const PfW2BufD<RB * CP> ws(a.pqf_w, lane);
-    h8 wh[RB][CP], wl[RB][CP];
-#pragma unroll
-    for (int ob = 0; ob < RB; ++ob)
-#pragma unroll
-        for (int cp = 0; cp < CP; ++cp) {
-            wh[ob][cp] = ws.load((wave_u * RB + ob) * CP + cp, 0);
-            wl[ob][cp] = ws.load((wave_u * RB + ob) * CP + cp, 1);
-        }
+    const PfW2BufD<CP> ws(a.pqf_w, lane);
     const float inv = a.pqf_scales[6];
-    f4 acc[RB];
 #pragma unroll
-    for (int ob = 0; ob < RB; ++ob) acc[ob] = pf_splat(0.f);
+    for (int ob0 = 0; ob0 < RB; ob0 += OBW) {
+        h8 wh[OBW][CP], wl[OBW][CP];
 #pragma unroll
-    for (int cp = 0; cp < CP; ++cp) {
-        const h8 fh = __builtin_bit_cast(h8, hb[(cp * 2 + 0) * 64 + lane]), fl = __builtin_bit_cast(h8, hb[(cp * 2 + 1) * 64 + lane]);
+        for (int o = 0; o < OBW; ++o)
 #pragma unroll
-        for (int ob = 0; ob < RB; ++ob) {
-            f4 x = acc[ob];
-            if constexpr (PF_MMN_TERMS == 3) {
-                x = pf_mfma_f16(wh[ob][cp], fl, x);
-                x = pf_mfma_f16(wl[ob][cp], fh, x);
+            for (int cp = 0; cp < CP; ++cp) {
+                wh[o][cp] = ws.load((wave_u * RB + ob0 + o) * CP + cp, 0);
+                wl[o][cp] = ws.load((wave_u * RB + ob0 + o) * CP + cp, 1);
             }
-            x = pf_mfma_f16(wh[ob][cp], fh, x);
-            acc[ob] = x;
-        }
-    }
-    const int pt = pt0_tile + col;
-    if (pt < a.T) {
 #pragma unroll
-        for (int ob = 0; ob < RB; ++ob) {
-            const f4 bias = *reinterpret_cast<const f4*>(a.pqf_bias + (wave_u * RB + ob) * 16 + 4 * q);
-            f4 o;
+        for (int t = 0; t < PQF_NT; ++t) {
+            if (t >= nst) break;                              // uniform
+            const u4* hbt = hb + t * (CP * 2 * 64);
+            f4 acc[OBW];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = fmaf(acc[ob][r], inv, bias[r]);
-            *reinterpret_cast<f4*>(a.pqf_out + (size_t)pt * ROWS + (wave_u * RB + ob) * 16 + 4 * q) = o;
+            for (int o = 0; o < OBW; ++o) acc[o] = pf_splat(0.f);
+#pragma unroll
+            for (int cp = 0; cp < CP; ++cp) {
+                const h8 fh = __builtin_bit_cast(h8, hbt[(cp * 2 + 0) * 64 + lane]), fl = __builtin_bit_cast(h8, hbt[(cp * 2 + 1) * 64 + lane]);
+#pragma unroll
+                for (int o = 0; o < OBW; ++o) {
+                    f4 x = acc[o];
+                    if constexpr (PF_MMN_TERMS == 3) {
+                        x = pf_mfma_f16(wh[o][cp], fl, x);
+                        x = pf_mfma_f16(wl[o][cp], fh, x);
+                    }
+                    x = pf_mfma_f16(wh[o][cp], fh, x);
+                    acc[o] = x;
+                }
+            }
+            const int pt = tpt[t] + col;
+            if (pt < a.T) {
+#pragma unroll
+                for (int o = 0; o < OBW; ++o) {
+                    const f4 bias = *reinterpret_cast<const f4*>(a.pqf_bias + (wave_u * RB + ob0 + o) * 16 + 4 * q);     // L1-resident
+                    f4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[o][r], inv, bias[r]);
+                    *reinterpret_cast<f4*>(a.pqf_out + (size_t)pt * ROWS + (wave_u * RB + ob0 + o) * 16 + 4 * q) = v;
+                }
+            }
         }
     }
 }
 
+// staged-tile bookkeeping of a PQF kernel: slot of the current tile, first point of every staged tile (uniform values)
+struct PqfState {
+    int nst = 0;
+    int tpt[PQF_NT] = {0, 0, 0, 0};
+    __device__ __forceinline__ void push(int pt0) {
+#pragma unroll
+        for (int k = 0; k < PQF_NT; ++k) tpt[k] = k == nst ? pt0 : tpt[k];
+        ++nst;
+    }
+};
 
 template <int GB, int NCONV, int ODIM, bool C3, int P, int NW>
 __global__ __launch_bounds__(NW * 64) void edgeconv_kernel(EcArgs a) {
@@ -269,9 +293,9 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
     // (edge, 4-channel) lane layout cost as many texture-addresser cycles as the Q gathers themselves (16 lanes fetching
     // the same 16 bytes still take a full quad-lane slot each): 392 -> 272 TA cycles per point.
     __shared__ f4 plds[NW * P][64];
-    __shared__ u4 hb[PQF ? 2 * (ODIM / 32) * 2 * 64 : 1];                 // PQF: the tile's pooled features as B operands, per tile parity
-    int parity = 0;
-    for (int i = threadIdx.x; i < NWF * 2 * 64; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
+    __shared__ u4 hb[PQF ? PQF_NT * (ODIM / 32) * 2 * 64 : 1];            // PQF: the staged tiles' pooled features as B operands
+    PqfState pqf;
+    pf_stage_lds(wlds, reinterpret_cast<const u4*>(a.wg), NWF * 2 * 64);
     __syncthreads();
     const PfW2Lds ws_lds{wlds, lane};
     const auto ws = [&] { if constexpr ((DBG & 4) != 0) return EcWConst{lane}; else return ws_lds; }();
@@ -398,18 +422,19 @@ __global__ __launch_bounds__(NW * 64) void edgeconv4_kernel(EcArgs a) {
                 o[64] = h1;
             }
             if constexpr (PQF) {
-                u4* hbt = hb + parity * ((ODIM / 32) * 2 * 64);
+                u4* hbt = hb + pqf.nst * ((ODIM / 32) * 2 * 64);
                 pqf_stage<ODIM>(hbt, ch, wave * P + p, h0);
                 pqf_stage<ODIM>(hbt, ch + 64, wave * P + p, h1);
             }
         }
         if constexpr (PQF) {
-            // one barrier per tile: the staging buffer alternates, and a wave reaches the barrier of tile t + 1 only after it
-            // has finished reading tile t's buffer - which tile t + 2 overwrites
-            __syncthreads();
-            pqf_gemm<ODIM, 2 * S, NW>(a, hb + parity * ((ODIM / 32) * 2 * 64), __builtin_amdgcn_readfirstlane(wave), lane,
-                                      pf_xcd_tile(v, a.chunk) * NW * P);
-            parity ^= 1;
+            pqf.push(pf_xcd_tile(v, a.chunk) * NW * P);
+            if (pqf.nst == PQF_NT || vn >= vend) {             // uniform: flush the staged tiles (two barriers per flush)
+                __syncthreads();
+                pqf_gemm<ODIM, 2 * S, NW>(a, hb, pqf.nst, pqf.tpt, __builtin_amdgcn_readfirstlane(wave), lane);
+                __syncthreads();
+                pqf.nst = 0;
+            }
         }
         v = vn;
     }
@@ -446,9 +471,9 @@ __global__ __launch_bounds__(NW * 64) void edgeconv1n_kernel(EcArgs a) {
     const int col = lane & 15, q = lane >> 4;
     __shared__ u4 wlds[NWF * 128];
     __shared__ float plds[C3 ? 1 : NW * P][C3 ? 1 : S];
-    __shared__ u4 hb[PQF ? 2 * (ODIM / 32) * 2 * 64 : 1];
-    int parity = 0;
-    for (int i = threadIdx.x; i < NWF * 128; i += blockDim.x) wlds[i] = reinterpret_cast<const u4*>(a.wg)[i];
+    __shared__ u4 hb[PQF ? PQF_NT * (ODIM / 32) * 2 * 64 : 1];
+    PqfState pqf;
+    pf_stage_lds(wlds, reinterpret_cast<const u4*>(a.wg), NWF * 128);
     __syncthreads();
     const PfW2Lds ws{wlds, lane};
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(C3 ? a.xyz : a.pq), 0, 0x7fffffff, 0x00020000);
@@ -568,13 +593,23 @@ __global__ __launch_bounds__(NW * 64) void edgeconv1n_kernel(EcArgs a) {
             if (pt0 + p < a.T && (OBO == 4 || (q & 1) == 0))
                 a.out[(size_t)gi[p] * ODIM + ch] = hv;
             if constexpr (PQF) {
-                if (OBO == 4 || (q & 1) == 0) pqf_stage<ODIM>(hb + parity * ((ODIM / 32) * 2 * 64), ch, wave * P + p, hv);
+                if (OBO == 4 || (q & 1) == 0) pqf_stage<ODIM>(hb + pqf.nst * ((ODIM / 32) * 2 * 64), ch, wave * P + p, hv);
             }
         }
         if constexpr (PQF) {
-            __syncthreads();                       // one per tile (alternating staging buffer: see edgeconv4_kernel)
-            pqf_gemm<ODIM, PQ_ROWS, NW>(a, hb + parity * ((ODIM / 32) * 2 * 64), __builtin_amdgcn_readfirstlane(wave), lane, tile * NW * P);
-            parity ^= 1;
+            pqf.push(tile * NW * P);
+            if (pqf.nst == PQF_NT) {                 // uniform: flush (the tail is flushed after the loop)
+                __syncthreads();
+                pqf_gemm<ODIM, PQ_ROWS, NW>(a, hb, pqf.nst, pqf.tpt, __builtin_amdgcn_readfirstlane(wave), lane);
+                __syncthreads();
+                pqf.nst = 0;
+            }
+        }
+    }
+    if constexpr (PQF) {
+        if (pqf.nst > 0) {
+            __syncthreads();
+            pqf_gemm<ODIM, PQ_ROWS, NW>(a, hb, pqf.nst, pqf.tpt, __builtin_amdgcn_readfirstlane(wave), lane);
         }
     }
 }

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(FlowArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, q = lane >> 4;
     __shared__ f4 wl[6 * FLOW_REC / 4];
-    for (int i = threadIdx.x; i < 6 * FLOW_REC / 4; i += NW * 64) wl[i] = reinterpret_cast<const f4*>(a.w)[i];
+    pf_stage_lds(wl, reinterpret_cast<const f4*>(a.w), 6 * FLOW_REC / 4);
     __syncthreads();
     const float* wlf = reinterpret_cast<const float*>(wl);
 
@@ -201,36 +201,36 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(FlowArgs a) {
         // interpflow.py:339-345), a fixed order whichever workgroup that is.  No release fence (it would write the whole L2
         // back, tens of microseconds): the partials are agent-scope stores, waiting for their acknowledgement orders them
         // before the arrival count (the same protocol as train_fused.hip stat_flush).
-        __shared__ float sa[NW * 64], sb[NW * 64];
+        __shared__ float sa[NW * 64];
         __shared__ int is_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) is_last = atomicAdd(a.counter, 1u) == gridDim.x - 1 ? 1 : 0;
         __syncthreads();
         if (!is_last) return;
-        const int tid = threadIdx.x, NT = NW * 64;
+        // one WAVE per batch item (items wave, wave + NW, ...): lane-strided sums of the item's N / 16 wave-tile sums, then a
+        // fixed shuffle tree - no workgroup barrier per item
+        const int tid = threadIdx.x;
         const int per = a.N >> 4, half = a.rows >> 4;
-        float tot = 0.f;
-        for (int b = 0; b < a.B; ++b) {
+        for (int b = wave; b < a.B; b += NW) {
             float accl = 0.f, accz = 0.f;
-            for (int i = tid; i < per; i += NT) {
+            for (int i = lane; i < per; i += 64) {
                 accl += __hip_atomic_load(a.part + b * per + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 accz += __hip_atomic_load(a.part + half + b * per + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            sa[tid] = accl; sb[tid] = accz;
-            __syncthreads();
-            for (int st = NT / 2; st > 0; st >>= 1) {
-                if (tid < st) { sa[tid] += sa[tid + st]; sb[tid] += sb[tid + st]; }
-                __syncthreads();
-            }
-            if (tid == 0) {
-                const float l = sa[0] + a.ld_const * (float)a.N;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) { accl += __shfl_xor(accl, m); accz += __shfl_xor(accz, m); }
+            if (lane == 0) {
+                const float l = accl + a.ld_const * (float)a.N;
                 a.ldj[b] = l;
-                a.lps[b] = sb[0] + l;
-                tot += sb[0] + l;
+                a.lps[b] = accz + l;
+                if (b < NW * 64) sa[b] = accz + l;
             }
-            __syncthreads();
         }
+        __syncthreads();
+        float tot = 0.f;
+        if (tid == 0)
+            for (int b = 0; b < a.B; ++b) tot += b < NW * 64 ? sa[b] : a.lps[b];       // batch order, whatever wave produced the term
         if (tid == 0) {
             *a.logp = -tot / (float)a.B;
             __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch

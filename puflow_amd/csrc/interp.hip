@@ -42,7 +42,9 @@ struct InterpArgs {
     const float* w;
     long long off[15];
     float* u;            // [T*R,3]  row = n*R + r
-    int T, N, ntiles, R;     // R = upsampling ratio actually written (1..4; BIG: 5..32)
+    int T, N, ntiles, R;     // ntiles: WAVE tiles of 2 P points; R = upsampling ratio actually written (1..4; BIG: 5..32)
+    int per;                 // wave tiles per workgroup
+    int contiguous;          // the seven LDS-resident matrices lie back to back in the blob, in LDS order: one copy
 };
 
 template <int P, int NW, bool BIG = false>     // BIG: upsampling ratios 5..32 (all 32 rows of the last weight conv)
@@ -58,10 +60,13 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
     {
         auto stage = [&](int f0, int nf, long long off) {
             const u4* src = reinterpret_cast<const u4*>(a.w + off);
-            for (int i = threadIdx.x; i < nf * 128; i += blockDim.x) wl[f0 * 128 + i] = src[i];
+            pf_stage_lds(wl + f0 * 128, src, nf * 128);
         };
-        stage(L_DT, 4, a.off[0]); stage(L_ET, 8, a.off[5]); stage(L_WT, 8, a.off[8]); stage(L_D3, 8, a.off[1]);
-        stage(L_EC, 16, a.off[6]); stage(L_D6, 16, a.off[3]); stage(L_W3, 16, a.off[9]);
+        if (a.contiguous) stage(L_DT, L_END, a.off[0]);
+        else {
+            stage(L_DT, 4, a.off[0]); stage(L_ET, 8, a.off[5]); stage(L_WT, 8, a.off[8]); stage(L_D3, 8, a.off[1]);
+            stage(L_EC, 16, a.off[6]); stage(L_D6, 16, a.off[3]); stage(L_W3, 16, a.off[9]);
+        }
         __syncthreads();
     }
     const PfW2Lds wsDT{wl + L_DT * 128, lane}, wsET{wl + L_ET * 128, lane}, wsWT{wl + L_WT * 128, lane},
@@ -72,8 +77,12 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
     const float* sc = a.w + a.off[4];
     const float iDT = sc[0], iD3 = sc[1], iW1 = sc[2], iEC = sc[3], iW3 = sc[4], iW6 = sc[5];
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int pt0 = (tile * NW + wave) * P * 2;
+    // a workgroup owns `per` consecutive WAVE tiles (2 P points each), its waves take them round-robin: every CU gets the same
+    // number of wave tiles (4 x 2048 points: 16 per CU = one full round + four waves, instead of two full rounds on a third
+    // of the CUs with whole-workgroup tiles)
+    const int wt_end = min((int)(blockIdx.x + 1) * a.per, a.ntiles);
+    for (int wt = blockIdx.x * a.per + wave; wt < wt_end; wt += NW) {
+        const int pt0 = wt * P * 2;
         int gi[P], gj[P];
         bool ok[P];
         PfPairN e[P][1];                 // raw edge inputs (x_i, x_j, |x_i - x_j|, 1) in k-slots 0..7 (lanes q = 0)
@@ -264,9 +273,13 @@ extern "C" int pf_interp(const float* xyz, const float* z, const int* idx16, con
     InterpArgs a{};
     a.xyz = xyz; a.z = z; a.idx = idx16; a.w = w; a.u = u_out; a.T = B * N; a.N = N; a.R = R;
     for (int i = 0; i < 15; ++i) a.off[i] = off[i];
+    a.contiguous = off[5] == off[0] + 4 * 512 && off[8] == off[5] + 8 * 512 && off[1] == off[8] + 8 * 512 &&
+                   off[6] == off[1] + 8 * 512 && off[3] == off[6] + 16 * 512 && off[9] == off[3] + 16 * 512;
     const int nw = R <= 4 ? NW : NWB;
-    a.ntiles = (a.T + nw * P * 2 - 1) / (nw * P * 2);
-    const int grid = a.ntiles < 256 ? a.ntiles : 256;         // persistent: 152 KiB of LDS = one workgroup per CU
+    a.ntiles = (a.T + P * 2 - 1) / (P * 2);
+    const int wgt = (a.ntiles + nw - 1) / nw;
+    const int grid = wgt < 256 ? wgt : 256;                   // persistent: 152 KiB of LDS = one workgroup per CU
+    a.per = (a.ntiles + grid - 1) / grid;
     if (R <= 4) hipLaunchKernelGGL((interp_kernel<P, NW, false>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((interp_kernel<P, NWB, true>), dim3(grid), dim3(NWB * 64), 0, (hipStream_t)stream, a);
     return pf_last_launch_status();

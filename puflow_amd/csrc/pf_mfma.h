@@ -335,9 +335,25 @@ __device__ __forceinline__ void pf_mmn(const WS& ws, int frag0, const PfPairN (&
 }
 
 
-// cooperative global -> LDS copy of `nf4` float4 by the whole workgroup (call before a __syncthreads)
-__device__ __forceinline__ void pf_stage_lds(f4* __restrict__ dst, const f4* __restrict__ src, int nf4) {
-    for (int i = threadIdx.x; i < nf4; i += blockDim.x) dst[i] = src[i];
+// cooperative global -> LDS copy of n 16-byte words by the whole workgroup (call before a __syncthreads).  D loads per thread
+// are in flight before the first LDS store: a plain load -> store loop pays one full memory latency per iteration, and at
+// 88 - 152 KiB of weights per workgroup (6 - 32 iterations) that was most of what a small-batch launch of these kernels cost.
+template <int D = 8, class T4>
+__device__ __forceinline__ void pf_stage_lds(T4* __restrict__ dst, const T4* __restrict__ src, int n) {
+    const int nt = blockDim.x;
+    for (int base = threadIdx.x; base < n; base += nt * D) {
+        T4 v[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int i = base + k * nt;
+            v[k] = src[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int i = base + k * nt;
+            if (i < n) dst[i] = v[k];
+        }
+    }
 }
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)

@@ -134,11 +134,12 @@ struct CondArgs {
     float* st;                            // [T, 8]      s0 s1 s2 t0 t1 t2 - -
     float* cp;                            // [T, 64]
     int T, ntiles;
+    int contiguous;                       // M1 | H1 | S2 | T2 | ST4 lie back to back in the blob (packing.py packs them so): one copy
 };
 
 __device__ __forceinline__ f4 pf_scale(f4 v, float k) { return v * k; }
 
-// body of the conditioner stage of one unit for the workgroup's tiles  tile0, tile0 + tstride, ... < a.ntiles;  wl: LDS for
+// body of the conditioner stage of one unit for workgroup tile0 of tstride (a.ntiles = WAVE tiles of 16 points);  wl: LDS for
 // the unit's fragment images (cond_lds_bytes<ODIM>())
 template <int ODIM>
 constexpr int cond_lds_bytes() { return ((ODIM / 32) * ((ODIM / 16 + 1) / 2) + 12 * ((ODIM / 32 + 1) / 2) + 20) * 2048; }
@@ -155,10 +156,13 @@ __device__ __forceinline__ void cond_body(const CondArgs& a, u4* wl, int tile0, 
     {
         auto stage = [&](int f0, int nf, long long off) {
             const u4* src = reinterpret_cast<const u4*>(a.w + off);
-            for (int i = threadIdx.x; i < nf * 128; i += blockDim.x) wl[f0 * 128 + i] = src[i];
+            pf_stage_lds(wl + f0 * 128, src, nf * 128);
         };
-        stage(F_M1, MB * HP, a.off[0]); stage(F_H1, 12 * MP, a.off[3]); stage(F_S2, 8, a.off[4]); stage(F_T2, 8, a.off[6]);
-        stage(F_ST4, 4, a.off[8]);
+        if (a.contiguous) stage(F_M1, F_END, a.off[0]);
+        else {
+            stage(F_M1, MB * HP, a.off[0]); stage(F_H1, 12 * MP, a.off[3]); stage(F_S2, 8, a.off[4]); stage(F_T2, 8, a.off[6]);
+            stage(F_ST4, 4, a.off[8]);
+        }
         __syncthreads();
     }
     const PfW2Lds wsM1{wl + F_M1 * 128, lane}, wsH1{wl + F_H1 * 128, lane}, wsS2{wl + F_S2 * 128, lane},
@@ -171,8 +175,12 @@ __device__ __forceinline__ void cond_body(const CondArgs& a, u4* wl, int tile0, 
     const float* bT2 = a.w + a.off[7];
     const float* bST4 = a.w + a.off[9];
 
-    for (int tile = tile0; tile < a.ntiles; tile += tstride) {
-        const int g = (tile * NW + wave) * 16 + col;
+    // the workgroup owns the consecutive WAVE tiles (16 points each) [tile0 * per, (tile0 + 1) * per), its waves take them
+    // round-robin (tstride = workgroups of this unit: every one gets the same number of wave tiles)
+    const int per = (a.ntiles + tstride - 1) / tstride;
+    const int wt_end = min((tile0 + 1) * per, a.ntiles);
+    for (int wt = tile0 * per + wave; wt < wt_end; wt += NW) {
+        const int g = wt * 16 + col;
         const bool ok = g < a.T;
         const int pt = ok ? g : a.T - 1;
         PfPairN hp[1][HP];
@@ -288,16 +296,31 @@ void cond_allow_lds(KERNEL k, int bytes) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// the five LDS-resident matrices of a unit back to back in the blob, in LDS order?  (fragment pair = 512 floats)
+inline int cond_contiguous(const long long* off, int odim) {
+    const int HB = odim / 16, MB = odim / 32, HP = (HB + 1) / 2, MP = (MB + 1) / 2;
+    long long e = off[0] + (long long)MB * HP * 512;
+    if (off[3] != e) return 0;
+    e += 12ll * MP * 512;
+    if (off[4] != e) return 0;
+    e += 8 * 512;
+    if (off[6] != e) return 0;
+    e += 8 * 512;
+    return off[8] == e ? 1 : 0;
+}
+
 template <int ODIM, int CDIM>
 int launch_cond(CondArgs a, hipStream_t s) {
     constexpr int NW = COND_NW, lds = cond_lds_bytes<ODIM>();
-    a.ntiles = (a.T + NW * 16 - 1) / (NW * 16);
+    a.contiguous = cond_contiguous(a.off, ODIM);
+    a.ntiles = (a.T + 15) / 16;                            // wave tiles
+    const int wgt = (a.ntiles + NW - 1) / NW;
     int per_cu = (160 * 1024) / lds;                       // persistent workgroups that fit one CU's LDS
     const int by_waves = 32 / NW;
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     const int cap = 256 * per_cu;
-    const int grid = a.ntiles < cap ? a.ntiles : cap;
+    const int grid = wgt < cap ? wgt : cap;
     cond_allow_lds(cond_kernel<ODIM, CDIM>, lds);
     hipLaunchKernelGGL((cond_kernel<ODIM, CDIM>), dim3(grid), dim3(NW * 64), lds, s, a);
     return pf_last_launch_status();
@@ -344,9 +367,12 @@ extern "C" int pf_cond_all(const float* const* h, const float* w, const long lon
     if (!h || !w || !off || !st || !cp) return PF_ERR_NULL;
     if (T <= 0) return PF_ERR_SHAPE;
     CondAllArgs g{};
-    const int ntiles = (T + COND_NW * 16 - 1) / (COND_NW * 16);
-    // workgroups per unit: units 0 / 1 carry about half the work of a 128-channel unit; one workgroup per CU (LDS)
-    static const int share[6] = {32, 32, 48, 48, 48, 48};
+    const int ntiles = (T + 15) / 16;                      // wave tiles
+    const int wgt = (ntiles + COND_NW - 1) / COND_NW;      // workgroups that give every wave one tile
+    // workgroups per unit: units 0 / 1 carry about half the work of a 128-channel unit; one workgroup per CU (LDS).  Small
+    // batches (a 128-channel unit fits one round of 50 workgroups): the narrow units take two rounds of their cheaper body
+    static const int share_big[6] = {32, 32, 48, 48, 48, 48}, share_small[6] = {24, 32, 50, 50, 50, 50};
+    const int* share = wgt <= 50 ? share_small : share_big;
     g.first[0] = 0;
     for (int u = 0; u < 6; ++u) {
         if (!h[u]) return PF_ERR_NULL;
@@ -354,7 +380,8 @@ extern "C" int pf_cond_all(const float* const* h, const float* w, const long lon
         a.h = h[u]; a.w = w; a.c = c ? c[u] : nullptr; a.st = st + (size_t)u * T * 8; a.cp = cp + (size_t)u * T * 64; a.T = T;
         a.ntiles = ntiles;
         for (int i = 0; i < 13; ++i) a.off[i] = off[u * 13 + i];
-        const int n = ntiles < share[u] ? ntiles : share[u];
+        a.contiguous = cond_contiguous(a.off, u == 0 ? 32 : (u == 1 ? 64 : 128));
+        const int n = wgt < share[u] ? wgt : share[u];
         g.first[u + 1] = g.first[u] + n;
     }
     constexpr int lds = cond_lds_bytes<128>();

@@ -454,8 +454,11 @@ def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, objec
         def img(name, W):
             im, inv[name] = frag_pack_f16n_scaled(W)
             return B.add(im)
-        offs = {"M1": img("M1", m["W1"]), "M2": img("M2", m["W2"]), "H1": img("H1", H1),
-                "S2": img("S2", f["s_W2"]), "T2": img("T2", f["t_W2"]), "ST4": img("ST4", ST4)}
+        # M1 | H1 | S2 | T2 | ST4 back to back = the LDS image of cond_body (csrc/pointwise.hip): staged with ONE contiguous copy
+        offs = {"M1": img("M1", m["W1"]), "H1": img("H1", H1), "S2": img("S2", f["s_W2"]), "T2": img("T2", f["t_W2"]),
+                "ST4": img("ST4", ST4)}
+        assert offs["ST4"] + 4 * 512 == B.n and (B.n - offs["M1"]) % 512 == 0
+        offs["M2"] = img("M2", m["W2"])
         offs["b1"] = B.add(_pad_vec(m["b1"], ((m["b1"].size + 15) // 16) * 16) / inv["M1"])
         offs["bS2"] = B.add(f["s_b2"] / inv["S2"]); offs["bT2"] = B.add(f["t_b2"] / inv["T2"])
         offs["bST4"] = B.add(bST4 / inv["ST4"])
@@ -500,18 +503,21 @@ def pack_plan(plan: Dict[str, object], ec_mode: str = "f16n") -> Dict[str, objec
     s_ec, ec_imgs = grp(ectab_d, *ecG)
     s_w3, (i_w3,) = grp(ip["w_W3"])
     s_w6, (i_w6r, i_w6f) = grp(W6r, ip["w_W6"])
-    io = {
-        "dtab": B.add(i_dt), "d_W3": B.add(i_d3), "d_b3": B.add(ip["d_b3"] * s_d3),
-        "d_W6": B.add(i_d6),                                                        # folded: W0a.W6 on d2
+    io = {}
+    # the LDS image of interp_kernel, back to back in its order (4 + 8 + 8 + 8 + 16 + 16 + 16 = 76 fragment pairs of 2 KiB):
+    # edge tables (distance encoder, growth pre-activations, w1 bracket), d_W3, the growth chain, (W0a W6), w_W3 - ONE copy
+    for k, im in (("dtab", i_dt), ("ectab", ec_imgs[0]), ("w_b0", i_w1t), ("d_W3", i_d3), ("ec_w", np.concatenate(ec_imgs[1:])),
+                  ("d_W6", i_d6), ("w_W3", i_w3)):
+        io[k] = B.add(im)
+    assert B.n - io["dtab"] == 76 * 512
+    io.update({
+        "d_b3": B.add(ip["d_b3"] * s_d3),
         "scales": B.add(_pad_vec(np.array([1 / s_dt, 1 / s_d3, 1 / s_w1, 1 / s_ec, 1 / s_w3, 1 / s_w6], np.float32), 16)),
-        "ectab": B.add(ec_imgs[0]),                                                 # growth pre-activations
-        "ec_w": B.add(np.concatenate(ec_imgs[1:])),
         "w_W0": B.add(i_w0),                                                        # folded: W0b.Gout
-        "w_b0": B.add(i_w1t),
-        "w_W3": B.add(i_w3), "w_b3": B.add(ip["w_b3"] * s_w3),
+        "w_b3": B.add(ip["w_b3"] * s_w3),
         "w_W6": B.add(i_w6r), "w_b6": B.add(b6r * s_w6),
         "w_W6full": B.add(i_w6f), "w_b6full": B.add(ip["w_b6"] * s_w6),
-    }
+    })
     out["interp"] = [io[k] for k in INTERP_SLOTS]
     out["blob"] = B.data()
     return out

@@ -1023,6 +1023,16 @@ def bnmlp_fused(mlp, xa: Tensor, xb=None) -> Tensor:
     return out
 
 
+_SIDE = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 _DESC_BUF = {}
 
 
@@ -1278,6 +1288,31 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     csr16 = knn_csr(idx16) if fused_ec else None
     csr8 = knn_csr(idx8) if fused_ec else None
 
+    # ---- interpolation weights (interpflow.py:85-151): a function of xyz and the neighbour lists only, independent of the
+    # feature extractor / flow f chain that follows.  At 32 x 256 points no kernel of the step fills the chip, so this branch
+    # (two BatchNorm MLPs + one EdgeConv unit, forward and - autograd keeps the stream - backward) runs on a side stream
+    # beside the main chain; inside a captured step it becomes a parallel branch of the graph.  Scratch buffers are per
+    # (device, stream) (_ws / _stat), results are identical to the one-stream order (net.train_streams = False).
+    def interp_weights():
+        ip = net.interp
+        fd = torch.empty((B * N * 8, 10), dtype=torch.float32, device=xyz.device)        # inputs only: no gradient
+        _lib.check(_lib.load().pf_dist_feature(xyz.data_ptr(), idx8.data_ptr(), B, N, 8, fd.data_ptr(), _stream()), "pf_dist_feature")
+        fused_bn = _FUSED and not _sync_bn_active()
+        d = bnmlp_fused(ip.knn_context.distance_encoder.mlp, fd) if fused_bn else _mlp_bn(ip.knn_context.distance_encoder.mlp, fd)
+        feat = edgeconv_train(ip.knn_context.feat_conv, xyz, idx8, pooling=False, csr=csr8)      # d, feat: [E8,128]
+        if fused_bn:
+            return bnmlp_fused(ip.weight_unit.mlp, d, feat)       # on cat[d, feat] (interpflow.py:146) without building it
+        return _mlp_bn(ip.weight_unit.mlp, torch.cat([d, feat], dim=1))  # [E8,32]
+
+    side = None
+    if getattr(net, "train_streams", True) and not _sync_bn_active():
+        side = _side_stream(xyz.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            w = interp_weights()
+    else:
+        w = interp_weights()
+
     # ---- feature extractor
     cs: List[Tensor] = []
     h = xyz
@@ -1348,17 +1383,10 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     else:
         logp = -torch.mean(BatchSumFn.apply(z, 1) + ldj)
 
-    # ---- interpolation
-    ip = net.interp
-    fd = torch.empty((B * N * 8, 10), dtype=torch.float32, device=xyz.device)        # inputs only: no gradient
-    _lib.check(_lib.load().pf_dist_feature(xyz.data_ptr(), idx8.data_ptr(), B, N, 8, fd.data_ptr(), _stream()), "pf_dist_feature")
-    fused_bn = _FUSED and not _sync_bn_active()
-    d = bnmlp_fused(ip.knn_context.distance_encoder.mlp, fd) if fused_bn else _mlp_bn(ip.knn_context.distance_encoder.mlp, fd)
-    feat = edgeconv_train(ip.knn_context.feat_conv, xyz, idx8, pooling=False, csr=csr8)      # d, feat: [E8,128]
-    if fused_bn:
-        w = bnmlp_fused(ip.weight_unit.mlp, d, feat)              # on cat[d, feat] (interpflow.py:146) without building it
-    else:
-        w = _mlp_bn(ip.weight_unit.mlp, torch.cat([d, feat], dim=1))  # [E8,32]
+    # ---- interpolation: the weights w were started on the side stream before the feature extractor
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+        w.record_stream(torch.cuda.current_stream())
     zj = GatherRowsFn.apply(z, idx8)                              # [E8,3]
     fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)      # [T,3,R]
     u = fz.transpose(1, 2).reshape(B, N * R, 3)

@@ -212,9 +212,11 @@ def cnf_state_dict_spec():
     return spec
 
 
-def synth_cnf_state_dict(seed: int = 2021) -> "OrderedDict[str, torch.Tensor]":
+def synth_cnf_state_dict(seed: int = 2021, dynamics: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
     """Random-init weights of the continuous model: the shared extractor / interpolation part is the discrete
-    generator's, the ODE nets get nn.Linear-style fan-in scaling (large enough that dopri5 takes real steps)."""
+    generator's, the ODE nets get nn.Linear-style fan-in scaling (large enough that dopri5 takes real steps).
+    dynamics > 1 scales the main path of the ODE nets (`_layer` weights): a stiffer right-hand side, more and rejected steps -
+    bench.py --mode cnf uses it to give the solver the workload it has on the reference's pretrained checkpoint."""
     base = synth_state_dict(seed)
     rng = np.random.Generator(np.random.PCG64(seed + 104729))
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -227,6 +229,6 @@ def synth_cnf_state_dict(seed: int = 2021) -> "OrderedDict[str, torch.Tensor]":
             sd[key] = torch.tensor(0.0, dtype=torch.float32)
         else:
             fan_in = shape[1] if len(shape) == 2 else 64
-            scale = (1.6 if "_layer" in key else 1.0) / np.sqrt(fan_in)
+            scale = (1.6 * dynamics if "_layer" in key else 1.0) / np.sqrt(fan_in)
             sd[key] = torch.from_numpy((rng.uniform(-1, 1, shape) * scale).astype(np.float32))
     return sd

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("graph", ["1", "0"])
 def test_bench_train_fresh_process(graph):
     env = dict(os.environ, PF_BENCH_GRAPH=graph)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--steps", "4", "--warmup", "2"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--steps", "4", "--warmup", "2", "--cpu-seconds", "2"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -23,6 +23,12 @@ def test_bench_train_fresh_process(graph):
     assert rec["unit"] == "patches/s" and rec["value"] > 0 and rec["steps"] == 4
     assert rec["loss"] == rec["loss"] and abs(rec["loss"]) < 1e3          # finite, sane
     assert "capture failed" not in out.stderr
+    # the measurement contract of the line: roofline of the dominant launch group (live HIP events) and the CPU oracle's step
+    roof, cpu = rec["roofline"], rec["cpu_baseline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and 0 < roof["frac"] < 1 and roof["avg_launch_ms"] > 0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert cpu["kind"] == "port" and cpu["unit"] == "patches/s" and cpu["value"] > 0 and cpu["cores"] >= 1
+    assert rec["value"] > 10 * cpu["value"]
 
 
 def test_bench_reduced_precision_line():
@@ -75,3 +81,19 @@ def test_bench_gpus_n_starts_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT,
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_bench_cnf_line():
+    """`bench.py --mode cnf` (BASELINE configs[4]) on a small batch: the contract fields, the solver's work on the scaled
+    synthetic ODE (rejected steps included) and the same evaluation / accept / reject counts as the CPU oracle's dopri5."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "cnf", "--batch", "2", "--npoint", "256", "--steps", "2",
+                          "--warmup", "1", "--cpu-seconds", "1"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["unit"] == "patches/s" and rec["value"] > 0 and rec["steps"] == 2 and "configs[4]" in rec["config"]["workload"]
+    work = rec["config"]["solver_work"]
+    assert work["nfe"] >= 300 and work["rejected"] >= 1            # not the trivial 168-evaluation ODE of random-init weights
+    roof, cpu, par = rec["roofline"], rec["cpu_baseline"], rec["parity"]
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and cpu["kind"] == "port" and cpu["value"] > 0
+    assert par["nfe"][0] == par["nfe"][1] and par["accepted"][0] == par["accepted"][1] and par["rejected"][0] == par["rejected"][1]
+    assert par["max_abs_dx_vs_oracle"] < 2e-2      # a stiff synthetic map (|x| up to ~5) through 12 chained integrations at rtol 1e-5

@@ -329,3 +329,37 @@ def test_graphed_train_step_follows_the_eager_trajectory():
     assert np.isfinite(l_other) and l_other != losses[-1]
     step.set_lr(5e-4)
     assert float(optg.param_groups[0]["lr"]) == pytest.approx(5e-4)
+
+
+def test_side_stream_branch_of_the_training_forward_changes_nothing():
+    """The interpolation weights of the train-mode forward run on a side stream beside the feature extractor / flow f chain
+    (a parallel branch of a captured step).  Same loss, same outputs, same gradients as the one-stream order (float atomics of
+    the neighbour scatter make gradients equal to rounding, not to the bit), eagerly and from a captured graph."""
+    from puflow_amd import ops
+    from puflow_amd.interpflow import PointInterpFlow
+    sd = synth_state_dict(31)
+    dense = synth_patches(4, 1024, seed=32).to(DEV)
+    sparse = dense[:, ::4].contiguous()
+    res = {}
+    for streams in (False, True):
+        net = PointInterpFlow(3)
+        net.load_state_dict(sd)
+        net.set_to_initialized_state()
+        net = net.to(DEV).train()
+        net.train_streams = streams
+        x, logp = net(sparse, 4)
+        cd, _ = ops.chamfer_distance(x, dense)
+        loss = logp * 1e-4 + cd * 1e-1
+        loss.backward()
+        torch.cuda.synchronize()
+        res[streams] = (x.detach().clone(), float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None},
+                        {k: b.detach().clone() for k, b in net.named_buffers()})
+    xa, la, ga, ba = res[False]
+    xb, lb, gb, bb = res[True]
+    assert torch.equal(xa, xb) and la == lb
+    assert ga.keys() == gb.keys() and len(ga) > 150
+    for k in ga:
+        scale = float(ga[k].abs().max()) + 1e-12
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * scale, k
+    for k in ba:
+        assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-6, atol=1e-7), k

@@ -11,7 +11,7 @@ net = PointInterpFlow(3); net.load_state_dict(sd); net.set_to_initialized_state(
 for case in ("a", "b"):
     B, N, seed = (int(v) for v in g[f"{case}/meta"])
     xyz = synth_patches(B, N, seed=seed, surface=True).cuda()
-    for mode in ("f16n", "f16x2", "bf16x3", "f32"):
+    for mode in ("f16n", "f32"):
         net.ec_mode = mode
         st = net.forward_stages(xyz, 4)
         errs = {}

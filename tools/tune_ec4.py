@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""GPU box: edgeconv4_kernel (PF_EC_MODE=f16n) launch shapes vs the previous split-fp16 kernel on unit 3 at 32 x 2048:
-time per launch (HIP events, interleaved rounds, one process) and deviation from the bit-exact f32 MFMA kernel."""
+"""GPU box: edgeconv4_kernel (the product arithmetic, ec_mode "f16n") on unit 3 at 32 x 2048: time per launch (HIP events,
+interleaved rounds, one process) and deviation from the bit-exact f32 MFMA kernel.  The default library carries only the
+shipped launch shape; the alternatives and the timing-only ablations need a -DPF_TUNING_VARIANTS build:
+    python -c "from puflow_amd import build as b; b.build(defines=['PF_TUNING_VARIANTS'], tag='abl', only=('edgeconv.hip',))"
+    python tools/tune_ec4.py abl"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -39,13 +42,9 @@ def unit_inputs(mode, upto=3):
 
 e32, idx16, pq32, h32 = unit_inputs("f32")
 en, _, pqn, hn = unit_inputs("f16n")
-ex, _, pqx, hx = unit_inputs("f16x2")
-print(f"unit 3 |h|max {float(h32.abs().max()):.2f}   f16n vs f32 max|d| {float((hn - h32).abs().max()):.3e}   "
-      f"f16x2 vs f32 max|d| {float((hx - h32).abs().max()):.3e}", flush=True)
+print(f"unit 3 |h|max {float(h32.abs().max()):.2f}   f16n vs f32 max|d| {float((hn - h32).abs().max()):.3e}", flush=True)
 
-cands = [("f16n v0 (P1,NW16)", 7, 0, en, pqn, "ec4_w", lib), ("f16n v1 (P2,NW8)", 7, 1, en, pqn, "ec4_w", lib),
-         ("f16n v2 (P1,NW8)", 7, 2, en, pqn, "ec4_w", lib), ("f16n v3 (P2,NW4)", 7, 3, en, pqn, "ec4_w", lib),
-         ("f16x2 v2 (P1,NW16) [r1]", 4, 2, ex, pqx, "ec2h_w", lib)]
+cands = [("f16n v0 (P1,NW16)", 7, 0, en, pqn, "ec4_w", lib)]
 # side-by-side tuning builds: python tools/tune_ec4.py <tag> ...  loads libpuflow_hip_<tag>.so (puflow_amd.build.build(defines, tag))
 import ctypes
 for tag in sys.argv[1:]:
@@ -54,7 +53,7 @@ for tag in sys.argv[1:]:
         fn = getattr(l, name); fn.restype, fn.argtypes = res, args
     if tag == "abl":       # -DPF_TUNING_VARIANTS build: timing-only ablations of the (P1, NW16) shape
         cands += [(f"[abl] {what}", 7, v, en, pqn, "ec4_w", l) for v, what in
-                  ((0, "full"), (8, "no gathers"), (9, "no MFMAs"), (10, "no LDS weight reads"), (11, "no gathers, no LDS reads"),
+                  ((0, "full"), (1, "shape (P2,NW8)"), (2, "shape (P1,NW8)"), (3, "shape (P2,NW4)"), (8, "no gathers"), (9, "no MFMAs"), (10, "no LDS weight reads"), (11, "no gathers, no LDS reads"),
                    (12, "no gathers, no MFMAs"), (13, "no MFMAs, no LDS reads"), (14, "no gathers, LDS reads, growth epilogues"))]
         continue
     cands += [(f"[{tag}] f16n v0 (P1,NW16)", 7, 0, en, pqn, "ec4_w", l), (f"[{tag}] f16n v1 (P2,NW8)", 7, 1, en, pqn, "ec4_w", l)]
