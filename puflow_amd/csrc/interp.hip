@@ -269,18 +269,28 @@ extern "C" int pf_interp(const float* xyz, const float* z, const int* idx16, con
     if (!xyz || !z || !idx16 || !w || !off || !u_out) return PF_ERR_NULL;
     if (B <= 0 || N < 8 || (long long)B * N > (1ll << 28)) return PF_ERR_SHAPE;
     if (R < 1 || R > 32) return PF_ERR_UNSUPPORTED;          // r_max of WeightEstimationUnit (interpflow.py:142)
-    constexpr int P = PF_INTERP_P, NW = PF_INTERP_NW, NWB = 8;      // the R > 4 variant needs more registers: 2 waves per SIMD
+    constexpr int NWB = 8;                                     // the R > 4 variant needs more registers: 2 waves per SIMD
     InterpArgs a{};
     a.xyz = xyz; a.z = z; a.idx = idx16; a.w = w; a.u = u_out; a.T = B * N; a.N = N; a.R = R;
     for (int i = 0; i < 15; ++i) a.off[i] = off[i];
     a.contiguous = off[5] == off[0] + 4 * 512 && off[8] == off[5] + 8 * 512 && off[1] == off[8] + 8 * 512 &&
                    off[6] == off[1] + 8 * 512 && off[3] == off[6] + 16 * 512 && off[9] == off[3] + 16 * 512;
-    const int nw = R <= 4 ? NW : NWB;
-    a.ntiles = (a.T + P * 2 - 1) / (P * 2);
-    const int wgt = (a.ntiles + nw - 1) / nw;
-    const int grid = wgt < 256 ? wgt : 256;                   // persistent: 152 KiB of LDS = one workgroup per CU
-    a.per = (a.ntiles + grid - 1) / grid;
-    if (R <= 4) hipLaunchKernelGGL((interp_kernel<P, NW, false>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((interp_kernel<P, NWB, true>), dim3(grid), dim3(NWB * 64), 0, (hipStream_t)stream, a);
+    // launch shape (tools/tune_interp.py, MI355X): two column tiles per wave x 8 waves share every weight fragment read (half
+    // the LDS / L2 weight traffic per tile: 169 -> 160 us at 32 x 2048) once there are several tiles per wave; small batches
+    // keep one tile per wave x 12 waves (more waves to spread a handful of tiles over)
+    auto go = [&](auto pc, auto nwc, auto bigc) {
+        constexpr int P = decltype(pc)::value, NW = decltype(nwc)::value;
+        constexpr bool BIG = decltype(bigc)::value;
+        a.ntiles = (a.T + P * 2 - 1) / (P * 2);
+        const int wgt = (a.ntiles + NW - 1) / NW;
+        const int grid = wgt < 256 ? wgt : 256;               // persistent: 152 KiB of LDS = one workgroup per CU
+        a.per = (a.ntiles + grid - 1) / grid;
+        hipLaunchKernelGGL((interp_kernel<P, NW, BIG>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, a);
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if (R > 4) go(I1{}, std::integral_constant<int, NWB>{}, std::true_type{});
+    else if (a.T >= 4 * 2 * 2 * 8 * 256) go(I2{}, std::integral_constant<int, 8>{}, std::false_type{});      // >= 4 rounds of (2, 8) tiles
+    else go(std::integral_constant<int, PF_INTERP_P>{}, std::integral_constant<int, PF_INTERP_NW>{}, std::false_type{});
     return pf_last_launch_status();
 }

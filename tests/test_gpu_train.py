@@ -358,8 +358,8 @@ def test_side_stream_branch_of_the_training_forward_changes_nothing():
     xb, lb, gb, bb = res[True]
     assert torch.equal(xa, xb) and la == lb
     assert ga.keys() == gb.keys() and len(ga) > 150
+    floor = 1e-5 * max(float(g.abs().max()) for g in ga.values())        # a bias in front of a BatchNorm has gradient 0 + rounding noise
     for k in ga:
-        scale = float(ga[k].abs().max()) + 1e-12
-        assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * scale, k
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * float(ga[k].abs().max()) + floor, k
     for k in ba:
         assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-6, atol=1e-7), k

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: per-stage milliseconds of the eval forward at B x N (HIP events on the launch stream), eager and graph-replayed
-step time.  python tools/stage_times.py [B] [N]"""
+step time.  python tools/stage_times.py [B] [N] [fuse]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,9 +9,11 @@ from puflow_amd.weights import synth_patches, synth_state_dict
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+FUSE = int(sys.argv[3]) if len(sys.argv) > 3 else -1          # pf_edgeconv_pq: -1 by size, 0 never, 1 always
 net = PointInterpFlow(3); net.load_state_dict(synth_state_dict(2021)); net.set_to_initialized_state(); net = net.cuda().eval()
 xyz = synth_patches(B, N, seed=2021).cuda()
 e = net._engine(4)
+e.fuse_pq = FUSE
 pr = e.profile_stages(xyz, iters=8)
 tot = sum(pr.values())
 for k, v in pr.items():
