@@ -167,7 +167,23 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0, out
 
-    el, (x, logp) = timed(make_runner(pipe))
+    runner = make_runner(pipe)
+    el, (x, logp) = timed(runner)
+    # K steps of this path are a few tens of milliseconds at the driver's K = 20: too short a region to trust on its own.  The
+    # K-step pass is therefore REPEATED (each pass bracketed like the first: barrier + synchronize on both sides) until at least
+    # MIN_TIMED_S of timed work has accumulated; `value` / `ms_per_step` are totals over all passes, `timed_passes` says how many
+    # (every rank derives the same count from the max-over-ranks time of the first pass)
+    MIN_TIMED_S = 0.25
+    t1 = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+    passes = 1 + (0 if float(t1.item()) >= MIN_TIMED_S else min(int(MIN_TIMED_S / max(float(t1.item()), 1e-6)), 200))
+    for _ in range(passes - 1):
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x, logp = runner(args.steps)
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        el += time.perf_counter() - t0
     # secondary figure (never `value`): the same K steps with two of them in flight on two streams - independent batches
     # overlap; what a serving loop with more than one batch queued gets
     el_pipe = None
@@ -182,7 +198,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
     patches = (args.total_batch if args.scaling == "strong" else world * args.batch) * args.steps
-    value = patches / el
+    value = patches * passes / el
+    el /= passes                                          # per K-step pass from here on (ms_per_step = el / K)
 
     out = None
     if rank == 0:
@@ -298,6 +315,7 @@ def main():
             extra["reduced_precision"] = reduced_precision_line(args)
         out = {"metric": "patches/sec x4 2048->8192 (PU1K discrete, eval)", "value": value, "unit": "patches/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+               "timed_passes": passes, "timed_steps_total": passes * args.steps,
                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                # the arithmetic the path computes in: fp32 values, each product as 2-term split-fp16 on the fp16 MFMA
                # with fp32 accumulation (PF_EC_MODE=f32: plain f32 MFMA in the 128-channel EdgeConv units)

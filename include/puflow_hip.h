@@ -118,6 +118,15 @@ int pf_flow_fwd_logp(const float* xyz, const float* cp, const float* st, const f
 int pf_interp(const float* xyz, const float* z, const int* idx16, const float* w, const long long* off, float* u_out,
               int B, int N, int R, void* stream);
 
+/* The same module split so that its heavy part does not wait for the latents: pf_interp_weights writes the softmax weights
+ * aw [B*N][8][4] (a function of xyz and the neighbour lists only: it can run beside the feature extractor / flow f chain, e.g.
+ * as a parallel branch of a captured graph), pf_flow_inv_interp forms u[n R + r] = sum_k aw[n][k][r] z[idx8[n][k]] inside the
+ * flow-g kernel.  R <= 4.  The pair returns the bits of pf_interp followed by pf_flow_inv. */
+int pf_interp_weights(const float* xyz, const int* idx16, const float* w, const long long* off, float* aw_out, int B, int N,
+                      void* stream);
+int pf_flow_inv_interp(const float* aw, const float* z, const int* idx16, const float* cp, const float* st, const float* w,
+                       float* x, int B, int N, int R, void* stream);
+
 /* Chamfer forward: dist1/idx1 [B,N] (x -> y), dist2/idx2 [B,M] (y -> x), squared L2, first-minimum ties.
  * per_sample [B] = mean_n dist1 + mean_m dist2 (nullable); mean_sum [2] = {mean_b, sum_b} of per_sample
  * (nullable).  Replaces pytorch3d chamfer_distance (metric/loss.py:42), kaolin chamfer (metric/loss.py:35)

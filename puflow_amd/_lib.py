@@ -68,6 +68,8 @@ SIGNATURES = {
     "pf_logp": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_interp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_int, c_int, c_int,
                           c_void_p]),
+    "pf_interp_weights": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_longlong), c_void_p, c_int, c_int, c_void_p]),
+    "pf_flow_inv_interp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pf_chamfer_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
     "pf_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -59,6 +59,10 @@ struct FlowArgs {
     float* ldj; float* lps; float* logp;      // [B], [B], [1]
     float ld_const;
     int B, N;
+    // inv fed by the interpolation WEIGHTS instead of u (pf_flow_inv_interp; R <= 4): u[n R + r] = sum_k aw[n][k][r] z[j_k]
+    const float* aw;     // [T][8][4]  (nullable = read `in`)
+    const float* z;      // [T,3]
+    const int* idx;      // [T,16] (first 8 used), index inside the batch item
 };
 
 struct FlowCond { f4 cp[4]; f4 s0, s1; };        // one block's conditioning of one row: cp [64] (this lane's 16), s|t [8]
@@ -127,8 +131,29 @@ __global__ __launch_bounds__(NW * 64) void flow_kernel(FlowArgs a) {
         const int row = ok ? g : a.rows - 1;
         const int pt = row / a.R;
         float v[3], ld = 0.f;
+        if (INV && a.aw) {
+            // the weighted latent sum of the interpolation module (interpflow.py:183-185) in the order of interp_kernel's
+            // shuffle tree - ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)), products and sums unfused - so that the
+            // split path (pf_interp_weights + this) returns the bits of pf_interp + pf_flow_inv
+            const int r = row - pt * a.R, bN = (pt / a.N) * a.N;
+            const int4 j0 = *reinterpret_cast<const int4*>(a.idx + (size_t)pt * 16), j1 = *reinterpret_cast<const int4*>(a.idx + (size_t)pt * 16 + 4);
+            const int jj[8] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w};
+            float sk[8][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = a.in[(size_t)row * 3 + c];
+            for (int k = 0; k < 8; ++k) {
+                const float wk = a.aw[((size_t)pt * 8 + k) * 4 + r];
+                const float* zz = a.z + (size_t)(bN + jj[k]) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sk[k][c] = __fmul_rn(wk, zz[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v[c] = __fadd_rn(__fadd_rn(__fadd_rn(sk[0][c], sk[1][c]), __fadd_rn(sk[2][c], sk[3][c])),
+                                 __fadd_rn(__fadd_rn(sk[4][c], sk[5][c]), __fadd_rn(sk[6][c], sk[7][c])));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = a.in[(size_t)row * 3 + c];
+        }
         FlowCond cn = flow_cond(a.cp, a.st, a.T, INV ? 5 : 0, pt, q);
 
         pf_static_for<0, 6>([&](auto uc) {
@@ -329,6 +354,19 @@ extern "C" int pf_flow_inv(const float* u, const float* cp, const float* st, con
     if (T <= 0 || R <= 0 || (long long)T * R > (1ll << 30)) return PF_ERR_SHAPE;
     FlowArgs a{};
     a.in = u; a.cp = cp; a.st = st; a.w = w; a.out = x; a.ld_pt = nullptr; a.T = T; a.R = R; a.rows = T * R;
+    return launch<true>(a, (hipStream_t)stream);
+}
+
+// Flow g fed by the interpolation weights: x [B, N R, 3] = g(u) with u[n R + r] = sum_k aw[n][k][r] z[idx8[n][k]] formed inside
+// the kernel (R <= 4) - bit-identical to pf_interp followed by pf_flow_inv.  aw: pf_interp_weights.
+extern "C" int pf_flow_inv_interp(const float* aw, const float* z, const int* idx16, const float* cp, const float* st, const float* w,
+                                  float* x, int B, int N, int R, void* stream) {
+    if (!aw || !z || !idx16 || !cp || !st || !w || !x) return PF_ERR_NULL;
+    if (B <= 0 || N < 8 || (long long)B * N * R > (1ll << 30)) return PF_ERR_SHAPE;
+    if (R < 1 || R > 4) return PF_ERR_UNSUPPORTED;
+    FlowArgs a{};
+    a.in = nullptr; a.cp = cp; a.st = st; a.w = w; a.out = x; a.ld_pt = nullptr; a.T = B * N; a.R = R; a.rows = B * N * R;
+    a.aw = aw; a.z = z; a.idx = idx16; a.N = N;
     return launch<true>(a, (hipStream_t)stream);
 }
 

@@ -42,6 +42,8 @@ struct InterpArgs {
     const float* w;
     long long off[15];
     float* u;            // [T*R,3]  row = n*R + r
+    float* aw;           // non-null (R <= 4 only): write the softmax weights [T][8 neighbours][4 rows] INSTEAD of u (z unused):
+                         // the weighted latent sum then runs inside flow g (pf_flow_inv_interp), and this kernel no longer waits for z
     int T, N, ntiles, R;     // ntiles: WAVE tiles of 2 P points; R = upsampling ratio actually written (1..4; BIG: 5..32)
     int per;                 // wave tiles per workgroup
     int contiguous;          // the seven LDS-resident matrices lie back to back in the blob, in LDS order: one copy
@@ -250,6 +252,13 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
                     s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
                     av[r] = ex / s;
                 }
+                if (a.aw) {                                                      // weights only (uniform branch)
+                    if (ok[p] && q == 0) {
+                        f4 o = {av[0], av[1], av[2], av[3]};
+                        *reinterpret_cast<f4*>(a.aw + ((size_t)gi[p] * 8 + k) * 4) = o;
+                    }
+                    continue;
+                }
                 const float zj = a.z[(size_t)gj[p] * 3 + (q < 3 ? q : 0)];      // lane q handles latent channel q
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -264,14 +273,13 @@ __global__ __launch_bounds__(NW * 64) void interp_kernel(InterpArgs a) {
 
 }  // namespace
 
-extern "C" int pf_interp(const float* xyz, const float* z, const int* idx16, const float* w, const long long* off,
-                         float* u_out, int B, int N, int R, void* stream) {
-    if (!xyz || !z || !idx16 || !w || !off || !u_out) return PF_ERR_NULL;
+static int interp_launch(const float* xyz, const float* z, const int* idx16, const float* w, const long long* off,
+                         float* u_out, float* aw_out, int B, int N, int R, void* stream) {
     if (B <= 0 || N < 8 || (long long)B * N > (1ll << 28)) return PF_ERR_SHAPE;
     if (R < 1 || R > 32) return PF_ERR_UNSUPPORTED;          // r_max of WeightEstimationUnit (interpflow.py:142)
     constexpr int NWB = 8;                                     // the R > 4 variant needs more registers: 2 waves per SIMD
     InterpArgs a{};
-    a.xyz = xyz; a.z = z; a.idx = idx16; a.w = w; a.u = u_out; a.T = B * N; a.N = N; a.R = R;
+    a.xyz = xyz; a.z = z; a.idx = idx16; a.w = w; a.u = u_out; a.aw = aw_out; a.T = B * N; a.N = N; a.R = R;
     for (int i = 0; i < 15; ++i) a.off[i] = off[i];
     a.contiguous = off[5] == off[0] + 4 * 512 && off[8] == off[5] + 8 * 512 && off[1] == off[8] + 8 * 512 &&
                    off[6] == off[1] + 8 * 512 && off[3] == off[6] + 16 * 512 && off[9] == off[3] + 16 * 512;
@@ -294,3 +302,19 @@ extern "C" int pf_interp(const float* xyz, const float* z, const int* idx16, con
     else go(std::integral_constant<int, PF_INTERP_P>{}, std::integral_constant<int, PF_INTERP_NW>{}, std::false_type{});
     return pf_last_launch_status();
 }
+
+extern "C" int pf_interp(const float* xyz, const float* z, const int* idx16, const float* w, const long long* off,
+                         float* u_out, int B, int N, int R, void* stream) {
+    if (!xyz || !z || !idx16 || !w || !off || !u_out) return PF_ERR_NULL;
+    return interp_launch(xyz, z, idx16, w, off, u_out, nullptr, B, N, R, stream);
+}
+
+// The interpolation weights alone (everything of pf_interp but the weighted latent sum): aw [B*N][8][4] = softmax over the 8
+// neighbours of the first 4 rows of the weight unit's output (interpflow.py:180).  A function of xyz and the neighbour lists
+// only - it can run beside the feature extractor / flow f chain; pf_flow_inv_interp consumes it.
+extern "C" int pf_interp_weights(const float* xyz, const int* idx16, const float* w, const long long* off, float* aw_out,
+                                 int B, int N, void* stream) {
+    if (!xyz || !idx16 || !w || !off || !aw_out) return PF_ERR_NULL;
+    return interp_launch(xyz, nullptr, idx16, w, off, nullptr, aw_out, B, N, 4, stream);
+}
+

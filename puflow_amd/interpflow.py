@@ -171,6 +171,13 @@ class _Engine:
         self.interp_off = _lib.offsets(pk["interp"])
         self.ld_const = pk["ld_const"]
         self._logp_ws = {}
+        self._side = None
+        # interpolation weights as a parallel branch (side stream) + the weighted latent sum inside flow g: 1 = on, 0 = off.
+        # Off by default: measured on MI355X it does not pay at any batch size (4 x 2048: 0.245 -> 0.255 ms per captured step;
+        # 32 x 2048: unchanged) - the 152 KiB-LDS interpolation workgroups cannot share a CU with the EdgeConv chain's, so the
+        # branch only time-slices the CUs and pays a fork / join.  Kept because a caller that has no other use for the wait
+        # (e.g. z produced elsewhere, later) can start the weights early; bit-identical either way (tests/test_gpu_parity.py).
+        self.split_interp = 0
         self.fuse_pq = -1          # pf_edgeconv_pq: -1 = fuse the P|Q GEMM into the EdgeConv launch for small batches, 0 never, 1 always
 
     def _p(self, off: int) -> int:
@@ -267,6 +274,30 @@ class _Engine:
         _lib.check(self.lib.pf_interp(xyz.data_ptr(), z.data_ptr(), idx16.data_ptr(), self.base, self.interp_off,
                                       u.data_ptr(), B, N, R, self._stream()), "pf_interp")
         return u
+
+    def interp_weights(self, xyz: Tensor, idx16: Tensor) -> Tensor:
+        """Softmax weights of the interpolation module, aw [B*N, 8, 4] (pf_interp_weights): no latents needed."""
+        B, N, _ = xyz.shape
+        aw = torch.empty((B * N, 8, 4), dtype=torch.float32, device=xyz.device)
+        _lib.check(self.lib.pf_interp_weights(xyz.data_ptr(), idx16.data_ptr(), self.base, self.interp_off, aw.data_ptr(), B, N,
+                                              self._stream()), "pf_interp_weights")
+        return aw
+
+    def flow_g_interp(self, aw: Tensor, z: Tensor, idx16: Tensor, cp: Tensor, st: Tensor, R: int) -> Tensor:
+        """x = g(u) with u = the weighted latent sum formed inside the flow kernel (pf_flow_inv_interp, R <= 4)."""
+        B, N, _ = z.shape
+        x = torch.empty((B, N * R, 3), dtype=torch.float32, device=z.device)
+        _lib.check(self.lib.pf_flow_inv_interp(aw.data_ptr(), z.data_ptr(), idx16.data_ptr(), cp.data_ptr(), st.data_ptr(),
+                                               self._p(self.flow), x.data_ptr(), B, N, R, self._stream()), "pf_flow_inv_interp")
+        return x
+
+    def side_stream(self) -> "torch.cuda.Stream":
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def split_interp_for(self, T: int, R: int) -> bool:
+        return R <= 4 and self.split_interp == 1
 
     def flow_g(self, u: Tensor, cp: Tensor, st: Tensor, R: int) -> Tensor:
         B, NR, _ = u.shape
@@ -458,10 +489,24 @@ class PointInterpFlow(nn.Module):
         xyz = self._prep(xyz)
         e = self._engine(upratio)
         idx16 = e.knn(xyz)
-        _, cp, st = e.features(xyz, idx16, want_cs=False)
-        z, _, logp = e.flow_f(xyz, cp, st, ws)
-        u = e.interp(xyz, z, idx16, upratio)
-        x = e.flow_g(u, cp, st, upratio)
+        if e.split_interp_for(xyz.shape[0] * xyz.shape[1], upratio):
+            # the interpolation weights depend on xyz and the neighbour lists only: a parallel branch (side stream; inside a
+            # captured graph a parallel branch of it) beside EdgeConv chain -> conditioners -> flow f; the weighted latent
+            # sum happens inside the flow-g kernel.  Same bits as the fused order below.
+            main, side = torch.cuda.current_stream(), e.side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                aw = e.interp_weights(xyz, idx16)
+            _, cp, st = e.features(xyz, idx16, want_cs=False)
+            z, _, logp = e.flow_f(xyz, cp, st, ws)
+            main.wait_stream(side)
+            aw.record_stream(main)
+            x = e.flow_g_interp(aw, z, idx16, cp, st, upratio)
+        else:
+            _, cp, st = e.features(xyz, idx16, want_cs=False)
+            z, _, logp = e.flow_f(xyz, cp, st, ws)
+            u = e.interp(xyz, z, idx16, upratio)
+            x = e.flow_g(u, cp, st, upratio)
         if _CHECK_FINITE and not bool(torch.isfinite(x).all() & torch.isfinite(logp)):
             # the split-fp16 kernels overflow to inf/NaN when an activation or weight leaves the fp16 range (65504):
             # loud by construction; this opt-in check (it synchronises) turns it into an error with the remedy

@@ -448,3 +448,28 @@ def test_fused_pq_epilogue_is_bit_identical(lib, B, N):
         assert torch.equal(a["cs"][i], b["cs"][i]), i
     if B * N <= 4096:
         _check_stages(b, O.forward(sd, xyz.cpu(), 4, stages=True))
+
+
+@pytest.mark.parametrize("B,N,R", [(4, 2048, 4), (2, 250, 3), (1, 64, 1), (3, 1000, 2)])
+def test_split_interpolation_branch_is_bit_identical(lib, B, N, R):
+    """Small batches: the interpolation weights on a side stream beside the feature chain (pf_interp_weights) and the weighted
+    latent sum inside the flow-g kernel (pf_flow_inv_interp) - the bits of the fused pf_interp + pf_flow_inv, eagerly and from
+    a captured graph (where the side stream is a parallel branch)."""
+    sd = synth_state_dict(9)
+    net = _net(sd)
+    xyz = synth_patches(B, N, seed=B * N).to(DEV)
+    e = net._engine(4)
+    e.split_interp = 0
+    xa, la = net(xyz, R)
+    xa, la = xa.clone(), la.clone()
+    e.split_interp = 1
+    xb, lb = net(xyz, R)
+    assert torch.equal(xa, xb) and torch.equal(la, lb)
+    run = net.graphed(B, N, R)
+    for _ in range(3):
+        xc, lc = run(xyz)
+    assert torch.equal(xa, xc) and torch.equal(la, lc)
+    e.split_interp = 0
+    if B * N <= 4096:
+        ref = O.forward(sd, xyz.cpu(), R)
+        assert (xb.cpu() - ref[0]).abs().max() < 1e-5

@@ -1,0 +1,27 @@
+#!/bin/bash
+# GPU box: kernel trace of the captured training step (bench.py --mode train), per-step kernel table
+set -o pipefail
+TAG=${1:-r3_train}
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+(cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o tr -- python3 $ROOT/bench.py --mode train --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/trace.log" 2>&1)
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, re
+out = sys.argv[1]
+f = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+# 2 eager warm-up steps + 3 eager profiled steps (bench's call profile) + capture + 25 replays: count = calls of the one-per-step fused optimizer kernel
+n = max(int(r["Calls"]) for r in rows if "adam_update_kernel" in r["Name"])
+tot = 0.0
+lines = []
+for r in rows:
+    per = float(r["TotalDurationNs"]) / n / 1e3
+    tot += per
+    lines.append(f"{re.sub(r'\(anonymous namespace\)::', '', r['Name'])[:100]:100s} {int(r['Calls']) / n:6.1f}/step {per:8.1f} us/step")
+open(out + "/kernel_stats_per_step.txt", "w").write(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --mode train --steps 20 --warmup 5   ({n} executions of the step's kernels)\n" + "\n".join(lines[:70]) + f"\ntotal {tot / 1e3:.2f} ms of kernel time per step, {sum(int(r['Calls']) for r in rows) / n:.0f} launches per step\n")
+print("\n".join(lines[:45])); print(f"total {tot / 1e3:.2f} ms, launches {sum(int(r['Calls']) for r in rows) / n:.0f}")
+PY
+find "$OUT" -name "*kernel_trace.csv" -delete
+echo "done $TAG"

@@ -10,10 +10,12 @@ from puflow_amd.weights import synth_patches, synth_state_dict
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 FUSE = int(sys.argv[3]) if len(sys.argv) > 3 else -1          # pf_edgeconv_pq: -1 by size, 0 never, 1 always
+SPLIT = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # interpolation weights as a parallel branch: 0 off (default), 1 on
 net = PointInterpFlow(3); net.load_state_dict(synth_state_dict(2021)); net.set_to_initialized_state(); net = net.cuda().eval()
 xyz = synth_patches(B, N, seed=2021).cuda()
 e = net._engine(4)
 e.fuse_pq = FUSE
+e.split_interp = SPLIT
 pr = e.profile_stages(xyz, iters=8)
 tot = sum(pr.values())
 for k, v in pr.items():
