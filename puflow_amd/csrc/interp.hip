@@ -283,9 +283,10 @@ static int interp_launch(const float* xyz, const float* z, const int* idx16, con
     for (int i = 0; i < 15; ++i) a.off[i] = off[i];
     a.contiguous = off[5] == off[0] + 4 * 512 && off[8] == off[5] + 8 * 512 && off[1] == off[8] + 8 * 512 &&
                    off[6] == off[1] + 8 * 512 && off[3] == off[6] + 16 * 512 && off[9] == off[3] + 16 * 512;
-    // launch shape (tools/tune_interp.py, MI355X): two column tiles per wave x 8 waves share every weight fragment read (half
-    // the LDS / L2 weight traffic per tile: 169 -> 160 us at 32 x 2048) once there are several tiles per wave; small batches
-    // keep one tile per wave x 12 waves (more waves to spread a handful of tiles over)
+    // launch shape: one column tile per wave x 12 waves.  (2, 8) - two tiles share each weight fragment read, half the LDS / L2
+    // weight traffic per tile - measures 169 -> 160 us in a back-to-back loop of this kernel alone (tools/tune_interp.py) and
+    // changes nothing inside the step (191 us either way): the kernel is bound by its dependent MFMA -> VALU -> MFMA chains
+    // (four per SIMD in both shapes), not by weight traffic.  The same holds for cond_all_kernel at (8, 2): 83 us either way.
     auto go = [&](auto pc, auto nwc, auto bigc) {
         constexpr int P = decltype(pc)::value, NW = decltype(nwc)::value;
         constexpr bool BIG = decltype(bigc)::value;
@@ -295,10 +296,7 @@ static int interp_launch(const float* xyz, const float* z, const int* idx16, con
         a.per = (a.ntiles + grid - 1) / grid;
         hipLaunchKernelGGL((interp_kernel<P, NW, BIG>), dim3(grid), dim3(NW * 64), 0, (hipStream_t)stream, a);
     };
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    if (R > 4) go(I1{}, std::integral_constant<int, NWB>{}, std::true_type{});
-    else if (a.T >= 4 * 2 * 2 * 8 * 256) go(I2{}, std::integral_constant<int, 8>{}, std::false_type{});      // >= 4 rounds of (2, 8) tiles
+    if (R > 4) go(std::integral_constant<int, 1>{}, std::integral_constant<int, NWB>{}, std::true_type{});
     else go(std::integral_constant<int, PF_INTERP_P>{}, std::integral_constant<int, PF_INTERP_NW>{}, std::false_type{});
     return pf_last_launch_status();
 }
