@@ -248,8 +248,13 @@ def main():
             roof["traffic"] = pmc[key].get("hbm_bytes_per_launch")
             roof["profile"] = {"file": "profiles/pmc_latest.json", "kernel": key, "avg_launch_ms": pmc[key].get("avg_us", 0.0) / 1e3,
                                "mfma_util_pct": pmc[key].get("mfma_util_pct"), "shader_clock_ghz": pmc[key].get("shader_clock_ghz")}
+            alg_bytes = T * (512 * 4 + 16 * 4 + 128 * 4)                     # P|Q row + 16 indices + the 128-channel output row, per point
+            if roof["traffic"]:
+                roof["traffic_vs_algorithmic"] = roof["traffic"] / alg_bytes
             roof["traffic_note"] = ("bytes per launch at 32 x 2048 (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction); "
-                                    "algorithmic HBM bytes per launch = PQ 134.2 MB + idx 4.2 MB + out 33.6 MB")
+                                    "algorithmic HBM bytes per launch = PQ 134.2 MB + idx 4.2 MB + out 33.6 MB; the measured figure is an UPPER bound: the x2 "
+                                    "is calibrated for 16-B-per-lane loads only and half of this kernel's gathers are 4-B loads, and Infinity-"
+                                    "Cache hits (the 134 MB table was written by the kernel before) are counted as traffic")
         except Exception:
             pass
         # kNN: north_star asks for HBM GB/s; the kernel is VALU/selection-bound by construction (216 flop/B), so the VALU
