@@ -117,8 +117,12 @@ __device__ __forceinline__ void stat_flush(float (&s0)[NT], float (&s1)[NT], int
             f.acc[k * 2 * STAT_W + c] = 0.0; f.acc[k * 2 * STAT_W + STAT_W + c] = 0.0;
         }
         if (f.mode == 1) {
-            const double mean = a0 / f.R;
-            double var = a1 / f.R - mean * mean;
+            // a0, a1 are sums of (y - pivot), (y - pivot)^2 with pivot = the running mean the kernels started from (read here
+            // before it is updated below; 0 without running statistics)
+            const double pv = f.run_mean ? (double)f.run_mean[c] : 0.0;
+            const double dm = a0 / f.R;
+            const double mean = pv + dm;
+            double var = a1 / f.R - dm * dm;
             if (var < 0.0) var = 0.0;
             const float rstd = 1.0f / sqrtf((float)var + f.eps);
             const float sc = f.gamma[c] * rstd;
@@ -189,9 +193,16 @@ __global__ __launch_bounds__(256) void ec_fwd_kernel(EcFwdArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
     const f4 ident = ident_b(row, q);
-    float s0[NT], s1[NT];
+    // column statistics are accumulated CENTRED on a pivot (the layer's running mean as every workgroup reads it at its
+    // start - the last workgroup updates it only after all have arrived): sum (y - p), sum (y - p)^2.  E[y^2] - E[y]^2 on raw
+    // fp32 partial sums loses |mean|^2 / var digits; the running mean tracks the batch mean, so the centred form does not
+    float s0[NT], s1[NT], piv[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) s0[nt] = s1[nt] = 0.f;
+    for (int nt = 0; nt < NT; ++nt) {
+        s0[nt] = s1[nt] = 0.f;
+        const int col = nt * 16 + row;
+        piv[nt] = (!OUT && a.fin.run_mean && col < a.nout) ? a.fin.run_mean[col] : 0.f;
+    }
     const int tile0 = blockIdx.x * 4 + wave;
     int jnext = tile0 < a.ntiles ? a.idx[(long long)tile0 * 16 + row] : 0;
     for (int tile = tile0; tile < a.ntiles; tile += gridDim.x * 4) {
@@ -243,7 +254,8 @@ __global__ __launch_bounds__(256) void ec_fwd_kernel(EcFwdArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const float v = acc[nt][r];
                         a.Y[(e0 + 4 * q + r) * a.ldy + a.col0 + col] = v;
-                        s0[nt] += v; s1[nt] = fmaf(v, v, s1[nt]);
+                        const float vc = v - piv[nt];
+                        s0[nt] += vc; s1[nt] = fmaf(vc, vc, s1[nt]);
                     }
                 }
             }
@@ -1032,12 +1044,13 @@ __global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
     const bool vec = (a.kin & 3) == 0 && (a.ldx & 3) == 0;
     const float slope = a.sc ? a.slope : 1.f;                     // raw input: identity
-    float s0[NT], s1[NT], bv[NT];
+    float s0[NT], s1[NT], bv[NT], piv[NT];                      // piv: centred statistics, see ec_fwd_kernel
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         s0[nt] = s1[nt] = 0.f;
         const int col = nt * 16 + row;
         bv[nt] = (a.bias && col < a.nout) ? a.bias[col] : 0.f;
+        piv[nt] = (a.want_stats && a.fin.run_mean && col < a.nout) ? a.fin.run_mean[col] : 0.f;
     }
     for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
         const int r0 = tile * 16;
@@ -1082,7 +1095,8 @@ __global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
                         float v = acc[nt][r] + bv[nt];
                         if (a.accum) v += *op;
                         *op = v;
-                        s0[nt] += v; s1[nt] = fmaf(v, v, s1[nt]);
+                        const float vc = v - piv[nt];
+                        s0[nt] += vc; s1[nt] = fmaf(vc, vc, s1[nt]);
                     }
                 }
             }
@@ -1362,7 +1376,7 @@ constexpr int BNL_CHUNK = 256;
 
 int bnl_check(const PfBnMlpTrain* p) {
     if (!p) return PF_ERR_NULL;
-    if (p->rows < 16 || (p->nl != 2 && p->nl != 3)) return PF_ERR_SHAPE;
+    if (p->rows < 16 || (p->nl != 2 && p->nl != 3)) return PF_ERR_SHAPE;       // (rows >= 2 also keeps the unbiased-variance factor R / (R - 1) finite)
     if (p->kin0a < 1 || p->kin0a > 128 || p->kin0b < 0 || p->kin0b > 128) return PF_ERR_UNSUPPORTED;
     if (p->kin0b > 0 && (p->kin0a & 3)) return PF_ERR_UNSUPPORTED;
     for (int l = 0; l < p->nl; ++l)

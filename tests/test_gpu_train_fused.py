@@ -316,3 +316,34 @@ def test_training_forward_backward_other_up_ratios(R):
     assert u_f.shape == (2, 128 * R, 3)
     assert (u_f - u_u).abs().max() < 2e-5 and abs(l_f - l_u) < 1e-5 * abs(l_u)
     assert float((g_f - g_u).abs().max()) < 2e-2 * float(g_u.abs().max())
+
+
+def test_fused_batchnorm_statistics_with_a_large_mean():
+    """The fused kernels accumulate a layer's batch statistics centred on its running mean (sum (y - p), sum (y - p)^2).  A
+    BatchNorm input whose mean is 300 standard deviations away from zero - a conv bias of 30 on activations of std 0.1 - loses
+    ~1e-2 of its variance with E[y^2] - E[y]^2 on fp32 partial sums; with running statistics that have tracked the batch (as in
+    training after a few steps) the fused path matches the two-pass un-fused kernels and float64."""
+    from puflow_amd import train_ops
+    from puflow_amd.interpflow import _InterpParams
+    torch.manual_seed(3)
+    rows = 32768
+    mlp = _InterpParams().cuda().train().knn_context.distance_encoder.mlp
+    x = torch.randn(rows, 10, device="cuda")
+    with torch.no_grad():
+        mlp[0].weight.mul_(0.03)
+        mlp[0].bias.fill_(30.0)
+        y0 = torch.nn.functional.linear(x.double(), mlp[0].weight.view(64, 10).double(), mlp[0].bias.double())
+        mean64, var64 = y0.mean(0), y0.var(0, unbiased=False)
+        assert float((mean64.abs() / var64.sqrt()).min()) > 100          # the regime this test is about
+    outs = {}
+    for fused in (True, False):
+        with torch.no_grad():
+            mlp[1].running_mean.copy_(mean64.float()); mlp[1].running_var.fill_(1.0)     # running statistics that have tracked the data
+            mlp[4].running_mean.zero_(); mlp[4].running_var.fill_(1.0)
+        out = train_ops.bnmlp_fused(mlp, x) if fused else train_ops._mlp_bn(mlp, x)
+        outs[fused] = (out.detach().clone(), mlp[1].running_var.clone())
+    (o_f, v_f), (o_u, v_u) = outs[True], outs[False]
+    want = 0.9 * 1.0 + 0.1 * var64 * rows / (rows - 1)                                   # momentum 0.1, unbiased variance
+    assert float(((v_f.double() - want).abs() / want).max()) < 1e-5
+    assert float(((v_u.double() - want).abs() / want).max()) < 1e-5
+    assert float((o_f - o_u).abs().max()) < 2e-4 * float(o_u.abs().max())
