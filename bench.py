@@ -456,16 +456,18 @@ def bench_train(args, world, rank, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
     roof = cpu = None
+    # ---- dominant launch group, timed live: HIP events around every C-ABI call of three EAGER steps (the same kernels
+    # the graph replays).  The step is ~440 launches of 5 - 100 us; the largest share belongs to the backward of the
+    # 128-channel EdgeConv units (pf_ec_train_bwd: conv_out / growth dA, one split-K launch for all weight gradients, the
+    # neighbour scatter, two P|Q GEMMs), priced against the fp32 matrix pipe it runs on (v_mfma_f32_16x16x4_f32).
+    # Every rank runs these steps (they contain the gradient all-reduce); rank 0 reports.
+    from puflow_amd._prof import profile_calls
+    with profile_calls() as prof:
+        for _ in range(3):
+            tm.train_step(batch, opt)
+        torch.cuda.synchronize()
+    barrier()
     if rank == 0:
-        # ---- dominant launch group, timed live: HIP events around every C-ABI call of three EAGER steps (the same kernels
-        # the graph replays).  The step is ~440 launches of 5 - 100 us; the largest share belongs to the backward of the
-        # 128-channel EdgeConv units (pf_ec_train_bwd: conv_out / growth dA, one split-K launch for all weight gradients, the
-        # neighbour scatter, two P|Q GEMMs), priced against the fp32 matrix pipe it runs on (v_mfma_f32_16x16x4_f32).
-        from puflow_amd._prof import profile_calls
-        with profile_calls() as prof:
-            for _ in range(3):
-                tm.train_step(batch, opt)
-            torch.cuda.synchronize()
         tab = prof.table()
         calls_ms = {k: v[1] / 3 for k, v in sorted(tab.items(), key=lambda kv: -kv[1][1])[:8]}
         evs = prof.events.get("pf_ec_train_bwd", [])

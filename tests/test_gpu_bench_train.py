@@ -97,3 +97,16 @@ def test_bench_cnf_line():
     assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and cpu["kind"] == "port" and cpu["value"] > 0
     assert par["nfe"][0] == par["nfe"][1] and par["accepted"][0] == par["accepted"][1] and par["rejected"][0] == par["rejected"][1]
     assert par["max_abs_dx_vs_oracle"] < 2e-2      # a stiff synthetic map (|x| up to ~5) through 12 chained integrations at rtol 1e-5
+
+
+def test_bench_train_two_ranks_self_launched():
+    """`bench.py --gpus 2 --mode train` (rehearsal knobs: both ranks on cuda:0, gloo): the per-rank steps, the call profile's
+    eager steps (they contain the gradient all-reduce, so EVERY rank must run them) and the report on rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PF_BENCH_SINGLE_DEVICE="1", PF_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "train", "--batch", "4", "--steps", "3",
+                          "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["loss"] == rec["loss"]
+    assert rec["roofline"]["avg_launch_ms"] > 0 and rec["cpu_baseline"] is None
