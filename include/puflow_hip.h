@@ -358,6 +358,57 @@ int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream);
 int pf_mlp_train_fwd_batch(const PfMlpTrain* descs, int n, void* dev_descs, void* stream);
 int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_descs, void* stream);
 
+/* Weight gradients only (split-K launch + reduction) of n <= 16 networks whose dz / h / dout are already in memory
+ * (written by pf_flowchain_bwd); same descriptors as pf_mlp_train_bwd_batch. */
+int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_descs, void* stream);
+
+/* ---- all flow blocks of one direction of the training step: one launch forward, four backward (csrc/train_flowchain.hip) ----
+ * Replaces PointInterpFlow.f / .g over FlowBlock.forward / .inverse (modules/discrete/interpflow.py:46-82, 302-321) in train()
+ * mode: ActNorm (normalize.py:28-54), the invertible 3x3 linear (permutate.py:117-124), the additive coupling with its LinearA1D
+ * conditioner on cat[coords[:td], c] (coupling.py:55-58,114-118; interpflow.py:22-43; hidden width 64, 32 / 64 / 128
+ * conditioning channels), the reverse permutation (permutate.py:77-80) and the conditional affine injector with s, t given per ORIGINAL
+ * point (coupling.py:120-137).  inv = 0: x [T,3] -> z, ssum[i] = sum(s_i), ld[i] = (sum(logs_i) + log|det W_i|) n_ld;
+ * inv = 1: u [T R, 3] -> x through the blocks in reverse order, conditioning rows shared by R in {1,2,4,8,16} consecutive rows.
+ * Slabs (`pin`, `mid`, `o`, `h1`, `h2`, `dz1`, `dz2`, `dob`) are indexed by block and kept between forward and backward.
+ * Backward: dout [rows,3] (+ dssum, dld [nb], nullable) -> dx (nullable), dc[i] [rows / R, cc[i]], ds[i], dt[i] [rows / R, 3] and
+ * every parameter gradient.  part: pf_flowchain_part_floats() floats; counter: one zero word (left zero); ws:
+ * pf_flowchain_ws_floats() floats; dev_descs: nb * sizeof(PfMlpTrain) bytes. */
+#define PF_FLOWCHAIN_MAXB 8
+typedef struct PfFlowChain {
+    int nb, rows, R, inv;
+    int td[PF_FLOWCHAIN_MAXB];       /* untouched leading coordinates of block i's coupling (1 or 2) */
+    int cc[PF_FLOWCHAIN_MAXB];       /* conditioning channels of block i (32, 64 or 128) */
+    float n_ld;                      /* inv = 0: points per batch item (factor of the log-determinant) */
+    const float* x;                  /* [rows, 3] */
+    const float* c[PF_FLOWCHAIN_MAXB];                                       /* [rows / R, cc[i]] */
+    const float* s[PF_FLOWCHAIN_MAXB]; const float* t[PF_FLOWCHAIN_MAXB];    /* [rows / R, 3] */
+    const float* logs[PF_FLOWCHAIN_MAXB]; const float* bias[PF_FLOWCHAIN_MAXB]; const float* W[PF_FLOWCHAIN_MAXB];
+    const float* w0[PF_FLOWCHAIN_MAXB];                                      /* [64, td + cc] (no bias) */
+    const float* w2[PF_FLOWCHAIN_MAXB]; const float* b2[PF_FLOWCHAIN_MAXB];  /* [64, 64], [64] */
+    const float* w4[PF_FLOWCHAIN_MAXB]; const float* b4[PF_FLOWCHAIN_MAXB];  /* [3 - td, 64], [3 - td] */
+    float* pin; float* mid;          /* [nb][rows, 3]: block input; y (inv = 0) / v (inv = 1) */
+    float* o;                        /* [nb][rows, 2] coupling shift (inv = 1) */
+    float* h1; float* h2;            /* [nb][rows, 64] */
+    float* out;                      /* [rows, 3] */
+    float* ssum; float* ld;          /* [nb] (inv = 0) */
+    float* part; unsigned* counter;
+    /* backward only */
+    const float* dout; const float* dssum; const float* dld;
+    float* dx;
+    float* dc[PF_FLOWCHAIN_MAXB]; float* ds[PF_FLOWCHAIN_MAXB]; float* dt[PF_FLOWCHAIN_MAXB];
+    float* dz1; float* dz2;          /* [nb][rows, 64] */
+    float* dob;                      /* [nb] slabs of rows * 2 floats; slab i holds [rows, 3 - td_i] */
+    float* dlogs[PF_FLOWCHAIN_MAXB]; float* dbias[PF_FLOWCHAIN_MAXB]; float* dW[PF_FLOWCHAIN_MAXB];
+    float* dw0[PF_FLOWCHAIN_MAXB]; float* dw2[PF_FLOWCHAIN_MAXB]; float* db2[PF_FLOWCHAIN_MAXB];
+    float* dw4[PF_FLOWCHAIN_MAXB]; float* db4[PF_FLOWCHAIN_MAXB];
+    float* ws; long long ws_floats;
+    void* dev_descs;
+} PfFlowChain;
+long long pf_flowchain_ws_floats(const PfFlowChain* a);
+long long pf_flowchain_part_floats(const PfFlowChain* a);
+int pf_flowchain_fwd(const PfFlowChain* a, void* stream);
+int pf_flowchain_bwd(const PfFlowChain* a, void* stream);
+
 /* ---- element-wise half of a flow block in the training step, fused per direction (csrc/train_flow.hip) ----
  * Replaces ActNorm / InvertibleConv1x1-style 3x3 linear / AffineCoupling / reverse permutation / AffineInjector of
  * modules/discrete/interpflow.py:46-82 (normalize.py:28-54, permutate.py:77-124, coupling.py:55-137) in train() mode.

@@ -626,3 +626,43 @@ extern "C" int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_
     hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(256), 0, s, b.p[0], dd);
     return pf_last_launch_status();
 }
+
+// weight gradients only: dz / h / dout of every network are already in memory (csrc/train_flowchain.hip writes them from its
+// own chain kernel); split-K launch + reduction over all n networks
+extern "C" int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_descs, void* stream) {
+    if (!descs || !dev_descs) return PF_ERR_NULL;
+    if (n < 1 || n > MLP_BATCH_MAX) return PF_ERR_SHAPE;
+    size_t lds_w = 0;
+    int cmax = 1, tmax = 1;
+    MlpBatch b{};
+    for (int k = 0; k < n; ++k) {
+        const PfMlpTrain* p = descs + k;
+        int st = mlp_check(p);
+        if (st) return st;
+        if (p->nl != descs[0].nl || !p->dout || !p->ws) return PF_ERR_NULL;
+        for (int l = 0; l < p->nl - 1; ++l)
+            if (!p->h[l] || !p->dz[l]) return PF_ERR_NULL;
+        for (int l = 0; l < p->nl; ++l)
+            if (!p->dW[l]) return PF_ERR_NULL;
+        if (p->ws_floats < pf_mlp_train_ws_floats(p)) return PF_ERR_WORKSPACE;
+        const MlpShape sh = mlp_shape(*p);
+        const MlpDwLayout L = mlp_dw_layout(*p, sh);
+        int ramax = 0, rbmax = 0, total = 0;
+        for (int l = 0; l < p->nl; ++l) {
+            ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l];
+            total += sh.wo[l] * (sh.in[l] + 1);
+        }
+        const size_t w2 = sizeof(float) * (size_t)MLP_EB * ((ramax + 16) + (rbmax + 16));
+        lds_w = w2 > lds_w ? w2 : lds_w;
+        const int nchunk = (p->rows + mlp_chunk(p->rows) - 1) / mlp_chunk(p->rows);
+        cmax = nchunk > cmax ? nchunk : cmax;
+        tmax = total > tmax ? total : tmax;
+        b.p[k] = *p;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mlp_desc_upload_kernel, dim3(1), dim3(256), 0, s, b, (unsigned*)dev_descs, (int)(n * sizeof(PfMlpTrain) / 4));
+    const PfMlpTrain* dd = (const PfMlpTrain*)dev_descs;
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(256), lds_w, s, b.p[0], dd);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(256), 0, s, b.p[0], dd);
+    return pf_last_launch_status();
+}

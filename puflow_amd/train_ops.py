@@ -855,6 +855,114 @@ class InjectInv2Fn(Function):
         return du, ds, dt, None
 
 
+class FlowChainFn(Function):
+    """All flow blocks of one direction as ONE autograd node: one launch forward, four backward (csrc/train_flowchain.hip).
+    apply(inv, R, n_ld, nb, x, *c[nb], *s[nb], *t[nb], *[logs, bias, W, w0, w2, b2, w4, b4] per block)
+      inv = 0 (PointInterpFlow.f, interpflow.py:302-310): x [B,N,3] -> (z, ssum [nb] = sum(s_i), ld [nb] = (sum(logs_i) + log|det W_i|) n_ld)
+      inv = 1 (PointInterpFlow.g, interpflow.py:312-321): u [B,N R,3] -> (x,), blocks in reverse order, c / s / t per ORIGINAL point
+    Replaces, per block, FlowParamsFn + FlowAffineFn + MlpFn + CoupleInject2Fn / InjectInv2Fn and the gradient-accumulation adds
+    autograd inserted between them."""
+    NPRM = 8
+
+    @staticmethod
+    def _desc(inv, R, n_ld, nb, x, cs, ss, tt, prm):
+        d = _lib.PfFlowChain()
+        d.nb, d.rows, d.R, d.inv, d.n_ld = nb, x.numel() // 3, R, inv, float(n_ld)
+        d.x = x.data_ptr()
+        for i in range(nb):
+            lg, bi, W, w0, w2, b2, w4, b4 = prm[8 * i:8 * i + 8]
+            d.cc[i] = cs[i].shape[-1]
+            d.td[i] = w0.shape[1] - d.cc[i]
+            d.c[i], d.s[i], d.t[i] = cs[i].data_ptr(), ss[i].data_ptr(), tt[i].data_ptr()
+            d.logs[i], d.bias[i], d.W[i] = lg.data_ptr(), bi.data_ptr(), W.data_ptr()
+            d.w0[i], d.w2[i], d.b2[i], d.w4[i], d.b4[i] = w0.data_ptr(), w2.data_ptr(), b2.data_ptr(), w4.data_ptr(), b4.data_ptr()
+        return d
+
+    @staticmethod
+    def forward(ctx, inv, R, n_ld, nb, x, *ts):
+        lib = _lib.load()
+        x = x.contiguous()
+        cs = [t.contiguous() for t in ts[:nb]]
+        ss = [t.contiguous() for t in ts[nb:2 * nb]]
+        tt = [t.contiguous() for t in ts[2 * nb:3 * nb]]
+        prm = [t.contiguous() for t in ts[3 * nb:]]
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        d = FlowChainFn._desc(inv, R, n_ld, nb, x, cs, ss, tt, prm)
+        rows = d.rows
+        keep = torch.empty((2, nb, rows, 3), **f32)                      # block inputs | y (f) / v (g)
+        hh = torch.empty((2, nb, rows, 64), **f32)
+        o = torch.empty((nb, rows, 2), **f32) if inv else None
+        out = torch.empty_like(x)
+        ssum, ld = torch.empty((nb,), **f32), torch.empty((nb,), **f32)   # sum(s) | log-det term, per block
+        d.pin, d.mid, d.h1, d.h2, d.out = keep[0].data_ptr(), keep[1].data_ptr(), hh[0].data_ptr(), hh[1].data_ptr(), out.data_ptr()
+        d.o = _ptr(o)
+        d.ssum, d.ld = ssum.data_ptr(), ld.data_ptr()
+        d.part = _ws(dev, nb * ((rows + 15) // 16)).data_ptr()
+        d.counter = _counter(dev).data_ptr()
+        _lib.check(lib.pf_flowchain_fwd(ctypes.byref(d), _stream()), "pf_flowchain_fwd")
+        ctx.cfg = (inv, R, float(n_ld), nb, [t.shape for t in ts[3 * nb:]])
+        ctx.save_for_backward(x, out, keep, hh, *(() if o is None else (o,)), *cs, *ss, *tt, *prm)
+        if inv:
+            return out
+        return out, ssum, ld
+
+    @staticmethod
+    def backward(ctx, dout, dssum=None, dld=None):
+        lib = _lib.load()
+        inv, R, n_ld, nb, pshapes = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        x, out, keep, hh = sv[:4]
+        k = 4
+        o = None
+        if inv:
+            o, k = sv[4], 5
+        cs, ss, tt, prm = sv[k:k + nb], sv[k + nb:k + 2 * nb], sv[k + 2 * nb:k + 3 * nb], sv[k + 3 * nb:]
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        d = FlowChainFn._desc(inv, R, n_ld, nb, x, cs, ss, tt, prm)
+        rows = d.rows
+        T = rows // R
+        d.pin, d.mid, d.h1, d.h2, d.out = keep[0].data_ptr(), keep[1].data_ptr(), hh[0].data_ptr(), hh[1].data_ptr(), out.data_ptr()
+        d.o = _ptr(o)
+        dout = dout.contiguous()
+        dssum = dssum.contiguous() if dssum is not None else None
+        dld = dld.contiguous() if dld is not None else None
+        d.dout, d.dssum, d.dld = dout.data_ptr(), _ptr(dssum), _ptr(dld)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[4] else None
+        d.dx = _ptr(dx)
+        dcs = [torch.empty_like(c) for c in cs]
+        dst = torch.empty((2, nb, T, 3), **f32)
+        dz = torch.empty((2, nb, rows, 64), **f32)
+        dob = torch.empty((nb, rows, 2), **f32)
+        d.dz1, d.dz2, d.dob = dz[0].data_ptr(), dz[1].data_ptr(), dob.data_ptr()
+        sizes = [int(p.numel()) for p in prm]
+        flat = torch.empty((sum(sizes),), **f32)                         # every parameter gradient of the chain, one buffer
+        gp, off = [], 0
+        for n_ in sizes:
+            gp.append(flat[off:off + n_])
+            off += n_
+        for i in range(nb):
+            d.dc[i], d.ds[i], d.dt[i] = dcs[i].data_ptr(), dst[0, i].data_ptr(), dst[1, i].data_ptr()
+            g = gp[8 * i:8 * i + 8]
+            d.dlogs[i], d.dbias[i], d.dW[i] = g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr()
+            d.dw0[i], d.dw2[i], d.db2[i], d.dw4[i], d.db4[i] = (g[3].data_ptr(), g[4].data_ptr(), g[5].data_ptr(), g[6].data_ptr(),
+                                                                 g[7].data_ptr())
+        npart = lib.pf_flowchain_part_floats(ctypes.byref(d))
+        need = lib.pf_flowchain_ws_floats(ctypes.byref(d))
+        if need < 0 or npart < 0:
+            raise _lib.PuflowHipError("pf_flowchain: unsupported shape")
+        ws = _ws(dev, npart + need)
+        d.part = ws.data_ptr()
+        d.ws, d.ws_floats = ws.data_ptr() + 4 * npart, need
+        d.dev_descs = _desc_buf(dev).data_ptr()
+        _lib.check(lib.pf_flowchain_bwd(ctypes.byref(d), _stream()), "pf_flowchain_bwd")
+        sshape = ss[0].shape
+        grads = [g.view(shp) for g, shp in zip(gp, pshapes)]
+        return (None, None, None, None, dx, *dcs, *[dst[0, i].view(sshape) for i in range(nb)],
+                *[dst[1, i].view(sshape) for i in range(nb)], *grads)
+
+
 class MlpFn(Function):
     """2- or 3-layer point-wise MLP (LinearA1D / FeatMergeUnit, interpflow.py:22-43, 251-258) on cat[y[:, :td], c[row // cdiv]]:
     one launch forward, three backward (csrc/train_mlp.hip).  wb = W0, b0, W1, b1[, W2, b2] (None for a missing bias)."""
@@ -1247,6 +1355,8 @@ class _Lin:
 
 
 _FAN = os.environ.get("PF_TRAIN_FAN", "1") != "0"
+# all flow blocks of a direction as one autograd node (FlowChainFn); "0" = one node per block piece (the A/B reference)
+_CHAIN = os.environ.get("PF_TRAIN_CHAIN", "1") != "0"
 
 
 def _flow_param_aliases(net):
@@ -1269,6 +1379,19 @@ def _flow_param_aliases(net):
         a["net"] = [[_Lin(a["w0"][j]), _Lin(a["w2"][j], a["b2"][j]), _Lin(a["w4"][j], a["b4"][j])] for j in range(2)]
         out.append(a)
     return out
+
+
+def _flow_chain_params(net):
+    """The eight parameters of every flow block, twice (f and g share them): two alias lists for FlowChainFn."""
+    plist = []
+    for blk in net.flow_blocks:
+        L = blk.coupling1.bias_net.layers
+        plist += [blk.actnorm.logs, blk.actnorm.bias, blk.permutate1.permutater.W, L[0].weight, L[2].weight, L[2].bias,
+                  L[4].weight, L[4].bias]
+    if _FAN:
+        flat = list(ParamFanFn.apply(tuple(2 for _ in plist), *plist))
+        return flat[0::2], flat[1::2]
+    return plist, plist
 
 
 def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
@@ -1335,6 +1458,26 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
                 prm += [L[0].weight, L[2].weight, L[2].bias, L[4].weight, L[4].bias]
         cidx = tuple(i for i in range(net.num_blocks) for _ in range(2))
         st_all = CondNetBatchFn.apply(cidx, *cs, *prm)
+
+    # ---- f, interpolation, g with every flow block of a direction in one autograd node (csrc/train_flowchain.hip).  ActNorm's
+    # data-dependent init needs each block's input on the host side of the chain: the first step takes the per-block path below
+    nb = net.num_blocks
+    chain = (_CHAIN and _FUSED and st_all is not None and nb <= 8 and R in (1, 2, 4, 8, 16)
+             and all(b.actnorm.is_inited for b in net.flow_blocks) and all(c.shape[-1] in (32, 64, 128) for c in cs)
+             and all(b.coupling1.bias_net.layers[2].weight.shape == (64, 64) for b in net.flow_blocks))
+    if chain:
+        pf, pg = _flow_chain_params(net)
+        ss, ts_ = [st_all[2 * i] for i in range(nb)], [st_all[2 * i + 1] for i in range(nb)]
+        z, ssum, ld = FlowChainFn.apply(0, 1, float(N), nb, xyz, *cs, *ss, *ts_, *pf)
+        logp = -(BatchSumFn.apply(z, 1).mean() + ld.sum() - ssum.sum() / B)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            w.record_stream(torch.cuda.current_stream())
+        zj = GatherRowsFn.apply(z, idx8)
+        fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)
+        u = fz.transpose(1, 2).reshape(B, N * R, 3)
+        x = FlowChainFn.apply(1, R, float(N), nb, u, *cs, *ss, *ts_, *pg)
+        return x, logp
 
     # ---- f + log-likelihood
     p = xyz

@@ -363,3 +363,46 @@ def test_side_stream_branch_of_the_training_forward_changes_nothing():
         assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * float(ga[k].abs().max()) + floor, k
     for k in ba:
         assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-6, atol=1e-7), k
+
+
+@pytest.mark.parametrize("B,N", [(4, 256), (3, 100)])
+def test_flow_chain_node_matches_the_per_block_nodes(B, N):
+    """All flow blocks of a direction as one autograd node (csrc/train_flowchain.hip, FlowChainFn) against one node per block
+    piece (PF_TRAIN_CHAIN=0: train_flow.hip + train_mlp.hip): outputs, loss and every gradient.  Same products in the same
+    MFMA order; sums over rows are taken in a different (fixed) order, hence rounding-level differences.  N = 100: partial
+    16-row tiles in both directions."""
+    from puflow_amd import ops, train_ops as T
+    from puflow_amd._prof import profile_calls
+    from puflow_amd.interpflow import PointInterpFlow
+    sd = synth_state_dict(41)
+    dense = synth_patches(B, 4 * N, seed=42).to(DEV)
+    sparse = dense[:, ::4].contiguous()
+    res = {}
+    keep = T._CHAIN
+    try:
+        for chain in (False, True):
+            T._CHAIN = chain
+            net = PointInterpFlow(3)
+            net.load_state_dict(sd)
+            net.set_to_initialized_state()
+            net = net.to(DEV).train()
+            with profile_calls() as prof:
+                x, logp = net(sparse, 4)
+                cd, _ = ops.chamfer_distance(x, dense)
+                loss = logp * 1e-4 + cd * 1e-1
+                loss.backward()
+            torch.cuda.synchronize()
+            assert len(prof.events.get("pf_flowchain_fwd", [])) == (2 if chain else 0)        # the path under test really ran
+            assert len(prof.events.get("pf_flowchain_bwd", [])) == (2 if chain else 0)
+            res[chain] = (x.detach().clone(), float(logp), float(loss),
+                          {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    finally:
+        T._CHAIN = keep
+    xa, pa, la, ga = res[False]
+    xb, pb, lb, gb = res[True]
+    assert float((xa - xb).abs().max()) <= 2e-6
+    assert abs(pa - pb) <= 1e-6 * abs(pa) and abs(la - lb) <= 1e-6 * abs(la)
+    assert ga.keys() == gb.keys() and len(ga) > 150
+    floor = 1e-5 * max(float(g.abs().max()) for g in ga.values())
+    for k in ga:
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-4 * float(ga[k].abs().max()) + floor, k

@@ -19,7 +19,8 @@ lines = []
 for r in rows:
     per = float(r["TotalDurationNs"]) / n / 1e3
     tot += per
-    lines.append(f"{re.sub(r'\(anonymous namespace\)::', '', r['Name'])[:100]:100s} {int(r['Calls']) / n:6.1f}/step {per:8.1f} us/step")
+    nm = re.sub(r"\(anonymous namespace\)::", "", r["Name"])[:100]
+    lines.append(f"{nm:100s} {int(r['Calls']) / n:6.1f}/step {per:8.1f} us/step")
 open(out + "/kernel_stats_per_step.txt", "w").write(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --mode train --steps 20 --warmup 5   ({n} executions of the step's kernels)\n" + "\n".join(lines[:70]) + f"\ntotal {tot / 1e3:.2f} ms of kernel time per step, {sum(int(r['Calls']) for r in rows) / n:.0f} launches per step\n")
 print("\n".join(lines[:45])); print(f"total {tot / 1e3:.2f} ms, launches {sum(int(r['Calls']) for r in rows) / n:.0f}")
 PY
