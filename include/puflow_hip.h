@@ -362,7 +362,7 @@ int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_descs, void
  * (written by pf_flowchain_bwd); same descriptors as pf_mlp_train_bwd_batch. */
 int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_descs, void* stream);
 
-/* ---- all flow blocks of one direction of the training step: one launch forward, four backward (csrc/train_flowchain.hip) ----
+/* ---- all flow blocks of one direction of the training step: two launches forward, four backward (csrc/train_flowchain.hip) ----
  * Replaces PointInterpFlow.f / .g over FlowBlock.forward / .inverse (modules/discrete/interpflow.py:46-82, 302-321) in train()
  * mode: ActNorm (normalize.py:28-54), the invertible 3x3 linear (permutate.py:117-124), the additive coupling with its LinearA1D
  * conditioner on cat[coords[:td], c] (coupling.py:55-58,114-118; interpflow.py:22-43; hidden width 64, 32 / 64 / 128
@@ -392,6 +392,7 @@ typedef struct PfFlowChain {
     float* out;                      /* [rows, 3] */
     float* ssum; float* ld;          /* [nb] (inv = 0) */
     float* part; unsigned* counter;
+    float* img;                      /* pf_flowchain_img_floats(): packed weights, written by the forward, read by the backward */
     /* backward only */
     const float* dout; const float* dssum; const float* dld;
     float* dx;
@@ -406,6 +407,7 @@ typedef struct PfFlowChain {
 } PfFlowChain;
 long long pf_flowchain_ws_floats(const PfFlowChain* a);
 long long pf_flowchain_part_floats(const PfFlowChain* a);
+long long pf_flowchain_img_floats(const PfFlowChain* a);
 int pf_flowchain_fwd(const PfFlowChain* a, void* stream);
 int pf_flowchain_bwd(const PfFlowChain* a, void* stream);
 

@@ -46,54 +46,75 @@ __device__ __forceinline__ f4 fc_lrelu(f4 z) {
     return r;
 }
 
-// 64 x w block (w = 32, 64 or 128 columns from column `off`) of a row-major matrix with row stride `ld_src` -> LDS
-// [64][w + 4], or transposed [w][FC_LD]; eight loads in flight per thread before the first LDS store
-template <bool TRANS>
-__device__ __forceinline__ void fc_stage64(float* dst, const float* __restrict__ src, int ld_src, int off, int w) {
-    const int sft = 31 - __clz(w);
-    for (int i0 = 0; i0 < 64 * w; i0 += 256 * 8) {
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = i0 + 256 * k + threadIdx.x, c = i >> sft, u = i & (w - 1);
-            v[k] = src[(size_t)c * ld_src + off + u];
+// The LDS image of a block's conditioner is written ONCE per call by a small pack kernel (flowchain_pack_kernel) into global
+// memory in exactly the layout the chain kernels use; a workgroup then stages a block as one linear float4 copy, fetched into
+// registers while the previous block is still being computed (the strided, transposing reads of the parameter tensors cost
+// seven dependent memory round trips per block when every workgroup did them itself: 100 us per launch instead of ~30).
+__device__ __forceinline__ void fc_image_fwd(float* img, const PfFlowChain& a, int i) {
+    const int td = a.td[i], cc = a.cc[i], wo = 3 - td, ld0 = cc + 4;
+    for (int k = blockIdx.z * blockDim.x + threadIdx.x; k < FF_FLOATS; k += gridDim.z * blockDim.x) {
+        float v = 0.f;
+        if (k < FF_W1) {
+            const int c = k / ld0, u = k - c * ld0;
+            if (c < 64 && u < cc) v = a.w0[i][(size_t)c * (td + cc) + td + u];
+        } else if (k < FF_W2) {
+            const int c = (k - FF_W1) / FC_LD, u = (k - FF_W1) % FC_LD;
+            if (u < 64) v = a.w2[i][c * 64 + u];
+        } else if (k < FF_B1) {
+            const int c = (k - FF_W2) / FC_LD, u = (k - FF_W2) % FC_LD;
+            if (c < wo && u < 64) v = a.w4[i][c * 64 + u];
+        } else if (k < FF_B2) v = a.b2[i][k - FF_B1];
+        else if (k < FF_WX) { if (k - FF_B2 < wo) v = a.b4[i][k - FF_B2]; }
+        else {
+            const int c = (k - FF_WX) >> 2, j = (k - FF_WX) & 3;
+            if (j < td) v = a.w0[i][(size_t)c * (td + cc) + j];
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = i0 + 256 * k + threadIdx.x, c = i >> sft, u = i & (w - 1);
-            dst[TRANS ? u * FC_LD + c : c * (w + 4) + u] = v[k];
-        }
+        img[k] = v;
     }
+}
+__device__ __forceinline__ void fc_image_bwd(float* img, const PfFlowChain& a, int i) {
+    const int td = a.td[i], cc = a.cc[i], wo = 3 - td;
+    for (int k = blockIdx.z * blockDim.x + threadIdx.x; k < FB_FLOATS; k += gridDim.z * blockDim.x) {
+        float v = 0.f;
+        if (k < FB_T1) {
+            const int u = k / FC_LD, c = k % FC_LD;
+            if (u < cc && c < 64) v = a.w0[i][(size_t)c * (td + cc) + td + u];
+        } else if (k < FB_T2) {
+            const int u = (k - FB_T1) / FC_LD, c = (k - FB_T1) % FC_LD;
+            if (c < 64) v = a.w2[i][c * 64 + u];
+        } else if (k < FB_WX) {
+            const int u = (k - FB_T2) / 20, c = (k - FB_T2) % 20;
+            if (c < wo) v = a.w4[i][c * 64 + u];
+        } else {
+            const int c = (k - FB_WX) >> 2, j = (k - FB_WX) & 3;
+            if (j < td) v = a.w0[i][(size_t)c * (td + cc) + j];
+        }
+        img[k] = v;
+    }
+}
+__global__ __launch_bounds__(256) void flowchain_pack_kernel(PfFlowChain a) {
+    const int i = blockIdx.x;
+    if (blockIdx.y == 0) fc_image_fwd(a.img + (size_t)i * FF_FLOATS, a, i);
+    else fc_image_bwd(a.img + (size_t)a.nb * FF_FLOATS + (size_t)i * FB_FLOATS, a, i);
 }
 
-__device__ __forceinline__ void fc_stage_fwd(float* lds, const PfFlowChain& a, int i, int td) {
-    const int wo = 3 - td;
-    const int cc = a.cc[i];
-    fc_stage64<false>(lds + FF_W0, a.w0[i], td + cc, td, cc);
-    fc_stage64<false>(lds + FF_W1, a.w2[i], 64, 0, 64);
-    for (int k = threadIdx.x; k < 16 * 64; k += 256) {
-        const int c = k >> 6, u = k & 63;
-        lds[FF_W2 + c * FC_LD + u] = c < wo ? a.w4[i][c * 64 + u] : 0.f;
-    }
-    if (threadIdx.x < 64) lds[FF_B1 + threadIdx.x] = a.b2[i][threadIdx.x];
-    if (threadIdx.x < 16) lds[FF_B2 + threadIdx.x] = (int)threadIdx.x < wo ? a.b4[i][threadIdx.x] : 0.f;
-    {
-        const int c = threadIdx.x >> 2, j = threadIdx.x & 3;
-        lds[FF_WX + threadIdx.x] = j < td ? a.w0[i][(size_t)c * (td + cc) + j] : 0.f;
+// image -> registers -> LDS: N4 float4 per image, FC_PRE per thread
+constexpr int FC_PRE = 15;
+static_assert(FF_FLOATS % 4 == 0 && FB_FLOATS % 4 == 0 && FF_FLOATS <= FC_PRE * 4 * 64 * FC_NW && FB_FLOATS <= FC_PRE * 4 * 64 * FC_NW, "image");
+template <int FLOATS>
+__device__ __forceinline__ void fc_fetch(f4 (&pre)[FC_PRE], const float* __restrict__ img) {
+#pragma unroll
+    for (int n = 0; n < FC_PRE; ++n) {
+        const int k = threadIdx.x + 64 * FC_NW * n;
+        pre[n] = k < FLOATS / 4 ? reinterpret_cast<const f4*>(img)[k] : pf_splat(0.f);
     }
 }
-__device__ __forceinline__ void fc_stage_bwd(float* lds, const PfFlowChain& a, int i, int td) {
-    const int wo = 3 - td;
-    const int cc = a.cc[i];
-    fc_stage64<true>(lds + FB_T0, a.w0[i], td + cc, td, cc);
-    fc_stage64<true>(lds + FB_T1, a.w2[i], 64, 0, 64);
-    for (int k = threadIdx.x; k < 16 * 64; k += 256) {
-        const int c = k >> 6, u = k & 63;
-        lds[FB_T2 + u * 20 + c] = c < wo ? a.w4[i][c * 64 + u] : 0.f;
-    }
-    {
-        const int c = threadIdx.x >> 2, j = threadIdx.x & 3;
-        lds[FB_WX + threadIdx.x] = j < td ? a.w0[i][(size_t)c * (td + cc) + j] : 0.f;
+template <int FLOATS>
+__device__ __forceinline__ void fc_commit(const f4 (&pre)[FC_PRE], float* lds) {
+#pragma unroll
+    for (int n = 0; n < FC_PRE; ++n) {
+        const int k = threadIdx.x + 64 * FC_NW * n;
+        if (k < FLOATS / 4) reinterpret_cast<f4*>(lds)[k] = pre[n];
     }
 }
 
@@ -246,12 +267,15 @@ __global__ __launch_bounds__(64 * FC_NW) void flowchain_fwd_kernel(PfFlowChain a
     float p[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = a.x[(size_t)pr * 3 + c];
+    f4 pre[FC_PRE];
+    fc_fetch<FF_FLOATS>(pre, a.img + (size_t)(a.inv ? a.nb - 1 : 0) * FF_FLOATS);
     for (int k = 0; k < a.nb; ++k) {
         const int i = a.inv ? a.nb - 1 - k : k;
         const int td = a.td[i];
         __syncthreads();
-        fc_stage_fwd(lds, a, i, td);
+        fc_commit<FF_FLOATS>(pre, lds);
         __syncthreads();
+        if (k + 1 < a.nb) fc_fetch<FF_FLOATS>(pre, a.img + (size_t)(a.inv ? i - 1 : i + 1) * FF_FLOATS);
         float M[9], el[3], b[3];
 #pragma unroll
         for (int j = 0; j < 9; ++j) M[j] = prm[i][j];
@@ -343,12 +367,16 @@ __global__ __launch_bounds__(64 * FC_NW) void flowchain_bwd_kernel(PfFlowChain a
     float g[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) g[c] = valid ? a.dout[(size_t)pr * 3 + c] : 0.f;
+    const float* bimg = a.img + (size_t)a.nb * FF_FLOATS;
+    f4 pre[FC_PRE];
+    fc_fetch<FB_FLOATS>(pre, bimg + (size_t)(a.inv ? 0 : a.nb - 1) * FB_FLOATS);
     for (int k = 0; k < a.nb; ++k) {
         const int i = a.inv ? k : a.nb - 1 - k;         // the forward walk backwards
         const int td = a.td[i], wo = 3 - td;
         __syncthreads();
-        fc_stage_bwd(lds, a, i, td);
+        fc_commit<FB_FLOATS>(pre, lds);
         __syncthreads();
+        if (k + 1 < a.nb) fc_fetch<FB_FLOATS>(pre, bimg + (size_t)(a.inv ? i + 1 : i - 1) * FB_FLOATS);
         float M[9], el[3], b[3];
 #pragma unroll
         for (int j = 0; j < 9; ++j) M[j] = prm[i][j];
@@ -526,7 +554,7 @@ int fc_check(const PfFlowChain* a, bool bwd) {
     if (a->nb < 1 || a->nb > PF_FLOWCHAIN_MAXB || a->rows <= 0) return PF_ERR_SHAPE;
     if (a->R != 1 && a->R != 2 && a->R != 4 && a->R != 8 && a->R != 16) return PF_ERR_UNSUPPORTED;
     if (a->rows % a->R != 0) return PF_ERR_SHAPE;
-    if (!a->x || !a->pin || !a->mid || !a->h1 || !a->h2 || !a->out) return PF_ERR_NULL;
+    if (!a->x || !a->pin || !a->mid || !a->h1 || !a->h2 || !a->out || !a->img) return PF_ERR_NULL;
     if (a->inv ? !a->o : (!bwd && (!a->ssum || !a->part || !a->counter))) return PF_ERR_NULL;
     for (int i = 0; i < a->nb; ++i) {
         if (a->td[i] != 1 && a->td[i] != 2) return PF_ERR_UNSUPPORTED;
@@ -580,11 +608,19 @@ extern "C" long long pf_flowchain_part_floats(const PfFlowChain* a) {
     return (long long)a->nb * ((a->rows + 15) / 16) * 16;
 }
 
+// floats of `img`: the packed conditioner weights of every block (forward and backward layout), written by pf_flowchain_fwd
+// and read again by pf_flowchain_bwd
+extern "C" long long pf_flowchain_img_floats(const PfFlowChain* a) {
+    if (!a || a->nb < 1 || a->nb > PF_FLOWCHAIN_MAXB) return -1;
+    return (long long)a->nb * (FF_FLOATS + FB_FLOATS);
+}
+
 extern "C" int pf_flowchain_fwd(const PfFlowChain* a, void* stream) {
     int st = fc_check(a, false);
     if (st) return st;
     const int ntiles = (a->rows + 15) / 16;
     const size_t lds = FF_FLOATS * sizeof(float);
+    hipLaunchKernelGGL(flowchain_pack_kernel, dim3(a->nb, 2, 14), dim3(256), 0, (hipStream_t)stream, *a);
     hipLaunchKernelGGL(flowchain_fwd_kernel, dim3((ntiles + FC_NW - 1) / FC_NW), dim3(64 * FC_NW), lds, (hipStream_t)stream, *a);
     return pf_last_launch_status();
 }

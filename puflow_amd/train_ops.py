@@ -856,39 +856,46 @@ class InjectInv2Fn(Function):
 
 
 class FlowChainFn(Function):
-    """All flow blocks of one direction as ONE autograd node: one launch forward, four backward (csrc/train_flowchain.hip).
-    apply(inv, R, n_ld, nb, x, *c[nb], *s[nb], *t[nb], *[logs, bias, W, w0, w2, b2, w4, b4] per block)
+    """All flow blocks of one direction as ONE autograd node: two launches forward, four backward (csrc/train_flowchain.hip).
+    apply(inv, R, n_ld, ccs, x, cflat, st, *[logs, bias, W, w0, w2, b2, w4, b4] per block)
+      ccs    conditioning channels per block; cflat = the blocks' conditioning features [T, cc_i], flattened and concatenated
+             (ONE tensor: its three consumers cost two gradient additions instead of twelve)
+      st     [2 nb, T, 3]: injector scale (2 i) and shift (2 i + 1) of block i per ORIGINAL point
       inv = 0 (PointInterpFlow.f, interpflow.py:302-310): x [B,N,3] -> (z, ssum [nb] = sum(s_i), ld [nb] = (sum(logs_i) + log|det W_i|) n_ld)
-      inv = 1 (PointInterpFlow.g, interpflow.py:312-321): u [B,N R,3] -> (x,), blocks in reverse order, c / s / t per ORIGINAL point
+      inv = 1 (PointInterpFlow.g, interpflow.py:312-321): u [B,N R,3] -> x, blocks in reverse order
     Replaces, per block, FlowParamsFn + FlowAffineFn + MlpFn + CoupleInject2Fn / InjectInv2Fn and the gradient-accumulation adds
     autograd inserted between them."""
-    NPRM = 8
 
     @staticmethod
-    def _desc(inv, R, n_ld, nb, x, cs, ss, tt, prm):
+    def _desc(inv, R, n_ld, ccs, x, cflat, st, prm):
+        nb = len(ccs)
         d = _lib.PfFlowChain()
         d.nb, d.rows, d.R, d.inv, d.n_ld = nb, x.numel() // 3, R, inv, float(n_ld)
         d.x = x.data_ptr()
+        T = d.rows // R
+        off = 0
         for i in range(nb):
             lg, bi, W, w0, w2, b2, w4, b4 = prm[8 * i:8 * i + 8]
-            d.cc[i] = cs[i].shape[-1]
-            d.td[i] = w0.shape[1] - d.cc[i]
-            d.c[i], d.s[i], d.t[i] = cs[i].data_ptr(), ss[i].data_ptr(), tt[i].data_ptr()
+            d.cc[i] = ccs[i]
+            d.td[i] = w0.shape[1] - ccs[i]
+            d.c[i] = cflat.data_ptr() + 4 * off
+            off += T * ccs[i]
+            d.s[i], d.t[i] = st[2 * i].data_ptr(), st[2 * i + 1].data_ptr()
             d.logs[i], d.bias[i], d.W[i] = lg.data_ptr(), bi.data_ptr(), W.data_ptr()
             d.w0[i], d.w2[i], d.b2[i], d.w4[i], d.b4[i] = w0.data_ptr(), w2.data_ptr(), b2.data_ptr(), w4.data_ptr(), b4.data_ptr()
+        if cflat.numel() != off or tuple(st.shape) != (2 * nb, T, 3):
+            raise ValueError("FlowChainFn: conditioning tensors do not match the row count")
         return d
 
     @staticmethod
-    def forward(ctx, inv, R, n_ld, nb, x, *ts):
+    def forward(ctx, inv, R, n_ld, ccs, x, cflat, st, *prm):
         lib = _lib.load()
-        x = x.contiguous()
-        cs = [t.contiguous() for t in ts[:nb]]
-        ss = [t.contiguous() for t in ts[nb:2 * nb]]
-        tt = [t.contiguous() for t in ts[2 * nb:3 * nb]]
-        prm = [t.contiguous() for t in ts[3 * nb:]]
+        x, cflat, st = x.contiguous(), cflat.contiguous(), st.contiguous()
+        prm = [t.contiguous() for t in prm]
+        nb = len(ccs)
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
-        d = FlowChainFn._desc(inv, R, n_ld, nb, x, cs, ss, tt, prm)
+        d = FlowChainFn._desc(inv, R, n_ld, ccs, x, cflat, st, prm)
         rows = d.rows
         keep = torch.empty((2, nb, rows, 3), **f32)                      # block inputs | y (f) / v (g)
         hh = torch.empty((2, nb, rows, 64), **f32)
@@ -900,9 +907,11 @@ class FlowChainFn(Function):
         d.ssum, d.ld = ssum.data_ptr(), ld.data_ptr()
         d.part = _ws(dev, nb * ((rows + 15) // 16)).data_ptr()
         d.counter = _counter(dev).data_ptr()
+        img = torch.empty((lib.pf_flowchain_img_floats(ctypes.byref(d)),), **f32)      # packed weights, kept for the backward
+        d.img = img.data_ptr()
         _lib.check(lib.pf_flowchain_fwd(ctypes.byref(d), _stream()), "pf_flowchain_fwd")
-        ctx.cfg = (inv, R, float(n_ld), nb, [t.shape for t in ts[3 * nb:]])
-        ctx.save_for_backward(x, out, keep, hh, *(() if o is None else (o,)), *cs, *ss, *tt, *prm)
+        ctx.cfg = (inv, R, float(n_ld), tuple(ccs), [t.shape for t in prm])
+        ctx.save_for_backward(x, out, keep, hh, img, cflat, st, *(() if o is None else (o,)), *prm)
         if inv:
             return out
         return out, ssum, ld
@@ -910,29 +919,27 @@ class FlowChainFn(Function):
     @staticmethod
     def backward(ctx, dout, dssum=None, dld=None):
         lib = _lib.load()
-        inv, R, n_ld, nb, pshapes = ctx.cfg
+        inv, R, n_ld, ccs, pshapes = ctx.cfg
+        nb = len(ccs)
         sv = list(ctx.saved_tensors)
-        x, out, keep, hh = sv[:4]
-        k = 4
-        o = None
-        if inv:
-            o, k = sv[4], 5
-        cs, ss, tt, prm = sv[k:k + nb], sv[k + nb:k + 2 * nb], sv[k + 2 * nb:k + 3 * nb], sv[k + 3 * nb:]
+        x, out, keep, hh, img, cflat, st = sv[:7]
+        o, prm = (sv[7], sv[8:]) if inv else (None, sv[7:])
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
-        d = FlowChainFn._desc(inv, R, n_ld, nb, x, cs, ss, tt, prm)
+        d = FlowChainFn._desc(inv, R, n_ld, ccs, x, cflat, st, prm)
         rows = d.rows
         T = rows // R
         d.pin, d.mid, d.h1, d.h2, d.out = keep[0].data_ptr(), keep[1].data_ptr(), hh[0].data_ptr(), hh[1].data_ptr(), out.data_ptr()
         d.o = _ptr(o)
+        d.img = img.data_ptr()
         dout = dout.contiguous()
         dssum = dssum.contiguous() if dssum is not None else None
         dld = dld.contiguous() if dld is not None else None
         d.dout, d.dssum, d.dld = dout.data_ptr(), _ptr(dssum), _ptr(dld)
         dx = torch.empty_like(x) if ctx.needs_input_grad[4] else None
         d.dx = _ptr(dx)
-        dcs = [torch.empty_like(c) for c in cs]
-        dst = torch.empty((2, nb, T, 3), **f32)
+        dcflat = torch.empty_like(cflat)
+        dst = torch.empty_like(st)
         dz = torch.empty((2, nb, rows, 64), **f32)
         dob = torch.empty((nb, rows, 2), **f32)
         d.dz1, d.dz2, d.dob = dz[0].data_ptr(), dz[1].data_ptr(), dob.data_ptr()
@@ -942,8 +949,11 @@ class FlowChainFn(Function):
         for n_ in sizes:
             gp.append(flat[off:off + n_])
             off += n_
+        coff = 0
         for i in range(nb):
-            d.dc[i], d.ds[i], d.dt[i] = dcs[i].data_ptr(), dst[0, i].data_ptr(), dst[1, i].data_ptr()
+            d.dc[i] = dcflat.data_ptr() + 4 * coff
+            coff += T * ccs[i]
+            d.ds[i], d.dt[i] = dst[2 * i].data_ptr(), dst[2 * i + 1].data_ptr()
             g = gp[8 * i:8 * i + 8]
             d.dlogs[i], d.dbias[i], d.dW[i] = g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr()
             d.dw0[i], d.dw2[i], d.db2[i], d.dw4[i], d.db4[i] = (g[3].data_ptr(), g[4].data_ptr(), g[5].data_ptr(), g[6].data_ptr(),
@@ -957,10 +967,90 @@ class FlowChainFn(Function):
         d.ws, d.ws_floats = ws.data_ptr() + 4 * npart, need
         d.dev_descs = _desc_buf(dev).data_ptr()
         _lib.check(lib.pf_flowchain_bwd(ctypes.byref(d), _stream()), "pf_flowchain_bwd")
-        sshape = ss[0].shape
         grads = [g.view(shp) for g, shp in zip(gp, pshapes)]
-        return (None, None, None, None, dx, *dcs, *[dst[0, i].view(sshape) for i in range(nb)],
-                *[dst[1, i].view(sshape) for i in range(nb)], *grads)
+        return (None, None, None, None, dx, dcflat, dst, *grads)
+
+
+class CondNetStackFn(Function):
+    """The injector scale / shift conditioners (LinearA1D, first layer without bias, interpflow.py:22-43) of ALL flow blocks on the
+    flattened conditioning features: one launch forward, four backward (csrc/train_mlp.hip, batched entry points), ONE output
+    tensor.  apply(ccs, T, cflat, *[W0, W1, b1, W2, b2 per net]) -> st [n, T, 3]; net k reads block k // 2's features."""
+
+    @staticmethod
+    def _descs(ccs, T, cflat, prm, n):
+        descs = (_lib.PfMlpTrain * n)()
+        offs, off = [], 0
+        for cc in ccs:
+            offs.append(off)
+            off += T * cc
+        for k in range(n):
+            W0, W1, b1, W2, b2 = prm[5 * k:5 * k + 5]
+            d = _lib.PfMlpTrain()
+            d.rows, d.nl, d.td, d.cc, d.cdiv, d.ldy = T, 3, 0, ccs[k // 2], 1, 0
+            for l, w in enumerate((W0, W1, W2)):
+                d.width[l] = w.shape[0]
+                d.W[l] = w.data_ptr()
+            d.slope[0] = d.slope[1] = 0.01
+            d.c = cflat.data_ptr() + 4 * offs[k // 2]
+            descs[k] = d
+        return descs, offs
+
+    @staticmethod
+    def forward(ctx, ccs, T, cflat, *prm):
+        lib = _lib.load()
+        n = len(prm) // 5
+        cflat = cflat.contiguous()
+        prm = [w.contiguous() for w in prm]
+        dev = cflat.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        descs, _ = CondNetStackFn._descs(ccs, T, cflat, prm, n)
+        hs = torch.empty((n, 2, T, 64), **f32)
+        st = torch.empty((n, T, 3), **f32)
+        for k in range(n):
+            W0, W1, b1, W2, b2 = prm[5 * k:5 * k + 5]
+            if W0.shape[0] != 64 or W1.shape[0] != 64 or W2.shape[0] != 3:
+                raise ValueError("CondNetStackFn: unexpected conditioner shape")
+            descs[k].b[1], descs[k].b[2] = b1.data_ptr(), b2.data_ptr()
+            descs[k].h[0], descs[k].h[1], descs[k].out = hs[k, 0].data_ptr(), hs[k, 1].data_ptr(), st[k].data_ptr()
+        _lib.check(lib.pf_mlp_train_fwd_batch(descs, n, _desc_buf(dev).data_ptr(), _stream()), "pf_mlp_train_fwd_batch")
+        ctx.cfg = (tuple(ccs), T, n)
+        ctx.save_for_backward(cflat, hs, *prm)
+        return st
+
+    @staticmethod
+    def backward(ctx, dst):
+        lib = _lib.load()
+        ccs, T, n = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        cflat, hs, prm = sv[0], sv[1], sv[2:]
+        dev = cflat.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dst = dst.contiguous()
+        descs, offs = CondNetStackFn._descs(ccs, T, cflat, prm, n)
+        dz = torch.empty_like(hs)
+        dc2 = torch.empty((2, cflat.numel()), **f32)                    # gradients through the scale nets | through the shift nets
+        sizes = [int(p.numel()) for p in prm]
+        flat = torch.empty((sum(sizes),), **f32)
+        gp, off = [], 0
+        for n_ in sizes:
+            gp.append(flat[off:off + n_])
+            off += n_
+        need = [lib.pf_mlp_train_ws_floats(ctypes.byref(descs[k])) for k in range(n)]
+        ws = _ws(dev, sum(need))
+        woff = 0
+        for k in range(n):
+            d = descs[k]
+            d.h[0], d.h[1], d.dz[0], d.dz[1] = hs[k, 0].data_ptr(), hs[k, 1].data_ptr(), dz[k, 0].data_ptr(), dz[k, 1].data_ptr()
+            d.dout = dst[k].data_ptr()
+            d.dc = dc2[k % 2].data_ptr() + 4 * offs[k // 2]
+            g = gp[5 * k:5 * k + 5]
+            d.dW[0], d.dW[1], d.dW[2] = g[0].data_ptr(), g[1].data_ptr(), g[3].data_ptr()
+            d.db[1], d.db[2] = g[2].data_ptr(), g[4].data_ptr()
+            d.ws, d.ws_floats = ws.data_ptr() + 4 * woff, need[k]
+            woff += need[k]
+            descs[k] = d
+        _lib.check(lib.pf_mlp_train_bwd_batch(descs, n, _desc_buf(dev).data_ptr(), _stream()), "pf_mlp_train_bwd_batch")
+        return (None, None, dc2[0] + dc2[1], *[g.view(p.shape) for g, p in zip(gp, prm)])
 
 
 class MlpFn(Function):
@@ -1450,25 +1540,28 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
 
     # ---- injector nets (s, t) of every block: functions of cs[i] only - one batched launch (and shared by f and g)
     st_all = None
+    st_prm = []
+    nb = net.num_blocks
+    chain = (_CHAIN and _FUSED and nb <= 8 and R in (1, 2, 4, 8, 16)
+             and all(b.actnorm.is_inited for b in net.flow_blocks) and all(c.shape[-1] in (32, 64, 128) for c in cs)
+             and all(b.coupling1.bias_net.layers[2].weight.shape == (64, 64) for b in net.flow_blocks))
     if _FUSED:
-        prm = []
         for blk in net.flow_blocks:
             for cn in (blk.coupling2.scale_net, blk.coupling2.bias_net):
                 L = cn.layers
-                prm += [L[0].weight, L[2].weight, L[2].bias, L[4].weight, L[4].bias]
-        cidx = tuple(i for i in range(net.num_blocks) for _ in range(2))
-        st_all = CondNetBatchFn.apply(cidx, *cs, *prm)
+                st_prm += [L[0].weight, L[2].weight, L[2].bias, L[4].weight, L[4].bias]
+        if not chain:
+            cidx = tuple(i for i in range(net.num_blocks) for _ in range(2))
+            st_all = CondNetBatchFn.apply(cidx, *cs, *st_prm)
 
     # ---- f, interpolation, g with every flow block of a direction in one autograd node (csrc/train_flowchain.hip).  ActNorm's
     # data-dependent init needs each block's input on the host side of the chain: the first step takes the per-block path below
-    nb = net.num_blocks
-    chain = (_CHAIN and _FUSED and st_all is not None and nb <= 8 and R in (1, 2, 4, 8, 16)
-             and all(b.actnorm.is_inited for b in net.flow_blocks) and all(c.shape[-1] in (32, 64, 128) for c in cs)
-             and all(b.coupling1.bias_net.layers[2].weight.shape == (64, 64) for b in net.flow_blocks))
     if chain:
         pf, pg = _flow_chain_params(net)
-        ss, ts_ = [st_all[2 * i] for i in range(nb)], [st_all[2 * i + 1] for i in range(nb)]
-        z, ssum, ld = FlowChainFn.apply(0, 1, float(N), nb, xyz, *cs, *ss, *ts_, *pf)
+        ccs = tuple(int(c.shape[-1]) for c in cs)
+        cflat = torch.cat([c.reshape(-1) for c in cs])               # one tensor for its three consumers
+        st = CondNetStackFn.apply(ccs, B * N, cflat, *st_prm)
+        z, ssum, ld = FlowChainFn.apply(0, 1, float(N), ccs, xyz, cflat, st, *pf)
         logp = -(BatchSumFn.apply(z, 1).mean() + ld.sum() - ssum.sum() / B)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
@@ -1476,7 +1569,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         zj = GatherRowsFn.apply(z, idx8)
         fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)
         u = fz.transpose(1, 2).reshape(B, N * R, 3)
-        x = FlowChainFn.apply(1, R, float(N), nb, u, *cs, *ss, *ts_, *pg)
+        x = FlowChainFn.apply(1, R, float(N), ccs, u, cflat, st, *pg)
         return x, logp
 
     # ---- f + log-likelihood
