@@ -371,7 +371,7 @@ int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_descs, void*
  * inv = 1: u [T R, 3] -> x through the blocks in reverse order, conditioning rows shared by R in {1,2,4,8,16} consecutive rows.
  * Slabs (`pin`, `mid`, `o`, `h1`, `h2`, `dz1`, `dz2`, `dob`) are indexed by block and kept between forward and backward.
  * Backward: dout [rows,3] (+ dssum, dld [nb], nullable) -> dx (nullable), dc[i] [rows / R, cc[i]], ds[i], dt[i] [rows / R, 3] and
- * every parameter gradient.  part: pf_flowchain_part_floats() floats; counter: one zero word (left zero); ws:
+ * every parameter gradient.  part: pf_flowchain_part_floats() floats (both directions); counter: one zero word (left zero); ws:
  * pf_flowchain_ws_floats() floats; dev_descs: nb * sizeof(PfMlpTrain) bytes. */
 #define PF_FLOWCHAIN_MAXB 8
 typedef struct PfFlowChain {
@@ -391,10 +391,12 @@ typedef struct PfFlowChain {
     float* h1; float* h2;            /* [nb][rows, 64] */
     float* out;                      /* [rows, 3] */
     float* ssum; float* ld;          /* [nb] (inv = 0) */
+    float* logp; int Bsz;            /* inv = 0, nullable: logp[0] = -(sum_rows log N(z) / Bsz + sum_i ld_i - sum_i ssum_i / Bsz), nb <= 7 */
     float* part; unsigned* counter;
     float* img;                      /* pf_flowchain_img_floats(): packed weights, written by the forward, read by the backward */
     /* backward only */
     const float* dout; const float* dssum; const float* dld;
+    const float* dlogp;              /* gradient of logp[0]; replaces dssum / dld when given (dout then nullable) */
     float* dx;
     float* dc[PF_FLOWCHAIN_MAXB]; float* ds[PF_FLOWCHAIN_MAXB]; float* dt[PF_FLOWCHAIN_MAXB];
     float* dz1; float* dz2;          /* [nb][rows, 64] */
@@ -429,6 +431,25 @@ int pf_couple_inject2_bwd(const float* out, const float* dout, const float* dssu
 int pf_inject_inv2_fwd(const float* u, const float* s, const float* t, int Rr, long long R, float* v, void* stream);
 int pf_inject_inv2_bwd(const float* u, const float* s, const float* dv, int Rr, long long R, float* du, float* ds, float* dt,
                        void* stream);
+
+/* ---- fused glue of the training step (csrc/train_glue.hip): what were chains of one-element torch launches ----
+ * pf_interp_wsum: interpolation of the latent (modules/discrete/interpflow.py:153-186, 312-318): softmax over the K = 8
+ *   neighbours of the first R <= 8 weight channels of w [T, 8, ldw] and the weighted sum of the gathered latent rows
+ *   z [B N, 3] (idx [T, 8] batch-local), written as the [T R, 3] rows flow g reads; a [T, 8, R] is kept for the backward,
+ *   which returns dw [T, 8, ldw] and dz [B N, 3] (zero-filled, then scatter-added with float atomics).
+ * pf_emd_init: inputs of the auction (metric/emd/emd_module.py:45-56): price = 0, assignment = assignment_inv = -1.
+ * pf_pugan_loss: train_pugan.py:52-67, out[0] = w_logp logp + w_emd sum_b sum_n dist[b,n] / radius[b] + w_cd mean_b per[b],
+ *   out[1..3] = the weighted EMD, logp and CD terms; backward: the seeds graddist [B,N] (pf_emd_backward), g1 [B,N], g2 [B,M]
+ *   (pf_chamfer_bwd), dlogp [1] and the zero-filled gx [B,N,3], gy [B,M,3] those kernels accumulate into. */
+int pf_interp_wsum_fwd(const float* w, int ldw, const float* z, const int* idx, int N, int K, int R, long long T, float* a,
+                       float* u, void* stream);
+int pf_interp_wsum_bwd(const float* a, const float* z, const int* idx, const float* du, int N, int K, int R, int ldw, long long T,
+                       float* dw, float* dz, void* stream);
+int pf_emd_init(float* price, int* assign2, long long Bn, void* stream);
+int pf_pugan_loss_fwd(const float* logp, const float* dist, const float* radius, const float* per, int B, int n, float w_logp,
+                      float w_emd, float w_cd, float* out, void* stream);
+int pf_pugan_loss_bwd(const float* g, const float* radius, int B, int N, int M, float w_logp, float w_emd, float w_cd,
+                      float* graddist, float* g1, float* g2, float* dlogp, float* gx, float* gy, void* stream);
 
 /* ---- gradient clipping (L2 norm over all parameters) + Adam for the whole model in two launches (csrc/optim.hip) ----
  * Replaces torch.nn.utils.clip_grad_norm_ (Lightning gradient_clip_val, train_pu1k.py:149) + torch.optim.Adam.step

@@ -53,8 +53,8 @@ class PfFlowChain(ctypes.Structure):
                 ("x", c_void_p), ("c", _P8), ("s", _P8), ("t", _P8), ("logs", _P8), ("bias", _P8), ("W", _P8),
                 ("w0", _P8), ("w2", _P8), ("b2", _P8), ("w4", _P8), ("b4", _P8),
                 ("pin", c_void_p), ("mid", c_void_p), ("o", c_void_p), ("h1", c_void_p), ("h2", c_void_p), ("out", c_void_p),
-                ("ssum", c_void_p), ("ld", c_void_p), ("part", c_void_p), ("counter", c_void_p), ("img", c_void_p),
-                ("dout", c_void_p), ("dssum", c_void_p), ("dld", c_void_p), ("dx", c_void_p),
+                ("ssum", c_void_p), ("ld", c_void_p), ("logp", c_void_p), ("Bsz", c_int), ("part", c_void_p), ("counter", c_void_p), ("img", c_void_p),
+                ("dout", c_void_p), ("dssum", c_void_p), ("dld", c_void_p), ("dlogp", c_void_p), ("dx", c_void_p),
                 ("dc", _P8), ("ds", _P8), ("dt", _P8), ("dz1", c_void_p), ("dz2", c_void_p), ("dob", c_void_p),
                 ("dlogs", _P8), ("dbias", _P8), ("dW", _P8), ("dw0", _P8), ("dw2", _P8), ("db2", _P8), ("dw4", _P8), ("db4", _P8),
                 ("ws", c_void_p), ("ws_floats", c_longlong), ("dev_descs", c_void_p)]
@@ -160,6 +160,13 @@ SIGNATURES = {
     "pf_flowchain_img_floats": (c_longlong, [c_void_p]),
     "pf_flowchain_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_flowchain_bwd": (c_int, [c_void_p, c_void_p]),
+    "pf_interp_wsum_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p]),
+    "pf_interp_wsum_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p,
+                                   c_void_p]),
+    "pf_emd_init": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
+    "pf_pugan_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "pf_pugan_loss_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_bnmlp_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_bnmlp_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_bnmlp_train_bwd": (c_int, [c_void_p, c_void_p]),

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpuflow_hip.so")
-SOURCES = ["api.hip", "knn.hip", "edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip", "chamfer.hip", "emd.hip", "train_ops.hip", "train_fused.hip", "train_mlp.hip", "train_flow.hip", "train_flowchain.hip", "optim.hip", "patch_ops.hip", "cnf.hip", "xyz_io.hip"]
+SOURCES = ["api.hip", "knn.hip", "edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip", "chamfer.hip", "emd.hip", "train_ops.hip", "train_fused.hip", "train_mlp.hip", "train_flow.hip", "train_flowchain.hip", "train_glue.hip", "optim.hip", "patch_ops.hip", "cnf.hip", "xyz_io.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-result"]
 # The fused MFMA kernels never see NaNs; without the flag every fmaxf() is preceded by a canonicalising v_max x,x and
 # the DPP row-max steps stay as v_mov_dpp + v_max instead of one v_max_f32_dpp (3x the instructions of a max-pool).

@@ -143,7 +143,9 @@ __device__ __forceinline__ void fc_params(float (*prm)[16], const PfFlowChain& a
             prm[i][9 + k] = expf(a.inv ? -a.logs[i][k] : a.logs[i][k]);
             prm[i][12 + k] = a.bias[i][k];
         }
-        if (write_ld && a.ld) a.ld[i] = (a.logs[i][0] + a.logs[i][1] + a.logs[i][2] + logf(fabsf(det))) * a.n_ld;
+        const float ldv = (a.logs[i][0] + a.logs[i][1] + a.logs[i][2] + logf(fabsf(det))) * a.n_ld;
+        prm[i][15] = ldv;
+        if (write_ld && a.ld) a.ld[i] = ldv;
     }
 }
 
@@ -332,6 +334,13 @@ __global__ __launch_bounds__(64 * FC_NW) void flowchain_fwd_kernel(PfFlowChain a
 #pragma unroll
         for (int c = 0; c < 3; ++c) a.out[(size_t)p0 * 3 + c] = p[c];
     if (a.inv) return;
+    if (a.logp) {                                       // standard-normal log-density of z (probs.py:73-75), per wave tile
+        float gv = (valid && q == 0) ? -0.5f * ((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2] + 3.f * 1.8378770664093453f) : 0.f;
+#pragma unroll
+        for (int w = 1; w < 64; w <<= 1) gv += __shfl_xor(gv, w);
+        if (lane == 0 && tile < ntiles)
+            __hip_atomic_store(a.part + (size_t)a.nb * ntiles + tile, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // sum(s) of every block: the workgroup that arrives last adds the per-tile sums in a fixed order
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -339,15 +348,26 @@ __global__ __launch_bounds__(64 * FC_NW) void flowchain_fwd_kernel(PfFlowChain a
     __syncthreads();
     if (!last) return;
     {
+        __shared__ float tot[PF_FLOWCHAIN_MAXB + 1];
         const int i = threadIdx.x >> 5, sub = threadIdx.x & 31;
+        const int nrow = a.nb + (a.logp ? 1 : 0);          // row nb: the log-density partials (nb <= 7 when logp is asked for)
         float sv = 0.f;
-        if (i < a.nb)
+        if (i < nrow)
             for (int w = sub; w < ntiles; w += 32)
                 sv += __hip_atomic_load(a.part + (size_t)i * ntiles + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int w = 1; w < 32; w <<= 1) sv += __shfl_xor(sv, w);
         if (i < a.nb && sub == 0) a.ssum[i] = sv;
-        if (threadIdx.x == 0) *a.counter = 0u;
+        if (i < nrow && sub == 0) tot[i] = sv;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *a.counter = 0u;
+            if (a.logp) {                                 // -mean_b(log N(z_b) + sum_i (ld_i - sum(s_i)[b]))  (interpflow.py:327-337)
+                float lds_ = 0.f, ss = 0.f;
+                for (int k2 = 0; k2 < a.nb; ++k2) { lds_ += prm[k2][15]; ss += tot[k2]; }
+                a.logp[0] = -(tot[a.nb] / (float)a.Bsz + lds_ - ss / (float)a.Bsz);
+            }
+        }
     }
 }
 
@@ -366,7 +386,11 @@ __global__ __launch_bounds__(64 * FC_NW) void flowchain_bwd_kernel(PfFlowChain a
     fc_params(prm, a, false);
     float g[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) g[c] = valid ? a.dout[(size_t)pr * 3 + c] : 0.f;
+    for (int c = 0; c < 3; ++c) g[c] = (valid && a.dout) ? a.dout[(size_t)pr * 3 + c] : 0.f;
+    const float glp = (!a.inv && a.dlogp) ? a.dlogp[0] / (float)a.Bsz : 0.f;       // d logp / d z = z / B,  d logp / d ssum_i = 1 / B
+    if (!a.inv && a.dlogp && valid)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] = fmaf(glp, a.out[(size_t)pr * 3 + c], g[c]);
     const float* bimg = a.img + (size_t)a.nb * FF_FLOATS;
     f4 pre[FC_PRE];
     fc_fetch<FB_FLOATS>(pre, bimg + (size_t)(a.inv ? 0 : a.nb - 1) * FB_FLOATS);
@@ -391,7 +415,7 @@ __global__ __launch_bounds__(64 * FC_NW) void flowchain_bwd_kernel(PfFlowChain a
         if (!a.inv) {
             // injector + reverse + coupling:  out = (reverse([y_head, y_tail - o]) - t) e^-s
             const float* outp = i == a.nb - 1 ? a.out + (size_t)pr * 3 : a.pin + ((size_t)(i + 1) * rows + pr) * 3;
-            const float gs = a.dssum ? a.dssum[i] : 0.f;
+            const float gs = a.dlogp ? glp : (a.dssum ? a.dssum[i] : 0.f);
             float dv[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -527,7 +551,7 @@ __global__ __launch_bounds__(256) void flowchain_param_kernel(PfFlowChain a) {
     for (int k = 0; k < 9; ++k) W[k] = a.W[i][k];
     fc_inv3(W, Wi, det);
     if (!a.inv) {
-        const float gl = a.dld ? a.dld[i] * a.n_ld : 0.f;
+        const float gl = a.dlogp ? -a.dlogp[0] * a.n_ld : (a.dld ? a.dld[i] * a.n_ld : 0.f);       // d logp / d ld_i = -1
         for (int c = 0; c < 3; ++c) { a.dlogs[i][c] = sm[c] + gl; a.dbias[i][c] = sm[3 + c]; }
         for (int r = 0; r < 3; ++r)
             for (int j = 0; j < 3; ++j) a.dW[i][r * 3 + j] = sm[6 + r * 3 + j] + gl * Wi[j * 3 + r];
@@ -556,6 +580,7 @@ int fc_check(const PfFlowChain* a, bool bwd) {
     if (a->rows % a->R != 0) return PF_ERR_SHAPE;
     if (!a->x || !a->pin || !a->mid || !a->h1 || !a->h2 || !a->out || !a->img) return PF_ERR_NULL;
     if (a->inv ? !a->o : (!bwd && (!a->ssum || !a->part || !a->counter))) return PF_ERR_NULL;
+    if (!a->inv && (a->logp || a->dlogp) && (a->Bsz < 1 || a->nb >= PF_FLOWCHAIN_MAXB)) return PF_ERR_SHAPE;
     for (int i = 0; i < a->nb; ++i) {
         if (a->td[i] != 1 && a->td[i] != 2) return PF_ERR_UNSUPPORTED;
         if (a->cc[i] != 32 && a->cc[i] != 64 && a->cc[i] != 128) return PF_ERR_UNSUPPORTED;
@@ -566,7 +591,7 @@ int fc_check(const PfFlowChain* a, bool bwd) {
                     !a->db2[i] || !a->dw4[i] || !a->db4[i]))
             return PF_ERR_NULL;
     }
-    if (bwd && (!a->dout || !a->dz1 || !a->dz2 || !a->dob || !a->part || !a->ws || !a->dev_descs)) return PF_ERR_NULL;
+    if (bwd && ((!a->dout && !a->dlogp) || !a->dz1 || !a->dz2 || !a->dob || !a->part || !a->ws || !a->dev_descs)) return PF_ERR_NULL;
     return PF_OK;
 }
 

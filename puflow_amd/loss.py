@@ -115,3 +115,69 @@ class ChamferCUDA(nn.Module):
     def forward(self, xyz1: Tensor, xyz2: Tensor, nxyz1: Tensor = None, nxyz2: Tensor = None):
         return ops.chamfer_distance(xyz1, xyz2, x_normals=nxyz1, y_normals=nxyz2, batch_reduction="mean",
                                     point_reduction="mean")
+
+
+class PuganLossFn(Function):
+    """The PU-GAN training loss (train_pugan.py:52-67) as ONE autograd node:
+        loss = w_logp logp + w_emd sum_b sum_n emd_dist[b, n] / radius[b] + w_cd mean_b chamfer(pred_b, gt_b)
+    = emdFunction + _ChamferFn + the torch expressions between them (EarthMoverDistance, ChamferCUDA, the weighted sum), whose
+    ~25 one-element launches forward and ~15 backward become one kernel each way (csrc/train_glue.hip); the EMD and Chamfer
+    gradient kernels accumulate into one buffer.  apply(pred, gt, radius | None, logp, eps, iters, groups, (w_logp, w_emd, w_cd))
+    -> (loss [], terms [3] = weighted EMD, logp, CD for logging; not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, radius, logp, eps, iters, groups, weights):
+        lib = _lib.load()
+        pred, gt = ops._f32c(pred), ops._f32c(gt)
+        B, n, _ = pred.shape
+        if gt.shape[1] != n:
+            raise ValueError("PuganLossFn: prediction and ground truth must have the same number of points (EMD)")
+        dev = pred.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        radius = radius.contiguous().float().view(-1) if radius is not None else None
+        logp1 = logp.detach().contiguous().float().view(1)
+        # ---- auction (emd_module.py:31-72): price | assignments initialised by one kernel
+        price = torch.empty((B, n), **f32)
+        assign2 = torch.empty((2, B, n), dtype=torch.int32, device=dev)
+        scratch = torch.empty((5, B, n), dtype=torch.int32, device=dev)
+        dist = torch.empty((B, n), **f32)
+        _lib.check(lib.pf_emd_init(price.data_ptr(), assign2.data_ptr(), B * n, ops._stream()), "pf_emd_init")
+        max_inc, bid_inc, max_idx, bid, unass_idx = scratch[0], scratch[1], scratch[2], scratch[3], scratch[4]
+        _lib.check(lib.pf_emd_forward_ex(pred.data_ptr(), gt.data_ptr(), dist.data_ptr(), assign2[0].data_ptr(), price.data_ptr(),
+                                         assign2[1].data_ptr(), bid.data_ptr(), bid_inc.data_ptr(), max_inc.data_ptr(),
+                                         unass_idx.data_ptr(), max_idx.data_ptr(), float(eps), int(iters), B, n, int(groups),
+                                         _emd_status(dev).data_ptr(), ops._stream()), "pf_emd_forward")
+        # ---- Chamfer (metric/loss.py:39-42: mean over points of both directions, mean over the batch)
+        d1, d2, i1, i2, per, _ = ops.chamfer_nn(pred, gt)
+        out = torch.empty((4,), **f32)
+        w_logp, w_emd, w_cd = (float(v) for v in weights)
+        _lib.check(lib.pf_pugan_loss_fwd(logp1.data_ptr(), dist.data_ptr(), radius.data_ptr() if radius is not None else None,
+                                         per.data_ptr(), B, n, w_logp, w_emd, w_cd, out.data_ptr(), ops._stream()),
+                   "pf_pugan_loss_fwd")
+        ctx.save_for_backward(pred, gt, assign2, i1, i2, *(() if radius is None else (radius,)))
+        ctx.cfg = (B, n, (w_logp, w_emd, w_cd), radius is not None, logp.shape)
+        terms = out[1:4]
+        ctx.mark_non_differentiable(terms)
+        return out[0], terms
+
+    @staticmethod
+    def backward(ctx, g, _gterms):
+        lib = _lib.load()
+        B, n, (w_logp, w_emd, w_cd), has_r, lshape = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        pred, gt, assign2, i1, i2 = sv[:5]
+        radius = sv[5] if has_r else None
+        dev = pred.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g1d = g.contiguous().float().view(1)
+        seeds = torch.empty((3, B, n), **f32)              # graddist | g1 | g2
+        dlogp = torch.empty((1,), **f32)
+        gx, gy = torch.empty_like(pred), torch.empty_like(gt)
+        _lib.check(lib.pf_pugan_loss_bwd(g1d.data_ptr(), radius.data_ptr() if radius is not None else None, B, n, n, w_logp, w_emd,
+                                         w_cd, seeds[0].data_ptr(), seeds[1].data_ptr(), seeds[2].data_ptr(), dlogp.data_ptr(),
+                                         gx.data_ptr(), gy.data_ptr(), ops._stream()), "pf_pugan_loss_bwd")
+        _lib.check(lib.pf_chamfer_bwd(pred.data_ptr(), gt.data_ptr(), i1.data_ptr(), i2.data_ptr(), seeds[1].data_ptr(),
+                                      seeds[2].data_ptr(), gx.data_ptr(), gy.data_ptr(), B, n, n, ops._stream()), "pf_chamfer_bwd")
+        _lib.check(lib.pf_emd_backward(pred.data_ptr(), gt.data_ptr(), gx.data_ptr(), seeds[0].data_ptr(), assign2[0].data_ptr(),
+                                       B, n, ops._stream()), "pf_emd_backward")
+        return gx, None, None, dlogp.view(lshape), None, None, None, None

@@ -393,6 +393,38 @@ class SoftmaxWsumFn(Function):
         return dw, dzj, None
 
 
+class InterpWsumFn(Function):
+    """Interpolation of the latent (interpflow.py:153-186, 312-318): w [T,8,ldw] logits (first R channels), z [B,N,3], idx8 int32
+    [B,N,16|8] -> u [B, N R, 3], the rows flow g reads.  One launch forward (gather + softmax + weighted sum + layout), two
+    backward (csrc/train_glue.hip); replaces GatherRowsFn + SoftmaxWsumFn + a transposing copy."""
+
+    @staticmethod
+    def forward(ctx, w, z, idx8, R):
+        lib = _lib.load()
+        w, z, idx8 = w.contiguous(), z.contiguous(), idx8.contiguous()
+        B, N, _ = z.shape
+        T, K, ldw = w.shape
+        a = torch.empty((T, K, R), dtype=torch.float32, device=w.device)
+        u = torch.empty((B, N * R, 3), dtype=torch.float32, device=w.device)
+        _lib.check(lib.pf_interp_wsum_fwd(w.data_ptr(), ldw, z.data_ptr(), idx8.data_ptr(), N, K, R, T, a.data_ptr(), u.data_ptr(),
+                                          _stream()), "pf_interp_wsum_fwd")
+        ctx.save_for_backward(a, z, idx8)
+        ctx.dims = (N, K, R, ldw, T)
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        lib = _lib.load()
+        a, z, idx8 = ctx.saved_tensors
+        N, K, R, ldw, T = ctx.dims
+        du = du.contiguous()
+        dw = torch.empty((T, K, ldw), dtype=torch.float32, device=du.device)
+        dz = torch.empty_like(z)
+        _lib.check(lib.pf_interp_wsum_bwd(a.data_ptr(), z.data_ptr(), idx8.data_ptr(), du.data_ptr(), N, K, R, ldw, T, dw.data_ptr(),
+                                          dz.data_ptr(), _stream()), "pf_interp_wsum_bwd")
+        return dw, dz, None, None
+
+
 def _det_inv3(W: Tensor):
     """(det, inverse) of a 3x3 matrix in closed form (cross products), differentiable.  torch.slogdet / torch.inverse go
     through a LAPACK-style solver that synchronises with the host, which a captured training step cannot do."""
@@ -857,11 +889,13 @@ class InjectInv2Fn(Function):
 
 class FlowChainFn(Function):
     """All flow blocks of one direction as ONE autograd node: two launches forward, four backward (csrc/train_flowchain.hip).
-    apply(inv, R, n_ld, ccs, x, cflat, st, *[logs, bias, W, w0, w2, b2, w4, b4] per block)
+    apply(inv, R, n_ld, ccs, x, cflat, st, Bsz, *[logs, bias, W, w0, w2, b2, w4, b4] per block)
       ccs    conditioning channels per block; cflat = the blocks' conditioning features [T, cc_i], flattened and concatenated
              (ONE tensor: its three consumers cost two gradient additions instead of twelve)
       st     [2 nb, T, 3]: injector scale (2 i) and shift (2 i + 1) of block i per ORIGINAL point
-      inv = 0 (PointInterpFlow.f, interpflow.py:302-310): x [B,N,3] -> (z, ssum [nb] = sum(s_i), ld [nb] = (sum(logs_i) + log|det W_i|) n_ld)
+      inv = 0 (PointInterpFlow.f, interpflow.py:302-310): x [B,N,3] -> (z, ssum [nb] = sum(s_i), ld [nb] = (sum(logs_i) + log|det W_i|) n_ld);
+              with Bsz > 0 instead (z, logp [1]) - the log-likelihood -mean_b(log N(z_b) + sum_i (ld_i - sum(s_i)[b])) of
+              interpflow.py:327-337 from the kernel's own epilogue, its backward folded into the chain kernel
       inv = 1 (PointInterpFlow.g, interpflow.py:312-321): u [B,N R,3] -> x, blocks in reverse order
     Replaces, per block, FlowParamsFn + FlowAffineFn + MlpFn + CoupleInject2Fn / InjectInv2Fn and the gradient-accumulation adds
     autograd inserted between them."""
@@ -888,7 +922,7 @@ class FlowChainFn(Function):
         return d
 
     @staticmethod
-    def forward(ctx, inv, R, n_ld, ccs, x, cflat, st, *prm):
+    def forward(ctx, inv, R, n_ld, ccs, x, cflat, st, Bsz, *prm):
         lib = _lib.load()
         x, cflat, st = x.contiguous(), cflat.contiguous(), st.contiguous()
         prm = [t.contiguous() for t in prm]
@@ -905,21 +939,30 @@ class FlowChainFn(Function):
         d.pin, d.mid, d.h1, d.h2, d.out = keep[0].data_ptr(), keep[1].data_ptr(), hh[0].data_ptr(), hh[1].data_ptr(), out.data_ptr()
         d.o = _ptr(o)
         d.ssum, d.ld = ssum.data_ptr(), ld.data_ptr()
-        d.part = _ws(dev, nb * ((rows + 15) // 16)).data_ptr()
+        logp = None
+        if Bsz and not inv:
+            logp = torch.empty((1,), **f32)
+            d.logp, d.Bsz = logp.data_ptr(), int(Bsz)
+        d.part = _ws(dev, (nb + 1) * ((rows + 15) // 16)).data_ptr()
         d.counter = _counter(dev).data_ptr()
         img = torch.empty((lib.pf_flowchain_img_floats(ctypes.byref(d)),), **f32)      # packed weights, kept for the backward
         d.img = img.data_ptr()
         _lib.check(lib.pf_flowchain_fwd(ctypes.byref(d), _stream()), "pf_flowchain_fwd")
-        ctx.cfg = (inv, R, float(n_ld), tuple(ccs), [t.shape for t in prm])
+        ctx.cfg = (inv, R, float(n_ld), tuple(ccs), [t.shape for t in prm], int(Bsz) if logp is not None else 0)
         ctx.save_for_backward(x, out, keep, hh, img, cflat, st, *(() if o is None else (o,)), *prm)
         if inv:
             return out
+        if logp is not None:
+            return out, logp
         return out, ssum, ld
 
     @staticmethod
     def backward(ctx, dout, dssum=None, dld=None):
         lib = _lib.load()
-        inv, R, n_ld, ccs, pshapes = ctx.cfg
+        inv, R, n_ld, ccs, pshapes, Bsz = ctx.cfg
+        dlogp = None
+        if Bsz:                                            # outputs were (z, logp)
+            dlogp, dssum = (dssum.contiguous().view(1) if dssum is not None else None), None
         nb = len(ccs)
         sv = list(ctx.saved_tensors)
         x, out, keep, hh, img, cflat, st = sv[:7]
@@ -932,10 +975,12 @@ class FlowChainFn(Function):
         d.pin, d.mid, d.h1, d.h2, d.out = keep[0].data_ptr(), keep[1].data_ptr(), hh[0].data_ptr(), hh[1].data_ptr(), out.data_ptr()
         d.o = _ptr(o)
         d.img = img.data_ptr()
-        dout = dout.contiguous()
+        dout = dout.contiguous() if dout is not None else None
         dssum = dssum.contiguous() if dssum is not None else None
         dld = dld.contiguous() if dld is not None else None
-        d.dout, d.dssum, d.dld = dout.data_ptr(), _ptr(dssum), _ptr(dld)
+        if dout is None and dlogp is None:
+            dout = torch.zeros_like(x)
+        d.dout, d.dssum, d.dld, d.dlogp, d.Bsz = _ptr(dout), _ptr(dssum), _ptr(dld), _ptr(dlogp), Bsz
         dx = torch.empty_like(x) if ctx.needs_input_grad[4] else None
         d.dx = _ptr(dx)
         dcflat = torch.empty_like(cflat)
@@ -968,7 +1013,7 @@ class FlowChainFn(Function):
         d.dev_descs = _desc_buf(dev).data_ptr()
         _lib.check(lib.pf_flowchain_bwd(ctypes.byref(d), _stream()), "pf_flowchain_bwd")
         grads = [g.view(shp) for g, shp in zip(gp, pshapes)]
-        return (None, None, None, None, dx, dcflat, dst, *grads)
+        return (None, None, None, None, dx, dcflat, dst, None, *grads)
 
 
 class CondNetStackFn(Function):
@@ -1447,6 +1492,9 @@ class _Lin:
 _FAN = os.environ.get("PF_TRAIN_FAN", "1") != "0"
 # all flow blocks of a direction as one autograd node (FlowChainFn); "0" = one node per block piece (the A/B reference)
 _CHAIN = os.environ.get("PF_TRAIN_CHAIN", "1") != "0"
+# chains of one-element torch launches as fused kernels (csrc/train_glue.hip: interpolation of the latent, the log-likelihood
+# inside the f chain, the loss head of loss.PuganLossFn); "0" = the torch expressions (the A/B reference)
+_GLUE = os.environ.get("PF_TRAIN_GLUE", "1") != "0"
 
 
 def _flow_param_aliases(net):
@@ -1561,15 +1609,22 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         ccs = tuple(int(c.shape[-1]) for c in cs)
         cflat = torch.cat([c.reshape(-1) for c in cs])               # one tensor for its three consumers
         st = CondNetStackFn.apply(ccs, B * N, cflat, *st_prm)
-        z, ssum, ld = FlowChainFn.apply(0, 1, float(N), ccs, xyz, cflat, st, *pf)
-        logp = -(BatchSumFn.apply(z, 1).mean() + ld.sum() - ssum.sum() / B)
+        if _GLUE and nb < 8:
+            z, logp1 = FlowChainFn.apply(0, 1, float(N), ccs, xyz, cflat, st, B, *pf)       # log-likelihood from the kernel's epilogue
+            logp = logp1.view(())
+        else:
+            z, ssum, ld = FlowChainFn.apply(0, 1, float(N), ccs, xyz, cflat, st, 0, *pf)
+            logp = -(BatchSumFn.apply(z, 1).mean() + ld.sum() - ssum.sum() / B)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             w.record_stream(torch.cuda.current_stream())
-        zj = GatherRowsFn.apply(z, idx8)
-        fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)
-        u = fz.transpose(1, 2).reshape(B, N * R, 3)
-        x = FlowChainFn.apply(1, R, float(N), ccs, u, cflat, st, *pg)
+        if _GLUE and R <= 8:
+            u = InterpWsumFn.apply(w.view(B * N, 8, -1), z, idx8, R)
+        else:
+            zj = GatherRowsFn.apply(z, idx8)
+            fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)
+            u = fz.transpose(1, 2).reshape(B, N * R, 3)
+        x = FlowChainFn.apply(1, R, float(N), ccs, u, cflat, st, 0, *pg)
         return x, logp
 
     # ---- f + log-likelihood

@@ -406,3 +406,45 @@ def test_flow_chain_node_matches_the_per_block_nodes(B, N):
     floor = 1e-5 * max(float(g.abs().max()) for g in ga.values())
     for k in ga:
         assert float((ga[k] - gb[k]).abs().max()) <= 2e-4 * float(ga[k].abs().max()) + floor, k
+
+
+def test_fused_glue_of_the_training_step_matches_the_torch_expressions():
+    """PF_TRAIN_GLUE: the log-likelihood from the f chain kernel's epilogue, the latent interpolation as one kernel and the PU-GAN
+    loss head as one autograd node (csrc/train_glue.hip, loss.PuganLossFn) against the torch expressions they replace: the
+    training step's loss, its logged terms and every gradient, with per-sample radii."""
+    import copy
+    from puflow_amd import train_ops as T
+    from puflow_amd._prof import profile_calls
+    from puflow_amd.trainer import TrainerModule, default_cfg
+    dense = ((synth_patches(4, 1024, seed=52) + 1) / 2).to(DEV)
+    batch = (dense[:, ::4].contiguous(), dense, torch.tensor([0.8, 1.0, 1.3, 0.9], device=DEV))
+    tm = TrainerModule(default_cfg(learning_rate=1e-3), loss_mix="pugan")
+    tm.network.load_state_dict(synth_state_dict(51))
+    tm.network.set_to_initialized_state()
+    tm = tm.to(DEV).train()
+    state = copy.deepcopy(tm.state_dict())
+    res = {}
+    keep = T._GLUE
+    try:
+        for glue in (False, True):
+            T._GLUE = glue
+            tm.load_state_dict(state)
+            for p in tm.parameters():
+                p.grad = None
+            with profile_calls() as prof:
+                loss = tm.training_step(batch, 0)
+                loss.backward()
+            torch.cuda.synchronize()
+            for name in ("pf_pugan_loss_fwd", "pf_pugan_loss_bwd", "pf_interp_wsum_fwd", "pf_interp_wsum_bwd"):
+                assert len(prof.events.get(name, [])) == (1 if glue else 0), name
+            res[glue] = (float(loss), tm.logged_values(), {k: p.grad.detach().clone() for k, p in tm.named_parameters() if p.grad is not None})
+    finally:
+        T._GLUE = keep
+    (la, ta, ga), (lb, tb, gb) = res[False], res[True]
+    assert abs(la - lb) <= 2e-6 * abs(la)
+    for k in ("CD", "EMD", "logpx"):
+        assert abs(ta[k] - tb[k]) <= 2e-6 * abs(ta[k]) + 1e-9, k
+    assert ga.keys() == gb.keys() and len(ga) > 150
+    floor = 1e-5 * max(float(g.abs().max()) for g in ga.values())
+    for k in ga:
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-4 * float(ga[k].abs().max()) + floor, k
