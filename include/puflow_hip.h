@@ -348,6 +348,7 @@ typedef struct PfMlpTrain {
     float* dc;                      /* [rows / cdiv, cc], nullable */
     float* dW[3]; float* db[3];     /* db[l] nullable */
     float* ws; long long ws_floats; /* >= pf_mlp_train_ws_floats() */
+    int chunk;                      /* rows per split-K chunk of the weight-gradient launch: 0 = default, else a multiple of 32 */
 } PfMlpTrain;
 long long pf_mlp_train_ws_floats(const PfMlpTrain* p);
 int pf_mlp_train_fwd(const PfMlpTrain* p, void* stream);

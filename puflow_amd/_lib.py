@@ -41,7 +41,7 @@ class PfMlpTrain(ctypes.Structure):
                 ("width", c_int * 3), ("slope", c_float * 2), ("y", c_void_p), ("c", c_void_p),
                 ("W", c_void_p * 3), ("b", c_void_p * 3), ("h", c_void_p * 2), ("out", c_void_p), ("dout", c_void_p),
                 ("dz", c_void_p * 2), ("dy", c_void_p), ("dc", c_void_p), ("dW", c_void_p * 3), ("db", c_void_p * 3),
-                ("ws", c_void_p), ("ws_floats", c_longlong)]
+                ("ws", c_void_p), ("ws_floats", c_longlong), ("chunk", c_int)]
 
 
 _P8 = c_void_p * 8

@@ -26,7 +26,9 @@ namespace {
 
 constexpr int MLP_GRID = 512;
 constexpr int MLP_EB = 32, MLP_SLOTS = 9;
-__host__ __device__ inline int mlp_chunk(int rows) { return rows > 16384 ? 128 : 64; }      // rows per split-K chunk (multiple of MLP_EB)
+// rows per split-K chunk (multiple of MLP_EB): the descriptor's choice (batched launches have networks x layers of parallelism
+// already and want long chunks: fewer partial sums to write and add), else sized so that one network fills the chip
+__host__ __device__ inline int mlp_chunk(const PfMlpTrain& p) { return p.chunk > 0 ? p.chunk : (p.rows > 16384 ? 128 : 64); }
 
 __device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 c) {
     c = pf_mfma(a.x, b.x, c); c = pf_mfma(a.y, b.y, c); c = pf_mfma(a.z, b.z, c); c = pf_mfma(a.w, b.w, c);
@@ -297,7 +299,7 @@ __host__ __device__ inline MlpDwLayout mlp_dw_layout(const PfMlpTrain& p, const 
 __global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
     extern __shared__ float lds[];
     const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;
-    const int chunk = mlp_chunk(p.rows);
+    const int chunk = mlp_chunk(p);
     if ((int)blockIdx.x * chunk >= p.rows || (int)blockIdx.y >= p.nl) return;
     float* part = p.ws;
     const MlpShape sh = mlp_shape(p);
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpT
 __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
     const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;
     const float* part = p.ws;
-    const int nchunk = (p.rows + mlp_chunk(p.rows) - 1) / mlp_chunk(p.rows);
+    const int nchunk = (p.rows + mlp_chunk(p) - 1) / mlp_chunk(p);
     const MlpShape sh = mlp_shape(p);
     const MlpDwLayout L = mlp_dw_layout(p, sh);
     int cnt[3] = {0, 0, 0};
@@ -472,6 +474,7 @@ int mlp_check(const PfMlpTrain* p) {
     if (p->cc != 16 && p->cc != 32 && p->cc != 64 && p->cc != 128) return PF_ERR_UNSUPPORTED;
     if (p->cdiv != 1 && p->cdiv != 2 && p->cdiv != 4 && p->cdiv != 8 && p->cdiv != 16) return PF_ERR_UNSUPPORTED;
     if (p->rows % p->cdiv != 0) return PF_ERR_SHAPE;
+    if (p->chunk < 0 || p->chunk % MLP_EB != 0) return PF_ERR_SHAPE;
     for (int l = 0; l < p->nl; ++l) {
         if (p->width[l] < 1 || p->width[l] > 128) return PF_ERR_UNSUPPORTED;
         if (l < p->nl - 1 && p->width[l] != 16 && p->width[l] != 32 && p->width[l] != 64 && p->width[l] != 128) return PF_ERR_UNSUPPORTED;
@@ -488,7 +491,7 @@ extern "C" long long pf_mlp_train_ws_floats(const PfMlpTrain* p) {
     if (mlp_check(p) != PF_OK) return -1;
     const MlpShape sh = mlp_shape(*p);
     const MlpDwLayout L = mlp_dw_layout(*p, sh);
-    const int chunk = mlp_chunk(p->rows);
+    const int chunk = mlp_chunk(*p);
     const long long nchunk = (p->rows + chunk - 1) / chunk;
     return nchunk * L.total;
 }
@@ -532,7 +535,7 @@ extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
         if (p->nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr); }
         else { allow_lds(mlp_bwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(grid), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr); }
     }
-    const int chunk = mlp_chunk(p->rows);
+    const int chunk = mlp_chunk(*p);
     const int nchunk = (p->rows + chunk - 1) / chunk;
     {
         int ramax = 0, rbmax = 0;
@@ -612,7 +615,7 @@ extern "C" int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_
         const int ntiles = (p->rows + 15) / 16;
         const int g = (ntiles + 3) / 4 < MLP_GRID ? (ntiles + 3) / 4 : MLP_GRID;
         gmax = g > gmax ? g : gmax;
-        const int nchunk = (p->rows + mlp_chunk(p->rows) - 1) / mlp_chunk(p->rows);
+        const int nchunk = (p->rows + mlp_chunk(*p) - 1) / mlp_chunk(*p);
         cmax = nchunk > cmax ? nchunk : cmax;
         tmax = total > tmax ? total : tmax;
         b.p[k] = *p;
@@ -654,7 +657,7 @@ extern "C" int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_d
         }
         const size_t w2 = sizeof(float) * (size_t)MLP_EB * ((ramax + 16) + (rbmax + 16));
         lds_w = w2 > lds_w ? w2 : lds_w;
-        const int nchunk = (p->rows + mlp_chunk(p->rows) - 1) / mlp_chunk(p->rows);
+        const int nchunk = (p->rows + mlp_chunk(*p) - 1) / mlp_chunk(*p);
         cmax = nchunk > cmax ? nchunk : cmax;
         tmax = total > tmax ? total : tmax;
         b.p[k] = *p;

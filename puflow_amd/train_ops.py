@@ -1036,6 +1036,7 @@ class CondNetStackFn(Function):
                 d.width[l] = w.shape[0]
                 d.W[l] = w.data_ptr()
             d.slope[0] = d.slope[1] = 0.01
+            d.chunk = 256                                   # n networks x 3 layers in one launch: long split-K chunks
             d.c = cflat.data_ptr() + 4 * offs[k // 2]
             descs[k] = d
         return descs, offs
@@ -1252,6 +1253,19 @@ class BnMlpFn(Function):
         return (dxa, dxb, None, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dgs[0], dbe[0], dgs[1], dbe[1])
 
 
+_NBT_PENDING = None        # inside forward_train: the BatchNorm layers whose batch counters are bumped by ONE launch at its end
+
+
+def _count_batches(bns) -> None:
+    """num_batches_tracked += 1 (torch.nn.BatchNorm in train mode): deferred to the end of the training forward when one is
+    running (a launch per unit is pure latency on the step's dependency chain), immediate otherwise."""
+    if _NBT_PENDING is not None:
+        _NBT_PENDING.extend(bns)
+        return
+    with torch.no_grad():
+        torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+
+
 def bnmlp_fused(mlp, xa: Tensor, xb=None) -> Tensor:
     convs, bns = [mlp[0], mlp[3], mlp[6]], [mlp[1], mlp[4]]
     cfg = (0.01, float(bns[0].eps), float(bns[0].momentum), [bn.running_mean for bn in bns], [bn.running_var for bn in bns])
@@ -1261,8 +1275,7 @@ def bnmlp_fused(mlp, xa: Tensor, xb=None) -> Tensor:
     for bn in bns:
         prm += [bn.weight, bn.bias]
     out = BnMlpFn.apply(xa, xb, cfg, *prm)
-    with torch.no_grad():
-        torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+    _count_batches(bns)
     return out
 
 
@@ -1412,8 +1425,7 @@ def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=No
            [bn.running_mean for bn in bns], [bn.running_var for bn in bns], csr)
     out = EdgeConvUnitFn.apply(x, idx, cfg, *[c.weight for c in convs], *[c.bias for c in convs],
                                *[bn.weight for bn in bns], *[bn.bias for bn in bns])
-    with torch.no_grad():
-        torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)          # one launch for the unit's counters
+    _count_batches(bns)
     return out
 
 
@@ -1534,8 +1546,16 @@ def _flow_chain_params(net):
 
 def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     """PointInterpFlow.forward in train() mode (interpflow.py:327-337) with gradients."""
-    with sync_bn(getattr(net, "sync_batchnorm", False)):
-        return _forward_train(net, xyz, upratio)
+    global _NBT_PENDING
+    _NBT_PENDING = []
+    try:
+        with sync_bn(getattr(net, "sync_batchnorm", False)):
+            return _forward_train(net, xyz, upratio)
+    finally:
+        pending, _NBT_PENDING = _NBT_PENDING, None
+        if pending:                                   # on the calling stream, after the side stream has been joined
+            with torch.no_grad():
+                torch._foreach_add_([bn.num_batches_tracked for bn in pending], 1)
 
 
 def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
