@@ -592,9 +592,16 @@ struct EcDwArgs {
     float* part;
     float* bpart;                    // [nchunk][S]: column sums of dYfull over the chunk (the conv bias gradients)
 };
-constexpr int DW_EB = 32;
+#ifndef PF_DW_EB
+#define PF_DW_EB 32
+#endif
+constexpr int DW_EB = PF_DW_EB;                     // edges per staged block
 
-__global__ __launch_bounds__(256) void ec_dw_kernel(EcDwArgs a) {
+// NWV waves per workgroup share one staged block: 8 waves (4 per SIMD with two workgroups per CU) keep the matrix pipe fed while
+// other waves sit in the load -> LDS -> barrier phase (PMC at 4 waves: MFMA busy 24 %, 57 % of the wave cycles waiting)
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void ec_dw_kernel(EcDwArgs a) {
+    constexpr int NTH = 64 * NWV, SL = 32 / NWV;         // row-tile slots per wave: 8 at 4 waves, 4 at 8
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
     const bool outrows = blockIdx.y == 0;
@@ -606,14 +613,14 @@ __global__ __launch_bounds__(256) void ec_dw_kernel(EcDwArgs a) {
     // them along the rows; a wave owns column tiles ct_j = w % WC + WC j (j < 2) and row tiles rt_s = w / WC + (4 / WC) s
     // (s < 8): per K-step it reads <= 2 B values and <= 8 A values from LDS for <= 16 MFMAs
     const int NT = a.GT / 16, NRT = RA / 16;
-    const int WC = NT < 4 ? NT : 4, rstep = 4 / WC, rbase = wave / WC;
+    const int WC = NT < 4 ? NT : 4, rstep = NWV / WC, rbase = wave / WC;
     int ctj[2];
     bool cval[2];
 #pragma unroll
     for (int jc = 0; jc < 2; ++jc) { ctj[jc] = wave % WC + WC * jc; cval[jc] = ctj[jc] < NT; }
-    bool val[8][2];
+    bool val[SL][2];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < SL; ++s) {
         const int rt = rbase + rstep * s;
         int ntn = NT;
         if (!outrows) {
@@ -623,19 +630,19 @@ __global__ __launch_bounds__(256) void ec_dw_kernel(EcDwArgs a) {
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc) val[s][jc] = rt < NRT && cval[jc] && ctj[jc] < ntn;
     }
-    f4 acc[8][2];
+    f4 acc[SL][2];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { acc[s][0] = pf_splat(0.f); acc[s][1] = pf_splat(0.f); }
+    for (int s = 0; s < SL; ++s) { acc[s][0] = pf_splat(0.f); acc[s][1] = pf_splat(0.f); }
     const int e_lo = blockIdx.x * a.chunk, e_hi = min((int)a.E, e_lo + a.chunk);      // E < 2^30: 32-bit edge indices
     const int ra4 = RA / 4, gt4 = a.GT / 4;
     float bsum = 0.f;
     // float4 staging units, thread t owns units t, t + 256, ... (fixed (edge, column) per unit); the next block's units are
     // fetched into registers while the current block is multiplied
-    constexpr int UN = 4;                                // DW_EB * 128 / 4 / 256
+    constexpr int UN = DW_EB * 32 / NTH;                 // DW_EB * 128 / 4 / threads
     int elA[UN], cA[UN], elB[UN], cB[UN];
 #pragma unroll
     for (int n = 0; n < UN; ++n) {
-        const int k = threadIdx.x + 256 * n;
+        const int k = threadIdx.x + NTH * n;
         elA[n] = k / ra4; cA[n] = (k - elA[n] * ra4) * 4;
         elB[n] = k / gt4; cB[n] = (k - elB[n] * gt4) * 4;
     }
@@ -686,7 +693,7 @@ __global__ __launch_bounds__(256) void ec_dw_kernel(EcDwArgs a) {
             const float* br = Bs + (4 * ks + q) * ldb + row;
             const float b0 = cval[0] ? br[ctj[0] * 16] : 0.f, b1 = cval[1] ? br[ctj[1] * 16] : 0.f;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < SL; ++s) {
                 if (val[s][0] || val[s][1]) {
                     const float av = ar[rstep * s * 16];
                     if (val[s][0]) acc[s][0] = pf_mfma(av, b0, acc[s][0]);
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(256) void ec_dw_kernel(EcDwArgs a) {
     if (threadIdx.x < RA) a.bpart[(size_t)blockIdx.x * a.S + (outrows ? a.GT : 0) + threadIdx.x] = bsum;
     float* out = a.part + ((size_t)blockIdx.x * a.S + (outrows ? a.GT : 0)) * a.GT;
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < SL; ++s)
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc)
             if (val[s][jc])
@@ -784,6 +791,9 @@ struct Dims {
     int ntiles, grid, grid_light, nchunk;
 };
 constexpr int EC_DW_CHUNK = 512;
+#ifndef EC_DW_WAVES
+#define EC_DW_WAVES 8
+#endif
 
 int ec_dims(const PfEcTrain* p, Dims& d) {
     if (!p) return PF_ERR_NULL;
@@ -976,7 +986,10 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
                    p->slope, dwpart, bpart};
         const int ramax = p->odim > d.GT ? p->odim : d.GT;
         const size_t lds = sizeof(float) * (size_t)DW_EB * ((ramax + 16) + (d.GT + 16));
-        hipLaunchKernelGGL(ec_dw_kernel, dim3(d.nchunk, 2), dim3(256), lds, s, a);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ec_dw_kernel<EC_DW_WAVES>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(ec_dw_kernel<EC_DW_WAVES>, dim3(d.nchunk, 2), dim3(64 * EC_DW_WAVES), lds, s, a);
     }
     if (p->dx) {
         st = pf_gemm(p->dPQ, 2 * d.S, 1, p->Wpq, p->C, 1, p->dx, p->C, nullptr, d.T, p->C, 2 * d.S, gws,
@@ -1223,6 +1236,7 @@ __global__ __launch_bounds__(256) void bnl_bwd_kernel(BnlBwdArgs a) {
 }
 
 // part[chunk][c][u] = sum over the chunk's rows of dy[row, c] * act(X[row, u]) (c < RA, u < RB), bpart[chunk][c] = sum dy
+constexpr int BNL_EB = 32;                          // rows per staged block of bnl_dw_kernel
 struct BnlDwArgs {
     const float* dy; int RA;                   // [rows, RA]
     const float* X; int ldx, RB;               // [rows, ldx], RB columns used
@@ -1236,7 +1250,7 @@ __global__ __launch_bounds__(256) void bnl_dw_kernel(BnlDwArgs a) {
     const int RA = (a.RA + 15) & ~15, RB = (a.RB + 15) & ~15;
     const int lda = RA + 16, ldb = RB + 16;
     float* As = lds;
-    float* Bs = lds + DW_EB * lda;
+    float* Bs = lds + BNL_EB * lda;
     const int NT = RB / 16, NRT = RA / 16;
     const int WC = NT < 4 ? NT : 4, rstep = 4 / (WC == 3 ? 4 : WC), rbase = wave / (WC == 3 ? 4 : WC);
     int ctj[2];
@@ -1269,7 +1283,7 @@ __global__ __launch_bounds__(256) void bnl_dw_kernel(BnlDwArgs a) {
         for (int n = 0; n < UN; ++n) {
             f4 v = pf_splat(0.f);
             const int r = rb + elA[n], c = cA[n];
-            if (elA[n] < DW_EB && r < r_hi && c < a.RA) {
+            if (elA[n] < BNL_EB && r < r_hi && c < a.RA) {
                 if (veca) v = *reinterpret_cast<const f4*>(a.dy + (size_t)r * a.RA + c);
                 else
 #pragma unroll
@@ -1282,7 +1296,7 @@ __global__ __launch_bounds__(256) void bnl_dw_kernel(BnlDwArgs a) {
         for (int n = 0; n < UN; ++n) {
             f4 v = pf_splat(0.f);
             const int r = rb + elB[n], c = cB[n];
-            if (elB[n] < DW_EB && r < r_hi && c < a.RB) {
+            if (elB[n] < BNL_EB && r < r_hi && c < a.RB) {
                 f4 x = pf_splat(0.f), s1 = pf_splat(1.f), s2 = pf_splat(0.f);
                 if (vecb) x = *reinterpret_cast<const f4*>(a.X + (size_t)r * a.ldx + c);
                 else
@@ -1303,20 +1317,20 @@ __global__ __launch_bounds__(256) void bnl_dw_kernel(BnlDwArgs a) {
     };
     float bsum = 0.f;
     fetch(r_lo);
-    for (int rb = r_lo; rb < r_hi; rb += DW_EB) {
+    for (int rb = r_lo; rb < r_hi; rb += BNL_EB) {
         __syncthreads();
 #pragma unroll
         for (int n = 0; n < UN; ++n) {
-            if (elA[n] < DW_EB) *reinterpret_cast<f4*>(As + elA[n] * lda + cA[n]) = ra[n];
-            if (elB[n] < DW_EB) *reinterpret_cast<f4*>(Bs + elB[n] * ldb + cB[n]) = rbv[n];
+            if (elA[n] < BNL_EB) *reinterpret_cast<f4*>(As + elA[n] * lda + cA[n]) = ra[n];
+            if (elB[n] < BNL_EB) *reinterpret_cast<f4*>(Bs + elB[n] * ldb + cB[n]) = rbv[n];
         }
         __syncthreads();
-        if (rb + DW_EB < r_hi) fetch(rb + DW_EB);
+        if (rb + BNL_EB < r_hi) fetch(rb + BNL_EB);
         if (threadIdx.x < RA)
 #pragma unroll 8
-            for (int el = 0; el < DW_EB; ++el) bsum += As[el * lda + threadIdx.x];
+            for (int el = 0; el < BNL_EB; ++el) bsum += As[el * lda + threadIdx.x];
 #pragma unroll
-        for (int ks = 0; ks < DW_EB / 4; ++ks) {
+        for (int ks = 0; ks < BNL_EB / 4; ++ks) {
             const float* ar = As + (4 * ks + q) * lda + row + rbase * 16;
             const float* br = Bs + (4 * ks + q) * ldb + row;
             const float b0 = cval[0] ? br[ctj[0] * 16] : 0.f, b1 = cval[1] ? br[ctj[1] * 16] : 0.f;
@@ -1484,7 +1498,7 @@ extern "C" int pf_bnmlp_train_bwd(const PfBnMlpTrain* p, void* stream) {
                   int coff, float* db) {
         const int RA16 = (RA + 15) & ~15, RB16 = (RB + 15) & ~15;
         BnlDwArgs a{dy, RA, X, ldx, RB, sc, sh, p->slope, p->rows, BNL_CHUNK, part, bpart};
-        const size_t lds = sizeof(float) * (size_t)DW_EB * ((RA16 + 16) + (RB16 + 16));
+        const size_t lds = sizeof(float) * (size_t)BNL_EB * ((RA16 + 16) + (RB16 + 16));
         hipLaunchKernelGGL(bnl_dw_kernel, dim3(nchunk), dim3(256), lds, s, a);
         const int total = RA * (RB + 1);
         hipLaunchKernelGGL(bnl_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, part, bpart, nchunk, RA, RB, RA16, RB16, dW,
