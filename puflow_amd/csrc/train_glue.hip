@@ -19,76 +19,65 @@ namespace {
 
 constexpr int IW_K = 8, IW_RMAX = 8;
 
-// one thread per original point t: a[t,k,r] = softmax_k w[t,k,r];  u[t R + r, c] = sum_k a[t,k,r] z[b(t) N + idx[t,k], c]
+// one thread per (point t, replica r): a[t,k,r] = softmax_k w[t,k,r];  u[t R + r, c] = sum_k a[t,k,r] z[b(t) N + idx[t,k], c]
 __global__ __launch_bounds__(256) void interp_wsum_fwd_kernel(const float* __restrict__ w, int ldw, const float* __restrict__ z,
                                                              const int* __restrict__ idx, int N, int R, long long T,
                                                              float* __restrict__ a, float* __restrict__ u) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
+    const long long tr = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tr >= T * R) return;
+    const long long t = tr / R;
+    const int r = (int)(tr - t * R);
     const long long base = (t / N) * N;
-    float zz[IW_K][3];
+    float lg[IW_K], zz[IW_K][3];
 #pragma unroll
     for (int k = 0; k < IW_K; ++k) {
+        lg[k] = w[(t * IW_K + k) * ldw + r];
         const float* zp = z + (base + idx[t * IW_K + k]) * 3;
         zz[k][0] = zp[0]; zz[k][1] = zp[1]; zz[k][2] = zp[2];
     }
-    for (int r = 0; r < R; ++r) {
-        float m = -__builtin_inff();
+    float m = lg[0];
 #pragma unroll
-        for (int k = 0; k < IW_K; ++k) m = fmaxf(m, w[(t * IW_K + k) * ldw + r]);
-        float e[IW_K], s = 0.f;
+    for (int k = 1; k < IW_K; ++k) m = fmaxf(m, lg[k]);
+    float e[IW_K], s = 0.f;
 #pragma unroll
-        for (int k = 0; k < IW_K; ++k) { e[k] = expf(w[(t * IW_K + k) * ldw + r] - m); s += e[k]; }
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    for (int k = 0; k < IW_K; ++k) { e[k] = expf(lg[k] - m); s += e[k]; }
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < IW_K; ++k) {
-            const float ak = e[k] / s;
-            a[(t * IW_K + k) * R + r] = ak;
-            o0 += ak * zz[k][0]; o1 += ak * zz[k][1]; o2 += ak * zz[k][2];
-        }
-        float* up = u + (t * R + r) * 3;
-        up[0] = o0; up[1] = o1; up[2] = o2;
+    for (int k = 0; k < IW_K; ++k) {
+        const float ak = e[k] / s;
+        a[(t * IW_K + k) * R + r] = ak;
+        o0 += ak * zz[k][0]; o1 += ak * zz[k][1]; o2 += ak * zz[k][2];
     }
+    float* up = u + tr * 3;
+    up[0] = o0; up[1] = o1; up[2] = o2;
 }
+// one thread per (point t, neighbour k), the 8 lanes of a point side by side:
 // dw[t,k,r] = a (da - sum_k a da), da[t,k,r] = sum_c du[t R + r, c] z_k[c] (dw beyond R = 0);  dz[neighbour] += sum_r a du
 __global__ __launch_bounds__(256) void interp_wsum_bwd_kernel(const float* __restrict__ a, const float* __restrict__ z,
                                                              const int* __restrict__ idx, const float* __restrict__ du, int N,
                                                              int R, int ldw, long long T, float* __restrict__ dw,
                                                              float* __restrict__ dz) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
+    const long long tk = (long long)blockIdx.x * 256 + threadIdx.x;      // T * 8 is a multiple of 8: a point's lanes are all in or all out
+    if (tk >= T * IW_K) return;
+    const long long t = tk / IW_K;
     const long long base = (t / N) * N;
-    float zz[IW_K][3], g[IW_K][3];
-    int jj[IW_K];
-#pragma unroll
-    for (int k = 0; k < IW_K; ++k) {
-        jj[k] = idx[t * IW_K + k];
-        const float* zp = z + (base + jj[k]) * 3;
-        zz[k][0] = zp[0]; zz[k][1] = zp[1]; zz[k][2] = zp[2];
-        g[k][0] = g[k][1] = g[k][2] = 0.f;
-    }
+    const int j = idx[tk];
+    const float* zp = z + (base + j) * 3;
+    const float z0 = zp[0], z1 = zp[1], z2 = zp[2];
+    float g0s = 0.f, g1s = 0.f, g2s = 0.f;
     for (int r = 0; r < R; ++r) {
         const float* gp = du + (t * R + r) * 3;
         const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
-        float da[IW_K], ak[IW_K], dot = 0.f;
-#pragma unroll
-        for (int k = 0; k < IW_K; ++k) {
-            ak[k] = a[(t * IW_K + k) * R + r];
-            da[k] = g0 * zz[k][0] + g1 * zz[k][1] + g2 * zz[k][2];
-            dot += ak[k] * da[k];
-            g[k][0] += ak[k] * g0; g[k][1] += ak[k] * g1; g[k][2] += ak[k] * g2;
-        }
-#pragma unroll
-        for (int k = 0; k < IW_K; ++k) dw[(t * IW_K + k) * ldw + r] = ak[k] * (da[k] - dot);
+        const float ak = a[tk * R + r];
+        const float da = g0 * z0 + g1 * z1 + g2 * z2;
+        float dot = ak * da;
+        dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);
+        dw[tk * ldw + r] = ak * (da - dot);
+        g0s += ak * g0; g1s += ak * g1; g2s += ak * g2;
     }
-    for (int r = R; r < ldw; ++r)
-#pragma unroll
-        for (int k = 0; k < IW_K; ++k) dw[(t * IW_K + k) * ldw + r] = 0.f;
-#pragma unroll
-    for (int k = 0; k < IW_K; ++k) {
-        float* dp = dz + (base + jj[k]) * 3;
-        atomicAdd(dp, g[k][0]); atomicAdd(dp + 1, g[k][1]); atomicAdd(dp + 2, g[k][2]);
-    }
+    for (int r = R; r < ldw; ++r) dw[tk * ldw + r] = 0.f;
+    float* dp = dz + (base + j) * 3;
+    atomicAdd(dp, g0s); atomicAdd(dp + 1, g1s); atomicAdd(dp + 2, g2s);
 }
 __global__ __launch_bounds__(256) void glue_zero_kernel(float* p, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0.f;
@@ -101,27 +90,30 @@ __global__ __launch_bounds__(256) void emd_init_kernel(float* price, int* assign
     }
 }
 
-// one workgroup: out[0] = loss, out[1] = w_emd emd, out[2] = w_logp logp, out[3] = w_cd cd
-__global__ __launch_bounds__(256) void pugan_loss_fwd_kernel(const float* __restrict__ logp, const float* __restrict__ dist,
-                                                            const float* __restrict__ radius, const float* __restrict__ per,
-                                                            int B, int n, float w_logp, float w_emd, float w_cd,
-                                                            float* __restrict__ out) {
-    __shared__ float sh[256];
+// one workgroup of 16 waves, a wave per sample (strided): out[0] = loss, out[1] = w_emd emd, out[2] = w_logp logp, out[3] = w_cd cd
+__global__ __launch_bounds__(1024) void pugan_loss_fwd_kernel(const float* __restrict__ logp, const float* __restrict__ dist,
+                                                             const float* __restrict__ radius, const float* __restrict__ per,
+                                                             int B, int n, float w_logp, float w_emd, float w_cd,
+                                                             float* __restrict__ out) {
+    __shared__ float part[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float emd = 0.f;
-    for (int b0 = 0; b0 < B; b0 += 4) {                  // a wave per sample, samples in order: fixed summation order
-        const int b = b0 + wave;
-        float s = 0.f;
-        if (b < B)
-            for (int i = lane; i < n; i += 64) s += dist[(size_t)b * n + i];
+    float acc = 0.f;                                     // this wave's samples, in order
+    for (int b = wave; b < B; b += 16) {
+        const float* dp = dist + (size_t)b * n;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = lane;
+        for (; i + 192 < n; i += 256) { s0 += dp[i]; s1 += dp[i + 64]; s2 += dp[i + 128]; s3 += dp[i + 192]; }
+        for (; i < n; i += 64) s0 += dp[i];
+        float sv = (s0 + s1) + (s2 + s3);
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
-        if (lane == 0) sh[wave] = b < B ? s / (radius ? radius[b] : 1.f) : 0.f;
-        __syncthreads();
-        if (threadIdx.x == 0) emd += (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        __syncthreads();
+        for (int m = 1; m < 64; m <<= 1) sv += __shfl_xor(sv, m);
+        acc += sv / (radius ? radius[b] : 1.f);
     }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        float emd = 0.f;
+        for (int k = 0; k < 16; ++k) emd += part[k];
         float cd = 0.f;
         for (int b = 0; b < B; ++b) cd += per[b];
         cd /= (float)B;
@@ -162,8 +154,8 @@ extern "C" int pf_interp_wsum_fwd(const float* w, int ldw, const float* z, const
                                   float* a, float* u, void* stream) {
     if (!w || !z || !idx || !a || !u) return PF_ERR_NULL;
     if (K != IW_K || R <= 0 || R > IW_RMAX || R > ldw || T <= 0 || N <= 0 || T % N != 0) return PF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(interp_wsum_fwd_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, z, idx,
-                       N, R, T, a, u);
+    hipLaunchKernelGGL(interp_wsum_fwd_kernel, dim3((unsigned)((T * R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, z,
+                       idx, N, R, T, a, u);
     return pf_last_launch_status();
 }
 // du [T R, 3] -> dw [T, 8, ldw], dz [B N, 3] (zero-filled here, then accumulated)
@@ -172,8 +164,8 @@ extern "C" int pf_interp_wsum_bwd(const float* a, const float* z, const int* idx
     if (!a || !z || !idx || !du || !dw || !dz) return PF_ERR_NULL;
     if (K != IW_K || R <= 0 || R > IW_RMAX || R > ldw || T <= 0 || N <= 0 || T % N != 0) return PF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(glue_zero_kernel, dim3(glue_grid(T * 3)), dim3(256), 0, (hipStream_t)stream, dz, T * 3);
-    hipLaunchKernelGGL(interp_wsum_bwd_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, z, idx, du,
-                       N, R, ldw, T, dw, dz);
+    hipLaunchKernelGGL(interp_wsum_bwd_kernel, dim3((unsigned)((T * IW_K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, z,
+                       idx, du, N, R, ldw, T, dw, dz);
     return pf_last_launch_status();
 }
 
@@ -190,7 +182,7 @@ extern "C" int pf_pugan_loss_fwd(const float* logp, const float* dist, const flo
                                  float w_logp, float w_emd, float w_cd, float* out, void* stream) {
     if (!logp || !dist || !per || !out) return PF_ERR_NULL;
     if (B <= 0 || n <= 0) return PF_ERR_SHAPE;
-    hipLaunchKernelGGL(pugan_loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, dist, radius, per, B, n, w_logp,
+    hipLaunchKernelGGL(pugan_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, dist, radius, per, B, n, w_logp,
                        w_emd, w_cd, out);
     return pf_last_launch_status();
 }
