@@ -760,9 +760,10 @@ __global__ __launch_bounds__(256) void ec_fold_kernel(EcConvs cv, float* Wpq, fl
 }
 // dW_t[r, :] = [dWp | dWq | dWq - dWp | sum_chunks part[:, rowoff_t + r, :g t]],  dbias_t[r] = sum_chunks bpart[:, rowoff_t + r].
 // 64 consecutive elements per workgroup, the chunk sum split four ways (threadIdx.y) and joined through LDS.
-__global__ __launch_bounds__(256) void ec_assemble_kernel(EcConvs cv, const float* dWpq, const float* part, int nchunk,
-                                                          const float* bpart, int total) {
-    __shared__ double sh[4][64], shb[4][64];
+constexpr int ASM_G = 16;            // groups of 64 threads that share the chunk range of an output element
+__global__ __launch_bounds__(64 * ASM_G) void ec_assemble_kernel(EcConvs cv, const float* dWpq, const float* part, int nchunk,
+                                                                const float* bpart, int total) {
+    __shared__ double sh[ASM_G][64], shb[ASM_G][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;
     int t = 0, r = 0, col = 0, srow = 0;
@@ -778,15 +779,16 @@ __global__ __launch_bounds__(256) void ec_assemble_kernel(EcConvs cv, const floa
     if (ok && grow) {
         const int u = col - 3 * cv.C;
         int k = ty;
-        for (; k + 12 < nchunk; k += 16) {                            // four loads in flight per thread
-            const float v0 = part[((size_t)k * cv.S + srow) * cv.GT + u], v1 = part[((size_t)(k + 4) * cv.S + srow) * cv.GT + u];
-            const float v2 = part[((size_t)(k + 8) * cv.S + srow) * cv.GT + u], v3 = part[((size_t)(k + 12) * cv.S + srow) * cv.GT + u];
+        for (; k + 3 * ASM_G < nchunk; k += 4 * ASM_G) {              // four loads in flight per thread
+            const float v0 = part[((size_t)k * cv.S + srow) * cv.GT + u], v1 = part[((size_t)(k + ASM_G) * cv.S + srow) * cv.GT + u];
+            const float v2 = part[((size_t)(k + 2 * ASM_G) * cv.S + srow) * cv.GT + u];
+            const float v3 = part[((size_t)(k + 3 * ASM_G) * cv.S + srow) * cv.GT + u];
             s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
         }
-        for (; k < nchunk; k += 4) s += (double)part[((size_t)k * cv.S + srow) * cv.GT + u];
+        for (; k < nchunk; k += ASM_G) s += (double)part[((size_t)k * cv.S + srow) * cv.GT + u];
     }
     if (ok && col == 0)
-        for (int k = ty; k < nchunk; k += 4) sb += (double)bpart[(size_t)k * cv.S + srow];
+        for (int k = ty; k < nchunk; k += ASM_G) sb += (double)bpart[(size_t)k * cv.S + srow];
     sh[ty][tx] = s; shb[ty][tx] = sb;
     __syncthreads();
     if (ty != 0 || !ok) return;
@@ -794,9 +796,19 @@ __global__ __launch_bounds__(256) void ec_assemble_kernel(EcConvs cv, const floa
     if (col < cv.C) v = dWpq[(size_t)srow * cv.C + col];
     else if (col < 2 * cv.C) v = dWpq[(size_t)(cv.S + srow) * cv.C + col - cv.C];
     else if (col < 3 * cv.C) v = dWpq[(size_t)(cv.S + srow) * cv.C + col - 2 * cv.C] - dWpq[(size_t)srow * cv.C + col - 2 * cv.C];
-    else v = (float)((sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]));
+    else {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < ASM_G; ++k) a += sh[k][tx];
+        v = (float)a;
+    }
     cv.dW[t][(size_t)r * cv.width[t] + col] = v;
-    if (col == 0) cv.dbias[t][r] = (float)((shb[0][tx] + shb[1][tx]) + (shb[2][tx] + shb[3][tx]));
+    if (col == 0) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < ASM_G; ++k) a += shb[k][tx];
+        cv.dbias[t][r] = (float)a;
+    }
 }
 
 __global__ __launch_bounds__(256) void ec_zero_kernel(f4* p, long long n4) {
@@ -1026,7 +1038,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     if (st) return st;
     int total = 0;
     for (int t = 0; t < d.nconvs; ++t) total += cv.rows[t] * cv.width[t];
-    hipLaunchKernelGGL(ec_assemble_kernel, dim3((total + 63) / 64), dim3(256), 0, s, cv, p->dWpq, dwpart, d.nchunk, bpart, total);
+    hipLaunchKernelGGL(ec_assemble_kernel, dim3((total + 63) / 64), dim3(64 * ASM_G), 0, s, cv, p->dWpq, dwpart, d.nchunk, bpart, total);
     return pf_last_launch_status();
 }
 
