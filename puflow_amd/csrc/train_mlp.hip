@@ -25,7 +25,13 @@
 namespace {
 
 constexpr int MLP_GRID = 512;
-constexpr int MLP_EB = 32, MLP_SLOTS = 9;
+#ifndef PF_MLP_DW_WAVES
+#define PF_MLP_DW_WAVES 4
+#endif
+#ifndef PF_MLP_RG
+#define PF_MLP_RG 16
+#endif
+constexpr int MLP_EB = 32, MLP_DW_WAVES = PF_MLP_DW_WAVES, MLP_SLOTS = (36 + MLP_DW_WAVES - 1) / MLP_DW_WAVES;   // 36 = 4 x 9 tiles of the widest layer
 // rows per split-K chunk (multiple of MLP_EB): the descriptor's choice (batched launches have networks x layers of parallelism
 // already and want long chunks: fewer partial sums to write and add), else sized so that one network fills the chip
 __host__ __device__ inline int mlp_chunk(const PfMlpTrain& p) { return p.chunk > 0 ? p.chunk : (p.rows > 16384 ? 128 : 64); }
@@ -296,7 +302,10 @@ __host__ __device__ inline MlpDwLayout mlp_dw_layout(const PfMlpTrain& p, const 
     return L;
 }
 
-__global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
+// MLP_DW_WAVES waves share one staged block (as csrc/train_fused.hip ec_dw_kernel: more waves per SIMD keep the matrix pipe fed
+// while others sit in the load -> LDS -> barrier phase)
+__global__ __launch_bounds__(64 * MLP_DW_WAVES) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
+    constexpr int NTH = 64 * MLP_DW_WAVES;
     extern __shared__ float lds[];
     const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;
     const int chunk = mlp_chunk(p);
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpT
     bool val[MLP_SLOTS];
 #pragma unroll
     for (int s = 0; s < MLP_SLOTS; ++s) {
-        const int id = wave + 4 * s;
+        const int id = wave + MLP_DW_WAVES * s;
         val[s] = id < NRT * NT;
         rts[s] = val[s] ? id / NT : 0; cts[s] = val[s] ? id % NT : 0;
     }
@@ -331,13 +340,13 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpT
     // staging in float4 units, thread t owns units t, t + 256, ...: (row, column) of each unit fixed for the whole kernel.
     // The next block's units are fetched into registers while the current block is multiplied (the products are short:
     // without this every block paid a full memory latency between two barriers)
-    constexpr int UA = 4, UB = 5;                       // MLP_EB * 128 / 4 / 256, MLP_EB * 144 / 4 / 256 rounded up
+    constexpr int UA = (MLP_EB * 32 + NTH - 1) / NTH, UB = (MLP_EB * 36 + NTH - 1) / NTH;     // float4 units of a 128- / 144-wide block per thread
     const int ra4 = RA / 4, rb4 = RB / 4;
     int elA[UA], cA[UA], elB[UB], cB[UB];
 #pragma unroll
-    for (int n = 0; n < UA; ++n) { const int k = threadIdx.x + 256 * n; elA[n] = k / ra4; cA[n] = (k - elA[n] * ra4) * 4; }
+    for (int n = 0; n < UA; ++n) { const int k = threadIdx.x + NTH * n; elA[n] = k / ra4; cA[n] = (k - elA[n] * ra4) * 4; }
 #pragma unroll
-    for (int n = 0; n < UB; ++n) { const int k = threadIdx.x + 256 * n; elB[n] = k / rb4; cB[n] = (k - elB[n] * rb4) * 4; }
+    for (int n = 0; n < UB; ++n) { const int k = threadIdx.x + NTH * n; elB[n] = k / rb4; cB[n] = (k - elB[n] * rb4) * 4; }
     const int dsh = 31 - __clz(p.cdiv);                 // cdiv is a power of two
     f4 ra[UA], rbv[UB];
     auto fetch = [&](int rb) {
@@ -407,7 +416,8 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpT
 }
 
 // partial sums -> dW[l] [wo, in_l] (column j < td of layer 0 sits behind the cc conditioning columns in the partials), db[l]
-__global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
+constexpr int MLP_RG = PF_MLP_RG;           // groups of 64 threads that share the chunk range of an output element
+__global__ __launch_bounds__(64 * MLP_RG) void mlp_dw_reduce_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
     const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;
     const float* part = p.ws;
     const int nchunk = (p.rows + mlp_chunk(p) - 1) / mlp_chunk(p);
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(PfMlpTrain p0, const
     for (int l = 0; l < 3; ++l)
         if (l < p.nl) cnt[l] = sh.wo[l] * (sh.in[l] + 1);
     const int total = cnt[0] + cnt[1] + cnt[2];
-    __shared__ double shr[4][64];
+    __shared__ double shr[MLP_RG][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;
     const bool ok = i < total;
@@ -438,17 +448,19 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(PfMlpTrain p0, const
     if (ok)
     {
         int k = ty;
-        for (; k + 12 < nchunk; k += 16) {                            // four loads in flight per thread
-            const float v0 = part[(size_t)k * L.total + src], v1 = part[(size_t)(k + 4) * L.total + src];
-            const float v2 = part[(size_t)(k + 8) * L.total + src], v3 = part[(size_t)(k + 12) * L.total + src];
+        for (; k + 3 * MLP_RG < nchunk; k += 4 * MLP_RG) {            // four loads in flight per thread
+            const float v0 = part[(size_t)k * L.total + src], v1 = part[(size_t)(k + MLP_RG) * L.total + src];
+            const float v2 = part[(size_t)(k + 2 * MLP_RG) * L.total + src], v3 = part[(size_t)(k + 3 * MLP_RG) * L.total + src];
             s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
         }
-        for (; k < nchunk; k += 4) s += (double)part[(size_t)k * L.total + src];
+        for (; k < nchunk; k += MLP_RG) s += (double)part[(size_t)k * L.total + src];
     }
     shr[ty][tx] = s;
     __syncthreads();
     if (ty != 0 || !ok) return;
-    s = (shr[0][tx] + shr[1][tx]) + (shr[2][tx] + shr[3][tx]);
+    s = 0.0;
+#pragma unroll
+    for (int k = 0; k < MLP_RG; ++k) s += shr[k][tx];
     float* db = sel3(p.db, l);
     if (j == inl) { if (db) db[c] = (float)s; }
     else sel3(p.dW, l)[(size_t)c * inl + j] = (float)s;
@@ -541,11 +553,11 @@ extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
         int ramax = 0, rbmax = 0;
         for (int l = 0; l < p->nl; ++l) { ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l]; }
         const size_t lds = sizeof(float) * (size_t)MLP_EB * ((ramax + 16) + (rbmax + 16));
-        hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr);
+        hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(64 * MLP_DW_WAVES), lds, s, *p, (const PfMlpTrain*)nullptr);
     }
     int total = 0;
     for (int l = 0; l < p->nl; ++l) total += sh.wo[l] * (sh.in[l] + 1);
-    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, *p, (const PfMlpTrain*)nullptr);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((total + 63) / 64), dim3(64 * MLP_RG), 0, s, *p, (const PfMlpTrain*)nullptr);
     return pf_last_launch_status();
 }
 
@@ -625,8 +637,8 @@ extern "C" int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_
     const PfMlpTrain* dd = (const PfMlpTrain*)dev_descs;
     if (descs[0].nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(gmax, 1, n), dim3(256), lds_b, s, b.p[0], dd); }
     else { allow_lds(mlp_bwd_kernel<3>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(gmax, 1, n), dim3(256), lds_b, s, b.p[0], dd); }
-    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(256), lds_w, s, b.p[0], dd);
-    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(256), 0, s, b.p[0], dd);
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b.p[0], dd);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(64 * MLP_RG), 0, s, b.p[0], dd);
     return pf_last_launch_status();
 }
 
@@ -665,7 +677,7 @@ extern "C" int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_d
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(mlp_desc_upload_kernel, dim3(1), dim3(256), 0, s, b, (unsigned*)dev_descs, (int)(n * sizeof(PfMlpTrain) / 4));
     const PfMlpTrain* dd = (const PfMlpTrain*)dev_descs;
-    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(256), lds_w, s, b.p[0], dd);
-    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(256), 0, s, b.p[0], dd);
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b.p[0], dd);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(64 * MLP_RG), 0, s, b.p[0], dd);
     return pf_last_launch_status();
 }
