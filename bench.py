@@ -479,6 +479,29 @@ def bench_train(args, world, rank, dev, dist):
                     "flops_basis": f"executed: {EC_BWD_MAC_PER_EDGE} MAC per edge x {E} edges per call (all products on "
                                    "v_mfma_f32_16x16x4_f32); live HIP-event duration of the call's launches on the launch stream",
                     "calls_ms_per_step": calls_ms}
+            # HBM bytes of the same call from the committed PMC summary of the training kernels (collected offline over eager
+            # steps: tools/pmc_cmd.sh + tools/train_eager_steps.py): the launches of one 128-channel unit's backward
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_train_latest.json")) as f:
+                    pk = json.load(f)
+                pk = pk.get("kernels", pk)
+                group = {"ec_bwd_kernel<8, 0>": 1, "ec_bwd_kernel<8, 2>": 1, "ec_bwd_kernel<4, 2>": 1, "ec_bwd_kernel<2, 2>": 1,
+                         "ec_bwd0_kernel": 1, "ec_pq_bwd_csr_kernel": 1, "ec_dw_kernel<8>": 1, "gemm_kernel<2, 2, 2, 2, true>": 2,
+                         "gemm_reduce_kernel": 1, "ec_assemble_kernel": 1}
+                tot, us = 0.0, 0.0
+                for k, n in group.items():
+                    tot += n * pk[k]["hbm_bytes_per_launch"]
+                    us += n * pk[k]["avg_us"]
+                alg = E * 128 * 4 * (1 + 1 + 1) + 8192 * (256 + 512 + 128) * 4      # Y, dA read once, dA written once; dh, dPQ, dx
+                roof["traffic"] = tot
+                roof["traffic_vs_algorithmic"] = tot / alg
+                roof["profile"] = {"file": "profiles/pmc_train_latest.json", "kernels": group, "sum_avg_us": us,
+                                   "note": "FETCH_SIZE x2 + WRITE_SIZE per launch (gfx950 correction), summed over the call's launches; "
+                                           "algorithmic bytes = the [E, 128] growth outputs and their gradient read once and the "
+                                           "gradient written once + the per-point tensors; the dense block re-reads its gradient "
+                                           "tensor once per layer by construction (in-place accumulation into the earlier layers' columns)"}
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             cpu = train_cpu_baseline(sd, dense_cpu, args.cpu_seconds)
     if world > 1:
