@@ -444,6 +444,184 @@ __global__ __launch_bounds__(256) void ec_bwd_kernel(EcBwdArgs a) {
     stat_flush<NT>(s0, s1, a.sc0, a.sg, a.fin, red);
 }
 
+// ------------------------------------------------------------------------------------------------ backward, gather form
+// The scatter form above walks the convs from last to first and ADDS each one's contribution into the gradient columns of all
+// earlier layers: the [E, GT] gradient tensor is read and rewritten once per layer (452 MB per 128-channel unit, 2.5 - 2.8 TB/s
+// in every one of those kernels).  Here layer s GATHERS its own g columns from everything that consumes them, once:
+//     G_s = dYout Wout[:, cols_s] + sum_{t > s} dy_t W_t[:, cols_s]
+// with dy_t = BatchNorm + LeakyReLU backward of G_t (formed on load for t = s + 1, whose sums the previous launch finalised, and
+// stored back; already in place for t > s + 1).  Same products, 4 + 4 + ... launches replaced by one per layer, every gradient
+// column written once raw and once transformed: ~230 MB per unit.  Epilogue: the BatchNorm-backward sums of layer s.
+struct EcBwdgArgs {
+    const float* dh; const unsigned char* arg; const float* dyout; int odim;
+    float* dA; const float* Y; int ld;
+    const float* aff; const float* coef;
+    const float* Wout; int ldwout;       // Wout[c * ldwout + col]: conv_out row c, growth column col (pointer offset by 3C)
+    const float* Wg[8]; int ldwg[8];     // growth conv t: Wg[t][c * ldwg[t] + col]
+    int s, nc, g, ntiles;
+    float slope;
+    StatFin fin;
+};
+
+template <int NTG, int SRC>
+__global__ __launch_bounds__(256) void ec_bwdg_kernel(EcBwdgArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float red[8 * STAT_W];
+    const int g = a.g, g16 = (g + 15) & ~15, od16 = (a.odim + 15) & ~15;
+    const int kpo = od16 + 4, kpg = g16 + 4, KSo = od16 / 16, KSg = g16 / 16;
+    const int c0 = g * a.s, nsrc = a.nc - 1 - a.s;
+    float* Wo = lds;                                   // Wo[u][c] = Wout[c][c0 + u]
+    float* Wgl = Wo + NTG * 16 * kpo;                  // per later layer t: [NTG * 16][kpg], Wg_t[u][c] = Wg[t][c][c0 + u]
+    float* cf = Wgl + nsrc * NTG * 16 * kpg;           // [6][g16]: scale, shift, mean, rstd, m1, m2 of layer s + 1
+    for (int c = threadIdx.x >> 4; c < od16; c += 16) {
+        float v[NTG];
+#pragma unroll
+        for (int k = 0; k < NTG; ++k) {
+            const int u = (threadIdx.x & 15) + 16 * k;
+            v[k] = (c < a.odim && u < g) ? a.Wout[(size_t)c * a.ldwout + c0 + u] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NTG; ++k) Wo[((threadIdx.x & 15) + 16 * k) * kpo + c] = v[k];
+    }
+    for (int n = 0; n < nsrc; ++n) {
+        const int t = a.s + 1 + n;
+        const float* W = a.Wg[t];
+        const int ldw = a.ldwg[t];
+        float* dst = Wgl + n * NTG * 16 * kpg;
+        for (int c = threadIdx.x >> 4; c < g16; c += 16) {
+#pragma unroll
+            for (int k = 0; k < NTG; ++k) {
+                const int u = (threadIdx.x & 15) + 16 * k;
+                dst[u * kpg + c] = (c < g && u < g) ? W[(size_t)c * ldw + c0 + u] : 0.f;
+            }
+        }
+    }
+    if (nsrc > 0) {
+        const int c1 = c0 + g;
+        for (int i = threadIdx.x; i < g16; i += 256) {
+            const bool ok = i < g;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) cf[w * g16 + i] = ok ? a.aff[w * a.ld + c1 + i] : 0.f;
+            cf[4 * g16 + i] = ok ? a.coef[c1 + i] : 0.f;
+            cf[5 * g16 + i] = ok ? a.coef[a.ld + c1 + i] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    float s0[NTG], s1[NTG], ssc[NTG], ssh[NTG], smu[NTG], srs[NTG];
+#pragma unroll
+    for (int nt = 0; nt < NTG; ++nt) {
+        s0[nt] = s1[nt] = 0.f;
+        const int cl = nt * 16 + row;
+        const bool ok = cl < g;
+        ssc[nt] = ok ? a.aff[c0 + cl] : 0.f;
+        ssh[nt] = ok ? a.aff[a.ld + c0 + cl] : 0.f;
+        smu[nt] = ok ? a.aff[2 * a.ld + c0 + cl] : 0.f;
+        srs[nt] = ok ? a.aff[3 * a.ld + c0 + cl] : 0.f;
+    }
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
+        const long long e0 = (long long)tile * 16;
+        // the tile's loads first: conv_out's gradient rows, then the later layers' gradient columns of this lane's edge
+        f4 src[8];
+        unsigned ag[SRC == 0 ? 8 : 1];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int c = ks * 16 + 4 * q;
+            src[ks] = pf_splat(0.f);
+            if (ks < KSo && c < a.odim) {
+                if (SRC == 0) {
+                    src[ks] = *reinterpret_cast<const f4*>(a.dh + (long long)tile * a.odim + c);
+                    ag[ks] = *reinterpret_cast<const unsigned*>(a.arg + (long long)tile * a.odim + c);
+                } else src[ks] = *reinterpret_cast<const f4*>(a.dyout + (e0 + row) * a.odim + c);
+            }
+        }
+        float* drow = a.dA + (e0 + row) * a.ld;
+        f4 gsrc[7][2];
+        f4 ysrc[2];
+#pragma unroll
+        for (int n = 0; n < 7; ++n)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                gsrc[n][ks] = pf_splat(0.f);
+                const int c = ks * 16 + 4 * q;
+                if (n < nsrc && ks < KSg && c < g) gsrc[n][ks] = *reinterpret_cast<const f4*>(drow + c0 + g * (n + 1) + c);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            ysrc[ks] = pf_splat(0.f);
+            const int c = ks * 16 + 4 * q;
+            if (nsrc > 0 && ks < KSg && c < g) ysrc[ks] = *reinterpret_cast<const f4*>(a.Y + (e0 + row) * a.ld + c0 + g + c);
+        }
+        f4 acc[NTG];
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt) acc[nt] = pf_splat(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks < KSo) {
+                const int c = ks * 16 + 4 * q;
+                f4 av = src[ks];
+                if (SRC == 0) {
+                    const f4 dv = src[ks];
+                    const unsigned g4 = ag[ks];
+                    av.x = (int)(g4 & 255u) == row ? dv.x : 0.f; av.y = (int)((g4 >> 8) & 255u) == row ? dv.y : 0.f;
+                    av.z = (int)((g4 >> 16) & 255u) == row ? dv.z : 0.f; av.w = (int)(g4 >> 24) == row ? dv.w : 0.f;
+                    if (c >= a.odim) av = pf_splat(0.f);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTG; ++nt)
+                    acc[nt] = mfma4(av, *reinterpret_cast<const f4*>(Wo + (nt * 16 + row) * kpo + c), acc[nt]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 7; ++n) {
+            if (n < nsrc) {
+                const float* Wt = Wgl + n * NTG * 16 * kpg;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (ks < KSg) {
+                        const int c = ks * 16 + 4 * q;
+                        f4 av = gsrc[n][ks];
+                        if (n == 0 && c < g) {                      // layer s + 1: raw gradient -> dy, stored back
+                            const f4 d = gsrc[0][ks], y = ysrc[ks];
+                            const f4 sc = *reinterpret_cast<const f4*>(cf + c), sh = *reinterpret_cast<const f4*>(cf + g16 + c);
+                            const f4 mu = *reinterpret_cast<const f4*>(cf + 2 * g16 + c), rs = *reinterpret_cast<const f4*>(cf + 3 * g16 + c);
+                            const f4 m1 = *reinterpret_cast<const f4*>(cf + 4 * g16 + c), m2 = *reinterpret_cast<const f4*>(cf + 5 * g16 + c);
+                            const f4 z = y * sc + sh;
+                            const f4 xh = (y - mu) * rs;
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) {
+                                const float dz = d[w] * (z[w] > 0.f ? 1.f : a.slope);
+                                av[w] = sc[w] * (dz - m1[w] - xh[w] * m2[w]);
+                            }
+                            *reinterpret_cast<f4*>(drow + c0 + g + c) = av;
+                        }
+#pragma unroll
+                        for (int nt = 0; nt < NTG; ++nt)
+                            acc[nt] = mfma4(av, *reinterpret_cast<const f4*>(Wt + (nt * 16 + row) * kpg + c), acc[nt]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt) {
+            const int cl = nt * 16 + row;
+            if (cl < g) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long e = e0 + 4 * q + r;
+                    const float v = acc[nt][r];
+                    a.dA[e * a.ld + c0 + cl] = v;
+                    const float y = a.Y[e * a.ld + c0 + cl];
+                    const float dz = v * (fmaf(y, ssc[nt], ssh[nt]) > 0.f ? 1.f : a.slope);
+                    s0[nt] += dz;
+                    s1[nt] = fmaf(dz, (y - smu[nt]) * srs[nt], s1[nt]);
+                }
+            }
+        }
+    }
+    stat_flush<NTG>(s0, s1, 0, g, a.fin, red);
+}
+
 // growth layer 0 has no growth input: only dA[:, 0:g] -> dy in place
 __global__ __launch_bounds__(256) void ec_bwd0_kernel(float* dA, const float* Y, int ld, const float* aff, const float* coef, int g,
                                                       long long E, float slope) {
@@ -971,6 +1149,27 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     if (!csr)
         hipLaunchKernelGGL(ec_zero_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<f4*>(p->dPQ), (long long)d.T * 2 * d.S / 4);
 
+#ifndef PF_EC_BWD_SCATTER
+    // ---- gather form: layer s = nc - 1 .. 0 collects its own gradient columns from conv_out and the later growth convs
+    for (int sl = nc - 1; sl >= 0; --sl) {
+        EcBwdgArgs a{};
+        a.dh = p->dout; a.arg = p->arg; a.dyout = p->dout; a.odim = p->odim;
+        a.dA = p->dA; a.Y = p->Y; a.ld = d.GT; a.aff = p->aff; a.coef = p->coef;
+        a.Wout = p->W[nc] + 3 * p->C; a.ldwout = cv.width[nc];
+        for (int t = 1; t < nc; ++t) { a.Wg[t] = p->W[t] + 3 * p->C; a.ldwg[t] = cv.width[t]; }
+        a.s = sl; a.nc = nc; a.g = g; a.ntiles = d.ntiles; a.slope = p->slope;
+        a.fin = StatFin{p->stat, 2, g, g * sl, d.GT, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, p->coef,
+                        p->dgamma[sl], p->dbeta[sl], (double)d.E};
+        const int g16 = (g + 15) & ~15, od16 = (p->odim + 15) & ~15, ntg = g16 / 16;
+        const size_t lds = sizeof(float) * ((size_t)ntg * 16 * ((od16 + 4) + (size_t)(nc - 1 - sl) * (g16 + 4)) + 6 * g16);
+#define PF_ECG(NTG, SRC)                                                                                                  \
+    do { allow_lds(ec_bwdg_kernel<NTG, SRC>, lds);                                                                        \
+         hipLaunchKernelGGL((ec_bwdg_kernel<NTG, SRC>), dim3(d.grid), dim3(256), lds, s, a); } while (0)
+        if (p->pooling) { if (ntg == 1) PF_ECG(1, 0); else PF_ECG(2, 0); }
+        else { if (ntg == 1) PF_ECG(1, 1); else PF_ECG(2, 1); }
+#undef PF_ECG
+    }
+#else
     // ---- conv_out: dA = dYout Wg_out (+ sums of the last growth layer)
     {
         EcBwdArgs a{};
@@ -1002,6 +1201,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         if (nt == 1) PF_ECB(1, 2); else if (nt == 2) PF_ECB(2, 2); else if (nt == 4) PF_ECB(4, 2); else PF_ECB(8, 2);
 #undef PF_ECB
     }
+#endif
     {
         const long long n = d.E * (g / 4);
         hipLaunchKernelGGL(ec_bwd0_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s,
