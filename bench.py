@@ -472,8 +472,8 @@ def bench_train(args, world, rank, dev, dist):
             ec_ms = sum(big) / len(big)
             E = args.batch * 256 * 16
             flops = 2.0 * EC_BWD_MAC_PER_EDGE * E
-            roof = {"bound": "mfma", "kernel": "pf_ec_train_bwd of a 128-channel EdgeConv unit (csrc/train_fused.hip: ec_bwd_kernel x4, "
-                                             "ec_pq_bwd_kernel, ec_dw_kernel, two gemm_kernel, ec_assemble_kernel)",
+            roof = {"bound": "mfma", "kernel": "pf_ec_train_bwd of a 128-channel EdgeConv unit (csrc/train_fused.hip: ec_bwdg_kernel x4, ec_bwd0_kernel, "
+                                             "ec_pq_bwd_csr_kernel, ec_dw_kernel, two gemm_kernel, ec_assemble_kernel)",
                     "achieved": flops / (ec_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": flops / (ec_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None, "avg_launch_ms": ec_ms,
                     "flops_basis": f"executed: {EC_BWD_MAC_PER_EDGE} MAC per edge x {E} edges per call (all products on "
@@ -485,8 +485,7 @@ def bench_train(args, world, rank, dev, dist):
                 with open(os.path.join(ROOT, "profiles", "pmc_train_latest.json")) as f:
                     pk = json.load(f)
                 pk = pk.get("kernels", pk)
-                group = {"ec_bwd_kernel<8, 0>": 1, "ec_bwd_kernel<8, 2>": 1, "ec_bwd_kernel<4, 2>": 1, "ec_bwd_kernel<2, 2>": 1,
-                         "ec_bwd0_kernel": 1, "ec_pq_bwd_csr_kernel": 1, "ec_dw_kernel<8>": 1, "gemm_kernel<2, 2, 2, 2, true>": 2,
+                group = {"ec_bwdg_kernel<2, 0>": 4, "ec_bwd0_kernel": 1, "ec_pq_bwd_csr_kernel": 1, "ec_dw_kernel<8>": 1, "gemm_kernel<2, 2, 2, 2, true>": 2,
                          "gemm_reduce_kernel": 1, "ec_assemble_kernel": 1}
                 tot, us = 0.0, 0.0
                 for k, n in group.items():
@@ -498,8 +497,8 @@ def bench_train(args, world, rank, dev, dist):
                 roof["profile"] = {"file": "profiles/pmc_train_latest.json", "kernels": group, "sum_avg_us": us,
                                    "note": "FETCH_SIZE x2 + WRITE_SIZE per launch (gfx950 correction), summed over the call's launches; "
                                            "algorithmic bytes = the [E, 128] growth outputs and their gradient read once and the "
-                                           "gradient written once + the per-point tensors; the dense block re-reads its gradient "
-                                           "tensor once per layer by construction (in-place accumulation into the earlier layers' columns)"}
+                                           "gradient written once + the per-point tensors; layer s of the dense block reads the gradient columns of every later layer (gather form), "
+                                           "ec_dw and the dPQ sums read the whole tensor again"}
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
