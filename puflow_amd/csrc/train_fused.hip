@@ -916,6 +916,215 @@ __global__ __launch_bounds__(64 * NWV) void ec_dw_kernel(EcDwArgs a) {
                     out[(size_t)((rbase + rstep * s) * 16 + 4 * q + r) * a.GT + ctj[jc] * 16 + row] = acc[s][jc][r];
 }
 
+// ------------------------------------------------------------------------------------------------ growth-weight gradients, no LDS
+// The same partial sums with the operands loaded straight into the 32x32x2 f32 MFMA layout: a K-step is two edges, lane l holds
+// A[channel l & 31][edge l >> 5] and B[edge l >> 5][channel l & 31] - one 4-byte load each, 128 contiguous bytes per half wave.
+// No LDS image, no barriers: every wave streams its own operands four K-steps ahead and owns a strip of <= 4 output tiles
+// (64 accumulator registers).  Jobs (one wave each): conv_out row strips with all GT / 32 column tiles, growth row strips with
+// the column tiles their layers can see.  The staged kernel above spent 54 % of its wave cycles waiting with the matrix pipe
+// 30 % busy; it stays for shapes that are not multiples of 32.
+struct EcDw2Job { int out, rt, nct; };
+struct EcDw2Args {
+    EcDwArgs d;
+    EcDw2Job job[8];
+    int njob;
+};
+typedef float f16v __attribute__((ext_vector_type(16)));
+#ifndef PF_DW2_D
+#define PF_DW2_D 8
+#endif
+constexpr int DW2_D = PF_DW2_D;                               // K-steps (of two edges) per software-pipeline stage
+
+__global__ __launch_bounds__(512) void ec_dw2_kernel(EcDw2Args g2) {
+    const EcDwArgs& a = g2.d;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+    if (wave >= g2.njob) return;
+    const EcDw2Job jb = g2.job[wave];
+    const int e_lo = blockIdx.x * a.chunk, e_hi = min((int)a.E, e_lo + a.chunk);      // multiples of 16
+    const int crow = jb.rt * 32 + col;                  // this lane's A channel
+    const bool outj = jb.out != 0;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = t * 32 + col;
+        sc[t] = t < jb.nct ? a.aff[c] : 0.f;
+        sh[t] = t < jb.nct ? a.aff[a.ld + c] : 0.f;
+    }
+    f16v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float asum = 0.f;
+    // one stage = DW2_D K-steps = 8 edges (inside one point: K = 16 edges per point for pooled units)
+    float an[DW2_D], bn[DW2_D][4];
+    auto fetch = [&](int e0) {
+        if (outj && a.pooled) {
+            const int ii = e0 >> 4;
+            const float dv = a.dh[(size_t)ii * a.odim + crow];
+            const int kk = a.arg[(size_t)ii * a.odim + crow];
+#pragma unroll
+            for (int k = 0; k < DW2_D; ++k) an[k] = (((e0 + 2 * k + h) & 15) == kk) ? dv : 0.f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < DW2_D; ++k) {
+                const size_t e = (size_t)(e0 + 2 * k + h);
+                an[k] = outj ? a.dyout[e * a.odim + crow] : a.dY[e * a.ld + crow];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DW2_D; ++k) {
+            const float* yr = a.Y + (size_t)(e0 + 2 * k + h) * a.ld + col;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bn[k][t] = t < jb.nct ? yr[t * 32] : 0.f;
+        }
+    };
+    if (e_lo < e_hi) fetch(e_lo);
+    for (int e0 = e_lo; e0 < e_hi; e0 += 2 * DW2_D) {
+        float ac[DW2_D], bc[DW2_D][4];
+#pragma unroll
+        for (int k = 0; k < DW2_D; ++k) {
+            ac[k] = an[k];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bc[k][t] = bn[k][t];
+        }
+        if (e0 + 2 * DW2_D < e_hi) fetch(e0 + 2 * DW2_D);
+#pragma unroll
+        for (int k = 0; k < DW2_D; ++k) {
+            asum += ac[k];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < jb.nct) {
+                    const float z = fmaf(bc[k][t], sc[t], sh[t]);
+                    const float bv = fmaxf(z, z * a.slope);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[k], bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int rowbase = outj ? a.GT : 0;
+    asum += __shfl_xor(asum, 32);
+    if (h == 0) a.bpart[(size_t)blockIdx.x * a.S + rowbase + crow] = asum;
+    float* out = a.part + ((size_t)blockIdx.x * a.S + rowbase + jb.rt * 32) * a.GT;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (t < jb.nct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)ri * a.GT + t * 32 + col] = acc[t][r];
+            }
+}
+
+// The same jobs on the bf16 matrix pipe: x = hi + mid with hi = the top 16 bits of x and mid = bf16(x - hi) (16 mantissa bits
+// together, fp32 exponent range - gradients of 1e-7 keep their digits, which fp16 halves would not), three
+// v_mfma_f32_32x32x16_bf16 per tile and 16 edges (hi hi + hi mid + mid hi, fp32 accumulate) instead of eight f32 MFMAs: 96 against
+// 512 matrix-pipe cycles.  Lane l holds its channel for the 8 edges 8 (l >> 5) + j of a 16-edge step.  In the no-LDS structure
+// the f32 pipe WAS the limit (the busiest SIMD of a workgroup owns 7 of its 22 tiles: 448 cycles per two edges); in the staged
+// kernel the same change bought nothing.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+struct Bf2 { bf8 hi, mid; };
+__device__ __forceinline__ Bf2 dw3_split(const float (&x)[8]) {
+    unsigned hw[4], mw[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned b0 = __float_as_uint(x[2 * p]), b1 = __float_as_uint(x[2 * p + 1]);
+        const unsigned h0 = b0 & 0xffff0000u, h1 = b1 & 0xffff0000u;
+        const unsigned m0 = __float_as_uint(x[2 * p] - __uint_as_float(h0)), m1 = __float_as_uint(x[2 * p + 1] - __uint_as_float(h1));
+        hw[p] = (h0 >> 16) | h1;
+        mw[p] = (m0 >> 16) | (m1 & 0xffff0000u);
+    }
+    Bf2 r;
+    r.hi = __builtin_bit_cast(bf8, *reinterpret_cast<const uint4*>(hw));
+    r.mid = __builtin_bit_cast(bf8, *reinterpret_cast<const uint4*>(mw));
+    return r;
+}
+
+__global__ __launch_bounds__(512) void ec_dw3_kernel(EcDw2Args g2) {
+    const EcDwArgs& a = g2.d;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+    if (wave >= g2.njob) return;
+    const EcDw2Job jb = g2.job[wave];
+    const int e_lo = blockIdx.x * a.chunk, e_hi = min((int)a.E, e_lo + a.chunk);      // multiples of 16
+    const int crow = jb.rt * 32 + col;
+    const bool outj = jb.out != 0;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = t * 32 + col;
+        sc[t] = t < jb.nct ? a.aff[c] : 0.f;
+        sh[t] = t < jb.nct ? a.aff[a.ld + c] : 0.f;
+    }
+    f16v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float asum = 0.f;
+    float an[8], bn[4][8];                               // the next 16-edge step's operands, in flight
+    auto fetch = [&](int e0) {
+        if (outj && a.pooled) {
+            const int ii = e0 >> 4;
+            const float dv = a.dh[(size_t)ii * a.odim + crow];
+            const int kk = a.arg[(size_t)ii * a.odim + crow];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) an[j] = (8 * h + j == kk) ? dv : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const size_t e = (size_t)(e0 + 8 * h + j);
+                an[j] = outj ? a.dyout[e * a.odim + crow] : a.dY[e * a.ld + crow];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* yr = a.Y + (size_t)(e0 + 8 * h + j) * a.ld + col;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bn[t][j] = t < jb.nct ? yr[t * 32] : 0.f;
+        }
+    };
+    if (e_lo < e_hi) fetch(e_lo);
+    for (int e0 = e_lo; e0 < e_hi; e0 += 16) {
+        float ac[8], bc[4][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ac[j] = an[j];
+            asum += an[j];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bc[t][j] = bn[t][j];
+        }
+        if (e0 + 16 < e_hi) fetch(e0 + 16);
+        const Bf2 A = dw3_split(ac);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < jb.nct) {
+                float bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float z = fmaf(bc[t][j], sc[t], sh[t]);
+                    bv[j] = fmaxf(z, z * a.slope);
+                }
+                const Bf2 B = dw3_split(bv);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.mid, B.hi, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.mid, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.hi, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    const int rowbase = outj ? a.GT : 0;
+    asum += __shfl_xor(asum, 32);
+    if (h == 0) a.bpart[(size_t)blockIdx.x * a.S + rowbase + crow] = asum;
+    float* out = a.part + ((size_t)blockIdx.x * a.S + rowbase + jb.rt * 32) * a.GT;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (t < jb.nct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)ri * a.GT + t * 32 + col] = acc[t][r];
+            }
+}
+
 // ------------------------------------------------------------------------------------------------ weight folding / un-folding
 struct EcConvs {
     const float* W[9]; const float* bias[9];
@@ -1004,7 +1213,10 @@ struct Dims {
     long long E;
     int ntiles, grid, grid_light, nchunk;
 };
-constexpr int EC_DW_CHUNK = 512;
+#ifndef PF_EC_DW_CHUNK
+#define PF_EC_DW_CHUNK 512
+#endif
+constexpr int EC_DW_CHUNK = PF_EC_DW_CHUNK;
 #ifndef EC_DW_WAVES
 #define EC_DW_WAVES 8
 #endif
@@ -1221,12 +1433,38 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     {
         EcDwArgs a{p->dA, p->Y, d.GT, p->aff, p->dout, p->arg, p->dout, p->pooling, g, d.GT, p->odim, d.S, p->K, d.E, EC_DW_CHUNK,
                    p->slope, dwpart, bpart};
-        const int ramax = p->odim > d.GT ? p->odim : d.GT;
-        const size_t lds = sizeof(float) * (size_t)DW_EB * ((ramax + 16) + (d.GT + 16));
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ec_dw_kernel<EC_DW_WAVES>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ec_dw_kernel<EC_DW_WAVES>, dim3(d.nchunk, 2), dim3(64 * EC_DW_WAVES), lds, s, a);
+        // jobs of the no-LDS kernel: conv_out strips, then growth strips (a strip's column tiles: what its LAST row's layer sees)
+        EcDw2Args a2{};
+        a2.d = a;
+        int nj = 0;
+        bool direct = d.GT % 32 == 0 && p->odim % 32 == 0 && d.GT <= 128 && (!p->pooling || p->K == 16) && EC_DW_CHUNK % 16 == 0;
+#ifdef PF_EC_DW_STAGED
+        direct = false;
+#endif
+        if (direct) {
+            for (int rt = 0; rt < p->odim / 32 && nj < 8; ++rt) a2.job[nj++] = EcDw2Job{1, rt, d.GT / 32};
+            for (int rt = d.GT / 32 - 1; rt >= 0; --rt) {
+                const int see = ((rt * 32 + 31) / g) * g;                   // growth columns u < g * layer(last row)
+                const int nct = (see + 31) / 32;                            // 0: the strip still owes its bias sums
+                if (nj >= 8) { direct = false; break; }
+                a2.job[nj++] = EcDw2Job{0, rt, nct};
+            }
+            a2.njob = nj;
+        }
+        if (direct) {
+#ifdef PF_EC_DW_F32
+            hipLaunchKernelGGL(ec_dw2_kernel, dim3(d.nchunk), dim3(64 * nj), 0, s, a2);
+#else
+            hipLaunchKernelGGL(ec_dw3_kernel, dim3(d.nchunk), dim3(64 * nj), 0, s, a2);
+#endif
+        } else {
+            const int ramax = p->odim > d.GT ? p->odim : d.GT;
+            const size_t lds = sizeof(float) * (size_t)DW_EB * ((ramax + 16) + (d.GT + 16));
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ec_dw_kernel<EC_DW_WAVES>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(ec_dw_kernel<EC_DW_WAVES>, dim3(d.nchunk, 2), dim3(64 * EC_DW_WAVES), lds, s, a);
+        }
     }
     if (p->dx) {
         st = pf_gemm(p->dPQ, 2 * d.S, 1, p->Wpq, p->C, 1, p->dx, p->C, nullptr, d.T, p->C, 2 * d.S, gws,
