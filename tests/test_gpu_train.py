@@ -448,3 +448,59 @@ def test_fused_glue_of_the_training_step_matches_the_torch_expressions():
     floor = 1e-5 * max(float(g.abs().max()) for g in ga.values())
     for k in ga:
         assert float((ga[k] - gb[k]).abs().max()) <= 2e-4 * float(ga[k].abs().max()) + floor, k
+
+
+@pytest.mark.parametrize("B,N,R", [(2, 100, 4), (3, 256, 2), (1, 37, 1)])
+def test_latent_interpolation_kernel_matches_torch(B, N, R):
+    """pf_interp_wsum (csrc/train_glue.hip) against the torch expression it replaces (interpflow.py:153-186, 312-318): gather of
+    the neighbours' latent rows, softmax over the 8 neighbours of the first R weight channels, weighted sum, [B, N R, 3] layout -
+    forward and both gradients."""
+    from puflow_amd import train_ops as T
+    g = torch.Generator(device="cpu").manual_seed(7 + N)
+    ldw = 32
+    w0 = torch.randn(B * N, 8, ldw, generator=g).to(DEV)
+    z0 = torch.randn(B, N, 3, generator=g).to(DEV)
+    idx = torch.randint(0, N, (B, N, 8), generator=g, dtype=torch.int32).to(DEV)
+    gu = torch.randn(B, N * R, 3, generator=g).to(DEV)
+
+    def ref(w, z):
+        zj = z[torch.arange(B, device=DEV).view(B, 1, 1), idx.long()]                   # [B,N,8,3]
+        a = torch.softmax(w.view(B, N, 8, ldw)[..., :R].double(), dim=2)                # [B,N,8,R]
+        return torch.einsum("bnkr,bnkc->bnrc", a, zj.double()).reshape(B, N * R, 3)
+
+    w1, z1 = w0.clone().requires_grad_(True), z0.clone().requires_grad_(True)
+    u1 = T.InterpWsumFn.apply(w1, z1, idx, R)
+    (u1 * gu).sum().backward()
+    w2, z2 = w0.clone().requires_grad_(True), z0.clone().requires_grad_(True)
+    u2 = ref(w2, z2)
+    (u2 * gu.double()).sum().backward()
+    assert float((u1.double() - u2).abs().max()) <= 2e-6
+    assert float((w1.grad.double() - w2.grad.double()).abs().max()) <= 2e-6 * max(1.0, float(w2.grad.abs().max()))
+    assert float((z1.grad.double() - z2.grad.double()).abs().max()) <= 1e-5 * max(1.0, float(z2.grad.abs().max()))
+    assert float(w1.grad[..., R:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("with_radius", [True, False])
+def test_pugan_loss_node_matches_the_separate_losses(with_radius):
+    """loss.PuganLossFn against EarthMoverDistance + ChamferCUDA + the weighted sum (train_pugan.py:52-67): value, logged terms,
+    gradient of the prediction and of logp."""
+    from puflow_amd.loss import ChamferCUDA, EarthMoverDistance, PuganLossFn
+    B, n = 3, 512
+    pred0 = ((synth_patches(B, n, seed=61) + 1) / 2).to(DEV)
+    gt = ((synth_patches(B, n, seed=62) + 1) / 2).to(DEV)
+    radius = torch.tensor([0.7, 1.0, 1.4], device=DEV) if with_radius else None
+    lp0 = torch.tensor(123.456, device=DEV)
+    p1, l1 = pred0.clone().requires_grad_(True), lp0.clone().requires_grad_(True)
+    loss1, terms = PuganLossFn.apply(p1, gt, radius, l1, 0.005, 50, 0, (1e-4, 5e-2, 1e-1))
+    loss1.backward()
+    p2, l2 = pred0.clone().requires_grad_(True), lp0.clone().requires_grad_(True)
+    emd = EarthMoverDistance()(p2, gt, radius=radius)
+    cd, _ = ChamferCUDA()(p2, gt)
+    loss2 = l2 * 1e-4 + emd * 5e-2 + cd * 1e-1
+    loss2.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss1) - float(loss2)) <= 2e-6 * abs(float(loss2))
+    for got, want in zip(terms.tolist(), (float(emd) * 5e-2, float(lp0) * 1e-4, float(cd) * 1e-1)):
+        assert abs(got - want) <= 2e-6 * abs(want) + 1e-9
+    assert float((p1.grad - p2.grad).abs().max()) <= 2e-6 * float(p2.grad.abs().max())
+    assert abs(float(l1.grad) - float(l2.grad)) <= 1e-9
