@@ -622,6 +622,196 @@ __global__ __launch_bounds__(256) void ec_bwdg_kernel(EcBwdgArgs a) {
     stat_flush<NTG>(s0, s1, 0, g, a.fin, red);
 }
 
+// The same gather on the bf16 matrix pipe (both operands split as in ec_dw3_kernel: x = hi + mid, fp32 exponent range, three
+// v_mfma_f32_16x16x32_bf16 per 32 channels instead of eight f32 MFMAs): lane (row = edge, kg = l >> 4) holds the 8 channels
+// 8 kg .. 8 kg + 7 of a 32-channel chunk of its edge's gradient row (two 16-byte loads), the weights sit in LDS as ready
+// fragments [tile][chunk][hi | mid][lane][8 x bf16] written once per workgroup.  Accumulators, epilogue and statistics are those of
+// the f32 kernel (the 16x16 accumulator layout does not depend on the input type).
+typedef __bf16 gbf8 __attribute__((ext_vector_type(8)));
+struct GBf2 { gbf8 hi, mid; };
+__device__ __forceinline__ GBf2 g_split(const float (&x)[8]) {
+    unsigned hw[4], mw[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned b0 = __float_as_uint(x[2 * p]), b1 = __float_as_uint(x[2 * p + 1]);
+        const unsigned h0 = b0 & 0xffff0000u, h1 = b1 & 0xffff0000u;
+        const unsigned m0 = __float_as_uint(x[2 * p] - __uint_as_float(h0)), m1 = __float_as_uint(x[2 * p + 1] - __uint_as_float(h1));
+        hw[p] = (h0 >> 16) | h1;
+        mw[p] = (m0 >> 16) | (m1 & 0xffff0000u);
+    }
+    GBf2 r;
+    r.hi = __builtin_bit_cast(gbf8, *reinterpret_cast<const uint4*>(hw));
+    r.mid = __builtin_bit_cast(gbf8, *reinterpret_cast<const uint4*>(mw));
+    return r;
+}
+
+template <int NTG, int SRC>
+__global__ __launch_bounds__(256) void ec_bwdg16_kernel(EcBwdgArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float red[8 * STAT_W];
+    const int g = a.g, g16 = (g + 15) & ~15;
+    const int nco = (a.odim + 31) / 32, ncg = (g + 31) / 32;       // 32-channel chunks of conv_out / of a growth layer
+    const int c0 = g * a.s, nsrc = a.nc - 1 - a.s;
+    uint4* Wf = reinterpret_cast<uint4*>(lds);                    // fragments: ((frag * 2 + hi|mid) * 64 + lane), 16 bytes each
+    const int nfrag = NTG * (nco + nsrc * ncg);                   // frag = nt * nco + chunk | NTG * nco + (n * NTG + nt) * ncg + chunk
+    float* cf = lds + (size_t)nfrag * 2 * 64 * 4;                 // [6][g16]: scale, shift, mean, rstd, m1, m2 of layer s + 1
+    for (int unit = threadIdx.x; unit < nfrag * 64; unit += 256) {
+        const int frag = unit >> 6, ln = unit & 63, u = ln & 15, kg = ln >> 4;
+        const float* W;
+        int ldw, kin, nt, chunk;
+        if (frag < NTG * nco) { nt = frag / nco; chunk = frag % nco; W = a.Wout; ldw = a.ldwout; kin = a.odim; }
+        else {
+            const int f2 = frag - NTG * nco, n = f2 / (NTG * ncg), r2 = f2 % (NTG * ncg);
+            nt = r2 / ncg; chunk = r2 % ncg; W = a.Wg[a.s + 1 + n]; ldw = a.ldwg[a.s + 1 + n]; kin = g;
+        }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = chunk * 32 + 8 * kg + j, uu = nt * 16 + u;
+            v[j] = (c < kin && uu < g) ? W[(size_t)c * ldw + c0 + uu] : 0.f;
+        }
+        const GBf2 f = g_split(v);
+        Wf[(frag * 2 + 0) * 64 + ln] = __builtin_bit_cast(uint4, f.hi);
+        Wf[(frag * 2 + 1) * 64 + ln] = __builtin_bit_cast(uint4, f.mid);
+    }
+    if (nsrc > 0) {
+        const int c1 = c0 + g;
+        for (int i = threadIdx.x; i < g16; i += 256) {
+            const bool ok = i < g;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) cf[w * g16 + i] = ok ? a.aff[w * a.ld + c1 + i] : 0.f;
+            cf[4 * g16 + i] = ok ? a.coef[c1 + i] : 0.f;
+            cf[5 * g16 + i] = ok ? a.coef[a.ld + c1 + i] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    float s0[NTG], s1[NTG], ssc[NTG], ssh[NTG], smu[NTG], srs[NTG];
+#pragma unroll
+    for (int nt = 0; nt < NTG; ++nt) {
+        s0[nt] = s1[nt] = 0.f;
+        const int cl = nt * 16 + row;
+        const bool ok = cl < g;
+        ssc[nt] = ok ? a.aff[c0 + cl] : 0.f;
+        ssh[nt] = ok ? a.aff[a.ld + c0 + cl] : 0.f;
+        smu[nt] = ok ? a.aff[2 * a.ld + c0 + cl] : 0.f;
+        srs[nt] = ok ? a.aff[3 * a.ld + c0 + cl] : 0.f;
+    }
+    auto mma = [&](const GBf2& A, int frag, f4& acc) {
+        const gbf8 bh = __builtin_bit_cast(gbf8, Wf[(frag * 2 + 0) * 64 + lane]);
+        const gbf8 bm = __builtin_bit_cast(gbf8, Wf[(frag * 2 + 1) * 64 + lane]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.mid, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.hi, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.hi, bh, acc, 0, 0, 0);
+    };
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
+        const long long e0 = (long long)tile * 16;
+        // the tile's loads first: 8 channels per 32-channel chunk of conv_out's gradient row and of the later layers' columns
+        float csrc[4][8];
+        unsigned ag[SRC == 0 ? 4 : 1][2];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int c = ch * 32 + 8 * q;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) csrc[ch][j] = 0.f;
+            if (ch < nco && c < a.odim) {                            // odim is a multiple of 16: an 8-channel group is all in or all out
+                const float* sp = SRC == 0 ? a.dh + (long long)tile * a.odim + c : a.dyout + (e0 + row) * a.odim + c;
+                const f4 v0 = *reinterpret_cast<const f4*>(sp), v1 = *reinterpret_cast<const f4*>(sp + 4);
+                csrc[ch][0] = v0.x; csrc[ch][1] = v0.y; csrc[ch][2] = v0.z; csrc[ch][3] = v0.w;
+                csrc[ch][4] = v1.x; csrc[ch][5] = v1.y; csrc[ch][6] = v1.z; csrc[ch][7] = v1.w;
+                if (SRC == 0) {
+                    const unsigned* apw = reinterpret_cast<const unsigned*>(a.arg + (long long)tile * a.odim + c);
+                    ag[ch][0] = apw[0]; ag[ch][1] = apw[1];
+                }
+            }
+        }
+        float* drow = a.dA + (e0 + row) * a.ld;
+        float gsrc[7][8], ysrc[8];
+        const int cq = 8 * q;                                      // g <= 32: one chunk per growth layer
+#pragma unroll
+        for (int n = 0; n < 7; ++n) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gsrc[n][j] = 0.f;
+            if (n < nsrc && cq < g) {                              // g is a multiple of 8
+                const float* sp = drow + c0 + g * (n + 1) + cq;
+                const f4 v0 = *reinterpret_cast<const f4*>(sp), v1 = *reinterpret_cast<const f4*>(sp + 4);
+                gsrc[n][0] = v0.x; gsrc[n][1] = v0.y; gsrc[n][2] = v0.z; gsrc[n][3] = v0.w;
+                gsrc[n][4] = v1.x; gsrc[n][5] = v1.y; gsrc[n][6] = v1.z; gsrc[n][7] = v1.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ysrc[j] = 0.f;
+        if (nsrc > 0 && cq < g) {
+            const float* sp = a.Y + (e0 + row) * a.ld + c0 + g + cq;
+            const f4 v0 = *reinterpret_cast<const f4*>(sp), v1 = *reinterpret_cast<const f4*>(sp + 4);
+            ysrc[0] = v0.x; ysrc[1] = v0.y; ysrc[2] = v0.z; ysrc[3] = v0.w; ysrc[4] = v1.x; ysrc[5] = v1.y; ysrc[6] = v1.z; ysrc[7] = v1.w;
+        }
+        f4 acc[NTG];
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt) acc[nt] = pf_splat(0.f);
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            if (ch < nco) {
+                float av[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    av[j] = csrc[ch][j];
+                    if (SRC == 0) {
+                        const unsigned wv = ag[ch][j >> 2];
+                        av[j] = (int)((wv >> (8 * (j & 3))) & 255u) == row ? csrc[ch][j] : 0.f;
+                    }
+                }
+                const GBf2 A = g_split(av);
+#pragma unroll
+                for (int nt = 0; nt < NTG; ++nt) mma(A, nt * nco + ch, acc[nt]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 7; ++n) {
+            if (n < nsrc) {
+                float av[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = gsrc[n][j];
+                if (n == 0 && cq < g) {                            // layer s + 1: raw gradient -> dy, stored back
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = cq + j;
+                        const float sc = cf[c], sh = cf[g16 + c], mu = cf[2 * g16 + c], rs = cf[3 * g16 + c];
+                        const float m1 = cf[4 * g16 + c], m2 = cf[5 * g16 + c];
+                        const float y = ysrc[j], z = fmaf(y, sc, sh), xh = (y - mu) * rs;
+                        const float dz = gsrc[0][j] * (z > 0.f ? 1.f : a.slope);
+                        av[j] = sc * (dz - m1 - xh * m2);
+                    }
+                    float* dp = drow + c0 + g + cq;
+                    f4 o0 = {av[0], av[1], av[2], av[3]}, o1 = {av[4], av[5], av[6], av[7]};
+                    *reinterpret_cast<f4*>(dp) = o0;
+                    *reinterpret_cast<f4*>(dp + 4) = o1;
+                }
+                const GBf2 A = g_split(av);
+#pragma unroll
+                for (int nt = 0; nt < NTG; ++nt) mma(A, NTG * nco + (n * NTG + nt) * ncg, acc[nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt) {
+            const int cl = nt * 16 + row;
+            if (cl < g) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long e = e0 + 4 * q + r;
+                    const float v = acc[nt][r];
+                    a.dA[e * a.ld + c0 + cl] = v;
+                    const float y = a.Y[e * a.ld + c0 + cl];
+                    const float dz = v * (fmaf(y, ssc[nt], ssh[nt]) > 0.f ? 1.f : a.slope);
+                    s0[nt] += dz;
+                    s1[nt] = fmaf(dz, (y - smu[nt]) * srs[nt], s1[nt]);
+                }
+            }
+        }
+    }
+    stat_flush<NTG>(s0, s1, 0, g, a.fin, red);
+}
+
 // growth layer 0 has no growth input: only dA[:, 0:g] -> dy in place
 __global__ __launch_bounds__(256) void ec_bwd0_kernel(float* dA, const float* Y, int ld, const float* aff, const float* coef, int g,
                                                       long long E, float slope) {
@@ -1373,10 +1563,19 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         a.fin = StatFin{p->stat, 2, g, g * sl, d.GT, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, p->coef,
                         p->dgamma[sl], p->dbeta[sl], (double)d.E};
         const int g16 = (g + 15) & ~15, od16 = (p->odim + 15) & ~15, ntg = g16 / 16;
+#ifdef PF_EC_BWDG_F32
         const size_t lds = sizeof(float) * ((size_t)ntg * 16 * ((od16 + 4) + (size_t)(nc - 1 - sl) * (g16 + 4)) + 6 * g16);
 #define PF_ECG(NTG, SRC)                                                                                                  \
     do { allow_lds(ec_bwdg_kernel<NTG, SRC>, lds);                                                                        \
          hipLaunchKernelGGL((ec_bwdg_kernel<NTG, SRC>), dim3(d.grid), dim3(256), lds, s, a); } while (0)
+#else
+        (void)od16;
+        const size_t nfrag = (size_t)ntg * ((p->odim + 31) / 32 + (size_t)(nc - 1 - sl) * ((g + 31) / 32));
+        const size_t lds = nfrag * 2 * 64 * 16 + sizeof(float) * 6 * g16;
+#define PF_ECG(NTG, SRC)                                                                                                  \
+    do { allow_lds(ec_bwdg16_kernel<NTG, SRC>, lds);                                                                      \
+         hipLaunchKernelGGL((ec_bwdg16_kernel<NTG, SRC>), dim3(d.grid), dim3(256), lds, s, a); } while (0)
+#endif
         if (p->pooling) { if (ntg == 1) PF_ECG(1, 0); else PF_ECG(2, 0); }
         else { if (ntg == 1) PF_ECG(1, 1); else PF_ECG(2, 1); }
 #undef PF_ECG
