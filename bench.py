@@ -472,13 +472,12 @@ def bench_train(args, world, rank, dev, dist):
             ec_ms = sum(big) / len(big)
             E = args.batch * 256 * 16
             flops = 2.0 * EC_BWD_MAC_PER_EDGE * E
-            roof = {"bound": "mfma", "kernel": "pf_ec_train_bwd of a 128-channel EdgeConv unit (csrc/train_fused.hip: ec_bwdg_kernel x4, ec_bwd0_kernel, "
+            roof = {"bound": "mfma", "kernel": "pf_ec_train_bwd of a 128-channel EdgeConv unit (csrc/train_fused.hip: ec_bwdg16_kernel x4, ec_bwd0_kernel, "
                                              "ec_pq_bwd_csr_kernel, ec_dw3_kernel, two gemm_kernel, ec_assemble_kernel)",
                     "achieved": flops / (ec_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": flops / (ec_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None, "avg_launch_ms": ec_ms,
-                    "flops_basis": f"algorithmic: {EC_BWD_MAC_PER_EDGE} MAC per edge x {E} edges per call, each product once (the input-"
-                                   "gradient products run on v_mfma_f32_16x16x4_f32, the weight-gradient products - 57 % of the MACs - as "
-                                   "three v_mfma_f32_32x32x16_bf16 each); live HIP-event duration of the call's launches on the launch stream",
+                    "flops_basis": f"algorithmic: {EC_BWD_MAC_PER_EDGE} MAC per edge x {E} edges per call, each product once (split-bf16 "
+                                   "products: three v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16 each; the two point GEMMs on v_mfma_f32_16x16x4_f32); live HIP-event duration of the call's launches on the launch stream",
                     "calls_ms_per_step": calls_ms}
             # HBM bytes of the same call from the committed PMC summary of the training kernels (collected offline over eager
             # steps: tools/pmc_cmd.sh + tools/train_eager_steps.py): the launches of one 128-channel unit's backward
@@ -486,7 +485,7 @@ def bench_train(args, world, rank, dev, dist):
                 with open(os.path.join(ROOT, "profiles", "pmc_train_latest.json")) as f:
                     pk = json.load(f)
                 pk = pk.get("kernels", pk)
-                group = {"ec_bwdg_kernel<2, 0>": 4, "ec_bwd0_kernel": 1, "ec_pq_bwd_csr_kernel": 1, "ec_dw3_kernel": 1, "gemm_kernel<2, 2, 2, 2, true>": 2,
+                group = {"ec_bwdg16_kernel<2, 0>": 4, "ec_bwd0_kernel": 1, "ec_pq_bwd_csr_kernel": 1, "ec_dw3_kernel": 1, "gemm_kernel<2, 2, 2, 2, true>": 2,
                          "gemm_reduce_kernel": 1, "ec_assemble_kernel": 1}
                 tot, us = 0.0, 0.0
                 for k, n in group.items():
