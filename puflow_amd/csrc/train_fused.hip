@@ -292,6 +292,131 @@ __global__ __launch_bounds__(256) void ec_fwd_kernel(EcFwdArgs a) {
     if (!OUT) stat_flush<NT>(s0, s1, 0, a.nout, a.fin, red);
 }
 
+// ------------------------------------------------------------------------------------------------ forward, conv_out on the fp16 pipe
+// conv_out is the one forward kernel whose matrix work is not negligible (E x GT x odim products: 38 % pipe-busy on f32 MFMAs).
+// Here its products run as split-fp16 (csrc/pf_mfma.h "f16x2": x = hi + lo' 2^-11, hi.hi in the main accumulator, hi.lo' + lo'.hi
+// in a second one folded in as acc + accx 2^-11 - 22+ significant bits per operand; activations after BatchNorm + LeakyReLU and
+// weights are far inside the fp16 range): three v_mfma_f32_16x16x32_f16 per 32 channels instead of eight f32 MFMAs.  Lane
+// (row = edge, kg = l >> 4) holds the 8 channels 8 kg .. 8 kg + 7 of a 32-channel chunk of its edge's feature row; the weights
+// are converted once per workgroup into ready fragments [tile][chunk][hi | lo'][lane][8 x f16]; the per-edge addend P[i] + Q[j]
+// enters through an identity B operand, split the same way.  Accumulator layout, pooling and outputs as in ec_fwd_kernel.
+template <int NT, bool POOL>
+__global__ __launch_bounds__(256) void ec_fwd16_kernel(EcFwdArgs a) {
+    extern __shared__ float lds[];
+    const int nch = (a.kin + 31) / 32;
+    uint4* Wf = reinterpret_cast<uint4*>(lds);                    // ((nt * nch + chunk) * 2 + hi|lo) * 64 + lane
+    float* al = lds + (size_t)NT * nch * 2 * 64 * 4;
+    float* bl = al + nch * 32;
+    for (int unit = threadIdx.x; unit < NT * nch * 64; unit += 256) {
+        const int frag = unit >> 6, ln = unit & 63, u = ln & 15, kg = ln >> 4, nt = frag / nch, ch = frag % nch;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = ch * 32 + 8 * kg + j, o = nt * 16 + u;
+            v[j] = (c < a.kin && o < a.nout) ? a.W[(size_t)o * a.ldw + c] : 0.f;
+        }
+        const f4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
+        const PfPair2 f = pf_pair2(v0, v1);
+        Wf[(frag * 2 + 0) * 64 + ln] = __builtin_bit_cast(uint4, f.h);
+        Wf[(frag * 2 + 1) * 64 + ln] = __builtin_bit_cast(uint4, f.l);
+    }
+    for (int i = threadIdx.x; i < nch * 32; i += 256) {
+        al[i] = i < a.kin ? a.aff[i] : 0.f;
+        bl[i] = i < a.kin ? a.aff[a.ldy + i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    h8 identh;                                            // B[k][j] = (k == j) for k < 16, this lane: j = row, k = 8 q + jj
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) identh[jj] = (8 * q + jj == row) ? (_Float16)1.f : (_Float16)0.f;
+    const int tile0 = blockIdx.x * 4 + wave;
+    int jnext = tile0 < a.ntiles ? a.idx[(long long)tile0 * 16 + row] : 0;
+    for (int tile = tile0; tile < a.ntiles; tile += gridDim.x * 4) {
+        const long long e0 = (long long)tile * 16;
+        const int er = (int)e0 + row;
+        const int ir = er / a.K;
+        const long long jr = (long long)(ir / a.N) * a.N + jnext;
+        {
+            const int tn = tile + gridDim.x * 4;
+            if (tn < a.ntiles) jnext = a.idx[(long long)tn * 16 + row];
+        }
+        const float* yrow = a.Y + (size_t)er * a.ldy;
+        f4 y0[4], y1[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            y0[ch] = y1[ch] = pf_splat(0.f);
+            const int c = ch * 32 + 8 * q;
+            if (ch < nch && c < a.kin) {                             // kin is a multiple of 8
+                y0[ch] = *reinterpret_cast<const f4*>(yrow + c);
+                y1[ch] = *reinterpret_cast<const f4*>(yrow + c + 4);
+            }
+        }
+        f4 acc[NT], accx[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c8 = nt * 16 + 8 * q;                          // the addend's channels: k = 8 q + jj < 16 of this tile
+            f4 e0v = pf_splat(0.f), e1v = pf_splat(0.f);
+            if (q < 2 && c8 < a.nout) {
+                const float* pp = a.pq + (size_t)ir * a.ldpq + a.poff + c8;
+                const float* qp = a.pq + (size_t)jr * a.ldpq + a.qoff + c8;
+                e0v = *reinterpret_cast<const f4*>(pp) + *reinterpret_cast<const f4*>(qp);
+                e1v = *reinterpret_cast<const f4*>(pp + 4) + *reinterpret_cast<const f4*>(qp + 4);
+            }
+            const PfPair2 E = pf_pair2(e0v, e1v);
+            acc[nt] = pf_mfma_f16(E.h, identh, pf_splat(0.f));
+            accx[nt] = pf_mfma_f16(E.l, identh, pf_splat(0.f));
+        }
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            if (ch < nch) {
+                const int c = ch * 32 + 8 * q;
+                const f4 a0 = lrelu4(y0[ch] * *reinterpret_cast<const f4*>(al + c) + *reinterpret_cast<const f4*>(bl + c), a.slope);
+                const f4 a1 = lrelu4(y1[ch] * *reinterpret_cast<const f4*>(al + c + 4) + *reinterpret_cast<const f4*>(bl + c + 4), a.slope);
+                const PfPair2 A = pf_pair2(c < a.kin ? a0 : pf_splat(0.f), c < a.kin ? a1 : pf_splat(0.f));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const h8 bh = __builtin_bit_cast(h8, Wf[((nt * nch + ch) * 2 + 0) * 64 + lane]);
+                    const h8 blo = __builtin_bit_cast(h8, Wf[((nt * nch + ch) * 2 + 1) * 64 + lane]);
+                    acc[nt] = pf_mfma_f16(A.h, bh, acc[nt]);
+                    accx[nt] = pf_mfma_f16(A.h, blo, accx[nt]);
+                    accx[nt] = pf_mfma_f16(A.l, bh, accx[nt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = acc[nt] + accx[nt] * PF_LO_INV;
+        if (!POOL) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = nt * 16 + row;
+                if (col < a.nout)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a.out[(e0 + 4 * q + r) * a.nout + col] = acc[nt][r];
+            }
+        } else {                                                       // K = 16: the tile is point `tile`
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float best = acc[nt][0];
+                int bk = 4 * q;
+#pragma unroll
+                for (int r = 1; r < 4; ++r)
+                    if (acc[nt][r] > best) { best = acc[nt][r]; bk = 4 * q + r; }
+#pragma unroll
+                for (int m = 16; m < 64; m <<= 1) {
+                    const float ov = __shfl_xor(best, m);
+                    const int ok = __shfl_xor(bk, m);
+                    if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; }
+                }
+                const int col = nt * 16 + row;
+                if (q == 0 && col < a.nout) {
+                    a.out[(long long)tile * a.nout + col] = best;
+                    a.arg[(long long)tile * a.nout + col] = (unsigned char)bk;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward through one conv
 // SRC 0: the conv is conv_out of a pooled unit: dYout[e, c] = dh[i, c] if argmax[i, c] == k else 0, formed on load
 // SRC 1: conv_out without pooling: dYout [E, kin] dense
@@ -1514,6 +1639,7 @@ extern "C" int pf_ec_train_fwd(const PfEcTrain* p, void* stream) {
     a.W = p->W[p->nconv] + 3 * p->C; a.ldw = cv.width[p->nconv]; a.poff = d.GT; a.qoff = d.S + d.GT;
     a.kin = d.GT; a.col0 = 0; a.nout = p->odim; a.out = p->out; a.arg = p->arg; a.fin = StatFin{};
     const int nto = p->odim / 16;
+#ifdef PF_EC_FWD_F32
     const size_t lds = sizeof(float) * ((size_t)(nto <= 2 ? 2 : (nto <= 4 ? 4 : 8)) * 16 * (d.GT + 4) + 2 * d.GT);
 #define PF_ECO(NT)                                                                                                        \
     do {                                                                                                                  \
@@ -1522,6 +1648,17 @@ extern "C" int pf_ec_train_fwd(const PfEcTrain* p, void* stream) {
         else { allow_lds(ec_fwd_kernel<NT, true, false>, lds);                                                            \
             hipLaunchKernelGGL((ec_fwd_kernel<NT, true, false>), dim3(d.grid), dim3(256), lds, s, a); }                   \
     } while (0)
+#else
+    const int nchk = (d.GT + 31) / 32;
+    const size_t lds = (size_t)(nto <= 2 ? 2 : (nto <= 4 ? 4 : 8)) * nchk * 2 * 64 * 16 + sizeof(float) * 2 * nchk * 32;
+#define PF_ECO(NT)                                                                                                        \
+    do {                                                                                                                  \
+        if (p->pooling) { allow_lds(ec_fwd16_kernel<NT, true>, lds);                                                      \
+            hipLaunchKernelGGL((ec_fwd16_kernel<NT, true>), dim3(d.grid), dim3(256), lds, s, a); }                        \
+        else { allow_lds(ec_fwd16_kernel<NT, false>, lds);                                                                \
+            hipLaunchKernelGGL((ec_fwd16_kernel<NT, false>), dim3(d.grid), dim3(256), lds, s, a); }                       \
+    } while (0)
+#endif
     if (nto <= 2) PF_ECO(2); else if (nto <= 4) PF_ECO(4); else PF_ECO(8);
 #undef PF_ECO
     return pf_last_launch_status();
