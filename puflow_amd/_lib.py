@@ -96,6 +96,7 @@ SIGNATURES = {
     "pf_gemm_ws_floats": (c_longlong, [c_int, c_int, c_int]),
     "pf_gemm": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p,
                         c_int, c_int, c_int, c_void_p, c_longlong, c_void_p]),
+    "pf_gemm_reduce": (c_int, [c_void_p, c_void_p, c_int, c_int, c_longlong, c_int, c_void_p]),
     "pf_gemm_ex": (c_int, [c_int, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p,
                         c_int, c_int, c_int, c_void_p, c_longlong, c_void_p]),
     "pf_bn_chunks": (c_int, [c_longlong]),

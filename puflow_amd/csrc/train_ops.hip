@@ -339,6 +339,10 @@ void gemm_launch(const GemmArgs& g, int split, bool vec, hipStream_t s) {
 
 // tile shape for (M, N): 0 = 128x128, 1..3 = 256 x {16,32,64} (skinny N), 4..6 = {16,32,64} x 256 (skinny M)
 inline int gemm_shape(int M, int N) {
+    // a skinny output whose 256-row tiles would not even give every second CU a workgroup (the [8192, 16..64] input-gradient
+    // GEMMs of the training step: 32 tiles, 65 us for 0.27 G MAC) takes 64 x 64 tiles instead: 4 x the workgroups, no split-K
+    // reduction, the wasted tile columns cost nothing at this size
+    if (N <= 64 && M > 64 && (M + 255) / 256 < 128 && (M + 63) / 64 >= 64) return 7;
     if (N <= 16) return 1;
     if (N <= 32) return 2;
     if (N <= 64 && M > 64) return 3;
@@ -770,6 +774,16 @@ extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sa
     if (use_ws)
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(((long long)M * N + 63) / 64)), dim3(256), 0, s, ws, C, bias, M,
                            N, ldc, split);
+    return pf_last_launch_status();
+}
+
+// C [M, ldc] = sum of nslab split-K slabs [nslab][M * N] (fixed combine order): the reduction step of pf_gemm, for callers that
+// produce their own slabs (csrc/train_fused.hip)
+extern "C" int pf_gemm_reduce(const float* slabs, float* C, int M, int N, long long ldc, int nslab, void* stream) {
+    if (!slabs || !C) return PF_ERR_NULL;
+    if (M <= 0 || N <= 0 || nslab <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(((long long)M * N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, slabs, C,
+                       (const float*)nullptr, M, N, ldc, nslab);
     return pf_last_launch_status();
 }
 
