@@ -1566,8 +1566,13 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     idx16, _ = ops.knn_idx32(xyz, xyz, 16)
     idx8 = idx16[..., :8].contiguous()
     fused_ec = _FUSED and not _sync_bn_active()
-    csr16 = knn_csr(idx16) if fused_ec else None
-    csr8 = knn_csr(idx8) if fused_ec else None
+    use_side = getattr(net, "train_streams", True) and not _sync_bn_active()
+    # transposed neighbour lists: only the BACKWARD of the EdgeConv units reads them - with a side stream they are built there,
+    # off the main chain (8 small launches, ~55 us), and joined with the interpolation weights
+    csr16 = csr8 = None
+    csr_side = use_side and os.environ.get("PF_TRAIN_CSR_SIDE", "1") != "0"
+    if fused_ec and not csr_side:
+        csr16, csr8 = knn_csr(idx16), knn_csr(idx8)
 
     # ---- interpolation weights (interpflow.py:85-151): a function of xyz and the neighbour lists only, independent of the
     # feature extractor / flow f chain that follows.  At 32 x 256 points no kernel of the step fills the chip, so this branch
@@ -1586,10 +1591,12 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         return _mlp_bn(ip.weight_unit.mlp, torch.cat([d, feat], dim=1))  # [E8,32]
 
     side = None
-    if getattr(net, "train_streams", True) and not _sync_bn_active():
+    if use_side:
         side = _side_stream(xyz.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            if fused_ec and csr_side:
+                csr8, csr16 = knn_csr(idx8), knn_csr(idx16)
             w = interp_weights()
     else:
         w = interp_weights()
@@ -1638,6 +1645,8 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             w.record_stream(torch.cuda.current_stream())
+            for t in (csr16 or ()) + (csr8 or ()):
+                t.record_stream(torch.cuda.current_stream())
         if _GLUE and R <= 8:
             u = InterpWsumFn.apply(w.view(B * N, 8, -1), z, idx8, R)
         else:
@@ -1699,6 +1708,8 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     if side is not None:
         torch.cuda.current_stream().wait_stream(side)
         w.record_stream(torch.cuda.current_stream())
+        for t in (csr16 or ()) + (csr8 or ()):
+            t.record_stream(torch.cuda.current_stream())
     zj = GatherRowsFn.apply(z, idx8)                              # [E8,3]
     fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)      # [T,3,R]
     u = fz.transpose(1, 2).reshape(B, N * R, 3)
