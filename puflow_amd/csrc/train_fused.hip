@@ -1250,6 +1250,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 #endif
 constexpr int DW2_D = PF_DW2_D;                               // K-steps (of two edges) per software-pipeline stage
 
+#ifdef PF_EC_DW_F32                                    // the f32-product form of the no-LDS kernel: A/B builds only
 __global__ __launch_bounds__(512) void ec_dw2_kernel(EcDw2Args g2) {
     const EcDwArgs& a = g2.d;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
@@ -1330,6 +1331,7 @@ __global__ __launch_bounds__(512) void ec_dw2_kernel(EcDw2Args g2) {
                 out[(size_t)ri * a.GT + t * 32 + col] = acc[t][r];
             }
 }
+#endif
 
 // The same jobs on the bf16 matrix pipe: x = hi + mid with hi = the top 16 bits of x and mid = bf16(x - hi) (16 mantissa bits
 // together, fp32 exponent range - gradients of 1e-7 keep their digits, which fp16 halves would not), three
