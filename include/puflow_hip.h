@@ -442,7 +442,7 @@ int pf_inject_inv2_bwd(const float* u, const float* s, const float* dv, int Rr, 
  *   which returns dw [T, 8, ldw] and dz [B N, 3] (zero-filled, then scatter-added with float atomics).
  * pf_emd_init: inputs of the auction (metric/emd/emd_module.py:45-56): price = 0, assignment = assignment_inv = -1.
  * pf_pugan_loss: train_pugan.py:52-67, out[0] = w_logp logp + w_emd sum_b sum_n dist[b,n] / radius[b] + w_cd mean_b per[b],
- *   out[1..3] = the weighted EMD, logp and CD terms; backward: the seeds graddist [B,N] (pf_emd_backward), g1 [B,N], g2 [B,M]
+ *   out[1..3] = the weighted EMD, logp and CD terms (per nullable: the EMD-only mix of train_pu1k.py:62-67); backward: the seeds graddist [B,N] (pf_emd_backward), g1 [B,N], g2 [B,M]
  *   (pf_chamfer_bwd), dlogp [1] and the zero-filled gx [B,N,3], gy [B,M,3] those kernels accumulate into. */
 int pf_interp_wsum_fwd(const float* w, int ldw, const float* z, const int* idx, int N, int K, int R, long long T, float* a,
                        float* u, void* stream);

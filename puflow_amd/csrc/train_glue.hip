@@ -115,8 +115,10 @@ __global__ __launch_bounds__(1024) void pugan_loss_fwd_kernel(const float* __res
         float emd = 0.f;
         for (int k = 0; k < 16; ++k) emd += part[k];
         float cd = 0.f;
-        for (int b = 0; b < B; ++b) cd += per[b];
-        cd /= (float)B;
+        if (per) {
+            for (int b = 0; b < B; ++b) cd += per[b];
+            cd /= (float)B;
+        }
         const float l = logp[0];
         out[1] = w_emd * emd; out[2] = w_logp * l; out[3] = w_cd * cd;
         out[0] = (w_logp * l + w_emd * emd) + w_cd * cd;
@@ -177,10 +179,10 @@ extern "C" int pf_emd_init(float* price, int* assign2, long long Bn, void* strea
     return pf_last_launch_status();
 }
 
-// logp [1], dist [B, n] (EMD auction), radius [B] (nullable), per [B] (per-sample Chamfer) -> out [4]
+// logp [1], dist [B, n] (EMD auction), radius [B] (nullable), per [B] (per-sample Chamfer; nullable: no such term) -> out [4]
 extern "C" int pf_pugan_loss_fwd(const float* logp, const float* dist, const float* radius, const float* per, int B, int n,
                                  float w_logp, float w_emd, float w_cd, float* out, void* stream) {
-    if (!logp || !dist || !per || !out) return PF_ERR_NULL;
+    if (!logp || !dist || !out) return PF_ERR_NULL;          // per nullable: no Chamfer term
     if (B <= 0 || n <= 0) return PF_ERR_SHAPE;
     hipLaunchKernelGGL(pugan_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, dist, radius, per, B, n, w_logp,
                        w_emd, w_cd, out);

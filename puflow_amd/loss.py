@@ -147,13 +147,18 @@ class PuganLossFn(Function):
                                          assign2[1].data_ptr(), bid.data_ptr(), bid_inc.data_ptr(), max_inc.data_ptr(),
                                          unass_idx.data_ptr(), max_idx.data_ptr(), float(eps), int(iters), B, n, int(groups),
                                          _emd_status(dev).data_ptr(), ops._stream()), "pf_emd_forward")
-        # ---- Chamfer (metric/loss.py:39-42: mean over points of both directions, mean over the batch)
-        d1, d2, i1, i2, per, _ = ops.chamfer_nn(pred, gt)
-        out = torch.empty((4,), **f32)
+        # ---- Chamfer (metric/loss.py:39-42: mean over points of both directions, mean over the batch); w_cd = 0: the EMD-only
+        # mix of train_pu1k.py:62-67 - no nearest-neighbour search at all
         w_logp, w_emd, w_cd = (float(v) for v in weights)
+        if w_cd != 0.0:
+            d1, d2, i1, i2, per, _ = ops.chamfer_nn(pred, gt)
+        else:
+            i1 = i2 = torch.empty((0,), dtype=torch.int32, device=dev)
+            per = None
+        out = torch.empty((4,), **f32)
         _lib.check(lib.pf_pugan_loss_fwd(logp1.data_ptr(), dist.data_ptr(), radius.data_ptr() if radius is not None else None,
-                                         per.data_ptr(), B, n, w_logp, w_emd, w_cd, out.data_ptr(), ops._stream()),
-                   "pf_pugan_loss_fwd")
+                                         per.data_ptr() if per is not None else None, B, n, w_logp, w_emd, w_cd, out.data_ptr(),
+                                         ops._stream()), "pf_pugan_loss_fwd")
         ctx.save_for_backward(pred, gt, assign2, i1, i2, *(() if radius is None else (radius,)))
         ctx.cfg = (B, n, (w_logp, w_emd, w_cd), radius is not None, logp.shape)
         terms = out[1:4]
@@ -176,8 +181,9 @@ class PuganLossFn(Function):
         _lib.check(lib.pf_pugan_loss_bwd(g1d.data_ptr(), radius.data_ptr() if radius is not None else None, B, n, n, w_logp, w_emd,
                                          w_cd, seeds[0].data_ptr(), seeds[1].data_ptr(), seeds[2].data_ptr(), dlogp.data_ptr(),
                                          gx.data_ptr(), gy.data_ptr(), ops._stream()), "pf_pugan_loss_bwd")
-        _lib.check(lib.pf_chamfer_bwd(pred.data_ptr(), gt.data_ptr(), i1.data_ptr(), i2.data_ptr(), seeds[1].data_ptr(),
-                                      seeds[2].data_ptr(), gx.data_ptr(), gy.data_ptr(), B, n, n, ops._stream()), "pf_chamfer_bwd")
+        if w_cd != 0.0:
+            _lib.check(lib.pf_chamfer_bwd(pred.data_ptr(), gt.data_ptr(), i1.data_ptr(), i2.data_ptr(), seeds[1].data_ptr(),
+                                          seeds[2].data_ptr(), gx.data_ptr(), gy.data_ptr(), B, n, n, ops._stream()), "pf_chamfer_bwd")
         _lib.check(lib.pf_emd_backward(pred.data_ptr(), gt.data_ptr(), gx.data_ptr(), seeds[0].data_ptr(), assign2[0].data_ptr(),
                                        B, n, ops._stream()), "pf_emd_backward")
         return gx, None, None, dlogp.view(lshape), None, None, None, None

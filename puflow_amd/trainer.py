@@ -105,6 +105,14 @@ class TrainerModule(_Base):
         xyz_sparse, xyz_dense, radius = self._unpack(batch)
         upratio = int(xyz_dense.shape[1] / xyz_sparse.shape[1])
         xyz_pred, logpx = self(xyz_sparse, upratio=upratio)
+        if self.loss_mix != "pugan" and self._fused_loss(xyz_pred, xyz_dense):
+            # train_pu1k.py:62-67: logp + EMD (no radius, no Chamfer term) through the same node
+            from .loss import PuganLossFn
+            loss, terms = PuganLossFn.apply(xyz_pred, xyz_dense, None, logpx, self.emd_loss.eps, self.emd_loss.iters,
+                                            self.emd_loss.groups, (1e-4, 5e-2, 0.0))
+            self.log("EMD", terms[0])
+            self.log("logpx", terms[1])
+            return loss
         if self.loss_mix == "pugan" and self._fused_loss(xyz_pred, xyz_dense):
             # the same three terms from one autograd node (loss.PuganLossFn: the ~40 one-element launches between the EMD /
             # Chamfer kernels and the scalar loss fused into two)

@@ -480,6 +480,30 @@ def test_latent_interpolation_kernel_matches_torch(B, N, R):
     assert float(w1.grad[..., R:].abs().max()) == 0.0
 
 
+def test_loss_node_without_the_chamfer_term_matches_the_pu1k_mix():
+    """w_cd = 0 (train_pu1k.py:62-67: logp + EMD, no radius): no nearest-neighbour search runs, value and gradient as the torch
+    expression."""
+    from puflow_amd._prof import profile_calls
+    from puflow_amd.loss import EarthMoverDistance, PuganLossFn
+    B, n = 2, 512
+    pred0 = ((synth_patches(B, n, seed=71) + 1) / 2).to(DEV)
+    gt = ((synth_patches(B, n, seed=72) + 1) / 2).to(DEV)
+    lp0 = torch.tensor(-50.0, device=DEV)
+    p1, l1 = pred0.clone().requires_grad_(True), lp0.clone().requires_grad_(True)
+    with profile_calls() as prof:
+        loss1, terms = PuganLossFn.apply(p1, gt, None, l1, 0.005, 50, 0, (1e-4, 5e-2, 0.0))
+        loss1.backward()
+    torch.cuda.synchronize()
+    assert "pf_chamfer_fwd" not in prof.events and "pf_chamfer_bwd" not in prof.events
+    p2, l2 = pred0.clone().requires_grad_(True), lp0.clone().requires_grad_(True)
+    loss2 = l2 * 1e-4 + EarthMoverDistance()(p2, gt) * 5e-2
+    loss2.backward()
+    assert abs(float(loss1) - float(loss2)) <= 2e-6 * abs(float(loss2))
+    assert float(terms[2]) == 0.0
+    assert float((p1.grad - p2.grad).abs().max()) <= 2e-6 * float(p2.grad.abs().max())
+    assert abs(float(l1.grad) - float(l2.grad)) <= 1e-9
+
+
 @pytest.mark.parametrize("with_radius", [True, False])
 def test_pugan_loss_node_matches_the_separate_losses(with_radius):
     """loss.PuganLossFn against EarthMoverDistance + ChamferCUDA + the weighted sum (train_pugan.py:52-67): value, logged terms,
