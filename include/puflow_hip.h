@@ -155,7 +155,8 @@ int pf_emd_forward(const float* xyz1, const float* xyz2, float* dist, int* assig
  * runs only when hipOccupancyMaxActiveBlocksPerMultiprocessor(kernel) x CU count says all B*G workgroups are resident at once
  * (G = largest power of two <= 16 that fits, >= 64 points per workgroup), otherwise one workgroup per sample; 1 = always one
  * workgroup per sample (no inter-workgroup waits: the setting for a GPU shared between processes); g > 1 = at most g.
- * status: nullable device word; += 1 per sample whose barrier timed out (that sample's dist is NaN).  The caller reads it
+ * status: nullable device word; += 1 per WORKGROUP whose barrier timed out (its slice of dist is NaN): any non-zero value is
+ * a failure.  The caller reads it
  * at its next synchronisation point (puflow_amd.loss.check_emd_status raises). */
 int pf_emd_forward_ex(const float* xyz1, const float* xyz2, float* dist, int* assignment, float* price,
                       int* assignment_inv, int* bid, float* bid_increments, float* max_increments, int* unass_idx,
@@ -459,7 +460,9 @@ int pf_pugan_loss_bwd(const float* g, const float* radius, int B, int N, int M, 
  * (train_pu1k.py:46).  flat_g / m / v: [numel] in the chunk table's flat layout; params: device array of parameter addresses;
  * chunks: device int32 [nchunks][4] = (tensor id, offset in the tensor, length, offset in the flat buffers), no chunk crosses
  * a tensor; lr, step: device scalars (step is incremented here, before use); partial: >= nchunks doubles; counter: one zero
- * word (left zero); coef: 2 floats out (clip coefficient, gradient norm before clipping). */
+ * word (left zero); coef: 4 floats - [0] clip coefficient, [1] gradient norm before clipping, [2] 1 when THIS update was skipped
+ * because the norm is not finite (parameters, moments and the step counter untouched), [3] += 1 per skipped update (the caller
+ * zeroes it). */
 int pf_clip_adam(float* flat_g, float* m, float* v, float* const* params, const int* chunks, int nchunks, const float* lr,
                  float* step, float beta1, float beta2, float eps, float max_norm, double* partial, unsigned* counter,
                  float* coef, void* stream);
@@ -477,8 +480,14 @@ int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, int* idx_out
 /* Layout of pf_fps's scratch when the cooperative kernel runs (return value 1; 0 = single-workgroup kernel, no ring):
  * cloud b's ring starts at 64-bit word b * stride_words of `mind`; word `abort_word` of a ring is the cloud's status after
  * the launch: 0 = every step completed; 1 = its workgroups gave up waiting for each other (bounded spin); 2 = it never
- * finished (or never got its workgroups).  Non-zero = that cloud's idx_out row is invalid. */
+ * finished (or never got its workgroups).  Non-zero = that cloud's idx_out row is invalid.  Word abort_word + 1 holds the
+ * number of exchange rounds the cloud took (two-sample kernel: npoint / rounds samples per round; measurement only). */
 int pf_fps_scratch_layout(int N, long long* stride_words, long long* abort_word);
+
+/* Measurement aid (bench.py --mode pugan): `rounds` rounds of the cooperative FPS kernel's candidate exchange between G
+ * workgroups (2..32) with no points to update - the latency floor of one round of pf_fps's cooperative kernel.  ring: >= 1032
+ * 64-bit words of scratch; ring[1024] == 0 afterwards when every round completed.  No reference counterpart. */
+int pf_fps_exchange_probe(int G, int rounds, unsigned long long* ring, void* stream);
 
 /* PatchHelper.normalize_pc (modules/utils/patch.py:168-178): centroid = mean over the N points, x - centroid, divided by the
  * largest norm.  x, out [B,N,3] (out may alias x), centroid [B,3], fdist [B].  One workgroup per cloud with a fixed

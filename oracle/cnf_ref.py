@@ -174,7 +174,7 @@ def cnf_block(sd: SD, i: int, x: Tensor, c: Tensor, e: Tensor, reverse: bool, st
     """FlowBlock.forward / .inverse with batch_norm=False (continuous/interpflow.py:30-49) around CNF.forward
     (cnf.py:54-121).  x, e [rows, 3], c [rows, cdim] -> (x', delta_logp [rows])."""
     T = float(sd[f"flow_blocks.{i}.cnf.sqrt_end_time"]) ** 2           # cnf.py:75-78 (train_T)
-    y0 = torch.cat([x, torch.zeros(x.shape[0], 1)], dim=-1)
+    y0 = torch.cat([x, torch.zeros(x.shape[0], 1, dtype=x.dtype)], dim=-1)
     n_extra = c.numel()
     d0c = float(((c / (ATOL + RTOL * c.abs())) ** 2).sum().double())
     if not reverse:
@@ -186,21 +186,30 @@ def cnf_block(sd: SD, i: int, x: Tensor, c: Tensor, e: Tensor, reverse: bool, st
 
 
 @torch.no_grad()
-def forward(sd: SD, xyz: Tensor, upratio: int = 4, noise: Optional[List[Tensor]] = None, stages: bool = False):
+def forward(sd: SD, xyz: Tensor, upratio: int = 4, noise: Optional[List[Tensor]] = None, stages: bool = False,
+            dtype: torch.dtype = torch.float32):
     """continuous PointInterpFlow.forward (continuous/interpflow.py:116-126).  `noise[i]` [B,N,3] is block i's
     Hutchinson vector (the reference draws torch.randn_like lazily at the first RHS call of f and re-uses it,
-    repeat_interleaved, in g: odefunc.py:134-137,11-12); default: drawn here from torch's global generator."""
+    repeat_interleaved, in g: odefunc.py:134-137,11-12); default: drawn here from torch's global generator.
+    `dtype=torch.float64` evaluates the same model (weights, inputs and noise are the fp32 values, exactly
+    representable) with every operation of the network and the solver in double: the ANCHOR that tells the fp32
+    oracle's own rounding error from a kernel's (tools/cnf_fp64_anchor.py).  The neighbour lists are always those of
+    the fp32 distances - a discrete choice that is part of the model's input, not of its arithmetic."""
     xyz = xyz.float()
     B, N, _ = xyz.shape
     _, idx16 = O.knn_canonical(xyz, xyz, O.K_FEAT)
     idx8 = idx16[..., :O.K_INTERP].contiguous()
+    if dtype != torch.float32:
+        sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+        xyz = xyz.to(dtype)
+        noise = None if noise is None else [n.to(dtype) for n in noise]
     cs, _ = O.feat_extract(sd, xyz, idx16)
     if noise is None:
-        noise = [torch.randn(B, N, 3) for _ in range(NUM_BLOCKS)]
+        noise = [torch.randn(B, N, 3).to(dtype) for _ in range(NUM_BLOCKS)]
     st = Dopri5Stats()
     # ---- f (continuous/interpflow.py:87-99)
     p = xyz.reshape(B * N, 3)
-    ldj = torch.zeros(B)
+    ldj = torch.zeros(B, dtype=dtype)
     for i in range(NUM_BLOCKS):
         p, dl = cnf_block(sd, i, p, cs[i].reshape(B * N, -1), noise[i].reshape(B * N, 3), False, st)
         ldj = ldj + dl.view(B, N).sum(1)

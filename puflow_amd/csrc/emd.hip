@@ -216,7 +216,7 @@ struct EmdCoopArgs {
     unsigned* mb0; unsigned* mb1; int* mi0; int* mi1;     // [B,n] each: maximum increment bits / winner index, per parity
     unsigned long long* k0; unsigned long long* k1;        // KEY64: [B,n] (increment bits << 32 | bidder) per parity, instead
     unsigned* sync;                                        // [B,n] zeroed by the host: [0] arrivals, [1],[2] unassigned count per parity
-    unsigned* status;                                      // nullable: [0] += 1 for every sample whose grid barrier timed out
+    unsigned* status;                                      // nullable: [0] += 1 for every WORKGROUP whose grid barrier timed out
     int n, iters, G;
     float eps;
 };
@@ -351,9 +351,10 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
         }
         a.dist[o0 + i] = d;
     }
-    // a timed-out barrier is REPORTED (one count per sample; the host raises at its next synchronisation point), the NaN
-    // distances above only keep a consumer from using the partial assignment silently
-    if (dead && w == 0 && tid == 0 && a.status) atomicAdd(a.status, 1u);
+    // a timed-out barrier is REPORTED by EVERY workgroup that saw it (workgroup 0 of the sample may have got through its last
+    // barrier while a peer timed out: that peer's slice of dist is NaN): the host raises on any non-zero count at its next
+    // synchronisation point; the NaN distances above only keep a consumer from using the partial assignment silently
+    if (dead && tid == 0 && a.status) atomicAdd(a.status, 1u);
 }
 
 __global__ __launch_bounds__(256) void emd_grad_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -377,7 +378,9 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(const float* __restrict__
 
 // groups: workgroups per sample of the multi-workgroup auction - 0 = choose from the device (below), 1 = the one-workgroup
 // kernel (always safe: no inter-workgroup waits), g > 1 = at most g.  status: nullable device word; the multi-workgroup
-// kernel adds 1 to it for every sample whose grid barrier timed out (such a sample's distances are NaN).
+// kernel adds 1 to it for every workgroup whose grid barrier timed out (that workgroup's slice of dist is NaN): any non-zero
+// value is a failure.  The occupancy test below counts THIS kernel alone: kernels of the same process on other streams (a
+// training side stream, a second captured graph in flight) take CUs too - the bounded spin + status word cover that case.
 // The multi-workgroup kernel waits on grid barriers, so ALL its B * G workgroups must be resident at once.  That is decided
 // here from what the device can hold for THIS kernel - hipOccupancyMaxActiveBlocksPerMultiprocessor (its LDS / VGPR / wave
 // footprint) x the CU count - not assumed: G is the largest power of two with B * G <= resident capacity (and at most one

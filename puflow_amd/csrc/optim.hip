@@ -55,9 +55,16 @@ __global__ __launch_bounds__(256) void adam_norm_kernel(AdamArgs a) {
     if (threadIdx.x == 0) {
         const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
         const float cf = a.max_norm / (norm + 1e-6f);
-        a.coef[0] = cf < 1.f ? cf : 1.f;
+        // a non-finite gradient norm (a NaN / inf loss: e.g. the NaN distances a timed-out EMD grid barrier leaves) must not
+        // reach the parameters or the moments - one such update makes the whole run unrecoverable, and inside a captured step
+        // the host reads the status words only every few replays.  The update is SKIPPED on the device (no step count, moments and
+        // parameters untouched) and counted in coef[3]; the late host check only reports it.
+        const bool bad = !(norm <= 3.0e38f);
+        a.coef[0] = bad ? 0.f : (cf < 1.f ? cf : 1.f);
         a.coef[1] = norm;
-        a.step[0] += 1.f;
+        a.coef[2] = bad ? 1.f : 0.f;
+        if (bad) a.coef[3] += 1.f;
+        else a.step[0] += 1.f;
         *a.counter = 0u;
     }
 }
@@ -66,6 +73,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
     const int c = blockIdx.x;
     const int tid = a.chunks[c * 4 + 0], lo = a.chunks[c * 4 + 1], len = a.chunks[c * 4 + 2], fo = a.chunks[c * 4 + 3];
     float* p = a.params[tid] + lo;
+    if (a.coef[2] != 0.f) return;                         // non-finite gradient norm: this update is skipped (adam_norm_kernel)
     const float cf = a.coef[0], lr = a.lr[0], t = a.step[0];
     const float bc1 = 1.f - powf(a.beta1, t), bc2 = 1.f - powf(a.beta2, t);
     const float step_size = lr / bc1, bc2s = sqrtf(bc2);
@@ -85,7 +93,9 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
 // flat_g / m / v: [numel] fp32 in the chunk table's flat layout; params: device array of the parameter tensors' addresses;
 // chunks: device int32 [nchunks][4] = (tensor id, offset in the tensor, length, offset in the flat buffers);
 // lr, step: device scalars (step counts completed updates: incremented here, before use); partial: >= nchunks doubles;
-// counter: one zeroed 32-bit word (left zero); coef: 2 floats out (clip coefficient, gradient norm before clipping).
+// counter: one zeroed 32-bit word (left zero); coef: 4 floats - [0] clip coefficient, [1] gradient norm before clipping,
+// [2] 1 when this update was skipped because the norm is not finite (nothing written, step not counted), [3] += 1 per skipped
+// update (zeroed by the caller).
 extern "C" int pf_clip_adam(float* flat_g, float* m, float* v, float* const* params, const int* chunks, int nchunks,
                             const float* lr, float* step, float beta1, float beta2, float eps, float max_norm, double* partial,
                             unsigned* counter, float* coef, void* stream) {

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop2_kernel(const float* __restri
     if (g == 0 && tid == 0) o[0] = 0;
     float l1x = p[0], l1y = p[1], l1z = p[2], l2x = 0.f, l2y = 0.f, l2z = 0.f;
     bool have2 = false;
-    int j = 1;
+    int j = 1, rounds = 0;
     for (int r = 0; j < npoint; ++r) {
         // update with the sample(s) of the previous round; per-lane best two by (distance, then smaller index)
         float b1 = -1.f, b2 = -1.f;
@@ -362,6 +362,59 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop2_kernel(const float* __restri
         l1x = sl[0]; l1y = sl[1]; l1z = sl[2]; l2x = sl[3]; l2y = sl[4]; l2z = sl[5];
         have2 = sl[6] > 0.f;
         j += have2 ? 2 : 1;
+        rounds = r + 1;
+    }
+    // the word after the status word: exchange rounds this cloud took (measurement only: bench.py --mode pugan reports
+    // samples per round and the time per round next to the exchange floor of pf_fps_exchange_probe)
+    if (g == 0 && tid == 0) { fps_st(abort_w + 1, (unsigned long long)rounds); fps_st(abort_w, FPSC_ST_DONE); }
+}
+
+// ---- the exchange alone: what a round of fps_coop2_kernel costs with NO points to update ------------------------------
+// Same protocol, same ring, same shapes (G workgroups of FPSC_T threads, two words per wave, wave 0 polls 4 words per lane,
+// reduces them and hands a result to the other waves through the double-buffered LDS words, one barrier per round) - only the
+// per-point min-distance update and the candidate's coordinate fetch are missing.  Timed with HIP events it is the floor of a
+// round: the store -> load round trip through the fabric plus waiting for the slowest of the G peers.
+__global__ __launch_bounds__(FPSC_T) void fps_exchange_probe_kernel(int G, int rounds, unsigned long long* __restrict__ ring) {
+    constexpr int NW = FPSC_T / 64;
+    __shared__ float s_l[2][2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x;
+    unsigned long long* abort_w = ring + FPSC_RING2;
+    const int S2 = 2 * G * NW;
+    unsigned acc = (unsigned)(g * NW + wave) + 1u;
+    for (int r = 0; r < rounds; ++r) {
+        unsigned long long* slot = ring + (r & 3) * FPSC_SLOTS2;
+        const unsigned tag = ((unsigned)(((r >> 2) & 3) << 1) | 1u) << 29;
+        if (lane == 0) {
+            fps_st(slot + 2 * (g * NW + wave), ((unsigned long long)acc << 32) | tag | 1u);
+            fps_st(slot + 2 * (g * NW + wave) + 1, ((unsigned long long)(acc >> 1) << 32) | tag);
+        }
+        if (wave == 0) {
+            unsigned long long k[4];
+            unsigned spins = 0;
+            bool dead = false;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    k[t] = lane + 64 * t < S2 ? fps_ld(slot + lane + 64 * t) : (unsigned long long)tag;
+                    ok = ok && ((unsigned)k[t] & (7u << 29)) == tag;
+                }
+                if (!__any(!ok)) break;
+                if (++spins > FPSC_SPIN_MAX || (spins % 1024 == 0 && fps_ld(abort_w) == FPSC_ST_ABORT)) { dead = true; break; }
+            }
+            if (dead) {
+                if (lane == 0) { fps_st(abort_w, FPSC_ST_ABORT); s_l[r & 1][1] = -1.f; }
+            } else {
+                const unsigned long long K1 = wave_max_u64(u64max(u64max(k[0], k[1]), u64max(k[2], k[3])));
+                if (lane == 0) { s_l[r & 1][0] = __uint_as_float((unsigned)(K1 >> 32) & 0xffffu); s_l[r & 1][1] = 1.f; }
+            }
+        }
+        __syncthreads();
+        if (s_l[r & 1][1] < 0.f) return;
+        acc = acc * 1664525u + (unsigned)__float_as_uint(s_l[r & 1][0]) + 1013904223u;      // the next word depends on this round's result
+        acc &= 0x7fffffffu;
     }
     if (g == 0 && tid == 0) fps_st(abort_w, FPSC_ST_DONE);
 }
@@ -528,6 +581,19 @@ extern "C" int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, i
         return pf_last_launch_status();
     }
     hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(FPS_T), 0, s, xyz, N, npoint, mind, idx_out);
+    return pf_last_launch_status();
+}
+
+// `rounds` exchange rounds of the cooperative FPS protocol between G workgroups (2 <= G <= 32) with no points to update: the
+// floor of a round of fps_coop2_kernel.  ring: >= 1032 64-bit words of scratch (cleared here); its word 1024 is 0 afterwards
+// when every round completed (1 = the bounded spin gave up).  Measurement aid of bench.py --mode pugan.
+extern "C" int pf_fps_exchange_probe(int G, int rounds, unsigned long long* ring, void* stream) {
+    if (!ring) return PF_ERR_NULL;
+    if (G < 2 || G > FPSC_GMAX || rounds <= 0 || ((size_t)ring & 7) != 0) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fps_init_kernel, dim3(8), dim3(256), 0, s, reinterpret_cast<float*>(ring), 2ll * (FPSC_RING2 + 8), 1,
+                       (long long)(FPSC_RING2 + 8), FPSC_RING2);
+    hipLaunchKernelGGL(fps_exchange_probe_kernel, dim3(G), dim3(FPSC_T), 0, s, G, rounds, ring);
     return pf_last_launch_status();
 }
 

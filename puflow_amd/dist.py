@@ -14,6 +14,27 @@ import torch
 import torch.distributed as dist
 
 
+_FORCE_COLLECTIVES = False
+
+
+def force_collectives(on: bool = True) -> None:
+    """Run the multi-rank code path (gradient bucket all-reduce between the two step graphs, module / buffer broadcasts,
+    ActNorm-init broadcast, SyncBN statistics all-reduce) even in a process group of ONE rank.  The arithmetic is unchanged
+    (a one-rank all-reduce is the identity, the mean divides by 1); it exists so that the RCCL backend, the interleaving of
+    eager collectives with graph replays and the group's teardown can be exercised on a single GPU
+    (tests/test_gpu_rccl_smoke.py, `bench.py` with PF_BENCH_FORCE_DIST=1)."""
+    global _FORCE_COLLECTIVES
+    _FORCE_COLLECTIVES = bool(on)
+
+
+def multi_rank() -> bool:
+    """True when the collectives of the training path have to run: an initialised process group of more than one rank (or of
+    one rank under `force_collectives`)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or _FORCE_COLLECTIVES
+
+
 def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) slice of `total` patches owned by `rank`; sizes differ by at most one."""
     base, rem = divmod(total, world)
@@ -95,7 +116,7 @@ class FlatGradBucket:
     def all_reduce_mean(self, always_pack: bool = False) -> None:
         """grad <- mean over ranks of grad (missing grads count as zero).  always_pack: concatenate into the flat buffer in a
         single process too (the fused optimizer reads the flat buffer)."""
-        multi = dist.is_initialized() and dist.get_world_size() > 1
+        multi = multi_rank()
         if self.as_views:
             if not self.views_intact():
                 self.rebind()
@@ -128,7 +149,7 @@ def _broadcast_tensors(tensors, src: int) -> None:
 
 def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
     """Same weights / buffers on every rank (e.g. after ActNorm's data-dependent init on rank 0)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not multi_rank():
         return
     _broadcast_tensors(list(module.parameters()) + list(module.buffers()), src)
 
@@ -137,7 +158,7 @@ def broadcast_buffers(module: torch.nn.Module, src: int = 0) -> None:
     """BatchNorm running statistics are updated from each rank's own shard (local batch statistics, like
     DistributedDataParallel without SyncBN); like DDP's `broadcast_buffers`, rank `src`'s copies are made
     authoritative before anything reads them in eval mode (validation, checkpoints)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not multi_rank():
         return
     _broadcast_tensors(list(module.buffers()), src)
 

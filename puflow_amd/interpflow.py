@@ -392,9 +392,9 @@ class PointInterpFlow(nn.Module):
         return super()._apply(fn, *a, **kw)
 
     def _signature(self):
-        """What the packed eval plan was built from: the version counter of every parameter / buffer (and their addresses,
-        taken when the tensor list is (re)built: _apply() / load_state_dict() drop it).  Compared on EVERY use of the plan -
-        ~400 attribute reads, tens of microseconds - so in-place edits are seen in eval mode too.  Writers that go around
+        """What the packed eval plan was built from: the address and the version counter of every parameter / buffer (the
+        tensor LIST is cached: _apply() / load_state_dict() drop it).  Compared on EVERY use of the plan - ~800 attribute
+        reads, tens of microseconds - so in-place edits and `.data` rebinds are seen in eval mode too.  Writers that go around
         torch's version counters must bump them (torch._C._increment_version): the fused optimizer
         (optim.FusedClipAdam.step_flat) and a replayed training graph (train_graph.GraphedTrainStep.__call__) do,
         dist.broadcast_* write with in-place copies; a train-mode forward, whose fused kernels update the BatchNorm running
@@ -403,8 +403,8 @@ class PointInterpFlow(nn.Module):
         ts = getattr(self, "_sig_tensors", None)
         if ts is None:
             ts = self._sig_tensors = list(self.parameters()) + list(self.buffers())
-            self._sig_addr = tuple(t.data_ptr() for t in ts)
-        return (self._sig_addr, tuple([t._version for t in ts]), getattr(self, "_train_forwards", 0))
+        # addresses are read on every use too: a rebind (`p.data = new_tensor`) changes the address without bumping _version
+        return (tuple([t.data_ptr() for t in ts]), tuple([t._version for t in ts]), getattr(self, "_train_forwards", 0))
 
     def _engine(self, upratio: int = 4) -> _Engine:
         """The packed plan (it does not depend on the upsampling ratio; the argument is kept for callers of round 1)."""

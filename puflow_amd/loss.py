@@ -30,9 +30,9 @@ def check_emd_status(device=None) -> None:
         n = int(t[0].item())
         if n:
             t.zero_()
-            raise _lib.PuflowHipError(f"pf_emd_forward: {n} sample(s) of a multi-workgroup auction timed out on a grid barrier "
-                                      "(workgroups not co-resident - is the GPU shared with another process?); their "
-                                      "distances are NaN.  Use EarthMoverDistance(groups=1) on a shared device")
+            raise _lib.PuflowHipError(f"pf_emd_forward: {n} workgroup(s) of a multi-workgroup auction timed out on a grid barrier "
+                                      "(workgroups not co-resident - is the GPU shared with another process?); their slices "
+                                      "of the distances are NaN.  Use EarthMoverDistance(groups=1) on a shared device")
 
 
 class emdFunction(Function):
@@ -186,4 +186,5 @@ class PuganLossFn(Function):
                                           seeds[2].data_ptr(), gx.data_ptr(), gy.data_ptr(), B, n, n, ops._stream()), "pf_chamfer_bwd")
         _lib.check(lib.pf_emd_backward(pred.data_ptr(), gt.data_ptr(), gx.data_ptr(), seeds[0].data_ptr(), assign2[0].data_ptr(),
                                        B, n, ops._stream()), "pf_emd_backward")
-        return gx, None, None, dlogp.view(lshape), None, None, None, None
+        # the ground truth's gradient: the Chamfer term's only (the EMD has none, emd_module.py:68-72) - like _ChamferFn returns it
+        return gx, (gy if ctx.needs_input_grad[1] else None), None, dlogp.view(lshape), None, None, None, None

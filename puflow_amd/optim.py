@@ -43,7 +43,8 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.step_t = torch.zeros(1, **f32)
         self.lr_t = torch.full((1,), float(lr), **f32)
         self._lr_host = float(lr)
-        self.coef = torch.zeros(2, **f32)                       # [clip coefficient, gradient norm] of the last step
+        # [clip coefficient, gradient norm, this update skipped (non-finite norm), number of skipped updates] - csrc/optim.hip
+        self.coef = torch.zeros(4, **f32)
         self._partial = torch.empty(len(rows), dtype=torch.float64, device=dev)
         self._counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.lib = _lib.load()
@@ -75,6 +76,14 @@ class FusedClipAdam(torch.optim.Optimizer):
         # the kernel writes the parameters through raw pointers: tell torch (autograd's saved-tensor checks, and the packed
         # eval plan of PointInterpFlow, which is keyed on the version counters)
         torch._C._increment_version(self.params)
+
+    def skipped_updates(self, reset: bool = True) -> int:
+        """Updates the kernel SKIPPED since the last call because the global gradient norm was not finite (parameters, moments
+        and step counter were left untouched).  One device read: call where the host synchronises anyway."""
+        n = int(self.coef[3].item())
+        if n and reset:
+            self.coef[3].zero_()
+        return n
 
     @torch.no_grad()
     def step(self, closure=None):

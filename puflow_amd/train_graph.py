@@ -48,8 +48,10 @@ class GraphedTrainStep:
             raise RuntimeError("graphed_train_step: SyncBN reads the global row count on the host; capture is not possible")
         self.module, self.optimizer, self.clip = module, optimizer, clip
         dev = next(module.parameters()).device
+        from .dist import multi_rank
         self.world = torch.distributed.get_world_size() if (torch.distributed.is_available() and
                                                              torch.distributed.is_initialized()) else 1
+        self.multi = multi_rank()           # the two-graph form with the eager all-reduce in between (dist.force_collectives: also with one rank)
         from .optim import FusedClipAdam
         self.fused = isinstance(optimizer, FusedClipAdam)
         if self.fused:
@@ -75,7 +77,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
-        if self.world == 1:
+        if not self.multi:
             with torch.cuda.graph(self.graph_a):
                 self.loss = self._fwd_bwd()
                 self._update()
@@ -107,18 +109,18 @@ class GraphedTrainStep:
         self.bucket.drop_grads()
         loss = self.module.training_step(self.static, 0)
         loss.backward()
-        if self.world > 1:
+        if self.multi:
             self.bucket.pack()
         return loss.detach()
 
     def _reduce(self) -> None:
-        if self.world > 1:
+        if self.multi:
             torch.distributed.all_reduce(self.bucket.flat)
             self.bucket.flat.div_(self.world)
 
     def _update(self) -> None:
         if self.fused:                                      # clip + Adam as two launches on the flat gradient buffer
-            if self.world == 1:
+            if not self.multi:
                 self.bucket.pack()
             self.optimizer.step_flat(self.bucket.flat)
             return

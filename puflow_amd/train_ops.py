@@ -231,7 +231,8 @@ def sync_bn(on: bool):
 
 def _multi_rank() -> bool:
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    from .dist import multi_rank
+    return multi_rank()
 
 
 def _sync_bn_active() -> bool:
@@ -1507,6 +1508,7 @@ _CHAIN = os.environ.get("PF_TRAIN_CHAIN", "1") != "0"
 # chains of one-element torch launches as fused kernels (csrc/train_glue.hip: interpolation of the latent, the log-likelihood
 # inside the f chain, the loss head of loss.PuganLossFn); "0" = the torch expressions (the A/B reference)
 _GLUE = os.environ.get("PF_TRAIN_GLUE", "1") != "0"
+_CSR_SIDE = os.environ.get("PF_TRAIN_CSR_SIDE", "1") != "0"      # A/B switch, read once at import like its neighbours (README "Switches")
 
 
 def _flow_param_aliases(net):
@@ -1570,7 +1572,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     # transposed neighbour lists: only the BACKWARD of the EdgeConv units reads them - with a side stream they are built there,
     # off the main chain (8 small launches, ~55 us), and joined with the interpolation weights
     csr16 = csr8 = None
-    csr_side = use_side and os.environ.get("PF_TRAIN_CSR_SIDE", "1") != "0"
+    csr_side = use_side and _CSR_SIDE
     if fused_ec and not csr_side:
         csr16, csr8 = knn_csr(idx16), knn_csr(idx8)
 

@@ -184,8 +184,8 @@ class TrainerModule(_Base):
         gradient averaging never reconciles parameters: run the init forward once, then broadcast rank 0's module."""
         if all(b.actnorm.is_inited for b in self.network.flow_blocks):
             return
-        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
-        if not multi:
+        from .dist import multi_rank
+        if not multi_rank():
             return                      # single process: the init happens inside the first real forward, as in the reference
         from .dist import broadcast_module
         with torch.no_grad():
@@ -206,6 +206,13 @@ class TrainerModule(_Base):
         printed, like the reference's `loss is nan`)."""
         from .loss import check_emd_status
         check_emd_status(next(self.parameters()).device)
+        opt = getattr(self, "_fused_opt", None)
+        if opt is not None:
+            k = opt.skipped_updates()
+            if k:
+                print(f"optimizer: {k} update(s) skipped on the device (non-finite gradient norm; parameters and moments untouched)")
+                if raise_on_nan:
+                    raise RuntimeError(f"{k} training step(s) produced a non-finite gradient")
         n = 0
         if self._nan_subs is not None:
             n = int(self._nan_subs.item())
@@ -219,7 +226,10 @@ class TrainerModule(_Base):
     def graphed_train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2, warmup: int = 2):
         """`train_step` for a fixed batch shape captured in hipGraphs (puflow_amd/train_graph.py): returns
         `step(batch) -> loss` that replays forward + backward (+ clip + Adam) with one launch instead of ~3 500."""
+        from .optim import FusedClipAdam
         from .train_graph import GraphedTrainStep
+        if isinstance(optimizer, FusedClipAdam):
+            self._fused_opt = optimizer                         # check_device_status reports its skipped updates
         return GraphedTrainStep(self, optimizer, batch, clip, warmup)
 
     def train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2) -> Tensor:
@@ -232,6 +242,7 @@ class TrainerModule(_Base):
         loss.backward()
         from .optim import FusedClipAdam
         if isinstance(optimizer, FusedClipAdam):
+            self._fused_opt = optimizer
             self._bucket.all_reduce_mean(always_pack=True)      # ONE concatenation (+ ONE 3.2 MB RCCL all-reduce when multi-rank)
             optimizer.param_groups[0]["max_norm"] = clip
             optimizer.step_flat(self._bucket.flat)              # clip by the global norm + Adam: two launches

@@ -212,11 +212,22 @@ def cnf_state_dict_spec():
     return spec
 
 
-def synth_cnf_state_dict(seed: int = 2021, dynamics: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+# Integration end times T = sqrt_end_time^2 of the six CNF blocks of the reference's trained checkpoint
+# (pretrain/puflow-x4-cnf-pu1k.pt, `flow_blocks.{i}.cnf.sqrt_end_time`; cnf.py:41 initialises every block to 0.5 and trains
+# it): the last two blocks integrate 10x / 100x longer than the first four.  Six numbers describing the checkpoint; the
+# synthetic benchmark workload uses them so that dopri5 sees a trained model's mix of short stiff and long smooth blocks.
+CNF_PU1K_END_TIMES = (0.330, 0.372, 0.310, 0.195, 2.92, 36.3)
+CNF_PU1K_DYNAMICS = 1.7     # with the end times above: 462 evaluations / 59 accepted / 14 rejected steps per 1 x 2048 forward
+                            # (the trained checkpoint: 462 / 62 / 11), and a map as well-conditioned as the trained one
+                            # (fp32 vs fp64 oracle: 3e-4 of max|x|; the old `dynamics=5, T=0.5` workload: 1e-2)
+
+
+def synth_cnf_state_dict(seed: int = 2021, dynamics: float = 1.0, end_times=None) -> "OrderedDict[str, torch.Tensor]":
     """Random-init weights of the continuous model: the shared extractor / interpolation part is the discrete
     generator's, the ODE nets get nn.Linear-style fan-in scaling (large enough that dopri5 takes real steps).
-    dynamics > 1 scales the main path of the ODE nets (`_layer` weights): a stiffer right-hand side, more and rejected steps -
-    bench.py --mode cnf uses it to give the solver the workload it has on the reference's pretrained checkpoint."""
+    dynamics > 1 scales the main path of the ODE nets (`_layer` weights): a stiffer right-hand side, more and rejected steps;
+    end_times: the six integration end times (default: cnf.py:41's initial 0.5 everywhere).  bench.py --mode cnf uses
+    (CNF_PU1K_DYNAMICS, CNF_PU1K_END_TIMES) to give the solver the workload it has on the reference's pretrained checkpoint."""
     base = synth_state_dict(seed)
     rng = np.random.Generator(np.random.PCG64(seed + 104729))
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -224,7 +235,8 @@ def synth_cnf_state_dict(seed: int = 2021, dynamics: float = 1.0) -> "OrderedDic
         if not key.startswith("flow_blocks."):
             sd[key] = base[key].clone()
         elif kind == "T":
-            sd[key] = torch.tensor(float(np.sqrt(0.5)), dtype=torch.float32)           # cnf.py:41, T = 0.5
+            T_end = 0.5 if end_times is None else float(end_times[int(key.split(".")[1])])       # cnf.py:41: T = 0.5 at init
+            sd[key] = torch.tensor(float(np.sqrt(T_end)), dtype=torch.float32)
         elif kind == "nfe":
             sd[key] = torch.tensor(0.0, dtype=torch.float32)
         else:

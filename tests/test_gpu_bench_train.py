@@ -96,7 +96,12 @@ def test_bench_cnf_line():
     roof, cpu, par = rec["roofline"], rec["cpu_baseline"], rec["parity"]
     assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and cpu["kind"] == "port" and cpu["value"] > 0
     assert par["nfe"][0] == par["nfe"][1] and par["accepted"][0] == par["accepted"][1] and par["rejected"][0] == par["rejected"][1]
-    assert par["max_abs_dx_vs_oracle"] < 2e-2      # a stiff synthetic map (|x| up to ~5) through 12 chained integrations at rtol 1e-5
+    # the bound comes from the line's own float64 anchor: the synthetic map expands in g, the fp32 CPU oracle itself sits
+    # ~2e-3 from the float64 evaluation; the HIP path may be no further from fp64 than 4x that
+    anc = par["fp64_anchor"]
+    for k in ("x", "z", "ldj"):
+        assert anc[k]["hip_vs_f64"] <= 4.0 * anc[k]["oracle_f32_vs_f64"] + 1e-4, (k, anc[k])
+    assert par["max_abs_dx_vs_oracle"] <= 5.0 * anc["x"]["oracle_f32_vs_f64"] + 1e-4
 
 
 def test_bench_train_two_ranks_self_launched():

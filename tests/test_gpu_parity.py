@@ -412,6 +412,26 @@ def test_graphed_forward_is_pinned_to_its_plan(lib):
         run2(xyz)
 
 
+def test_data_rebind_invalidates_the_plan(lib):
+    """`p.data = new_tensor` changes a parameter's address without bumping its version counter: the plan signature compares
+    addresses on every use, so the next eval forward re-packs instead of silently keeping the old weights."""
+    sd = synth_state_dict(21)
+    xyz = synth_patches(2, 256, seed=22).to(DEV)
+    net = _net(sd)
+    x0, _ = net(xyz, 4)
+    x0 = x0.clone()
+    p = net.flow_blocks[0].actnorm.bias
+    v = p._version
+    p.data = p.data.clone() + 0.25
+    assert p._version == v                                  # the rebind is invisible to version counters
+    x1, _ = net(xyz, 4)
+    assert not torch.equal(x1, x0)
+    sd2 = {k: t.clone() for k, t in sd.items()}
+    sd2["flow_blocks.0.actnorm.bias"] = sd2["flow_blocks.0.actnorm.bias"] + 0.25
+    xr, _ = O.forward(sd2, xyz.cpu(), 4)
+    assert (x1.cpu() - xr).abs().max() < 1e-5
+
+
 def test_logp_reduction_in_the_flow_kernel_is_deterministic(lib):
     """Flow f and the log-likelihood run as ONE launch (the workgroup that finishes last reduces the wave tiles' sums in a
     fixed order): whichever workgroup that is, per-item log-dets and logp are bit-identical from run to run, at a shape with

@@ -1,0 +1,60 @@
+"""GPU: the RCCL backend on the one GPU this box has.  Every multi-rank test of the suite swaps RCCL for gloo (two ranks
+cannot share a device under RCCL), so until this test nothing had ever initialised backend "nccl".  ONE fresh child process
+runs `bench.py` as a process group of one rank with the multi-rank code path forced (`PF_BENCH_FORCE_DIST=1` ->
+`puflow_amd.dist.force_collectives`): init_process_group("nccl", device_id=...), `broadcast_module`, the training step as
+graph A -> eager `all_reduce` of the 806 103-float gradient bucket on the same stream -> graph B, timing barriers, the MAX
+all-reduce of the elapsed time, `destroy_process_group` - and must exit 0.  No process that touched the GPU is exec'ed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "MASTER_PORT", "PF_BENCH_BACKEND", "PF_BENCH_SINGLE_DEVICE")}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", PF_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_training_step_over_rccl_one_rank(graph):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", "train", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], cwd=ROOT, env=dict(_env(), PF_BENCH_GRAPH=graph), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "capture failed" not in out.stderr
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    col = rec["config"]["collectives"]
+    assert col == {"backend": "nccl", "world_size": 1, "forced_one_rank_group": True}
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["loss"] == rec["loss"] and abs(rec["loss"]) < 1e3
+    if graph == "1":
+        assert "eager all-reduce" in rec["config"]["launch"]
+
+
+def test_forced_collectives_do_not_change_the_step():
+    """The forced one-rank path (pack -> all-reduce -> / 1 -> update) and the plain single-process path take the same
+    optimisation steps: same loss after the same number of steps from the same state (the EMD's float atomics aside,
+    which the bound covers)."""
+    losses = []
+    for force in ("1", "0"):
+        env = _env()
+        if force == "0":
+            for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PF_BENCH_FORCE_DIST"):
+                env.pop(k)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--steps", "2", "--warmup", "1",
+                              "--no-cpu-baseline"], cwd=ROOT, env=dict(env, PF_BENCH_GRAPH="0"), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        losses.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["loss"])
+    assert abs(losses[0] - losses[1]) <= 2e-3 * abs(losses[1]), losses
+
+
+def test_inference_bench_over_rccl_one_rank():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2", "--no-cpu-baseline",
+                          "--no-reduced"], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0

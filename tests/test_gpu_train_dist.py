@@ -19,9 +19,10 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    # The two ranks SHARE one GPU here.  The EMD auction picks its workgroups per sample from the device's occupancy for the
-    # kernel (csrc/emd.hip pf_emd_forward_ex): 2 samples x 16 workgroups per rank, 64 of 256 CUs for both ranks together -
-    # co-resident; a timed-out grid barrier would be REPORTED by train_step (loss.check_emd_status), not hidden in a NaN.
+    # The two ranks SHARE one GPU here.  The EMD auction's occupancy query (csrc/emd.hip pf_emd_forward_ex) knows nothing about
+    # another process on the device, so shared-device callers pass groups = 1 (cfg.emd_workgroups=1: one workgroup per sample,
+    # no inter-workgroup waits) - as bench.py does under PF_BENCH_SINGLE_DEVICE.  The multi-workgroup auction (groups = 0) has
+    # its own test on an unshared device: tests/test_gpu_losses.py::test_emd_groups_argument_and_status_word.
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -31,7 +32,7 @@ def _worker(rank, world, port, q):
         dev = "cuda:0"
         dense = ((synth_patches(4, 1024, seed=11) + 1) / 2)[2 * rank:2 * rank + 2].to(dev)      # this rank's shard
         batch = (dense[:, ::4].contiguous(), dense, torch.ones(2, device=dev))
-        tm = TrainerModule(default_cfg(learning_rate=1e-3), loss_mix="pugan")
+        tm = TrainerModule(default_cfg(learning_rate=1e-3, emd_workgroups=1), loss_mix="pugan")
         tm.network.load_state_dict(synth_state_dict(21))
         tm = tm.to(dev)
         opt = tm.configure_optimizers()["optimizer"]
@@ -71,10 +72,10 @@ def _bn_buffers(tm):
             if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
 
 
-def _make_tm(dev, sync):
+def _make_tm(dev, sync, emd_workgroups=0):
     from puflow_amd.trainer import TrainerModule, default_cfg
     from puflow_amd.weights import synth_state_dict
-    tm = TrainerModule(default_cfg(learning_rate=1e-3, sync_batchnorm=sync), loss_mix="pugan")
+    tm = TrainerModule(default_cfg(learning_rate=1e-3, sync_batchnorm=sync, emd_workgroups=emd_workgroups), loss_mix="pugan")
     tm.network.load_state_dict(synth_state_dict(21))
     for b in tm.network.flow_blocks:
         b.actnorm.is_inited = False                       # a fresh model: the first step runs the data-dependent init
@@ -89,7 +90,7 @@ def _worker_bn(rank, world, port, q):
         dev = "cuda:0"
         dense = ((synth_patches(4, 1024, seed=11) + 1) / 2)[2 * rank:2 * rank + 2].to(dev)
         batch = (dense[:, ::4].contiguous(), dense, torch.ones(2, device=dev))
-        tm = _make_tm(dev, True)
+        tm = _make_tm(dev, True, emd_workgroups=1)            # two processes on one device: no grid barriers (see _worker)
         opt = tm.configure_optimizers()["optimizer"]
         loss = float(tm.train_step(batch, opt))
         q.put((rank, loss, _bn_buffers(tm)))

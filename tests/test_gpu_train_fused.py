@@ -252,6 +252,40 @@ def test_fused_clip_adam_matches_torch():
     assert float(fa.step_t) == 5.0
 
 
+def test_fused_clip_adam_skips_a_non_finite_gradient():
+    """A NaN / inf anywhere in the flat gradient (what a timed-out EMD barrier or a NaN loss leaves) must not reach the
+    parameters or the moments: the update is skipped ON THE DEVICE (a captured step reads its status words only every few
+    replays), counted, and the next finite gradient updates exactly as if the bad step had never happened."""
+    from puflow_amd.optim import FusedClipAdam
+    torch.manual_seed(5)
+    shapes = [(64, 33), (64,), (5000,)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    fa, fb = FusedClipAdam(pa, lr=1e-3, max_norm=1e-2), FusedClipAdam(pb, lr=1e-3, max_norm=1e-2)
+    g1 = [torch.randn_like(p) for p in pa]
+    g2 = [torch.randn_like(p) * 1e-4 for p in pa]
+    for opt, ps in ((fa, pa), (fb, pb)):
+        for p, g in zip(ps, g1):
+            p.grad = g.clone()
+        opt.step()
+    for bad in (float("nan"), float("inf")):
+        before = [p.detach().clone() for p in pa]
+        m0, v0, s0 = fa.exp_avg.clone(), fa.exp_avg_sq.clone(), float(fa.step_t)
+        for p, g in zip(pa, g2):
+            p.grad = g.clone()
+        pa[2].grad[1234] = bad
+        fa.step()
+        assert float(fa.coef[2]) == 1.0 and float(fa.step_t) == s0
+        assert all(torch.equal(p, b) for p, b in zip(pa, before)) and torch.equal(fa.exp_avg, m0) and torch.equal(fa.exp_avg_sq, v0)
+    assert fa.skipped_updates() == 2 and fa.skipped_updates() == 0
+    for opt, ps in ((fa, pa), (fb, pb)):
+        for p, g in zip(ps, g2):
+            p.grad = g.clone()
+        opt.step()
+    assert float(fa.coef[2]) == 0.0 and float(fa.step_t) == 2.0
+    assert all(torch.equal(p, q) for p, q in zip(pa, pb))
+
+
 def test_training_forward_backward_on_an_odd_patch_size():
     """A patch size whose edge count is not a multiple of 16 (N = 255, K = 8 in the interpolation unit -> 2040 edges): the fused
     EdgeConv unit declines it and the per-op path takes over inside the same step; everything else stays fused; the result

@@ -11,6 +11,7 @@ import sys
 from collections import defaultdict
 
 SIMD_PER_CU, CUS, XCDS = 4, 256, 8
+NOMINAL_GHZ = 2.4            # MI355X_MICROARCH.md: peak engine clock
 
 
 def short(name: str) -> str:
@@ -47,6 +48,16 @@ def main(root: str) -> None:
             e["mfma_util_pct"] = 100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (gui * SIMD_PER_CU * CUS)
             if e.get("avg_us"):
                 e["shader_clock_ghz"] = gui / e["avg_us"] / 1e3
+                # GRBM_GUI_ACTIVE counts from before the dispatch's first wave to after its last: for a short kernel the window is
+                # longer than the kernel and "GUI cycles / duration" comes out above the 2.4 GHz the part can clock.  Such a window
+                # UNDERSTATES every per-cycle ratio; the utilisation is then taken against duration x the nominal clock (an upper
+                # bound on the cycles the kernel really had) and the row is flagged.
+                if e["shader_clock_ghz"] > NOMINAL_GHZ * 1.02:
+                    e["mfma_util_pct_gui_window"] = e["mfma_util_pct"]
+                    e["mfma_util_pct"] = 100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (e["avg_us"] * 1e3 * NOMINAL_GHZ * SIMD_PER_CU * CUS)
+                    e["clock_unphysical"] = True
+                    e["shader_clock_ghz_gui_window"] = e["shader_clock_ghz"]
+                    e["shader_clock_ghz"] = None
         if e.get("SQ_LDS_IDX_ACTIVE_mean"):
             e["lds_conflict_pct"] = 100.0 * e.get("SQ_LDS_BANK_CONFLICT_mean", 0.0) / e["SQ_LDS_IDX_ACTIVE_mean"]
         out[k] = e
