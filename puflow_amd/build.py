@@ -72,8 +72,22 @@ def build_f16(force: bool = False, verbose: bool = True) -> str:
     return build(force=force, verbose=verbose, defines=["PF_MMN_TERMS=1"], tag="f16", only=F16_SOURCES)
 
 
+LIB_GRADF32 = LIB.replace(".so", "_gradf32.so")
+GRADF32_DEFINES = ["PF_EC_BWDG_F32", "PF_EC_DW_F32", "PF_EC_FWD_F32"]
+
+
+def build_gradf32(force: bool = False, verbose: bool = True) -> str:
+    """The A/B reference of the training step's arithmetic: the same kernels with plain f32 MFMA products where the default
+    build multiplies split-bf16 (EdgeConv backward, weight gradients) / split-fp16 (conv_out forward) operands.  bench.py
+    --mode train loads it in a child process and reports every parameter gradient's distance to it (`grad_parity`)."""
+    build(force=False, verbose=verbose)
+    return build(force=force, verbose=verbose, defines=GRADF32_DEFINES, tag="gradf32", only=("train_fused.hip",))
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     build_f16(force="--force" in sys.argv)
+    build_gradf32(force="--force" in sys.argv)
     print(LIB)
     print(LIB_F16)
+    print(LIB_GRADF32)
