@@ -74,6 +74,8 @@ def build_f16(force: bool = False, verbose: bool = True) -> str:
 
 LIB_GRADF32 = LIB.replace(".so", "_gradf32.so")
 GRADF32_DEFINES = ["PF_EC_BWDG_F32", "PF_EC_DW_F32", "PF_EC_FWD_F32"]
+LIB_BWDF32 = LIB.replace(".so", "_bwdf32.so")
+BWDF32_DEFINES = ["PF_EC_BWDG_F32", "PF_EC_DW_F32"]
 
 
 def build_gradf32(force: bool = False, verbose: bool = True) -> str:
@@ -81,6 +83,9 @@ def build_gradf32(force: bool = False, verbose: bool = True) -> str:
     build multiplies split-bf16 (EdgeConv backward, weight gradients) / split-fp16 (conv_out forward) operands.  bench.py
     --mode train loads it in a child process and reports every parameter gradient's distance to it (`grad_parity`)."""
     build(force=False, verbose=verbose)
+    # the same with the FORWARD left as in the default build: isolates the backward arithmetic (a forward that differs by 1e-6
+    # already moves ill-conditioned gradients by 1e-3 through max-pool routes and the flow's conditioning)
+    build(force=force, verbose=verbose, defines=BWDF32_DEFINES, tag="bwdf32", only=("train_fused.hip",))
     return build(force=force, verbose=verbose, defines=GRADF32_DEFINES, tag="gradf32", only=("train_fused.hip",))
 
 

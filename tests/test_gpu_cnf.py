@@ -247,5 +247,6 @@ def test_full_size_properties_32x2048():
     for i in reversed(range(6)):
         p = eng.integrate(i, p, ctxs[i], e, 1, True, 0, 0.0)[:, :3].contiguous()
     err = (p.view(B, N, 3) - xyz).abs().max()
-    print("g(f(x)) - x at 32 x 2048:", float(err))
-    assert err < 1e-3
+    zmax = float(full["z"].abs().max())
+    print("g(f(x)) - x at 32 x 2048:", float(err), "max|z|", zmax)
+    assert err < 2e-4 * max(1.0, zmax)           # the solver's rtol = 1e-5 per step on latents of this size, 12 chained integrations
