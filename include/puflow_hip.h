@@ -294,7 +294,15 @@ typedef struct PfEcTrain {
                                        every kernel that uses them leaves them zero again */
     const int* csr_off; const int* csr_edge;   /* backward, nullable: transposed neighbour lists (pf_knn_csr) - the neighbour
                                        scatter-add of dQ then runs as a gather without float atomics */
+    int flags;                      /* PF_EC_PERSISTENT: the forward may run as ONE persistent launch with a grid barrier per
+                                       BatchNorm layer (pooling units, K = 16, nconv = 4, every tile resident at once - decided by
+                                       the library from the device's occupancy).  The caller sets it only when no other barrier
+                                       kernel of the process can run beside this call (another stream, another captured graph in
+                                       flight, another process on the device): two such kernels can starve each other */
+    unsigned* sync;                 /* flags != 0: 4 words, zeroed ONCE by the caller; [0..2] are left zero by every launch, [3] is
+                                       sticky: 1 = a grid barrier timed out (the unit's output is NaN) */
 } PfEcTrain;
+#define PF_EC_PERSISTENT 1
 /* transposed neighbour lists of idx [B*N, K]: off [T+1], edge [T*K]; cnt: T ints (4-aligned size) of scratch */
 int pf_knn_csr(const int* idx, int B, int N, int K, int* off, int* edge, int* cnt, void* stream);
 long long pf_ec_train_ws_floats(const PfEcTrain* p);

@@ -21,7 +21,8 @@ class PfEcTrain(ctypes.Structure):
                 ("Wpq", c_void_p), ("bpq", c_void_p), ("PQ", c_void_p), ("Y", c_void_p), ("aff", c_void_p), ("out", c_void_p),
                 ("arg", c_void_p), ("dout", c_void_p), ("dA", c_void_p), ("dPQ", c_void_p), ("coef", c_void_p),
                 ("dWpq", c_void_p), ("dx", c_void_p), ("dW", c_void_p * 9), ("dbias", c_void_p * 9),
-                ("dgamma", c_void_p * 8), ("dbeta", c_void_p * 8), ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p), ("csr_off", c_void_p), ("csr_edge", c_void_p)]
+                ("dgamma", c_void_p * 8), ("dbeta", c_void_p * 8), ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p), ("csr_off", c_void_p), ("csr_edge", c_void_p),
+                ("flags", c_int), ("sync", c_void_p)]
 
 
 class PfBnMlpTrain(ctypes.Structure):

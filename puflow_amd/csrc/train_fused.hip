@@ -417,6 +417,421 @@ __global__ __launch_bounds__(256) void ec_fwd16_kernel(EcFwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, the whole unit in ONE launch
+// The per-layer kernels above pay, per unit, five launch ramps / drains and re-read every earlier layer's pre-BatchNorm output
+// from memory (0 + 1 + 2 + 3 growth blocks for the growth layers, all four again for conv_out: ~170 MB per 128-channel unit next
+// to the 67 MB it has to write for the backward).  BatchNorm's batch statistics are the only thing that couples two edges, so a
+// PERSISTENT grid can keep an edge tile's features in registers through the whole dense block and meet at a grid barrier once
+// per BatchNorm layer:
+//   * one workgroup per CU (512 threads = 8 waves, 2 per SIMD, <= 256 VGPRs), a wave owns up to ECP_TPW tiles of 16 edges (= one
+//     point and its K = 16 neighbours) for the whole launch;
+//   * channel-major chain (pf_mfma.h): output channels on MFMA rows, the 16 edges on the columns - a layer's accumulator tile
+//     IS the next layer's B operand, no transposition, no LDS round trip;
+//   * layer t: y_t = P_t[i] + Q_t[j] + W_t f_{<t} (v_mfma_f32_16x16x4_f32, the k order of ec_fwd_kernel: the stored Y is bit
+//     for bit the per-layer kernels'), Y stored once for the backward, column sums (centred on the running mean) -> 16 spread
+//     double accumulators -> arrival counter; the workgroup that arrives last turns the sums into scale / shift / running
+//     statistics (the StatFin arithmetic) and publishes the barrier's generation word; everyone applies BatchNorm + LeakyReLU to
+//     the tile it still holds;
+//   * conv_out on split-fp16 products (the f16x2 arithmetic of ec_fwd16_kernel, weights converted once per workgroup into A
+//     fragments in LDS), max over the 16 edges = the 16 lanes of a DPP row, argmax = smallest k among the maxima.
+// Barrier: agent-scope relaxed atomics only (arrive: s_waitcnt vmcnt(0) + atomic add; release: the last arriver's atomic stores
+// of aff, s_waitcnt, then the generation word) - no release fence (a device-scope fence writes the L2 back: tens of us).
+// Co-residency is the HOST's job (pf_ec_train_fwd: occupancy x CU count >= grid, and the caller's PF_EC_PERSISTENT flag says no
+// other barrier kernel of this process can be in flight); the spin is bounded anyway: on timeout the status word sync[3] is
+// set, the unit's output becomes NaN and the grid drains.
+constexpr int ECP_WAVES = 8, ECP_T = 64 * ECP_WAVES, ECP_TPW = 4;
+constexpr int ECP_SPIN = 1 << 22;
+// timing-only ablations of ec_fwdp_kernel (tools/time_ecunit.py with -DPF_ECP_DBG=mask builds; results are WRONG with any bit set):
+// 1 no conv_out, 2 barriers pass at once, 4 no weight staging, 8 no Y stores, 16 no statistics atomics
+#ifndef PF_ECP_DBG
+#define PF_ECP_DBG 0
+#endif
+
+struct EcFwdPArgs {
+    float* Y; int ldy;               // [E, GT]
+    float* aff;                      // [4][GT]
+    const float* Wg[8]; int ldwg[8]; // growth columns of conv t (pointer past the 3C edge-feature columns)
+    const float* Wout; int ldwout;
+    const float* pq; int ldpq; int S;
+    const int* idx; int N;
+    int ntiles;                      // = points (K = 16)
+    float slope;
+    float* out; unsigned char* arg;
+    const float* gamma[8]; const float* beta[8]; float* run_mean[8]; float* run_var[8];
+    float eps, momentum; double R;
+    double* acc;                     // [STAT_COPIES][2][STAT_W] accumulators (zero between uses)
+    unsigned* sync;                  // [0] arrivals [1] generation [2] exits [3] status (sticky: 1 = a barrier timed out)
+};
+
+__device__ __forceinline__ float ecp_ald(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ecp_ast(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int CTRL>
+__device__ __forceinline__ float ecp_dppf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float ecp_rowsum16(float v) {           // sum over the 16 lanes of a DPP row, in every lane
+    v += ecp_dppf<0x128>(v); v += ecp_dppf<0x124>(v); v += ecp_dppf<0x122>(v); v += ecp_dppf<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ float ecp_rowmax16(float v) {
+    v = fmaxf(v, ecp_dppf<0x128>(v)); v = fmaxf(v, ecp_dppf<0x124>(v)); v = fmaxf(v, ecp_dppf<0x122>(v)); v = fmaxf(v, ecp_dppf<0x121>(v));
+    return v;
+}
+__device__ __forceinline__ int ecp_rowmin16(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false)); v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false)); v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+// grid barrier number `gen` (1, 2, ...) of this launch: pure arrival counting - the workgroup that arrives last publishes
+// the generation word at once (what follows a barrier is done by every workgroup for itself).  Returns false when the spin gave
+// up (uniform over the workgroup).
+__device__ __forceinline__ bool ecp_barrier(unsigned* sync, unsigned gen, int* flag) {
+    if (PF_ECP_DBG & 2) { __syncthreads(); return true; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int fl = 0;
+        if (atomicAdd(sync, 1u) == gen * gridDim.x - 1)
+            __hip_atomic_store(sync + 1, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else {
+            int budget = ECP_SPIN;
+            while (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen && --budget > 0) __builtin_amdgcn_s_sleep(1);
+            if (budget <= 0) { fl = 2; __hip_atomic_store(sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        *flag = fl;
+    }
+    __syncthreads();
+    return *flag != 2;
+}
+
+template <int G, int NC, int ODIM>
+__global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
+    constexpr int GT = G * NC, NB = GT / 16, NTG = (G + 15) / 16, NTO = ODIM / 16, NCP = NB / 2;
+#ifndef PF_ECP_OCH
+#define PF_ECP_OCH 1
+#endif
+    constexpr int OCH = NB >= 8 ? PF_ECP_OCH : 2;                           // conv_out blocks per accumulator chunk: 2 x 4 x ECP_TPW x OCH accumulator
+                                                               // registers beside the wave's ECP_TPW x NB x 4 feature registers
+    constexpr bool OWN = G % 16 == 0;                          // a layer's 16-channel blocks are its own (G = 8: two layers share one)
+    static_assert(GT % 32 == 0 && ODIM % 16 == 0 && NTO % OCH == 0 && 32 * NC <= STAT_W && G <= 32, "shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[ECP_WAVES * 2 * 32];
+    __shared__ float scsh[2 * 32];
+    __shared__ int flag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+
+    // ---- this wave's tiles
+    int tl[ECP_TPW], jr[ECP_TPW];
+    bool ok[ECP_TPW];
+#pragma unroll
+    for (int s = 0; s < ECP_TPW; ++s) {
+        tl[s] = blockIdx.x * ECP_WAVES + wave + s * gridDim.x * ECP_WAVES;
+        ok[s] = tl[s] < a.ntiles;
+        const int tt = ok[s] ? tl[s] : 0;
+        jr[s] = (tt / a.N) * a.N + a.idx[(size_t)tt * 16 + col];
+        tl[s] = tt;
+    }
+    f4 f[ECP_TPW][NB];
+#pragma unroll
+    for (int s = 0; s < ECP_TPW; ++s)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) f[s][b] = pf_splat(0.f);
+    // the addends P_t[i] + Q_t[j] of layer t for all the wave's tiles (independent gathers, all in flight together).  OWN layers
+    // accumulate in the feature slots they are about to fill (free until then), so layer t + 1's addends can be fetched BEFORE
+    // the barrier of layer t and their latency disappears behind it
+    f4 accs[OWN ? 1 : ECP_TPW][NTG];
+    auto addends = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int col0 = G * t, b0 = col0 / 16;
+#pragma unroll
+        for (int s = 0; s < ECP_TPW; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NTG; ++nt) {
+                const int c4 = 16 * (b0 + nt) + 4 * q;
+                f4 v = pf_splat(0.f);
+                if (c4 >= col0 && c4 < col0 + G)
+                    v = *reinterpret_cast<const f4*>(a.pq + (size_t)tl[s] * a.ldpq + c4) +
+                        *reinterpret_cast<const f4*>(a.pq + (size_t)jr[s] * a.ldpq + a.S + c4);
+                if constexpr (OWN) f[s][b0 + nt] = v;
+                else accs[s][nt] = v;
+            }
+    };
+    addends(std::integral_constant<int, 0>{});                // layer 0 needs no weights: its gathers fly while the weights are staged
+
+    // ---- LDS images: growth weights of layers 1 .. NC-1 (fp32, row = channel inside the layer's first block, padded rows /
+    // columns zero), then conv_out as split-fp16 A fragments [ob][cp][hi | lo'][lane]; first read after barrier 1
+    int woff[NC];
+    {
+        int o = 0;
+#pragma unroll
+        for (int t = 1; t < NC; ++t) { woff[t] = o; o += NTG * 16 * (((G * t + 15) & ~15) + 4); }
+        woff[0] = o;                                           // [0]: start of the conv_out fragments (a multiple of 64 floats)
+    }
+    // (all of a thread's loads of a matrix are in flight before its first LDS store: a load -> store loop pays one memory
+    // latency per element)
+    pf_static_for<1, NC>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (PF_ECP_DBG & 4) return;
+        constexpr int kin = G * t, kin16 = (kin + 15) & ~15, kp = kin16 + 4, ro = (G * t) % 16, NE = NTG * 16 * kin16;
+        constexpr int IT = (NE + ECP_T - 1) / ECP_T;
+        float* Wl = lds + woff[t];
+        float v[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = threadIdx.x + k * ECP_T, rw = i / kin16, u = i % kin16, c = rw - ro;      // tile row -> row of the conv
+            v[k] = (i < NE && c >= 0 && c < G && u < kin) ? a.Wg[t][(size_t)c * a.ldwg[t] + u] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = threadIdx.x + k * ECP_T;
+            if (i < NE) Wl[(i / kin16) * kp + i % kin16] = v[k];
+        }
+    });
+    uint4* Wf = reinterpret_cast<uint4*>(lds + woff[0]);
+    if (!(PF_ECP_DBG & 4)) {
+        constexpr int NU = NTO * NCP * 64, IT = (NU + ECP_T - 1) / ECP_T;
+        f4 w0[IT], w1[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int unit = threadIdx.x + k * ECP_T, uu = unit < NU ? unit : 0;
+            const int frag = uu >> 6, ln = uu & 63, o = (frag / NCP) * 16 + (ln & 15), cp = frag % NCP, kq = ln >> 4;
+            const float* wr = a.Wout + (size_t)o * a.ldwout + 32 * cp + 4 * kq;
+            w0[k] = (f4){wr[0], wr[1], wr[2], wr[3]};
+            w1[k] = (f4){wr[16], wr[17], wr[18], wr[19]};
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int unit = threadIdx.x + k * ECP_T;
+            if (unit < NU) {
+                const PfPair2 fr = pf_pair2(w0[k], w1[k]);
+                Wf[((unit >> 6) * 2 + 0) * 64 + (unit & 63)] = __builtin_bit_cast(uint4, fr.h);
+                Wf[((unit >> 6) * 2 + 1) * 64 + (unit & 63)] = __builtin_bit_cast(uint4, fr.l);
+            }
+        }
+    }
+
+    bool alive = true;
+    pf_static_for<0, NC>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int col0 = G * t, b0 = col0 / 16, KS = (G * t + 15) / 16, kp = ((G * t + 15) & ~15) + 4;
+        if (!alive) return;
+        const float* Wl = lds + woff[t];
+        auto A = [&](int s, int nt) -> f4& {
+            if constexpr (OWN) return f[s][b0 + nt];
+            else return accs[s][nt];
+        };
+        if constexpr (!OWN && t > 0) addends(tc);
+        // this lane's channels of the layer: c4 = 16 (b0 + nt) + 4 q .. + 3
+        bool cv[NTG];
+        f4 piv[NTG], s0[NTG], s1[NTG], ycur[OWN ? 1 : ECP_TPW][NTG];
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt) {
+            const int c4 = 16 * (b0 + nt) + 4 * q;
+            cv[nt] = c4 >= col0 && c4 < col0 + G;
+            piv[nt] = pf_splat(0.f);
+            if (cv[nt] && a.run_mean[t]) piv[nt] = *reinterpret_cast<const f4*>(a.run_mean[t] + (c4 - col0));
+            s0[nt] = s1[nt] = pf_splat(0.f);
+        }
+        if constexpr (t > 0) {                                  // the tiles' MFMA chains, interleaved (independent accumulators)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NTG; ++nt) {
+                    const f4 w = *reinterpret_cast<const f4*>(Wl + (nt * 16 + col) * kp + ks * 16 + 4 * q);
+#pragma unroll
+                    for (int s = 0; s < ECP_TPW; ++s) A(s, nt) = mfma4(w, f[s][ks], A(s, nt));
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < ECP_TPW; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NTG; ++nt) {
+                const f4 v = A(s, nt);
+                if constexpr (!OWN) ycur[s][nt] = v;
+                if (cv[nt] && ok[s]) {
+                    const f4 vc = v - piv[nt];
+                    s0[nt] = s0[nt] + vc;
+                    s1[nt] = s1[nt] + vc * vc;
+                }
+            }
+        // ---- column sums: DPP row -> LDS over the waves -> spread double accumulators (columns 32 t ..: a layer has its own,
+        // nothing has to be cleared between two barriers of a launch)
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a0 = ecp_rowsum16(s0[nt][r]), a1 = ecp_rowsum16(s1[nt][r]);
+                const int c = 16 * (b0 + nt) + 4 * q + r - col0;
+                if (col == 0 && c >= 0 && c < G) { red[wave * 64 + c] = a0; red[wave * 64 + 32 + c] = a1; }
+            }
+        __syncthreads();
+        if (!(PF_ECP_DBG & 16) && threadIdx.x < 64 && (threadIdx.x & 31) < G) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < ECP_WAVES; ++w) v += red[w * 64 + threadIdx.x];
+            unsafeAtomicAdd(a.acc + (blockIdx.x % STAT_COPIES) * 2 * STAT_W + (threadIdx.x >> 5) * STAT_W + 32 * t + (threadIdx.x & 31), (double)v);
+        }
+        if constexpr (OWN && t + 1 < NC) addends(std::integral_constant<int, t + 1>{});      // next layer's gathers fly during the barrier
+        alive = ecp_barrier(a.sync, (unsigned)(t + 1), &flag);
+        if (!alive) return;
+        // ---- every workgroup turns the sums into the layer's constants for itself (the StatFin mode-1 arithmetic); workgroup 0
+        // also leaves them in `aff` for the backward and updates the running statistics
+        // 256 threads: thread (part = tid & 3, stat = (tid >> 2) & 1, column = tid >> 3) fetches 4 of the 16 copies of one sum
+        // (all loads of the workgroup in flight at once, 8 registers each), the 4 parts meet through lane shuffles
+        double part = 0.0;
+        if (threadIdx.x < 256) {
+            const int pt = threadIdx.x & 3, stt = (threadIdx.x >> 2) & 1, c = threadIdx.x >> 3;
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                v[k] = __hip_atomic_load(a.acc + (4 * pt + k) * 2 * STAT_W + stt * STAT_W + 32 * t + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            part = (v[0] + v[1]) + (v[2] + v[3]);
+            part += __shfl_xor(part, 1);
+            part += __shfl_xor(part, 2);                       // lanes pt = 0..3 now hold the sum over all 16 copies
+        }
+        const double other = __shfl_xor(part, 4);              // the other statistic of the same column
+        if (threadIdx.x < 256 && (threadIdx.x & 7) == 0 && (threadIdx.x >> 3) < G) {
+            const int c = threadIdx.x >> 3;
+            const double a0 = part, a1 = other;
+            const double pv = a.run_mean[t] ? (double)a.run_mean[t][c] : 0.0;
+            const double dm = a0 / a.R;
+            const double mean = pv + dm;
+            double var = a1 / a.R - dm * dm;
+            if (var < 0.0) var = 0.0;
+            const float rstd = 1.0f / sqrtf((float)var + a.eps);
+            const float sc = a.gamma[t][c] * rstd, sh = a.beta[t][c] - (float)mean * sc;
+            scsh[c] = sc;
+            scsh[32 + c] = sh;
+            if (blockIdx.x == 0) {
+                a.aff[col0 + c] = sc;
+                a.aff[a.ldy + col0 + c] = sh;
+                a.aff[2 * a.ldy + col0 + c] = (float)mean;
+                a.aff[3 * a.ldy + col0 + c] = rstd;
+                if (a.run_mean[t]) {            // every workgroup read its pivot before it arrived at the barrier above
+                    a.run_mean[t][c] = (1.f - a.momentum) * a.run_mean[t][c] + a.momentum * (float)mean;
+                    a.run_var[t][c] = (1.f - a.momentum) * a.run_var[t][c] + a.momentum * (float)(var * (a.R / (a.R - 1.0)));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- BatchNorm + LeakyReLU on the tiles this wave still holds: they become f[.][b0 ..] (rows of other layers that share
+        // the block stay as they are: scale = shift = 0 outside the layer gives lrelu(0) = 0)
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt) {
+            f4 sc = pf_splat(0.f), sh = pf_splat(0.f);
+            if (cv[nt]) {
+                const int cl = 16 * (b0 + nt) + 4 * q - col0;
+                sc = *reinterpret_cast<const f4*>(scsh + cl);
+                sh = *reinterpret_cast<const f4*>(scsh + 32 + cl);
+            }
+            // the raw tile goes to memory only now (the backward reads it): its stores are in flight during the next layer
+            // instead of in front of this layer's barrier, whose s_waitcnt would have waited for them
+#pragma unroll
+            for (int s = 0; s < ECP_TPW; ++s) {
+                f4 raw;
+                if constexpr (OWN) raw = f[s][b0 + nt];
+                else raw = ycur[s][nt];
+                if (cv[nt] && ok[s] && !(PF_ECP_DBG & 8))
+                    *reinterpret_cast<f4*>(a.Y + ((size_t)tl[s] * 16 + col) * a.ldy + 16 * (b0 + nt) + 4 * q) = raw;
+                if constexpr (OWN) f[s][b0 + nt] = lrelu4(raw * sc + sh, a.slope);
+                else f[s][b0 + nt] = f[s][b0 + nt] + lrelu4(raw * sc + sh, a.slope);
+            }
+        }
+    });
+
+    // ---- conv_out + max over the 16 edges of the point
+    // Operands swapped against the growth layers: the feature pair registers are bit for bit also the A operand with the EDGES on
+    // the MFMA rows, the weight fragments the B operand with the channels on the columns, so D[edge][channel] puts 4 edges of ONE
+    // channel into a lane - the max over the 16 edges is 3 in-lane comparisons + 2 exchanges across the lane rows instead of a
+    // 16-lane reduction per value.  The addend comes in the same layout: P_out[i][c] once, Q_out[j_k][c] for the lane's four
+    // edges k = 4 q + r (4-byte gathers, 64 B per 16 lanes).
+    // What bounded this phase (58 of 128 us, and the 60 us of ec_fwd16_kernel) is the LDS weight stream: every tile read all
+    // 64 KiB of fragments.  Here the features are converted ONCE into split operand pairs - in place of the fp32 registers they
+    // replace, same count - and every fragment read serves all of the wave's tiles: a quarter of the LDS bytes.
+    if (alive && !(PF_ECP_DBG & 1)) {
+        PfPair2 fp[ECP_TPW][NCP];
+#pragma unroll
+        for (int s = 0; s < ECP_TPW; ++s)
+#pragma unroll
+            for (int cp = 0; cp < NCP; ++cp) fp[s][cp] = pf_pair2(f[s][2 * cp], f[s][2 * cp + 1]);
+        int jq[ECP_TPW][4];
+#pragma unroll
+        for (int s = 0; s < ECP_TPW; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) jq[s][r] = __shfl(jr[s], 4 * q + r);
+#pragma unroll
+        for (int oc = 0; oc < NTO; oc += OCH) {
+            f4 acc[ECP_TPW][OCH], accx[ECP_TPW][OCH];
+#pragma unroll
+            for (int s = 0; s < ECP_TPW; ++s)
+#pragma unroll
+                for (int o = 0; o < OCH; ++o) {
+                    const int c = GT + 16 * (oc + o) + col;
+                    const float pv = a.pq[(size_t)tl[s] * a.ldpq + c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[s][o][r] = pv + a.pq[(size_t)jq[s][r] * a.ldpq + a.S + c];
+                    accx[s][o] = pf_splat(0.f);
+                }
+#pragma unroll
+            for (int cp = 0; cp < NCP; ++cp)
+#pragma unroll
+                for (int o = 0; o < OCH; ++o) {
+                    const h8 wh = __builtin_bit_cast(h8, Wf[(((oc + o) * NCP + cp) * 2 + 0) * 64 + lane]);
+                    const h8 wl = __builtin_bit_cast(h8, Wf[(((oc + o) * NCP + cp) * 2 + 1) * 64 + lane]);
+#pragma unroll
+                    for (int s = 0; s < ECP_TPW; ++s) {
+                        acc[s][o] = pf_mfma_f16(fp[s][cp].h, wh, acc[s][o]);
+                        accx[s][o] = pf_mfma_f16(fp[s][cp].l, wh, accx[s][o]);
+                        accx[s][o] = pf_mfma_f16(fp[s][cp].h, wl, accx[s][o]);
+                    }
+                }
+#pragma unroll
+            for (int s = 0; s < ECP_TPW; ++s)
+#pragma unroll
+                for (int o = 0; o < OCH; ++o) {
+                    const f4 v = acc[s][o] + accx[s][o] * PF_LO_INV;
+                    float best = v[0];
+                    int bk = 4 * q;
+#pragma unroll
+                    for (int r = 1; r < 4; ++r)
+                        if (v[r] > best) { best = v[r]; bk = 4 * q + r; }
+#pragma unroll
+                    for (int m = 16; m < 64; m <<= 1) {
+                        const float ov = __shfl_xor(best, m);
+                        const int okk = __shfl_xor(bk, m);
+                        if (ov > best || (ov == best && okk < bk)) { best = ov; bk = okk; }
+                    }
+                    if (q == 0 && ok[s]) {
+                        const size_t o0 = (size_t)tl[s] * ODIM + 16 * (oc + o) + col;
+                        a.out[o0] = best;
+                        a.arg[o0] = (unsigned char)bk;
+                    }
+                }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < ECP_TPW; ++s)
+            if (ok[s] && col == 0)
+                for (int c = 4 * q; c < ODIM; c += 16)
+                    *reinterpret_cast<f4*>(a.out + (size_t)tl[s] * ODIM + c) = pf_splat(__builtin_nanf(""));
+    }
+    // ---- the workgroup that leaves last clears the accumulator columns the layers used and puts the barrier words back to zero
+    // (every workgroup is past every barrier and has read every sum by then)
+    __syncthreads();
+    if (threadIdx.x == 0) flag = atomicAdd(a.sync + 2, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (flag == 1) {
+        for (int i = threadIdx.x; i < STAT_COPIES * 2 * STAT_W; i += ECP_T)
+            if ((i % STAT_W) < 32 * NC) __hip_atomic_store(a.acc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(a.sync + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward through one conv
 // SRC 0: the conv is conv_out of a pooled unit: dYout[e, c] = dh[i, c] if argmax[i, c] == k else 0, formed on load
 // SRC 1: conv_out without pooling: dYout [E, kin] dense
@@ -1621,6 +2036,59 @@ long long gemm_ws_max(const PfEcTrain* p, const Dims& d) {
     return gm > g3 ? gm : g3;
 }
 
+// ---- the unit's forward as ONE persistent launch (ec_fwdp_kernel): shapes it is instantiated for, and whether all of its
+// workgroups can be resident at once on this device (grid barriers).  The caller's PF_EC_PERSISTENT flag is the promise that no
+// OTHER barrier kernel of this process runs beside it (two barrier kernels can starve each other; ordinary kernels only delay it).
+template <int G, int ODIM>
+size_t ecp_lds_bytes() {
+    size_t fl = 0;
+    for (int t = 1; t < 4; ++t) fl += (size_t)((G + 15) / 16) * 16 * (((G * t + 15) & ~15) + 4);
+    return fl * sizeof(float) + (size_t)(ODIM / 16) * (G * 4 / 32) * 2 * 64 * 16;
+}
+template <int G, int ODIM>
+int ecp_capacity() {
+    const size_t lds = ecp_lds_bytes<G, ODIM>();
+    allow_lds(ec_fwdp_kernel<G, 4, ODIM>, lds);
+    int ncu = 0, dev = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ec_fwdp_kernel<G, 4, ODIM>, ECP_T, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return per_cu >= 1 ? ncu : 0;                  // one workgroup per CU at most: each wants most of a CU's registers
+}
+bool ec_persistent_ok(const PfEcTrain* p, const Dims& d) {
+    if (!(p->flags & PF_EC_PERSISTENT) || !p->sync || !p->pooling || p->K != 16 || p->nconv != 4) return false;
+    int cap = 0;
+    if (p->growth == 8 && p->odim == 32) cap = ecp_capacity<8, 32>();
+    else if (p->growth == 16 && p->odim == 64) cap = ecp_capacity<16, 64>();
+    else if (p->growth == 32 && p->odim == 128) cap = ecp_capacity<32, 128>();
+    return cap > 0 && (long long)d.ntiles <= (long long)cap * ECP_WAVES * ECP_TPW;
+}
+int ec_fwd_persistent(const PfEcTrain* p, const Dims& d, const EcConvs& cv, hipStream_t s) {
+    EcFwdPArgs a{};
+    a.Y = p->Y; a.ldy = d.GT; a.aff = p->aff; a.pq = p->PQ; a.ldpq = 2 * d.S; a.S = d.S; a.idx = p->idx; a.N = p->N;
+    a.ntiles = d.ntiles; a.slope = p->slope; a.out = p->out; a.arg = p->arg;
+    for (int t = 0; t < p->nconv; ++t) {
+        a.Wg[t] = p->W[t] + 3 * p->C; a.ldwg[t] = cv.width[t];
+        a.gamma[t] = p->gamma[t]; a.beta[t] = p->beta[t]; a.run_mean[t] = p->run_mean[t]; a.run_var[t] = p->run_var[t];
+    }
+    a.Wout = p->W[p->nconv] + 3 * p->C; a.ldwout = cv.width[p->nconv];
+    a.eps = p->eps; a.momentum = p->momentum; a.R = (double)d.E; a.acc = p->stat; a.sync = p->sync;
+    const int wgs = (d.ntiles + ECP_WAVES * ECP_TPW - 1) / (ECP_WAVES * ECP_TPW);     // fewest workgroups that hold every tile ...
+    int ncu = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int spread = (d.ntiles + ECP_WAVES - 1) / ECP_WAVES;                         // ... spread over the CUs when there are fewer tiles
+    const int grid = spread < ncu ? (spread > wgs ? spread : wgs) : (wgs > ncu ? wgs : ncu);
+    const size_t l8 = ecp_lds_bytes<8, 32>(), l16 = ecp_lds_bytes<16, 64>(), l32 = ecp_lds_bytes<32, 128>();
+    if (p->growth == 8) hipLaunchKernelGGL((ec_fwdp_kernel<8, 4, 32>), dim3(grid), dim3(ECP_T), l8, s, a);
+    else if (p->growth == 16) hipLaunchKernelGGL((ec_fwdp_kernel<16, 4, 64>), dim3(grid), dim3(ECP_T), l16, s, a);
+    else hipLaunchKernelGGL((ec_fwdp_kernel<32, 4, 128>), dim3(grid), dim3(ECP_T), l32, s, a);
+    return pf_last_launch_status();
+}
+
 }  // namespace
 
 // floats of scratch for either direction: dw partials [nchunk][S][GT] + [nchunk][S] + split-K slabs of the point GEMMs
@@ -1665,6 +2133,7 @@ extern "C" int pf_ec_train_fwd(const PfEcTrain* p, void* stream) {
                  pf_gemm_ws_floats(d.T, 2 * d.S, p->C), stream);
     if (st) return st;
     const int g = p->growth;
+    if (ec_persistent_ok(p, d)) return ec_fwd_persistent(p, d, cv, s);
     EcFwdArgs a{};
     a.Y = p->Y; a.ldy = d.GT; a.aff = p->aff; a.pq = p->PQ; a.ldpq = 2 * d.S; a.idx = p->idx; a.N = p->N; a.K = p->K;
     a.ntiles = d.ntiles; a.slope = p->slope;

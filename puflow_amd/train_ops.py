@@ -66,6 +66,42 @@ def _stat(dev) -> Tensor:
     return t
 
 
+_SYNCW = {}
+# persistent (grid-barrier) kernels of the training step (csrc/train_fused.hip: ec_fwdp_kernel): "1" = the main chain's EdgeConv
+# units may use them (the default; the network attribute `train_persistent` and a device shared between processes switch them
+# off per module), "0" = the per-layer kernels everywhere (the A/B reference).  Read once at import.
+_PERSIST = os.environ.get("PF_TRAIN_PERSIST", "1") != "0"
+
+
+def _sync_words(dev) -> Tensor:
+    """4 zero-initialised 32-bit words per (device, stream): arrivals / generation / exits of the persistent kernels' grid
+    barriers (left zero by every launch) and a sticky status word (check_persist_status)."""
+    key = (dev, _stream())
+    t = _SYNCW.get(key)
+    if t is None:
+        t = torch.zeros(4, dtype=torch.int32, device=dev)
+        _SYNCW[key] = t
+    return t
+
+
+def check_persist_status(device=None) -> None:
+    """Raise if a grid barrier of a persistent training kernel timed out since the last check (its workgroups were not all
+    resident: another barrier kernel or another process held the CUs).  The unit's output was NaN, the optimizer skipped the
+    update on the device; the statistics accumulators of that stream are cleared here.  One word read per stream that used a
+    persistent kernel: call where the host synchronises anyway."""
+    for (dev, stream), t in list(_SYNCW.items()):
+        if device is not None and torch.device(device) != dev:
+            continue
+        if int(t[3].item()):
+            t.zero_()
+            st = _STAT.get((dev, stream))
+            if st is not None:
+                st.zero_()
+            raise _lib.PuflowHipError("a persistent training kernel timed out on a grid barrier (workgroups not co-resident - is the GPU "
+                                      "shared with another process, or did two barrier kernels run side by side?).  Set "
+                                      "net.train_persistent = False (cfg.persistent_kernels = False) on a shared device")
+
+
 def _gemm(A: Tensor, sam: int, sak: int, Bm: Tensor, sbk: int, sbn: int, C: Tensor, ldc: int, bias, M: int, N: int, K: int,
           arith: int = 0):
     lib = _lib.load()
@@ -599,7 +635,7 @@ def edgeconv_train_unfolded(p, x: Tensor, idx: Tensor, pooling: bool = True) -> 
     return MaxPoolKFn.apply(y, K).view(B, N, -1)
 
 
-def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None) -> Tensor:
+def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None, persistent: bool = False) -> Tensor:
     """FeatureExtractUnit in train mode (interpflow.py:234-248). x [B,N,C]; returns [B,N,odim] or [B*N*K, odim].
 
     Same algebra as the inference path's edge-feature fold (packing.fold_edgeconv): every conv of the dense block sees
@@ -611,7 +647,7 @@ def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None) ->
     if _UNFOLDED:
         return edgeconv_train_unfolded(p, x, idx, pooling)
     if _FUSED and not _sync_bn_active() and _ec_fused_supported(p, x, idx, pooling):
-        return edgeconv_train_fused(p, x, idx, pooling, csr)
+        return edgeconv_train_fused(p, x, idx, pooling, csr, persistent)
     B, N, C = x.shape
     K = idx.shape[-1]
     convs = [seq[0] for seq in p.convs] + [p.conv_out]
@@ -689,6 +725,8 @@ class EdgeConvUnitFn(Function):
         ws = _ws(dev, need)
         d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
         d.stat = _stat(dev).data_ptr()
+        if len(cfg) > 11 and cfg[11]:                         # the whole forward as one persistent launch where the library can
+            d.flags, d.sync = 1, _sync_words(dev).data_ptr()
         _lib.check(lib.pf_ec_train_fwd(ctypes.byref(d), _stream()), "pf_ec_train_fwd")
         ctx.cfg = cfg
         ctx.has_arg = pooling
@@ -1418,12 +1456,12 @@ def _ec_fused_supported(p, x: Tensor, idx: Tensor, pooling: bool) -> bool:
             and (B * N * K) % 16 == 0 and (K == 16 or not pooling))
 
 
-def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None) -> Tensor:
+def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None, persistent: bool = False) -> Tensor:
     convs = [seq[0] for seq in p.convs] + [p.conv_out]
     bns = [seq[1] for seq in p.convs]
     g, nconv, odim = convs[0].weight.shape[0], len(bns), p.conv_out.weight.shape[0]
     cfg = (idx.shape[-1], g, nconv, odim, bool(pooling), 0.05, float(bns[0].eps), float(bns[0].momentum),
-           [bn.running_mean for bn in bns], [bn.running_var for bn in bns], csr)
+           [bn.running_mean for bn in bns], [bn.running_var for bn in bns], csr, bool(persistent) and _PERSIST)
     out = EdgeConvUnitFn.apply(x, idx, cfg, *[c.weight for c in convs], *[c.bias for c in convs],
                                *[bn.weight for bn in bns], *[bn.bias for bn in bns])
     _count_batches(bns)
@@ -1608,7 +1646,9 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     cs: List[Tensor] = []
     h = xyz
     for i in range(net.num_blocks):
-        h = edgeconv_train(net.feat_convs[i], h, idx16, csr=csr16)
+        # the main chain's units may run as persistent grid-barrier launches: nothing else with a grid barrier runs beside them
+        # (the side stream's interpolation unit keeps the per-layer kernels; the EMD auction starts after the forward)
+        h = edgeconv_train(net.feat_convs[i], h, idx16, csr=csr16, persistent=getattr(net, "train_persistent", True))
         m = net.merge_convs[i]
         if _FUSED:
             cs.append(mlp_fused(None, h, 0, 1, (0.0,), [m.conv1, m.conv2]).view(B, N, -1))

@@ -28,8 +28,10 @@ except Exception:                        # pragma: no cover - not installed in t
 def default_cfg(**kw):
     # sync_batchnorm: BatchNorm statistics over ALL ranks (an extension: the reference trains on one GPU, where it is
     # the same thing; default False = each rank normalises with its own shard, like DDP without SyncBatchNorm)
+    # persistent_kernels: the training step's grid-barrier kernels (EdgeConv units as one launch each).  None = on, unless
+    # emd_workgroups == 1 says the device is shared with other processes (grid barriers need every workgroup resident)
     cfg = dict(net="UpsamplingFlow", learning_rate=1e-3, sched_patience=10, sched_factor=0.5, seed=2021, sync_batchnorm=False,
-               fused_optimizer=True, emd_workgroups=0)
+               fused_optimizer=True, emd_workgroups=0, persistent_kernels=None)
     cfg.update(kw)
     return SimpleNamespace(**cfg)
 
@@ -44,6 +46,8 @@ class TrainerModule(_Base):
         self.loss_mix = loss_mix
         self.network = PointInterpFlow(pc_channel=3)
         self.network.sync_batchnorm = bool(getattr(self.cfg, "sync_batchnorm", False))     # an argument of its train-mode forward
+        pk = getattr(self.cfg, "persistent_kernels", None)
+        self.network.train_persistent = bool(pk) if pk is not None else int(getattr(self.cfg, "emd_workgroups", 0)) != 1
         # cfg.emd_workgroups: workgroups per sample of the EMD auction (0 = chosen from the device, 1 = safe on a GPU that is
         # shared with other processes: no inter-workgroup waits; csrc/emd.hip)
         self.emd_loss = EarthMoverDistance(groups=int(getattr(self.cfg, "emd_workgroups", 0)))
@@ -205,7 +209,9 @@ class TrainerModule(_Base):
         number of NaN losses a CAPTURED step replaced by the reference's constant 0.1 (train_pu1k.py:71-73) is returned (and
         printed, like the reference's `loss is nan`)."""
         from .loss import check_emd_status
+        from .train_ops import check_persist_status
         check_emd_status(next(self.parameters()).device)
+        check_persist_status(next(self.parameters()).device)
         opt = getattr(self, "_fused_opt", None)
         if opt is not None:
             k = opt.skipped_updates()

@@ -381,3 +381,60 @@ def test_fused_batchnorm_statistics_with_a_large_mean():
     assert float(((v_f.double() - want).abs() / want).max()) < 1e-5
     assert float(((v_u.double() - want).abs() / want).max()) < 1e-5
     assert float((o_f - o_u).abs().max()) < 2e-4 * float(o_u.abs().max())
+
+
+@pytest.mark.parametrize("cin,odim,growth,B,N", [
+    (3, 32, 8, 32, 256), (32, 64, 16, 32, 256), (128, 128, 32, 32, 256), (64, 128, 32, 4, 256),
+    (128, 128, 32, 3, 100),                      # 300 tiles: waves without a tile, workgroups with a partial round
+    (3, 32, 8, 1, 64), (32, 64, 16, 7, 256)])
+def test_edgeconv_unit_persistent_forward_matches_the_per_layer_kernels(cin, odim, growth, B, N):
+    """The unit's forward as ONE persistent launch with a grid barrier per BatchNorm layer (ec_fwdp_kernel) against the
+    per-layer kernels: the stored pre-BatchNorm tensor is bit-identical (same products in the same order), the statistics
+    agree to summation order, the pooled output to the split-fp16 conv_out's operand order, and the backward - which reads what
+    the forward stored (Y, aff, argmax) - gives the same gradients.  The barrier words are left zero, the status word clean."""
+    from puflow_amd import ops, train_ops
+    from puflow_amd.weights import synth_patches
+    xyz = synth_patches(B, N, seed=9).cuda()
+    idx, _ = ops.knn_idx32(xyz, xyz, 16)
+    torch.manual_seed(cin + growth + B)
+    x = (xyz if cin == 3 else torch.randn(B, N, cin, device="cuda"))
+    p = _unit(cin, odim, growth, seed=B)
+    wout = torch.randn(B * N, odim, device="cuda")
+    wout, _ = _mask_ambiguous_pools(p, x, idx, wout, 16)
+    csr = train_ops.knn_csr(idx)
+
+    def run(persistent):
+        for q in p.parameters():
+            q.grad = None
+        for seq in p.convs:
+            seq[1].running_mean.zero_(); seq[1].running_var.fill_(1.0)
+        xx = x.clone().requires_grad_(True)
+        out = train_ops.edgeconv_train_fused(p, xx, idx, True, csr, persistent)
+        saved = out.grad_fn.saved_tensors                              # x, idx, Wpq, PQ, Y, aff, arg, ...
+        Y, aff, arg = saved[4].clone(), saved[5].clone(), saved[6].clone()
+        (out * wout.view_as(out)).sum().backward()
+        grads = {n: q.grad.detach().clone() for n, q in p.named_parameters()}
+        stats = [(seq[1].running_mean.clone(), seq[1].running_var.clone()) for seq in p.convs]
+        return out.detach().clone(), xx.grad.detach().clone(), grads, stats, Y, aff, arg
+
+    assert train_ops._PERSIST
+    o_p, dx_p, g_p, st_p, Y_p, aff_p, arg_p = run(True)
+    sync = train_ops._sync_words(xyz.device)
+    assert sync.tolist() == [0, 0, 0, 0]                               # barrier words back to zero, no timeout
+    o_l, dx_l, g_l, st_l, Y_l, aff_l, arg_l = run(False)
+    g = growth
+    assert torch.equal(Y_p[:, :g], Y_l[:, :g])                         # layer 0: P[i] + Q[j], no statistics involved yet
+    _close(Y_p, Y_l, "Y", 2e-6)
+    _close(aff_p, aff_l, "aff", 2e-6)
+    _close(o_p, o_l, "out", 2e-6)
+    same = (arg_p == arg_l) | (wout.view(-1, odim) == 0)
+    assert bool(same.all()), int((~same).sum())
+    _close(dx_p, dx_l, "dx", 2e-5)
+    for n in g_l:
+        if ".0.bias" in n:                                             # a conv bias in front of BatchNorm: zero gradient, rounding residue
+            continue
+        _close(g_p[n], g_l[n], n, 2e-4)
+    for (m_p, v_p), (m_l, v_l) in zip(st_p, st_l):
+        _close(m_p, m_l, "running_mean", 1e-5)
+        _close(v_p, v_l, "running_var", 1e-5)
+    train_ops.check_persist_status()
