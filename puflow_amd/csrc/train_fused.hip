@@ -673,6 +673,10 @@ __global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
             unsafeAtomicAdd(a.acc + (blockIdx.x % STAT_COPIES) * 2 * STAT_W + (threadIdx.x >> 5) * STAT_W + 32 * t + (threadIdx.x & 31), (double)v);
         }
         if constexpr (OWN && t + 1 < NC) addends(std::integral_constant<int, t + 1>{});      // next layer's gathers fly during the barrier
+        // the pivot of the column this thread finalises below, read BEFORE the barrier: workgroup 0 updates the running mean right
+        // after it (every workgroup has arrived, i.e. has read its pivots, by then)
+        const int fc = threadIdx.x >> 3;
+        const float fpv = (a.run_mean[t] && threadIdx.x < 256 && fc < G) ? a.run_mean[t][fc] : 0.f;
         alive = ecp_barrier(a.sync, (unsigned)(t + 1), &flag);
         if (!alive) return;
         // ---- every workgroup turns the sums into the layer's constants for itself (the StatFin mode-1 arithmetic); workgroup 0
@@ -694,7 +698,7 @@ __global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
         if (threadIdx.x < 256 && (threadIdx.x & 7) == 0 && (threadIdx.x >> 3) < G) {
             const int c = threadIdx.x >> 3;
             const double a0 = part, a1 = other;
-            const double pv = a.run_mean[t] ? (double)a.run_mean[t][c] : 0.0;
+            const double pv = (double)fpv;
             const double dm = a0 / a.R;
             const double mean = pv + dm;
             double var = a1 / a.R - dm * dm;
