@@ -1356,6 +1356,275 @@ __global__ __launch_bounds__(256) void ec_bwdg16_kernel(EcBwdgArgs a) {
     stat_flush<NTG>(s0, s1, 0, g, a.fin, red);
 }
 
+// ------------------------------------------------------------------------------------------------ backward of the dense block in ONE launch
+// The gather-form backward above is one launch per growth layer (+ ec_bwd0_kernel): layer s reads conv_out's gradient and the dy
+// of EVERY later layer from memory again, and each launch ends in the BatchNorm-backward sums of its layer.  Same construction
+// as ec_fwdp_kernel: a persistent grid (one workgroup per CU, 8 waves, a wave owns up to ECP_TPW tiles for the whole launch) keeps
+// the tile's dy of the layers done so far in registers and meets at a grid barrier once per layer:
+//   layer s = NC-1 .. 0:  G_s = dYout Wout[:, cols_s] + sum_{t > s} dy_t W_t[:, cols_s]   (channel-major: the columns of layer s on
+//                          the MFMA rows, edges on the columns - a dy tile is the B operand of every earlier layer as it stands;
+//                          split-bf16 products like ec_bwdg16_kernel: x = hi + mid, three v_mfma_f32_16x16x32_bf16 per 32
+//                          channels; the weights are split once per workgroup into A fragments in LDS; dYout is formed from
+//                          (dh, argmax) on load)
+//                        dz = G_s lrelu'(bn(y_s));  sums of dz and dz xhat -> barrier -> dy_s = scale (dz - m1 - xhat m2), kept in
+//                          registers for the layers below and stored ONCE to dA (the weight-gradient and dPQ kernels read it).
+// dA ends up exactly as ec_bwd0_kernel leaves it; coef / dgamma / dbeta are written by workgroup 0.
+struct EcBwdPArgs {
+    const float* dh; const unsigned char* arg;       // [T, ODIM]
+    float* dA; const float* Y; int ld;               // [E, GT]
+    const float* aff; float* coef;                   // [4][GT], [2][GT]
+    const float* Wout; int ldwout;
+    const float* Wg[8]; int ldwg[8];
+    float* dgamma[8]; float* dbeta[8];
+    int ntiles;
+    float slope; double R;
+    double* acc; unsigned* sync;
+};
+
+template <int G, int NC, int ODIM>
+__global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
+    constexpr int GT = G * NC, NB = GT / 16, NTG = (G + 15) / 16, NCO = ODIM / 32, NCP = GT / 32;
+    constexpr bool OWN = G % 16 == 0;
+    static_assert(GT % 32 == 0 && ODIM % 32 == 0 && 32 * NC <= STAT_W && G <= 32, "shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[ECP_WAVES * 2 * 32];
+    __shared__ float m12[2 * 32];
+    __shared__ float bnc2[2][4 * 32];     // double-buffered by layer parity: a wave may enter the next layer while another still reads
+    __shared__ int flag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+    // ---- A fragments (split-bf16, [hi | mid][lane] x 16 B): first conv_out's, one per (16-column block b of the growth
+    // channels, 32-channel chunk co of odim) - Wout[c][16 b + row] - then per layer s its dy chunks cp >= cpmin(s) (32 growth
+    // channels each: rows of the LATER layers' convs, zero for channels of layers <= s): frag fbase(s) + nt * ndy(s) + (cp - cpmin(s))
+    auto cpmin = [](int s) { return (G * (s + 1)) / 32; };
+    auto ndy = [&](int s) { return NCP - cpmin(s); };
+    int fbase[NC + 1];
+    fbase[0] = NB * NCO;
+#pragma unroll
+    for (int s = 0; s < NC; ++s) fbase[s + 1] = fbase[s] + NTG * ndy(s);
+    uint4* Wf = reinterpret_cast<uint4*>(lds);
+    {
+        const int nunit = fbase[NC] * 64;
+        constexpr int MAXU = ((NB * NCO + NTG * NC * NCP) * 64 + ECP_T - 1) / ECP_T;
+        float v[MAXU][8];
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) {
+            const int unit = threadIdx.x + k * ECP_T, uu = unit < nunit ? unit : 0;
+            const int frag = uu >> 6, ln = uu & 63, row = ln & 15, kq = ln >> 4;
+            if (frag < NB * NCO) {
+                const int b = frag / NCO, co = frag % NCO, ug = 16 * b + row;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[k][j] = a.Wout[(size_t)(32 * co + (j < 4 ? 0 : 16) + 4 * kq + (j & 3)) * a.ldwout + ug];
+            } else {
+                int s = 0;
+#pragma unroll
+                for (int t = 1; t < NC; ++t) s = frag >= fbase[t] ? t : s;
+                const int fr = frag - fbase[s], nd = ndy(s) > 0 ? ndy(s) : 1, nt = fr / nd, cp = cpmin(s) + fr % nd;
+                const int b0 = (G * s) / 16, ug = 16 * (b0 + nt) + row;             // growth column of this output row
+                const bool rowok = ug >= G * s && ug < G * (s + 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 32 * cp + (j < 4 ? 0 : 16) + 4 * kq + (j & 3), t = c / G;
+                    v[k][j] = (rowok && t > s) ? a.Wg[t][(size_t)(c - G * t) * a.ldwg[t] + ug] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) {
+            const int unit = threadIdx.x + k * ECP_T;
+            if (unit < nunit) {
+                const GBf2 f2 = g_split(v[k]);
+                Wf[((unit >> 6) * 2 + 0) * 64 + (unit & 63)] = __builtin_bit_cast(uint4, f2.hi);
+                Wf[((unit >> 6) * 2 + 1) * 64 + (unit & 63)] = __builtin_bit_cast(uint4, f2.mid);
+            }
+        }
+    }
+    // ---- this wave's tiles
+    int tl[ECP_TPW];
+    bool ok[ECP_TPW];
+#pragma unroll
+    for (int s = 0; s < ECP_TPW; ++s) {
+        tl[s] = blockIdx.x * ECP_WAVES + wave + s * gridDim.x * ECP_WAVES;
+        ok[s] = tl[s] < a.ntiles;
+        tl[s] = ok[s] ? tl[s] : 0;
+    }
+    f4 dy[ECP_TPW][NB];
+#pragma unroll
+    for (int s = 0; s < ECP_TPW; ++s)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) dy[s][b] = pf_splat(0.f);
+    __syncthreads();
+    auto mma = [&](int frag, const GBf2& B, f4& acc) {
+        const gbf8 wh = __builtin_bit_cast(gbf8, Wf[(frag * 2 + 0) * 64 + lane]);
+        const gbf8 wm = __builtin_bit_cast(gbf8, Wf[(frag * 2 + 1) * 64 + lane]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, B.hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, B.mid, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, B.hi, acc, 0, 0, 0);
+    };
+
+    // ---- conv_out's contribution to EVERY layer in one pass: dy[.][b] = Wout[:, 16 b ..]^T dYout, dYout formed from (dh, argmax)
+    // and split once per (tile, chunk) - this lane's 8 channels of a 32-channel chunk, edge = col.  Layer s adds the later
+    // layers' part into its own slots below.
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) {
+#pragma unroll
+        for (int t = 0; t < ECP_TPW; ++t) {
+            const float* dp = a.dh + (size_t)tl[t] * ODIM + 32 * co + 4 * q;
+            const unsigned char* ap = a.arg + (size_t)tl[t] * ODIM + 32 * co + 4 * q;
+            const f4 d0 = *reinterpret_cast<const f4*>(dp), d1 = *reinterpret_cast<const f4*>(dp + 16);
+            const unsigned g0 = *reinterpret_cast<const unsigned*>(ap), g1 = *reinterpret_cast<const unsigned*>(ap + 16);
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[j] = (int)((g0 >> (8 * j)) & 255u) == col ? d0[j] : 0.f;
+                x[4 + j] = (int)((g1 >> (8 * j)) & 255u) == col ? d1[j] : 0.f;
+            }
+            const GBf2 B = g_split(x);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) mma(b * NCO + co, B, dy[t][b]);
+        }
+    }
+
+    bool alive = true;
+    pf_static_for<0, NC>([&](auto sc_) {
+        constexpr int s = NC - 1 - decltype(sc_)::value;             // layers last to first
+        constexpr int col0 = G * s, b0 = col0 / 16, CP0 = (G * (s + 1)) / 32, NDY = NCP - CP0;
+        if (!alive) return;
+        const int fb = fbase[s];
+        // the layer's BatchNorm constants (scale, shift, mean, 1/std) as f4 rows in LDS: read when needed, not held in registers
+        float* bnc = bnc2[s & 1];
+        if (threadIdx.x < 4 * 32) {
+            const int w = threadIdx.x >> 5, c = threadIdx.x & 31;
+            bnc[w * 32 + c] = c < G ? a.aff[w * a.ld + col0 + c] : 0.f;
+        }
+        bool cv[NTG];
+        f4 yv[ECP_TPW][NTG], accs[OWN ? 1 : ECP_TPW][NTG];
+        auto A = [&](int t, int nt) -> f4& {
+            if constexpr (OWN) return dy[t][b0 + nt];                // the layer's own slots hold conv_out's part already
+            else return accs[t][nt];
+        };
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt) {
+            const int c4 = 16 * (b0 + nt) + 4 * q;
+            cv[nt] = c4 >= col0 && c4 < col0 + G;
+#pragma unroll
+            for (int t = 0; t < ECP_TPW; ++t) {
+                yv[t][nt] = pf_splat(0.f);
+                if (cv[nt] && ok[t]) yv[t][nt] = *reinterpret_cast<const f4*>(a.Y + ((size_t)tl[t] * 16 + col) * a.ld + c4);
+                if constexpr (!OWN) accs[t][nt] = cv[nt] ? dy[t][b0 + nt] : pf_splat(0.f);   // rows of the layer that shares the block: not ours
+            }
+        }
+        // ---- the later layers' dy (registers)
+#pragma unroll
+        for (int cp = CP0; cp < NCP; ++cp) {
+#pragma unroll
+            for (int t = 0; t < ECP_TPW; ++t) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { x[j] = dy[t][2 * cp][j]; x[4 + j] = dy[t][2 * cp + 1][j]; }
+                const GBf2 B = g_split(x);
+#pragma unroll
+                for (int nt = 0; nt < NTG; ++nt) mma(fb + nt * NDY + cp - CP0, B, A(t, nt));
+            }
+        }
+        __syncthreads();                                              // bnc
+        // ---- dz (it replaces the raw gradient), its sums; xhat stays for the transform behind the barrier
+        f4 s0[NTG], s1[NTG], xh[ECP_TPW][NTG];
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt) {
+            s0[nt] = s1[nt] = pf_splat(0.f);
+            const int cl = cv[nt] ? 16 * (b0 + nt) + 4 * q - col0 : 0;
+            const f4 bsc = *reinterpret_cast<const f4*>(bnc + cl), bsh = *reinterpret_cast<const f4*>(bnc + 32 + cl);
+            const f4 bmu = *reinterpret_cast<const f4*>(bnc + 64 + cl), brs = *reinterpret_cast<const f4*>(bnc + 96 + cl);
+#pragma unroll
+            for (int t = 0; t < ECP_TPW; ++t) {
+                const f4 y = yv[t][nt], z = y * bsc + bsh;
+                xh[t][nt] = (y - bmu) * brs;
+                f4 dz;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz[r] = A(t, nt)[r] * (z[r] > 0.f ? 1.f : a.slope);
+                if (cv[nt]) {
+                    A(t, nt) = dz;
+                    if (ok[t]) { s0[nt] = s0[nt] + dz; s1[nt] = s1[nt] + dz * xh[t][nt]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a0 = ecp_rowsum16(s0[nt][r]), a1 = ecp_rowsum16(s1[nt][r]);
+                const int c = 16 * (b0 + nt) + 4 * q + r - col0;
+                if (col == 0 && c >= 0 && c < G) { red[wave * 64 + c] = a0; red[wave * 64 + 32 + c] = a1; }
+            }
+        __syncthreads();
+        if (threadIdx.x < 64 && (threadIdx.x & 31) < G) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < ECP_WAVES; ++w) v += red[w * 64 + threadIdx.x];
+            unsafeAtomicAdd(a.acc + (blockIdx.x % STAT_COPIES) * 2 * STAT_W + (threadIdx.x >> 5) * STAT_W + 32 * s + (threadIdx.x & 31), (double)v);
+        }
+        alive = ecp_barrier(a.sync, (unsigned)(NC - s), &flag);
+        if (!alive) return;
+        double part = 0.0;
+        if (threadIdx.x < 256) {
+            const int pt = threadIdx.x & 3, stt = (threadIdx.x >> 2) & 1, c = threadIdx.x >> 3;
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                v[k] = __hip_atomic_load(a.acc + (4 * pt + k) * 2 * STAT_W + stt * STAT_W + 32 * s + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            part = (v[0] + v[1]) + (v[2] + v[3]);
+            part += __shfl_xor(part, 1);
+            part += __shfl_xor(part, 2);
+        }
+        const double other = __shfl_xor(part, 4);
+        if (threadIdx.x < 256 && (threadIdx.x & 7) == 0 && (threadIdx.x >> 3) < G) {
+            const int c = threadIdx.x >> 3;
+            m12[c] = (float)(part / a.R);
+            m12[32 + c] = (float)(other / a.R);
+            if (blockIdx.x == 0) {                                    // the StatFin mode-2 outputs
+                a.coef[col0 + c] = (float)(part / a.R);
+                a.coef[a.ld + col0 + c] = (float)(other / a.R);
+                a.dbeta[s][c] = (float)part;
+                a.dgamma[s][c] = (float)other;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NTG; ++nt) {
+            if (!cv[nt]) continue;
+            const int cl = 16 * (b0 + nt) + 4 * q - col0;
+            const f4 m1 = *reinterpret_cast<const f4*>(m12 + cl), m2 = *reinterpret_cast<const f4*>(m12 + 32 + cl);
+            const f4 bsc = *reinterpret_cast<const f4*>(bnc + cl);
+#pragma unroll
+            for (int t = 0; t < ECP_TPW; ++t) {
+                const f4 v = bsc * (A(t, nt) - m1 - xh[t][nt] * m2);
+                if (ok[t]) *reinterpret_cast<f4*>(a.dA + ((size_t)tl[t] * 16 + col) * a.ld + 16 * (b0 + nt) + 4 * q) = v;
+                dy[t][b0 + nt] = v;
+            }
+        }
+    });
+    if (!alive) {                                                     // loud: the layers that were not finished
+#pragma unroll
+        for (int t = 0; t < ECP_TPW; ++t)
+            if (ok[t])
+                for (int c = 4 * q; c < GT; c += 16)
+                    *reinterpret_cast<f4*>(a.dA + ((size_t)tl[t] * 16 + col) * a.ld + c) = pf_splat(__builtin_nanf(""));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) flag = atomicAdd(a.sync + 2, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (flag == 1) {
+        for (int i = threadIdx.x; i < STAT_COPIES * 2 * STAT_W; i += ECP_T)
+            if ((i % STAT_W) < 32 * NC) __hip_atomic_store(a.acc + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(a.sync + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // growth layer 0 has no growth input: only dA[:, 0:g] -> dy in place
 __global__ __launch_bounds__(256) void ec_bwd0_kernel(float* dA, const float* Y, int ld, const float* aff, const float* coef, int g,
                                                       long long E, float slope) {
@@ -2070,6 +2339,50 @@ bool ec_persistent_ok(const PfEcTrain* p, const Dims& d) {
     else if (p->growth == 32 && p->odim == 128) cap = ecp_capacity<32, 128>();
     return cap > 0 && (long long)d.ntiles <= (long long)cap * ECP_WAVES * ECP_TPW;
 }
+template <int G, int ODIM>
+size_t ecpb_lds_bytes() {
+    int nf = (G * 4 / 16) * (ODIM / 32);
+    for (int s = 0; s < 4; ++s) nf += ((G + 15) / 16) * (G * 4 / 32 - (G * (s + 1)) / 32);
+    return (size_t)nf * 2 * 64 * 16;
+}
+template <int G, int ODIM>
+bool ecpb_fits() {
+    const size_t lds = ecpb_lds_bytes<G, ODIM>();
+    allow_lds(ec_bwdp_kernel<G, 4, ODIM>, lds);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ec_bwdp_kernel<G, 4, ODIM>, ECP_T, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return per_cu >= 1;
+}
+bool ec_bwd_persistent_fits(const PfEcTrain* p) {
+    return p->growth == 8 ? ecpb_fits<8, 32>() : (p->growth == 16 ? ecpb_fits<16, 64>() : ecpb_fits<32, 128>());
+}
+int ecp_grid(const Dims& d) {
+    const int wgs = (d.ntiles + ECP_WAVES * ECP_TPW - 1) / (ECP_WAVES * ECP_TPW);     // fewest workgroups that hold every tile ...
+    int ncu = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int spread = (d.ntiles + ECP_WAVES - 1) / ECP_WAVES;                         // ... spread over the CUs when there are fewer tiles
+    return spread < ncu ? (spread > wgs ? spread : wgs) : (wgs > ncu ? wgs : ncu);
+}
+int ec_bwd_persistent(const PfEcTrain* p, const Dims& d, const EcConvs& cv, hipStream_t s) {
+    EcBwdPArgs a{};
+    a.dh = p->dout; a.arg = p->arg; a.dA = p->dA; a.Y = p->Y; a.ld = d.GT; a.aff = p->aff; a.coef = p->coef;
+    a.Wout = p->W[p->nconv] + 3 * p->C; a.ldwout = cv.width[p->nconv];
+    for (int t = 0; t < p->nconv; ++t) {
+        a.Wg[t] = p->W[t] + 3 * p->C; a.ldwg[t] = cv.width[t];
+        a.dgamma[t] = p->dgamma[t]; a.dbeta[t] = p->dbeta[t];
+    }
+    a.ntiles = d.ntiles; a.slope = p->slope; a.R = (double)d.E; a.acc = p->stat; a.sync = p->sync;
+    const int grid = ecp_grid(d);
+    const size_t l8 = ecpb_lds_bytes<8, 32>(), l16 = ecpb_lds_bytes<16, 64>(), l32 = ecpb_lds_bytes<32, 128>();
+    if (p->growth == 8) hipLaunchKernelGGL((ec_bwdp_kernel<8, 4, 32>), dim3(grid), dim3(ECP_T), l8, s, a);
+    else if (p->growth == 16) hipLaunchKernelGGL((ec_bwdp_kernel<16, 4, 64>), dim3(grid), dim3(ECP_T), l16, s, a);
+    else hipLaunchKernelGGL((ec_bwdp_kernel<32, 4, 128>), dim3(grid), dim3(ECP_T), l32, s, a);
+    return pf_last_launch_status();
+}
 int ec_fwd_persistent(const PfEcTrain* p, const Dims& d, const EcConvs& cv, hipStream_t s) {
     EcFwdPArgs a{};
     a.Y = p->Y; a.ldy = d.GT; a.aff = p->aff; a.pq = p->PQ; a.ldpq = 2 * d.S; a.S = d.S; a.idx = p->idx; a.N = p->N;
@@ -2080,12 +2393,7 @@ int ec_fwd_persistent(const PfEcTrain* p, const Dims& d, const EcConvs& cv, hipS
     }
     a.Wout = p->W[p->nconv] + 3 * p->C; a.ldwout = cv.width[p->nconv];
     a.eps = p->eps; a.momentum = p->momentum; a.R = (double)d.E; a.acc = p->stat; a.sync = p->sync;
-    const int wgs = (d.ntiles + ECP_WAVES * ECP_TPW - 1) / (ECP_WAVES * ECP_TPW);     // fewest workgroups that hold every tile ...
-    int ncu = 0, dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    const int spread = (d.ntiles + ECP_WAVES - 1) / ECP_WAVES;                         // ... spread over the CUs when there are fewer tiles
-    const int grid = spread < ncu ? (spread > wgs ? spread : wgs) : (wgs > ncu ? wgs : ncu);
+    const int grid = ecp_grid(d);
     const size_t l8 = ecp_lds_bytes<8, 32>(), l16 = ecp_lds_bytes<16, 64>(), l32 = ecp_lds_bytes<32, 128>();
     if (p->growth == 8) hipLaunchKernelGGL((ec_fwdp_kernel<8, 4, 32>), dim3(grid), dim3(ECP_T), l8, s, a);
     else if (p->growth == 16) hipLaunchKernelGGL((ec_fwdp_kernel<16, 4, 64>), dim3(grid), dim3(ECP_T), l16, s, a);
@@ -2205,8 +2513,13 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         hipLaunchKernelGGL(ec_zero_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<f4*>(p->dPQ), (long long)d.T * 2 * d.S / 4);
 
 #ifndef PF_EC_BWD_SCATTER
+    const bool persistent = ec_persistent_ok(p, d) && ec_bwd_persistent_fits(p);
+    if (persistent) {
+        st = ec_bwd_persistent(p, d, cv, s);
+        if (st) return st;
+    }
     // ---- gather form: layer s = nc - 1 .. 0 collects its own gradient columns from conv_out and the later growth convs
-    for (int sl = nc - 1; sl >= 0; --sl) {
+    for (int sl = nc - 1; sl >= 0 && !persistent; --sl) {
         EcBwdgArgs a{};
         a.dh = p->dout; a.arg = p->arg; a.dyout = p->dout; a.odim = p->odim;
         a.dA = p->dA; a.Y = p->Y; a.ld = d.GT; a.aff = p->aff; a.coef = p->coef;
@@ -2265,6 +2578,9 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         if (nt == 1) PF_ECB(1, 2); else if (nt == 2) PF_ECB(2, 2); else if (nt == 4) PF_ECB(4, 2); else PF_ECB(8, 2);
 #undef PF_ECB
     }
+#endif
+#ifndef PF_EC_BWD_SCATTER
+    if (!persistent)
 #endif
     {
         const long long n = d.E * (g / 4);

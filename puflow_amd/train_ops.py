@@ -774,6 +774,8 @@ class EdgeConvUnitFn(Function):
         csr = cfg[10] if len(cfg) > 10 else None
         if csr is not None:                                   # transposed neighbour lists: dQ as a gather, no float atomics
             d.csr_off, d.csr_edge = csr[0].data_ptr(), csr[1].data_ptr()
+        if len(cfg) > 11 and cfg[11]:                         # the dense block's backward as one persistent launch (see forward)
+            d.flags, d.sync = 1, _sync_words(dev).data_ptr()
         _lib.check(lib.pf_ec_train_bwd(ctypes.byref(d), _stream()), "pf_ec_train_bwd")
         return (dx, None, None, *dWs, *dbs, *dgs, *dbe)
 
