@@ -215,7 +215,8 @@ struct EmdCoopArgs {
     float* dist; int* assignment; int* assignment_inv; float* price;
     unsigned* mb0; unsigned* mb1; int* mi0; int* mi1;     // [B,n] each: maximum increment bits / winner index, per parity
     unsigned long long* k0; unsigned long long* k1;        // KEY64: [B,n] (increment bits << 32 | bidder) per parity, instead
-    unsigned* sync;                                        // [B,n] zeroed by the host: [0] arrivals, [1],[2] unassigned count per parity
+    unsigned* sync;                                        // [B,n] zeroed by the host: words [0..1] = one 64-bit barrier word per sample
+                                                           // (arrivals | running total of unassigned points << 32)
     unsigned* status;                                      // nullable: [0] += 1 for every WORKGROUP whose grid barrier timed out
     int n, iters, G;
     float eps;
@@ -244,16 +245,23 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
     const int i0 = (int)((long long)w * n / G), i1 = (int)((long long)(w + 1) * n / G);
     unsigned nb = 0;
     if (tid == 0) dead = 0;
-    auto barrier = [&]() {
+    // The barrier word is 64 bits: arrivals in the low half, the running total of unassigned points in the high half - a
+    // workgroup adds (its count << 32 | 1) in ONE atomic, and the poll that sees every arrival has the sample's total with it
+    // (a separate counter cost one more dependent memory round trip per iteration; a round trip is ~1.2 us, an iteration ~17).
+    unsigned long long* cnt64 = reinterpret_cast<unsigned long long*>(cnt);
+    __shared__ unsigned utot;
+    auto barrier = [&](unsigned add_u) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         ++nb;
         if (tid == 0) {
-            atomicAdd(cnt, 1u);
+            atomicAdd(cnt64, ((unsigned long long)add_u << 32) | 1ull);
             const unsigned target = nb * (unsigned)G;
             int budget = 1 << 18;                       // ~0.2 s: a barrier normally completes in microseconds
-            while (ald(cnt) < target && --budget > 0) __builtin_amdgcn_s_sleep(2);
+            unsigned long long w = ald(cnt64);
+            while ((unsigned)w < target && --budget > 0) { __builtin_amdgcn_s_sleep(2); w = ald(cnt64); }
             if (budget <= 0) dead = 1;
+            utot = (unsigned)(w >> 32);
         }
         __syncthreads();
     };
@@ -262,8 +270,9 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
         if (KEY64) { ast(a.k0 + o0 + i, 0ull); ast(a.k1 + o0 + i, 0ull); }
         else { ast(a.mb0 + o0 + i, 0u); ast(a.mb1 + o0 + i, 0u); ast(a.mi0 + o0 + i, -1); ast(a.mi1 + o0 + i, -1); }
     }
-    barrier();
+    barrier(0u);
     int pU = 0;
+    unsigned uprev = 0;
     for (int it = 0; it < a.iters && !dead; ++it) {
         const bool last = it == a.iters - 1;
         const int par = it & 1;
@@ -273,14 +282,16 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
         int* mio = KEY64 ? nullptr : (par ? a.mi0 : a.mi1) + o0;
         unsigned long long* key = KEY64 ? (par ? a.k1 : a.k0) + o0 : nullptr;
         unsigned long long* keyo = KEY64 ? (par ? a.k0 : a.k1) + o0 : nullptr;
+        // the slice's assignments are fetched together with the prices (one memory round trip, not two)
+        const int as0 = i0 + tid < i1 ? ald(assignment + i0 + tid) : 0;
         for (int i = tid; i < n; i += EMD_THREADS) sprice[i] = ald(price + i);
         if (tid == 0) ucount = 0;
         __syncthreads();
-        for (int i = i0 + tid; i < i1; i += EMD_THREADS)
+        if (i0 + tid < i1 && as0 == -1) ulist[atomicAdd(&ucount, 1)] = i0 + tid;
+        for (int i = i0 + tid + EMD_THREADS; i < i1; i += EMD_THREADS)
             if (ald(assignment + i) == -1) ulist[atomicAdd(&ucount, 1)] = i;
         __syncthreads();
         const int U = ucount;
-        if (tid == 0 && U > 0) atomicAdd(cnt + 1 + par, (unsigned)U);
         // ---- bid: one wave per unassigned point of this workgroup's slice
         for (int u = wave; u < U; u += EMD_THREADS / 64) {
             const int i = ulist[u];
@@ -307,15 +318,17 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
                 else atomicMax(mb + tidx, __float_as_uint(inc));
             }
         }
-        barrier();
-        if (ald(cnt + 1 + par) == 0u) break;                     // nothing left to assign in the whole sample (uniform)
+        barrier((unsigned)U);
+        const unsigned ucur = utot;                              // every workgroup reads the same total: its poll saw all arrivals
+        if (ucur == uprev) break;                                // nothing left to assign in the whole sample (uniform)
+        uprev = ucur;
         if (!KEY64) {
             // ---- winner of each object: largest index among the bidders holding the exact maximum increment
             for (int u = tid; u < U; u += EMD_THREADS) {
                 const int o = sbid[u];
                 if (__float_as_uint(sinc[u]) == ald(mb + o)) atomicMax(mi + o, ulist[u]);
             }
-            barrier();
+            barrier(0u);
         }
         // ---- assign; clear the OTHER parity's entries this workgroup wrote in the previous iteration
         for (int u = tid; u < U; u += EMD_THREADS) {
@@ -335,10 +348,9 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
             if (KEY64) ast(keyo + pbid[u], 0ull);
             else { ast(mbo + pbid[u], 0u); ast(mio + pbid[u], -1); }
         }
-        if (w == 0 && tid == 0) ast(cnt + 1 + (1 - par), 0u);
         for (int u = tid; u < U; u += EMD_THREADS) pbid[u] = sbid[u];
         pU = U;
-        barrier();
+        barrier(0u);
     }
     // ---- squared distance to the assigned ground-truth point (cu:217-226)
     for (int i = i0 + tid; i < i1; i += EMD_THREADS) {
@@ -404,7 +416,7 @@ extern "C" int pf_emd_forward_ex(const float* xyz1, const float* xyz2, float* di
     const bool pair1 = bid == max_idx + bn && (reinterpret_cast<size_t>(max_idx) & 7) == 0;
     const bool key64 = pair0 && pair1;
     int G = 1;
-    if (groups != 1 && n <= EMDC_NMAX) {
+    if (groups != 1 && n <= EMDC_NMAX && (n & 1) == 0 && (reinterpret_cast<size_t>(unass_idx) & 7) == 0) {   // 64-bit barrier word per sample
         int ncu = 0, dev = 0, per_cu = 0;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         const hipError_t oc = key64
