@@ -197,7 +197,7 @@ class _CnfEngine:
                                         self._stream()), "pf_cnf_init")
 
         # ---- adaptive steps: ONE launch per attempt (six fused stage evaluations) + a one-wave controller kernel; the
-        # accept / reject / next-dt decisions are taken on the device (csrc/cnf.hip: cnf_ctl_kernel), the host enqueues a batch
+        # accept / reject / next-dt decisions are taken on the device (csrc/cnf.hip: cnf_ctl_update, run by the workgroup of a step attempt that finishes last), the host enqueues a batch
         # of attempts and reads the controller state once per batch (attempts past the end of the integration are no-ops)
         out = torch.empty_like(y)
         f0, f1 = K[0], K[6]

@@ -15,7 +15,7 @@
 // Weight record of one block (floats; packing.pack_cnf_record), resident in LDS:
 //   [0,4096)      f16x2 image of W2          [4096,8192)  f16x2 image of W2^T
 //   [8192,9216)   f16x2 image of W3 (3 rows replicated into every 4-row q group)
-//   [9216,9472)   W1  [64][4] (3 used)       [9472,9728)  W3^T [64][4] (3 used)
+//   [9216,9472)   [W1 | b1]  [64][4]         [9472,9728)  W3^T [64][4] (3 used, 4th zero)
 //   [9728,9792) b1   [9792,9856) b2   [9856,9872) b3 (replicated)   [9872,10160) time coefficients, ctx layout
 // ctx layout (per point, 288 floats): gate1[64] bias1[64] gate2[64] bias2[64] gate3[16, replicated] bias3[16, replicated]
 #include <hip/hip_runtime.h>
@@ -29,7 +29,8 @@ constexpr int CNF_CTX = 288;
 constexpr int CNF_NW = 4;                 // waves per workgroup
 
 constexpr int CTL_T = 0, CTL_DT = 1, CTL_T1 = 2, CTL_NTOT = 3, CTL_CUR = 4, CTL_DONE = 5, CTL_ACC = 6, CTL_REJ = 7, CTL_NFE = 8,
-              CTL_STATUS = 9, CTL_REV = 10, CTL_H0 = 11, CTL_D1 = 12;   // device-side dopri5 state, see cnf_ctl_kernel
+              CTL_STATUS = 9, CTL_REV = 10, CTL_H0 = 11, CTL_D1 = 12,    // device-side dopri5 state, see cnf_ctl_update
+              CTL_ARRIVE = 13;                                           // (as a 32-bit word) workgroups of the running attempt that are done
 
 struct CnfArgs {
     const float* y0;        // [rows,4] state at the start of the step
@@ -64,18 +65,21 @@ __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, floa
                                        float e0, float e1, float e2) {
     const float* rec = w.rec;
     const float* tv = rec + 9872;
-    // ---- layer 1 (3 -> 64): this lane's channels 16 cb + 4 q + r
+    const int col = threadIdx.x & 15;
+    // ---- layer 1 (3 -> 64): this lane's channels 16 cb + 4 q + r.  W1 y + b1 is ONE v_mfma_f32_16x16x4_f32 per 16 channels
+    // ([W1 | b1] x [y; 1]: k = 3 carries the bias) instead of 16 x (an LDS row + 3 fmas) on a VALU that PMC shows ~90 % busy
+    // (profiles/r4_cnf/: 50 M VALU wave-instructions per step launch on 1024 SIMDs)
+    const float yb = q == 0 ? y.x : (q == 1 ? y.y : (q == 2 ? y.z : 1.f));
     f4 h1[1][4], g1[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         const int ch = cb * 16 + 4 * q;
         const f4 gc = *reinterpret_cast<const f4*>(cx + ch), bc = *reinterpret_cast<const f4*>(cx + 64 + ch);
         const f4 gt = *reinterpret_cast<const f4*>(tv + ch), bt = *reinterpret_cast<const f4*>(tv + 64 + ch);
-        const f4 b1 = *reinterpret_cast<const f4*>(rec + 9728 + ch);
+        const f4 lin4 = pf_mfma(rec[9216 + (cb * 16 + col) * 4 + q], yb, pf_splat(0.f));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f4 wr = *reinterpret_cast<const f4*>(rec + 9216 + (ch + r) * 4);
-            const float lin = fmaf(wr.z, y.z, fmaf(wr.y, y.y, fmaf(wr.x, y.x, b1[r])));
+            const float lin = lin4[r];
             const float gate = sigm(fmaf(gt[r], t, gc[r]));
             g1[cb][r] = gate;
             h1[0][cb][r] = tanh_fast(fmaf(lin, gate, fmaf(bt[r], t, bc[r])));
@@ -123,16 +127,17 @@ __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, floa
     }
     // ---- Hutchinson term e^T J e by the vector-Jacobian product of e through the three layers
     const float v0 = e0 * g3.x, v1 = e1 * g3.y, v2 = e2 * g3.z;
+    const float vb = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : 0.f));       // W3^T v as one f32 MFMA per 16 channels, like layer 1
     f4 w2v[1][4];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < 4; ++cb) {
+        const f4 u4 = pf_mfma(rec[9472 + (cb * 16 + col) * 4 + q], vb, pf_splat(0.f));               // W3[:, ch] (4th column zero)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f4 wr = *reinterpret_cast<const f4*>(rec + 9472 + (cb * 16 + 4 * q + r) * 4);      // W3[:, ch]
-            const float u = fmaf(wr.z, v2, fmaf(wr.y, v1, wr.x * v0));
             const float hh = h2[0][cb][r];
-            w2v[0][cb][r] = u * (1.f - hh * hh) * g2[cb][r];
+            w2v[0][cb][r] = u4[r] * (1.f - hh * hh) * g2[cb][r];
         }
+    }
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
     {
         PfPair2 wp[1][2];
@@ -298,6 +303,42 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_kernel(CnfStepArgs a) {
 // The step that covers t1 writes the dense-output value at t1 (quartic through y0, y_mid, y1: torchdiffeq's interpolation)
 // straight into `out`; if that attempt is rejected a later covering attempt overwrites it.
 
+// one wave (lane 0 decides): torchdiffeq's `_adaptive_step` decisions on the error norm of the attempt just made.  Called by
+// the first wave of the workgroup of cnf_step_dev_kernel that finishes LAST (every partial sum is in place by then).
+__device__ __forceinline__ void cnf_ctl_update(double* ctl, const double* partial, int nblocks) {
+    double sum = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 64)                          // fixed order: deterministic
+        sum += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
+    if (threadIdx.x != 0) return;
+    const double ratio = sqrt(sum / ctl[CTL_NTOT]);
+    const double t = ctl[CTL_T], dt = ctl[CTL_DT], t1 = ctl[CTL_T1];
+    ctl[CTL_NFE] += 6.0;
+    if (!(ratio == ratio) || ratio > 1.7e308) { ctl[CTL_STATUS] = 1.0; ctl[CTL_DONE] = 1.0; return; }
+    if (!(t + dt > t)) { ctl[CTL_STATUS] = 2.0; ctl[CTL_DONE] = 1.0; return; }
+    double tn = t;
+    if (ratio <= 1.0) {
+        ctl[CTL_ACC] += 1.0;
+        tn = t + dt;
+        ctl[CTL_T] = tn;
+        ctl[CTL_CUR] = 1.0 - ctl[CTL_CUR];                       // accepted state; FSAL: f1 becomes the next f0
+    } else {
+        ctl[CTL_REJ] += 1.0;
+    }
+    double ndt;
+    if (ratio == 0.0) ndt = dt * 10.0;
+    else {
+        const double dfac = ratio < 1.0 ? 1.0 : 0.2;
+        double fac = 0.9 / pow(ratio, 1.0 / 5.0);
+        fac = fac > dfac ? fac : dfac;
+        fac = fac < 10.0 ? fac : 10.0;
+        ndt = dt * fac;
+    }
+    ctl[CTL_DT] = ndt;
+    if (!(t1 > tn)) ctl[CTL_DONE] = 1.0;
+}
+
 struct CnfDevArgs {
     double* ctl;
     float* yb[2];
@@ -413,46 +454,21 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_dev_kernel(CnfDevArgs a)
     for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
     if (lane == 0) red[wave] = acc;
     __syncthreads();
+    // ---- this workgroup's share of the error sum; the workgroup that finishes LAST takes the controller's decision (it was a
+    // one-wave launch of its own behind every attempt: ~100 launches of 5 - 7 us per forward).  Every workgroup has read the
+    // controller state at its start, before the last one can have arrived here.
+    __shared__ int last;
     if (threadIdx.x == 0) {
         double tt = 0.0;
         for (int i = 0; i < CNF_NW; ++i) tt += red[i];
-        a.partial[blockIdx.x] = tt;
+        __hip_atomic_store(a.partial + blockIdx.x, tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* counter = reinterpret_cast<unsigned*>(a.ctl + CTL_ARRIVE);
+        last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1 : 0;
+        if (last) *counter = 0u;
     }
-}
-
-// one wave (lane 0 decides): torchdiffeq's `_adaptive_step` decisions on the error norm of the attempt just made
-__global__ void cnf_ctl_kernel(double* ctl, const double* partial, int nblocks) {
-    if (blockIdx.x != 0 || threadIdx.x >= 64 || ctl[CTL_DONE] != 0.0) return;
-    double sum = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 64) sum += partial[i];       // fixed order: deterministic
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
-    if (threadIdx.x != 0) return;
-    const double ratio = sqrt(sum / ctl[CTL_NTOT]);
-    const double t = ctl[CTL_T], dt = ctl[CTL_DT], t1 = ctl[CTL_T1];
-    ctl[CTL_NFE] += 6.0;
-    if (!(ratio == ratio) || ratio > 1.7e308) { ctl[CTL_STATUS] = 1.0; ctl[CTL_DONE] = 1.0; return; }
-    if (!(t + dt > t)) { ctl[CTL_STATUS] = 2.0; ctl[CTL_DONE] = 1.0; return; }
-    double tn = t;
-    if (ratio <= 1.0) {
-        ctl[CTL_ACC] += 1.0;
-        tn = t + dt;
-        ctl[CTL_T] = tn;
-        ctl[CTL_CUR] = 1.0 - ctl[CTL_CUR];                       // accepted state; FSAL: f1 becomes the next f0
-    } else {
-        ctl[CTL_REJ] += 1.0;
-    }
-    double ndt;
-    if (ratio == 0.0) ndt = dt * 10.0;
-    else {
-        const double dfac = ratio < 1.0 ? 1.0 : 0.2;
-        double fac = 0.9 / pow(ratio, 1.0 / 5.0);
-        fac = fac > dfac ? fac : dfac;
-        fac = fac < 10.0 ? fac : 10.0;
-        ndt = dt * fac;
-    }
-    ctl[CTL_DT] = ndt;
-    if (!(t1 > tn)) ctl[CTL_DONE] = 1.0;
+    __syncthreads();
+    if (last && threadIdx.x < 64) cnf_ctl_update(a.ctl, a.partial, (int)gridDim.x);
 }
 
 // torchdiffeq's `_select_initial_step` (oracle/cnf_ref.py::dopri5, first lines) in two one-thread kernels around the
@@ -621,8 +637,8 @@ extern "C" int pf_cnf_step(const float* y0, const float* f0, float t, float h, i
     return pf_last_launch_status();
 }
 
-// `n_attempts` step attempts of the adaptive integration whose state is in `ctl` (layout above), enqueued back to back with
-// the device-side controller in between: no host synchronisation.  ya / yb and fa / fb: the two state and derivative buffers
+// `n_attempts` step attempts of the adaptive integration whose state is in `ctl` (layout above), enqueued back to back; the
+// controller's decision is taken inside each attempt's launch by the workgroup that finishes last: no host synchronisation.  ya / yb and fa / fb: the two state and derivative buffers
 // ([rows,4]; ctl's `cur` says which one holds the current state), out: the solution at t1 once ctl's `done` is set with
 // status 0.  ws: >= 1024 doubles.
 extern "C" int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float* fb, const float* ctx, const float* e,
@@ -640,7 +656,6 @@ extern "C" int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float*
         // context rows through LDS when a tile's 64 rows belong to <= 16 whole points
         if (R >= 4 && (CNF_NW * 16) % R == 0) hipLaunchKernelGGL(cnf_step_dev_kernel<true>, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
         else hipLaunchKernelGGL(cnf_step_dev_kernel<false>, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
-        hipLaunchKernelGGL(cnf_ctl_kernel, dim3(1), dim3(64), 0, s, ctl, ws, grid);
     }
     return pf_last_launch_status();
 }

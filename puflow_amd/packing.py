@@ -573,7 +573,7 @@ def pack_cnf_block(sd, i: int):
         W3r[4 * qq:4 * qq + 3] = W3
         b3r[4 * qq:4 * qq + 3] = L[2]["_layer.bias"]
     rec[8192:9216] = frag_pack_f16x2(W3r)
-    W1t = np.zeros((64, 4), np.float32); W1t[:, :3] = W1
+    W1t = np.zeros((64, 4), np.float32); W1t[:, :3] = W1; W1t[:, 3] = L[0]["_layer.bias"]     # [W1 | b1]: the kernel's layer 1 is [W1 | b1] [y; 1]
     W3t = np.zeros((64, 4), np.float32); W3t[:, :3] = W3.T
     rec[9216:9472] = W1t.reshape(-1)
     rec[9472:9728] = W3t.reshape(-1)

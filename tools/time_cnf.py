@@ -5,15 +5,16 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from puflow_amd.cnf import PointInterpFlow
-from puflow_amd.weights import synth_cnf_state_dict, synth_patches
+from puflow_amd.weights import CNF_PU1K_DYNAMICS, CNF_PU1K_END_TIMES, synth_cnf_state_dict, synth_patches
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-net = PointInterpFlow(3); net.load_state_dict(synth_cnf_state_dict(2021)); net = net.cuda().eval()
+# the bench workload (bench.py --mode cnf): the trained checkpoint's end times, ODE nets scaled until dopri5 works like on it
+net = PointInterpFlow(3); net.load_state_dict(synth_cnf_state_dict(2021, dynamics=CNF_PU1K_DYNAMICS, end_times=CNF_PU1K_END_TIMES)); net = net.cuda().eval()
 xyz = synth_patches(B, N, seed=2021).cuda()
 torch.manual_seed(0)
 noise = [torch.randn(B, N, 3, device="cuda") for _ in range(6)]
-for it in range(3):
+for it in range(int(os.environ.get("PF_TIME_CNF_ITERS", "3"))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     x, logp = net(xyz, 4, noise=noise)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
