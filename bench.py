@@ -46,7 +46,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU (weak scaling)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch patches per GPU; strong: --total-batch patches split over the ranks")
-    ap.add_argument("--total-batch", type=int, default=32, help="patches of the whole job under --scaling strong")
+    ap.add_argument("--total-batch", type=int, default=256,
+                    help="patches of the whole job under --scaling strong (default 8 x 32: 32 per GPU at 8 GPUs - SURVEY 8e's threshold for "
+                         "the >= 6x claim is >= 8 patches per GPU, i.e. a total of >= 64; one 32-patch batch over 8 GPUs predicts 4.7x, "
+                         "DESIGN section 6)")
     ap.add_argument("--npoint", type=int, default=2048)
     ap.add_argument("--mode", choices=["infer", "train", "cnf", "pugan"], default="infer",
                     help="infer = headline metric (BASELINE configs[1]); train = configs[2] training step (CD+EMD, RCCL all-reduce); "
@@ -519,7 +522,10 @@ def bench_train(args, world, rank, dev, dist):
             ec_ms = sum(big) / len(big)
             E = args.batch * 256 * 16
             flops = 2.0 * EC_BWD_MAC_PER_EDGE * E
-            roof = {"bound": "mfma", "kernel": "pf_ec_train_bwd of a 128-channel EdgeConv unit (csrc/train_fused.hip: ec_bwdg16_kernel x4, ec_bwd0_kernel, "
+            persist = getattr(tm.network, "train_persistent", False) and os.environ.get("PF_TRAIN_PERSIST", "1") != "0"
+            roof = {"bound": "mfma", "kernel": "pf_ec_train_bwd of a 128-channel EdgeConv unit (csrc/train_fused.hip: " +
+                                             ("ec_bwdp_kernel - the dense block's backward as one persistent launch with a grid barrier per "
+                                              "BatchNorm layer - " if persist else "ec_bwdg16_kernel x4, ec_bwd0_kernel, ") +
                                              "ec_pq_bwd_csr_kernel, ec_dw3_kernel, two gemm_kernel, ec_assemble_kernel)",
                     "achieved": flops / (ec_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": flops / (ec_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None, "avg_launch_ms": ec_ms,
@@ -532,8 +538,8 @@ def bench_train(args, world, rank, dev, dist):
                 with open(os.path.join(ROOT, "profiles", "pmc_train_latest.json")) as f:
                     pk = json.load(f)
                 pk = pk.get("kernels", pk)
-                group = {"ec_bwdg16_kernel<2, 0>": 4, "ec_bwd0_kernel": 1, "ec_pq_bwd_csr_kernel": 1, "ec_dw3_kernel": 1, "gemm_kernel<2, 2, 2, 2, true>": 2,
-                         "gemm_reduce_kernel": 1, "ec_assemble_kernel": 1}
+                group = {"ec_pq_bwd_csr_kernel": 1, "ec_dw3_kernel": 1, "gemm_kernel<2, 2, 2, 2, true>": 2, "gemm_reduce_kernel": 1, "ec_assemble_kernel": 1}
+                group.update({"ec_bwdp_kernel<32, 4, 128>": 1} if persist else {"ec_bwdg16_kernel<2, 0>": 4, "ec_bwd0_kernel": 1})
                 tot, us = 0.0, 0.0
                 for k, n in group.items():
                     tot += n * pk[k]["hbm_bytes_per_launch"]
