@@ -439,8 +439,10 @@ def bench_train(args, world, rank, dev, dist):
     # rehearsal on one GPU (several ranks share the device): one EMD workgroup per sample - the multi-workgroup auction's grid
     # barriers assume this process's workgroups are co-resident (csrc/emd.hip)
     shared = os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1" and world > 1
+    syncbn = os.environ.get("PF_BENCH_SYNCBN") == "1"      # BatchNorm statistics over all ranks (cfg.sync_batchnorm) on the fused kernels
+
     def fresh_module():
-        m = TrainerModule(default_cfg(learning_rate=1e-3, emd_workgroups=1 if shared else 0), loss_mix="pugan")
+        m = TrainerModule(default_cfg(learning_rate=1e-3, emd_workgroups=1 if shared else 0, sync_batchnorm=syncbn), loss_mix="pugan")
         m.network.load_state_dict(synth_state_dict(2021))
         return m.to(dev)
     sd = synth_state_dict(2021)
@@ -578,7 +580,7 @@ def bench_train(args, world, rank, dev, dist):
                                      "loss": "1e-4 logp + 5e-2 EMD(eps .005, 50 it) + 1e-1 CD", "optimizer": "Adam 1e-3, clip 1e-2",
                                      "launch": ("hipGraph replay (graph A: forward + loss + backward + gradient packing; eager all-reduce of the flat "
                                                 "gradient bucket; graph B: clip + Adam)" if use_dist else "hipGraph replay") if graphed else "eager",
-                                     "collectives": args.collectives,
+                                     "collectives": args.collectives, "sync_batchnorm": syncbn,
                                      "patches_per_gpu": args.batch, "sharding": f"patch batch over {world} rank(s); one RCCL "
                                      "all-reduce of the flat 806 103-float gradient per step"},
                           "roofline": roof, "cpu_baseline": cpu}), flush=True)

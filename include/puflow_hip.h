@@ -301,6 +301,15 @@ typedef struct PfEcTrain {
                                        flight, another process on the device): two such kernels can starve each other */
     unsigned* sync;                 /* flags != 0: 4 words, zeroed ONCE by the caller; [0..2] are left zero by every launch, [3] is
                                        sticky: 1 = a grid barrier timed out (the unit's output is NaN) */
+    /* SyncBN (BatchNorm statistics over all ranks, interpflow.py:93,96,205,216 with global-batch semantics): sync_sums != NULL
+     * makes every BatchNorm layer leave its LOCAL column sums + row count in sync_sums (2 * 128 + 1 doubles) instead of
+     * finishing; the library then calls sync_cb(sync_user, sync_sums, 257, stream) - which must all-reduce (SUM) those doubles
+     * over the ranks, stream-ordered, and return 0 - and finishes the layer with the global sums in one small launch.  dgamma /
+     * dbeta stay the local sums (as torch.nn.SyncBatchNorm: the gradient bucket's mean over ranks follows).  The persistent
+     * launches are not used in this mode. */
+    int (*sync_cb)(void* user, double* sums, int n, void* stream);
+    void* sync_user;
+    double* sync_sums;
 } PfEcTrain;
 #define PF_EC_PERSISTENT 1
 /* transposed neighbour lists of idx [B*N, K]: off [T+1], edge [T*K]; cnt: T ints (4-aligned size) of scratch */
@@ -332,6 +341,9 @@ typedef struct PfBnMlpTrain {
     float* dW[3]; float* db[3]; float* dgamma[2]; float* dbeta[2];
     float* ws; long long ws_floats; /* >= pf_bnmlp_train_ws_floats() */
     double* stat;                   /* PF_TRAIN_STAT_DOUBLES doubles, zeroed once by the caller (see PfEcTrain) */
+    int (*sync_cb)(void* user, double* sums, int n, void* stream);      /* SyncBN, as in PfEcTrain */
+    void* sync_user;
+    double* sync_sums;
 } PfBnMlpTrain;
 long long pf_bnmlp_train_ws_floats(const PfBnMlpTrain* p);
 int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream);

@@ -22,7 +22,7 @@ class PfEcTrain(ctypes.Structure):
                 ("arg", c_void_p), ("dout", c_void_p), ("dA", c_void_p), ("dPQ", c_void_p), ("coef", c_void_p),
                 ("dWpq", c_void_p), ("dx", c_void_p), ("dW", c_void_p * 9), ("dbias", c_void_p * 9),
                 ("dgamma", c_void_p * 8), ("dbeta", c_void_p * 8), ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p), ("csr_off", c_void_p), ("csr_edge", c_void_p),
-                ("flags", c_int), ("sync", c_void_p)]
+                ("flags", c_int), ("sync", c_void_p), ("sync_cb", c_void_p), ("sync_user", c_void_p), ("sync_sums", c_void_p)]
 
 
 class PfBnMlpTrain(ctypes.Structure):
@@ -33,7 +33,8 @@ class PfBnMlpTrain(ctypes.Structure):
                 ("run_mean", c_void_p * 2), ("run_var", c_void_p * 2), ("y", c_void_p * 3), ("aff", c_void_p * 2),
                 ("dout", c_void_p), ("d", c_void_p * 2), ("coef", c_void_p * 2), ("dxa", c_void_p), ("dxb", c_void_p),
                 ("dW", c_void_p * 3), ("db", c_void_p * 3), ("dgamma", c_void_p * 2), ("dbeta", c_void_p * 2),
-                ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p)]
+                ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p),
+                ("sync_cb", c_void_p), ("sync_user", c_void_p), ("sync_sums", c_void_p)]
 
 
 class PfMlpTrain(ctypes.Structure):

@@ -70,11 +70,43 @@ struct StatFin {
     float* aff; const float* gamma; const float* beta; float* run_mean; float* run_var; float eps, momentum;
     float* coef; float* dgamma; float* dbeta;
     double R;
+    double* defer;                    // SyncBN: non-null = the last workgroup does NOT finish the layer; it leaves the LOCAL sums in
+                                      // defer[0 .. ncol) / defer[STAT_W ..] and the local row count in defer[2 STAT_W] (mode 2: dbeta /
+                                      // dgamma are written from the local sums, as torch.nn.SyncBatchNorm does); the host all-reduces
+                                      // the 2 STAT_W + 1 doubles over the ranks and stat_finalize_kernel finishes with the global sums
 };
 
 constexpr int STAT_COPIES = 16;       // workgroups spread their atomics over this many accumulator sets (same-address atomics serialise)
 constexpr int STAT_W = 128;           // statistics columns per launch (EdgeConv layers use <= 32, the BatchNorm MLPs up to 128)
 constexpr int STAT_DOUBLES = STAT_COPIES * 2 * STAT_W + 1;
+
+// sums of one column -> the layer's constants.  R: rows the sums run over (the GLOBAL count under SyncBN); param_grads: mode 2
+// also writes dbeta / dgamma from these sums (not under SyncBN: there they are the LOCAL sums, written by stat_flush)
+__device__ __forceinline__ void stat_finish_col(const StatFin& f, int c, double a0, double a1, double R, bool param_grads) {
+    if (f.mode == 1) {
+        // a0, a1 are sums of (y - pivot), (y - pivot)^2 with pivot = the running mean the kernels started from (read here
+        // before it is updated below; 0 without running statistics)
+        const double pv = f.run_mean ? (double)f.run_mean[c] : 0.0;
+        const double dm = a0 / R;
+        const double mean = pv + dm;
+        double var = a1 / R - dm * dm;
+        if (var < 0.0) var = 0.0;
+        const float rstd = 1.0f / sqrtf((float)var + f.eps);
+        const float sc = f.gamma[c] * rstd;
+        f.aff[f.col0 + c] = sc;
+        f.aff[f.ld + f.col0 + c] = f.beta[c] - (float)mean * sc;
+        f.aff[2 * f.ld + f.col0 + c] = (float)mean;
+        f.aff[3 * f.ld + f.col0 + c] = rstd;
+        if (f.run_mean) {
+            f.run_mean[c] = (1.f - f.momentum) * f.run_mean[c] + f.momentum * (float)mean;
+            f.run_var[c] = (1.f - f.momentum) * f.run_var[c] + f.momentum * (float)(var * (R / (R - 1.0)));
+        }
+    } else {
+        f.coef[f.col0 + c] = (float)(a0 / R);
+        f.coef[f.ld + f.col0 + c] = (float)(a1 / R);
+        if (param_grads) { f.dbeta[c] = (float)a0; f.dgamma[c] = (float)a1; }
+    }
+}
 
 // s0 / s1: this lane's sums for column (lane & 15) of each 16-column tile; `first`: the column that maps to statistics
 // column 0; ncol <= STAT_W.  red: 4 * 2 * STAT_W floats of LDS.
@@ -116,32 +148,23 @@ __device__ __forceinline__ void stat_flush(float (&s0)[NT], float (&s1)[NT], int
             a1 += __hip_atomic_load(f.acc + k * 2 * STAT_W + STAT_W + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             f.acc[k * 2 * STAT_W + c] = 0.0; f.acc[k * 2 * STAT_W + STAT_W + c] = 0.0;
         }
-        if (f.mode == 1) {
-            // a0, a1 are sums of (y - pivot), (y - pivot)^2 with pivot = the running mean the kernels started from (read here
-            // before it is updated below; 0 without running statistics)
-            const double pv = f.run_mean ? (double)f.run_mean[c] : 0.0;
-            const double dm = a0 / f.R;
-            const double mean = pv + dm;
-            double var = a1 / f.R - dm * dm;
-            if (var < 0.0) var = 0.0;
-            const float rstd = 1.0f / sqrtf((float)var + f.eps);
-            const float sc = f.gamma[c] * rstd;
-            f.aff[f.col0 + c] = sc;
-            f.aff[f.ld + f.col0 + c] = f.beta[c] - (float)mean * sc;
-            f.aff[2 * f.ld + f.col0 + c] = (float)mean;
-            f.aff[3 * f.ld + f.col0 + c] = rstd;
-            if (f.run_mean) {
-                f.run_mean[c] = (1.f - f.momentum) * f.run_mean[c] + f.momentum * (float)mean;
-                f.run_var[c] = (1.f - f.momentum) * f.run_var[c] + f.momentum * (float)(var * (f.R / (f.R - 1.0)));
-            }
-        } else {
-            f.coef[f.col0 + c] = (float)(a0 / f.R);
-            f.coef[f.ld + f.col0 + c] = (float)(a1 / f.R);
-            f.dbeta[c] = (float)a0;
-            f.dgamma[c] = (float)a1;
-        }
+        if (f.defer) {                                                // SyncBN: local sums out, the layer is finished after the all-reduce
+            f.defer[c] = a0;
+            f.defer[STAT_W + c] = a1;
+            if (f.mode == 2) { f.dbeta[c] = (float)a0; f.dgamma[c] = (float)a1; }
+        } else
+            stat_finish_col(f, c, a0, a1, f.R, true);
     }
-    if (threadIdx.x == 0) *counter = 0u;
+    if (threadIdx.x == 0) {
+        if (f.defer) f.defer[2 * STAT_W] = f.R;
+        *counter = 0u;
+    }
+}
+
+// SyncBN: the layer's constants from the all-reduced sums (defer[] as stat_flush left it, summed over the ranks by the host)
+__global__ __launch_bounds__(STAT_W) void stat_finalize_kernel(StatFin f, int ncol) {
+    const int c = threadIdx.x;
+    if (c < ncol) stat_finish_col(f, c, f.defer[c], f.defer[STAT_W + c], f.defer[2 * STAT_W], false);
 }
 
 // ------------------------------------------------------------------------------------------------ forward, one conv
@@ -2254,6 +2277,18 @@ void allow_lds(KERNEL k, size_t bytes) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// SyncBN on the fused kernels: after a launch whose StatFin defers (the local sums sit in fin.defer), the caller's callback
+// all-reduces them over the ranks (stream-ordered, e.g. torch.distributed.all_reduce on the tensor behind the pointer) and
+// one small launch finishes the layer with the global sums.
+typedef int (*PfSyncFn)(void* user, double* sums, int n, void* stream);
+int stat_sync(const StatFin& fin, int ncol, PfSyncFn cb, void* user, hipStream_t s) {
+    if (!fin.defer) return PF_OK;
+    if (!cb) return PF_ERR_NULL;
+    if (cb(user, fin.defer, 2 * STAT_W + 1, (void*)s) != 0) return PF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(stat_finalize_kernel, dim3(1), dim3(STAT_W), 0, s, fin, ncol);
+    return PF_OK;
+}
+
 struct Dims {
     int T, GT, S, nconvs;
     long long E;
@@ -2332,7 +2367,7 @@ int ecp_capacity() {
     return per_cu >= 1 ? ncu : 0;                  // one workgroup per CU at most: each wants most of a CU's registers
 }
 bool ec_persistent_ok(const PfEcTrain* p, const Dims& d) {
-    if (!(p->flags & PF_EC_PERSISTENT) || !p->sync || !p->pooling || p->K != 16 || p->nconv != 4) return false;
+    if (!(p->flags & PF_EC_PERSISTENT) || !p->sync || !p->pooling || p->K != 16 || p->nconv != 4 || p->sync_sums) return false;
     int cap = 0;
     if (p->growth == 8 && p->odim == 32) cap = ecp_capacity<8, 32>();
     else if (p->growth == 16 && p->odim == 64) cap = ecp_capacity<16, 64>();
@@ -2453,12 +2488,13 @@ extern "C" int pf_ec_train_fwd(const PfEcTrain* p, void* stream) {
         a.W = p->W[t] + 3 * p->C; a.ldw = cv.width[t]; a.poff = g * t; a.qoff = d.S + g * t;
         a.kin = g * t; a.col0 = g * t; a.nout = g;
         a.fin = StatFin{p->stat, 1, g, g * t, d.GT, p->aff, p->gamma[t], p->beta[t], p->run_mean[t], p->run_var[t], p->eps,
-                        p->momentum, nullptr, nullptr, nullptr, (double)d.E};
+                        p->momentum, nullptr, nullptr, nullptr, (double)d.E, p->sync_sums};
         const int kin16 = (a.kin + 15) & ~15;
         const int nt = g > 16 ? 2 : 1;
         const size_t lds = sizeof(float) * ((size_t)nt * 16 * (kin16 + 4) + 2 * kin16);
         if (nt == 2) hipLaunchKernelGGL((ec_fwd_kernel<2, false, false>), dim3(d.grid_light), dim3(256), lds, s, a);
         else hipLaunchKernelGGL((ec_fwd_kernel<1, false, false>), dim3(d.grid_light), dim3(256), lds, s, a);
+        if ((st = stat_sync(a.fin, g, p->sync_cb, p->sync_user, s))) return st;     // SyncBN: global statistics before the next layer
     }
     a.W = p->W[p->nconv] + 3 * p->C; a.ldw = cv.width[p->nconv]; a.poff = d.GT; a.qoff = d.S + d.GT;
     a.kin = d.GT; a.col0 = 0; a.nout = p->odim; a.out = p->out; a.arg = p->arg; a.fin = StatFin{};
@@ -2527,7 +2563,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         for (int t = 1; t < nc; ++t) { a.Wg[t] = p->W[t] + 3 * p->C; a.ldwg[t] = cv.width[t]; }
         a.s = sl; a.nc = nc; a.g = g; a.ntiles = d.ntiles; a.slope = p->slope;
         a.fin = StatFin{p->stat, 2, g, g * sl, d.GT, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, p->coef,
-                        p->dgamma[sl], p->dbeta[sl], (double)d.E};
+                        p->dgamma[sl], p->dbeta[sl], (double)d.E, p->sync_sums};
         const int g16 = (g + 15) & ~15, od16 = (p->odim + 15) & ~15, ntg = g16 / 16;
 #ifdef PF_EC_BWDG_F32
         const size_t lds = sizeof(float) * ((size_t)ntg * 16 * ((od16 + 4) + (size_t)(nc - 1 - sl) * (g16 + 4)) + 6 * g16);
@@ -2545,8 +2581,10 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         if (p->pooling) { if (ntg == 1) PF_ECG(1, 0); else PF_ECG(2, 0); }
         else { if (ntg == 1) PF_ECG(1, 1); else PF_ECG(2, 1); }
 #undef PF_ECG
+        if ((st = stat_sync(a.fin, g, p->sync_cb, p->sync_user, s))) return st;     // SyncBN: global sums before the transform of this layer
     }
 #else
+    if (p->sync_sums) return PF_ERR_UNSUPPORTED;                     // SyncBN is wired into the gather form only
     // ---- conv_out: dA = dYout Wg_out (+ sums of the last growth layer)
     {
         EcBwdArgs a{};
@@ -3110,7 +3148,7 @@ extern "C" int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream) {
         BnlFwdArgs a{};
         a.slope = p->slope; a.out = p->y[l]; a.nout = p->width[l]; a.rows = p->rows; a.ntiles = ntiles;
         if (bn) a.fin = StatFin{p->stat, 1, p->width[l], 0, p->width[l], p->aff[l], p->gamma[l], p->beta[l], p->run_mean[l],
-                                p->run_var[l], p->eps, p->momentum, nullptr, nullptr, nullptr, (double)p->rows};
+                                p->run_var[l], p->eps, p->momentum, nullptr, nullptr, nullptr, (double)p->rows, p->sync_sums};
         if (l == 0) {
             a.X = p->xa; a.ldx = p->kin0a; a.kin = p->kin0a; a.W = p->W[0]; a.ldw = in0; a.bias = p->b[0];
             a.want_stats = bn && p->kin0b == 0;
@@ -3126,6 +3164,7 @@ extern "C" int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream) {
             a.W = p->W[l]; a.ldw = p->width[l - 1]; a.bias = p->b[l]; a.want_stats = bn;
             bnl_fwd_dispatch(a, grid, s);
         }
+        if (bn && (st = stat_sync(a.fin, p->width[l], p->sync_cb, p->sync_user, s))) return st;   // SyncBN: global statistics
     }
     return pf_last_launch_status();
 }
@@ -3167,8 +3206,9 @@ extern "C" int pf_bnmlp_train_bwd(const PfBnMlpTrain* p, void* stream) {
             a.W = p->W[l]; a.ldw = p->width[l - 1]; a.dx = p->d[l - 1]; a.nout = p->width[l - 1];
             a.xpre = p->y[l - 1]; a.aff_prev = p->aff[l - 1]; a.want_stats = 1;
             a.fin = StatFin{p->stat, 2, p->width[l - 1], 0, p->width[l - 1], nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f,
-                            p->coef[l - 1], p->dgamma[l - 1], p->dbeta[l - 1], (double)p->rows};
+                            p->coef[l - 1], p->dgamma[l - 1], p->dbeta[l - 1], (double)p->rows, p->sync_sums};
             bnl_bwd_dispatch(a, bn ? 2 : 1, grid, s);
+            if ((st = stat_sync(a.fin, p->width[l - 1], p->sync_cb, p->sync_user, s))) return st;   // SyncBN: global sums of layer l - 1
             dw(dyl, p->width[l], p->y[l - 1], p->width[l - 1], p->width[l - 1], p->aff[l - 1], p->aff[l - 1] + p->width[l - 1],
                p->dW[l], p->width[l - 1], 0, p->db[l]);
         } else {

@@ -14,8 +14,8 @@ capture they live in the graph's pool, at fixed addresses), so there is neither 
 parameter.
 
 Preconditions, all checked: the module is in train() mode with ActNorm initialised (the data-dependent first-batch init is a
-host-side branch - run one eager `train_step` first, `GraphedTrainStep` does it for you when needed), SyncBN off (its
-statistics all-reduce reads the row count on the host), Adam built with `capturable=True` (`make_capturable` converts an
+host-side branch - run one eager `train_step` first, `GraphedTrainStep` does it for you when needed), SyncBN only on the fused
+kernels over RCCL (their per-layer all-reduces of 257 doubles are captured; the row count travels with the sums), Adam built with `capturable=True` (`make_capturable` converts an
 existing optimizer).  The learning rate lives in a device tensor: `set_lr()` (or a scheduler through `sync_lr()`) changes it
 without re-capturing.  Results are those of the eager step with the same kernels in the same order; the NaN-loss guard of
 the reference (train_pu1k.py:71-73) becomes a tensor select (trainer.training_step).
@@ -45,7 +45,11 @@ class GraphedTrainStep:
         from . import train_ops
         from .dist import FlatGradBucket
         if getattr(getattr(module, "network", module), "sync_batchnorm", False) and train_ops._multi_rank():
-            raise RuntimeError("graphed_train_step: SyncBN reads the global row count on the host; capture is not possible")
+            # SyncBN on the fused kernels all-reduces a layer's sums between two launches: RCCL collectives can be captured into
+            # the graph, gloo's (host-side) cannot; the un-fused kernels read the global row count on the host
+            if not train_ops._FUSED or torch.distributed.get_backend() != "nccl":
+                raise RuntimeError("graphed_train_step with SyncBN needs the fused kernels and the nccl (RCCL) backend: its per-layer "
+                                   "all-reduces are captured into the graph")
         self.module, self.optimizer, self.clip = module, optimizer, clip
         dev = next(module.parameters()).device
         from .dist import multi_rank

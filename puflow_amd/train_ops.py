@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 
 import math
 from typing import List, Tuple
@@ -100,6 +101,43 @@ def check_persist_status(device=None) -> None:
             raise _lib.PuflowHipError("a persistent training kernel timed out on a grid barrier (workgroups not co-resident - is the GPU "
                                       "shared with another process, or did two barrier kernels run side by side?).  Set "
                                       "net.train_persistent = False (cfg.persistent_kernels = False) on a shared device")
+
+
+# ---- SyncBN on the fused kernels: the library leaves a BatchNorm layer's LOCAL column sums in `sync_sums` and calls back;
+# the callback all-reduces them (stream-ordered on torch's current stream, which is the stream the kernels were enqueued on)
+_SYNC_SUMS = {}
+_SYNC_CB_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
+
+
+def _sync_sums(dev) -> Tensor:
+    key = (dev, _stream())
+    t = _SYNC_SUMS.get(key)
+    if t is None:
+        t = _SYNC_SUMS[key] = torch.zeros(2 * 128 + 1, dtype=torch.float64, device=dev)
+    return t
+
+
+def _sync_cb_impl(user, sums, n, stream):
+    try:
+        import torch.distributed as dist
+        for t in _SYNC_SUMS.values():
+            if t.data_ptr() == sums:
+                dist.all_reduce(t)                      # SUM over the ranks: 2 x 128 column sums + the row count
+                return 0
+        return 1
+    except Exception as ex:                             # an exception must not unwind through the C caller
+        print(f"puflow_amd: SyncBN all-reduce failed: {type(ex).__name__}: {ex}", file=sys.stderr)
+        return 2
+
+
+_SYNC_CB = _SYNC_CB_T(_sync_cb_impl)                    # module-level: must outlive every call
+
+
+def _attach_sync(d, dev) -> None:
+    """Global-batch BatchNorm statistics for a fused-kernel call (PfEcTrain / PfBnMlpTrain)."""
+    d.sync_cb = ctypes.cast(_SYNC_CB, ctypes.c_void_p)
+    d.sync_user = None
+    d.sync_sums = _sync_sums(dev).data_ptr()
 
 
 def _gemm(A: Tensor, sam: int, sak: int, Bm: Tensor, sbk: int, sbn: int, C: Tensor, ldc: int, bias, M: int, N: int, K: int,
@@ -646,7 +684,7 @@ def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None, pe
     and the gather's scatter-add - exact algebra, same results up to fp32 rounding."""
     if _UNFOLDED:
         return edgeconv_train_unfolded(p, x, idx, pooling)
-    if _FUSED and not _sync_bn_active() and _ec_fused_supported(p, x, idx, pooling):
+    if _FUSED and _ec_fused_supported(p, x, idx, pooling):
         return edgeconv_train_fused(p, x, idx, pooling, csr, persistent)
     B, N, C = x.shape
     K = idx.shape[-1]
@@ -727,6 +765,8 @@ class EdgeConvUnitFn(Function):
         d.stat = _stat(dev).data_ptr()
         if len(cfg) > 11 and cfg[11]:                         # the whole forward as one persistent launch where the library can
             d.flags, d.sync = 1, _sync_words(dev).data_ptr()
+        if len(cfg) > 12 and cfg[12]:                         # SyncBN: statistics over all ranks (fixed at forward time: the
+            _attach_sync(d, dev)                              # backward runs after the sync_bn() scope has ended)
         _lib.check(lib.pf_ec_train_fwd(ctypes.byref(d), _stream()), "pf_ec_train_fwd")
         ctx.cfg = cfg
         ctx.has_arg = pooling
@@ -776,6 +816,8 @@ class EdgeConvUnitFn(Function):
             d.csr_off, d.csr_edge = csr[0].data_ptr(), csr[1].data_ptr()
         if len(cfg) > 11 and cfg[11]:                         # the dense block's backward as one persistent launch (see forward)
             d.flags, d.sync = 1, _sync_words(dev).data_ptr()
+        if len(cfg) > 12 and cfg[12]:
+            _attach_sync(d, dev)
         _lib.check(lib.pf_ec_train_bwd(ctypes.byref(d), _stream()), "pf_ec_train_bwd")
         return (dx, None, None, *dWs, *dbs, *dgs, *dbe)
 
@@ -1223,7 +1265,7 @@ class BnMlpFn(Function):
 
     @staticmethod
     def _desc(xa, xb, cfg, Ws):
-        slope, eps, momentum, rmeans, rvars = cfg
+        slope, eps, momentum, rmeans, rvars = cfg[:5]
         d = _lib.PfBnMlpTrain()
         d.rows, d.nl = xa.shape[0], len(Ws)
         d.kin0a, d.kin0b = xa.shape[1], (xb.shape[1] if xb is not None else 0)
@@ -1237,7 +1279,7 @@ class BnMlpFn(Function):
     @staticmethod
     def forward(ctx, xa, xb, cfg, *prm):
         lib = _lib.load()
-        slope, eps, momentum, rmeans, rvars = cfg
+        slope, eps, momentum, rmeans, rvars = cfg[:5]
         xa = xa.contiguous()
         xb = xb.contiguous() if xb is not None else None
         Ws = [w.contiguous() for w in prm[0:6:2]]
@@ -1254,6 +1296,8 @@ class BnMlpFn(Function):
             d.gamma[l], d.beta[l], d.aff[l] = gb[2 * l].data_ptr(), gb[2 * l + 1].data_ptr(), affs[l].data_ptr()
             d.run_mean[l], d.run_var[l] = _ptr(rmeans[l]), _ptr(rvars[l])
         d.stat = _stat(dev).data_ptr()
+        if len(cfg) > 5 and cfg[5]:
+            _attach_sync(d, dev)
         _lib.check(lib.pf_bnmlp_train_fwd(ctypes.byref(d), _stream()), "pf_bnmlp_train_fwd")
         ctx.cfg, ctx.has_b = cfg, xb is not None
         ctx.save_for_backward(xa, *(() if xb is None else (xb,)), *Ws, *ys, *affs, gb[0], gb[2])
@@ -1290,6 +1334,8 @@ class BnMlpFn(Function):
         ws = _ws(dev, need)
         d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
         d.stat = _stat(dev).data_ptr()
+        if len(ctx.cfg) > 5 and ctx.cfg[5]:
+            _attach_sync(d, dev)
         _lib.check(lib.pf_bnmlp_train_bwd(ctypes.byref(d), _stream()), "pf_bnmlp_train_bwd")
         return (dxa, dxb, None, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dgs[0], dbe[0], dgs[1], dbe[1])
 
@@ -1309,7 +1355,8 @@ def _count_batches(bns) -> None:
 
 def bnmlp_fused(mlp, xa: Tensor, xb=None) -> Tensor:
     convs, bns = [mlp[0], mlp[3], mlp[6]], [mlp[1], mlp[4]]
-    cfg = (0.01, float(bns[0].eps), float(bns[0].momentum), [bn.running_mean for bn in bns], [bn.running_var for bn in bns])
+    cfg = (0.01, float(bns[0].eps), float(bns[0].momentum), [bn.running_mean for bn in bns], [bn.running_var for bn in bns],
+           _sync_bn_active())
     prm = []
     for c in convs:
         prm += [c.weight, c.bias]
@@ -1463,7 +1510,8 @@ def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=No
     bns = [seq[1] for seq in p.convs]
     g, nconv, odim = convs[0].weight.shape[0], len(bns), p.conv_out.weight.shape[0]
     cfg = (idx.shape[-1], g, nconv, odim, bool(pooling), 0.05, float(bns[0].eps), float(bns[0].momentum),
-           [bn.running_mean for bn in bns], [bn.running_var for bn in bns], csr, bool(persistent) and _PERSIST)
+           [bn.running_mean for bn in bns], [bn.running_var for bn in bns], csr,
+           bool(persistent) and _PERSIST and not _sync_bn_active(), _sync_bn_active())
     out = EdgeConvUnitFn.apply(x, idx, cfg, *[c.weight for c in convs], *[c.bias for c in convs],
                                *[bn.weight for bn in bns], *[bn.bias for bn in bns])
     _count_batches(bns)
@@ -1607,7 +1655,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     R = upratio
     idx16, _ = ops.knn_idx32(xyz, xyz, 16)
     idx8 = idx16[..., :8].contiguous()
-    fused_ec = _FUSED and not _sync_bn_active()
+    fused_ec = _FUSED                                     # also under SyncBN: the fused kernels defer a layer's statistics to an all-reduce
     use_side = getattr(net, "train_streams", True) and not _sync_bn_active()
     # transposed neighbour lists: only the BACKWARD of the EdgeConv units reads them - with a side stream they are built there,
     # off the main chain (8 small launches, ~55 us), and joined with the interpolation weights
@@ -1625,7 +1673,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         ip = net.interp
         fd = torch.empty((B * N * 8, 10), dtype=torch.float32, device=xyz.device)        # inputs only: no gradient
         _lib.check(_lib.load().pf_dist_feature(xyz.data_ptr(), idx8.data_ptr(), B, N, 8, fd.data_ptr(), _stream()), "pf_dist_feature")
-        fused_bn = _FUSED and not _sync_bn_active()
+        fused_bn = _FUSED
         d = bnmlp_fused(ip.knn_context.distance_encoder.mlp, fd) if fused_bn else _mlp_bn(ip.knn_context.distance_encoder.mlp, fd)
         feat = edgeconv_train(ip.knn_context.feat_conv, xyz, idx8, pooling=False, csr=csr8)      # d, feat: [E8,128]
         if fused_bn:

@@ -58,3 +58,19 @@ def test_inference_bench_over_rccl_one_rank():
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_syncbn_training_step_over_rccl_one_rank(graph):
+    """cfg.sync_batchnorm on the fused kernels with RCCL: every BatchNorm layer's 257-double all-reduce (csrc/train_fused.hip
+    stat_sync -> train_ops._sync_cb_impl -> dist.all_reduce) between two launches - eager, and CAPTURED into the step's hipGraph
+    (graph = 1: graphed_train_step no longer refuses SyncBN when the backend is nccl).  One rank, multi-rank path forced."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", "train", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-grad-parity"], cwd=ROOT, env=dict(_env(), PF_BENCH_GRAPH=graph, PF_BENCH_SYNCBN="1"),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "capture failed" not in out.stderr, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["config"]["sync_batchnorm"] is True and rec["config"]["collectives"]["backend"] == "nccl"
+    assert rec["value"] > 0 and rec["loss"] == rec["loss"] and abs(rec["loss"]) < 1e3
+    print("SyncBN step over RCCL (1 rank), graph =", graph, ":", rec["ms_per_step"], "ms")
