@@ -553,7 +553,8 @@ class PointInterpFlow(nn.Module):
         torch.cuda.current_stream(dev).wait_stream(side)
         engine = self._engine(upratio)                     # pinned: the graph reads this engine's blob
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # see train_graph._CAPTURE_MODE: other threads (an RCCL
+                                                                              # watchdog polling its events) must not break the capture
             out_x, out_logp = self._forward_eval(static_in, upratio, ws)
         if self._engine_cache is not engine:
             raise _lib.PuflowHipError("the plan was re-packed during capture")

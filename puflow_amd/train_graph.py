@@ -28,6 +28,13 @@ import torch
 from torch import Tensor
 
 
+# Capture in thread-local error mode: under the default (global) mode ANY thread's "unsafe" runtime call invalidates a running
+# capture - and the RCCL process group's watchdog thread polls the events of earlier eager collectives (broadcast_module, the
+# warm-up all-reduces) with hipEventQuery whenever it likes: "operation not permitted when stream is capturing", the watchdog
+# dies and takes the process down.  Found by the one-rank RCCL smoke test, intermittently (a race with the watchdog's poll).
+_CAPTURE_MODE = "thread_local"
+
+
 def make_capturable(optimizer: torch.optim.Optimizer, device) -> torch.optim.Optimizer:
     """Adam(capturable=True) with the learning rate and the step counters as device tensors (required for capture)."""
     for g in optimizer.param_groups:
@@ -82,14 +89,14 @@ class GraphedTrainStep:
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
         if not self.multi:
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, capture_error_mode=_CAPTURE_MODE):
                 self.loss = self._fwd_bwd()
                 self._update()
         else:
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, capture_error_mode=_CAPTURE_MODE):
                 self.loss = self._fwd_bwd()
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._update()
 
     # ---- pieces (the same calls in warm-up, capture and - implicitly - replay)
