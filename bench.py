@@ -589,8 +589,9 @@ def bench_train(args, world, rank, dev, dist):
 def train_grad_parity(args, step_grads):
     """How far the default build's gradients (split-bf16 / split-fp16 products in the EdgeConv units' kernels) are from the SAME
     kernels on plain f32 MFMA products, loaded in child processes (the library is chosen at load time):
-      backward_only : libpuflow_hip_bwdf32.so  = -DPF_EC_BWDG_F32 -DPF_EC_DW_F32 (the forward is bit for bit the default build's:
-                      what differs is the arithmetic of the backward kernels alone)
+      backward_only : libpuflow_hip_bwdf32.so  = -DPF_EC_BWDG_F32 -DPF_EC_DW_F32 (the persistent dense-block backward, the per-layer
+                      one of the interpolation unit and the weight-gradient kernel on f32 products; the forward is bit for bit the
+                      default build's: what differs is the arithmetic of the backward kernels alone)
       all           : libpuflow_hip_gradf32.so = the above + -DPF_EC_FWD_F32 (conv_out forward on f32 products too: the forward
                       then differs by ~1e-6, which ill-conditioned gradients - max-pool routes, the flow's conditioning -
                       amplify; the difference to `backward_only` is that amplification, not backward arithmetic)

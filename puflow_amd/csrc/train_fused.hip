@@ -1424,6 +1424,19 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
     fbase[0] = NB * NCO;
 #pragma unroll
     for (int s = 0; s < NC; ++s) fbase[s + 1] = fbase[s] + NTG * ndy(s);
+#ifdef PF_EC_BWDG_F32
+    // A/B build (bench.py grad_parity): the SAME kernel on plain f32 products - fp32 images [row][k] with row = growth column,
+    // k = source channel: Wo [GT][ODIM + 4] (conv_out), Ms [NC][NTG * 16][GT + 4] (the later layers' rows, zero for layers <= s)
+    constexpr int KPO = ODIM + 4, KPG = GT + 4;
+    float* Wo = lds;
+    float* Ms = lds + GT * KPO;
+    for (int i = threadIdx.x; i < GT * ODIM; i += ECP_T) Wo[(i % GT) * KPO + i / GT] = a.Wout[(size_t)(i / GT) * a.ldwout + i % GT];
+    for (int i = threadIdx.x; i < NC * NTG * 16 * GT; i += ECP_T) {
+        const int s = i / (NTG * 16 * GT), rw = (i / GT) % (NTG * 16), c = i % GT, t = c / G;
+        const int ug = 16 * ((G * s) / 16) + rw;
+        Ms[(s * NTG * 16 + rw) * KPG + c] = (ug >= G * s && ug < G * (s + 1) && t > s) ? a.Wg[t][(size_t)(c - G * t) * a.ldwg[t] + ug] : 0.f;
+    }
+#else
     uint4* Wf = reinterpret_cast<uint4*>(lds);
     {
         const int nunit = fbase[NC] * 64;
@@ -1462,6 +1475,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
             }
         }
     }
+#endif
     // ---- this wave's tiles
     int tl[ECP_TPW];
     bool ok[ECP_TPW];
@@ -1477,6 +1491,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) dy[s][b] = pf_splat(0.f);
     __syncthreads();
+#ifndef PF_EC_BWDG_F32
     auto mma = [&](int frag, const GBf2& B, f4& acc) {
         const gbf8 wh = __builtin_bit_cast(gbf8, Wf[(frag * 2 + 0) * 64 + lane]);
         const gbf8 wm = __builtin_bit_cast(gbf8, Wf[(frag * 2 + 1) * 64 + lane]);
@@ -1484,6 +1499,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, B.mid, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, B.hi, acc, 0, 0, 0);
     };
+#endif
 
     // ---- conv_out's contribution to EVERY layer in one pass: dy[.][b] = Wout[:, 16 b ..]^T dYout, dYout formed from (dh, argmax)
     // and split once per (tile, chunk) - this lane's 8 channels of a 32-channel chunk, edge = col.  Layer s adds the later
@@ -1502,9 +1518,18 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
                 x[j] = (int)((g0 >> (8 * j)) & 255u) == col ? d0[j] : 0.f;
                 x[4 + j] = (int)((g1 >> (8 * j)) & 255u) == col ? d1[j] : 0.f;
             }
+#ifdef PF_EC_BWDG_F32
+            const f4 x0 = {x[0], x[1], x[2], x[3]}, x1 = {x[4], x[5], x[6], x[7]};
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                dy[t][b] = mfma4(*reinterpret_cast<const f4*>(Wo + (16 * b + col) * KPO + 32 * co + 4 * q), x0, dy[t][b]);
+                dy[t][b] = mfma4(*reinterpret_cast<const f4*>(Wo + (16 * b + col) * KPO + 32 * co + 16 + 4 * q), x1, dy[t][b]);
+            }
+#else
             const GBf2 B = g_split(x);
 #pragma unroll
             for (int b = 0; b < NB; ++b) mma(b * NCO + co, B, dy[t][b]);
+#endif
         }
     }
 
@@ -1542,12 +1567,21 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
         for (int cp = CP0; cp < NCP; ++cp) {
 #pragma unroll
             for (int t = 0; t < ECP_TPW; ++t) {
+#ifdef PF_EC_BWDG_F32
+#pragma unroll
+                for (int nt = 0; nt < NTG; ++nt) {
+                    const float* mrow = Ms + ((size_t)s * NTG * 16 + nt * 16 + col) * KPG + 32 * cp + 4 * q;
+                    A(t, nt) = mfma4(*reinterpret_cast<const f4*>(mrow), dy[t][2 * cp], A(t, nt));
+                    A(t, nt) = mfma4(*reinterpret_cast<const f4*>(mrow + 16), dy[t][2 * cp + 1], A(t, nt));
+                }
+#else
                 float x[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { x[j] = dy[t][2 * cp][j]; x[4 + j] = dy[t][2 * cp + 1][j]; }
                 const GBf2 B = g_split(x);
 #pragma unroll
                 for (int nt = 0; nt < NTG; ++nt) mma(fb + nt * NDY + cp - CP0, B, A(t, nt));
+#endif
             }
         }
         __syncthreads();                                              // bnc
@@ -2376,9 +2410,13 @@ bool ec_persistent_ok(const PfEcTrain* p, const Dims& d) {
 }
 template <int G, int ODIM>
 size_t ecpb_lds_bytes() {
+#ifdef PF_EC_BWDG_F32
+    return sizeof(float) * ((size_t)G * 4 * (ODIM + 4) + (size_t)4 * ((G + 15) / 16) * 16 * (G * 4 + 4));
+#else
     int nf = (G * 4 / 16) * (ODIM / 32);
     for (int s = 0; s < 4; ++s) nf += ((G + 15) / 16) * (G * 4 / 32 - (G * (s + 1)) / 32);
     return (size_t)nf * 2 * 64 * 16;
+#endif
 }
 template <int G, int ODIM>
 bool ecpb_fits() {

@@ -6,7 +6,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-(cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o tr -- python3 $ROOT/bench.py --mode train --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/trace.log" 2>&1)
+(cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o tr -- python3 $ROOT/bench.py --mode train --steps 20 --warmup 5 --no-cpu-baseline --no-grad-parity > "$OUT/trace.log" 2>&1)
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, re
 out = sys.argv[1]
@@ -21,7 +21,7 @@ for r in rows:
     tot += per
     nm = re.sub(r"\(anonymous namespace\)::", "", r["Name"])[:100]
     lines.append(f"{nm:100s} {int(r['Calls']) / n:6.1f}/step {per:8.1f} us/step")
-open(out + "/kernel_stats_per_step.txt", "w").write(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --mode train --steps 20 --warmup 5   ({n} executions of the step's kernels)\n" + "\n".join(lines[:70]) + f"\ntotal {tot / 1e3:.2f} ms of kernel time per step, {sum(int(r['Calls']) for r in rows) / n:.0f} launches per step\n")
+open(out + "/kernel_stats_per_step.txt", "w").write(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --mode train --steps 20 --warmup 5 --no-cpu-baseline --no-grad-parity   ({n} executions of the step's kernels)\n" + "\n".join(lines[:70]) + f"\ntotal {tot / 1e3:.2f} ms of kernel time per step, {sum(int(r['Calls']) for r in rows) / n:.0f} launches per step\n")
 print("\n".join(lines[:45])); print(f"total {tot / 1e3:.2f} ms, launches {sum(int(r['Calls']) for r in rows) / n:.0f}")
 PY
 python3 - "$OUT" <<'PY'
