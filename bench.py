@@ -497,6 +497,7 @@ def bench_train(args, world, rank, dev, dist):
         loss = step(batch)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    grad_norm_last = float(opt.coef[1]) if hasattr(opt, "coef") else None      # of the last TIMED step (the call profile below runs more)
     tm.check_device_status()                      # EMD barrier time-outs raise, NaN substitutions of the captured steps are printed
     t = torch.tensor([el], dtype=torch.float64, device=dev)
     if use_dist:
@@ -576,6 +577,9 @@ def bench_train(args, world, rank, dev, dist):
                                    "backward; measured against the f32-product build in `grad_parity`",
                           "grad_parity": grad_parity,
                           "data": "synthetic", "loss": float(loss),
+                          # global gradient norm (before clipping) of the last step, as the fused optimizer's norm kernel saw it:
+                          # after the gradient all-reduce when ranks > 1 (or the forced one-rank path)
+                          "grad_norm_last_step": grad_norm_last,
                           "config": {"workload": "BASELINE configs[2]: discrete x4 training step, 32 x (256->1024) patches per GPU",
                                      "loss": "1e-4 logp + 5e-2 EMD(eps .005, 50 it) + 1e-1 CD", "optimizer": "Adam 1e-3, clip 1e-2",
                                      "launch": ("hipGraph replay (graph A: forward + loss + backward + gradient packing; eager all-reduce of the flat "

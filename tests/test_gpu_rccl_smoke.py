@@ -36,20 +36,24 @@ def test_training_step_over_rccl_one_rank(graph):
 
 
 def test_forced_collectives_do_not_change_the_step():
-    """The forced one-rank path (pack -> all-reduce -> / 1 -> update) and the plain single-process path take the same
-    optimisation steps: same loss after the same number of steps from the same state (the EMD's float atomics aside,
-    which the bound covers)."""
-    losses = []
+    """The forced one-rank path (gradient packing -> RCCL all-reduce -> / world -> clip + Adam) sees the same gradient as the plain
+    single-process path: the global gradient norm of the FIRST step from the same state agrees to the noise of the step's float
+    atomics (a wrong scale, a double reduction or a missed bucket would show at once; losses of LATER steps are not comparable -
+    Adam turns rounding noise into different trajectories within a few updates)."""
+    recs = []
     for force in ("1", "0"):
         env = _env()
         if force == "0":
             for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PF_BENCH_FORCE_DIST"):
                 env.pop(k)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--steps", "2", "--warmup", "1",
-                              "--no-cpu-baseline"], cwd=ROOT, env=dict(env, PF_BENCH_GRAPH="0"), capture_output=True, text=True, timeout=900)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--steps", "1", "--warmup", "0",
+                              "--no-cpu-baseline", "--no-grad-parity"], cwd=ROOT, env=dict(env, PF_BENCH_GRAPH="0"), capture_output=True,
+                             text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-3000:]
-        losses.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["loss"])
-    assert abs(losses[0] - losses[1]) <= 2e-3 * abs(losses[1]), losses
+        recs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+    g0, g1 = recs[0]["grad_norm_last_step"], recs[1]["grad_norm_last_step"]
+    assert g0 > 0 and abs(g0 - g1) <= 1e-4 * g1, (g0, g1)
+    assert abs(recs[0]["loss"] - recs[1]["loss"]) <= 1e-5 * abs(recs[1]["loss"])
 
 
 def test_inference_bench_over_rccl_one_rank():
