@@ -23,7 +23,7 @@ if [ "$PART" = a ]; then
   timeout -k 10 200 python3 tools/time_emd.py 0 1 2 4 8 16 2>&1 | grep -v amdgpu.ids > "$OUT/emd_groups.txt"
 else
   timeout -k 10 500 bash tools/profile_gpu.sh $TAG/pmc > "$OUT/profile_gpu.log" 2>&1; tail -1 "$OUT/profile_gpu.log"
-  timeout -k 10 200 bash tools/r3_train_prof.sh $TAG/train_trace > /dev/null 2>&1; head -3 "$OUT/train_trace/kernel_stats_per_step.txt"; tail -1 "$OUT/train_trace/kernel_stats_per_step.txt"
+  timeout -k 10 200 bash tools/train_prof.sh $TAG/train_trace > /dev/null 2>&1; head -3 "$OUT/train_trace/kernel_stats_per_step.txt"; tail -1 "$OUT/train_trace/kernel_stats_per_step.txt"
   timeout -k 10 400 bash tools/pmc_cmd.sh $TAG/train_pmc tools/train_eager_steps.py > "$OUT/train_pmc.log" 2>&1; tail -1 "$OUT/train_pmc.log"
   python3 tools/pmc_table.py "$OUT/train_pmc/pmc_summary.json" "rocprofv3 --pmc passes (tools/pmc_cmd.sh) over 4 EAGER training steps of BASELINE configs[2] (tools/train_eager_steps.py): per-kernel means" > "$OUT/train_pmc_table.txt"
   PF_TIME_CNF_ITERS=2 timeout -k 10 300 bash tools/pmc_cmd.sh $TAG/cnf_pmc tools/time_cnf.py > "$OUT/cnf_pmc.log" 2>&1; tail -1 "$OUT/cnf_pmc.log"
