@@ -130,6 +130,13 @@ class _CnfEngine:
         self.ctl = torch.empty(16, dtype=torch.float64, device=device)       # dopri5 controller state (csrc/cnf.hip)
         self.first_batch = int(os.environ.get("PF_CNF_FIRST_BATCH", "8"))    # step attempts enqueued before the first look
         self.next_batch = int(os.environ.get("PF_CNF_NEXT_BATCH", "4"))
+        # attempts enqueued per integration when the whole forward runs WITHOUT reading the controller in between (attempts past
+        # the end are ~4 us no-ops; an integration that needs more makes the forward fall back to the look-per-batch loop); 0 = off
+        self.async_attempts = int(os.environ.get("PF_CNF_ASYNC_ATTEMPTS", "1"))             # 0 = never run blind
+        self.logs = torch.zeros((2 * NUM_BLOCKS, 16), dtype=torch.float64, device=device)   # controller state after each integration
+        # step attempts each of the twelve integrations took the last time (accepted + rejected): the blind run enqueues that
+        # many + a margin (the trained model's blocks differ by 10x: 3 attempts for the short ones, 25 for the T = 36 block)
+        self.hint: Optional[List[int]] = None
         self.nfe = 0
         self.accepted = 0
         self.rejected = 0
@@ -172,8 +179,11 @@ class _CnfEngine:
 
     # ---- dopri5 (control flow of torchdiffeq's adaptive solver, restated: oracle/cnf_ref.py::dopri5) ------
     def integrate(self, i: int, x: Tensor, ctx: Tensor, e: Tensor, R: int, reverse: bool, extra_n: int,
-                  extra_d0: float) -> Tensor:
-        """x [rows,3] -> state [rows,4] = (x', delta logp) at the end time of block i."""
+                  extra_d0: float, log: Optional[Tensor] = None, blind: int = 0) -> Tensor:
+        """x [rows,3] -> state [rows,4] = (x', delta logp) at the end time of block i.
+        log (a [16] double device row): do not look at the controller - enqueue `blind` attempts, copy the final controller
+        state into `log` and return; the caller checks all rows once (`check_logs`).  Otherwise the look-per-batch loop, which
+        also leaves the number of attempts it took in `self.last_attempts`."""
         rows = x.shape[0]
         dev = x.device
         T = self.T_end[i]
@@ -201,6 +211,12 @@ class _CnfEngine:
         # of attempts and reads the controller state once per batch (attempts past the end of the integration are no-ops)
         out = torch.empty_like(y)
         f0, f1 = K[0], K[6]
+        if log is not None:
+            _lib.check(self.lib.pf_cnf_steps(ctl.data_ptr(), y.data_ptr(), y1.data_ptr(), f0.data_ptr(), f1.data_ptr(),
+                                             ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), out.data_ptr(), RTOL, ATOL,
+                                             rows, R, int(blind), self.ws1k.data_ptr(), self._stream()), "pf_cnf_steps")
+            log.copy_(ctl)
+            return out
         attempts = 0
         batch = self.first_batch
         while True:
@@ -215,6 +231,7 @@ class _CnfEngine:
                 raise _lib.PuflowHipError(f"dopri5: more than {MAX_NUM_STEPS} step attempts in block {i}")
             batch = self.next_batch
         t, dt = float(st[0]), float(st[1])
+        self.last_attempts = int(st[6]) + int(st[7])
         self.accepted += int(st[6])
         self.rejected += int(st[7])
         self.nfe += int(st[8])
@@ -226,6 +243,18 @@ class _CnfEngine:
         if st[9] == 2:
             raise _lib.PuflowHipError(f"dopri5: underflow in dt ({dt:g}) at t = {t:g}, block {i}")
         return out
+
+    def check_logs(self, n: int) -> bool:
+        """The controller states of the first n deferred integrations, ONE device -> host read: True when every one finished
+        cleanly inside its attempts (the counters are then added to the statistics)."""
+        L = self.logs[:n].cpu()
+        if not bool(((L[:, 5] != 0) & (L[:, 9] == 0)).all()):
+            return False
+        self.hint = [int(a) for a in (L[:, 6] + L[:, 7]).tolist()]
+        self.accepted += int(L[:, 6].sum())
+        self.rejected += int(L[:, 7].sum())
+        self.nfe += int(L[:, 8].sum())
+        return True
 
 
 class PointInterpFlow(nn.Module):
@@ -292,23 +321,50 @@ class PointInterpFlow(nn.Module):
         es = [n.reshape(T, 3).contiguous().float() for n in noise]
         cflat = [c.reshape(T, -1) for c in cs]
         ctx = [eng.context(i, cflat[i]) for i in range(NUM_BLOCKS)]
-        # the context is a state of the reference's ODE (zero derivative): it only enters the solver's norms
-        d0c = [float(((c / (ATOL + RTOL * c.abs())) ** 2).sum(dtype=torch.float64).item()) for c in cflat]
-        # ---- f
-        p = xyz.reshape(T, 3)
-        ldj = torch.zeros(B, dtype=torch.float32, device=xyz.device)
-        for i in range(NUM_BLOCKS):
-            st = eng.integrate(i, p, ctx[i], es[i], 1, False, cflat[i].numel(), d0c[i])
-            p = st[:, :3].contiguous()
-            ldj = ldj + st[:, 3].view(B, N).sum(1)
-        z = p.view(B, N, 3)
-        logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + math.log(2 * math.pi)), dim=(1, 2)) - ldj)
-        u = base.interp(xyz, z.contiguous(), idx16, upratio)                                   # [B, N*R, 3], row n*R + r
-        # ---- g
-        u = u.reshape(T * upratio, 3)
-        for i in reversed(range(NUM_BLOCKS)):
-            st = eng.integrate(i, u, ctx[i], es[i], upratio, True, cflat[i].numel() * upratio, d0c[i] * upratio)
-            u = st[:, :3].contiguous()
+        # the context is a state of the reference's ODE (zero derivative): it only enters the solver's norms (one read for all six)
+        d0c = torch.stack([((c / (ATOL + RTOL * c.abs())) ** 2).sum(dtype=torch.float64) for c in cflat]).tolist()
+
+        def run(deferred: bool):
+            """f, interpolation, g.  deferred: no look at a controller until all twelve integrations are enqueued."""
+            k = 0
+            took.clear()
+            p = xyz.reshape(T, 3)
+            ldj = torch.zeros(B, dtype=torch.float32, device=xyz.device)
+            for i in range(NUM_BLOCKS):
+                st = eng.integrate(i, p, ctx[i], es[i], 1, False, cflat[i].numel(), d0c[i], eng.logs[k] if deferred else None,
+                                   blind[k] if deferred else 0)
+                took.append(getattr(eng, "last_attempts", 0))
+                k += 1
+                p = st[:, :3].contiguous()
+                ldj = ldj + st[:, 3].view(B, N).sum(1)
+            z = p.view(B, N, 3)
+            logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + math.log(2 * math.pi)), dim=(1, 2)) - ldj)
+            u = base.interp(xyz, z.contiguous(), idx16, upratio).reshape(T * upratio, 3)            # row n*R + r
+            for i in reversed(range(NUM_BLOCKS)):
+                st = eng.integrate(i, u, ctx[i], es[i], upratio, True, cflat[i].numel() * upratio, d0c[i] * upratio,
+                                   eng.logs[k] if deferred else None, blind[k] if deferred else 0)
+                took.append(getattr(eng, "last_attempts", 0))
+                k += 1
+                u = st[:, :3].contiguous()
+            return z, ldj, logp, u
+
+        # The host used to read the controller after every batch of attempts (~2 reads x 12 integrations, each a pipeline
+        # bubble).  Now the whole forward is enqueued blind and the twelve final controller states are read ONCE; an integration
+        # that did not finish inside its attempts (or hit an error state) sends the forward through the look-per-batch loop,
+        # which also raises the errors.  Same arithmetic either way: attempts past the end of an integration are no-ops.
+        # How many attempts to enqueue blind: what each integration took on the previous forward + a quarter + 3 (the first
+        # forward of an engine, and any forward whose guess was too small, takes the loop and leaves the counts).
+        done = False
+        took: List[int] = []
+        if eng.async_attempts > 0 and eng.hint is not None:
+            blind = [h + h // 4 + 3 for h in eng.hint]
+            z, ldj, logp, u = run(True)
+            done = eng.check_logs(2 * NUM_BLOCKS)
+        if not done:
+            eng.nfe = eng.accepted = eng.rejected = 0
+            blind = []
+            z, ldj, logp, u = run(False)
+            eng.hint = list(took)
         x = u.view(B, N * upratio, 3)
         self.last_stats = dict(nfe=eng.nfe, accepted=eng.accepted, rejected=eng.rejected)
         if stages:

@@ -251,3 +251,30 @@ def test_full_size_properties_32x2048():
     zmax = float(full["z"].abs().max())
     print("g(f(x)) - x at 32 x 2048:", float(err), "max|z|", zmax)
     assert err < 2e-4 * max(1.0, zmax)           # the solver's rtol = 1e-5 per step on latents of this size, 12 chained integrations
+
+
+def test_deferred_forward_equals_the_look_per_batch_loop():
+    """The forward enqueued without a look at the step controller (one read of the twelve final controller states) gives the
+    result of the look-per-batch loop bit for bit, with the same evaluation / accept / reject counts - also when an
+    integration does not finish inside its blind attempts and the forward falls back."""
+    from puflow_amd.weights import CNF_PU1K_DYNAMICS, CNF_PU1K_END_TIMES
+    sd = synth_cnf_state_dict(2021, dynamics=CNF_PU1K_DYNAMICS, end_times=CNF_PU1K_END_TIMES)
+    net = _net(sd)
+    xyz = synth_patches(2, 512, seed=4).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    noise = [torch.randn(2, 512, 3, generator=g).to(DEV) for _ in range(6)]
+    eng = net._engine(4)
+    res = {}
+    eng.async_attempts = 0
+    res["loop"] = net(xyz, 4, noise=noise, stages=True)                 # also leaves the attempts each integration took
+    eng.async_attempts = 1
+    assert eng.hint is not None and len(eng.hint) == 12 and max(eng.hint) > 2 * min(eng.hint)     # the T = 36 block needs the most
+    res["deferred"] = net(xyz, 4, noise=noise, stages=True)
+    eng.hint = [1] * 12                                                 # a guess that is too small: blind run, then the loop
+    res["fallback"] = net(xyz, 4, noise=noise, stages=True)
+    assert eng.hint is not None and max(eng.hint) > 3
+    assert res["loop"]["rejected"] >= 3 and res["loop"]["nfe"] > 300
+    for name in ("deferred", "fallback"):
+        assert torch.equal(res[name]["x"], res["loop"]["x"]) and torch.equal(res[name]["z"], res["loop"]["z"])
+        assert torch.equal(res[name]["ldj"], res["loop"]["ldj"])
+        assert (res[name]["nfe"], res[name]["accepted"], res[name]["rejected"]) == (res["loop"]["nfe"], res["loop"]["accepted"], res["loop"]["rejected"])
