@@ -52,8 +52,10 @@ struct CnfArgs {
 // sigmoid and tanh on the hardware exp / rcp (1 ulp each): absolute error ~2e-7, against ~25 instructions for tanhf and a
 // full-precision division - the right-hand side is bound by these (32 tanh + 32 sigmoid per lane and evaluation), not by its
 // 54 MFMAs.  tanh(x) = 1 - 2 / (e^{2x} + 1) saturates correctly (e -> inf: 1, e -> 0: -1).
-__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return fmaf(-2.f, __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f), 1.f); }
+// The arguments arrive PRESCALED by the host (packing.pack_cnf_block): gates carry -log2e x, the tanh layers' pre-activations
+// 2 log2e x, so each function is v_exp_f32 + add + v_rcp_f32 (+ one fma): one multiply per gate and per tanh saved.
+__device__ __forceinline__ float sigm(float xs) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(xs)); }          // xs = -log2e x
+__device__ __forceinline__ float tanh_fast(float xs) { return fmaf(-2.f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.f), 1.f); }   // xs = 2 log2e x
 
 // One evaluation for this lane's row: k = sgn * (f(t, y), -e^T (df/dy) e).  All four q groups of a column return the same f4.
 struct CnfW {
@@ -160,7 +162,8 @@ __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, floa
     // sum over the 4 q groups of the column (lanes col, col+16, col+32, col+48)
     r0 += __shfl_xor(r0, 16); r1 += __shfl_xor(r1, 16); r2 += __shfl_xor(r2, 16);
     r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
-    const float div = fmaf(r2, e2, fmaf(r1, e1, r0 * e0));
+    // (the W1 rows of the record carry the forward's 2 log2e: taken out of the three sums here)
+    const float div = fmaf(r2, e2, fmaf(r1, e1, r0 * e0)) * 0.34657359027997264f;
     return (f4){sgn * dy.x, sgn * dy.y, sgn * dy.z, -sgn * div};
 }
 

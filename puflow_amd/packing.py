@@ -534,6 +534,9 @@ def _np32(t) -> np.ndarray:
     return t.detach().cpu().numpy().astype(np.float32) if hasattr(t, "detach") else np.asarray(t, np.float32)
 
 
+LOG2E = 1.4426950408889634
+
+
 def pack_cnf_block(sd, i: int):
     """-> (rec [CNF_REC] fp32, Hc [288, cdim], hb [288], T_end).  A ConcatSquash layer (diffeq_layers.py:72-86) is
     (W x + b) * sigmoid(Wg [t; c] + bg) + Wb [t; c]: the c-columns of Wg / Wb form the context GEMM `Hc` (with bg
@@ -562,11 +565,16 @@ def pack_cnf_block(sd, i: int):
     put(192, L[1]["_hyper_bias.weight"], None, False)
     put(256, L[2]["_hyper_gate.weight"], L[2]["_hyper_gate.bias"], True)
     put(272, L[2]["_hyper_bias.weight"], None, True)
+    # The kernel's sigmoid / tanh run on the hardware 2^x: sigmoid(a) = 1 / (1 + 2^(-log2e a)), tanh(a) = 1 - 2 / (2^(2 log2e a) + 1).
+    # The constants are folded HERE (one multiply per gate and per tanh less on a VALU-bound kernel): gate rows carry
+    # -log2e x their argument, the pre-activations of the two tanh layers (weights, biases, time / context bias rows) 2 log2e x.
+    for lo, hi, f in ((0, 64, -LOG2E), (128, 192, -LOG2E), (256, 272, -LOG2E), (64, 128, 2 * LOG2E), (192, 256, 2 * LOG2E)):
+        Hc[lo:hi] *= np.float32(f); hb[lo:hi] *= np.float32(f); tv[lo:hi] *= np.float32(f)
 
     rec = np.zeros(CNF_REC, np.float32)
     W1, W2, W3 = L[0]["_layer.weight"], L[1]["_layer.weight"], L[2]["_layer.weight"]
-    rec[0:4096] = frag_pack_f16x2(W2)
-    rec[4096:8192] = frag_pack_f16x2(np.ascontiguousarray(W2.T))
+    rec[0:4096] = frag_pack_f16x2((W2.astype(np.float64) * (2 * LOG2E)).astype(np.float32))     # forward image: 2 log2e folded in
+    rec[4096:8192] = frag_pack_f16x2(np.ascontiguousarray(W2.T))                                 # transposed image (VJP): plain
     W3r = np.zeros((16, 64), np.float32)
     b3r = np.zeros(16, np.float32)
     for qq in range(4):
@@ -574,11 +582,12 @@ def pack_cnf_block(sd, i: int):
         b3r[4 * qq:4 * qq + 3] = L[2]["_layer.bias"]
     rec[8192:9216] = frag_pack_f16x2(W3r)
     W1t = np.zeros((64, 4), np.float32); W1t[:, :3] = W1; W1t[:, 3] = L[0]["_layer.bias"]     # [W1 | b1]: the kernel's layer 1 is [W1 | b1] [y; 1]
+    W1t = (W1t.astype(np.float64) * (2 * LOG2E)).astype(np.float32)                            # (the VJP divides its W1^T sums by 2 log2e again)
     W3t = np.zeros((64, 4), np.float32); W3t[:, :3] = W3.T
     rec[9216:9472] = W1t.reshape(-1)
     rec[9472:9728] = W3t.reshape(-1)
     rec[9728:9792] = L[0]["_layer.bias"]
-    rec[9792:9856] = L[1]["_layer.bias"]
+    rec[9792:9856] = (L[1]["_layer.bias"].astype(np.float64) * (2 * LOG2E)).astype(np.float32)
     rec[9856:9872] = b3r
     rec[9872:10160] = tv
     T_end = float(_np32(sd[f"flow_blocks.{i}.cnf.sqrt_end_time"])) ** 2

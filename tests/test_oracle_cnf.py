@@ -62,15 +62,20 @@ def test_pack_cnf_block_layout():
     rec, Hc, hb, T_end = pack_cnf_block(sd, 3)
     p = "flow_blocks.3.cnf.odefunc.diffeq.layers"
     assert rec.size == CNF_REC and Hc.shape == (CNF_CTX, 128) and abs(T_end - 0.5) < 1e-6
+    from puflow_amd.packing import LOG2E
     W2 = sd[p + ".1._layer.weight"].numpy()
-    np.testing.assert_allclose(frag_unpack_f16x2(rec[0:4096], 64, 64), W2, rtol=2.0 ** -21, atol=1e-10)   # tiny |w|: hi is a subnormal fp16
+    # forward image: the tanh's 2 log2e folded in (the kernel's tanh is 1 - 2 / (2^a + 1)); transposed image (VJP): plain
+    np.testing.assert_allclose(frag_unpack_f16x2(rec[0:4096], 64, 64), (W2.astype(np.float64) * 2 * LOG2E).astype(np.float32),
+                               rtol=2.0 ** -21, atol=1e-10)   # tiny |w|: hi is a subnormal fp16
     np.testing.assert_allclose(frag_unpack_f16x2(rec[4096:8192], 64, 64), W2.T, rtol=2.0 ** -21, atol=1e-10)
     g3 = sd[p + ".2._hyper_gate.weight"].numpy()
-    for q in range(4):                                      # 3-row layer-3 pieces replicated per q group
-        np.testing.assert_array_equal(Hc[256 + 4 * q:256 + 4 * q + 3], g3[:, 1:])
-        np.testing.assert_array_equal(rec[9872 + 256 + 4 * q:9872 + 256 + 4 * q + 3], g3[:, 0])
-    np.testing.assert_array_equal(hb[0:64], sd[p + ".0._hyper_gate.bias"].numpy())
+    for q in range(4):                                      # 3-row layer-3 pieces replicated per q group; gates carry -log2e
+        np.testing.assert_allclose(Hc[256 + 4 * q:256 + 4 * q + 3], -LOG2E * g3[:, 1:].astype(np.float64), rtol=1e-6)
+        np.testing.assert_allclose(rec[9872 + 256 + 4 * q:9872 + 256 + 4 * q + 3], -LOG2E * g3[:, 0].astype(np.float64), rtol=1e-6)
+    np.testing.assert_allclose(hb[0:64], -LOG2E * sd[p + ".0._hyper_gate.bias"].numpy().astype(np.float64), rtol=1e-6)
     assert not hb[64:128].any()                             # hyper_bias has no bias term (diffeq_layers.py:76)
+    b3 = sd[p + ".2._hyper_bias.weight"].numpy()
+    np.testing.assert_array_equal(Hc[272:275], b3[:, 1:])   # the last layer has no tanh: its bias rows are plain
 
 
 def test_rhs_matches_reference_golden(golden_dir):
