@@ -562,16 +562,22 @@ int pf_cnf_step(const float* y0, const float* f0, float t, float h, int reverse,
  * ctl: 16 doubles - [0] t [1] dt [2] t1 [3] n_tot (elements of the RMS norm) [4] cur (which of ya / yb, fa / fb is current)
  * [5] done [6] accepted [7] rejected [8] nfe [9] status (0 ok, 1 non-finite error norm, 2 dt underflow) [10] reverse.
  * The host initialises ctl and the current buffers, enqueues batches and reads `done` once per batch; `out` [rows,4] holds
- * the state at t1 when done with status 0.  ws: >= 1024 doubles. */
+ * the state at t1 when done with status 0.  ws: >= 1024 doubles.
+ * flags: PF_CNF_SPLIT_GATES - the caller vouches that log2(e) x max|t-column of the three hyper_gate weights| x |t1 - t0| <= 100
+ * for this record (packing.cnf_split_ok).  The gates' 2^(gt (t + alpha h) + gc) then factor, without overflow, into a part per
+ * point and step and a part per channel and stage: 36 of an evaluation's 135 transcendental instructions less. */
+#define PF_CNF_SPLIT_GATES 1
 int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float* fb, const float* ctx, const float* e, const float* rec,
-                 float* out, float rtol, float atol, int rows, int R, int n_attempts, double* ws, void* stream);
+                 float* out, float rtol, float atol, int rows, int R, int n_attempts, double* ws, int flags, void* stream);
 
-/* The start of that integration over [t0, t1] on the device: resets ctl, f0 = f(t0, y), torchdiffeq's
- * `_select_initial_step` into ctl[1].  n_tot / extra_d0: elements of the RMS norm and what the state rows outside y add to
- * |y0|^2.  ftmp: [rows,4] scratch; ws: >= 256 doubles; red: 3 doubles. */
-int pf_cnf_init(double* ctl, const float* y, float* f0, float* ftmp, const float* ctx, const float* e, const float* rec,
-                double t0, double t1, double n_tot, double extra_d0, int reverse, float rtol, float atol, int rows, int R,
-                double* ws, double* red, void* stream);
+/* The start of that integration over [t0, t1] on the device, in two launches: the state rows y = (x, 0) from the points x
+ * (row stride x_stride = 3 or 4 floats - a previous block's [rows,4] state is read in place), f0 = f(t0, y), ctl reset,
+ * torchdiffeq's `_select_initial_step` into ctl[1].  n_tot / extra_d0: elements of the RMS norm and what the state rows
+ * outside y add to |y0|^2.  ws: >= 3072 doubles.  ctl: ALL ZERO before its first use (every launch leaves its arrival word,
+ * ctl[13], zero again). */
+int pf_cnf_init(double* ctl, const float* x, int x_stride, float* y, float* f0, const float* ctx, const float* e,
+                const float* rec, double t0, double t1, double n_tot, double extra_d0, int reverse, float rtol, float atol,
+                int rows, int R, double* ws, void* stream);
 
 /* out[i] = sum_{j<n_terms} w[j] * ptrs[j][i]   (n_terms <= 8; ptrs / w are HOST arrays).  Runge-Kutta solution,
  * mid-point and dense-output combinations of torchdiffeq's dopri5 (cnf.py:97-113 call site). */

@@ -30,7 +30,7 @@ from torch import Tensor
 from . import _lib
 from .interpflow import (COND_CHANNELS, FEAT_CHANNELS, GROWTH, NUM_BLOCKS, _EdgeConvParams, _Engine, _InterpParams,
                          _MergeParams)
-from .packing import CNF_CTX, pack_cnf_block
+from .packing import CNF_CTX, cnf_split_ok, pack_cnf_block
 from .train_ops import _gemm
 from .weights import state_dict_spec
 
@@ -116,18 +116,21 @@ class _CnfEngine:
         self.device = device
         self.R = upratio
         self.base = _Engine(_discrete_shell(sd), device)
-        self.rec, self.Hc, self.hb, self.T_end = [], [], [], []
+        self.rec, self.Hc, self.hb, self.T_end, self.split = [], [], [], [], []
         for i in range(NUM_BLOCKS):
             rec, Hc, hb, T_end = pack_cnf_block(sd, i)
             self.rec.append(torch.from_numpy(rec).to(device))
             self.Hc.append(torch.from_numpy(Hc).to(device))
             self.hb.append(torch.from_numpy(hb).to(device))
             self.T_end.append(T_end)
+            # PF_CNF_SPLIT_GATES (include/puflow_hip.h): only where the factored 2^x cannot overflow; PF_CNF_SPLIT=0 keeps the plain kernel
+            self.split.append(int(cnf_split_ok(rec, T_end) and os.environ.get("PF_CNF_SPLIT", "1") != "0"))
         self.ws = torch.empty(256, dtype=torch.float64, device=device)
         self.ws1k = torch.empty(1024, dtype=torch.float64, device=device)
+        self.ws3k = torch.empty(3072, dtype=torch.float64, device=device)
         self.red = torch.empty(1, dtype=torch.float64, device=device)
         self.red3 = torch.empty(3, dtype=torch.float64, device=device)
-        self.ctl = torch.empty(16, dtype=torch.float64, device=device)       # dopri5 controller state (csrc/cnf.hip)
+        self.ctl = torch.zeros(16, dtype=torch.float64, device=device)       # dopri5 controller state (csrc/cnf.hip; zero before its first use)
         self.first_batch = int(os.environ.get("PF_CNF_FIRST_BATCH", "8"))    # step attempts enqueued before the first look
         self.next_batch = int(os.environ.get("PF_CNF_NEXT_BATCH", "4"))
         # attempts enqueued per integration when the whole forward runs WITHOUT reading the controller in between (attempts past
@@ -180,10 +183,11 @@ class _CnfEngine:
     # ---- dopri5 (control flow of torchdiffeq's adaptive solver, restated: oracle/cnf_ref.py::dopri5) ------
     def integrate(self, i: int, x: Tensor, ctx: Tensor, e: Tensor, R: int, reverse: bool, extra_n: int,
                   extra_d0: float, log: Optional[Tensor] = None, blind: int = 0) -> Tensor:
-        """x [rows,3] -> state [rows,4] = (x', delta logp) at the end time of block i.
-        log (a [16] double device row): do not look at the controller - enqueue `blind` attempts, copy the final controller
-        state into `log` and return; the caller checks all rows once (`check_logs`).  Otherwise the look-per-batch loop, which
-        also leaves the number of attempts it took in `self.last_attempts`."""
+        """x [rows, >= 3] (row stride 3 or 4 floats: a previous block's state is taken as it lies) -> state [rows,4] =
+        (x', delta logp) at the end time of block i.
+        log (a [16] double device row, zero before its first use): do not look at the controller - `log` IS the controller
+        state of this integration; enqueue `blind` attempts and return; the caller checks all rows once (`check_logs`).
+        Otherwise the look-per-batch loop, which also leaves the number of attempts it took in `self.last_attempts`."""
         rows = x.shape[0]
         dev = x.device
         T = self.T_end[i]
@@ -194,35 +198,32 @@ class _CnfEngine:
         def net_t(s: float) -> float:                         # the time the network sees
             return s if not reverse else -s
 
-        y = torch.zeros((rows, 4), dtype=torch.float32, device=dev)
-        y[:, :3] = x
-        K = torch.empty((7, rows, 4), dtype=torch.float32, device=dev)
-        y1 = torch.empty_like(y)
-        f1 = torch.empty_like(y)
-        # f0 and torchdiffeq's initial step size, on the device (csrc/cnf.hip: pf_cnf_init); the controller state follows
-        ctl = self.ctl
-        _lib.check(self.lib.pf_cnf_init(ctl.data_ptr(), y.data_ptr(), K[0].data_ptr(), f1.data_ptr(), ctx.data_ptr(),
-                                        e.data_ptr(), self.rec[i].data_ptr(), t0, t1, n_tot, float(extra_d0),
-                                        1 if reverse else 0, RTOL, ATOL, rows, R, self.ws.data_ptr(), self.red3.data_ptr(),
-                                        self._stream()), "pf_cnf_init")
+        if x.dtype != torch.float32 or x.stride(1) != 1 or x.stride(0) not in (3, 4):
+            x = x.float().contiguous()[:, :3].contiguous()
+        bufs = torch.empty((5, rows, 4), dtype=torch.float32, device=dev)
+        y, y1, f0, f1, out = bufs[0], bufs[1], bufs[2], bufs[3], bufs[4]
+        # the state rows (x, 0), f0 and torchdiffeq's initial step size, on the device in two launches (csrc/cnf.hip:
+        # pf_cnf_init); the controller state follows
+        ctl = self.ctl if log is None else log
+        _lib.check(self.lib.pf_cnf_init(ctl.data_ptr(), x.data_ptr(), int(x.stride(0)), y.data_ptr(), f0.data_ptr(),
+                                        ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), t0, t1, n_tot, float(extra_d0),
+                                        1 if reverse else 0, RTOL, ATOL, rows, R, self.ws3k.data_ptr(), self._stream()),
+                   "pf_cnf_init")
 
         # ---- adaptive steps: ONE launch per attempt (six fused stage evaluations) + a one-wave controller kernel; the
         # accept / reject / next-dt decisions are taken on the device (csrc/cnf.hip: cnf_ctl_update, run by the workgroup of a step attempt that finishes last), the host enqueues a batch
         # of attempts and reads the controller state once per batch (attempts past the end of the integration are no-ops)
-        out = torch.empty_like(y)
-        f0, f1 = K[0], K[6]
         if log is not None:
             _lib.check(self.lib.pf_cnf_steps(ctl.data_ptr(), y.data_ptr(), y1.data_ptr(), f0.data_ptr(), f1.data_ptr(),
                                              ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), out.data_ptr(), RTOL, ATOL,
-                                             rows, R, int(blind), self.ws1k.data_ptr(), self._stream()), "pf_cnf_steps")
-            log.copy_(ctl)
+                                             rows, R, int(blind), self.ws1k.data_ptr(), self.split[i], self._stream()), "pf_cnf_steps")
             return out
         attempts = 0
         batch = self.first_batch
         while True:
             _lib.check(self.lib.pf_cnf_steps(ctl.data_ptr(), y.data_ptr(), y1.data_ptr(), f0.data_ptr(), f1.data_ptr(),
                                              ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), out.data_ptr(), RTOL, ATOL,
-                                             rows, R, batch, self.ws1k.data_ptr(), self._stream()), "pf_cnf_steps")
+                                             rows, R, batch, self.ws1k.data_ptr(), self.split[i], self._stream()), "pf_cnf_steps")
             attempts += batch
             st = ctl.cpu()                                      # the one device->host read per batch of attempts
             if st[5] != 0:
@@ -329,24 +330,24 @@ class PointInterpFlow(nn.Module):
             k = 0
             took.clear()
             p = xyz.reshape(T, 3)
-            ldj = torch.zeros(B, dtype=torch.float32, device=xyz.device)
+            sts = []
             for i in range(NUM_BLOCKS):
-                st = eng.integrate(i, p, ctx[i], es[i], 1, False, cflat[i].numel(), d0c[i], eng.logs[k] if deferred else None,
-                                   blind[k] if deferred else 0)
+                p = eng.integrate(i, p, ctx[i], es[i], 1, False, cflat[i].numel(), d0c[i], eng.logs[k] if deferred else None,
+                                  blind[k] if deferred else 0)            # [T,4]: the next block reads its first three columns in place
                 took.append(getattr(eng, "last_attempts", 0))
                 k += 1
-                p = st[:, :3].contiguous()
-                ldj = ldj + st[:, 3].view(B, N).sum(1)
-            z = p.view(B, N, 3)
+                sts.append(p)
+            # the six blocks' delta logp, summed per patch in one reduction (it was a reduce + an add per block)
+            ldj = torch.stack([s_[:, 3] for s_ in sts]).view(NUM_BLOCKS, B, N).sum(dim=(0, 2))
+            z = p[:, :3].reshape(B, N, 3)
             logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + math.log(2 * math.pi)), dim=(1, 2)) - ldj)
             u = base.interp(xyz, z.contiguous(), idx16, upratio).reshape(T * upratio, 3)            # row n*R + r
             for i in reversed(range(NUM_BLOCKS)):
-                st = eng.integrate(i, u, ctx[i], es[i], upratio, True, cflat[i].numel() * upratio, d0c[i] * upratio,
-                                   eng.logs[k] if deferred else None, blind[k] if deferred else 0)
+                u = eng.integrate(i, u, ctx[i], es[i], upratio, True, cflat[i].numel() * upratio, d0c[i] * upratio,
+                                  eng.logs[k] if deferred else None, blind[k] if deferred else 0)
                 took.append(getattr(eng, "last_attempts", 0))
                 k += 1
-                u = st[:, :3].contiguous()
-            return z, ldj, logp, u
+            return z, ldj, logp, u[:, :3].contiguous()
 
         # The host used to read the controller after every batch of attempts (~2 reads x 12 integrations, each a pipeline
         # bubble).  Now the whole forward is enqueued blind and the twelve final controller states are read ONCE; an integration

@@ -63,10 +63,20 @@ struct CnfW {
     PfW2Lds w2, w2t, w3;
 };
 
+// SPLIT (cnf_step_dev_kernel, context rows in LDS): the gates depend on (point, channel, stage time) only, and
+// 2^(gt (t + alpha h) + gc) = 2^(gt t + gc) x 2^(gt alpha h).  The first factor is computed ONCE per point and tile into the
+// context rows' gate slots (shared by the point's R rows and the step's six evaluations), the second once per launch into a
+// [stage][channel] table `tvg` points at: a gate is fma + v_rcp_f32, without the v_exp_f32 (36 of an evaluation's 135
+// quarter-rate transcendentals, on a kernel the PMC counters show VALU-bound).
+template <bool SPLIT = false>
 __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, float sgn, const float* __restrict__ cx,
-                                       float e0, float e1, float e2) {
+                                       float e0, float e1, float e2, const float* __restrict__ tvg = nullptr) {
     const float* rec = w.rec;
     const float* tv = rec + 9872;
+    if (!SPLIT) tvg = tv;
+    auto gatef = [](float gt, float tt, float gc) {
+        return SPLIT ? __builtin_amdgcn_rcpf(fmaf(gc, gt, 1.f)) : sigm(fmaf(gt, tt, gc));
+    };
     const int col = threadIdx.x & 15;
     // ---- layer 1 (3 -> 64): this lane's channels 16 cb + 4 q + r.  W1 y + b1 is ONE v_mfma_f32_16x16x4_f32 per 16 channels
     // ([W1 | b1] x [y; 1]: k = 3 carries the bias) instead of 16 x (an LDS row + 3 fmas) on a VALU that PMC shows ~90 % busy
@@ -77,12 +87,12 @@ __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, floa
     for (int cb = 0; cb < 4; ++cb) {
         const int ch = cb * 16 + 4 * q;
         const f4 gc = *reinterpret_cast<const f4*>(cx + ch), bc = *reinterpret_cast<const f4*>(cx + 64 + ch);
-        const f4 gt = *reinterpret_cast<const f4*>(tv + ch), bt = *reinterpret_cast<const f4*>(tv + 64 + ch);
+        const f4 gt = *reinterpret_cast<const f4*>(tvg + ch), bt = *reinterpret_cast<const f4*>(tv + 64 + ch);
         const f4 lin4 = pf_mfma(rec[9216 + (cb * 16 + col) * 4 + q], yb, pf_splat(0.f));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float lin = lin4[r];
-            const float gate = sigm(fmaf(gt[r], t, gc[r]));
+            const float gate = gatef(gt[r], t, gc[r]);
             g1[cb][r] = gate;
             h1[0][cb][r] = tanh_fast(fmaf(lin, gate, fmaf(bt[r], t, bc[r])));
         }
@@ -101,10 +111,10 @@ __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, floa
         for (int cb = 0; cb < 4; ++cb) {
             const int ch = cb * 16 + 4 * q;
             const f4 gc = *reinterpret_cast<const f4*>(cx + 128 + ch), bc = *reinterpret_cast<const f4*>(cx + 192 + ch);
-            const f4 gt = *reinterpret_cast<const f4*>(tv + 128 + ch), bt = *reinterpret_cast<const f4*>(tv + 192 + ch);
+            const f4 gt = *reinterpret_cast<const f4*>(tvg + 128 + ch), bt = *reinterpret_cast<const f4*>(tv + 192 + ch);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float gate = sigm(fmaf(gt[r], t, gc[r]));
+                const float gate = gatef(gt[r], t, gc[r]);
                 g2[cb][r] = gate;
                 h2[0][cb][r] = tanh_fast(fmaf(a2[0][cb][r], gate, fmaf(bt[r], t, bc[r])));
             }
@@ -120,10 +130,10 @@ __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, floa
         a3[0][0] = *reinterpret_cast<const f4*>(rec + 9856 + 4 * q);
         pf_mm2f<1, 2, 2>(w.w3, 0, hp, 0, a3, 0);
         const f4 gc = *reinterpret_cast<const f4*>(cx + 256 + 4 * q), bc = *reinterpret_cast<const f4*>(cx + 272 + 4 * q);
-        const f4 gt = *reinterpret_cast<const f4*>(tv + 256 + 4 * q), bt = *reinterpret_cast<const f4*>(tv + 272 + 4 * q);
+        const f4 gt = *reinterpret_cast<const f4*>(tvg + 256 + 4 * q), bt = *reinterpret_cast<const f4*>(tv + 272 + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            g3[r] = sigm(fmaf(gt[r], t, gc[r]));
+            g3[r] = gatef(gt[r], t, gc[r]);
             dy[r] = fmaf(a3[0][0][r], g3[r], fmaf(bt[r], t, bc[r]));
         }
     }
@@ -306,14 +316,33 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_kernel(CnfStepArgs a) {
 // The step that covers t1 writes the dense-output value at t1 (quartic through y0, y_mid, y1: torchdiffeq's interpolation)
 // straight into `out`; if that attempt is rejected a later covering attempt overwrites it.
 
-// one wave (lane 0 decides): torchdiffeq's `_adaptive_step` decisions on the error norm of the attempt just made.  Called by
-// the first wave of the workgroup of cnf_step_dev_kernel that finishes LAST (every partial sum is in place by then).
-__device__ __forceinline__ void cnf_ctl_update(double* ctl, const double* partial, int nblocks) {
-    double sum = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 64)                          // fixed order: deterministic
-        sum += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// The per-workgroup sums (<= 1024) added in a fixed order by a WHOLE workgroup: four independent loads per thread in flight at
+// once, then wave shuffles and four LDS words.  (One wave walking the array in a dependent loop was 16 L2 round trips in a
+// row: ~10 us at the tail of every step attempt, ~100 attempts per forward.)  Every thread returns the total.
+__device__ __forceinline__ double cnf_partial_total(const double* partial, int nblocks, double* red4) {
+    double v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = threadIdx.x + j * CNF_NW * 64;
+        v[j] = i < nblocks ? __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+    static_assert(CNF_NW * 64 * 4 >= 1024, "a workgroup covers the largest grid in four loads per thread");
+    double sum = ((v[0] + v[1]) + v[2]) + v[3];
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
+    __syncthreads();                                                         // red4 may still be read from an earlier total
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    double t = red4[0];
+#pragma unroll
+    for (int w = 1; w < CNF_NW; ++w) t += red4[w];
+    return t;
+}
+
+// torchdiffeq's `_adaptive_step` decisions on the error norm of the attempt just made (thread 0 decides).  Called by the whole
+// workgroup of cnf_step_dev_kernel that finishes LAST (every partial sum is in place by then).
+__device__ __forceinline__ void cnf_ctl_update(double* ctl, const double* partial, int nblocks, double* red4) {
+    const double sum = cnf_partial_total(partial, nblocks, red4);
     if (threadIdx.x != 0) return;
     const double ratio = sqrt(sum / ctl[CTL_NTOT]);
     const double t = ctl[CTL_T], dt = ctl[CTL_DT], t1 = ctl[CTL_T1];
@@ -353,13 +382,18 @@ struct CnfDevArgs {
     int rows, R, ntiles;
 };
 
+__device__ __forceinline__ bool cnf_gate_row(int r) { return r < 64 || (r >= 128 && r < 192) || (r >= 256 && r < 272); }
+
 // CTX_LDS (inverse direction, R >= 4 rows per original point): the context rows of the workgroup's 64 / R points are copied
 // to LDS once per tile and all six stage evaluations read them there - each evaluation re-read 1 152 B per row from L2 before
-template <bool CTX_LDS>
+// SPLIT (with CTX_LDS; the caller's PF_CNF_SPLIT_GATES): see cnf_eval.
+template <bool CTX_LDS, bool SPLIT>
 __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_dev_kernel(CnfDevArgs a) {
+    static_assert(!SPLIT || CTX_LDS, "the split gates live in the LDS context rows");
     __shared__ f4 wl[CNF_REC / 4];
     __shared__ double red[CNF_NW];
     __shared__ f4 sctx[CTX_LDS ? 16 * CNF_CTX / 4 : 1];
+    __shared__ float stf[SPLIT ? 6 * CNF_CTX : 1];                   // [stage][row]: 2^(gt tsign alpha_s h) on the gate rows
     if (a.ctl[CTL_DONE] != 0.0) return;                              // uniform over the grid
     const int cur = (int)a.ctl[CTL_CUR];
     const float t = (float)a.ctl[CTL_T], h = (float)a.ctl[CTL_DT];
@@ -394,6 +428,13 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_dev_kernel(CnfDevArgs a)
     constexpr float CM[7] = {(float)(6025192743. / 30085553152 / 2), 0, (float)(51252292925. / 65400821598 / 2),
                              (float)(-2691868925. / 45128329728 / 2), (float)(187940372067. / 1594534317056 / 2),
                              (float)(-1776094331. / 19743644256 / 2), (float)(11237099. / 235043384 / 2)};
+    if (SPLIT) {
+        const float* tv = w.rec + 9872;
+        for (int i = threadIdx.x; i < 6 * CNF_CTX; i += CNF_NW * 64) {
+            const int s = i / CNF_CTX, r = i % CNF_CTX;
+            stf[i] = cnf_gate_row(r) ? __builtin_amdgcn_exp2f(tv[r] * (tsign * AL[s] * h)) : 0.f;
+        }                                                             // (visible after the tile loop's barriers)
+    }
     double acc = 0.0;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int g = (tile * CNF_NW + wave) * 16 + col;
@@ -409,7 +450,14 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_dev_kernel(CnfDevArgs a)
             __syncthreads();                                       // every wave is done with the previous tile's rows
             for (int i = threadIdx.x; i < ppw * (CNF_CTX / 4); i += CNF_NW * 64) {
                 const long long pp = p0 + i / (CNF_CTX / 4);
-                sctx[i] = reinterpret_cast<const f4*>(a.ctx)[(pp < npts ? pp : npts - 1) * (CNF_CTX / 4) + i % (CNF_CTX / 4)];
+                f4 v = reinterpret_cast<const f4*>(a.ctx)[(pp < npts ? pp : npts - 1) * (CNF_CTX / 4) + i % (CNF_CTX / 4)];
+                if (SPLIT && cnf_gate_row(4 * (i % (CNF_CTX / 4)))) {  // the gate rows become 2^(gt tsign t + gc), once per point
+                    const f4 g4 = *reinterpret_cast<const f4*>(w.rec + 9872 + 4 * (i % (CNF_CTX / 4)));
+                    const float tt = tsign * t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_exp2f(fmaf(g4[r], tt, v[r]));
+                }
+                sctx[i] = v;
             }
             __syncthreads();
             const long long pl = pt - p0;                            // a clamped out-of-range lane may point past the tile
@@ -425,7 +473,7 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_dev_kernel(CnfDevArgs a)
 #pragma unroll
             for (int j = 1; j <= s; ++j) comb += k[j] * BE[s][j];
             yi = y0 + comb * h;
-            k[s + 1] = cnf_eval(w, q, yi, tsign * (t + AL[s] * h), sgn, cx, e0, e1, e2);
+            k[s + 1] = cnf_eval<SPLIT>(w, q, yi, tsign * (t + AL[s] * h), sgn, cx, e0, e1, e2, stf + (SPLIT ? s * CNF_CTX : 0));
         });
         f4 err = k[0] * CE[0];
 #pragma unroll
@@ -471,32 +519,113 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_step_dev_kernel(CnfDevArgs a)
         if (last) *counter = 0u;
     }
     __syncthreads();
-    if (last && threadIdx.x < 64) cnf_ctl_update(a.ctl, a.partial, (int)gridDim.x);
+    if (last) cnf_ctl_update(a.ctl, a.partial, (int)gridDim.x, red);                     // `last` is uniform over the workgroup
 }
 
-// torchdiffeq's `_select_initial_step` (oracle/cnf_ref.py::dopri5, first lines) in two one-thread kernels around the
-// probe evaluation f(t0 + h0, y0 + h0 f0).  red: [0] sumsq(y0 / scale) [1] sumsq(f0 / scale) [2] sumsq((f1 - f0) / scale)
-__global__ void cnf_ctl_reset_kernel(double* ctl, double t0, double t1, double n_tot, double reverse) {
-    if (threadIdx.x < 16 && blockIdx.x == 0) {
-        const int i = threadIdx.x;
-        ctl[i] = i == CTL_T ? t0 : i == CTL_T1 ? t1 : i == CTL_NTOT ? n_tot : i == CTL_REV ? reverse : 0.0;
+// torchdiffeq's `_select_initial_step` (oracle/cnf_ref.py::dopri5, first lines) around the probe evaluation
+// f(t0 + h0, y0 + h0 f0): d0 = rms(y0 / scale), d1 = rms(f0 / scale), d2 = rms((f1 - f0) / scale) / h0.
+// The same start in TWO launches (it was 13: reset, f0, two norms of two launches each, init_a, the probe, its norm, init_b -
+// ~5 us of timeline apiece, twelve integrations per forward).  Launch A builds the state rows (x, 0) from the caller's points
+// (row stride 3 or 4: the previous block's state is taken as it lies), evaluates f0 and sums |y0 / scale|^2 and |f0 / scale|^2;
+// launch B evaluates the probe f(t0 + h0, y0 + h0 f0) and sums |(f1 - f0) / scale|^2 without storing f1.  In both, the
+// workgroup that finishes last adds the per-workgroup sums in a fixed order and takes the one-thread decision.
+struct CnfInitArgs {
+    double* ctl;
+    const float* x; int xs;   // A: points, row stride in floats
+    float* y;                 // [rows,4]  A: written, B: read
+    float* f0;                // [rows,4]  A: written, B: read
+    const float* ctx; const float* e; const float* rec;
+    double t0, t1, n_tot, extra_d0, reverse;
+    float sgn, rtol, atol;
+    int rows, R, ntiles;
+    double* partial;          // [3][1024]
+};
+
+template <bool PROBE>
+__global__ __launch_bounds__(CNF_NW * 64) void cnf_init_kernel(CnfInitArgs a) {
+    __shared__ f4 wl[CNF_REC / 4];
+    __shared__ double red[2][CNF_NW];
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    const CnfW w = cnf_stage_weights(wl, a.rec, CNF_NW * 64, lane);
+    float h = 0.f, t = (float)(a.reverse != 0.0 ? -a.t0 : a.t0);
+    if (PROBE) {
+        const double hd = a.ctl[CTL_H0], td = a.ctl[CTL_T] + hd;
+        h = (float)hd;
+        t = (float)(a.ctl[CTL_REV] != 0.0 ? -td : td);
     }
-}
-__global__ void cnf_init_a_kernel(double* ctl, const double* red, double extra_d0) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double n = ctl[CTL_NTOT];
-    const double d0 = sqrt((red[0] + extra_d0) / n), d1 = sqrt(red[1] / n);
-    ctl[CTL_H0] = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-    ctl[CTL_D1] = d1;
-}
-__global__ void cnf_init_b_kernel(double* ctl, const double* red) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double h0 = ctl[CTL_H0], d1 = ctl[CTL_D1];
-    const double d2 = sqrt(red[2] / ctl[CTL_NTOT]) / h0;
-    const double dm = d1 > d2 ? d1 : d2;
-    const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? (1e-6 > h0 * 1e-3 ? 1e-6 : h0 * 1e-3) : pow(0.01 / dm, 1.0 / 5.0);
-    ctl[CTL_DT] = 100.0 * h0 < h1 ? 100.0 * h0 : h1;
-    ctl[CTL_NFE] = 2.0;
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int g = (tile * CNF_NW + wave) * 16 + col;
+        const bool ok = g < a.rows;
+        const int row = ok ? g : a.rows - 1;
+        const int pt = row / a.R;
+        f4 y0, f0 = pf_splat(0.f);
+        if (PROBE) {
+            y0 = *reinterpret_cast<const f4*>(a.y + (size_t)row * 4);
+            f0 = *reinterpret_cast<const f4*>(a.f0 + (size_t)row * 4);
+        } else {
+            const float* xp = a.x + (size_t)row * a.xs;
+            y0 = (f4){xp[0], xp[1], xp[2], 0.f};
+            if (ok && q == 0) *reinterpret_cast<f4*>(a.y + (size_t)row * 4) = y0;
+        }
+        f4 y = y0;
+        if (PROBE) y += f0 * (h * 1.f);
+        const float* cx = a.ctx + (size_t)pt * CNF_CTX;
+        const f4 k = cnf_eval(w, q, y, t, a.sgn, cx, a.e[(size_t)pt * 3 + 0], a.e[(size_t)pt * 3 + 1], a.e[(size_t)pt * 3 + 2]);
+        if (ok && q == 0) {
+            if (!PROBE) *reinterpret_cast<f4*>(a.f0 + (size_t)row * 4) = k;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float sc = a.atol + a.rtol * fabsf(y0[c]);
+                if (PROBE) {
+                    const float r = (k[c] - f0[c]) / sc;
+                    acc0 += (double)r * (double)r;
+                } else {
+                    const float r0 = y0[c] / sc, r1 = k[c] / sc;
+                    acc0 += (double)r0 * (double)r0;
+                    acc1 += (double)r1 * (double)r1;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { acc0 += __shfl_xor(acc0, m); acc1 += __shfl_xor(acc1, m); }
+    if (lane == 0) { red[0][wave] = acc0; red[1][wave] = acc1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < CNF_NW; ++i) { s0 += red[0][i]; s1 += red[1][i]; }
+        __hip_atomic_store(a.partial + (PROBE ? 2048 : 0) + blockIdx.x, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!PROBE) __hip_atomic_store(a.partial + 1024 + blockIdx.x, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* counter = reinterpret_cast<unsigned*>(a.ctl + CTL_ARRIVE);
+        last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1 : 0;
+        if (last) *counter = 0u;
+    }
+    __syncthreads();
+    if (!last) return;                                                                   // uniform over the workgroup
+    double* ctl = a.ctl;
+    if (PROBE) {
+        const double r2 = cnf_partial_total(a.partial + 2048, (int)gridDim.x, red[0]);
+        if (threadIdx.x != 0) return;
+        const double h0 = ctl[CTL_H0], d1 = ctl[CTL_D1];
+        const double d2 = sqrt(r2 / ctl[CTL_NTOT]) / h0;
+        const double dm = d1 > d2 ? d1 : d2;
+        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? (1e-6 > h0 * 1e-3 ? 1e-6 : h0 * 1e-3) : pow(0.01 / dm, 1.0 / 5.0);
+        ctl[CTL_DT] = 100.0 * h0 < h1 ? 100.0 * h0 : h1;
+        ctl[CTL_NFE] = 2.0;
+    } else {
+        const double r0 = cnf_partial_total(a.partial, (int)gridDim.x, red[0]);
+        const double r1 = cnf_partial_total(a.partial + 1024, (int)gridDim.x, red[0]);
+        if (threadIdx.x != 0) return;
+        for (int i = 0; i < 16; ++i)
+            ctl[i] = i == CTL_T ? a.t0 : i == CTL_T1 ? a.t1 : i == CTL_NTOT ? a.n_tot : i == CTL_REV ? a.reverse : 0.0;
+        const double d0 = sqrt((r0 + a.extra_d0) / a.n_tot), d1 = sqrt(r1 / a.n_tot);
+        ctl[CTL_H0] = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        ctl[CTL_D1] = d1;
+    }
 }
 
 // ---- Runge-Kutta bookkeeping -----------------------------------------------------------------------
@@ -644,9 +773,11 @@ extern "C" int pf_cnf_step(const float* y0, const float* f0, float t, float h, i
 // controller's decision is taken inside each attempt's launch by the workgroup that finishes last: no host synchronisation.  ya / yb and fa / fb: the two state and derivative buffers
 // ([rows,4]; ctl's `cur` says which one holds the current state), out: the solution at t1 once ctl's `done` is set with
 // status 0.  ws: >= 1024 doubles.
+// flags: PF_CNF_SPLIT_GATES - the caller vouches that log2(e) max|gate time weight| |t1 - t0| <= 100 for this record
+// (packing.cnf_split_ok); the gates' 2^x then factor into a per-point and a per-stage part without overflow (cnf_eval).
 extern "C" int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float* fb, const float* ctx, const float* e,
                             const float* rec, float* out, float rtol, float atol, int rows, int R, int n_attempts, double* ws,
-                            void* stream) {
+                            int flags, void* stream) {
     if (!ctl || !ya || !yb || !fa || !fb || !ctx || !e || !rec || !out || !ws) return PF_ERR_NULL;
     if (rows <= 0 || R <= 0 || n_attempts <= 0) return PF_ERR_SHAPE;
     CnfDevArgs a{};
@@ -657,39 +788,34 @@ extern "C" int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float*
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < n_attempts; ++i) {
         // context rows through LDS when a tile's 64 rows belong to <= 16 whole points
-        if (R >= 4 && (CNF_NW * 16) % R == 0) hipLaunchKernelGGL(cnf_step_dev_kernel<true>, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
-        else hipLaunchKernelGGL(cnf_step_dev_kernel<false>, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+        if (R >= 4 && (CNF_NW * 16) % R == 0) {
+            if (flags & PF_CNF_SPLIT_GATES) hipLaunchKernelGGL((cnf_step_dev_kernel<true, true>), dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+            else hipLaunchKernelGGL((cnf_step_dev_kernel<true, false>), dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((cnf_step_dev_kernel<false, false>), dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+        }
     }
     return pf_last_launch_status();
 }
 
-// The start of an adaptive integration over [t0, t1] (solver time; the network sees -t when reverse), all on the device:
-// resets the controller state, f0 = f(t0, y) into `f0`, torchdiffeq's initial step size into ctl[1].  ftmp: [rows,4] scratch
-// for the probe evaluation.  n_tot: elements of the RMS norms (rows*4 + the log-density rows torchdiffeq integrates
-// alongside), extra_d0: what those extra rows add to the squared norm of y0.  ws: >= 256 doubles, red: 3 doubles.
-extern "C" int pf_cnf_init(double* ctl, const float* y, float* f0, float* ftmp, const float* ctx, const float* e,
+// The start of an adaptive integration over [t0, t1] (solver time; the network sees -t when reverse), all on the device, two
+// launches (cnf_init_kernel): the state rows y = (x, 0) from the points x (row stride x_stride = 3 or 4 floats), f0 = f(t0, y),
+// the controller state reset, torchdiffeq's initial step size into ctl[1].  n_tot: elements of the RMS norms (rows*4 + the
+// context rows torchdiffeq integrates alongside), extra_d0: what those extra rows add to the squared norm of y0.
+// ws: >= 3072 doubles.  ctl: 16 doubles, ALL ZERO before its first use (the arrival word at [13] is left zero by every launch).
+extern "C" int pf_cnf_init(double* ctl, const float* x, int x_stride, float* y, float* f0, const float* ctx, const float* e,
                            const float* rec, double t0, double t1, double n_tot, double extra_d0, int reverse, float rtol,
-                           float atol, int rows, int R, double* ws, double* red, void* stream) {
-    if (!ctl || !y || !f0 || !ftmp || !ctx || !e || !rec || !ws || !red) return PF_ERR_NULL;
-    if (rows <= 0 || R <= 0 || !(n_tot > 0.0)) return PF_ERR_SHAPE;
+                           float atol, int rows, int R, double* ws, void* stream) {
+    if (!ctl || !x || !y || !f0 || !ctx || !e || !rec || !ws) return PF_ERR_NULL;
+    if (rows <= 0 || R <= 0 || !(n_tot > 0.0) || (x_stride != 3 && x_stride != 4)) return PF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const float sgn = reverse ? -1.f : 1.f;
-    hipLaunchKernelGGL(cnf_ctl_reset_kernel, dim3(1), dim3(64), 0, s, ctl, t0, t1, n_tot, reverse ? 1.0 : 0.0);
-    int st = pf_cnf_rhs(y, nullptr, nullptr, 0, 0.f, (float)(reverse ? -t0 : t0), sgn, ctx, e, rec, f0, nullptr, rows, R, stream);
-    if (st) return st;
-    const long long n = (long long)rows * 4;
-    if ((st = pf_scaled_sumsq(y, nullptr, y, nullptr, nullptr, nullptr, 0, 0.f, rtol, atol, n, ws, red + 0, stream))) return st;
-    if ((st = pf_scaled_sumsq(f0, nullptr, y, nullptr, nullptr, nullptr, 0, 0.f, rtol, atol, n, ws, red + 1, stream))) return st;
-    hipLaunchKernelGGL(cnf_init_a_kernel, dim3(1), dim3(64), 0, s, ctl, red, extra_d0);
-    {
-        CnfArgs a{};
-        a.y0 = y; a.k = f0; a.ncoef = 1; a.coef[0] = 1.f; a.sgn = sgn; a.ctx = ctx; a.e = e; a.rec = rec;
-        a.kout = ftmp; a.yout = nullptr; a.rows = rows; a.R = R; a.ctl = ctl;
-        a.ntiles = (rows + CNF_NW * 16 - 1) / (CNF_NW * 16);
-        const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
-        hipLaunchKernelGGL(cnf_rhs_kernel, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
-    }
-    if ((st = pf_scaled_sumsq(ftmp, f0, y, nullptr, nullptr, nullptr, 0, 0.f, rtol, atol, n, ws, red + 2, stream))) return st;
-    hipLaunchKernelGGL(cnf_init_b_kernel, dim3(1), dim3(64), 0, s, ctl, red);
+    CnfInitArgs a{};
+    a.ctl = ctl; a.x = x; a.xs = x_stride; a.y = y; a.f0 = f0; a.ctx = ctx; a.e = e; a.rec = rec;
+    a.t0 = t0; a.t1 = t1; a.n_tot = n_tot; a.extra_d0 = extra_d0; a.reverse = reverse ? 1.0 : 0.0;
+    a.sgn = reverse ? -1.f : 1.f; a.rtol = rtol; a.atol = atol; a.rows = rows; a.R = R; a.partial = ws;
+    a.ntiles = (rows + CNF_NW * 16 - 1) / (CNF_NW * 16);
+    const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
+    hipLaunchKernelGGL(cnf_init_kernel<false>, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+    hipLaunchKernelGGL(cnf_init_kernel<true>, dim3(grid), dim3(CNF_NW * 64), 0, s, a);
     return pf_last_launch_status();
 }

@@ -537,6 +537,14 @@ def _np32(t) -> np.ndarray:
 LOG2E = 1.4426950408889634
 
 
+def cnf_split_ok(rec, T_end: float) -> bool:
+    """May pf_cnf_steps take PF_CNF_SPLIT_GATES for this record?  The gate rows of its time vector already carry -log2e; the
+    per-stage factor 2^(gt alpha h) has |h| <= T_end, and 2^100 x (any fp32 2^x) neither overflows to NaN nor loses a gate bit."""
+    tv = np.asarray(rec[9872:9872 + CNF_CTX], np.float64)
+    g = np.concatenate([tv[0:64], tv[128:192], tv[256:272]])
+    return bool(np.abs(g).max() * abs(T_end) <= 100.0)
+
+
 def pack_cnf_block(sd, i: int):
     """-> (rec [CNF_REC] fp32, Hc [288, cdim], hb [288], T_end).  A ConcatSquash layer (diffeq_layers.py:72-86) is
     (W x + b) * sigmoid(Wg [t; c] + bg) + Wb [t; c]: the c-columns of Wg / Wb form the context GEMM `Hc` (with bg

@@ -278,3 +278,24 @@ def test_deferred_forward_equals_the_look_per_batch_loop():
         assert torch.equal(res[name]["x"], res["loop"]["x"]) and torch.equal(res[name]["z"], res["loop"]["z"])
         assert torch.equal(res[name]["ldj"], res["loop"]["ldj"])
         assert (res[name]["nfe"], res[name]["accepted"], res[name]["rejected"]) == (res["loop"]["nfe"], res["loop"]["accepted"], res["loop"]["rejected"])
+
+
+def test_split_gate_kernel_agrees_with_the_plain_one(golden_dir):
+    """PF_CNF_SPLIT_GATES (the inverse pass's step kernel computes 2^(gt t + gc) once per point and step and 2^(gt alpha h) once
+    per stage instead of one v_exp_f32 per gate and evaluation): same step sequence as the plain kernel on the trained
+    checkpoint, and a result no farther from it than the fp32 oracle is from its own float64 evaluation."""
+    g, sd = _pretrained(golden_dir)
+    net = _net(sd)
+    xyz = torch.from_numpy(g["xyz"]).to(DEV)
+    noise = [n.to(DEV) for n in torch.from_numpy(g["noise"])]
+    eng = net._engine(4)
+    assert eng.split == [1] * 6
+    res = {}
+    for name, flags in (("split", [1] * 6), ("plain", [0] * 6)):
+        eng.split = flags
+        res[name] = net(xyz, 4, noise=noise, stages=True)
+    a, b = res["split"], res["plain"]
+    assert abs(a["accepted"] - b["accepted"]) <= 1 and abs(a["rejected"] - b["rejected"]) <= 1
+    scale = float(b["x"].abs().max())
+    assert float((a["x"] - b["x"]).abs().max()) <= 2e-4 * scale        # the ODEs amplify one rounding difference (fp64 anchor test)
+    assert float((a["ldj"] - b["ldj"]).abs().max()) <= 2e-4 * max(1.0, float(b["ldj"].abs().max()))

@@ -144,3 +144,17 @@ def test_float64_anchor_of_the_oracle_on_the_trained_checkpoint(golden_dir):
     assert 400 <= o32["nfe"] <= 520 and o32["rejected"] >= 5 and abs(o32["nfe"] - o64["nfe"]) <= 24
     assert (o32["x"].double() - o64["x"]).abs().max() < 5e-3 and float(o64["x"].abs().max()) < 1.5
     assert (o32["z"].double() - o64["z"]).abs().max() < 5e-2 and 0.5 < float(o64["z"].std()) < 1.5      # latents ~ N(0, 1)
+
+
+def test_split_gates_flag_follows_the_overflow_bound(golden_dir):
+    """packing.cnf_split_ok: the trained checkpoint's blocks qualify (T = 36.3 x max|gt| 0.93 x log2e = 48.5 <= 100); a record
+    whose gate time weights could push the per-stage factor 2^(gt alpha h) past 2^100 does not."""
+    from puflow_amd.packing import cnf_split_ok, pack_cnf_block
+    _, sd = _pretrained(golden_dir)
+    for i in range(6):
+        rec, _, _, T = pack_cnf_block(sd, i)
+        assert cnf_split_ok(rec, T)
+    big = {k: v.clone() for k, v in sd.items()}
+    big["flow_blocks.5.cnf.odefunc.diffeq.layers.1._hyper_gate.weight"][7, 0] = 2.5
+    rec, _, _, T = pack_cnf_block(big, 5)
+    assert not cnf_split_ok(rec, T)

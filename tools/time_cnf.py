@@ -19,6 +19,8 @@ for it in range(int(os.environ.get("PF_TIME_CNF_ITERS", "3"))):
     x, logp = net(xyz, 4, noise=noise)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     print(f"forward {B} x {N} -> x4: {el * 1e3:8.2f} ms  ({B / el:8.1f} patches/s)  {net.last_stats}", flush=True)
+if os.environ.get("PF_TIME_CNF_NO_RHS"):        # tools/trace_sequence.sh: the trace ends with a forward
+    raise SystemExit(0)
 eng = net._engine(4)
 T = B * N
 ctx = torch.randn(T, 288, device="cuda"); e = noise[0].reshape(T, 3)
