@@ -572,12 +572,13 @@ int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float* fb, const 
 
 /* The start of that integration over [t0, t1] on the device, in two launches: the state rows y = (x, 0) from the points x
  * (row stride x_stride = 3 or 4 floats - a previous block's [rows,4] state is read in place), f0 = f(t0, y), ctl reset,
- * torchdiffeq's `_select_initial_step` into ctl[1].  n_tot / extra_d0: elements of the RMS norm and what the state rows
- * outside y add to |y0|^2.  ws: >= 3072 doubles.  ctl: ALL ZERO before its first use (every launch leaves its arrival word,
+ * torchdiffeq's `_select_initial_step` into ctl[1].  n_tot: elements of the RMS norm; extra_d0 (DEVICE double, nullable)
+ * x extra_scale: what the state rows outside y add to |y0 / scale|^2 (the context: pf_scaled_sumsq(c, NULL, c, ...)); no host
+ * read anywhere in an integration's start.  ws: >= 3072 doubles.  ctl: ALL ZERO before its first use (every launch leaves its arrival word,
  * ctl[13], zero again). */
 int pf_cnf_init(double* ctl, const float* x, int x_stride, float* y, float* f0, const float* ctx, const float* e,
-                const float* rec, double t0, double t1, double n_tot, double extra_d0, int reverse, float rtol, float atol,
-                int rows, int R, double* ws, void* stream);
+                const float* rec, double t0, double t1, double n_tot, const double* extra_d0, double extra_scale, int reverse,
+                float rtol, float atol, int rows, int R, double* ws, void* stream);
 
 /* out[i] = sum_{j<n_terms} w[j] * ptrs[j][i]   (n_terms <= 8; ptrs / w are HOST arrays).  Runge-Kutta solution,
  * mid-point and dense-output combinations of torchdiffeq's dopri5 (cnf.py:97-113 call site). */

@@ -181,13 +181,20 @@ class _CnfEngine:
         return float(self.red.item())                       # the one device->host read per norm
 
     # ---- dopri5 (control flow of torchdiffeq's adaptive solver, restated: oracle/cnf_ref.py::dopri5) ------
+    def context_norm(self, c: Tensor, out: Tensor) -> None:
+        """out[0] (device double) = sum (c / (atol + rtol |c|))^2: the context's share of the solver's initial-step norm."""
+        _lib.check(self.lib.pf_scaled_sumsq(c.data_ptr(), None, c.data_ptr(), None, None, (ctypes.c_float * 1)(0.0), 0, 0.0,
+                                            RTOL, ATOL, c.numel(), self.ws.data_ptr(), out.data_ptr(), self._stream()),
+                   "pf_scaled_sumsq")
+
     def integrate(self, i: int, x: Tensor, ctx: Tensor, e: Tensor, R: int, reverse: bool, extra_n: int,
-                  extra_d0: float, log: Optional[Tensor] = None, blind: int = 0) -> Tensor:
+                  extra_d0, log: Optional[Tensor] = None, blind: int = 0, extra_scale: float = 1.0) -> Tensor:
         """x [rows, >= 3] (row stride 3 or 4 floats: a previous block's state is taken as it lies) -> state [rows,4] =
         (x', delta logp) at the end time of block i.
         log (a [16] double device row, zero before its first use): do not look at the controller - `log` IS the controller
         state of this integration; enqueue `blind` attempts and return; the caller checks all rows once (`check_logs`).
-        Otherwise the look-per-batch loop, which also leaves the number of attempts it took in `self.last_attempts`."""
+        Otherwise the look-per-batch loop, which also leaves the number of attempts it took in `self.last_attempts`.
+        extra_d0: a device double (or a python float / 0) x extra_scale - the context rows' share of |y0 / scale|^2."""
         rows = x.shape[0]
         dev = x.device
         T = self.T_end[i]
@@ -205,8 +212,11 @@ class _CnfEngine:
         # the state rows (x, 0), f0 and torchdiffeq's initial step size, on the device in two launches (csrc/cnf.hip:
         # pf_cnf_init); the controller state follows
         ctl = self.ctl if log is None else log
+        if not isinstance(extra_d0, torch.Tensor):
+            extra_d0 = torch.tensor([float(extra_d0)], dtype=torch.float64, device=dev) if extra_d0 else None
         _lib.check(self.lib.pf_cnf_init(ctl.data_ptr(), x.data_ptr(), int(x.stride(0)), y.data_ptr(), f0.data_ptr(),
-                                        ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), t0, t1, n_tot, float(extra_d0),
+                                        ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), t0, t1, n_tot,
+                                        extra_d0.data_ptr() if extra_d0 is not None else None, float(extra_scale),
                                         1 if reverse else 0, RTOL, ATOL, rows, R, self.ws3k.data_ptr(), self._stream()),
                    "pf_cnf_init")
 
@@ -320,10 +330,13 @@ class PointInterpFlow(nn.Module):
         if noise is None:
             noise = [torch.randn(B, N, 3, device=xyz.device) for _ in range(NUM_BLOCKS)]
         es = [n.reshape(T, 3).contiguous().float() for n in noise]
-        cflat = [c.reshape(T, -1) for c in cs]
+        cflat = [c.reshape(T, -1).contiguous() for c in cs]
         ctx = [eng.context(i, cflat[i]) for i in range(NUM_BLOCKS)]
-        # the context is a state of the reference's ODE (zero derivative): it only enters the solver's norms (one read for all six)
-        d0c = torch.stack([((c / (ATOL + RTOL * c.abs())) ** 2).sum(dtype=torch.float64) for c in cflat]).tolist()
+        # the context is a state of the reference's ODE (zero derivative): it only enters the solver's norms.  Six device words
+        # (it was seven torch kernels per block and one host read in the middle of the forward)
+        d0c = torch.empty(NUM_BLOCKS, dtype=torch.float64, device=xyz.device)
+        for i in range(NUM_BLOCKS):
+            eng.context_norm(cflat[i], d0c[i:i + 1])
 
         def run(deferred: bool):
             """f, interpolation, g.  deferred: no look at a controller until all twelve integrations are enqueued."""
@@ -332,7 +345,7 @@ class PointInterpFlow(nn.Module):
             p = xyz.reshape(T, 3)
             sts = []
             for i in range(NUM_BLOCKS):
-                p = eng.integrate(i, p, ctx[i], es[i], 1, False, cflat[i].numel(), d0c[i], eng.logs[k] if deferred else None,
+                p = eng.integrate(i, p, ctx[i], es[i], 1, False, cflat[i].numel(), d0c[i:i + 1], eng.logs[k] if deferred else None,
                                   blind[k] if deferred else 0)            # [T,4]: the next block reads its first three columns in place
                 took.append(getattr(eng, "last_attempts", 0))
                 k += 1
@@ -343,8 +356,8 @@ class PointInterpFlow(nn.Module):
             logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + math.log(2 * math.pi)), dim=(1, 2)) - ldj)
             u = base.interp(xyz, z.contiguous(), idx16, upratio).reshape(T * upratio, 3)            # row n*R + r
             for i in reversed(range(NUM_BLOCKS)):
-                u = eng.integrate(i, u, ctx[i], es[i], upratio, True, cflat[i].numel() * upratio, d0c[i] * upratio,
-                                  eng.logs[k] if deferred else None, blind[k] if deferred else 0)
+                u = eng.integrate(i, u, ctx[i], es[i], upratio, True, cflat[i].numel() * upratio, d0c[i:i + 1],
+                                  eng.logs[k] if deferred else None, blind[k] if deferred else 0, extra_scale=float(upratio))
                 took.append(getattr(eng, "last_attempts", 0))
                 k += 1
             return z, ldj, logp, u[:, :3].contiguous()
@@ -353,12 +366,12 @@ class PointInterpFlow(nn.Module):
         # bubble).  Now the whole forward is enqueued blind and the twelve final controller states are read ONCE; an integration
         # that did not finish inside its attempts (or hit an error state) sends the forward through the look-per-batch loop,
         # which also raises the errors.  Same arithmetic either way: attempts past the end of an integration are no-ops.
-        # How many attempts to enqueue blind: what each integration took on the previous forward + a quarter + 3 (the first
+        # How many attempts to enqueue blind: what each integration took on the previous forward + an eighth + 2 (the first
         # forward of an engine, and any forward whose guess was too small, takes the loop and leaves the counts).
         done = False
         took: List[int] = []
         if eng.async_attempts > 0 and eng.hint is not None:
-            blind = [h + h // 4 + 3 for h in eng.hint]
+            blind = [h + h // 8 + 2 for h in eng.hint]
             z, ldj, logp, u = run(True)
             done = eng.check_logs(2 * NUM_BLOCKS)
         if not done:

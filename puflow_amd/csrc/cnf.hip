@@ -535,7 +535,8 @@ struct CnfInitArgs {
     float* y;                 // [rows,4]  A: written, B: read
     float* f0;                // [rows,4]  A: written, B: read
     const float* ctx; const float* e; const float* rec;
-    double t0, t1, n_tot, extra_d0, reverse;
+    double t0, t1, n_tot, extra_scale, reverse;
+    const double* extra_d0;   // nullable device word: what the state rows outside y add to |y0 / scale|^2 (x extra_scale)
     float sgn, rtol, atol;
     int rows, R, ntiles;
     double* partial;          // [3][1024]
@@ -622,7 +623,8 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_init_kernel(CnfInitArgs a) {
         if (threadIdx.x != 0) return;
         for (int i = 0; i < 16; ++i)
             ctl[i] = i == CTL_T ? a.t0 : i == CTL_T1 ? a.t1 : i == CTL_NTOT ? a.n_tot : i == CTL_REV ? a.reverse : 0.0;
-        const double d0 = sqrt((r0 + a.extra_d0) / a.n_tot), d1 = sqrt(r1 / a.n_tot);
+        const double extra = a.extra_d0 ? a.extra_d0[0] * a.extra_scale : 0.0;
+        const double d0 = sqrt((r0 + extra) / a.n_tot), d1 = sqrt(r1 / a.n_tot);
         ctl[CTL_H0] = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
         ctl[CTL_D1] = d1;
     }
@@ -801,17 +803,18 @@ extern "C" int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float*
 // The start of an adaptive integration over [t0, t1] (solver time; the network sees -t when reverse), all on the device, two
 // launches (cnf_init_kernel): the state rows y = (x, 0) from the points x (row stride x_stride = 3 or 4 floats), f0 = f(t0, y),
 // the controller state reset, torchdiffeq's initial step size into ctl[1].  n_tot: elements of the RMS norms (rows*4 + the
-// context rows torchdiffeq integrates alongside), extra_d0: what those extra rows add to the squared norm of y0.
+// context rows torchdiffeq integrates alongside), extra_d0 (a DEVICE double, nullable) x extra_scale: what those extra rows
+// add to the squared norm of y0 (pf_scaled_sumsq of the context with itself as the scale; the host never reads it).
 // ws: >= 3072 doubles.  ctl: 16 doubles, ALL ZERO before its first use (the arrival word at [13] is left zero by every launch).
 extern "C" int pf_cnf_init(double* ctl, const float* x, int x_stride, float* y, float* f0, const float* ctx, const float* e,
-                           const float* rec, double t0, double t1, double n_tot, double extra_d0, int reverse, float rtol,
-                           float atol, int rows, int R, double* ws, void* stream) {
+                           const float* rec, double t0, double t1, double n_tot, const double* extra_d0, double extra_scale,
+                           int reverse, float rtol, float atol, int rows, int R, double* ws, void* stream) {
     if (!ctl || !x || !y || !f0 || !ctx || !e || !rec || !ws) return PF_ERR_NULL;
     if (rows <= 0 || R <= 0 || !(n_tot > 0.0) || (x_stride != 3 && x_stride != 4)) return PF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     CnfInitArgs a{};
     a.ctl = ctl; a.x = x; a.xs = x_stride; a.y = y; a.f0 = f0; a.ctx = ctx; a.e = e; a.rec = rec;
-    a.t0 = t0; a.t1 = t1; a.n_tot = n_tot; a.extra_d0 = extra_d0; a.reverse = reverse ? 1.0 : 0.0;
+    a.t0 = t0; a.t1 = t1; a.n_tot = n_tot; a.extra_d0 = extra_d0; a.extra_scale = extra_scale; a.reverse = reverse ? 1.0 : 0.0;
     a.sgn = reverse ? -1.f : 1.f; a.rtol = rtol; a.atol = atol; a.rows = rows; a.R = R; a.partial = ws;
     a.ntiles = (rows + CNF_NW * 16 - 1) / (CNF_NW * 16);
     const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
