@@ -26,7 +26,13 @@ namespace {
 
 constexpr int CNF_REC = 10160;
 constexpr int CNF_CTX = 288;
-constexpr int CNF_NW = 4;                 // waves per workgroup
+#ifndef PF_CNF_NW
+#define PF_CNF_NW 4
+#endif
+#ifndef PF_CNF_WPE
+#define PF_CNF_WPE 2                      // waves per SIMD the step kernels are compiled for (register budget 512 / WPE)
+#endif
+constexpr int CNF_NW = PF_CNF_NW;         // waves per workgroup
 
 constexpr int CTL_T = 0, CTL_DT = 1, CTL_T1 = 2, CTL_NTOT = 3, CTL_CUR = 4, CTL_DONE = 5, CTL_ACC = 6, CTL_REJ = 7, CTL_NFE = 8,
               CTL_STATUS = 9, CTL_REV = 10, CTL_H0 = 11, CTL_D1 = 12,    // device-side dopri5 state, see cnf_ctl_update
@@ -388,11 +394,11 @@ __device__ __forceinline__ bool cnf_gate_row(int r) { return r < 64 || (r >= 128
 // to LDS once per tile and all six stage evaluations read them there - each evaluation re-read 1 152 B per row from L2 before
 // SPLIT (with CTX_LDS; the caller's PF_CNF_SPLIT_GATES): see cnf_eval.
 template <bool CTX_LDS, bool SPLIT>
-__global__ __launch_bounds__(CNF_NW * 64) void cnf_step_dev_kernel(CnfDevArgs a) {
+__global__ __launch_bounds__(CNF_NW * 64, PF_CNF_WPE) void cnf_step_dev_kernel(CnfDevArgs a) {
     static_assert(!SPLIT || CTX_LDS, "the split gates live in the LDS context rows");
     __shared__ f4 wl[CNF_REC / 4];
     __shared__ double red[CNF_NW];
-    __shared__ f4 sctx[CTX_LDS ? 16 * CNF_CTX / 4 : 1];
+    __shared__ f4 sctx[CTX_LDS ? CNF_NW * 4 * CNF_CTX / 4 : 1];
     __shared__ float stf[SPLIT ? 6 * CNF_CTX : 1];                   // [stage][row]: 2^(gt tsign alpha_s h) on the gate rows
     if (a.ctl[CTL_DONE] != 0.0) return;                              // uniform over the grid
     const int cur = (int)a.ctl[CTL_CUR];

@@ -107,14 +107,22 @@ class GraphedTrainStep:
         return tuple(v.clone() if isinstance(v, Tensor) else v for v in batch)
 
     def _copy_in(self, batch) -> None:
+        """The batch into the captured step's input tensors: ONE multi-tensor launch for the tensors that can take it (same
+        dtype and device as their destination), one copy each for the rest (it was one launch per tensor of the batch,
+        six per step, each with its own gap in front of the replay)."""
         if isinstance(batch, dict):
-            for k, v in batch.items():
-                if isinstance(v, Tensor):
-                    self.static[k].copy_(v)
+            pairs = [(self.static[k], v) for k, v in batch.items() if isinstance(v, Tensor)]
         else:
-            for d, v in zip(self.static, batch):
-                if isinstance(v, Tensor):
-                    d.copy_(v)
+            pairs = [(d, v) for d, v in zip(self.static, batch) if isinstance(v, Tensor)]
+        pairs = [(d, v) for d, v in pairs if d.data_ptr() != v.data_ptr() or d.shape != v.shape]      # already in place
+        fast = [(d, v) for d, v in pairs if v.dtype == d.dtype and v.device == d.device and v.shape == d.shape]
+        if len(fast) > 1:
+            torch._foreach_copy_([d for d, _ in fast], [v for _, v in fast])
+        else:
+            fast = []
+        for d, v in pairs:
+            if not any(d is f for f, _ in fast):
+                d.copy_(v)
 
     def _fwd_bwd(self) -> Tensor:
         self.bucket.drop_grads()
