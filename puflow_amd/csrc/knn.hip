@@ -7,7 +7,7 @@
 // ((dx*dx)+(dy*dy))+(dz*dz), result ordered by (distance asc, index asc), self included.
 // Bit-exact against oracle/ref_cpu.py::knn_canonical.
 //
-// Two kernels, same results bit for bit:
+// Four kernels, same results bit for bit:
 //  * knn_kernel (simple): one lane per query, references read with wave-uniform scalar loads,
 //    per-lane sorted top-K in registers, branch-free shifting insert.  Its cost is the insert:
 //    a lane inserts only ~K ln(M/K) times, but SOME lane of the 64 inserts at almost every
@@ -19,10 +19,19 @@
 //    are <= tau).  Sweep B appends every candidate with d <= tau to a per-lane LDS list (~22
 //    entries for K = 16: coupon-collector count of hitting K of 32 groups); only those are
 //    inserted.  A lane whose list overflows (heavy ties) makes its wave redo the exact simple scan.
-// Candidates are visited in increasing index in both kernels, so a strict `<` keeps equal
+//  * knn4_kernel: knn2 with the references split over the 4 / 8 / 16 waves of a workgroup (small and medium grids).
+//  * knn5_kernel (grids that fill the chip, M <= 4096): the two sweeps run on a filter the f32 MFMA computes for 16 x 16
+//    (query, reference) pairs per instruction; survivors are ranked by EXACT distances (see its header).
+// Candidates are visited in increasing index in every kernel, so a strict `<` keeps equal
 // distances in index order.
 #include <hip/hip_runtime.h>
 #include "pf_api_internal.h"
+#include <type_traits>
+
+#ifndef PF_KNN5
+#define PF_KNN5 1                        // 0: A/B builds without the matrix-pipe sweeps (knn5_kernel)
+#endif
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -42,6 +51,27 @@ __device__ __forceinline__ void topk_insert(float (&bd)[K], int (&bi)[K], float 
         bd[i] = ltl ? bd[i - 1] : (lti ? d : bd[i]);
     }
     if (d < bd[0]) { bd[0] = d; bi[0] = j; }
+}
+
+// the same when only the first T entries of the lists are finite (the T-th insertion into an empty list): slots 0 .. T
+template <int K, int T>
+__device__ __forceinline__ void topk_insert_head(float (&bd)[K], int (&bi)[K], float d, int j) {
+    constexpr int TOP = T < K - 1 ? T : K - 1;
+#pragma unroll
+    for (int i = TOP; i >= 1; --i) {
+        const bool ltl = d < bd[i - 1], lti = d < bd[i];
+        bi[i] = ltl ? bi[i - 1] : (lti ? j : bi[i]);
+        bd[i] = ltl ? bd[i - 1] : (lti ? d : bd[i]);
+    }
+    if (d < bd[0]) { bd[0] = d; bi[0] = j; }
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void pf_static_for_knn(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pf_static_for_knn<I + 1, N>(f);
+    }
 }
 
 // exact scan over all M references with wave-uniform (scalar) loads
@@ -461,6 +491,248 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
     }
 }
 
+// ---- knn5_kernel: the two sweeps on the MATRIX pipe ------------------------------------------------------------------
+// knn4's sweeps are bound by the VALU issue rate of their 6.5 operations per (query, reference) pair.  Here the sweeps run on
+// a filter the f32 MFMA computes for a 16 x 16 tile of pairs per instruction: with the reference table a_j = (-2x, -2y, -2z,
+// |r_j|^2) and b = (qx, qy, qz, 1), v_mfma_f32_16x16x4_f32 gives f_j = |r_j|^2 - 2 q.r_j = d^2 - |q|^2 - the same ORDER as the
+// distance for a fixed query.  A wave owns 16 queries (MFMA columns); lane (col, g) receives the 4 references 16 c + 4 g + r of
+// every 16-reference chunk c for query col: 8 strided group minima per lane = 32 per query (as before), 1 VALU minimum per
+// pair instead of 6.5 operations.  Error of the filter (4 roundings of sums bounded by (|r| + |q|)^2, plus 3 in |r|^2):
+// |f_j - (d_j^2 - |q|^2)| <= 8u (|r_j| + |q|)^2, u = 2^-24.  With E = 16u (sqrt(max |r|^2) + |q|)^2: at least K references have
+// f <= tau (the K-th smallest group minimum), so the exact K-th neighbour distance is <= (tau + E + |q|^2)(1 + 8u), and every
+// reference of the exact answer, ties included, has f <= tau + 2E + 17u (tau + E + |q|^2) <= tau + 3.2 E.  Sweep B keeps
+// f <= tau + 4E; the answer is computed from EXACT distances of the survivors (same bits as every other kernel of this file).
+// Badly scaled clouds (coordinates >> the neighbour distance) only make E large: more survivors, and past the list capacity
+// the exact scan - never a wrong answer.  NaN / inf coordinates: the filter comparisons fail -> too few survivors -> exact scan.
+// A workgroup is NW waves = 16 NW queries of one batch item and builds the item's table once (NW = 16 at 32 x 2048: one workgroup
+// per CU, one round over the chip).  Per-wave scratch (6 KiB): the group minima, then the survivor lists, then the sorted lists.
+constexpr int KNN5_CAP = 32;             // per-lane survivor list: ~22 survivors per query at K = 16, a quarter of them per lane
+constexpr int KNN5_WB = 6144;            // bytes of LDS scratch per wave
+template <int K, int NW>
+__global__ __launch_bounds__(NW * 64) void knn5_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int N, int M,
+                                                       int Mpad, int* __restrict__ idx_out, float* __restrict__ dist_out) {
+    static_assert(K <= 16, "threshold selection uses two 16-element sorted halves");
+    extern __shared__ float4 k5lds[];                        // [Mpad] table, then NW x KNN5_WB bytes of per-wave scratch
+    __shared__ float rmx[NW];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const int n = (blockIdx.x * NW + wave) * 16 + col;
+    const bool live = n < N;
+    const float* __restrict__ r = p2 + (size_t)b * M * 3;
+    float4* tab = k5lds;
+    unsigned char* wsm = reinterpret_cast<unsigned char*>(k5lds + Mpad) + wave * KNN5_WB;
+    float (*gms)[64] = reinterpret_cast<float (*)[64]>(wsm);                                  // [8][64] floats
+    unsigned short (*lst)[64] = reinterpret_cast<unsigned short (*)[64]>(wsm + 2048);       // [KNN5_CAP][64]
+    // ---- the reference table of this batch item, and max |r|^2
+    float rm = 0.f;
+    for (int j = threadIdx.x; j < Mpad; j += NW * 64) {
+        float4 e = make_float4(0.f, 0.f, 0.f, __builtin_inff());      // padding: f = +inf, never a minimum, never a survivor
+        if (j < M) {
+            const float x = r[j * 3 + 0], y = r[j * 3 + 1], z = r[j * 3 + 2];
+            const float R = fmaf(z, z, fmaf(y, y, x * x));
+            e = make_float4(-2.f * x, -2.f * y, -2.f * z, R);
+            rm = fmaxf(rm, R);
+        }
+        tab[j] = e;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) rm = fmaxf(rm, __shfl_xor(rm, m));
+    if (lane == 0) rmx[wave] = rm;
+    __syncthreads();
+    float Rmax = rmx[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) Rmax = fmaxf(Rmax, rmx[w]);
+#if defined(PF_KNN_ABL) && PF_KNN_ABL == 3          // timing-only builds (tools/time_knn5.py): table only
+    if (live && g == 0) idx_out[((size_t)b * N + n) * K] = __float_as_int(Rmax);
+    return;
+#endif
+    if ((blockIdx.x * NW + wave) * 16 >= N) return;           // a wave without queries (no workgroup barrier below this line)
+    const float* qp = p1 + ((size_t)b * N + (live ? n : N - 1)) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float bq = g == 0 ? qx : (g == 1 ? qy : (g == 2 ? qz : 1.f));
+    const float* tabf = reinterpret_cast<const float*>(tab) + col * 4 + g;       // A operand of chunk c: tabf[c * 64]
+    const int nch = Mpad / 16;                                                    // a multiple of 8
+    auto filt = [&](int c) {
+        const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(tabf[c * 64], bq, z4, 0, 0, 0);
+    };
+    // ---- sweep A: 8 strided group minima per lane (group = (chunk parity, register))
+    {
+        float gm[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gm[i] = __builtin_inff();
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+            f4 d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = filt(c0 + u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gm[(u & 1) * 4 + i] = fminf(gm[(u & 1) * 4 + i], d[u][i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gms[i][lane] = gm[i];
+    }
+    // (the exchanges below stay inside the wave: its lanes run in lockstep and its LDS operations complete in order; the wave
+    // barriers only keep the compiler from moving the reads above the writes)
+    __builtin_amdgcn_wave_barrier();
+    float tau;
+    {
+        float ha[16], hb[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ha[i] = gms[i][col]; ha[8 + i] = gms[i][col + 16];
+            hb[i] = gms[i][col + 32]; hb[8 + i] = gms[i][col + 48];
+        }
+        sort16(ha);
+        sort16(hb);
+        tau = fminf(ha[0], hb[K - 1]);
+#pragma unroll
+        for (int i = 1; i < K; ++i) tau = fmaxf(tau, fminf(ha[i], hb[K - 1 - i]));
+        const float s = __builtin_sqrtf(Rmax) + __builtin_sqrtf(fmaf(qz, qz, fmaf(qy, qy, qx * qx)));
+        tau = fmaf(3.814697265625e-6f, s * s, tau) + 1e-37f;              // + 4 E, E = 16 u s^2 (header)
+    }
+#if defined(PF_KNN_ABL) && PF_KNN_ABL == 2          // + sweep A and the threshold
+    if (live && g == 0) idx_out[((size_t)b * N + n) * K] = __float_as_int(tau);
+    return;
+#endif
+    // ---- sweep B: survivors of this lane's references, in index order.  ~1 % of the values pass, but SOME lane of the wave
+    // has one in almost every group of four: a branch or an exec-masked append per value costs ~10 instructions each.  Instead
+    // the comparisons of a batch (8 MFMAs = 32 values per lane) are shifted into one 32-bit mask per lane - v_cmp + add-with-carry,
+    // two VALU instructions per value, as many cycles as the MFMA that produced it - and the few set bits are appended afterwards
+    // (the first value of the batch is the mask's top bit: count-leading-zeros walks them in index order).
+    int cnt = 0;
+    for (int c0 = 0; c0 < nch; c0 += 8) {
+        f4 d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = filt(c0 + u);
+        __builtin_amdgcn_sched_barrier(0);                   // all eight MFMAs in flight before the first comparison waits for one
+        // four independent shift-in chains (MFMA pairs 0-1, 2-3, 4-5, 6-7; the comparison results travel in SGPR pairs, not
+        // VCC, so the chains interleave): at four waves per SIMD one dependent chain issued at half rate
+        unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int u = s >> 2, i = s & 3;
+            unsigned long long c0_, c1_, c2_, c3_;
+            asm("v_cmp_le_f32 %4, %8, %12\n\tv_cmp_le_f32 %5, %9, %12\n\tv_cmp_le_f32 %6, %10, %12\n\tv_cmp_le_f32 %7, %11, %12\n\t"
+                "v_addc_co_u32 %0, %4, %0, %0, %4\n\tv_addc_co_u32 %1, %5, %1, %1, %5\n\t"
+                "v_addc_co_u32 %2, %6, %2, %2, %6\n\tv_addc_co_u32 %3, %7, %3, %3, %7"
+                : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_), "=&s"(c3_)
+                : "v"(d[u][i]), "v"(d[2 + u][i]), "v"(d[4 + u][i]), "v"(d[6 + u][i]), "v"(tau));
+        }
+        unsigned mask = (m0 << 24) | (m1 << 16) | (m2 << 8) | m3;
+        // append the set bits: two straight-line pops (the wave's busiest lane has ~2 survivors per batch), a loop for the rest
+        auto pop = [&]() {
+            if (mask != 0) {
+                const int p = __clz((int)mask);                                  // value u * 4 + i of the batch
+                mask &= ~(0x80000000u >> p);
+                lst[cnt & (KNN5_CAP - 1)][lane] = (unsigned short)((c0 + (p >> 2)) * 16 + 4 * g + (p & 3));
+                ++cnt;                                                           // (a list that wraps is caught by its count below)
+            }
+        };
+        pop();
+        pop();
+        while (__any(mask != 0)) pop();
+    }
+#if defined(PF_KNN_ABL) && PF_KNN_ABL == 1          // + sweep B
+    if (live && g == 0) idx_out[((size_t)b * N + n) * K] = cnt;
+    return;
+#endif
+    // ---- this lane's survivors sorted by (exact distance, index); coordinates from the table (x = -0.5 (-2x), exact)
+    float bd[K];
+    int bi[K];
+    {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { bd[i] = __builtin_inff(); bi[i] = 0xffff; }
+        const int cme = cnt < KNN5_CAP ? cnt : KNN5_CAP;
+        // the t-th survivor can only land in the first t + 1 slots: the first K insertions are unrolled with an insert that
+        // touches just those (5 (t + 1) operations instead of 5 K; a lane has ~K / 3 survivors, the wave's longest list ~K).
+        // Straight-line code in groups of four (a lane past its list inserts +inf: a no-op), so that the LDS reads of the next
+        // survivors - list entry, then its table row - are in flight while the current one is inserted.
+        auto dist_of = [&](int t) {
+            int j = lst[t][lane];
+            j = j < Mpad ? j : 0;                                               // past the lane's count: any valid row
+            const float4 e = tab[j];
+            return t < cme ? sqdist(qx, qy, qz, -0.5f * e.x, -0.5f * e.y, -0.5f * e.z) : __builtin_inff();
+        };
+        pf_static_for_knn<0, (K + 3) / 4>([&](auto gc) {
+            constexpr int G4 = decltype(gc)::value;
+            if (G4 == 0 || __any(cme > 4 * G4)) {
+                float dd[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dd[k] = dist_of(4 * G4 + k);
+                pf_static_for_knn<0, 4>([&](auto kc) {
+                    constexpr int T = 4 * G4 + decltype(kc)::value;
+                    if (T < K) topk_insert_head<K, T>(bd, bi, dd[T - 4 * G4], (int)lst[T][lane]);
+                });
+            }
+        });
+        for (int t = K; __any(t < cme); ++t) {
+            if (t < cme) {
+                const int j = lst[t][lane];
+                const float4 e = tab[j];
+                topk_insert<K>(bd, bi, sqdist(qx, qy, qz, -0.5f * e.x, -0.5f * e.y, -0.5f * e.z), j);
+            }
+        }
+    }
+#if defined(PF_KNN_ABL) && PF_KNN_ABL == 5          // + the per-lane sorted lists
+    if (live && g == 0) idx_out[((size_t)b * N + n) * K] = bi[0] + bi[K - 1];
+    return;
+#endif
+    // the lists are read: the wave's scratch takes the sorted lists ([K][64] floats, then [K][64] indices)
+    __builtin_amdgcn_wave_barrier();
+    float (*sd)[64] = reinterpret_cast<float (*)[64]>(wsm);
+    unsigned short (*si)[64] = reinterpret_cast<unsigned short (*)[64]>(wsm + 4096);
+    static_assert(K * 64 * 4 <= 4096 && 4096 + K * 64 * 2 <= KNN5_WB, "per-wave scratch holds the sorted lists");
+#pragma unroll
+    for (int i = 0; i < K; ++i) { sd[i][lane] = bd[i]; si[i][lane] = (unsigned short)bi[i]; }
+    __builtin_amdgcn_wave_barrier();
+    // survivors of the query = the four lanes of its column
+    int ctot = cnt;
+    ctot += __shfl_xor(ctot, 16);
+    ctot += __shfl_xor(ctot, 32);
+    int cmax = cnt;
+    cmax = max(cmax, __shfl_xor(cmax, 16));
+    cmax = max(cmax, __shfl_xor(cmax, 32));
+#if defined(PF_KNN_ABL) && PF_KNN_ABL == 4          // timing-only: never the exact path
+    if (false) {
+#else
+    if (__any(cmax > KNN5_CAP || ctot < K)) {                 // heavy ties / NaN / inf coordinates: this wave's queries exactly
+#endif
+        exact_scan<K>(qx, qy, qz, r, M, bd, bi);
+        if (live && g == 0) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
+        return;
+    }
+    if (g != 0) return;
+    // merge the column's four sorted lists by (distance, index)
+    float hd[4];
+    int hi[4], hp[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { hd[w] = sd[0][col + 16 * w]; hi[w] = si[0][col + 16 * w]; hp[w] = 1; }
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        int wm = 0;
+        float dm = hd[0];
+        int im = hi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (hd[w] < dm || (hd[w] == dm && hi[w] < im)) { dm = hd[w]; im = hi[w]; wm = w; }
+        bd[i] = dm; bi[i] = im;
+        int pm = hp[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) pm = wm == w ? hp[w] : pm;
+        const int pc = pm < K ? pm : K - 1;
+        const float nd = pm < K ? sd[pc][col + 16 * wm] : __builtin_inff();
+        const int ni = pm < K ? (int)si[pc][col + 16 * wm] : 0xffff;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const bool m = wm == w;
+            hd[w] = m ? nd : hd[w]; hi[w] = m ? ni : hi[w]; hp[w] = m ? pm + 1 : hp[w];
+        }
+    }
+    if (live) store_topk<K>(bd, bi, (size_t)b * N + n, idx_out, dist_out);
+}
+
 // K = 1: nearest neighbour distance + index (first minimum wins ties).
 __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
                                                   int N, int M, float* __restrict__ dist_out,
@@ -521,6 +793,28 @@ extern "C" int pf_knn(const float* p1, const float* p2, int B, int N, int M, int
     if (K <= 16 && M >= 1024 && M <= 65536) {          // two-sweep kernel, references split over 4 / 8 / 16 waves
         const dim3 g4((N + 63) / 64, B);
         const long long wgs = (long long)g4.x * B;
+#if PF_KNN5
+        // the sweeps on the matrix pipe (knn5_kernel) when the grid fills the chip by itself and the reference table fits in LDS
+        if (wgs >= 1024 && M <= 4096 && (K == 4 || K == 8 || K == 16)) {
+            const int Mpad = (M + 127) / 128 * 128;
+            // waves per workgroup: as many as still give every CU a workgroup (the table is built once per workgroup)
+            int ncu = 256, dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+            int NW = 16;
+            while (NW > 4 && ((long long)B * ((N + 16 * NW - 1) / (16 * NW)) < ncu || (size_t)Mpad * 16 + (size_t)NW * KNN5_WB > 150 * 1024)) NW >>= 1;
+            const size_t lds = (size_t)Mpad * 16 + (size_t)NW * KNN5_WB;
+            const dim3 g5((N + 16 * NW - 1) / (16 * NW), B);
+#define PF_KNN5_LAUNCH(KK, W)                                                                                             \
+            do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn5_kernel<KK, W>),                             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+                 hipLaunchKernelGGL((knn5_kernel<KK, W>), g5, dim3(W * 64), lds, s, p1, p2, N, M, Mpad, idx_out, dist_out); } while (0)
+#define PF_KNN5_K(KK) do { if (NW == 16) PF_KNN5_LAUNCH(KK, 16); else if (NW == 8) PF_KNN5_LAUNCH(KK, 8); else PF_KNN5_LAUNCH(KK, 4); } while (0)
+            if (K == 4) PF_KNN5_K(4); else if (K == 8) PF_KNN5_K(8); else PF_KNN5_K(16);
+#undef PF_KNN5_K
+#undef PF_KNN5_LAUNCH
+            return pf_last_launch_status();
+        }
+#endif
         const int W = wgs >= 1024 ? 4 : (wgs >= 384 ? 8 : 16);
 #define PF_KNN4_LAUNCH(KK)                                                                                              \
         if (W == 4) hipLaunchKernelGGL((knn4_kernel<KK, 4>), g4, dim3(256), 0, s, p1, p2, N, M, idx_out, dist_out);         \

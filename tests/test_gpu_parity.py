@@ -32,10 +32,14 @@ def _net(sd):
 # ------------------------------------------------------------------------------------- kNN
 @pytest.mark.parametrize("B,N,M,K", [(2, 256, 256, 16), (1, 2048, 2048, 16), (3, 100, 77, 8), (1, 65, 300, 4),
                                      (2, 130, 130, 32), (1, 16, 16, 16), (2, 1000, 5000, 16), (1, 3000, 2049, 8),
-                                     (1, 257, 4096, 16), (8, 3072, 2048, 16), (32, 2048, 2048, 16), (4, 2048, 2048, 8)])
+                                     (1, 257, 4096, 16), (8, 3072, 2048, 16), (32, 2048, 2048, 16), (4, 2048, 2048, 8),
+                                     # >= 1024 workgroups and M <= 4096: the sweeps on the matrix pipe (knn5_kernel), K = 4 / 8 / 16,
+                                     # M not a multiple of the 128-row table padding, N not a multiple of 64
+                                     (16, 4096, 1024, 4), (17, 4000, 1100, 8), (9, 7300, 4096, 16)])
 def test_knn_bit_exact(lib, B, N, M, K):
-    """The two-sweep kernel splits the references over 16 / 8 / 4 waves for grids of < 384 / < 1024 / more workgroups
-    (the shapes above exercise all three), with the same results."""
+    """The two-sweep kernel splits the references over 16 / 8 waves for grids of < 384 / < 1024 workgroups; larger grids run
+    its sweeps as f32 MFMAs (knn5_kernel; knn4_kernel with 4 waves when M > 4096).  The shapes above exercise all of them,
+    with the same results."""
     from puflow_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + N + K)
     p1 = torch.rand(B, N, 3, generator=g) * 2 - 1
