@@ -279,17 +279,22 @@ def main():
                                     "Cache hits (the 134 MB table was written by the kernel before) are counted as traffic")
         except Exception:
             pass
-        # kNN: north_star asks for HBM GB/s; the kernel is VALU/selection-bound by construction (216 flop/B), so the VALU
-        # fraction is the meaningful roofline: pair evaluations x the VALU lane-slots the kernel EXECUTES per pair - two sweeps of
-        # 6 operations (fused filter distance) + 0.5 (minimum / threshold test) = 13 (csrc/knn.hip; 17 with the exact 8-operation
-        # distance in the sweeps) - against 1024 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s.  The candidate appends and the
-        # selection of the K survivors are not counted: the fraction is sweep arithmetic over the whole kernel time.
+        # kNN: north_star asks for HBM GB/s; the kernel is ALU/selection-bound by construction (216 flop/B), so the ALU fraction
+        # is the meaningful roofline.  knn5_kernel (csrc/knn.hip) runs its two sweeps as v_mfma_f32_16x16x4_f32 - 256 pairs per
+        # instruction at 32 cycles per SIMD, i.e. the rate of the vector FMA lanes (64 FLOP / clk / SIMD: the f32 MFMA does not
+        # add throughput over VALU, it replaces 6 operations per pair by 2 lane-slots) - plus 0.5 (v_min3, sweep A) and 1
+        # (v_alignbit, sweep B) VALU lane-slots per pair: 5.5 executed lane-slots per pair against 1024 SIMDs x 16 lanes x 2.4 GHz
+        # = 39.3 T lane-ops/s.  The appends and the exact ranking of the ~22 survivors per query are not counted: the fraction
+        # is sweep arithmetic over the whole kernel time (knn4_kernel, the VALU form it replaced at this shape: 13 per pair).
         pair_evals = float(args.batch) * args.npoint * args.npoint
-        roof_knn = {"kernel": "knn4_kernel<16>", "bound": "valu", "avg_launch_ms": knn_ms,
+        knn5 = args.batch * ((args.npoint + 63) // 64) >= 1024 and args.npoint <= 4096
+        slots = 5.5 if knn5 else 13.0
+        roof_knn = {"kernel": "knn5_kernel<16> (f32-MFMA filter sweeps + exact ranking)" if knn5 else "knn4_kernel<16>", "bound": "valu",
+                    "avg_launch_ms": knn_ms,
                     "hbm": {"achieved": knn_bytes / (knn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": knn_bytes / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                    "valu": {"pair_evals": pair_evals, "lane_slots_per_pair": 13, "achieved": pair_evals * 13 / (knn_ms * 1e-3) / 1e12,
-                             "peak": 39.3, "unit": "T lane-ops/s", "frac": pair_evals * 13 / (knn_ms * 1e-3) / 1e12 / 39.3}}
+                    "valu": {"pair_evals": pair_evals, "lane_slots_per_pair": slots, "achieved": pair_evals * slots / (knn_ms * 1e-3) / 1e12,
+                             "peak": 39.3, "unit": "T lane-ops/s", "frac": pair_evals * slots / (knn_ms * 1e-3) / 1e12 / 39.3}}
         extra = {"stage_ms": prof, "roofline_knn": roof_knn,
                  "model_algorithmic_tflops": model_ref_flops_per_patch() * value / world / 1e12}
         if el_pipe and patches / el_pipe > value:           # reported only when two steps in flight actually beat the headline on this box

@@ -500,8 +500,10 @@ __global__ __launch_bounds__(KNN4_W * 64) void knn4_kernel(const float* __restri
 // pair instead of 6.5 operations.  Error of the filter (4 roundings of sums bounded by (|r| + |q|)^2, plus 3 in |r|^2):
 // |f_j - (d_j^2 - |q|^2)| <= 8u (|r_j| + |q|)^2, u = 2^-24.  With E = 16u (sqrt(max |r|^2) + |q|)^2: at least K references have
 // f <= tau (the K-th smallest group minimum), so the exact K-th neighbour distance is <= (tau + E + |q|^2)(1 + 8u), and every
-// reference of the exact answer, ties included, has f <= tau + 2E + 17u (tau + E + |q|^2) <= tau + 3.2 E.  Sweep B keeps
-// f <= tau + 4E; the answer is computed from EXACT distances of the survivors (same bits as every other kernel of this file).
+// reference of the exact answer, ties included, has f <= tau + 2E + 17u (tau + E + |q|^2) <= tau + 3.2 E.  Sweep B computes
+// f - (tau + 4E) (the threshold enters as the MFMA's accumulator: one more rounding of the same magnitude, covered by the 0.8 E
+// of slack) and keeps the NEGATIVE results - the sign bit is the flag, shifted into a mask by one v_alignbit per value; the
+// answer is computed from EXACT distances of the survivors (same bits as every other kernel of this file).
 // Badly scaled clouds (coordinates >> the neighbour distance) only make E large: more survivors, and past the list capacity
 // the exact scan - never a wrong answer.  NaN / inf coordinates: the filter comparisons fail -> too few survivors -> exact scan.
 // A workgroup is NW waves = 16 NW queries of one batch item and builds the item's table once (NW = 16 at 32 x 2048: one workgroup
@@ -552,23 +554,29 @@ __global__ __launch_bounds__(NW * 64) void knn5_kernel(const float* __restrict__
     const float bq = g == 0 ? qx : (g == 1 ? qy : (g == 2 ? qz : 1.f));
     const float* tabf = reinterpret_cast<const float*>(tab) + col * 4 + g;       // A operand of chunk c: tabf[c * 64]
     const int nch = Mpad / 16;                                                    // a multiple of 8
+    auto filtc = [&](int c, f4 acc) { return __builtin_amdgcn_mfma_f32_16x16x4f32(tabf[c * 64], bq, acc, 0, 0, 0); };
     auto filt = [&](int c) {
         const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(tabf[c * 64], bq, z4, 0, 0, 0);
+        return filtc(c, z4);
     };
     // ---- sweep A: 8 strided group minima per lane (group = (chunk parity, register))
     {
         float gm[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) gm[i] = __builtin_inff();
+        // (measured: v_min3 instead of two v_min, and a software pipeline inside the wave - the next four MFMAs issued before the
+        // minima of the previous four - leave the sweep's time unchanged)
         for (int c0 = 0; c0 < nch; c0 += 8) {
             f4 d[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) d[u] = filt(c0 + u);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 8; u += 4)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gm[(u & 1) * 4 + i] = fminf(gm[(u & 1) * 4 + i], d[u][i]);
+                for (int v = 0; v < 2; ++v)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        gm[v * 4 + i] = __builtin_fminf(gm[v * 4 + i], __builtin_fminf(d[u + v][i], d[u + v + 2][i]));
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) gms[i][lane] = gm[i];
@@ -598,27 +606,30 @@ __global__ __launch_bounds__(NW * 64) void knn5_kernel(const float* __restrict__
 #endif
     // ---- sweep B: survivors of this lane's references, in index order.  ~1 % of the values pass, but SOME lane of the wave
     // has one in almost every group of four: a branch or an exec-masked append per value costs ~10 instructions each.  Instead
-    // the comparisons of a batch (8 MFMAs = 32 values per lane) are shifted into one 32-bit mask per lane - v_cmp + add-with-carry,
-    // two VALU instructions per value, as many cycles as the MFMA that produced it - and the few set bits are appended afterwards
-    // (the first value of the batch is the mask's top bit: count-leading-zeros walks them in index order).
+    // the flags of a batch (8 MFMAs = 32 values per lane) are shifted into one 32-bit mask per lane - one v_alignbit per value -
+    // and the few set bits are appended afterwards (the first value of the batch is the mask's top bit: count-leading-zeros
+    // walks them in index order).  Where the time goes at 32 x 2048, K = 16 (tools/time_knn5.py with -DPF_KNN_ABL=3 / 2 / 6 /
+    // 1 / 5 builds, one box): table + sweep A + threshold 23 us, the masks of sweep B 13.5, the appends 5, the per-lane sorted
+    // lists 8, merge + store 7 = 57 us (knn4_kernel on the same box: 76-79).
     int cnt = 0;
+    const f4 ntau = {-tau, -tau, -tau, -tau};                // the MFMA's accumulator input: results are f - tau
     for (int c0 = 0; c0 < nch; c0 += 8) {
         f4 d[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) d[u] = filt(c0 + u);
-        __builtin_amdgcn_sched_barrier(0);                   // all eight MFMAs in flight before the first comparison waits for one
-        // four independent shift-in chains (MFMA pairs 0-1, 2-3, 4-5, 6-7; the comparison results travel in SGPR pairs, not
-        // VCC, so the chains interleave): at four waves per SIMD one dependent chain issued at half rate
+        for (int u = 0; u < 8; ++u) d[u] = filtc(c0 + u, ntau);          // f - tau: the sign bit is the survivor flag
+        __builtin_amdgcn_sched_barrier(0);                   // all eight MFMAs in flight before the first result is waited for
+        // four independent shift-in chains (MFMA pairs 0-1, 2-3, 4-5, 6-7), ONE instruction per value:
+        // v_alignbit(m, x, 31) = (m << 1) | sign(x)
         unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int u = s >> 2, i = s & 3;
-            unsigned long long c0_, c1_, c2_, c3_;
-            asm("v_cmp_le_f32 %4, %8, %12\n\tv_cmp_le_f32 %5, %9, %12\n\tv_cmp_le_f32 %6, %10, %12\n\tv_cmp_le_f32 %7, %11, %12\n\t"
-                "v_addc_co_u32 %0, %4, %0, %0, %4\n\tv_addc_co_u32 %1, %5, %1, %1, %5\n\t"
-                "v_addc_co_u32 %2, %6, %2, %2, %6\n\tv_addc_co_u32 %3, %7, %3, %3, %7"
-                : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&s"(c0_), "=&s"(c1_), "=&s"(c2_), "=&s"(c3_)
-                : "v"(d[u][i]), "v"(d[2 + u][i]), "v"(d[4 + u][i]), "v"(d[6 + u][i]), "v"(tau));
+            // (inline asm: with the builtin, hipcc 7.2 reads component 0 of every MFMA result for all four - a demanded-bits
+            // simplification that only keeps the sign bit in view goes wrong on the accumulator vector)
+            asm("v_alignbit_b32 %0, %0, %4, 31\n\tv_alignbit_b32 %1, %1, %5, 31\n\t"
+                "v_alignbit_b32 %2, %2, %6, 31\n\tv_alignbit_b32 %3, %3, %7, 31"
+                : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)
+                : "v"(d[u][i]), "v"(d[2 + u][i]), "v"(d[4 + u][i]), "v"(d[6 + u][i]));
         }
         unsigned mask = (m0 << 24) | (m1 << 16) | (m2 << 8) | m3;
         // append the set bits: two straight-line pops (the wave's busiest lane has ~2 survivors per batch), a loop for the rest
@@ -630,11 +641,15 @@ __global__ __launch_bounds__(NW * 64) void knn5_kernel(const float* __restrict__
                 ++cnt;                                                           // (a list that wraps is caught by its count below)
             }
         };
+#if defined(PF_KNN_ABL) && PF_KNN_ABL == 6          // timing-only: the masks without the appends
+        cnt += __popc(mask);
+#else
         pop();
         pop();
         while (__any(mask != 0)) pop();
+#endif
     }
-#if defined(PF_KNN_ABL) && PF_KNN_ABL == 1          // + sweep B
+#if defined(PF_KNN_ABL) && (PF_KNN_ABL == 1 || PF_KNN_ABL == 6)          // + sweep B
     if (live && g == 0) idx_out[((size_t)b * N + n) * K] = cnt;
     return;
 #endif
