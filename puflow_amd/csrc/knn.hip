@@ -31,6 +31,9 @@
 #ifndef PF_KNN5
 #define PF_KNN5 1                        // 0: A/B builds without the matrix-pipe sweeps (knn5_kernel)
 #endif
+#ifndef PF_KNN5_MIN_WGS
+#define PF_KNN5_MIN_WGS 64               // 64-query tiles from which knn5_kernel is used: 4 x 2048 and up measured faster (28 vs 31 us; 16 x 2048: 35 vs 52); below: knn4_kernel's 16 reference slices
+#endif
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -809,8 +812,8 @@ extern "C" int pf_knn(const float* p1, const float* p2, int B, int N, int M, int
         const dim3 g4((N + 63) / 64, B);
         const long long wgs = (long long)g4.x * B;
 #if PF_KNN5
-        // the sweeps on the matrix pipe (knn5_kernel) when the grid fills the chip by itself and the reference table fits in LDS
-        if (wgs >= 1024 && M <= 4096 && (K == 4 || K == 8 || K == 16)) {
+        // the sweeps as f32 MFMAs (knn5_kernel) from 64 query tiles up, when the reference table fits in LDS
+        if (wgs >= PF_KNN5_MIN_WGS && M <= 4096 && (K == 4 || K == 8 || K == 16)) {
             const int Mpad = (M + 127) / 128 * 128;
             // waves per workgroup: as many as still give every CU a workgroup (the table is built once per workgroup)
             int ncu = 256, dev = 0;
