@@ -31,6 +31,9 @@
 #ifndef PF_KNN5
 #define PF_KNN5 1                        // 0: A/B builds without the matrix-pipe sweeps (knn5_kernel)
 #endif
+#ifndef PF_KNN5_MIN_M
+#define PF_KNN5_MIN_M 256
+#endif
 #ifndef PF_KNN5_MIN_WGS
 #define PF_KNN5_MIN_WGS 64               // 64-query tiles from which knn5_kernel is used: 4 x 2048 and up measured faster (28 vs 31 us; 16 x 2048: 35 vs 52); below: knn4_kernel's 16 reference slices
 #endif
@@ -808,12 +811,14 @@ extern "C" int pf_knn(const float* p1, const float* p2, int B, int N, int M, int
     if (!p1 || !p2 || !idx_out) return PF_ERR_NULL;
     if (B <= 0 || N <= 0 || M <= 0 || K <= 0 || K > M || B > 65535) return PF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (K <= 16 && M >= 1024 && M <= 65536) {          // two-sweep kernel, references split over 4 / 8 / 16 waves
+    if (K <= 16 && M >= (PF_KNN5_MIN_M < 1024 ? PF_KNN5_MIN_M : 1024) && M <= 65536) {  // two-sweep kernels: sweeps as f32 MFMAs, or references split over 4 / 8 / 16 waves
         const dim3 g4((N + 63) / 64, B);
         const long long wgs = (long long)g4.x * B;
 #if PF_KNN5
         // the sweeps as f32 MFMAs (knn5_kernel) from 64 query tiles up, when the reference table fits in LDS
-        if (wgs >= PF_KNN5_MIN_WGS && M <= 4096 && (K == 4 || K == 8 || K == 16)) {
+        // (256 <= M < 1024, the training step's 32 x 256: 46 -> 16 us while the grid is small - there the kernel's latency is what
+        // counts; PU-GAN's 2 496 patches of 256 points stay on knn2_kernel: 179 us against 219)
+        if (wgs >= PF_KNN5_MIN_WGS && (M >= 1024 || (M >= PF_KNN5_MIN_M && wgs <= 1024)) && M <= 4096 && (K == 4 || K == 8 || K == 16)) {
             const int Mpad = (M + 127) / 128 * 128;
             // waves per workgroup: as many as still give every CU a workgroup (the table is built once per workgroup)
             int ncu = 256, dev = 0;
@@ -833,6 +838,7 @@ extern "C" int pf_knn(const float* p1, const float* p2, int B, int N, int M, int
             return pf_last_launch_status();
         }
 #endif
+        if (M >= 1024) {
         const int W = wgs >= 1024 ? 4 : (wgs >= 384 ? 8 : 16);
 #define PF_KNN4_LAUNCH(KK)                                                                                              \
         if (W == 4) hipLaunchKernelGGL((knn4_kernel<KK, 4>), g4, dim3(256), 0, s, p1, p2, N, M, idx_out, dist_out);         \
@@ -846,6 +852,7 @@ extern "C" int pf_knn(const float* p1, const float* p2, int B, int N, int M, int
         }
 #undef PF_KNN4_LAUNCH
         return pf_last_launch_status();
+        }
     }
     if (K <= 16 && M >= 256 && M <= 65536) {           // two-sweep kernel (u16 candidate lists)
         dim3 g2((N + KNN2_T - 1) / KNN2_T, B), b2(KNN2_T);

@@ -35,7 +35,9 @@ def _net(sd):
                                      (1, 257, 4096, 16), (8, 3072, 2048, 16), (32, 2048, 2048, 16), (4, 2048, 2048, 8),
                                      # >= 1024 workgroups and M <= 4096: the sweeps on the matrix pipe (knn5_kernel), K = 4 / 8 / 16,
                                      # M not a multiple of the 128-row table padding, N not a multiple of 64
-                                     (16, 4096, 1024, 4), (17, 4000, 1100, 8), (9, 7300, 4096, 16)])
+                                     (16, 4096, 1024, 4), (17, 4000, 1100, 8), (9, 7300, 4096, 16),
+                                     # 256 <= M < 1024 on small grids (the training step's 32 x 256): knn5_kernel as well
+                                     (32, 256, 256, 16), (32, 256, 256, 8), (70, 130, 300, 8), (40, 200, 999, 4)])
 def test_knn_bit_exact(lib, B, N, M, K):
     """The two-sweep kernel splits the references over 16 / 8 waves for grids of < 384 / < 1024 workgroups; larger grids run
     its sweeps as f32 MFMAs (knn5_kernel; knn4_kernel with 4 waves when M > 4096).  The shapes above exercise all of them,

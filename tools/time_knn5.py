@@ -7,7 +7,7 @@ import torch
 from puflow_amd import ops
 from puflow_amd.weights import synth_patches
 
-for B, N, K in ((32, 2048, 16), (32, 2048, 8), (64, 1024, 16), (16, 2048, 16), (8, 2048, 16), (4, 2048, 16)):
+for B, N, K in ((32, 2048, 16), (32, 2048, 8), (64, 1024, 16), (16, 2048, 16), (8, 2048, 16), (4, 2048, 16), (32, 256, 16), (2496, 256, 16), (32, 256, 8), (32, 1024, 16)):
     p = synth_patches(B, N, seed=1).cuda()
     for _ in range(3):
         ops.knn_idx32(p, p, K)
