@@ -95,9 +95,11 @@ __device__ __forceinline__ void exact_scan(float qx, float qy, float qz, const f
 template <int K>
 __device__ __forceinline__ void store_topk(const float (&bd)[K], const int (&bi)[K], size_t row, int* __restrict__ idx_out,
                                            float* __restrict__ dist_out) {
-    int* o = idx_out + row * K;
+    if (idx_out) {                                          // (pf_nn1 may ask for the distances alone)
+        int* o = idx_out + row * K;
 #pragma unroll
-    for (int i = 0; i < K; ++i) o[i] = bi[i];
+        for (int i = 0; i < K; ++i) o[i] = bi[i];
+    }
     if (dist_out) {
         float* od = dist_out + row * K;
 #pragma unroll
@@ -598,13 +600,20 @@ __global__ __launch_bounds__(NW * 64) void knn5_kernel(const float* __restrict__
             ha[i] = gms[i][col]; ha[8 + i] = gms[i][col + 16];
             hb[i] = gms[i][col + 32]; hb[8 + i] = gms[i][col + 48];
         }
-        sort16(ha);
-        sort16(hb);
-        tau = fminf(ha[0], hb[K - 1]);
+        if constexpr (K == 1) {                               // nearest neighbour (pf_nn1): the smallest group minimum
+            tau = fminf(ha[0], hb[0]);
 #pragma unroll
-        for (int i = 1; i < K; ++i) tau = fmaxf(tau, fminf(ha[i], hb[K - 1 - i]));
+            for (int i = 1; i < 16; ++i) tau = fminf(tau, fminf(ha[i], hb[i]));
+        } else {
+            sort16(ha);
+            sort16(hb);
+            tau = fminf(ha[0], hb[K - 1]);
+#pragma unroll
+            for (int i = 1; i < K; ++i) tau = fmaxf(tau, fminf(ha[i], hb[K - 1 - i]));
+        }
         const float s = __builtin_sqrtf(Rmax) + __builtin_sqrtf(fmaf(qz, qz, fmaf(qy, qy, qx * qx)));
-        tau = fmaf(3.814697265625e-6f, s * s, tau) + 1e-37f;              // + 4 E, E = 16 u s^2 (header)
+        tau = fmaf(3.814697265625e-6f, s * s, tau) + 4e-37f;              // + 4 E, E = 16 u s^2 (header); the absolute term also
+                                                                          // covers results flushed to zero near the subnormals
     }
 #if defined(PF_KNN_ABL) && PF_KNN_ABL == 2          // + sweep A and the threshold
     if (live && g == 0) idx_out[((size_t)b * N + n) * K] = __float_as_int(tau);
@@ -804,6 +813,38 @@ __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ p1, 
     }
 }
 
+
+// knn5_kernel with as many waves per workgroup as still give every CU a workgroup (the table is built once per workgroup)
+template <int K>
+static void launch_knn5(const float* p1, const float* p2, int B, int N, int M, int* idx_out, float* dist_out, hipStream_t s) {
+    const int Mpad = (M + 127) / 128 * 128;
+    int ncu = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    int NW = 16;
+    while (NW > 4 && ((long long)B * ((N + 16 * NW - 1) / (16 * NW)) < ncu || (size_t)Mpad * 16 + (size_t)NW * KNN5_WB > 150 * 1024)) NW >>= 1;
+    const size_t lds = (size_t)Mpad * 16 + (size_t)NW * KNN5_WB;
+    const dim3 g5((N + 16 * NW - 1) / (16 * NW), B);
+#define PF_KNN5_LAUNCH(W)                                                                                                 \
+    do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn5_kernel<K, W>),                                      \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+         hipLaunchKernelGGL((knn5_kernel<K, W>), g5, dim3(W * 64), lds, s, p1, p2, N, M, Mpad, idx_out, dist_out); } while (0)
+    if (NW == 16) PF_KNN5_LAUNCH(16); else if (NW == 8) PF_KNN5_LAUNCH(8); else PF_KNN5_LAUNCH(4);
+#undef PF_KNN5_LAUNCH
+}
+
+// which shapes take knn5_kernel: the table must fit in LDS; 64 query tiles and up; 256 <= M < 1024 (the training step's 32 x 256:
+// 46 -> 16 us) only while the grid is small - there the kernel's latency is what counts; PU-GAN's 2 496 patches of 256 points
+// stay on knn2_kernel (179 us against 219)
+static bool use_knn5(int B, int N, int M) {
+#if PF_KNN5
+    const long long wgs = (long long)((N + 63) / 64) * B;
+    return wgs >= PF_KNN5_MIN_WGS && (M >= 1024 || (M >= PF_KNN5_MIN_M && wgs <= 1024)) && M <= 4096;
+#else
+    (void)B; (void)N; (void)M;
+    return false;
+#endif
+}
+
 }  // namespace
 
 extern "C" int pf_knn(const float* p1, const float* p2, int B, int N, int M, int K, int* idx_out,
@@ -814,30 +855,14 @@ extern "C" int pf_knn(const float* p1, const float* p2, int B, int N, int M, int
     if (K <= 16 && M >= (PF_KNN5_MIN_M < 1024 ? PF_KNN5_MIN_M : 1024) && M <= 65536) {  // two-sweep kernels: sweeps as f32 MFMAs, or references split over 4 / 8 / 16 waves
         const dim3 g4((N + 63) / 64, B);
         const long long wgs = (long long)g4.x * B;
-#if PF_KNN5
-        // the sweeps as f32 MFMAs (knn5_kernel) from 64 query tiles up, when the reference table fits in LDS
-        // (256 <= M < 1024, the training step's 32 x 256: 46 -> 16 us while the grid is small - there the kernel's latency is what
-        // counts; PU-GAN's 2 496 patches of 256 points stay on knn2_kernel: 179 us against 219)
-        if (wgs >= PF_KNN5_MIN_WGS && (M >= 1024 || (M >= PF_KNN5_MIN_M && wgs <= 1024)) && M <= 4096 && (K == 4 || K == 8 || K == 16)) {
-            const int Mpad = (M + 127) / 128 * 128;
-            // waves per workgroup: as many as still give every CU a workgroup (the table is built once per workgroup)
-            int ncu = 256, dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-            int NW = 16;
-            while (NW > 4 && ((long long)B * ((N + 16 * NW - 1) / (16 * NW)) < ncu || (size_t)Mpad * 16 + (size_t)NW * KNN5_WB > 150 * 1024)) NW >>= 1;
-            const size_t lds = (size_t)Mpad * 16 + (size_t)NW * KNN5_WB;
-            const dim3 g5((N + 16 * NW - 1) / (16 * NW), B);
-#define PF_KNN5_LAUNCH(KK, W)                                                                                             \
-            do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn5_kernel<KK, W>),                             \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
-                 hipLaunchKernelGGL((knn5_kernel<KK, W>), g5, dim3(W * 64), lds, s, p1, p2, N, M, Mpad, idx_out, dist_out); } while (0)
-#define PF_KNN5_K(KK) do { if (NW == 16) PF_KNN5_LAUNCH(KK, 16); else if (NW == 8) PF_KNN5_LAUNCH(KK, 8); else PF_KNN5_LAUNCH(KK, 4); } while (0)
-            if (K == 4) PF_KNN5_K(4); else if (K == 8) PF_KNN5_K(8); else PF_KNN5_K(16);
-#undef PF_KNN5_K
-#undef PF_KNN5_LAUNCH
+        if (use_knn5(B, N, M) && (K == 4 || K == 8 || K == 16)) {       // the sweeps as f32 MFMAs
+            switch (K) {
+                case 4:  launch_knn5<4>(p1, p2, B, N, M, idx_out, dist_out, s); break;
+                case 8:  launch_knn5<8>(p1, p2, B, N, M, idx_out, dist_out, s); break;
+                default: launch_knn5<16>(p1, p2, B, N, M, idx_out, dist_out, s); break;
+            }
             return pf_last_launch_status();
         }
-#endif
         if (M >= 1024) {
         const int W = wgs >= 1024 ? 4 : (wgs >= 384 ? 8 : 16);
 #define PF_KNN4_LAUNCH(KK)                                                                                              \
@@ -879,6 +904,10 @@ extern "C" int pf_nn1(const float* p1, const float* p2, int B, int N, int M, flo
                       void* stream) {
     if (!p1 || !p2 || !dist_out) return PF_ERR_NULL;
     if (B <= 0 || N <= 0 || M <= 0 || B > 65535) return PF_ERR_SHAPE;
+    if (use_knn5(B, N, M)) {             // K = 1 of the MFMA-filter kernel: (distance, index) order = the first minimum
+        launch_knn5<1>(p1, p2, B, N, M, idx_out, dist_out, (hipStream_t)stream);
+        return pf_last_launch_status();
+    }
     hipLaunchKernelGGL(nn1_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, p1, p2, N, M, dist_out,
                        idx_out);
     return pf_last_launch_status();

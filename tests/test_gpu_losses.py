@@ -17,7 +17,7 @@ def _unit_cube(B, n, seed):
     return torch.rand(B, n, 3, generator=g)
 
 
-@pytest.mark.parametrize("B,N,M", [(2, 256, 1024), (3, 1000, 777), (1, 8192, 8192)])
+@pytest.mark.parametrize("B,N,M", [(2, 256, 1024), (3, 1000, 777), (1, 8192, 8192), (32, 1024, 1024), (40, 300, 500)])
 def test_chamfer_forward(B, N, M):
     from puflow_amd import ops
     x = synth_patches(B, N, seed=N, surface=False)
@@ -56,6 +56,16 @@ def test_chamfer_nearest_neighbour_on_hard_clouds(mode):
     d1, d2, i1, i2 = ops.chamfer_3DDist()(x.to(DEV), y.to(DEV))
     assert torch.equal(d1.cpu(), d1r) and torch.equal(d2.cpu(), d2r)
     assert torch.equal(i1.cpu().long(), i1r) and torch.equal(i2.cpu().long(), i2r)
+    # the same clouds as a batch large enough (>= 64 query tiles) for the MFMA-filter kernel (knn5_kernel<1>: pf_nn1's path at
+    # the training step's 32 x 1024): every item shifted differently, the first one as above
+    reps = 24
+    sh = torch.arange(reps).view(reps, 1, 1) * (0.0 if mode in ("tiny", "lattice") else 0.013)
+    xb = (x[:1].repeat(reps, 1, 1) + sh).contiguous()
+    yb = (y[:1].repeat(reps, 1, 1) + sh).contiguous()
+    d1r, i1r, d2r, i2r = O.chamfer_nn(xb, yb)
+    d1, d2, i1, i2 = ops.chamfer_3DDist()(xb.to(DEV), yb.to(DEV))
+    assert torch.equal(d1.cpu(), d1r) and torch.equal(d2.cpu(), d2r), mode
+    assert torch.equal(i1.cpu().long(), i1r) and torch.equal(i2.cpu().long(), i2r), mode
 
 
 def test_chamfer_backward_matches_autograd():
