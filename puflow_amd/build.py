@@ -16,6 +16,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs; the AGPR form hipcc picks under pressure costs one
 # v_accvgpr_read per accumulator register before any VALU use (every layer here) and halves the occupancy.
 EXTRA_FLAGS = {s: ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=" + os.environ.get("PF_MFMA_VGPR_FORM", "1")] for s in ("edgeconv.hip", "pointwise.hip", "flow.hip", "interp.hip", "cnf.hip")}
+# interp_kernel<1,12> sits exactly on the 168-VGPR budget of three waves per SIMD; the scheduler's default register-pressure
+# tracker overshoots it by four registers (20 bytes of scratch per lane, the only spilling kernel of the eval path), the GCN
+# trackers do not (tools/check_resources.py: 168 VGPRs, no scratch)
+if os.environ.get("PF_INTERP_TRACKERS", "1") != "0":
+    EXTRA_FLAGS["interp.hip"] = EXTRA_FLAGS["interp.hip"] + ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
 
 
 def _stale(target: str, deps) -> bool:
