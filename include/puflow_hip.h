@@ -558,6 +558,12 @@ int pf_cnf_step(const float* y0, const float* f0, float t, float h, int reverse,
                 const float* rec, float* y1, float* f1, float* ymid, float rtol, float atol, int rows, int R, double* ws,
                 double* out, void* stream);
 
+/* ctx [T, 288] = c [T, cd] Hc^T + hb: the context's share of every gate / bias pre-activation of a flow block's three
+ * ConcatSquash layers (modules/continuous/diffeq_layers.py:72-86), one split-fp16 GEMM (fp32-grade, bound by its 1 152-byte row
+ * writes).  hc_image: Hc [288, cd] as the f16n fragment image of packing.pack_cnf_context, inv_scale: the inverse of the image's
+ * power-of-two scale.  cd: 32, 64 or 128. */
+int pf_cnf_context(const float* c, int cd, const float* hc_image, const float* hb, float inv_scale, float* ctx, int T, void* stream);
+
 /* n_attempts dopri5 step attempts with the step-size controller ON THE DEVICE (no host read between attempts).
  * ctl: 16 doubles - [0] t [1] dt [2] t1 [3] n_tot (elements of the RMS norm) [4] cur (which of ya / yb, fa / fb is current)
  * [5] done [6] accepted [7] rejected [8] nfe [9] status (0 ok, 1 non-finite error norm, 2 dt underflow) [10] reverse.

@@ -180,6 +180,7 @@ SIGNATURES = {
     "pf_ec_train_bwd": (c_int, [c_void_p, c_void_p]),
     "pf_cnf_init": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double,
                             c_void_p, c_double, c_int, c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+    "pf_cnf_context": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     "pf_cnf_steps": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                              c_float, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "pf_knn_large": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

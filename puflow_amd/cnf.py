@@ -30,7 +30,7 @@ from torch import Tensor
 from . import _lib
 from .interpflow import (COND_CHANNELS, FEAT_CHANNELS, GROWTH, NUM_BLOCKS, _EdgeConvParams, _Engine, _InterpParams,
                          _MergeParams)
-from .packing import CNF_CTX, cnf_split_ok, pack_cnf_block
+from .packing import CNF_CTX, cnf_split_ok, pack_cnf_block, pack_cnf_context
 from .train_ops import _gemm
 from .weights import state_dict_spec
 
@@ -116,11 +116,13 @@ class _CnfEngine:
         self.device = device
         self.R = upratio
         self.base = _Engine(_discrete_shell(sd), device)
-        self.rec, self.Hc, self.hb, self.T_end, self.split = [], [], [], [], []
+        self.rec, self.Hc, self.Hci, self.hb, self.T_end, self.split = [], [], [], [], [], []
         for i in range(NUM_BLOCKS):
             rec, Hc, hb, T_end = pack_cnf_block(sd, i)
             self.rec.append(torch.from_numpy(rec).to(device))
             self.Hc.append(torch.from_numpy(Hc).to(device))
+            img, inv = pack_cnf_context(Hc)
+            self.Hci.append((torch.from_numpy(img).to(device), float(inv)))
             self.hb.append(torch.from_numpy(hb).to(device))
             self.T_end.append(T_end)
             # PF_CNF_SPLIT_GATES (include/puflow_hip.h): only where the factored 2^x cannot overflow; PF_CNF_SPLIT=0 keeps the plain kernel
@@ -153,7 +155,12 @@ class _CnfEngine:
         """ctx [T,288] = c Hc^T + hb: everything a ConcatSquash layer takes from the context."""
         T, cd = c.shape
         ctx = torch.empty((T, CNF_CTX), dtype=torch.float32, device=c.device)
-        _gemm(c, cd, 1, self.Hc[i], 1, cd, ctx, CNF_CTX, self.hb[i], T, CNF_CTX, cd)
+        if cd in (32, 64, 128) and c.is_contiguous():            # split-fp16 GEMM with register-resident weights (pf_pq_gemm's kernel)
+            img, inv = self.Hci[i]
+            _lib.check(self.lib.pf_cnf_context(c.data_ptr(), cd, img.data_ptr(), self.hb[i].data_ptr(), inv, ctx.data_ptr(), T,
+                                               self._stream()), "pf_cnf_context")
+        else:
+            _gemm(c, cd, 1, self.Hc[i], 1, cd, ctx, CNF_CTX, self.hb[i], T, CNF_CTX, cd)
         return ctx
 
     def _rhs(self, i, y0, K, coef, h, t, sgn, ctx, e, kout, yout, rows, R):

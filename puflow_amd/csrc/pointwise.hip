@@ -37,6 +37,7 @@ struct PqArgs {
     const float* scales;  // POST_SCALES: [6] = 2^-sw of the PQ matrix
     float* pq;            // [T, ROWS]
     int T, ntiles, NT, nrounds;
+    float inv;            // used when scales == nullptr (pf_cnf_context)
 };
 
 template <int ODIM, int ROWS, int NW>
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(NW * 64) void pq_gemm_kernel(PqArgs a) {
         }
         bias[ob] = *reinterpret_cast<const f4*>(a.bias + (wave * RB + ob) * 16 + 4 * q);
     }
-    const float inv = a.scales[6];
+    const float inv = a.scales ? a.scales[6] : a.inv;
     for (int round = blockIdx.x; round < a.nrounds; round += gridDim.x) {
         const int tile0 = round * a.NT;
         const int nt = a.ntiles - tile0 < a.NT ? a.ntiles - tile0 : a.NT;
@@ -122,6 +123,21 @@ int launch_pq(PqArgs a, hipStream_t s) {
     a.nrounds = (a.ntiles + nt - 1) / nt;
     const int grid = a.nrounds < 256 ? a.nrounds : 256;    // one workgroup per CU (LDS, 16 waves)
     hipLaunchKernelGGL((pq_gemm_kernel<ODIM, ROWS, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    return pf_last_launch_status();
+}
+
+// the same kernel for the continuous model's context GEMM ctx = c Hc^T + hb ([288 x cd] x [cd x T], 75 MB written per
+// block at 32 x 2048): 18 row blocks = 9 waves x 2
+template <int ODIM>
+int launch_ctx(PqArgs a, hipStream_t s) {
+    constexpr int NW = 9;
+    a.ntiles = (a.T + 15) / 16;
+    int nt = a.ntiles / 256;
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+    a.NT = nt;
+    a.nrounds = (a.ntiles + nt - 1) / nt;
+    const int grid = a.nrounds < 256 ? a.nrounds : 256;
+    hipLaunchKernelGGL((pq_gemm_kernel<ODIM, 288, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
     return pf_last_launch_status();
 }
 
@@ -339,6 +355,24 @@ extern "C" int pf_pq_gemm(int unit, const float* h, const float* w, const long l
         case 0: return launch_pq<32, 256>(a, s);
         case 1: return launch_pq<64, 512>(a, s);
         case 2: case 3: case 4: return launch_pq<128, 512>(a, s);
+        default: return PF_ERR_UNSUPPORTED;
+    }
+}
+
+// ctx [T, 288] = c [T, cd] Hc^T + hb with Hc as an f16n fragment image (packing.pack_cnf_context; the products carry its
+// power-of-two scale, inv_scale takes it out) - modules/continuous/diffeq_layers.py:72-86: everything a ConcatSquash layer
+// takes from the context, for all three layers of a block in one GEMM.  cd: 32, 64 or 128.
+extern "C" int pf_cnf_context(const float* c, int cd, const float* hc_image, const float* hb, float inv_scale, float* ctx, int T,
+                              void* stream) {
+    if (!c || !hc_image || !hb || !ctx) return PF_ERR_NULL;
+    if (T <= 0) return PF_ERR_SHAPE;
+    PqArgs a{};
+    a.h = c; a.w = reinterpret_cast<const u4*>(hc_image); a.bias = hb; a.scales = nullptr; a.inv = inv_scale; a.pq = ctx; a.T = T;
+    hipStream_t s = (hipStream_t)stream;
+    switch (cd) {
+        case 32: return launch_ctx<32>(a, s);
+        case 64: return launch_ctx<64>(a, s);
+        case 128: return launch_ctx<128>(a, s);
         default: return PF_ERR_UNSUPPORTED;
     }
 }

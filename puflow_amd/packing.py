@@ -537,6 +537,11 @@ def _np32(t) -> np.ndarray:
 LOG2E = 1.4426950408889634
 
 
+def pack_cnf_context(Hc: np.ndarray):
+    """Hc [288, cd] of pack_cnf_block -> (f16n fragment image for pf_cnf_context, 2^-scale as float32)."""
+    return frag_pack_f16n_scaled(np.ascontiguousarray(Hc, dtype=np.float32))
+
+
 def cnf_split_ok(rec, T_end: float) -> bool:
     """May pf_cnf_steps take PF_CNF_SPLIT_GATES for this record?  The gate rows of its time vector already carry -log2e; the
     per-stage factor 2^(gt alpha h) has |h| <= T_end, and 2^100 x (any fp32 2^x) neither overflows to NaN nor loses a gate bit."""

@@ -297,5 +297,22 @@ def test_split_gate_kernel_agrees_with_the_plain_one(golden_dir):
     a, b = res["split"], res["plain"]
     assert abs(a["accepted"] - b["accepted"]) <= 1 and abs(a["rejected"] - b["rejected"]) <= 1
     scale = float(b["x"].abs().max())
-    assert float((a["x"] - b["x"]).abs().max()) <= 2e-4 * scale        # the ODEs amplify one rounding difference (fp64 anchor test)
-    assert float((a["ldj"] - b["ldj"]).abs().max()) <= 2e-4 * max(1.0, float(b["ldj"].abs().max()))
+    # the trained ODEs amplify one rounding difference: on this patch the fp32 CPU oracle is 2.2e-3 (of scale 0.76) from its own
+    # float64 evaluation (fp64 anchor test above); two fp32 evaluations that differ in the rounding of their gates stay inside that
+    assert float((a["x"] - b["x"]).abs().max()) <= 2e-3 * scale
+    assert float((a["ldj"] - b["ldj"]).abs().max()) <= 2e-3 * max(1.0, float(b["ldj"].abs().max()))
+
+
+@pytest.mark.parametrize("block", [0, 1, 4])
+def test_context_gemm_matches_float64(golden_dir, block):
+    """pf_cnf_context (the split-fp16 streaming GEMM, cd = 32 / 64 / 128) against c Hc^T + hb in float64 on the trained
+    checkpoint's hyper-network weights: fp32-grade (the products keep 22+ bits)."""
+    g, sd = _pretrained(golden_dir)
+    eng = _net(sd)._engine(4)
+    cd = eng.Hc[block].shape[1]
+    gen = torch.Generator().manual_seed(block)
+    c = (torch.randn(1000, cd, generator=gen) * 0.8).to(DEV)           # 1000 rows: a ragged last tile
+    ctx = eng.context(block, c)
+    ref = c.double().cpu() @ eng.Hc[block].double().cpu().T + eng.hb[block].double().cpu()
+    err = (ctx.double().cpu() - ref).abs().max()
+    assert float(err) <= 2e-6 * max(1.0, float(ref.abs().max())), float(err)
