@@ -581,19 +581,20 @@ __global__ __launch_bounds__(CNF_NW * 64) void cnf_init_kernel(CnfInitArgs a) {
         if (PROBE) y += f0 * (h * 1.f);
         const float* cx = a.ctx + (size_t)pt * CNF_CTX;
         const f4 k = cnf_eval(w, q, y, t, a.sgn, cx, a.e[(size_t)pt * 3 + 0], a.e[(size_t)pt * 3 + 1], a.e[(size_t)pt * 3 + 2]);
-        if (ok && q == 0) {
-            if (!PROBE) *reinterpret_cast<f4*>(a.f0 + (size_t)row * 4) = k;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float sc = a.atol + a.rtol * fabsf(y0[c]);
-                if (PROBE) {
-                    const float r = (k[c] - f0[c]) / sc;
-                    acc0 += (double)r * (double)r;
-                } else {
-                    const float r0 = y0[c] / sc, r1 = k[c] / sc;
-                    acc0 += (double)r0 * (double)r0;
-                    acc1 += (double)r1 * (double)r1;
-                }
+        if (ok && q == 0 && !PROBE) *reinterpret_cast<f4*>(a.f0 + (size_t)row * 4) = k;
+        if (ok) {                                            // the four lanes of a column take one component each (same box:
+                                                             // 12.96 -> 12.86 ms per forward against the q = 0 lanes doing all four)
+            const float yc = q == 0 ? y0.x : (q == 1 ? y0.y : (q == 2 ? y0.z : y0.w));
+            const float kc = q == 0 ? k.x : (q == 1 ? k.y : (q == 2 ? k.z : k.w));
+            const float sc = a.atol + a.rtol * fabsf(yc);
+            if (PROBE) {
+                const float fc = q == 0 ? f0.x : (q == 1 ? f0.y : (q == 2 ? f0.z : f0.w));
+                const float r = (kc - fc) / sc;
+                acc0 += (double)r * (double)r;
+            } else {
+                const float r0 = yc / sc, r1 = kc / sc;
+                acc0 += (double)r0 * (double)r0;
+                acc1 += (double)r1 * (double)r1;
             }
         }
     }
