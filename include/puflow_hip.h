@@ -80,7 +80,8 @@ int pf_post(int unit, const float* h, const float* w, const long long* off, floa
             float* pq_next, int T, void* stream);
 /* pf_cond of all six units in ONE launch (the stages only feed the flow kernels, so they run after the EdgeConv chain):
  * h[6] device pointers to the units' EdgeConv outputs (HOST array of device pointers), c[6] likewise (or NULL),
- * st [6][T][8], cp [6][T][64], off[6*13]. */
+ * st [6][T][8], cp [6][T][64], off[6*13].  st = cp = NULL with c given: the stage stops at the conditioning features (the
+ * continuous model needs nothing else of it). */
 int pf_cond_all(const float* const* h, const float* w, const long long* off, float* const* c, float* st, float* cp, int T,
                 void* stream);
 

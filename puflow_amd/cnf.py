@@ -333,7 +333,7 @@ class PointInterpFlow(nn.Module):
         eng.nfe = eng.accepted = eng.rejected = 0
         base = eng.base
         idx16 = base.knn(xyz)
-        cs, _, _ = base.features(xyz, idx16, want_cs=True)
+        cs, _, _ = base.features(xyz, idx16, want_cs=True, cs_only=True)
         if noise is None:
             noise = [torch.randn(B, N, 3, device=xyz.device) for _ in range(NUM_BLOCKS)]
         es = [n.reshape(T, 3).contiguous().float() for n in noise]

@@ -233,6 +233,7 @@ __device__ __forceinline__ void cond_body(const CondArgs& a, u4* wl, int tile0, 
                 for (int o = 0; o < CB; ++o)
                     *reinterpret_cast<f4*>(a.c + (size_t)pt * CDIM + o * 16 + 4 * q) = pf_scale(c[0][o], iM2);
         }
+        if (!a.st) continue;                               // conditioning features only (the continuous model: pf_cond_all with st = cp = NULL)
         // ---- coupling1 c-part (rows 128..191 of H1), stored raw
         {
             f4 acc[1][4];
@@ -398,7 +399,7 @@ extern "C" int pf_cond(int unit, const float* h, const float* w, const long long
 // none); st [6][T][8], cp [6][T][64] unit-major as the flow kernels read them; off: 6 x 13 offsets (POST_SLOTS per unit).
 extern "C" int pf_cond_all(const float* const* h, const float* w, const long long* off, float* const* c, float* st, float* cp,
                            int T, void* stream) {
-    if (!h || !w || !off || !st || !cp) return PF_ERR_NULL;
+    if (!h || !w || !off || (!st != !cp) || (!st && !c)) return PF_ERR_NULL;      // st = cp = NULL: only the conditioning features c
     if (T <= 0) return PF_ERR_SHAPE;
     CondAllArgs g{};
     const int ntiles = (T + 15) / 16;                      // wave tiles
@@ -411,7 +412,7 @@ extern "C" int pf_cond_all(const float* const* h, const float* w, const long lon
     for (int u = 0; u < 6; ++u) {
         if (!h[u]) return PF_ERR_NULL;
         CondArgs& a = g.u[u];
-        a.h = h[u]; a.w = w; a.c = c ? c[u] : nullptr; a.st = st + (size_t)u * T * 8; a.cp = cp + (size_t)u * T * 64; a.T = T;
+        a.h = h[u]; a.w = w; a.c = c ? c[u] : nullptr; a.st = st ? st + (size_t)u * T * 8 : nullptr; a.cp = cp ? cp + (size_t)u * T * 64 : nullptr; a.T = T;
         a.ntiles = ntiles;
         for (int i = 0; i < 13; ++i) a.off[i] = off[u * 13 + i];
         a.contiguous = cond_contiguous(a.off, u == 0 ? 32 : (u == 1 ? 64 : 128));

@@ -205,13 +205,14 @@ class _Engine:
                    "pf_knn")
         return idx
 
-    def features(self, xyz: Tensor, idx16: Tensor, want_cs: bool):
+    def features(self, xyz: Tensor, idx16: Tensor, want_cs: bool, cs_only: bool = False):
         """6x (EdgeConv -> next unit's P|Q GEMM), then the six conditioner stages (they only feed the flow kernels, so they
-        stay off the EdgeConv -> P|Q -> EdgeConv chain).  Returns cs (or None), cp [6,T,64], st [6,T,8]."""
+        stay off the EdgeConv -> P|Q -> EdgeConv chain).  Returns cs (or None), cp [6,T,64], st [6,T,8].
+        cs_only (with want_cs; the continuous model): the conditioner stage stops at the features - cp and st are None."""
         B, N, _ = xyz.shape
         T, dev, s = B * N, xyz.device, self._stream()
-        cp = torch.empty((NUM_BLOCKS, T, 64), dtype=torch.float32, device=dev)
-        st = torch.empty((NUM_BLOCKS, T, 8), dtype=torch.float32, device=dev)
+        cp = torch.empty((NUM_BLOCKS, T, 64), dtype=torch.float32, device=dev) if not (cs_only and want_cs) else None
+        st = torch.empty((NUM_BLOCKS, T, 8), dtype=torch.float32, device=dev) if not (cs_only and want_cs) else None
         pq = torch.empty((T, 512), dtype=torch.float32, device=dev)
         hs: List[Tensor] = []
         # units read their P|Q table while the next one's is written: two tables, alternating (the fused kernel reads and writes
@@ -237,13 +238,14 @@ class _Engine:
         self._cond_all(hs, cs if want_cs else None, st, cp, T, s)
         return (cs if want_cs else None), cp, st
 
-    def _cond_all(self, hs, cs, st: Tensor, cp: Tensor, T: int, s) -> None:
+    def _cond_all(self, hs, cs, st: Optional[Tensor], cp: Optional[Tensor], T: int, s) -> None:
         """The six conditioner stages in one launch (pf_cond_all)."""
         import ctypes
         PtrArr = ctypes.c_void_p * NUM_BLOCKS
         h_arr = PtrArr(*[h.data_ptr() for h in hs])
         c_arr = PtrArr(*[c.data_ptr() for c in cs]) if cs is not None else None
-        _lib.check(self.lib.pf_cond_all(h_arr, self.base, self.post_all, c_arr, st.data_ptr(), cp.data_ptr(), T, s), "pf_cond_all")
+        _lib.check(self.lib.pf_cond_all(h_arr, self.base, self.post_all, c_arr, st.data_ptr() if st is not None else None,
+                                        cp.data_ptr() if cp is not None else None, T, s), "pf_cond_all")
 
     def logp_ws(self, B: int, N: int, dev) -> Tensor:
         """A zeroed workspace of pf_flow_fwd_logp (wave-tile sums + the arrival counter the kernel leaves at zero)."""

@@ -316,3 +316,17 @@ def test_context_gemm_matches_float64(golden_dir, block):
     ref = c.double().cpu() @ eng.Hc[block].double().cpu().T + eng.hb[block].double().cpu()
     err = (ctx.double().cpu() - ref).abs().max()
     assert float(err) <= 2e-6 * max(1.0, float(ref.abs().max())), float(err)
+
+
+def test_features_only_mode_of_the_conditioner_stage():
+    """pf_cond_all with st = cp = NULL (the continuous model's call) writes the same conditioning features as the full stage."""
+    sd = synth_cnf_state_dict(5)
+    net = _net(sd)
+    base = net._engine(4).base
+    xyz = synth_patches(2, 300, seed=8).to(DEV)
+    idx16 = base.knn(xyz)
+    full, cp, st = base.features(xyz, idx16, want_cs=True)
+    only, cp0, st0 = base.features(xyz, idx16, want_cs=True, cs_only=True)
+    assert cp0 is None and st0 is None and cp is not None
+    for a, b in zip(full, only):
+        assert torch.equal(a, b)
