@@ -47,13 +47,18 @@ while time.time() < t_end:
     elif pick == 1:
         B, N = 8, int(torch.randint(3100, 4000, (1,), generator=g))                   # 384 .. 1023 workgroups: 8 slices
         M = int(torch.randint(1024, 1400, (1,), generator=g))
+    elif pick == 2:
+        B, N = 24, int(torch.randint(180, 700, (1,), generator=g))                    # 64 .. 1024 query tiles and 256 <= M < 1024:
+        M = int(torch.randint(256, 1024, (1,), generator=g))                          # knn5_kernel's small-table shapes (training)
+    # (picks 0 / 1 now run knn5_kernel - M <= 4096 and >= 64 query tiles; the reference-slice kernels keep the small grids)
     p = cloud(B, M, kind); q = p[:, :N].contiguous() if N <= M and int(torch.randint(0, 2, (1,), generator=g)) else cloud(B, N, kind)
     d_ref, i_ref = O.knn_canonical(q, p, min(K, M))
     i, d = ops.knn_idx32(q.to(DEV), p.to(DEV), min(K, M), want_dist=True)
     assert torch.equal(i.cpu().long(), i_ref) and torch.equal(d.cpu(), d_ref), ("knn", kind, B, N, M, K)
     n_knn += 1
     # ---- nearest neighbour
-    x, y = cloud(2, int(torch.randint(50, 2000, (1,), generator=g)), kind), cloud(2, int(torch.randint(33, 3000, (1,), generator=g)), kind)
+    Bn = 20 if int(torch.randint(0, 2, (1,), generator=g)) else 2                   # 20 items: >= 64 query tiles -> knn5_kernel<1>
+    x, y = cloud(Bn, int(torch.randint(300 if Bn == 20 else 50, 2000, (1,), generator=g)), kind), cloud(Bn, int(torch.randint(260 if Bn == 20 else 33, 3000, (1,), generator=g)), kind)
     d1r, i1r, d2r, i2r = O.chamfer_nn(x, y)
     d1, d2, i1, i2 = ops.chamfer_3DDist()(x.to(DEV), y.to(DEV))
     assert torch.equal(d1.cpu(), d1r) and torch.equal(d2.cpu(), d2r) and torch.equal(i1.cpu().long(), i1r) and torch.equal(i2.cpu().long(), i2r), ("nn1", kind)
