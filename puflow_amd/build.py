@@ -68,7 +68,29 @@ def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "", 
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    global _REFRESHING
+    if not tag and not defines and not _REFRESHING:
+        _REFRESHING = True
+        try:
+            _refresh_variants(lib, verbose)
+        finally:
+            _REFRESHING = False
     return lib
+
+
+_REFRESHING = False
+
+
+def _refresh_variants(lib: str, verbose: bool) -> None:
+    """The variant libraries the bench lines start children on link the main build's objects for every source they do not
+    recompile: one that exists but is older than the library just built lacks whatever that build added (a new exported symbol
+    makes _lib.load() refuse it - bench.py's grad_parity then reports `failed`) - keep them in step."""
+    pkg = os.path.dirname(lib)
+    if os.path.exists(os.path.join(pkg, "libpuflow_hip_f16.so")) and _stale(os.path.join(pkg, "libpuflow_hip_f16.so"), [lib]):
+        build_f16(verbose=verbose)
+    if any(os.path.exists(os.path.join(pkg, f"libpuflow_hip_{t}.so")) and _stale(os.path.join(pkg, f"libpuflow_hip_{t}.so"), [lib])
+           for t in ("bwdf32", "gradf32")):
+        build_gradf32(verbose=verbose)
 
 
 def build_f16(force: bool = False, verbose: bool = True) -> str:
