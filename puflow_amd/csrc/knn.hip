@@ -578,6 +578,7 @@ __global__ __launch_bounds__(NW * 64) void knn5_kernel(const float* __restrict__
             f4 d[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) d[u] = filt(c0 + u);
+            __builtin_amdgcn_sched_barrier(0);                  // all eight MFMAs in flight before a minimum waits for the first (57.5 -> 56 us)
 #pragma unroll
             for (int u = 0; u < 8; u += 4)
 #pragma unroll
