@@ -31,6 +31,9 @@
 #ifndef PF_KNN5
 #define PF_KNN5 1                        // 0: A/B builds without the matrix-pipe sweeps (knn5_kernel)
 #endif
+#ifndef PF_KNN5_NWMAX
+#define PF_KNN5_NWMAX 16              // waves per workgroup at most (A/B at 32 x 2048: 16 -> 55.9 us, 8 -> 65.3, 4 -> 72.4)
+#endif
 #ifndef PF_KNN5_MIN_M
 #define PF_KNN5_MIN_M 256
 #endif
@@ -821,7 +824,7 @@ static void launch_knn5(const float* p1, const float* p2, int B, int N, int M, i
     const int Mpad = (M + 127) / 128 * 128;
     int ncu = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    int NW = 16;
+    int NW = PF_KNN5_NWMAX;
     while (NW > 4 && ((long long)B * ((N + 16 * NW - 1) / (16 * NW)) < ncu || (size_t)Mpad * 16 + (size_t)NW * KNN5_WB > 150 * 1024)) NW >>= 1;
     const size_t lds = (size_t)Mpad * 16 + (size_t)NW * KNN5_WB;
     const dim3 g5((N + 16 * NW - 1) / (16 * NW), B);
