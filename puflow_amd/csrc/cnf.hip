@@ -26,6 +26,9 @@ namespace {
 
 constexpr int CNF_REC = 10160;
 constexpr int CNF_CTX = 288;
+#ifndef PF_CNF_SPLIT_FWD
+#define PF_CNF_SPLIT_FWD 1           // 0: A/B builds with the factored gates in the inverse pass only
+#endif
 #ifndef PF_CNF_NW
 #define PF_CNF_NW 4
 #endif
@@ -74,12 +77,18 @@ struct CnfW {
 // context rows' gate slots (shared by the point's R rows and the step's six evaluations), the second once per launch into a
 // [stage][channel] table `tvg` points at: a gate is fma + v_rcp_f32, without the v_exp_f32 (36 of an evaluation's 135
 // quarter-rate transcendentals, on a kernel the PMC counters show VALU-bound).
-template <bool SPLIT = false>
+// COMPACT (the forward pass's step kernel, R = 1: 64 points per tile, whose full context rows would not fit in LDS): cx / tvg hold
+// only the 144 gate columns, layer after layer (gate 1 at 0, gate 2 at 64, gate 3 at 128); the bias columns come from cxb (the
+// row in global memory, the full 288-column layout).
+template <bool SPLIT = false, bool COMPACT = false>
 __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, float sgn, const float* __restrict__ cx,
-                                       float e0, float e1, float e2, const float* __restrict__ tvg = nullptr) {
+                                       float e0, float e1, float e2, const float* __restrict__ tvg = nullptr,
+                                       const float* __restrict__ cxb = nullptr) {
     const float* rec = w.rec;
     const float* tv = rec + 9872;
     if (!SPLIT) tvg = tv;
+    if (!COMPACT) cxb = cx;
+    constexpr int G2 = COMPACT ? 64 : 128, G3 = COMPACT ? 128 : 256;
     auto gatef = [](float gt, float tt, float gc) {
         return SPLIT ? __builtin_amdgcn_rcpf(fmaf(gc, gt, 1.f)) : sigm(fmaf(gt, tt, gc));
     };
@@ -92,7 +101,7 @@ __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, floa
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         const int ch = cb * 16 + 4 * q;
-        const f4 gc = *reinterpret_cast<const f4*>(cx + ch), bc = *reinterpret_cast<const f4*>(cx + 64 + ch);
+        const f4 gc = *reinterpret_cast<const f4*>(cx + ch), bc = *reinterpret_cast<const f4*>(cxb + 64 + ch);
         const f4 gt = *reinterpret_cast<const f4*>(tvg + ch), bt = *reinterpret_cast<const f4*>(tv + 64 + ch);
         const f4 lin4 = pf_mfma(rec[9216 + (cb * 16 + col) * 4 + q], yb, pf_splat(0.f));
 #pragma unroll
@@ -116,8 +125,8 @@ __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, floa
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             const int ch = cb * 16 + 4 * q;
-            const f4 gc = *reinterpret_cast<const f4*>(cx + 128 + ch), bc = *reinterpret_cast<const f4*>(cx + 192 + ch);
-            const f4 gt = *reinterpret_cast<const f4*>(tvg + 128 + ch), bt = *reinterpret_cast<const f4*>(tv + 192 + ch);
+            const f4 gc = *reinterpret_cast<const f4*>(cx + G2 + ch), bc = *reinterpret_cast<const f4*>(cxb + 192 + ch);
+            const f4 gt = *reinterpret_cast<const f4*>(tvg + G2 + ch), bt = *reinterpret_cast<const f4*>(tv + 192 + ch);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float gate = gatef(gt[r], t, gc[r]);
@@ -135,8 +144,8 @@ __device__ __forceinline__ f4 cnf_eval(const CnfW& w, int q, f4 y, float t, floa
         f4 a3[1][1];
         a3[0][0] = *reinterpret_cast<const f4*>(rec + 9856 + 4 * q);
         pf_mm2f<1, 2, 2>(w.w3, 0, hp, 0, a3, 0);
-        const f4 gc = *reinterpret_cast<const f4*>(cx + 256 + 4 * q), bc = *reinterpret_cast<const f4*>(cx + 272 + 4 * q);
-        const f4 gt = *reinterpret_cast<const f4*>(tvg + 256 + 4 * q), bt = *reinterpret_cast<const f4*>(tv + 272 + 4 * q);
+        const f4 gc = *reinterpret_cast<const f4*>(cx + G3 + 4 * q), bc = *reinterpret_cast<const f4*>(cxb + 272 + 4 * q);
+        const f4 gt = *reinterpret_cast<const f4*>(tvg + G3 + 4 * q), bt = *reinterpret_cast<const f4*>(tv + 272 + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             g3[r] = gatef(gt[r], t, gc[r]);
@@ -392,14 +401,18 @@ __device__ __forceinline__ bool cnf_gate_row(int r) { return r < 64 || (r >= 128
 
 // CTX_LDS (inverse direction, R >= 4 rows per original point): the context rows of the workgroup's 64 / R points are copied
 // to LDS once per tile and all six stage evaluations read them there - each evaluation re-read 1 152 B per row from L2 before
-// SPLIT (with CTX_LDS; the caller's PF_CNF_SPLIT_GATES): see cnf_eval.
+// SPLIT (the caller's PF_CNF_SPLIT_GATES): see cnf_eval.  Without CTX_LDS (the forward pass, R = 1: 64 points per tile) only the
+// 144 gate columns of a point go to LDS, in the compact layout (cnf_eval<.., COMPACT>); the bias columns stay in global memory.
+constexpr int CNF_GATES = 144;
+__device__ __forceinline__ int cnf_gate_col(int c) { return c < 64 ? c : (c < 128 ? c + 64 : c + 128); }     // compact -> ctx column
 template <bool CTX_LDS, bool SPLIT>
 __global__ __launch_bounds__(CNF_NW * 64, PF_CNF_WPE) void cnf_step_dev_kernel(CnfDevArgs a) {
-    static_assert(!SPLIT || CTX_LDS, "the split gates live in the LDS context rows");
+    constexpr bool COMPACT = SPLIT && !CTX_LDS;
+    constexpr int TW = COMPACT ? CNF_GATES : CNF_CTX;               // width of a stage's row of the factor table
     __shared__ f4 wl[CNF_REC / 4];
     __shared__ double red[CNF_NW];
-    __shared__ f4 sctx[CTX_LDS ? CNF_NW * 4 * CNF_CTX / 4 : 1];
-    __shared__ float stf[SPLIT ? 6 * CNF_CTX : 1];                   // [stage][row]: 2^(gt tsign alpha_s h) on the gate rows
+    __shared__ f4 sctx[CTX_LDS ? CNF_NW * 4 * CNF_CTX / 4 : (COMPACT ? CNF_NW * 16 * CNF_GATES / 4 : 1)];
+    __shared__ float stf[SPLIT ? 6 * TW : 1];                        // [stage][column]: 2^(gt tsign alpha_s h) of the gate columns
     if (a.ctl[CTL_DONE] != 0.0) return;                              // uniform over the grid
     const int cur = (int)a.ctl[CTL_CUR];
     const float t = (float)a.ctl[CTL_T], h = (float)a.ctl[CTL_DT];
@@ -436,8 +449,8 @@ __global__ __launch_bounds__(CNF_NW * 64, PF_CNF_WPE) void cnf_step_dev_kernel(C
                              (float)(-1776094331. / 19743644256 / 2), (float)(11237099. / 235043384 / 2)};
     if (SPLIT) {
         const float* tv = w.rec + 9872;
-        for (int i = threadIdx.x; i < 6 * CNF_CTX; i += CNF_NW * 64) {
-            const int s = i / CNF_CTX, r = i % CNF_CTX;
+        for (int i = threadIdx.x; i < 6 * TW; i += CNF_NW * 64) {
+            const int s = i / TW, r = COMPACT ? cnf_gate_col(i % TW) : i % TW;
             stf[i] = cnf_gate_row(r) ? __builtin_amdgcn_exp2f(tv[r] * (tsign * AL[s] * h)) : 0.f;
         }                                                             // (visible after the tile loop's barriers)
     }
@@ -449,6 +462,31 @@ __global__ __launch_bounds__(CNF_NW * 64, PF_CNF_WPE) void cnf_step_dev_kernel(C
         const int pt = row / a.R;
         const f4 y0 = *reinterpret_cast<const f4*>(y0p + (size_t)row * 4);
         const float* cx = a.ctx + (size_t)pt * CNF_CTX;
+        const float* cxb = cx;
+        if (COMPACT) {
+            // the gate columns of the tile's points (rows [64 tile, 64 tile + 63] -> points first .. last) as 2^(gt tsign t + gc)
+            const long long npts = ((long long)a.rows + a.R - 1) / a.R;
+            const long long r0 = (long long)tile * CNF_NW * 16;
+            const long long p0 = r0 / a.R;
+            long long pe = (r0 + CNF_NW * 16 - 1) / a.R;
+            pe = pe < npts ? pe : npts - 1;
+            const int np = (int)(pe - p0 + 1);                     // <= 64
+            __syncthreads();                                       // every wave is done with the previous tile's columns
+            const float tt = tsign * t;
+            for (int i = threadIdx.x; i < np * (CNF_GATES / 4); i += CNF_NW * 64) {
+                const int pp = i / (CNF_GATES / 4), c4 = (i % (CNF_GATES / 4)) * 4;
+                const int r = cnf_gate_col(c4);
+                const f4 v = *reinterpret_cast<const f4*>(a.ctx + (size_t)(p0 + pp) * CNF_CTX + r);
+                const f4 g4 = *reinterpret_cast<const f4*>(w.rec + 9872 + r);
+                f4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = __builtin_amdgcn_exp2f(fmaf(g4[k], tt, v[k]));
+                sctx[i] = o;
+            }
+            __syncthreads();
+            const long long pl = pt - p0;
+            cx = reinterpret_cast<const float*>(sctx) + (size_t)(pl < 0 ? 0 : (pl >= np ? np - 1 : pl)) * CNF_GATES;
+        }
         if (CTX_LDS) {
             const int ppw = CNF_NW * 16 / a.R;                     // points of this workgroup's tile (<= 16)
             const long long p0 = (long long)tile * ppw;
@@ -479,7 +517,7 @@ __global__ __launch_bounds__(CNF_NW * 64, PF_CNF_WPE) void cnf_step_dev_kernel(C
 #pragma unroll
             for (int j = 1; j <= s; ++j) comb += k[j] * BE[s][j];
             yi = y0 + comb * h;
-            k[s + 1] = cnf_eval<SPLIT>(w, q, yi, tsign * (t + AL[s] * h), sgn, cx, e0, e1, e2, stf + (SPLIT ? s * CNF_CTX : 0));
+            k[s + 1] = cnf_eval<SPLIT, COMPACT>(w, q, yi, tsign * (t + AL[s] * h), sgn, cx, e0, e1, e2, stf + (SPLIT ? s * TW : 0), cxb);
         });
         f4 err = k[0] * CE[0];
 #pragma unroll
@@ -824,7 +862,8 @@ extern "C" int pf_cnf_steps(double* ctl, float* ya, float* yb, float* fa, float*
             if (flags & PF_CNF_SPLIT_GATES) hipLaunchKernelGGL((cnf_step_dev_kernel<true, true>), dim3(grid), dim3(CNF_NW * 64), 0, s, a);
             else hipLaunchKernelGGL((cnf_step_dev_kernel<true, false>), dim3(grid), dim3(CNF_NW * 64), 0, s, a);
         } else {
-            hipLaunchKernelGGL((cnf_step_dev_kernel<false, false>), dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+            if ((flags & PF_CNF_SPLIT_GATES) && PF_CNF_SPLIT_FWD) hipLaunchKernelGGL((cnf_step_dev_kernel<false, true>), dim3(grid), dim3(CNF_NW * 64), 0, s, a);
+            else hipLaunchKernelGGL((cnf_step_dev_kernel<false, false>), dim3(grid), dim3(CNF_NW * 64), 0, s, a);
         }
     }
     return pf_last_launch_status();
