@@ -330,3 +330,19 @@ def test_features_only_mode_of_the_conditioner_stage():
     assert cp0 is None and st0 is None and cp is not None
     for a, b in zip(full, only):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("R", [2, 3, 8])
+def test_forward_other_up_ratios_match_oracle(R):
+    """Up-ratios other than 4: R = 8 keeps the inverse pass on the LDS-context kernel (8 rows per point), R = 2 / 3 send it
+    through the forward pass's kernel with several rows per point (compact gate columns, rows -> points by division)."""
+    sd = synth_cnf_state_dict(11)
+    xyz = synth_patches(1, 200, seed=21)
+    g = torch.Generator().manual_seed(R)
+    noise = [torch.randn(1, 200, 3, generator=g) for _ in range(6)]
+    ref = C.forward(sd, xyz, R, noise=noise, stages=True)
+    net = _net(sd)
+    st = net(xyz.to(DEV), R, noise=[n.to(DEV) for n in noise], stages=True)
+    assert tuple(st["x"].shape) == (1, 200 * R, 3)
+    assert st["nfe"] == ref["nfe"] and st["accepted"] == ref["accepted"] and st["rejected"] == ref["rejected"]
+    assert (st["x"].cpu() - ref["x"]).abs().max() < 1e-4 and (st["z"].cpu() - ref["z"]).abs().max() < 1e-4
