@@ -346,3 +346,28 @@ def test_forward_other_up_ratios_match_oracle(R):
     assert tuple(st["x"].shape) == (1, 200 * R, 3)
     assert st["nfe"] == ref["nfe"] and st["accepted"] == ref["accepted"] and st["rejected"] == ref["rejected"]
     assert (st["x"].cpu() - ref["x"]).abs().max() < 1e-4 and (st["z"].cpu() - ref["z"]).abs().max() < 1e-4
+
+
+def test_scaled_sumsq_vector_and_scalar_paths():
+    """pf_scaled_sumsq: the 16-byte-load path (aligned, n % 4 == 0) and the element path (a view that starts one float in)
+    against the float64 sum, with and without the second state of the maximum and the subtrahend."""
+    import ctypes
+    from puflow_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    n = 4 * 50_001
+    base = [torch.randn(n + 4, generator=g).to(DEV) for _ in range(4)]
+    ws = torch.empty(256, dtype=torch.float64, device=DEV)
+    out = torch.empty(1, dtype=torch.float64, device=DEV)
+    w0 = (ctypes.c_float * 1)(0.0)
+    for off, nn_ in ((0, n), (1, n), (0, n - 2)):
+        a, b, s0, s1 = (t[off:off + nn_] for t in base)
+        for use_b, use_s1 in ((False, False), (True, True)):
+            _lib.check(lib.pf_scaled_sumsq(a.data_ptr(), b.data_ptr() if use_b else None, s0.data_ptr(),
+                                           s1.data_ptr() if use_s1 else None, None, w0, 0, 0.0, 1e-5, 1e-5, nn_, ws.data_ptr(),
+                                           out.data_ptr(), torch.cuda.current_stream().cuda_stream), "pf_scaled_sumsq")
+            v = (a - b) if use_b else a
+            m = torch.maximum(s0.abs(), s1.abs()) if use_s1 else s0.abs()
+            r = (v / (1e-5 + 1e-5 * m)).double()            # the kernel divides in fp32 (its denominator is one fma: an ulp from
+            ref = float((r * r).sum())                      # torch's mul + add), squares and sums in double
+            assert abs(float(out) - ref) <= 1e-7 * ref, (off, nn_, use_b, use_s1)
