@@ -262,17 +262,21 @@ class _CnfEngine:
             raise _lib.PuflowHipError(f"dopri5: underflow in dt ({dt:g}) at t = {t:g}, block {i}")
         return out
 
-    def check_logs(self, n: int) -> bool:
-        """The controller states of the first n deferred integrations, ONE device -> host read: True when every one finished
-        cleanly inside its attempts (the counters are then added to the statistics)."""
+    def check_logs(self, n: int, took: List[int]) -> int:
+        """The controller states of the first n deferred integrations, ONE device -> host read: how many of them, from the
+        first on, finished cleanly inside their attempts.  Their counters are added to the statistics and their attempt counts
+        written into `took`."""
         L = self.logs[:n].cpu()
-        if not bool(((L[:, 5] != 0) & (L[:, 9] == 0)).all()):
-            return False
-        self.hint = [int(a) for a in (L[:, 6] + L[:, 7]).tolist()]
-        self.accepted += int(L[:, 6].sum())
-        self.rejected += int(L[:, 7].sum())
-        self.nfe += int(L[:, 8].sum())
-        return True
+        ok = ((L[:, 5] != 0) & (L[:, 9] == 0)).tolist()
+        k = 0
+        while k < n and ok[k]:
+            k += 1
+        for j in range(k):
+            took[j] = int(L[j, 6] + L[j, 7])
+        self.accepted += int(L[:k, 6].sum())
+        self.rejected += int(L[:k, 7].sum())
+        self.nfe += int(L[:k, 8].sum())
+        return k
 
 
 class PointInterpFlow(nn.Module):
@@ -345,47 +349,55 @@ class PointInterpFlow(nn.Module):
         for i in range(NUM_BLOCKS):
             eng.context_norm(cflat[i], d0c[i:i + 1])
 
-        def run(deferred: bool):
-            """f, interpolation, g.  deferred: no look at a controller until all twelve integrations are enqueued."""
-            k = 0
-            took.clear()
-            p = xyz.reshape(T, 3)
-            sts = []
+        NI = 2 * NUM_BLOCKS
+
+        def run(deferred: bool, k0: int = 0, outs=None):
+            """f, interpolation, g = integrations 0 .. 11.  deferred: no look at a controller until all twelve are enqueued.
+            k0 > 0: integrations < k0 are taken from `outs` (a blind run that got that far) and the rest is integrated."""
+            outs = list(outs) if outs is not None else [None] * NI
             for i in range(NUM_BLOCKS):
-                p = eng.integrate(i, p, ctx[i], es[i], 1, False, cflat[i].numel(), d0c[i:i + 1], eng.logs[k] if deferred else None,
-                                  blind[k] if deferred else 0)            # [T,4]: the next block reads its first three columns in place
-                took.append(getattr(eng, "last_attempts", 0))
-                k += 1
-                sts.append(p)
+                if i < k0:
+                    continue
+                p_in = xyz.reshape(T, 3) if i == 0 else outs[i - 1]        # [T,4]: a block reads the previous state's first three columns in place
+                outs[i] = eng.integrate(i, p_in, ctx[i], es[i], 1, False, cflat[i].numel(), d0c[i:i + 1],
+                                        eng.logs[i] if deferred else None, blind[i] if deferred else 0)
+                took[i] = getattr(eng, "last_attempts", 0)
             # the six blocks' delta logp, summed per patch in one reduction (it was a reduce + an add per block)
-            ldj = torch.stack([s_[:, 3] for s_ in sts]).view(NUM_BLOCKS, B, N).sum(dim=(0, 2))
-            z = p[:, :3].reshape(B, N, 3)
+            ldj = torch.stack([s_[:, 3] for s_ in outs[:NUM_BLOCKS]]).view(NUM_BLOCKS, B, N).sum(dim=(0, 2))
+            z = outs[NUM_BLOCKS - 1][:, :3].reshape(B, N, 3)
             logp = -torch.mean(torch.sum(-0.5 * (z ** 2 + math.log(2 * math.pi)), dim=(1, 2)) - ldj)
-            u = base.interp(xyz, z.contiguous(), idx16, upratio).reshape(T * upratio, 3)            # row n*R + r
-            for i in reversed(range(NUM_BLOCKS)):
-                u = eng.integrate(i, u, ctx[i], es[i], upratio, True, cflat[i].numel() * upratio, d0c[i:i + 1],
-                                  eng.logs[k] if deferred else None, blind[k] if deferred else 0, extra_scale=float(upratio))
-                took.append(getattr(eng, "last_attempts", 0))
-                k += 1
-            return z, ldj, logp, u[:, :3].contiguous()
+            u0 = None
+            for j, i in enumerate(reversed(range(NUM_BLOCKS))):
+                k = NUM_BLOCKS + j
+                if k < k0:
+                    continue
+                if j == 0:
+                    u0 = base.interp(xyz, z.contiguous(), idx16, upratio).reshape(T * upratio, 3)        # row n*R + r
+                outs[k] = eng.integrate(i, u0 if j == 0 else outs[k - 1], ctx[i], es[i], upratio, True, cflat[i].numel() * upratio,
+                                        d0c[i:i + 1], eng.logs[k] if deferred else None, blind[k] if deferred else 0,
+                                        extra_scale=float(upratio))
+                took[k] = getattr(eng, "last_attempts", 0)
+            return z, ldj, logp, outs[NI - 1][:, :3].contiguous(), outs
 
         # The host used to read the controller after every batch of attempts (~2 reads x 12 integrations, each a pipeline
-        # bubble).  Now the whole forward is enqueued blind and the twelve final controller states are read ONCE; an integration
-        # that did not finish inside its attempts (or hit an error state) sends the forward through the look-per-batch loop,
-        # which also raises the errors.  Same arithmetic either way: attempts past the end of an integration are no-ops.
-        # How many attempts to enqueue blind: what each integration took on the previous forward + an eighth + 2 (the first
-        # forward of an engine, and any forward whose guess was too small, takes the loop and leaves the counts).
-        done = False
-        took: List[int] = []
+        # bubble).  Now the whole forward is enqueued blind and the twelve final controller states are read ONCE.  An integration
+        # that did not finish inside its attempts (or hit an error state) ends the blind part THERE: everything before it stands,
+        # it and the integrations behind it go through the look-per-batch loop (which also raises the errors).  Same arithmetic
+        # either way: attempts past the end of an integration are no-ops.
+        # How many attempts to enqueue blind: what each integration took before + an eighth + 2; the counts decay by at most one
+        # per forward, so an input stream whose counts flutter does not miss every other time (the first forward of an engine
+        # takes the loop and leaves the counts).
+        took: List[int] = [0] * NI
+        k0, outs = 0, None
         if eng.async_attempts > 0 and eng.hint is not None:
             blind = [h + h // 8 + 2 for h in eng.hint]
-            z, ldj, logp, u = run(True)
-            done = eng.check_logs(2 * NUM_BLOCKS)
-        if not done:
-            eng.nfe = eng.accepted = eng.rejected = 0
+            z, ldj, logp, u, outs = run(True)
+            k0 = eng.check_logs(NI, took)
+        if k0 < NI:
             blind = []
-            z, ldj, logp, u = run(False)
-            eng.hint = list(took)
+            z, ldj, logp, u, outs = run(False, k0, outs)
+        old = eng.hint if eng.hint is not None else took
+        eng.hint = [max(t, h - 1) for t, h in zip(took, old)]
         x = u.view(B, N * upratio, 3)
         self.last_stats = dict(nfe=eng.nfe, accepted=eng.accepted, rejected=eng.rejected)
         if stages:

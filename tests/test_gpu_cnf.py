@@ -270,11 +270,15 @@ def test_deferred_forward_equals_the_look_per_batch_loop():
     eng.async_attempts = 1
     assert eng.hint is not None and len(eng.hint) == 12 and max(eng.hint) > 2 * min(eng.hint)     # the T = 36 block needs the most
     res["deferred"] = net(xyz, 4, noise=noise, stages=True)
-    eng.hint = [1] * 12                                                 # a guess that is too small: blind run, then the loop
-    res["fallback"] = net(xyz, 4, noise=noise, stages=True)
+    good = list(eng.hint)
+    eng.hint = [1] * 12                                                 # a guess that is too small: the blind part ends at the first
+    res["fallback"] = net(xyz, 4, noise=noise, stages=True)             # integration that needs more, the loop takes over there
     assert eng.hint is not None and max(eng.hint) > 3
+    eng.hint = good[:6] + [1] + good[7:]                                # ... and at the start of the inverse pass (its first
+    res["resume_in_g"] = net(xyz, 4, noise=noise, stages=True)          # integration is the T = 36 block: 3 attempts are not enough)
+    assert good[6] > 3 and eng.hint[6] == good[6] and eng.hint[:6] == good[:6]
     assert res["loop"]["rejected"] >= 3 and res["loop"]["nfe"] > 300
-    for name in ("deferred", "fallback"):
+    for name in ("deferred", "fallback", "resume_in_g"):
         assert torch.equal(res[name]["x"], res["loop"]["x"]) and torch.equal(res[name]["z"], res["loop"]["z"])
         assert torch.equal(res[name]["ldj"], res["loop"]["ldj"])
         assert (res[name]["nfe"], res[name]["accepted"], res[name]["rejected"]) == (res["loop"]["nfe"], res["loop"]["accepted"], res["loop"]["rejected"])
