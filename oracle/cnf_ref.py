@@ -170,6 +170,60 @@ def rhs(sd: SD, i: int, t: float, state: Tensor, c: Tensor, e: Tensor) -> Tensor
     return torch.cat([dy.detach(), -div], dim=-1)
 
 
+def rhs_vjp(sd: SD, i: int, t: float, y: Tensor, c: Tensor, e: Tensor, a_y: Tensor, a_l: Tensor):
+    """Groundwork for the adjoint backward (torchdiffeq's odeint_adjoint @ cnf.py:89-99 evaluates exactly this product
+    at every step of the backward integration): the vector-Jacobian product of the right-hand side (dy, -div) with the adjoint
+    (a_y [rows,3], a_l [rows]) - the gradient of S = sum(a_y . dy - a_l e^T (d dy / d y) e) - WITHOUT autograd, by one
+    forward pass of (value, tangent along e) and one reverse pass through the three ConcatSquash layers.
+    Returns dict: y [rows,3], t (scalar), per layer l = 0..2: W, b ([out,in], [out]), gate_pre / bias_pre ([rows,out]: the
+    gradients with respect to the hyper-networks' outputs, from which d/d(hyper weights) = pre^T [t, c] and d/dc follow).
+    tests/test_oracle_cnf.py pins every entry to autograd."""
+    p = f"flow_blocks.{i}.cnf.odefunc.diffeq.layers"
+    rows = y.shape[0]
+    ctx = torch.cat([torch.full((rows, 1), float(t), dtype=y.dtype), c], dim=-1)
+    W = [sd[f"{p}.{l}._layer.weight"].to(y.dtype) for l in range(3)]
+    b = [sd[f"{p}.{l}._layer.bias"].to(y.dtype) for l in range(3)]
+    Wg = [sd[f"{p}.{l}._hyper_gate.weight"].to(y.dtype) for l in range(3)]
+    bg = [sd[f"{p}.{l}._hyper_gate.bias"].to(y.dtype) for l in range(3)]
+    Wb = [sd[f"{p}.{l}._hyper_bias.weight"].to(y.dtype) for l in range(3)]
+    # forward: value x_l and tangent xd_l along e
+    x, xd = [y], [e]
+    lin, lind, g, pd = [], [], [], []
+    for l in range(3):
+        g.append(torch.sigmoid(F.linear(ctx, Wg[l], bg[l])))
+        beta = F.linear(ctx, Wb[l])
+        lin.append(F.linear(x[l], W[l], b[l]))
+        lind.append(F.linear(xd[l], W[l]))
+        pl, pdl = lin[l] * g[l] + beta, lind[l] * g[l]
+        pd.append(pdl)
+        if l < 2:
+            xl = torch.tanh(pl)
+            x.append(xl)
+            xd.append((1 - xl * xl) * pdl)
+        else:
+            x.append(pl)
+            xd.append(pdl)
+    # reverse: seeds fbar = a_y, fdotbar = -a_l e
+    xbar, xdbar = a_y, -a_l[:, None] * e
+    out = {"t": y.new_zeros(())}
+    for l in (2, 1, 0):
+        if l < 2:
+            xl = x[l + 1]
+            pbar = (1 - xl * xl) * (xbar - 2 * xl * pd[l] * xdbar)
+            pdbar = (1 - xl * xl) * xdbar
+        else:
+            pbar, pdbar = xbar, xdbar
+        gl, gld = pbar * g[l], pdbar * g[l]
+        out[f"W{l}"] = gl.t() @ x[l] + gld.t() @ xd[l]
+        out[f"b{l}"] = gl.sum(0)
+        gate_pre = (pbar * lin[l] + pdbar * lind[l]) * g[l] * (1 - g[l])
+        out[f"gate_pre{l}"], out[f"bias_pre{l}"] = gate_pre, pbar
+        out["t"] = out["t"] + (gate_pre * Wg[l][:, 0]).sum() + (pbar * Wb[l][:, 0]).sum()
+        xbar, xdbar = gl @ W[l], gld @ W[l]
+    out["y"] = xbar
+    return out
+
+
 def cnf_block(sd: SD, i: int, x: Tensor, c: Tensor, e: Tensor, reverse: bool, stats: Optional[Dopri5Stats] = None):
     """FlowBlock.forward / .inverse with batch_norm=False (continuous/interpflow.py:30-49) around CNF.forward
     (cnf.py:54-121).  x, e [rows, 3], c [rows, cdim] -> (x', delta_logp [rows])."""

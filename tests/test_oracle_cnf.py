@@ -158,3 +158,43 @@ def test_split_gates_flag_follows_the_overflow_bound(golden_dir):
     big["flow_blocks.5.cnf.odefunc.diffeq.layers.1._hyper_gate.weight"][7, 0] = 2.5
     rec, _, _, T = pack_cnf_block(big, 5)
     assert not cnf_split_ok(rec, T)
+
+
+def test_rhs_vjp_matches_autograd(golden_dir):
+    """oracle/cnf_ref.py::rhs_vjp (the derivation of DESIGN 9a: value + tangent forward, one reverse pass) against autograd through
+    `odenet` and the Hutchinson term, on the trained checkpoint's weights in float64: gradients with respect to y, t, the layer
+    weights / biases and the hyper-networks (via their pre-activation gradients)."""
+    _, sd32 = _pretrained(golden_dir)
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}
+    g = torch.Generator().manual_seed(5)
+    for block in (0, 5):
+        cd = sd[f"flow_blocks.{block}.cnf.odefunc.diffeq.layers.0._hyper_gate.weight"].shape[1] - 1
+        rows = 40
+        y = torch.randn(rows, 3, generator=g, dtype=torch.float64) * 0.6
+        c = torch.randn(rows, cd, generator=g, dtype=torch.float64) * 0.7
+        e = torch.randn(rows, 3, generator=g, dtype=torch.float64)
+        a_y = torch.randn(rows, 3, generator=g, dtype=torch.float64)
+        a_l = torch.randn(rows, generator=g, dtype=torch.float64)
+        t = 0.37
+        p = f"flow_blocks.{block}.cnf.odefunc.diffeq.layers"
+        names = [f"{p}.{l}.{n}" for l in range(3) for n in ("_layer.weight", "_layer.bias", "_hyper_gate.weight", "_hyper_gate.bias",
+                                                            "_hyper_bias.weight")]
+        leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+        sdl = dict(sd); sdl.update(leaf)
+        yv = y.clone().requires_grad_(True)
+        tv = torch.tensor(t, dtype=torch.float64, requires_grad=True)
+        ctx = torch.cat([tv.expand(rows, 1), c], dim=-1)
+        dy = C.odenet(sdl, block, ctx, yv)
+        e_dzdx = torch.autograd.grad(dy, yv, e, create_graph=True)[0]
+        S = (a_y * dy).sum() - (a_l * (e_dzdx * e).sum(-1)).sum()
+        grads = torch.autograd.grad(S, [yv, tv] + [leaf[k] for k in names])
+        ref = dict(zip(["y", "t"] + names, grads))
+        got = C.rhs_vjp(sd, block, t, y, c, e, a_y, a_l)
+        close = lambda a, b: float((a - b).abs().max()) <= 1e-10 * max(1.0, float(b.abs().max()))
+        assert close(got["y"], ref["y"]) and close(got["t"], ref["t"])
+        tc = torch.cat([torch.full((rows, 1), t, dtype=torch.float64), c], dim=-1)
+        for l in range(3):
+            assert close(got[f"W{l}"], ref[f"{p}.{l}._layer.weight"]) and close(got[f"b{l}"], ref[f"{p}.{l}._layer.bias"])
+            assert close(got[f"gate_pre{l}"].t() @ tc, ref[f"{p}.{l}._hyper_gate.weight"])
+            assert close(got[f"gate_pre{l}"].sum(0), ref[f"{p}.{l}._hyper_gate.bias"])
+            assert close(got[f"bias_pre{l}"].t() @ tc, ref[f"{p}.{l}._hyper_bias.weight"])
