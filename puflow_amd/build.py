@@ -19,6 +19,9 @@ EXTRA_FLAGS = {s: ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=" + os.e
 # interp_kernel<1,12> sits exactly on the 168-VGPR budget of three waves per SIMD; the scheduler's default register-pressure
 # tracker overshoots it by four registers (20 bytes of scratch per lane, the only spilling kernel of the eval path), the GCN
 # trackers do not (tools/check_resources.py: 168 VGPRs, no scratch)
+# edgeconv.hip: three LDS weight fragments in flight instead of two (pf_mfma.h PfW2Lds::DEPTH; same VGPR count, same bits):
+# +0.3 - 0.7 % on the headline step in two same-box A/Bs (depth 4 the same)
+EXTRA_FLAGS["edgeconv.hip"] = EXTRA_FLAGS["edgeconv.hip"] + ["-DPF_W2LDS_DEPTH=" + os.environ.get("PF_EC_W2LDS_DEPTH", "3")]
 if os.environ.get("PF_INTERP_TRACKERS", "1") != "0":
     EXTRA_FLAGS["interp.hip"] = EXTRA_FLAGS["interp.hip"] + ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
 
