@@ -181,7 +181,8 @@ int pf_gemm(const float* A, long long sam, long long sak, const float* B, long l
             long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats, void* stream);
 /* the split-K reduction of pf_gemm for callers that wrote their own slabs [nslab][M * N]: C [M, ldc] = their sum, fixed order */
 int pf_gemm_reduce(const float* slabs, float* C, int M, int N, long long ldc, int nslab, void* stream);
-/* pf_gemm with the matrix-pipe arithmetic chosen by the caller: 0 = f32 MFMA (what pf_gemm runs), 2 = split-fp16 (operands
+/* pf_gemm with the matrix-pipe arithmetic chosen by the caller: 0 = f32 MFMA (what pf_gemm runs), 1 = the same products in the
+ * same order on the round-1 kernel (A/B reference: bit-identical to 0), 2 = split-fp16 (operands
  * inside the fp16 range: forward GEMMs), 3 = split-bf16 (gradient operands); all fp32-class results. */
 int pf_gemm_ex(int arith, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
                long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats, void* stream);

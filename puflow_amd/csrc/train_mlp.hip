@@ -31,6 +31,10 @@ constexpr int MLP_GRID = 512;
 #ifndef PF_MLP_RG
 #define PF_MLP_RG 16
 #endif
+#ifndef PF_DW_ABL
+#define PF_DW_ABL 0            // timing-only ablations of mlp_dw_kernel (tools/time_mlpdw.py): 1 no MFMA block, 2 no loads in the loop, 4 no LDS stores
+#endif
+constexpr int MLP_LD = 144;            // LDS row stride of the weight-gradient kernel's staged blocks: >= 128 / 144 columns, = 16 (mod 32) floats
 constexpr int MLP_EB = 32, MLP_DW_WAVES = PF_MLP_DW_WAVES, MLP_SLOTS = (36 + MLP_DW_WAVES - 1) / MLP_DW_WAVES;   // 36 = 4 x 9 tiles of the widest layer
 // rows per split-K chunk (multiple of MLP_EB): the descriptor's choice (batched launches have networks x layers of parallelism
 // already and want long chunks: fewer partial sums to write and add), else sized so that one network fills the chip
@@ -70,10 +74,57 @@ template <typename T>
 __host__ __device__ inline T sel2(const T (&a)[2], int l) { return l == 0 ? a[0] : a[1]; }
 
 // ------------------------------------------------------------------------------------------------ forward
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* rflp(T* ptr) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+// A descriptor that reaches a kernel through `descs ? descs[blockIdx.z] : p0` carries GENERIC pointers (only the pointer members
+// of a by-value kernel argument are known to be global): every access through them was a flat_load / flat_store, which counts
+// on the LDS counter as well as the memory counter - each `s_waitcnt lgkmcnt` in front of an LDS-fed MFMA then also waited for
+// the global prefetch in flight.  MlpG = the descriptor's pointers typed as what they are (address space 1); a cast to
+// address space 1 and back is folded away by hipcc, only an access THROUGH the typed pointer becomes global_load / global_store.
+#define PF_G __attribute__((address_space(1)))
+typedef const float PF_G* gcp;
+typedef float PF_G* gp;
+typedef const f4 PF_G* gc4p;
+typedef f4 PF_G* g4p;
+struct MlpG {
+    gcp y, c, W[3], b[3], dout;
+    gp h[2], out, dz[2], dy, dc, dW[3], db[3], ws;
+};
+__device__ __forceinline__ MlpG mlp_glob(const PfMlpTrain& p) {
+    MlpG g;
+    g.y = (gcp)p.y; g.c = (gcp)p.c; g.dout = (gcp)p.dout; g.out = (gp)p.out; g.dy = (gp)p.dy; g.dc = (gp)p.dc; g.ws = (gp)p.ws;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { g.W[i] = (gcp)p.W[i]; g.b[i] = (gcp)p.b[i]; g.dW[i] = (gp)p.dW[i]; g.db[i] = (gp)p.db[i]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { g.h[i] = (gp)p.h[i]; g.dz[i] = (gp)p.dz[i]; }
+    return g;
+}
+
+// the descriptor of this workgroup's network with wave-uniform shapes and global pointers (see above): with the fields as they
+// come out of the vector loads hipcc treats every shape derived from them as lane-dependent - exec-masked regions around each
+// tile's read + MFMA, one LDS read waited for per MFMA (mlp_dw_kernel: ~7 us per 32-row block of the widest layer)
+__device__ __forceinline__ PfMlpTrain mlp_desc(const PfMlpTrain& p0, const PfMlpTrain* descs) {
+    PfMlpTrain p = descs ? descs[blockIdx.z] : p0;             // batched launch: one network per blockIdx.z
+    p.rows = rfl(p.rows); p.nl = rfl(p.nl); p.td = rfl(p.td); p.cc = rfl(p.cc); p.cdiv = rfl(p.cdiv); p.ldy = rfl(p.ldy); p.chunk = rfl(p.chunk);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { p.width[i] = rfl(p.width[i]); p.W[i] = rflp(p.W[i]); p.b[i] = rflp(p.b[i]); p.dW[i] = rflp(p.dW[i]); p.db[i] = rflp(p.db[i]); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { p.h[i] = rflp(p.h[i]); p.dz[i] = rflp(p.dz[i]); }
+    p.y = rflp(p.y); p.c = rflp(p.c); p.out = rflp(p.out); p.dout = rflp(p.dout); p.dy = rflp(p.dy); p.dc = rflp(p.dc); p.ws = rflp(p.ws);
+    return p;
+}
+
 template <int NL>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
     extern __shared__ float lds[];
-    const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;             // batched launch: one network per blockIdx.z
+    const PfMlpTrain p = mlp_desc(p0, descs);
+    const MlpG G = mlp_glob(p);
     const int ntiles = (p.rows + 15) / 16;
     const MlpShape sh = mlp_shape(p);
     float* Wl[NL];
@@ -92,7 +143,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p0, const PfMlp
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int i = i0 + 256 * k, c = i >> sft, u = i & (sh.wi16[l] - 1);
-                v[k] = (i < sh.wo16[l] * sh.wi16[l] && c < sh.wo[l] && u < sh.wi[l]) ? p.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
+                v[k] = (i < sh.wo16[l] * sh.wi16[l] && c < sh.wo[l] && u < sh.wi[l]) ? G.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -100,11 +151,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p0, const PfMlp
                 if (i < sh.wo16[l] * sh.wi16[l]) Wl[l][c * ld + u] = v[k];
             }
         }
-        for (int i = threadIdx.x; i < sh.wo16[l]; i += 256) bl[l][i] = (p.b[l] && i < sh.wo[l]) ? p.b[l][i] : 0.f;
+        for (int i = threadIdx.x; i < sh.wo16[l]; i += 256) bl[l][i] = (G.b[l] && i < sh.wo[l]) ? G.b[l][i] : 0.f;
     }
     for (int i = threadIdx.x; i < sh.wo16[0] * 4; i += 256) {
         const int c = i >> 2, j = i & 3;
-        Wx[i] = (c < sh.wo[0] && j < p.td) ? p.W[0][(size_t)c * sh.in[0] + j] : 0.f;
+        Wx[i] = (c < sh.wo[0] && j < p.td) ? G.W[0][(size_t)c * sh.in[0] + j] : 0.f;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
@@ -113,16 +164,16 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p0, const PfMlp
         const bool valid = p0 < p.rows;
         const int pr = valid ? p0 : p.rows - 1;
         f4 act[8];
-        const float* crow = p.c + (size_t)(pr / p.cdiv) * p.cc;
+        gcp crow = G.c + (size_t)(pr / p.cdiv) * p.cc;
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) {
             act[cb] = pf_splat(0.f);
-            if (cb * 16 < sh.wi16[0]) act[cb] = *reinterpret_cast<const f4*>(crow + cb * 16 + 4 * q);
+            if (cb * 16 < sh.wi16[0]) act[cb] = *(gc4p)(crow + cb * 16 + 4 * q);
         }
         float xv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            if (j < p.td) xv[j] = p.y[(size_t)pr * p.ldy + j];
+            if (j < p.td) xv[j] = G.y[(size_t)pr * p.ldy + j];
         pf_static_for<0, NL>([&](auto lc) {
             constexpr int l = decltype(lc)::value;
             const int ld = sh.wi16[l] + 4;
@@ -146,15 +197,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p0, const PfMlp
                     if (l < NL - 1) {
                         constexpr int lh = l < 2 ? l : 1;
                         acc = lrelu4(acc, p.slope[lh]);
-                        if (valid) *reinterpret_cast<f4*>(p.h[lh] + (size_t)p0 * sh.wo[l] + ob * 16 + 4 * q) = acc;
+                        if (valid) *(g4p)(G.h[lh] + (size_t)p0 * sh.wo[l] + ob * 16 + 4 * q) = acc;
                         nxt[ob] = acc;
                     } else if (valid) {
-                        if ((sh.wo[l] & 15) == 0) *reinterpret_cast<f4*>(p.out + (size_t)p0 * sh.wo[l] + ob * 16 + 4 * q) = acc;
+                        if ((sh.wo[l] & 15) == 0) *(g4p)(G.out + (size_t)p0 * sh.wo[l] + ob * 16 + 4 * q) = acc;
                         else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int ch = ob * 16 + 4 * q + r;
-                                if (ch < sh.wo[l]) p.out[(size_t)p0 * sh.wo[l] + ch] = acc[r];
+                                if (ch < sh.wo[l]) G.out[(size_t)p0 * sh.wo[l] + ch] = acc[r];
                             }
                         }
                     }
@@ -170,7 +221,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p0, const PfMlp
 template <int NL>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
     extern __shared__ float lds[];
-    const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;
+    const PfMlpTrain p = mlp_desc(p0, descs);
+    const MlpG G = mlp_glob(p);
     const int ntiles = (p.rows + 15) / 16;
     const MlpShape sh = mlp_shape(p);
     float* Wt[NL];                                       // Wt[l][u][c] = W[l][c][off + u]
@@ -187,7 +239,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p0, const PfMlp
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int i = i0 + 256 * k, c = i >> sft, u = i & (sh.wi16[l] - 1);
-                v[k] = (i < sh.wo16[l] * sh.wi16[l] && c < sh.wo[l] && u < sh.wi[l]) ? p.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
+                v[k] = (i < sh.wo16[l] * sh.wi16[l] && c < sh.wo[l] && u < sh.wi[l]) ? G.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -198,7 +250,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p0, const PfMlp
     }
     for (int i = threadIdx.x; i < sh.wo16[0] * 4; i += 256) {
         const int c = i >> 2, j = i & 3;
-        Wx[i] = (c < sh.wo[0] && j < p.td) ? p.W[0][(size_t)c * sh.in[0] + j] : 0.f;
+        Wx[i] = (c < sh.wo[0] && j < p.td) ? G.W[0][(size_t)c * sh.in[0] + j] : 0.f;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
@@ -215,11 +267,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p0, const PfMlp
                 if (cb * 16 < sh.wo16[NL - 1] && valid) {
                     const int ch = cb * 16 + 4 * q;
                     if ((w & 3) == 0) {
-                        if (ch < w) g[cb] = *reinterpret_cast<const f4*>(p.dout + (size_t)p0 * w + ch);
+                        if (ch < w) g[cb] = *(gc4p)(G.dout + (size_t)p0 * w + ch);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (ch + r < w) g[cb][r] = p.dout[(size_t)p0 * w + ch + r];
+                            if (ch + r < w) g[cb][r] = G.dout[(size_t)p0 * w + ch + r];
                     }
                 }
             }
@@ -240,9 +292,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p0, const PfMlp
                 s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
                 s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
                 s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-                if (q == 0 && valid && p.dy) {
+                if (q == 0 && valid && G.dy) {
                     const float sv[3] = {s0, s1, s2};
-                    for (int j = 0; j < p.ldy; ++j) p.dy[(size_t)p0 * p.ldy + j] = (j < p.td && j < 3) ? sv[j < 3 ? j : 0] : 0.f;
+                    for (int j = 0; j < p.ldy; ++j) G.dy[(size_t)p0 * p.ldy + j] = (j < p.td && j < 3) ? sv[j < 3 ? j : 0] : 0.f;
                 }
             }
             f4 nxt[8];
@@ -257,13 +309,13 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p0, const PfMlp
                             acc = mfma4(*reinterpret_cast<const f4*>(Wt[l] + (ub * 16 + col) * ld + cb * 16 + 4 * q), g[cb], acc);
                     if (l > 0) {
                         constexpr int lm = l > 0 ? l - 1 : 0;
-                        const f4 hv = *reinterpret_cast<const f4*>(p.h[lm] + (size_t)pr * sh.wi[l] + ub * 16 + 4 * q);
+                        const f4 hv = *(gc4p)(G.h[lm] + (size_t)pr * sh.wi[l] + ub * 16 + 4 * q);
                         const float sl = p.slope[lm];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[r] *= hv[r] > 0.f ? 1.f : sl;
-                        if (valid) *reinterpret_cast<f4*>(p.dz[lm] + (size_t)p0 * sh.wi[l] + ub * 16 + 4 * q) = acc;
+                        if (valid) *(g4p)(G.dz[lm] + (size_t)p0 * sh.wi[l] + ub * 16 + 4 * q) = acc;
                         nxt[ub] = acc;
-                    } else if (p.dc) {                    // sum over the cdiv replicas of a conditioning row: adjacent columns
+                    } else if (G.dc) {                    // sum over the cdiv replicas of a conditioning row: adjacent columns
 #pragma unroll
                         for (int m = 1; m < 16; m <<= 1)
                             if (m < p.cdiv) {
@@ -271,7 +323,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p0, const PfMlp
                                 for (int r = 0; r < 4; ++r) acc[r] += __shfl_xor(acc[r], m);
                             }
                         if (valid && (col % p.cdiv) == 0)
-                            *reinterpret_cast<f4*>(p.dc + (size_t)(p0 / p.cdiv) * p.cc + ub * 16 + 4 * q) = acc;
+                            *(g4p)(G.dc + (size_t)(p0 / p.cdiv) * p.cc + ub * 16 + 4 * q) = acc;
                     }
                 }
             }
@@ -302,111 +354,185 @@ __host__ __device__ inline MlpDwLayout mlp_dw_layout(const PfMlpTrain& p, const 
     return L;
 }
 
+// one staged 32-row block of the split-K weight-gradient product for the NP output tiles of a wave (tile s = row tile rts[s],
+// column tile cts[s]); SAME: all in row tile rts[0]
+template <int NP, bool SAME>
+__device__ __forceinline__ void dw_block(const float* ar0, const float* br0, const int (&rts)[MLP_SLOTS],
+                                         const int (&cts)[MLP_SLOTS], f4 (&acc)[MLP_SLOTS]) {
+#pragma unroll
+    for (int ks = 0; ks < MLP_EB / 4; ++ks) {
+        const float* ar = ar0 + 4 * ks * MLP_LD;
+        const float* br = br0 + 4 * ks * MLP_LD;
+        float a[NP], b[NP];
+        a[0] = ar[rts[0] * 16];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            b[s] = br[cts[s] * 16];
+            if (s > 0) a[s] = SAME ? a[0] : ar[rts[s] * 16];
+        }
+#pragma unroll
+        for (int s = 0; s < NP; ++s) acc[s] = pf_mfma(a[s], b[s], acc[s]);
+    }
+}
+
 // MLP_DW_WAVES waves share one staged block (as csrc/train_fused.hip ec_dw_kernel: more waves per SIMD keep the matrix pipe fed
 // while others sit in the load -> LDS -> barrier phase)
-__global__ __launch_bounds__(64 * MLP_DW_WAVES) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
+#ifndef PF_DW_OCC
+#define PF_DW_OCC 1
+#endif
+__global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpTrain* __restrict__ descs) {
     constexpr int NTH = 64 * MLP_DW_WAVES;
     extern __shared__ float lds[];
-    const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;
+    const PfMlpTrain p = mlp_desc(p0, descs);
+    const MlpG G = mlp_glob(p);
     const int chunk = mlp_chunk(p);
     if ((int)blockIdx.x * chunk >= p.rows || (int)blockIdx.y >= p.nl) return;
-    float* part = p.ws;
+    gp part = G.ws;
     const MlpShape sh = mlp_shape(p);
     const MlpDwLayout L = mlp_dw_layout(p, sh);
     const int l = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    // the wave index through readfirstlane: everything derived from it (a wave's tile list, the branch on its tile count) is then
+    // wave-uniform TO THE COMPILER - with `threadIdx.x >> 6` hipcc put every tile's read + MFMA under its own exec mask
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), row = lane & 15, q = lane >> 4;
     const int RA = sel3(sh.wo16, l), RB = sel3(L.wb16, l);
-    const int lda = RA + 16, ldb = RB + 16;
+    // row stride = 16 (mod 32) floats: the two k rows a 32-lane group of a ds_read_b32 touches sit 16 banks apart (a 144-wide
+    // block padded to 160 put them on the SAME banks: every B read of the widest layer was a 2-way conflict)
+    // (and a COMPILE-TIME stride: with run-time strides every (k step, tile) read kept its own address register - 150 VGPRs of
+    // addresses, 328 in all - and hipcc, scheduling for register pressure, issued read -> wait -> MFMA one at a time)
+    constexpr int lda = MLP_LD, ldb = MLP_LD;
     float* As = lds;
     float* Bs = lds + MLP_EB * lda;
-    const float* asrc = l == p.nl - 1 ? p.dout : sel2(p.dz, l);
-    const float* hsrc = l > 0 ? sel2(p.h, l - 1) : nullptr;
+    gcp asrc = l == p.nl - 1 ? G.dout : (gcp)sel2(G.dz, l);
+    gcp hsrc = l > 0 ? (gcp)sel2(G.h, l - 1) : (gcp)nullptr;
     const int wa = sel3(sh.wo, l), wil = sel3(sh.wi, l);
     const int offl = sel3(L.off, l), boffl = sel3(L.boff, l);
     const int NT = RB / 16, NRT = RA / 16;
+    // a wave's output tiles are CONSECUTIVE ids (row tile major): with 4 row tiles (64 output channels) and 4 waves they are one
+    // row tile's columns, so the A fragment of a k step is read once for all of them (round 4 dealt the tiles round-robin: two
+    // ds_read_b32 per MFMA, the LDS pipe next to saturated)
     int rts[MLP_SLOTS], cts[MLP_SLOTS];
     bool val[MLP_SLOTS];
+    const int nper = (NRT * NT + MLP_DW_WAVES - 1) / MLP_DW_WAVES;
 #pragma unroll
     for (int s = 0; s < MLP_SLOTS; ++s) {
-        const int id = wave + MLP_DW_WAVES * s;
-        val[s] = id < NRT * NT;
+        const int id = wave * nper + s;
+        val[s] = s < nper && id < NRT * NT;
         rts[s] = val[s] ? id / NT : 0; cts[s] = val[s] ? id % NT : 0;
     }
+    bool same = true;                                  // all of this wave's tiles in one row tile: one A read per k step
+#pragma unroll
+    for (int s = 1; s < MLP_SLOTS; ++s) same = same && (!val[s] || rts[s] == rts[0]);
+    const int nper_w = min(nper, max(0, NRT * NT - wave * nper));     // tiles this wave really owns (the last wave may own fewer)
     f4 acc[MLP_SLOTS];
 #pragma unroll
     for (int s = 0; s < MLP_SLOTS; ++s) acc[s] = pf_splat(0.f);
     const int r_lo = blockIdx.x * chunk, r_hi = min(p.rows, r_lo + chunk);
-    float bsum = 0.f;
-    // staging in float4 units, thread t owns units t, t + 256, ...: (row, column) of each unit fixed for the whole kernel.
-    // The next block's units are fetched into registers while the current block is multiplied (the products are short:
-    // without this every block paid a full memory latency between two barriers)
-    constexpr int UA = (MLP_EB * 32 + NTH - 1) / NTH, UB = (MLP_EB * 36 + NTH - 1) / NTH;     // float4 units of a 128- / 144-wide block per thread
-    const int ra4 = RA / 4, rb4 = RB / 4;
-    int elA[UA], cA[UA], elB[UB], cB[UB];
-#pragma unroll
-    for (int n = 0; n < UA; ++n) { const int k = threadIdx.x + NTH * n; elA[n] = k / ra4; cA[n] = (k - elA[n] * ra4) * 4; }
-#pragma unroll
-    for (int n = 0; n < UB; ++n) { const int k = threadIdx.x + NTH * n; elB[n] = k / rb4; cB[n] = (k - elB[n] * rb4) * 4; }
+    // staging in float4 units: a block's A image is 32 rows x RA columns, its B image 32 rows x bw columns (layer 0: the cc
+    // conditioning columns; the td <= 3 columns behind them come from y, one scalar per thread).  RA / 4 and bw / 4 divide the
+    // 256 threads, so unit n of a thread is ITS unit 0 moved down by n * (256 / units-per-row) rows: one pointer, one LDS
+    // address and uniform strides per operand (round 4 kept a pointer, a row, a column and an LDS address per unit - with the
+    // fully unrolled k loop that was 250+ VGPRs, two waves per SIMD).  Every load is issued UNCONDITIONALLY through an address
+    // that is valid even when the unit is not (its value is then replaced by zero): the per-unit `if (valid) load` became ~120
+    // exec-masked regions with their own waits.
+    constexpr int UN = (MLP_EB * 32 + NTH - 1) / NTH;                  // <= 4 units per thread and operand (128 columns)
+    const bool vecA = (wa & 3) == 0;                   // the last layer of a conditioner has 1 - 3 output columns: scalar loads
     const int dsh = 31 - __clz(p.cdiv);                 // cdiv is a power of two
-    f4 ra[UA], rbv[UB];
+    const int ra4 = RA / 4;
+    const int bw = l > 0 ? wil : p.cc, bw4 = bw / 4;    // both are multiples of 16
+    gcp bsrc = l > 0 ? hsrc : G.c;
+    const int elA0 = threadIdx.x / ra4, cA = (threadIdx.x - elA0 * ra4) * 4, dEA = NTH / ra4;
+    const int elB0 = threadIdx.x / bw4, cB = (threadIdx.x - elB0 * bw4) * 4, dEB = NTH / bw4;
+    const bool colA = cA < wa;
+    gcp pA = asrc + (size_t)(r_lo + min(elA0, MLP_EB - 1)) * wa + (colA ? cA : 0);
+    const int bsh = l > 0 ? 0 : dsh;                    // layer 0 reads the conditioning row of point (row >> dsh)
+    int rowB = r_lo + elB0;
+    const long long offA = (long long)dEA * wa;        // unit n + 1 from unit n
+    const long long stepA = (long long)MLP_EB * wa;
+    float* const ldsA = As + elA0 * lda + cA;
+    float* const ldsB = Bs + elB0 * ldb + cB;
+    // layer 0: the td <= 3 columns behind the conditioning part come from y (row stride ldy): one scalar per thread and block
+    const bool ycol = l == 0 && p.td > 0 && (int)threadIdx.x < MLP_EB * p.td;
+    const int yel = ycol ? threadIdx.x / p.td : 0, yw = ycol ? threadIdx.x - yel * p.td : 0;
+    gcp pY = ycol ? G.y + (size_t)(r_lo + yel) * p.ldy + yw : bsrc;
+    const long long stepY = ycol ? (long long)MLP_EB * p.ldy : 0;
+    // bias gradients = column sums of A: thread (column, row group) sums its rows of every block from LDS
+    const int bcol = threadIdx.x & (RA - 1), bgrp = threadIdx.x / RA, brows = MLP_EB / (NTH / RA);
+    float bsum = 0.f;
+    // zero once what no block store writes: the padding columns read by the 16-wide column tiles
+    for (int i = threadIdx.x; i < MLP_EB * (lda + ldb); i += NTH) As[i] = 0.f;
+    f4 ra[UN], rbv[UN];
+    float yv = 0.f;
     auto fetch = [&](int rb) {
 #pragma unroll
-        for (int n = 0; n < UA; ++n) {
-            f4 v = pf_splat(0.f);
-            const int r = rb + elA[n], c = cA[n];
-            if (elA[n] < MLP_EB && r < r_hi && c < wa) {
-                if ((wa & 3) == 0) v = *reinterpret_cast<const f4*>(asrc + (size_t)r * wa + c);
-                else {
+        for (int n = 0; n < UN; ++n) {
+            const bool ok = colA && elA0 + n * dEA < MLP_EB && rb + elA0 + n * dEA < r_hi;
+            gcp ptr = ok ? pA + n * offA : asrc;
+            f4 v;
+            if (vecA) v = *(gc4p)ptr;
+            else {
+                v = pf_splat(0.f);
 #pragma unroll
-                    for (int w = 0; w < 4; ++w)
-                        if (c + w < wa) v[w] = asrc[(size_t)r * wa + c + w];
+                for (int w = 0; w < 3; ++w) {
+                    const float x = ptr[w < wa ? w : 0];
+                    v[w] = w < wa ? x : 0.f;
                 }
             }
-            ra[n] = v;
+            ra[n] = ok ? v : pf_splat(0.f);
         }
+        pA += stepA;
 #pragma unroll
-        for (int n = 0; n < UB; ++n) {
-            f4 v = pf_splat(0.f);
-            const int r = rb + elB[n], u = cB[n];
-            if (elB[n] < MLP_EB && r < r_hi) {
-                if (l > 0) { if (u < wil) v = *reinterpret_cast<const f4*>(hsrc + (size_t)r * wil + u); }
-                else if (u + 3 < p.cc) v = *reinterpret_cast<const f4*>(p.c + (size_t)(r >> dsh) * p.cc + u);
-                else {
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const int uu = u + w;
-                        if (uu < p.cc) v[w] = p.c[(size_t)(r >> dsh) * p.cc + uu];
-                        else if (uu < p.cc + p.td) v[w] = p.y[(size_t)r * p.ldy + uu - p.cc];
-                    }
-                }
-            }
-            rbv[n] = v;
+        for (int n = 0; n < UN; ++n) {
+            const bool ok = elB0 + n * dEB < MLP_EB && rb + elB0 + n * dEB < r_hi;
+            const f4 v = *(gc4p)(ok ? bsrc + (size_t)((rowB + n * dEB) >> bsh) * bw + cB : bsrc);
+            rbv[n] = ok ? v : pf_splat(0.f);
+        }
+        rowB += MLP_EB;
+        {
+            const float x = *pY;
+            yv = (ycol && rb + yel < r_hi) ? x : 0.f;
+            pY += stepY;
         }
     };
     fetch(r_lo);
     for (int rb = r_lo; rb < r_hi; rb += MLP_EB) {
         __syncthreads();
+#if !(PF_DW_ABL & 4)
 #pragma unroll
-        for (int n = 0; n < UA; ++n)
-            if (elA[n] < MLP_EB) *reinterpret_cast<f4*>(As + elA[n] * lda + cA[n]) = ra[n];
+        for (int n = 0; n < UN; ++n)
+            if (colA && elA0 + n * dEA < MLP_EB) *reinterpret_cast<f4*>(ldsA + n * dEA * lda) = ra[n];
 #pragma unroll
-        for (int n = 0; n < UB; ++n)
-            if (elB[n] < MLP_EB) *reinterpret_cast<f4*>(Bs + elB[n] * ldb + cB[n]) = rbv[n];
+        for (int n = 0; n < UN; ++n)
+            if (elB0 + n * dEB < MLP_EB) *reinterpret_cast<f4*>(ldsB + n * dEB * ldb) = rbv[n];
+        if (ycol) Bs[yel * ldb + p.cc + yw] = yv;
+#endif
         __syncthreads();
+#if !(PF_DW_ABL & 2)
         if (rb + MLP_EB < r_hi) fetch(rb + MLP_EB);
-        if (threadIdx.x < RA)
-#pragma unroll 8
-            for (int el = 0; el < MLP_EB; ++el) bsum += As[el * lda + threadIdx.x];
-#pragma unroll
-        for (int ks = 0; ks < MLP_EB / 4; ++ks) {
-            const float* ar = As + (4 * ks + q) * lda + row;
-            const float* br = Bs + (4 * ks + q) * ldb + row;
-#pragma unroll
-            for (int s = 0; s < MLP_SLOTS; ++s)
-                if (val[s]) acc[s] = pf_mfma(ar[rts[s] * 16], br[cts[s] * 16], acc[s]);
+#endif
+        for (int e = 0; e < brows; ++e) bsum += As[(bgrp * brows + e) * lda + bcol];
+        // branch-free per tile count: every operand read of a k step is issued before its MFMAs (with a uniform `if (val[s])`
+        // around each read + MFMA pair hipcc waited for every LDS read in front of its MFMA: ~200 cycles per MFMA)
+        const float* ar0 = As + q * lda + row;
+        const float* br0 = Bs + q * ldb + row;
+#if !(PF_DW_ABL & 1)
+        switch (same ? nper_w : -nper_w) {
+#define PF_DWB(NP)                                                                                     \
+            case NP: dw_block<NP, true>(ar0, br0, rts, cts, acc); break;                     \
+            case -NP: dw_block<NP, false>(ar0, br0, rts, cts, acc); break;
+            PF_DWB(1) PF_DWB(2) PF_DWB(3) PF_DWB(4) PF_DWB(5) PF_DWB(6) PF_DWB(7) PF_DWB(8) PF_DWB(9)
+#undef PF_DWB
+            default: break;
         }
+#endif
     }
-    float* out = part + (size_t)blockIdx.x * L.total;
+    // the row groups' bias sums through LDS, added in group order (the same for every chunk: deterministic)
+    __syncthreads();
+    As[bgrp * lda + bcol] = bsum;
+    __syncthreads();
+    bsum = 0.f;
+    if ((int)threadIdx.x < RA)
+        for (int gI = 0; gI < NTH / RA; ++gI) bsum += As[gI * lda + threadIdx.x];
+    gp out = part + (size_t)blockIdx.x * L.total;
     if (threadIdx.x < RA) out[boffl + threadIdx.x] = bsum;
 #pragma unroll
     for (int s = 0; s < MLP_SLOTS; ++s)
@@ -418,8 +544,9 @@ __global__ __launch_bounds__(64 * MLP_DW_WAVES) void mlp_dw_kernel(PfMlpTrain p0
 // partial sums -> dW[l] [wo, in_l] (column j < td of layer 0 sits behind the cc conditioning columns in the partials), db[l]
 constexpr int MLP_RG = PF_MLP_RG;           // groups of 64 threads that share the chunk range of an output element
 __global__ __launch_bounds__(64 * MLP_RG) void mlp_dw_reduce_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
-    const PfMlpTrain p = descs ? descs[blockIdx.z] : p0;
-    const float* part = p.ws;
+    const PfMlpTrain p = mlp_desc(p0, descs);
+    const MlpG G = mlp_glob(p);
+    gcp part = G.ws;
     const int nchunk = (p.rows + mlp_chunk(p) - 1) / mlp_chunk(p);
     const MlpShape sh = mlp_shape(p);
     const MlpDwLayout L = mlp_dw_layout(p, sh);
@@ -461,9 +588,9 @@ __global__ __launch_bounds__(64 * MLP_RG) void mlp_dw_reduce_kernel(PfMlpTrain p
     s = 0.0;
 #pragma unroll
     for (int k = 0; k < MLP_RG; ++k) s += shr[k][tx];
-    float* db = sel3(p.db, l);
+    gp db = sel3(G.db, l);
     if (j == inl) { if (db) db[c] = (float)s; }
-    else sel3(p.dW, l)[(size_t)c * inl + j] = (float)s;
+    else sel3(G.dW, l)[(size_t)c * inl + j] = (float)s;
 }
 
 // descriptors of a batched launch travel as kernel arguments of this copy kernel (capturable in a hipGraph, no host copy)
@@ -552,7 +679,7 @@ extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
     {
         int ramax = 0, rbmax = 0;
         for (int l = 0; l < p->nl; ++l) { ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l]; }
-        const size_t lds = sizeof(float) * (size_t)MLP_EB * ((ramax + 16) + (rbmax + 16));
+        const size_t lds = sizeof(float) * (size_t)MLP_EB * 2 * MLP_LD;
         hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(64 * MLP_DW_WAVES), lds, s, *p, (const PfMlpTrain*)nullptr);
     }
     int total = 0;
@@ -622,7 +749,7 @@ extern "C" int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_
             ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l];
             total += sh.wo[l] * (sh.in[l] + 1);
         }
-        const size_t w2 = sizeof(float) * (size_t)MLP_EB * ((ramax + 16) + (rbmax + 16));
+        const size_t w2 = sizeof(float) * (size_t)MLP_EB * 2 * MLP_LD;
         lds_w = w2 > lds_w ? w2 : lds_w;
         const int ntiles = (p->rows + 15) / 16;
         const int g = (ntiles + 3) / 4 < MLP_GRID ? (ntiles + 3) / 4 : MLP_GRID;
@@ -667,7 +794,7 @@ extern "C" int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_d
             ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l];
             total += sh.wo[l] * (sh.in[l] + 1);
         }
-        const size_t w2 = sizeof(float) * (size_t)MLP_EB * ((ramax + 16) + (rbmax + 16));
+        const size_t w2 = sizeof(float) * (size_t)MLP_EB * 2 * MLP_LD;
         lds_w = w2 > lds_w ? w2 : lds_w;
         const int nchunk = (p->rows + mlp_chunk(*p) - 1) / mlp_chunk(*p);
         cmax = nchunk > cmax ? nchunk : cmax;

@@ -169,6 +169,189 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
 }
 
+// ---- round 5: the same GEMM (same MFMA chain per output element, bit-identical results) with conflict-free LDS images ----
+// gemm_kernel above stages through As[BM][20] / Bs[16][BN + 4]: an operand whose contiguous dimension is NOT k is transposed
+// with scalar ds_write_b32 at a 20-float stride (8-way bank conflicts), the b32 fragment reads are 2-way (PMC: 54 - 86 % of
+// the LDS cycles were conflict cycles), every 16-deep step pays two barriers and the epilogue stores 64-byte pieces.  Here:
+//   * an operand that is contiguous along k goes to LDS in FRAGMENT order [16-k group][tile][lane = q 16 + row][j]
+//     (element j of lane (row, q) is k = 4 j + q: what MFMA step j of the group reads), written by four ds_write_b32 whose
+//     32-lane groups cover 32 banks, read back as ONE ds_read_b128 per tile and group;
+//   * an operand that is contiguous along its row index (m / n) keeps its memory order [k][rows + 16]: ds_write_b128 rows,
+//     ds_read_b32 fragments whose two k rows of a 32-lane group sit 16 banks apart;
+//   * 32-deep steps, two LDS buffers, ONE barrier per step, the next step's operands in registers during the MFMAs;
+//   * the output tile leaves through LDS as whole rows (float4 per lane).
+// The products and their order are those of gemm_kernel (k ascending through v_mfma_f32_16x16x4_f32, the same split-K chunks).
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm2_kernel(GemmArgs g, int cvec) {
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16, BK = 32;
+    constexpr int LDA = BM % 32 == 0 ? BM + 16 : BM + 32, LDB = BN % 32 == 0 ? BN + 16 : BN + 32;   // row stride = 16 mod 32 floats
+    constexpr int ASZ = BK * LDA, BSZ = BK * LDB, LDC = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) float g2lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ml = lane & 15, q = lane >> 4;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_lo = blockIdx.z * g.kchunk;
+    const int k_hi = min(g.K, k_lo + g.kchunk);
+    const bool a_kfast = g.sak == 1, b_kfast = g.sbk == 1 && g.sbn != 1;
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = pf_splat(0.f);
+    constexpr int NA = (BM * 8 + 255) / 256, NB = (BN * 8 + 255) / 256;
+    f4 ra[NA], rb[NB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * 256;
+            f4 x = pf_splat(0.f);
+            if (v < BM * 8) {
+                if (a_kfast) {
+                    const int gm = m0 + (v >> 3), gk = k0 + (v & 7) * 4;
+                    if (gm < g.M && gk < k_hi) x = *reinterpret_cast<const f4*>(g.A + gm * g.sam + gk);
+                } else {
+                    const int gk = k0 + v / (BM / 4), gm = m0 + (v % (BM / 4)) * 4;
+                    if (gm < g.M && gk < k_hi) x = *reinterpret_cast<const f4*>(g.A + gk * g.sak + gm);
+                }
+            }
+            ra[i] = x;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int v = tid + i * 256;
+            f4 x = pf_splat(0.f);
+            if (v < BN * 8) {
+                if (b_kfast) {
+                    const int gn = n0 + (v >> 3), gk = k0 + (v & 7) * 4;
+                    if (gn < g.N && gk < k_hi) x = *reinterpret_cast<const f4*>(g.B + gn * g.sbn + gk);
+                } else {
+                    const int gk = k0 + v / (BN / 4), gn = n0 + (v % (BN / 4)) * 4;
+                    if (gn < g.N && gk < k_hi) x = *reinterpret_cast<const f4*>(g.B + gk * g.sbk + gn);
+                }
+            }
+            rb[i] = x;
+        }
+    };
+    auto stash = [&](float* As, float* Bs) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * 256;
+            if (v < BM * 8) {
+                const f4 x = ra[i];
+                if (a_kfast) {
+                    const int r = v >> 3, c = v & 7;
+                    float* p = As + (c >> 2) * (BM * 16) + ((r >> 4) * 64 + (r & 15)) * 4 + (c & 3);
+                    p[0] = x.x; p[64] = x.y; p[128] = x.z; p[192] = x.w;
+                } else {
+                    *reinterpret_cast<f4*>(As + (v / (BM / 4)) * LDA + (v % (BM / 4)) * 4) = x;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int v = tid + i * 256;
+            if (v < BN * 8) {
+                const f4 x = rb[i];
+                if (b_kfast) {
+                    const int r = v >> 3, c = v & 7;
+                    float* p = Bs + (c >> 2) * (BN * 16) + ((r >> 4) * 64 + (r & 15)) * 4 + (c & 3);
+                    p[0] = x.x; p[64] = x.y; p[128] = x.z; p[192] = x.w;
+                } else {
+                    *reinterpret_cast<f4*>(Bs + (v / (BN / 4)) * LDB + (v % (BN / 4)) * 4) = x;
+                }
+            }
+        }
+    };
+    fetch(k_lo);
+    stash(g2lds, g2lds + ASZ);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
+        const float* As = g2lds + cur * (ASZ + BSZ);
+        const float* Bs = As + ASZ;
+        const bool more = k0 + BK < k_hi;
+        if (more) fetch(k0 + BK);
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+            f4 a[TM], b[TN];
+            if (a_kfast) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f4*>(As + gq * (BM * 16) + ((wm * TM + i) * 64 + lane) * 4);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) a[i][kk] = As[(gq * 16 + kk * 4 + q) * LDA + (wm * TM + i) * 16 + ml];
+            }
+            if (b_kfast) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f4*>(Bs + gq * (BN * 16) + ((wn * TN + j) * 64 + lane) * 4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) b[j][kk] = Bs[(gq * 16 + kk * 4 + q) * LDB + (wn * TN + j) * 16 + ml];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = pf_mfma(a[i][kk], b[j][kk], acc[i][j]);
+        }
+        if (more) {
+            float* An = g2lds + (cur ^ 1) * (ASZ + BSZ);
+            stash(An, An + ASZ);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- the tile through LDS: [BM][BN + 4] (a lane group's two 4-row blocks sit 16 banks apart), then whole rows out
+    float* Cs = g2lds;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[((wm * TM + i) * 16 + 4 * q + r) * LDC + (wn * TN + j) * 16 + ml] = acc[i][j][r];
+    __syncthreads();
+    float* C = g.C + (long long)blockIdx.z * g.M * g.ldc;
+    for (int v = tid; v < BM * (BN / 4); v += 256) {
+        const int row = v / (BN / 4), c4 = (v % (BN / 4)) * 4;
+        const int m = m0 + row, n = n0 + c4;
+        if (m >= g.M || n >= g.N) continue;
+        f4 x = *reinterpret_cast<const f4*>(Cs + row * LDC + c4);
+        if (cvec && n + 3 < g.N) {
+            if (g.bias) { const f4 bb = *reinterpret_cast<const f4*>(g.bias + n); x += bb; }
+            *reinterpret_cast<f4*>(C + m * g.ldc + n) = x;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < g.N) C[m * g.ldc + n + e] = x[e] + (g.bias ? g.bias[n + e] : 0.f);
+        }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+void gemm2_launch(const GemmArgs& g, int split, hipStream_t s) {
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+    constexpr int LDA = BM % 32 == 0 ? BM + 16 : BM + 32, LDB = BN % 32 == 0 ? BN + 16 : BN + 32;
+    constexpr int loop_floats = 2 * 32 * (LDA + LDB), out_floats = BM * (BN + 4);
+    constexpr size_t lds = sizeof(float) * (size_t)(loop_floats > out_floats ? loop_floats : out_floats);
+    static const bool once = [] {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<WAVES_M, WAVES_N, TM, TN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return true;
+    }();
+    (void)once;
+    auto al16 = [](const void* p) { return (reinterpret_cast<unsigned long long>(p) & 15ull) == 0; };
+    const long long ldc = g.ldc;
+    const int cvec = (ldc % 4 == 0) && al16(g.C) && (!g.bias || al16(g.bias)) && (((long long)g.M * ldc) % 4 == 0);
+    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, split);
+    hipLaunchKernelGGL((gemm2_kernel<WAVES_M, WAVES_N, TM, TN>), grid, dim3(256), lds, s, g, cvec);
+}
+
 // ---- split-precision GEMM: the same tiles on the fp16 / bf16 matrix pipe ------------------------------------------
 // The f32 MFMA runs at 1/16 of the 16-bit rate; the big layer GEMMs above already sit near ITS roofline.  Here both
 // operands are split while they are staged into LDS ([row][k] images, k contiguous: one 16-B read per MFMA operand):
@@ -725,11 +908,12 @@ extern "C" long long pf_gemm_ws_floats(int M, int N, int K) {
     return split > 1 ? (long long)split * M * N : 0;
 }
 
-// arith: 0 = f32 MFMA (bit-exact fp32 fma chain), 2 = split-fp16 (forward GEMMs), 3 = split-bf16 (gradient operands)
+// arith: 0 = f32 MFMA (bit-exact fp32 fma chain; gemm2_kernel when both operands take float4 loads), 1 = the same on the round-1
+// kernel (gemm_kernel: the A/B reference of tests/test_gpu_train_fused.py, bit-identical results), 2 = split-fp16 (forward GEMMs), 3 = split-bf16 (gradient operands)
 extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
                           float* C, long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats,
                           void* stream) {
-    if (arith != 0 && arith != 2 && arith != 3) return PF_ERR_UNSUPPORTED;
+    if (arith != 0 && arith != 1 && arith != 2 && arith != 3) return PF_ERR_UNSUPPORTED;
     if (!A || !B || !C) return PF_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return PF_ERR_SHAPE;
     const long long need = pf_gemm_ws_floats(M, N, K);
@@ -745,7 +929,7 @@ extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sa
     const bool va = (sak == 1) ? (K % 4 == 0 && sam % 4 == 0 && g.kchunk % 4 == 0) : (sam == 1 && M % 4 == 0 && sak % 4 == 0);
     const bool vb = (sbn == 1) ? (N % 4 == 0 && sbk % 4 == 0) : (sbk == 1 && K % 4 == 0 && sbn % 4 == 0);
     const bool vec = va && vb && al16(A) && al16(B);
-    if (arith != 0) {
+    if (arith >= 2) {
         // float4 staging of the split kernel: 4 consecutive elements along each operand's contiguous dimension
         const bool va2 = (sak == 1) ? (sam % 4 == 0) : (sam == 1 && sak % 4 == 0);
         const bool vb2 = (sbk == 1) ? (sbn % 4 == 0) : (sbn == 1 && sbk % 4 == 0);
@@ -759,6 +943,17 @@ extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sa
             case 5: gemm_split_launch<1, 4, 2, 4>(arith, g, split, vec2, s); break;
             case 7: gemm_split_launch<2, 2, 2, 2>(arith, g, split, vec2, s); break;
             default: gemm_split_launch<1, 4, 4, 4>(arith, g, split, vec2, s); break;
+        }
+    } else if (arith == 0 && vec) {
+        switch (gemm_shape(M, N)) {
+            case 0: gemm2_launch<2, 2, 4, 4>(g, split, s); break;
+            case 1: gemm2_launch<4, 1, 4, 1>(g, split, s); break;
+            case 2: gemm2_launch<4, 1, 4, 2>(g, split, s); break;
+            case 3: gemm2_launch<4, 1, 4, 4>(g, split, s); break;
+            case 4: gemm2_launch<1, 4, 1, 4>(g, split, s); break;
+            case 5: gemm2_launch<1, 4, 2, 4>(g, split, s); break;
+            case 7: gemm2_launch<2, 2, 2, 2>(g, split, s); break;
+            default: gemm2_launch<1, 4, 4, 4>(g, split, s); break;
         }
     } else
     switch (gemm_shape(M, N)) {

@@ -76,7 +76,10 @@ class GraphedTrainStep:
             module._nan_subs = torch.zeros((), dtype=torch.int64, device=dev)     # NaN losses replaced inside the capture
         self.calls = 0
         self.bucket = FlatGradBucket(module.parameters())
-        side = torch.cuda.Stream(device=dev)
+        # warm-up AND capture run on this one stream: the fused kernels' zero-initialised scratch words (barrier words, the sticky
+        # time-out word, statistics accumulators: train_ops._zeros_kept) are cached per (device, stream) and must be allocated
+        # OUTSIDE the capture - inside it their torch.zeros would be a memset node that clears the sticky word on every replay
+        side = self.capture_stream = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(max(warmup, 1)):               # ActNorm init, library loads, workspaces, Adam state
@@ -89,14 +92,14 @@ class GraphedTrainStep:
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
         if not self.multi:
-            with torch.cuda.graph(self.graph_a, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(self.graph_a, stream=side, capture_error_mode=_CAPTURE_MODE):
                 self.loss = self._fwd_bwd()
                 self._update()
         else:
-            with torch.cuda.graph(self.graph_a, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(self.graph_a, stream=side, capture_error_mode=_CAPTURE_MODE):
                 self.loss = self._fwd_bwd()
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=side, capture_error_mode=_CAPTURE_MODE):
                 self._update()
 
     # ---- pieces (the same calls in warm-up, capture and - implicitly - replay)

@@ -57,12 +57,25 @@ ARITH_FWD, ARITH_BWD = (2, 3) if _GEMM_MODE == "split" else (0, 0)
 _STAT = {}
 
 
+def _zeros_kept(n: int, dtype, dev) -> Tensor:
+    """Zero-initialised device words that the kernels keep zero themselves (barrier words, statistics accumulators) or that are
+    STICKY across launches (the time-out word).  They must exist before a hipGraph capture starts: a `torch.zeros` inside a
+    capture becomes a memset node that clears them on every replay - a time-out recorded by replay i would be erased by replay
+    i + 1 before the host ever looked.  GraphedTrainStep warms up on its capture stream, so the (device, stream) entries are
+    there; anything else that captures these kernels must run them once eagerly on the capture stream first."""
+    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("puflow_amd.train_ops: the zero-initialised scratch words of the fused training kernels would be allocated "
+                           "inside a hipGraph capture (a memset node would clear the sticky status word on every replay): run the "
+                           "step once eagerly on the capture stream before capturing it (train_graph.GraphedTrainStep does)")
+    return torch.zeros(n, dtype=dtype, device=dev)
+
+
 def _stat(dev) -> Tensor:
     """4097 doubles (PF_TRAIN_STAT_DOUBLES) per (device, stream): the column-statistics accumulators of the fused training kernels."""
     key = (dev, _stream())
     t = _STAT.get(key)
     if t is None:
-        t = torch.zeros(4097, dtype=torch.float64, device=dev)
+        t = _zeros_kept(4097, torch.float64, dev)
         _STAT[key] = t
     return t
 
@@ -80,7 +93,7 @@ def _sync_words(dev) -> Tensor:
     key = (dev, _stream())
     t = _SYNCW.get(key)
     if t is None:
-        t = torch.zeros(4, dtype=torch.int32, device=dev)
+        t = _zeros_kept(4, torch.int32, dev)
         _SYNCW[key] = t
     return t
 
@@ -113,7 +126,7 @@ def _sync_sums(dev) -> Tensor:
     key = (dev, _stream())
     t = _SYNC_SUMS.get(key)
     if t is None:
-        t = _SYNC_SUMS[key] = torch.zeros(2 * 128 + 1, dtype=torch.float64, device=dev)
+        t = _SYNC_SUMS[key] = _zeros_kept(2 * 128 + 1, torch.float64, dev)
     return t
 
 

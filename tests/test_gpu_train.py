@@ -331,6 +331,42 @@ def test_graphed_train_step_follows_the_eager_trajectory():
     assert float(optg.param_groups[0]["lr"]) == pytest.approx(5e-4)
 
 
+def test_sticky_timeout_word_survives_graph_replays():
+    """the persistent kernels' barrier / status words are cached per (device, stream) and zero-initialised; allocated
+    INSIDE the capture their torch.zeros would be a memset node that clears the sticky time-out word sync[3] on every replay,
+    so a time-out of replay i would be gone after replay i + 1.  GraphedTrainStep warms up on its capture stream (the words
+    exist before capture_begin); train_ops refuses to allocate them while capturing.  Here: a set word survives two replays and
+    check_persist_status raises."""
+    from puflow_amd import _lib, train_ops
+    from puflow_amd.trainer import TrainerModule, default_cfg
+    dense = ((synth_patches(4, 1024, seed=5) + 1) / 2).to(DEV)
+    batch = (dense[:, ::4].contiguous(), dense, torch.ones(4, device=DEV))
+    torch.manual_seed(0)
+    tm = TrainerModule(default_cfg(learning_rate=1e-3), loss_mix="pugan")
+    tm.network.load_state_dict(synth_state_dict(21))
+    tm = tm.to(DEV)
+    opt = tm.configure_optimizers()["optimizer"]
+    step = tm.graphed_train_step(batch, opt, warmup=1)
+    key = (torch.device(DEV), step.capture_stream.cuda_stream)
+    assert key in train_ops._SYNCW, "the capture stream's barrier words must exist before the capture (allocated by the warm-up)"
+    words = train_ops._SYNCW[key]
+    float(step(batch))
+    assert words.tolist() == [0, 0, 0, 0]
+    words[3] = 1                                   # what a timed-out grid barrier leaves
+    float(step(batch)); float(step(batch))
+    assert int(words[3]) == 1, "a replay cleared the sticky status word"
+    with pytest.raises(_lib.PuflowHipError):
+        train_ops.check_persist_status(DEV)
+    assert words.tolist() == [0, 0, 0, 0]
+    # and the guard: no zero-initialised scratch may be born inside a capture
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with pytest.raises(RuntimeError, match="inside a hipGraph capture"):
+        with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+            train_ops._sync_words(torch.device(DEV))
+    train_ops._SYNCW.pop((torch.device(DEV), s.cuda_stream), None)
+
+
 def test_side_stream_branch_of_the_training_forward_changes_nothing():
     """The interpolation weights of the train-mode forward run on a side stream beside the feature extractor / flow f chain
     (a parallel branch of a captured step).  Same loss, same outputs, same gradients as the one-stream order (float atomics of

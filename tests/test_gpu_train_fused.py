@@ -447,3 +447,41 @@ def test_edgeconv_unit_persistent_forward_matches_the_per_layer_kernels(cin, odi
         _close(m_p, m_l, "running_mean", 1e-5)
         _close(v_p, v_l, "running_var", 1e-5)
     train_ops.check_persist_status()
+
+
+# ---- round 5: pf_gemm on conflict-free LDS images (gemm2_kernel) = the round-1 kernel bit for bit ---------------------------
+# operand orientations of the three point GEMMs of an EdgeConv unit (train_fused.hip: PQ = x Wpq^T + b, dx = dPQ Wpq,
+# dWpq = dPQ^T x with split-K) plus ragged shapes, every tile shape of gemm_shape()
+@pytest.mark.parametrize("M,N,K,a_kfast,b_nfast,bias", [
+    (8192, 512, 128, True, False, True),        # PQ forward, 128-channel unit
+    (8192, 128, 512, True, True, False),        # dx
+    (512, 128, 8192, False, True, False),       # dWpq (split-K slabs + reduce)
+    (8192, 128, 64, True, False, True),         # unit 1
+    (8192, 64, 32, True, True, False),
+    (8192, 16, 128, True, False, True),         # skinny N
+    (8192, 32, 64, True, True, False),
+    (16, 256, 8192, False, True, False),        # skinny M, split-K
+    (64, 128, 8192, False, False, False),
+    (1000, 72, 100, True, False, True),         # ragged rows / columns, K not a multiple of 32
+    (260, 260, 36, False, True, True),
+    (4096, 512, 512, True, False, False),       # 128 x 128 tiles
+])
+def test_gemm_conflict_free_kernel_is_bit_identical(M, N, K, a_kfast, b_nfast, bias):
+    from puflow_amd import train_ops as T
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn((M, K) if a_kfast else (K, M), generator=g).cuda()
+    Bm = torch.randn((K, N) if b_nfast else (N, K), generator=g).cuda()
+    b = torch.randn(N, generator=g).cuda() if bias else None
+    sam, sak = (K, 1) if a_kfast else (1, M)
+    sbk, sbn = (N, 1) if b_nfast else (1, K)
+    out = []
+    for arith in (0, 1):
+        C = torch.full((M, N), float("nan"), device="cuda")
+        T._gemm(A, sam, sak, Bm, sbk, sbn, C, N, b, M, N, K, arith)
+        out.append(C)
+    torch.cuda.synchronize()
+    ref = (A if a_kfast else A.t()).double() @ (Bm if b_nfast else Bm.t()).double()
+    if bias:
+        ref = ref + b.double()
+    assert torch.equal(out[0], out[1]), float((out[0] - out[1]).abs().max())
+    assert float((out[0].double() - ref).abs().max()) <= 2e-6 * K ** 0.5 * float(ref.abs().max() + 1)
