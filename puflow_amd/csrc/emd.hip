@@ -226,16 +226,84 @@ __device__ __forceinline__ T ald(const T* p) { return __hip_atomic_load(p, __ATO
 template <typename T>
 __device__ __forceinline__ void ast(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// ---- a wave's bid for one point with a cheap FILTER in front of the exact values (round 5) -----------------------------------
+// A bid needs the exact largest and second largest value over all n objects (and the smallest index holding the largest).  The
+// exact value costs ~30 instructions per object - unfused distance, a correctly rounded square root, the reference's double
+// subtraction - and the auction is bound by exactly that.  Pass 1 evaluates every object APPROXIMATELY
+// (fused distance, v_sqrt_f32, float subtraction: 12 instructions with the running top two) and keeps the 16 values of a lane in
+// registers; the wave's second largest approximate value minus twice the error bound is a threshold below which no object can be
+// among the exact top two; pass 2 evaluates exactly only the objects at or above it (typically 2 - 4 of 1024).  |approx - exact|:
+// three float operations on magnitudes <= 4 + |price| against one rounding of the double expression, plus 1 ulp of the square
+// root: < 2^-22 (4 + |v|); the bound used is 2^-20 (4 + |v|).  The result is bit for bit that of the plain scan (same values,
+// same strict-`>` order inside a lane, same wave merge); NaN / inf rows produce no candidate, as before.
+#ifndef PF_EMD_FILTER
+#define PF_EMD_FILTER 1
+#endif
+__device__ __forceinline__ void emd_bid_scan(const float4* y4, int n, float x1, float y1, float z1, int lane, float& tbest,
+                                             float& tbetter, int& tidx) {
+    tbest = -1e9f; tbetter = -1e9f; tidx = 0x7fffffff;
+#if PF_EMD_FILTER
+    for (int k0 = 0; k0 < n; k0 += 64 * 16) {
+        float va[16];
+        float m1 = -__builtin_inff(), m2 = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + j * 64 + lane;
+            float v = -__builtin_inff();
+            if (k < n) {
+                const float4 o = y4[k];
+                const float dx = o.x - x1, dy = o.y - y1, dz = o.z - z1;
+                v = (3.0f - __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)))) - o.w;
+            }
+            va[j] = v;
+            const float lo = fminf(m1, v);
+            m1 = fmaxf(m1, v);
+            m2 = fmaxf(m2, lo);
+        }
+        int li = lane;
+        tri_wave(m1, m2, li);                                       // m2: the second largest approximate value of the chunk
+        const float thr = m2 - 0x1p-19f * (4.f + fabsf(m2));        // 2 x the error bound
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + j * 64 + lane;
+            if (va[j] >= thr && k < n) {
+                const float4 o = y4[k];
+                const float dx = __fsub_rn(o.x, x1), dy = __fsub_rn(o.y, y1), dz = __fsub_rn(o.z, z1);
+                const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                const float v = (float)((3.0 - (double)sqrtf(d2)) - (double)o.w);
+                if (v > tbest) { tbetter = tbest; tbest = v; tidx = k; }
+                else if (v > tbetter) tbetter = v;
+            }
+        }
+    }
+#else
+    for (int k = lane; k < n; k += 64) {
+        const float4 o = y4[k];
+        const float dx = __fsub_rn(o.x, x1), dy = __fsub_rn(o.y, y1), dz = __fsub_rn(o.z, z1);
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        const float v = (float)((3.0 - (double)sqrtf(d2)) - (double)o.w);
+        if (v > tbest) { tbetter = tbest; tbest = v; tidx = k; }
+        else if (v > tbetter) tbetter = v;
+    }
+#endif
+    tri_wave(tbest, tbetter, tidx);
+}
+
+#ifndef PF_EMD_SOLO
+#define PF_EMD_SOLO 16         // a sample with at most this many unassigned points is finished by one of its workgroups alone (0: never)
+#endif
 #ifndef PF_EMD_XCD
 #define PF_EMD_XCD 1            // 0: the linear mapping (A/B: 860 -> 843, 871 -> 850 us on the far case, the near case unchanged)
 #endif
 template <bool KEY64>
 __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
-    __shared__ float sy[3 * EMDC_NMAX];
-    __shared__ float sprice[EMDC_NMAX];
+    __shared__ float4 sy4[EMDC_NMAX];                            // (y, price) of every object: one 16-byte LDS read per evaluation
     __shared__ int ulist[EMDC_NMAX], sbid[EMDC_NMAX], pbid[EMDC_NMAX];
     __shared__ float sinc[EMDC_NMAX];
     __shared__ int ucount, dead;
+    // the one-workgroup endgame (PF_EMD_SOLO, below): the sample's whole state in this workgroup's LDS
+    __shared__ int sassign[EMDC_NMAX], sainv[EMDC_NMAX];
+    __shared__ unsigned long long skey[EMDC_NMAX];
     // workgroup -> (sample, slice).  Consecutive workgroup ids go round-robin over the 8 XCDs, so the linear mapping spreads the
     // G workgroups of a sample over G different XCDs; with PF_EMD_XCD the G workgroups of a sample share an XCD (its L2) when
     // the batch divides by 8
@@ -282,13 +350,14 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
         }
         __syncthreads();
     };
-    for (int i = tid; i < 3 * n; i += EMD_THREADS) sy[i] = a.y[o0 * 3 + i];
+    for (int i = tid; i < n; i += EMD_THREADS)
+        sy4[i] = make_float4(a.y[(o0 + i) * 3 + 0], a.y[(o0 + i) * 3 + 1], a.y[(o0 + i) * 3 + 2], 0.f);
     for (int i = i0 + tid; i < i1; i += EMD_THREADS) {
         if (KEY64) { ast(a.k0 + o0 + i, 0ull); ast(a.k1 + o0 + i, 0ull); }
         else { ast(a.mb0 + o0 + i, 0u); ast(a.mb1 + o0 + i, 0u); ast(a.mi0 + o0 + i, -1); ast(a.mi1 + o0 + i, -1); }
     }
     barrier(0u);
-    int pU = 0;
+    int pU = 0, solo_from = -1;
     unsigned uprev = 0;
     for (int it = 0; it < a.iters && !dead; ++it) {
         const bool last = it == a.iters - 1;
@@ -301,7 +370,7 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
         unsigned long long* keyo = KEY64 ? (par ? a.k0 : a.k1) + o0 : nullptr;
         // the slice's assignments are fetched together with the prices (one memory round trip, not two)
         const int as0 = i0 + tid < i1 ? ald(assignment + i0 + tid) : 0;
-        for (int i = tid; i < n; i += EMD_THREADS) sprice[i] = ald(price + i);
+        for (int i = tid; i < n; i += EMD_THREADS) sy4[i].w = ald(price + i);
         if (tid == 0) ucount = 0;
         __syncthreads();
         if (i0 + tid < i1 && as0 == -1) ulist[atomicAdd(&ucount, 1)] = i0 + tid;
@@ -313,17 +382,9 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
         for (int u = wave; u < U; u += EMD_THREADS / 64) {
             const int i = ulist[u];
             const float x1 = x[i * 3 + 0], y1 = x[i * 3 + 1], z1 = x[i * 3 + 2];
-            float tbest = -1e9f, tbetter = -1e9f;
-            int tidx = 0x7fffffff;
-            for (int k = lane; k < n; k += 64) {
-                const float dx = __fsub_rn(sy[k * 3 + 0], x1), dy = __fsub_rn(sy[k * 3 + 1], y1),
-                            dz = __fsub_rn(sy[k * 3 + 2], z1);
-                const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                const float v = (float)((3.0 - (double)sqrtf(d2)) - (double)sprice[k]);
-                if (v > tbest) { tbetter = tbest; tbest = v; tidx = k; }
-                else if (v > tbetter) tbetter = v;
-            }
-            tri_wave(tbest, tbetter, tidx);
+            float tbest, tbetter;
+            int tidx;
+            emd_bid_scan(sy4, n, x1, y1, z1, lane, tbest, tbetter, tidx);
             if (lane == 0) {
                 if ((unsigned)tidx >= (unsigned)n) { tidx = i; tbest = tbetter = 0.f; }      // NaN / inf row: see the kernel above
                 const float inc = __fadd_rn(__fsub_rn(tbest, tbetter), a.eps);
@@ -338,6 +399,7 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
         barrier((unsigned)U);
         const unsigned ucur = utot;                              // every workgroup reads the same total: its poll saw all arrivals
         if (ucur == uprev) break;                                // nothing left to assign in the whole sample (uniform)
+        const unsigned u_it = ucur - uprev;                      // the sample's unassigned points at the start of this iteration
         uprev = ucur;
         if (!KEY64) {
             // ---- winner of each object: largest index among the bidders holding the exact maximum increment
@@ -368,14 +430,79 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
         for (int u = tid; u < U; u += EMD_THREADS) pbid[u] = sbid[u];
         pU = U;
         barrier(0u);
+        // The unassigned count of a sample never grows (a winner takes one point off the list and evicts at most one), and once
+        // it is small an iteration is nothing but its fixed cost: the price copy, the list build and TWO grid barriers - 9 us
+        // for a handful of bids (a prediction near its target has <= 40 unassigned points from the fifth iteration on and
+        // still runs all 50).  From here on ONE workgroup finishes the sample out of its own LDS with workgroup barriers only.
+        if (KEY64 && PF_EMD_SOLO > 0 && !last && u_it <= (unsigned)PF_EMD_SOLO) { solo_from = it + 1; break; }
+    }
+    if (solo_from >= 0 && !dead) {                               // uniform over the sample's workgroups (u_it is the barrier's total)
+        if (w != 0) return;                                      // every write of the iterations so far is behind the barrier above
+        for (int i = tid; i < n; i += EMD_THREADS) {
+            sassign[i] = ald(assignment + i); sainv[i] = ald(ainv + i); sy4[i].w = ald(price + i); skey[i] = 0ull;
+        }
+        __syncthreads();
+        for (int it = solo_from; it < a.iters; ++it) {
+            const bool last = it == a.iters - 1;
+            if (tid == 0) ucount = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += EMD_THREADS)
+                if (sassign[i] == -1) ulist[atomicAdd(&ucount, 1)] = i;
+            __syncthreads();
+            const int U = ucount;
+            if (U == 0) break;
+            for (int u = wave; u < U; u += EMD_THREADS / 64) {     // the same bid, vote word and tie rules as above
+                const int i = ulist[u];
+                const float x1 = x[i * 3 + 0], y1 = x[i * 3 + 1], z1 = x[i * 3 + 2];
+                float tbest, tbetter;
+                int tidx;
+                emd_bid_scan(sy4, n, x1, y1, z1, lane, tbest, tbetter, tidx);
+                if (lane == 0) {
+                    if ((unsigned)tidx >= (unsigned)n) { tidx = i; tbest = tbetter = 0.f; }
+                    const float inc = __fadd_rn(__fsub_rn(tbest, tbetter), a.eps);
+                    sbid[u] = tidx;
+                    sinc[u] = inc;
+                    atomicMax(skey + tidx, ((unsigned long long)__float_as_uint(inc) << 32) | (unsigned)i);
+                }
+            }
+            __syncthreads();
+            for (int u = tid; u < U; u += EMD_THREADS) {
+                const int i = ulist[u], o = sbid[u];
+                const bool won = (int)(unsigned)(skey[o] & 0xffffffffull) == i;
+                if (last || won) {
+                    if (!last) {
+                        const int prev = sainv[o];
+                        if (prev != -1) sassign[prev] = -1;
+                    }
+                    sainv[o] = i;
+                    sassign[i] = o;
+                    atomicAdd(&sy4[o].w, sinc[u]);
+                }
+            }
+            __syncthreads();
+            for (int u = tid; u < U; u += EMD_THREADS) skey[sbid[u]] = 0ull;      // read again only behind the next iteration's barriers
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += EMD_THREADS) {
+            const int k = sassign[i];
+            assignment[i] = k; ainv[i] = sainv[i]; price[i] = sy4[i].w;
+            float d = __builtin_nanf("");
+            if ((unsigned)k < (unsigned)n) {
+                const float dx = __fsub_rn(x[i * 3 + 0], sy4[k].x), dy = __fsub_rn(x[i * 3 + 1], sy4[k].y),
+                            dz = __fsub_rn(x[i * 3 + 2], sy4[k].z);
+                d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            }
+            a.dist[o0 + i] = d;
+        }
+        return;
     }
     // ---- squared distance to the assigned ground-truth point (cu:217-226)
     for (int i = i0 + tid; i < i1; i += EMD_THREADS) {
         const int k = ald(assignment + i);
         float d = __builtin_nanf("");
         if (!dead && (unsigned)k < (unsigned)n) {
-            const float dx = __fsub_rn(x[i * 3 + 0], sy[k * 3 + 0]), dy = __fsub_rn(x[i * 3 + 1], sy[k * 3 + 1]),
-                        dz = __fsub_rn(x[i * 3 + 2], sy[k * 3 + 2]);
+            const float dx = __fsub_rn(x[i * 3 + 0], sy4[k].x), dy = __fsub_rn(x[i * 3 + 1], sy4[k].y),
+                        dz = __fsub_rn(x[i * 3 + 2], sy4[k].z);
             d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
         }
         a.dist[o0 + i] = d;
@@ -383,6 +510,195 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_coop_kernel(EmdCoopArgs a) {
     // a timed-out barrier is REPORTED by EVERY workgroup that saw it (workgroup 0 of the sample may have got through its last
     // barrier while a peer timed out: that peer's slice of dist is NaN): the host raises on any non-zero count at its next
     // synchronisation point; the NaN distances above only keep a consumer from using the partial assignment silently
+    if (dead && tid == 0 && a.status) atomicAdd(a.status, 1u);
+}
+
+// ---- round 5: the multi-workgroup auction with REPLICATED state - one grid barrier per iteration instead of two ---------------
+// emd_coop_kernel keeps a sample's assignment / owner / price arrays in global memory: every iteration its G workgroups reload
+// the prices, bid, meet at a barrier, resolve winners with global atomics and assign through global memory, and meet again -
+// ~9 us of round trips per iteration for what is, from the fifth iteration on, a handful of bids.  Here EVERY workgroup of the
+// sample keeps the WHOLE state (assignment, owner, price, vote words) in its own LDS and applies ALL bids of the sample to it:
+// the update is a deterministic function of the iteration's bid records, so the G copies stay identical.  Per iteration a
+// workgroup bids for the unassigned points of its slice, publishes one 8-byte record per bid
+// (increment bits << 32 | valid | object << 16 | bidder; slots of its own slice of a per-parity record array, stale slots
+// cleared), meets the others at ONE barrier, reads the sample's n record slots (8 bytes per thread) and resolves winners and
+// assignments in LDS.  No price reload, no global atomics, no second barrier.  Same bids, vote words and tie rules as the
+// other kernels: identical assignment (tests/test_gpu_losses.py compares all three with the oracle).
+#ifndef PF_EMD_REPL
+#define PF_EMD_REPL 1
+#endif
+__global__ __launch_bounds__(EMD_THREADS) void emd_repl_kernel(EmdCoopArgs a) {
+    __shared__ float4 sy4[EMDC_NMAX];
+    __shared__ int ulist[EMDC_NMAX], sbid[EMDC_NMAX];
+    __shared__ float sinc[EMDC_NMAX];
+    __shared__ int sassign[EMDC_NMAX], sainv[EMDC_NMAX];
+    __shared__ unsigned long long skey[EMDC_NMAX];
+    __shared__ int ucount, dead;
+    __shared__ unsigned utot;
+    const int G = a.G;
+    const int nsamp = gridDim.x / G;
+    int b = blockIdx.x / G, w = blockIdx.x % G;
+    if ((nsamp & 7) == 0) {                                      // a sample's workgroups on one XCD (speed only)
+        const int xc = blockIdx.x & 7, r = blockIdx.x >> 3;
+        b = xc * (nsamp >> 3) + r / G;
+        w = r % G;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n;
+    const size_t o0 = (size_t)b * n;
+    const float* x = a.x + o0 * 3;
+    int* assignment = a.assignment + o0;
+    int* ainv = a.assignment_inv + o0;
+    float* price = a.price + o0;
+    unsigned long long* cnt64 = reinterpret_cast<unsigned long long*>(a.sync + o0);
+    const int i0 = (int)((long long)w * n / G), i1 = (int)((long long)(w + 1) * n / G);
+    unsigned nb = 0;
+    if (tid == 0) dead = 0;
+    auto barrier = [&](unsigned add_u) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ++nb;
+        if (tid == 0) {
+            atomicAdd(cnt64, ((unsigned long long)add_u << 32) | 1ull);
+            const unsigned target = nb * (unsigned)G;
+            int budget = 1 << 18;
+            unsigned long long v = ald(cnt64);
+            while ((unsigned)v < target && --budget > 0) { __builtin_amdgcn_s_sleep(1); v = ald(cnt64); }
+            if (budget <= 0) dead = 1;
+            utot = (unsigned)(v >> 32);
+        }
+        __syncthreads();
+    };
+    for (int i = tid; i < n; i += EMD_THREADS) {
+        sy4[i] = make_float4(a.y[(o0 + i) * 3 + 0], a.y[(o0 + i) * 3 + 1], a.y[(o0 + i) * 3 + 2], price[i]);
+        sassign[i] = assignment[i]; sainv[i] = ainv[i]; skey[i] = 0ull;
+    }
+    for (int i = i0 + tid; i < i1; i += EMD_THREADS) { ast(a.k0 + o0 + i, 0ull); ast(a.k1 + o0 + i, 0ull); }
+    barrier(0u);
+    int pU0 = 0, pU1 = 0, solo_from = -1;
+    unsigned uprev = 0;
+    bool done = false;
+    for (int it = 0; it < a.iters && !dead; ++it) {
+        const bool last = it == a.iters - 1;
+        const int par = it & 1;
+        unsigned long long* rec = (par ? a.k1 : a.k0) + o0;
+        if (tid == 0) ucount = 0;
+        __syncthreads();
+        for (int i = i0 + tid; i < i1; i += EMD_THREADS)
+            if (sassign[i] == -1) ulist[atomicAdd(&ucount, 1)] = i;
+        __syncthreads();
+        const int U = ucount;
+        for (int u = wave; u < U; u += EMD_THREADS / 64) {
+            const int i = ulist[u];
+            float tbest, tbetter;
+            int tidx;
+            emd_bid_scan(sy4, n, x[i * 3 + 0], x[i * 3 + 1], x[i * 3 + 2], lane, tbest, tbetter, tidx);
+            if (lane == 0) {
+                if ((unsigned)tidx >= (unsigned)n) { tidx = i; tbest = tbetter = 0.f; }      // NaN / inf row: see emd_auction_kernel
+                const float inc = __fadd_rn(__fsub_rn(tbest, tbetter), a.eps);
+                ast(rec + i0 + u, ((unsigned long long)__float_as_uint(inc) << 32) | 0x80000000ull | ((unsigned long long)tidx << 16) |
+                                      (unsigned long long)i);
+            }
+        }
+        const int pUp = par ? pU1 : pU0;                          // slots this workgroup filled two iterations ago and does not refill
+        for (int u = U + tid; u < pUp; u += EMD_THREADS) ast(rec + i0 + u, 0ull);
+        if (par) pU1 = U; else pU0 = U;
+        barrier((unsigned)U);
+        const unsigned ucur = utot;
+        if (ucur == uprev) { done = true; break; }               // nothing left to assign in the whole sample (uniform)
+        const unsigned u_it = ucur - uprev;
+        uprev = ucur;
+        // ---- every workgroup applies every bid of the sample to its own copy of the state
+        unsigned long long r[(EMDC_NMAX + EMD_THREADS - 1) / EMD_THREADS];
+#pragma unroll
+        for (int q = 0; q < (EMDC_NMAX + EMD_THREADS - 1) / EMD_THREADS; ++q) {
+            const int t = tid + q * EMD_THREADS;
+            r[q] = t < n ? ald(rec + t) : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < (EMDC_NMAX + EMD_THREADS - 1) / EMD_THREADS; ++q)
+            if (r[q] & 0x80000000ull) atomicMax(skey + (int)((r[q] >> 16) & 0x7fffu), (r[q] & 0xffffffff00000000ull) | (r[q] & 0xffffull));
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < (EMDC_NMAX + EMD_THREADS - 1) / EMD_THREADS; ++q)
+            if (r[q] & 0x80000000ull) {
+                const int o = (int)((r[q] >> 16) & 0x7fffu), i = (int)(r[q] & 0xffffu);
+                if (last || (int)(unsigned)(skey[o] & 0xffffffffull) == i) {
+                    const float inc = __uint_as_float((unsigned)(r[q] >> 32));
+                    if (!last) {
+                        const int prev = sainv[o];
+                        if (prev != -1) sassign[prev] = -1;
+                        sy4[o].w = __fadd_rn(sy4[o].w, inc);           // one winner per object
+                    } else
+                        atomicAdd(&sy4[o].w, inc);                      // the forced last round: several bidders may take one object
+                    sainv[o] = i;
+                    sassign[i] = o;
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < (EMDC_NMAX + EMD_THREADS - 1) / EMD_THREADS; ++q)
+            if (r[q] & 0x80000000ull) skey[(int)((r[q] >> 16) & 0x7fffu)] = 0ull;     // read again behind the next iteration's barriers
+        // few unassigned points left in the sample (their number never grows): workgroup 0 finishes alone, without grid barriers
+        if (PF_EMD_SOLO > 0 && !last && u_it <= (unsigned)PF_EMD_SOLO) { solo_from = it + 1; break; }
+    }
+    (void)done;
+    int w0 = i0, w1 = i1;                                        // the slice of the outputs this workgroup writes
+    if (solo_from >= 0 && !dead) {
+        if (w != 0) return;
+        w0 = 0; w1 = n;
+        for (int it = solo_from; it < a.iters; ++it) {
+            const bool last = it == a.iters - 1;
+            if (tid == 0) ucount = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += EMD_THREADS)
+                if (sassign[i] == -1) ulist[atomicAdd(&ucount, 1)] = i;
+            __syncthreads();
+            const int U = ucount;
+            if (U == 0) break;
+            for (int u = wave; u < U; u += EMD_THREADS / 64) {
+                const int i = ulist[u];
+                float tbest, tbetter;
+                int tidx;
+                emd_bid_scan(sy4, n, x[i * 3 + 0], x[i * 3 + 1], x[i * 3 + 2], lane, tbest, tbetter, tidx);
+                if (lane == 0) {
+                    if ((unsigned)tidx >= (unsigned)n) { tidx = i; tbest = tbetter = 0.f; }
+                    const float inc = __fadd_rn(__fsub_rn(tbest, tbetter), a.eps);
+                    sbid[u] = tidx;
+                    sinc[u] = inc;
+                    atomicMax(skey + tidx, ((unsigned long long)__float_as_uint(inc) << 32) | (unsigned)i);
+                }
+            }
+            __syncthreads();
+            for (int u = tid; u < U; u += EMD_THREADS) {
+                const int i = ulist[u], o = sbid[u];
+                if (last || (int)(unsigned)(skey[o] & 0xffffffffull) == i) {
+                    if (!last) {
+                        const int prev = sainv[o];
+                        if (prev != -1) sassign[prev] = -1;
+                    }
+                    sainv[o] = i;
+                    sassign[i] = o;
+                    atomicAdd(&sy4[o].w, sinc[u]);
+                }
+            }
+            __syncthreads();
+            for (int u = tid; u < U; u += EMD_THREADS) skey[sbid[u]] = 0ull;
+        }
+    }
+    __syncthreads();
+    // ---- outputs: the slice's state and its squared distances to the assigned ground-truth points (cu:217-226)
+    for (int i = w0 + tid; i < w1; i += EMD_THREADS) {
+        const int k = sassign[i];
+        assignment[i] = k; ainv[i] = sainv[i]; price[i] = sy4[i].w;
+        float d = __builtin_nanf("");
+        if (!dead && (unsigned)k < (unsigned)n) {
+            const float dx = __fsub_rn(x[i * 3 + 0], sy4[k].x), dy = __fsub_rn(x[i * 3 + 1], sy4[k].y),
+                        dz = __fsub_rn(x[i * 3 + 2], sy4[k].z);
+            d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        }
+        a.dist[o0 + i] = d;
+    }
     if (dead && tid == 0 && a.status) atomicAdd(a.status, 1u);
 }
 
@@ -437,7 +753,8 @@ extern "C" int pf_emd_forward_ex(const float* xyz1, const float* xyz2, float* di
         int ncu = 0, dev = 0, per_cu = 0;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         const hipError_t oc = key64
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, emd_coop_kernel<true>, EMD_THREADS, 0)
+            ? (PF_EMD_REPL ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, emd_repl_kernel, EMD_THREADS, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, emd_coop_kernel<true>, EMD_THREADS, 0))
             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, emd_coop_kernel<false>, EMD_THREADS, 0);
         if (oc != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
         const long long resident = per_cu >= 1 ? (long long)ncu : 0;        // one workgroup per CU at most: each wants a whole CU's issue slots
@@ -453,7 +770,8 @@ extern "C" int pf_emd_forward_ex(const float* xyz1, const float* xyz2, float* di
             c.k0 = reinterpret_cast<unsigned long long*>(max_increments);
             c.k1 = reinterpret_cast<unsigned long long*>(max_idx);
             // each array pair holds 2 B n 32-bit words = B n 64-bit words: sample b's keys at word offset b n
-            hipLaunchKernelGGL(emd_coop_kernel<true>, dim3(B * G), dim3(EMD_THREADS), 0, s, c);
+            if (PF_EMD_REPL) hipLaunchKernelGGL(emd_repl_kernel, dim3(B * G), dim3(EMD_THREADS), 0, s, c);
+            else hipLaunchKernelGGL(emd_coop_kernel<true>, dim3(B * G), dim3(EMD_THREADS), 0, s, c);
         } else
             hipLaunchKernelGGL(emd_coop_kernel<false>, dim3(B * G), dim3(EMD_THREADS), 0, s, c);
         return pf_last_launch_status();
