@@ -2104,7 +2104,9 @@ __device__ __forceinline__ Bf2 dw3_split(const float (&x)[8]) {
 
 __global__ __launch_bounds__(512) void ec_dw3_kernel(EcDw2Args g2) {
     const EcDwArgs& a = g2.d;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+    // the wave index through readfirstlane: its job (row strip, column tile count) is then wave-uniform to the compiler - scalar
+    // loads of the job, scalar branches around the per-tile MFMAs instead of exec masks
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
     if (wave >= g2.njob) return;
     const EcDw2Job jb = g2.job[wave];
     const int e_lo = blockIdx.x * a.chunk, e_hi = min((int)a.E, e_lo + a.chunk);      // multiples of 16
@@ -2972,77 +2974,105 @@ struct BnlDwArgs {
     int rows, chunk;
     float* part; float* bpart;                 // [nchunk][RA16][RB16], [nchunk][RA16]
 };
-__global__ __launch_bounds__(256) void bnl_dw_kernel(BnlDwArgs a) {
+// one staged 32-row block for a wave that owns NS output tiles; SAME: consecutive row tiles of ONE column tile (one B read per
+// k step).  Every operand read of a k step is issued before its MFMAs, through one LDS address per tile with the k step as an
+// immediate offset (round 5: see mlp_dw_kernel in train_mlp.hip - with lane-dependent tile lists and run-time LDS strides hipcc
+// kept an address register per (k step, tile) read and waited for one LDS read per MFMA)
+constexpr int BNL_LD = 144;                         // LDS row stride of the staged blocks: >= 128 columns, = 16 (mod 32) floats
+constexpr int BNL_DW_WAVES = 8, BNL_DW_T = 64 * BNL_DW_WAVES, BNL_DW_SLOTS = 8;     // <= 64 output tiles over 8 waves
+template <int NS, bool SAME>
+__device__ __forceinline__ void bnl_dw_block(const float* ar0, const float* br0, const int (&rts)[BNL_DW_SLOTS],
+                                             const int (&cts)[BNL_DW_SLOTS], f4 (&acc)[BNL_DW_SLOTS]) {
+    const float* ap[NS];
+    const float* bp[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { ap[s] = ar0 + rts[s] * 16; bp[s] = br0 + cts[SAME ? 0 : s] * 16; }
+#pragma unroll
+    for (int ks = 0; ks < BNL_EB / 4; ++ks) {
+        float av[NS], bv[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            av[s] = ap[s][4 * ks * BNL_LD];
+            bv[s] = (SAME && s > 0) ? bv[0] : bp[s][4 * ks * BNL_LD];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = pf_mfma(av[s], bv[s], acc[s]);
+    }
+}
+__global__ __launch_bounds__(BNL_DW_T) void bnl_dw_kernel(BnlDwArgs a) {
     extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), row = lane & 15, q = lane >> 4;
     const int RA = (a.RA + 15) & ~15, RB = (a.RB + 15) & ~15;
-    const int lda = RA + 16, ldb = RB + 16;
+    constexpr int lda = BNL_LD, ldb = BNL_LD;
     float* As = lds;
     float* Bs = lds + BNL_EB * lda;
+    float* Sc = Bs + BNL_EB * ldb;                       // [2][128]: BatchNorm scale / shift of the input columns (1 / 0 without, 0 / 0 beyond RB)
     const int NT = RB / 16, NRT = RA / 16;
-    const int WC = NT < 4 ? NT : 4, rstep = 4 / (WC == 3 ? 4 : WC), rbase = wave / (WC == 3 ? 4 : WC);
-    int ctj[2];
-    bool cval[2];
+    // a wave's tiles: consecutive ids in column-major order (id = column tile x NRT + row tile)
+    const int nper = (NRT * NT + BNL_DW_WAVES - 1) / BNL_DW_WAVES;
+    const int ns = min(nper, max(0, NRT * NT - wave * nper));
+    int rts[BNL_DW_SLOTS], cts[BNL_DW_SLOTS];
+    bool same = true;
 #pragma unroll
-    for (int jc = 0; jc < 2; ++jc) { ctj[jc] = wave % (WC == 3 ? 4 : WC) + (WC == 3 ? 4 : WC) * jc; cval[jc] = ctj[jc] < NT; }
-    bool val[8][2];
+    for (int s = 0; s < BNL_DW_SLOTS; ++s) {
+        const int id = wave * nper + s;
+        const bool v = s < ns;
+        cts[s] = v ? id / NRT : 0; rts[s] = v ? id - cts[s] * NRT : 0;
+        if (v && cts[s] != cts[0]) same = false;
+    }
+    f4 acc[BNL_DW_SLOTS];
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int jc = 0; jc < 2; ++jc) val[s][jc] = rbase + rstep * s < NRT && cval[jc];
-    f4 acc[8][2];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) { acc[s][0] = pf_splat(0.f); acc[s][1] = pf_splat(0.f); }
+    for (int s = 0; s < BNL_DW_SLOTS; ++s) acc[s] = pf_splat(0.f);
     const int r_lo = blockIdx.x * a.chunk, r_hi = min(a.rows, r_lo + a.chunk);
     const int ra4 = RA / 4, rb4 = RB / 4;
-    constexpr int UN = 4;
+    constexpr int UN = (BNL_EB * 32 + BNL_DW_T - 1) / BNL_DW_T;
     int elA[UN], cA[UN], elB[UN], cB[UN];
 #pragma unroll
     for (int n = 0; n < UN; ++n) {
-        const int k = threadIdx.x + 256 * n;
+        const int k = threadIdx.x + BNL_DW_T * n;
         elA[n] = k / ra4; cA[n] = (k - elA[n] * ra4) * 4;
         elB[n] = k / rb4; cB[n] = (k - elB[n] * rb4) * 4;
     }
     const bool veca = (a.RA & 3) == 0, vecb = (a.RB & 3) == 0 && (a.ldx & 3) == 0;
     const float slope = a.sc ? a.slope : 1.f;
-    f4 ra[UN], rbv[UN];
+    for (int i = threadIdx.x; i < BNL_EB * (lda + ldb); i += BNL_DW_T) As[i] = 0.f;      // padding columns: never written again
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x;
+        Sc[c] = c < a.RB ? (a.sc ? a.sc[c] : 1.f) : 0.f;
+        Sc[128 + c] = (c < a.RB && a.sc) ? a.sh[c] : 0.f;
+    }
+    // every load is issued unconditionally through an address that is valid even when the unit is not (then replaced by zero)
+    f4 ra[UN], rbx[UN];
     auto fetch = [&](int rb) {
 #pragma unroll
         for (int n = 0; n < UN; ++n) {
-            f4 v = pf_splat(0.f);
             const int r = rb + elA[n], c = cA[n];
-            if (elA[n] < BNL_EB && r < r_hi && c < a.RA) {
-                if (veca) v = *reinterpret_cast<const f4*>(a.dy + (size_t)r * a.RA + c);
-                else
+            const bool ok = elA[n] < BNL_EB && r < r_hi && c < a.RA;
+            const float* ptr = ok ? a.dy + (size_t)r * a.RA + c : a.dy;
+            f4 v;
+            if (veca) v = *reinterpret_cast<const f4*>(ptr);
+            else {
 #pragma unroll
-                    for (int w = 0; w < 4; ++w)
-                        if (c + w < a.RA) v[w] = a.dy[(size_t)r * a.RA + c + w];
+                for (int w = 0; w < 4; ++w) { const bool okw = ok && c + w < a.RA; const float x = ptr[okw ? w : 0]; v[w] = okw ? x : 0.f; }
             }
-            ra[n] = v;
+            ra[n] = ok ? v : pf_splat(0.f);
         }
 #pragma unroll
         for (int n = 0; n < UN; ++n) {
-            f4 v = pf_splat(0.f);
             const int r = rb + elB[n], c = cB[n];
-            if (elB[n] < BNL_EB && r < r_hi && c < a.RB) {
-                f4 x = pf_splat(0.f), s1 = pf_splat(1.f), s2 = pf_splat(0.f);
-                if (vecb) x = *reinterpret_cast<const f4*>(a.X + (size_t)r * a.ldx + c);
-                else
+            const bool ok = elB[n] < BNL_EB && r < r_hi && c < a.RB;
+            const float* ptr = ok ? a.X + (size_t)r * a.ldx + c : a.X;
+            f4 v;
+            if (vecb) v = *reinterpret_cast<const f4*>(ptr);
+            else {
 #pragma unroll
-                    for (int w = 0; w < 4; ++w)
-                        if (c + w < a.RB) x[w] = a.X[(size_t)r * a.ldx + c + w];
-                if (a.sc)
-#pragma unroll
-                    for (int w = 0; w < 4; ++w)
-                        if (c + w < a.RB) { s1[w] = a.sc[c + w]; s2[w] = a.sh[c + w]; }
-                v = lrelu4(x * s1 + s2, slope);
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    if (c + w >= a.RB) v[w] = 0.f;
+                for (int w = 0; w < 4; ++w) { const bool okw = ok && c + w < a.RB; const float x = ptr[okw ? w : 0]; v[w] = okw ? x : 0.f; }
             }
-            rbv[n] = v;
+            rbx[n] = ok ? v : pf_splat(0.f);
         }
     };
+    const bool bpow = (RA & (RA - 1)) == 0;              // RA = 16 .. 128: thread (column, row group) sums its rows of every block
+    const int bcol = threadIdx.x & (RA - 1), bgrp = threadIdx.x / RA, brows = bpow ? BNL_EB / (BNL_DW_T / RA) : 0;
     float bsum = 0.f;
     fetch(r_lo);
     for (int rb = r_lo; rb < r_hi; rb += BNL_EB) {
@@ -3050,38 +3080,45 @@ __global__ __launch_bounds__(256) void bnl_dw_kernel(BnlDwArgs a) {
 #pragma unroll
         for (int n = 0; n < UN; ++n) {
             if (elA[n] < BNL_EB) *reinterpret_cast<f4*>(As + elA[n] * lda + cA[n]) = ra[n];
-            if (elB[n] < BNL_EB) *reinterpret_cast<f4*>(Bs + elB[n] * ldb + cB[n]) = rbv[n];
+            if (elB[n] < BNL_EB) {
+                const f4 s1 = *reinterpret_cast<const f4*>(Sc + cB[n]), s2 = *reinterpret_cast<const f4*>(Sc + 128 + cB[n]);
+                *reinterpret_cast<f4*>(Bs + elB[n] * ldb + cB[n]) = lrelu4(rbx[n] * s1 + s2, slope);
+            }
         }
         __syncthreads();
         if (rb + BNL_EB < r_hi) fetch(rb + BNL_EB);
-        if (threadIdx.x < RA)
+        if (bpow) {
+            for (int e = 0; e < brows; ++e) bsum += As[(bgrp * brows + e) * lda + bcol];
+        } else if ((int)threadIdx.x < RA) {
 #pragma unroll 8
             for (int el = 0; el < BNL_EB; ++el) bsum += As[el * lda + threadIdx.x];
-#pragma unroll
-        for (int ks = 0; ks < BNL_EB / 4; ++ks) {
-            const float* ar = As + (4 * ks + q) * lda + row + rbase * 16;
-            const float* br = Bs + (4 * ks + q) * ldb + row;
-            const float b0 = cval[0] ? br[ctj[0] * 16] : 0.f, b1 = cval[1] ? br[ctj[1] * 16] : 0.f;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (val[s][0] || val[s][1]) {
-                    const float av = ar[rstep * s * 16];
-                    if (val[s][0]) acc[s][0] = pf_mfma(av, b0, acc[s][0]);
-                    if (val[s][1]) acc[s][1] = pf_mfma(av, b1, acc[s][1]);
-                }
-            }
+        }
+        const float* ar0 = As + q * lda + row;
+        const float* br0 = Bs + q * ldb + row;
+        switch (same ? ns : -ns) {
+#define PF_BNLB(NS)                                                                 \
+            case NS: bnl_dw_block<NS, true>(ar0, br0, rts, cts, acc); break;        \
+            case -NS: bnl_dw_block<NS, false>(ar0, br0, rts, cts, acc); break;
+            PF_BNLB(1) PF_BNLB(2) PF_BNLB(3) PF_BNLB(4) PF_BNLB(5) PF_BNLB(6) PF_BNLB(7) PF_BNLB(8)
+#undef PF_BNLB
+            default: break;
         }
     }
-    if (threadIdx.x < RA) a.bpart[(size_t)blockIdx.x * RA + threadIdx.x] = bsum;
+    if (bpow) {                                          // the row groups' bias sums, added in group order
+        __syncthreads();
+        if (brows > 0) As[bgrp * lda + bcol] = bsum;
+        __syncthreads();
+        bsum = 0.f;
+        if ((int)threadIdx.x < RA)
+            for (int gI = 0; gI < BNL_DW_T / RA; ++gI) bsum += As[gI * lda + threadIdx.x];
+    }
+    if ((int)threadIdx.x < RA) a.bpart[(size_t)blockIdx.x * RA + threadIdx.x] = bsum;
     float* out = a.part + (size_t)blockIdx.x * RA * RB;
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < BNL_DW_SLOTS; ++s)
+        if (s < ns)
 #pragma unroll
-        for (int jc = 0; jc < 2; ++jc)
-            if (val[s][jc])
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    out[(size_t)((rbase + rstep * s) * 16 + 4 * q + r) * RB + ctj[jc] * 16 + row] = acc[s][jc][r];
+            for (int r = 0; r < 4; ++r) out[(size_t)(rts[s] * 16 + 4 * q + r) * RB + cts[s] * 16 + row] = acc[s][r];
 }
 
 // dW[c * ldw + coff + u] = sum_chunks part[k][c][u] (c < RA, u < RB); db[c] = sum_chunks bpart[k][c] (db nullable)
@@ -3227,8 +3264,9 @@ extern "C" int pf_bnmlp_train_bwd(const PfBnMlpTrain* p, void* stream) {
                   int coff, float* db) {
         const int RA16 = (RA + 15) & ~15, RB16 = (RB + 15) & ~15;
         BnlDwArgs a{dy, RA, X, ldx, RB, sc, sh, p->slope, p->rows, BNL_CHUNK, part, bpart};
-        const size_t lds = sizeof(float) * (size_t)BNL_EB * ((RA16 + 16) + (RB16 + 16));
-        hipLaunchKernelGGL(bnl_dw_kernel, dim3(nchunk), dim3(256), lds, s, a);
+        const size_t lds = sizeof(float) * ((size_t)BNL_EB * 2 * BNL_LD + 256);
+        (void)RA16; (void)RB16;
+        hipLaunchKernelGGL(bnl_dw_kernel, dim3(nchunk), dim3(BNL_DW_T), lds, s, a);
         const int total = RA * (RB + 1);
         hipLaunchKernelGGL(bnl_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, s, part, bpart, nchunk, RA, RB, RA16, RB16, dW,
                            ldw, coff, db);
