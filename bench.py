@@ -445,10 +445,17 @@ def bench_train(args, world, rank, dev, dist):
     # barriers assume this process's workgroups are co-resident (csrc/emd.hip)
     shared = os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1" and world > 1
     syncbn = os.environ.get("PF_BENCH_SYNCBN") == "1"      # BatchNorm statistics over all ranks (cfg.sync_batchnorm) on the fused kernels
+    det_env = os.environ.get("PF_BENCH_DETERMINISTIC") == "1"   # cfg.deterministic: bit-reproducible steps (tests; slower)
 
-    def fresh_module():
-        m = TrainerModule(default_cfg(learning_rate=1e-3, emd_workgroups=1 if shared else 0, sync_batchnorm=syncbn), loss_mix="pugan")
+    def fresh_module(det=None):
+        m = TrainerModule(default_cfg(learning_rate=1e-3, emd_workgroups=1 if shared else 0, sync_batchnorm=syncbn,
+                                      deterministic=det_env if det is None else det), loss_mix="pugan")
         m.network.load_state_dict(synth_state_dict(2021))
+        if os.environ.get("PF_BENCH_ACTNORM_INITED") == "1":
+            # tests only: skip ActNorm's data-dependent first-batch init (the multi-rank path runs it as an extra forward + a
+            # broadcast, the one-process path inside the first step: different kernels, different rounding) so that a forced
+            # one-rank group and the plain path take literally the same steps
+            m.network.set_to_initialized_state()
         return m.to(dev)
     sd = synth_state_dict(2021)
     dense_cpu = (synth_patches(args.batch, 1024, seed=2021 + rank) + 1) / 2                # [0,1] for the EMD
@@ -456,18 +463,21 @@ def bench_train(args, world, rank, dev, dist):
     sparse = dense[:, ::4].contiguous()
     batch = (sparse, dense, torch.ones(args.batch, device=dev))
 
-    def step_grads():
+    def step_grads(det=None, full_loss=False):
         """Gradients of ONE benchmark step (train-mode forward, loss, backward; no update) from the benchmark's initial state.
         The loss is the step's WITHOUT the EMD term (1e-4 logp + 1e-1 CD): the auction's assignment is a discrete, chaotic
         function of the prediction - a 1e-6 change of x re-assigns points and moves the EMD gradient by percents, which would
         bury what this leg measures (the arithmetic of the backward kernels); the EMD backward itself is 2 g (x - y), no
         matrix product."""
         from puflow_amd import ops
-        m = fresh_module()
+        m = fresh_module(det)
         m.train()
-        x, logp = m(sparse, upratio=4)
-        cd, _ = ops.chamfer_distance(x, dense)
-        loss = logp * 1e-4 + cd * 1e-1
+        if full_loss:                                        # the step's own loss, EMD term included (TrainerModule.training_step)
+            loss = m.training_step(batch, 0)
+        else:
+            x, logp = m(sparse, upratio=4)
+            cd, _ = ops.chamfer_distance(x, dense)
+            loss = logp * 1e-4 + cd * 1e-1
         loss.backward()
         torch.cuda.synchronize()
         return {k: (p.grad.detach().cpu().clone() if p.grad is not None else torch.zeros_like(p).cpu()) for k, p in m.named_parameters()}, float(loss)
@@ -587,6 +597,7 @@ def bench_train(args, world, rank, dev, dist):
                           "grad_norm_last_step": grad_norm_last,
                           "config": {"workload": "BASELINE configs[2]: discrete x4 training step, 32 x (256->1024) patches per GPU",
                                      "loss": "1e-4 logp + 5e-2 EMD(eps .005, 50 it) + 1e-1 CD", "optimizer": "Adam 1e-3, clip 1e-2",
+                                     "deterministic": bool(det_env),
                                      "launch": ("hipGraph replay (graph A: forward + loss + backward + gradient packing; eager all-reduce of the flat "
                                                 "gradient bucket; graph B: clip + Adam)" if use_dist else "hipGraph replay") if graphed else "eager",
                                      "collectives": args.collectives, "sync_batchnorm": syncbn,
@@ -650,7 +661,21 @@ def train_grad_parity(args, step_grads):
                 "zero_gradient_tensors": {"n": len(dead), "max_abs_value_default": max([float(ga[k].abs().max()) for k in dead], default=0.0),
                                           "max_abs_value_reference": max([scale[k] for k in dead], default=0.0), "largest_gradient": gmax},
                 "loss_values": [la, lr]}
-    out = {"loss": "1e-4 logp + 1e-1 CD of the benchmark batch (the step's loss without the EMD term: its assignment is discrete and chaotic in x)",
+    # ---- cfg.deterministic: two runs of the step's OWN loss (EMD term included) from the same state must agree to the bit, in
+    # the loss and in every gradient element; next to it the same two runs of the default build (float / double atomics in
+    # arrival order: a 1e-7 difference in x flips auction assignments and max-pool routes)
+    def two_runs(det):
+        g1, l1 = step_grads(det=det, full_loss=True)
+        g2, l2 = step_grads(det=det, full_loss=True)
+        gm = max(float(v.abs().max()) for v in g1.values())
+        return {"loss": [l1, l2], "loss_bit_identical": l1 == l2, "gradients_bit_identical": all(torch.equal(g1[k], g2[k]) for k in g1),
+                "max_abs_gradient_difference_over_largest_gradient": max(float((g1[k] - g2[k]).abs().max()) for k in g1) / gm}
+    determinism = {"loss": "the step's loss 1e-4 logp + 5e-2 EMD / radius + 1e-1 CD, forward + backward, two runs from the same state",
+                   "cfg.deterministic=True": two_runs(True), "default": two_runs(False)}
+    out = {"determinism": determinism,
+           "loss": "1e-4 logp + 1e-1 CD of the benchmark batch (the step's loss without the EMD term: the comparison is ACROSS BUILDS whose "
+                   "forward differs by ~1e-6, and the auction's assignment is a discrete, chaotic function of x - that is not noise and "
+                   "cfg.deterministic does not remove it)",
            "metric": "per parameter tensor: max|g - g_ref| / max|g_ref| over the tensor's elements; tensors whose reference gradient is <= 1e-5 of "
                      "the largest one (conv biases in front of BatchNorm: mathematically zero) are listed as absolute residue",
            "patches": args.batch}
@@ -723,25 +748,49 @@ def bench_cnf(args, world, rank, dev, dist):
     net.load_state_dict(sd)
     net = net.to(dev).eval()
     B, N = args.batch, args.npoint
-    xyz_cpu = synth_patches(B, N, seed=2021 + rank)
-    xyz = xyz_cpu.to(dev)
-    torch.manual_seed(0)
-    noise_cpu = [torch.randn(B, N, 3) for _ in range(6)]
-    noise = [n.to(dev) for n in noise_cpu]
+    # FOUR different input batches with their own Hutchinson vectors rotate through the timed loop: the forward is
+    # enqueued without a look at a controller, with per-integration attempt budgets taken from the PREVIOUS forward - on one
+    # repeated input those budgets are always exact and the fallback (discard the blind work behind the first integration that
+    # ran out, re-integrate through the look-per-batch loop) never runs.  The line reports how often it did.
+    NSETS = 4
+    sets = []
+    for k in range(NSETS):
+        xc = synth_patches(B, N, seed=2021 + rank + 101 * k)
+        g = torch.Generator().manual_seed(1000 * k + rank)
+        nc = [torch.randn(B, N, 3, generator=g) for _ in range(6)]
+        sets.append((xc, nc, xc.to(dev), [n.to(dev) for n in nc]))
+    xyz_cpu, noise_cpu, xyz, noise = sets[0]
 
     def barrier():
         if use_dist:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        net(xyz, 4, noise=noise)
+    for w in range(max(args.warmup, 1)):
+        net(sets[w % NSETS][2], 4, noise=sets[w % NSETS][3])
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    blind = {"forwards": 0, "ran_blind": 0, "fell_back": 0, "attempts_enqueued": 0, "attempts_taken": 0, "fallback_from": []}
+    work = {"nfe": [], "accepted": [], "rejected": []}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        x, logp = net(xyz, 4, noise=noise)
+    for st_i in range(args.steps):
+        k = st_i % NSETS
+        x, logp = net(sets[k][2], 4, noise=sets[k][3])
+        bs_ = net.last_stats.get("blind", {})
+        blind["forwards"] += 1
+        blind["ran_blind"] += int(bool(bs_.get("ran")))
+        blind["attempts_enqueued"] += int(bs_.get("attempts_enqueued", 0))
+        blind["attempts_taken"] += int(bs_.get("attempts_taken", 0))
+        if bs_.get("fallback_from") is not None:
+            blind["fell_back"] += 1
+            blind["fallback_from"].append(int(bs_["fallback_from"]))
+        if st_i < NSETS:                                     # the solver's work on each of the input sets
+            for kk in work:
+                work[kk].append(int(net.last_stats[kk]))
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    stats = dict(net.last_stats)
+    stats = dict(per_input_set=work, blind=blind,
+                 note="nfe / accepted / rejected of one forward on each of the 4 rotating input sets (a fallback counts the discarded "
+                      "blind attempts' evaluations too); blind: forwards enqueued without a look at a controller, how many fell back "
+                      "to the look-per-batch loop (and from which of the 12 integrations), step attempts enqueued vs taken")
     t = torch.tensor([el], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -749,38 +798,43 @@ def bench_cnf(args, world, rank, dev, dist):
     roof = cpu = None
     extra = {}
     if rank == 0:
-        # ---- dominant kernel: one dopri5 step attempt (cnf_step kernel: six fused right-hand-side evaluations) on the R-times
-        # replicated rows of the inverse pass; live HIP events over 20 launches through the C ABI
-        import ctypes
+        # ---- dominant kernel: one dopri5 step attempt (six fused right-hand-side evaluations) on the R-times replicated rows of
+        # the inverse pass, timed THROUGH pf_cnf_steps - the entry point and kernel of the timed forward (cnf_step_dev_kernel with
+        # the controller on the device; the round-4 line timed pf_cnf_step's host-stepped kernel instead): the block with the
+        # longest integration, 12 attempts enqueued without a look, HIP events on the launch stream around them
         eng = net._engine(4)
         rows = B * N * 4
-        y0 = torch.randn(rows, 4, device=dev) * 0.3
-        f0 = torch.randn(rows, 4, device=dev) * 0.1
-        ctx = torch.randn(B * N, 288, device=dev) * 0.3
-        e = noise[0].reshape(B * N, 3).contiguous()
-        y1, f1, ym = torch.empty_like(y0), torch.empty_like(y0), torch.empty_like(y0)
-        ws = torch.zeros(2048, dtype=torch.float64, device=dev)
-        outd = torch.zeros(4, dtype=torch.float64, device=dev)
-        s = torch.cuda.current_stream().cuda_stream
-        lib = _lib.load()
-
-        def attempt():
-            _lib.check(lib.pf_cnf_step(y0.data_ptr(), f0.data_ptr(), 0.1, 0.05, 1, ctx.data_ptr(), e.data_ptr(), eng.rec[2].data_ptr(),
-                                       y1.data_ptr(), f1.data_ptr(), ym.data_ptr(), 1e-5, 1e-5, rows, 4, ws.data_ptr(),
-                                       outd.data_ptr(), s), "pf_cnf_step")
+        got0 = net(xyz, 4, noise=noise, stages=True)
+        ib = max(range(6), key=lambda i_: eng.T_end[i_])
+        cflat = got0["cs"][ib].reshape(B * N, -1).contiguous()
+        ctx = eng.context(ib, cflat)
+        e = noise[ib].reshape(B * N, 3).contiguous().float()
+        u0 = (got0["z"].reshape(B * N, 1, 3).expand(B * N, 4, 3).reshape(rows, 3) * 1.0).contiguous()
+        ATT = 12
+        eng.time_step_attempts(ib, u0, ctx, e, 4, True, 0, None, ATT, 4.0)
+        tot_ms, real, finished = 0.0, 0, False
         for _ in range(3):
-            attempt()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(20):
-            attempt()
-        b.record(); torch.cuda.synchronize()
-        st_ms = a.elapsed_time(b) / 20
+            ms_, real_, fin_ = eng.time_step_attempts(ib, u0, ctx, e, 4, True, 0, None, ATT, 4.0)
+            tot_ms += ms_; real += real_; finished = finished or fin_
+        st_ms = tot_ms / max(real, 1)
         flops = rows / 16 * 6 * CNF_MFMA_PER_EVAL * 16384.0
-        roof = {"bound": "mfma", "kernel": "cnf_step kernel (csrc/cnf.hip: one Dormand-Prince step attempt = six fused right-hand-side "
-                                         "evaluations incl. the Hutchinson vector-Jacobian product), inverse pass, rows = 4 B N",
+        traffic = None
+        try:                                                 # committed PMC summary of the step kernels (tools/pmc_cmd.sh over tools/time_cnf.py)
+            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_cnf_latest.json")))
+            ent = [v for k_, v in pm.get("kernels", {}).items() if "cnf_step_dev_kernel" in k_ and "hbm_bytes_per_launch" in v]
+            if ent:
+                ent = max(ent, key=lambda v: v.get("pct", 0.0))
+                traffic = {"bytes_per_launch": ent["hbm_bytes_per_launch"], "profiled_avg_us": ent.get("avg_us"),
+                           "source": "profiles/pmc_cnf_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the "
+                                     "gfx950 note; mean over the step kernel's launches of two forwards, no-op attempts included)"}
+        except Exception:
+            traffic = None
+        roof = {"bound": "mfma", "kernel": "cnf_step_dev_kernel through pf_cnf_steps (csrc/cnf.hip: one Dormand-Prince step attempt = six fused "
+                                         "right-hand-side evaluations incl. the Hutchinson vector-Jacobian product + the controller), inverse "
+                                         f"pass of block {ib} (T = {eng.T_end[ib]:.3g}), rows = 4 B N",
                 "achieved": flops / (st_ms * 1e-3) / 1e12, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": flops / (st_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, "traffic": None, "avg_launch_ms": st_ms,
+                "frac": flops / (st_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, "traffic": traffic, "avg_launch_ms": st_ms,
+                "attempts_timed": {"enqueued": 3 * ATT, "real": real, "integration_finished": finished},
                 "flops_basis": f"executed: 6 evaluations x {CNF_MFMA_PER_EVAL} fp16 MFMAs x 16384 flop per 16-row tile, {rows} rows per launch; "
                                "live HIP-event duration on the launch stream",
                 "note": "the evaluation is bound by its 32 tanh + 32 sigmoid per lane on the transcendental unit, not by the matrix pipe "

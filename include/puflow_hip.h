@@ -139,6 +139,10 @@ int pf_chamfer_fwd(const float* x, const float* y, int B, int N, int M, float* d
  * (caller zero-fills).  d dist/d x_i = 2 (x_i - y_j), d dist/d y_j = -2 (x_i - y_j). */
 int pf_chamfer_bwd(const float* x, const float* y, const int* idx1, const int* idx2, const float* g1, const float* g2,
                    float* gx, float* gy, int B, int N, int M, void* stream);
+/* the same without float atomics (every point's incoming terms found by a scan of the other cloud's nearest-neighbour map and
+ * added in index order): bit-reproducible, O(N M) per sample - the training step's debugging switch (PF_TRAIN_DETERMINISTIC) */
+int pf_chamfer_bwd_det(const float* x, const float* y, const int* idx1, const int* idx2, const float* g1, const float* g2,
+                       float* gx, float* gy, int B, int N, int M, void* stream);
 
 /* Auction EMD forward.  Replaces emd.forward (metric/emd/emd.cpp:14-19 -> emd_cuda.cu:228-282).
  * Same ownership rule as the reference: the caller allocates outputs AND scratch (emd_module.py:43-56):
@@ -226,6 +230,9 @@ int pf_maxpool_k_bwd(const float* dy, const int* arg, long long T, int K, int C,
 
 /* backward of a neighbour-row gather x[idx] (interpflow.py:183): out [B*N,C] += g [B*N*K,C] (out zero-filled by caller) */
 int pf_scatter_rows(const float* g, const int* idx, int B, int N, int K, int C, float* out, void* stream);
+/* the same as a gather over the sorted transposed lists of idx (pf_knn_csr): out [T, C] = sum over the edges that point at a row,
+ * in list order - no float atomics (PF_TRAIN_DETERMINISTIC) */
+int pf_scatter_rows_det(const float* g, const int* csr_off, const int* csr_edge, long long T, int C, float* out, void* stream);
 /* backward of repeat_interleave(c, R, dim=1) (interpflow.py:319): out [T,C] = sum_r g[T*R,C] */
 int pf_group_sum(const float* g, long long T, int R, int C, float* out, void* stream);
 
@@ -314,6 +321,13 @@ typedef struct PfEcTrain {
     double* sync_sums;
 } PfEcTrain;
 #define PF_EC_PERSISTENT 1
+/* flags bit (PfEcTrain, PfBnMlpTrain): BatchNorm's batch statistics are accumulated as 64-bit fixed-point sums (quantum 2^-28)
+ * with integer atomics instead of double atomics - exact, hence independent of the order in which workgroups arrive: two runs
+ * of the same step give the same bits (the default's double sums round in arrival order once they need more than 53 bits, and
+ * a 1e-7 difference in x flips discrete auction assignments and max-pool routes).  Values differ from the default's by the
+ * quantisation (~4e-9 absolute per workgroup partial).  The persistent kernels are not used under it.  Debugging switch:
+ * puflow_amd sets it from `net.deterministic` / `cfg.deterministic`. */
+#define PF_TRAIN_DETERMINISTIC 2
 /* transposed neighbour lists of idx [B*N, K]: off [T+1], edge [T*K]; cnt: T ints (4-aligned size) of scratch */
 int pf_knn_csr(const int* idx, int B, int N, int K, int* off, int* edge, int* cnt, void* stream);
 long long pf_ec_train_ws_floats(const PfEcTrain* p);
@@ -346,6 +360,7 @@ typedef struct PfBnMlpTrain {
     int (*sync_cb)(void* user, double* sums, int n, void* stream);      /* SyncBN, as in PfEcTrain */
     void* sync_user;
     double* sync_sums;
+    int flags;                      /* PF_TRAIN_DETERMINISTIC */
 } PfBnMlpTrain;
 long long pf_bnmlp_train_ws_floats(const PfBnMlpTrain* p);
 int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream);
@@ -471,6 +486,10 @@ int pf_interp_wsum_fwd(const float* w, int ldw, const float* z, const int* idx, 
                        float* u, void* stream);
 int pf_interp_wsum_bwd(const float* a, const float* z, const int* idx, const float* du, int N, int K, int R, int ldw, long long T,
                        float* dw, float* dz, void* stream);
+/* csr_off / csr_edge non-NULL (pf_knn_csr of idx): dz as a gather over the sorted transposed lists instead of float atomics */
+int pf_interp_wsum_bwd_det(const float* a, const float* z, const int* idx, const float* du, int N, int K, int R, int ldw, long long T,
+                       float* dw, float* dz, const int* csr_off, const int* csr_edge,
+                           void* stream);
 int pf_emd_init(float* price, int* assign2, long long Bn, void* stream);
 int pf_pugan_loss_fwd(const float* logp, const float* dist, const float* radius, const float* per, int B, int n, float w_logp,
                       float w_emd, float w_cd, float* out, void* stream);

@@ -34,7 +34,7 @@ class PfBnMlpTrain(ctypes.Structure):
                 ("dout", c_void_p), ("d", c_void_p * 2), ("coef", c_void_p * 2), ("dxa", c_void_p), ("dxb", c_void_p),
                 ("dW", c_void_p * 3), ("db", c_void_p * 3), ("dgamma", c_void_p * 2), ("dbeta", c_void_p * 2),
                 ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p),
-                ("sync_cb", c_void_p), ("sync_user", c_void_p), ("sync_sums", c_void_p)]
+                ("sync_cb", c_void_p), ("sync_user", c_void_p), ("sync_sums", c_void_p), ("flags", c_int)]
 
 
 class PfMlpTrain(ctypes.Structure):
@@ -92,6 +92,8 @@ SIGNATURES = {
                                c_void_p, c_void_p]),
     "pf_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_int, c_void_p]),
+    "pf_chamfer_bwd_det": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_int, c_int, c_void_p]),
     "pf_emd_forward": (c_int, [c_void_p] * 11 + [c_float, c_int, c_int, c_int, c_void_p]),
     "pf_emd_forward_ex": (c_int, [c_void_p] * 11 + [c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_emd_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -121,6 +123,7 @@ SIGNATURES = {
     "pf_maxpool_k_fwd": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_maxpool_k_bwd": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "pf_scatter_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pf_scatter_rows_det": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p]),
     "pf_group_sum": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "pf_softmax_wsum_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p]),
     "pf_softmax_wsum_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p,
@@ -167,6 +170,8 @@ SIGNATURES = {
     "pf_interp_wsum_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p]),
     "pf_interp_wsum_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p,
                                    c_void_p]),
+    "pf_interp_wsum_bwd_det": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
     "pf_emd_init": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
     "pf_pugan_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
     "pf_pugan_loss_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,

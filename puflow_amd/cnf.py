@@ -262,6 +262,32 @@ class _CnfEngine:
             raise _lib.PuflowHipError(f"dopri5: underflow in dt ({dt:g}) at t = {t:g}, block {i}")
         return out
 
+    def time_step_attempts(self, i: int, x: Tensor, ctx: Tensor, e: Tensor, R: int, reverse: bool, extra_n: int, extra_d0,
+                           attempts: int, extra_scale: float = 1.0):
+        """bench.py's roofline leg: ONE integration of block i enqueued without a look at the controller, HIP events on the launch
+        stream around the `attempts` step attempts alone (pf_cnf_steps: the kernel of the timed forward, cnf_step_dev_kernel) ->
+        (milliseconds for all attempts, attempts the integration really took = accepted + rejected; the rest were no-ops)."""
+        rows = x.shape[0]
+        T = self.T_end[i]
+        t0, t1 = (0.0, T) if not reverse else (-T, 0.0)
+        x = x.float().contiguous()[:, :3].contiguous()
+        bufs = torch.empty((5, rows, 4), dtype=torch.float32, device=x.device)
+        y, y1, f0, f1, out = bufs[0], bufs[1], bufs[2], bufs[3], bufs[4]
+        ctl = torch.zeros(16, dtype=torch.float64, device=x.device)
+        _lib.check(self.lib.pf_cnf_init(ctl.data_ptr(), x.data_ptr(), int(x.stride(0)), y.data_ptr(), f0.data_ptr(),
+                                        ctx.data_ptr(), e.data_ptr(), self.rec[i].data_ptr(), t0, t1, float(rows * 4 + extra_n),
+                                        extra_d0.data_ptr() if extra_d0 is not None else None, float(extra_scale),
+                                        1 if reverse else 0, RTOL, ATOL, rows, R, self.ws3k.data_ptr(), self._stream()), "pf_cnf_init")
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.check(self.lib.pf_cnf_steps(ctl.data_ptr(), y.data_ptr(), y1.data_ptr(), f0.data_ptr(), f1.data_ptr(), ctx.data_ptr(),
+                                         e.data_ptr(), self.rec[i].data_ptr(), out.data_ptr(), RTOL, ATOL, rows, R, int(attempts),
+                                         self.ws1k.data_ptr(), self.split[i], self._stream()), "pf_cnf_steps")
+        b.record()
+        torch.cuda.synchronize()
+        st = ctl.cpu()
+        return a.elapsed_time(b), int(st[6]) + int(st[7]), bool(st[5] != 0)
+
     def check_logs(self, n: int, took: List[int]) -> int:
         """The controller states of the first n deferred integrations, ONE device -> host read: how many of them, from the
         first on, finished cleanly inside their attempts.  Their counters are added to the statistics and their attempt counts
@@ -389,8 +415,10 @@ class PointInterpFlow(nn.Module):
         # takes the loop and leaves the counts).
         took: List[int] = [0] * NI
         k0, outs = 0, None
+        ran_blind, enq = False, 0
         if eng.async_attempts > 0 and eng.hint is not None:
             blind = [h + h // 8 + 2 for h in eng.hint]
+            ran_blind, enq = True, sum(blind)
             z, ldj, logp, u, outs = run(True)
             k0 = eng.check_logs(NI, took)
         if k0 < NI:
@@ -399,7 +427,13 @@ class PointInterpFlow(nn.Module):
         old = eng.hint if eng.hint is not None else took
         eng.hint = [max(t, h - 1) for t, h in zip(took, old)]
         x = u.view(B, N * upratio, 3)
-        self.last_stats = dict(nfe=eng.nfe, accepted=eng.accepted, rejected=eng.rejected)
+        # blind: was the forward enqueued without a look at a controller, how many step attempts were enqueued that way against the
+        # attempts the twelve integrations took, and - when an integration did not finish inside its budget - from which
+        # integration on the look-per-batch loop re-integrated (None: the blind forward stands)
+        self.last_stats = dict(nfe=eng.nfe, accepted=eng.accepted, rejected=eng.rejected,
+                               blind=dict(ran=ran_blind, attempts_enqueued=enq, attempts_taken=sum(took),
+                                          fallback_from=(k0 if (ran_blind and k0 < NI) else None)))
+        self.last_took = list(took)
         if stages:
             return dict(idx16=idx16, cs=cs, z=z, ldj=ldj, logp=logp, x=x, **self.last_stats)
         return x, logp

@@ -55,6 +55,32 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(const float* __restri
     }
 }
 
+// The same gradients without float atomics (pf_chamfer_bwd_det): point t's own term, then the terms of the points j of the OTHER
+// cloud whose nearest neighbour is t, found by scanning that cloud's nearest-neighbour map in index order (all lanes read the
+// same word: M broadcast loads per thread, O(N M) per sample - 34 M compares for the training step's 32 x 1024 x 1024) and added
+// in that order: the same sum, one order, run after run.
+//   gx[b,t] += 2 g_own[t] (x_t - y_{idx_own[t]}) - sum_{j: idx_other[j] = t} 2 g_other[j] (y_j - x_t)
+__global__ __launch_bounds__(256) void chamfer_grad_det_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const int* __restrict__ idx_own, const float* __restrict__ g_own,
+                                                              const int* __restrict__ idx_other, const float* __restrict__ g_other,
+                                                              float* __restrict__ gx, int N, int M, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long long b = t / N;
+    const int tl = (int)(t - b * N);
+    const float x0 = x[t * 3], x1 = x[t * 3 + 1], x2 = x[t * 3 + 2];
+    const long long jo = b * M + idx_own[t];
+    const float w = 2.f * g_own[t];
+    float s0 = w * (x0 - y[jo * 3]), s1 = w * (x1 - y[jo * 3 + 1]), s2 = w * (x2 - y[jo * 3 + 2]);
+    for (int j = 0; j < M; ++j)
+        if (idx_other[b * M + j] == tl) {
+            const long long jj = b * M + j;
+            const float w2 = 2.f * g_other[jj];
+            s0 -= w2 * (y[jj * 3] - x0); s1 -= w2 * (y[jj * 3 + 1] - x1); s2 -= w2 * (y[jj * 3 + 2] - x2);
+        }
+    gx[t * 3] += s0; gx[t * 3 + 1] += s1; gx[t * 3 + 2] += s2;
+}
+
 }  // namespace
 
 extern "C" int pf_chamfer_fwd(const float* x, const float* y, int B, int N, int M, float* dist1, int* idx1,
@@ -82,5 +108,16 @@ extern "C" int pf_chamfer_bwd(const float* x, const float* y, const int* idx1, c
                        M, t1);
     hipLaunchKernelGGL(chamfer_grad_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, y, x, idx2, g2, gy, gx, M,
                        N, t2);
+    return pf_last_launch_status();
+}
+// pf_chamfer_bwd without float atomics: bit-reproducible (and O(N M) per sample instead of O(N + M): a debugging switch)
+extern "C" int pf_chamfer_bwd_det(const float* x, const float* y, const int* idx1, const int* idx2, const float* g1,
+                                  const float* g2, float* gx, float* gy, int B, int N, int M, void* stream) {
+    if (!x || !y || !idx1 || !idx2 || !g1 || !g2 || !gx || !gy) return PF_ERR_NULL;
+    if (B <= 0 || N <= 0 || M <= 0) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const long long t1 = (long long)B * N, t2 = (long long)B * M;
+    hipLaunchKernelGGL(chamfer_grad_det_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, x, y, idx1, g1, idx2, g2, gx, N, M, t1);
+    hipLaunchKernelGGL(chamfer_grad_det_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, y, x, idx2, g2, idx1, g1, gy, M, N, t2);
     return pf_last_launch_status();
 }

@@ -10,7 +10,10 @@
 //   * the reference's racy winner selection (float atomicMax by CAS + "within 1e-6, last writer
 //     wins", cu:10-20,188-191) becomes two integer atomics: max of the increment's bit pattern
 //     (increments are > 0, so the bits order like the floats), then max of the bidder index among
-//     exact-maximum bidders.  Deterministic; rules stated in oracle/emd_ref.py.
+//     exact-maximum bidders.  Deterministic PER KERNEL: the same (x, y) give the same assignment, bit for bit (rules stated in
+//     oracle/emd_ref.py).  The training STEP around it is bit-reproducible only under cfg.deterministic (PF_TRAIN_DETERMINISTIC:
+//     BatchNorm statistics as exact sums, ordered gathers instead of float atomics) - in the default mode x itself varies by
+//     ~1e-7 from run to run, and a discrete assignment turns that into different matchings.
 //
 // Arithmetic follows the reference text: value = float((3.0 - (double)sqrtf(d2)) - (double)price)
 // (the literal 3.0 in cu:146 is a double), d2 unfused fp32.

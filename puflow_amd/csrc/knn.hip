@@ -829,8 +829,7 @@ static void launch_knn5(const float* p1, const float* p2, int B, int N, int M, i
     const size_t lds = (size_t)Mpad * 16 + (size_t)NW * KNN5_WB;
     const dim3 g5((N + 16 * NW - 1) / (16 * NW), B);
 #define PF_KNN5_LAUNCH(W)                                                                                                 \
-    do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn5_kernel<K, W>),                                      \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+    do { pf_allow_lds(reinterpret_cast<const void*>(knn5_kernel<K, W>), lds);                                            \
          hipLaunchKernelGGL((knn5_kernel<K, W>), g5, dim3(W * 64), lds, s, p1, p2, N, M, Mpad, idx_out, dist_out); } while (0)
     if (NW == 16) PF_KNN5_LAUNCH(16); else if (NW == 8) PF_KNN5_LAUNCH(8); else PF_KNN5_LAUNCH(4);
 #undef PF_KNN5_LAUNCH

@@ -612,9 +612,7 @@ extern "C" int pf_knn_large(const float* ref, const float* query, int B, int N, 
         while (kp < K) kp <<= 1;
     }
     const size_t lds = (size_t)np * 8;
-    if (lds > 64 * 1024)        // idempotent opt-in to > 64 KiB of dynamic LDS (no state kept on our side)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            KS_NMAX * 8);
+    pf_allow_lds(reinterpret_cast<const void*>(knn_sort_kernel), lds);
     hipLaunchKernelGGL(knn_sort_kernel, dim3(M, B), dim3(KS_T), lds, (hipStream_t)stream, ref, query, N, M, K, np, kp,
                        idx_out, dist_out);
     return pf_last_launch_status();

@@ -7,3 +7,24 @@ static inline int pf_last_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PF_OK : PF_ERR_LAUNCH;
 }
+
+// Dynamic LDS above 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel.  Set ONCE per (device, kernel) to the
+// largest size any launcher of this library asks for (150 KiB: every launcher checks its own request against it), behind a
+// mutex: a per-launch set with the launch's own size let two host threads interleave set(small) between another thread's
+// set(large) and its launch, cost a driver call on every launch of the 1 ms paths and ran inside graph captures.
+#include <mutex>
+#include <utility>
+#include <vector>
+constexpr size_t PF_LDS_CAP = 150 * 1024;
+static inline void pf_allow_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return;
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void*>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& d : done)
+        if (d.first == dev && d.second == kernel) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes > PF_LDS_CAP ? bytes : PF_LDS_CAP));
+    done.emplace_back(dev, kernel);
+}

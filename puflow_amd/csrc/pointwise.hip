@@ -309,8 +309,7 @@ __global__ __launch_bounds__(COND_NW * 64) void cond_all_kernel(CondAllArgs g) {
 
 template <class KERNEL>
 void cond_allow_lds(KERNEL k, int bytes) {
-    if (bytes > 64 * 1024)       // idempotent opt-in to > 64 KiB of dynamic LDS (no state kept on our side)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    pf_allow_lds(reinterpret_cast<const void*>(k), (size_t)bytes);
 }
 
 // the five LDS-resident matrices of a unit back to back in the blob, in LDS order?  (fragment pair = 512 floats)

@@ -74,11 +74,28 @@ struct StatFin {
                                       // defer[0 .. ncol) / defer[STAT_W ..] and the local row count in defer[2 STAT_W] (mode 2: dbeta /
                                       // dgamma are written from the local sums, as torch.nn.SyncBatchNorm does); the host all-reduces
                                       // the 2 STAT_W + 1 doubles over the ranks and stat_finalize_kernel finishes with the global sums
+    int det;                          // PF_TRAIN_DETERMINISTIC: the accumulators hold 64-bit FIXED-POINT sums (quantum 2^-28) added with
+                                      // integer atomics - exact, so independent of the order in which the workgroups arrive; the
+                                      // default (double atomics) rounds in arrival order once a sum needs more than 53 bits
 };
 
 constexpr int STAT_COPIES = 16;       // workgroups spread their atomics over this many accumulator sets (same-address atomics serialise)
 constexpr int STAT_W = 128;           // statistics columns per launch (EdgeConv layers use <= 32, the BatchNorm MLPs up to 128)
 constexpr int STAT_DOUBLES = STAT_COPIES * 2 * STAT_W + 1;
+// deterministic accumulation (StatFin::det): a workgroup's float partial as a multiple of 2^-28 in a 64-bit integer (|sum| < 3.4e10);
+// the same 8-byte accumulator words, zero in either reading
+#define PF_DET(p) (((p)->flags & PF_TRAIN_DETERMINISTIC) ? 1 : 0)
+constexpr double STAT_FIX = 268435456.0, STAT_FIX_INV = 1.0 / 268435456.0;
+__device__ __forceinline__ void stat_add(double* acc, float v, int det) {
+    if (det) atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)__double2ll_rn((double)v * STAT_FIX));
+    else unsafeAtomicAdd(acc, (double)v);
+}
+__device__ __forceinline__ double stat_load(const double* acc, int det) {
+    if (det)
+        return (double)(long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) *
+               STAT_FIX_INV;
+    return __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // sums of one column -> the layer's constants.  R: rows the sums run over (the GLOBAL count under SyncBN); param_grads: mode 2
 // also writes dbeta / dgamma from these sums (not under SyncBN: there they are the LOCAL sums, written by stat_flush)
@@ -129,7 +146,7 @@ __device__ __forceinline__ void stat_flush(float (&s0)[NT], float (&s1)[NT], int
     if ((threadIdx.x & (STAT_W - 1)) < ncol) {                        // 256 threads = 2 x STAT_W sums
         const int t = threadIdx.x;
         const float v = (red[t] + red[2 * STAT_W + t]) + (red[4 * STAT_W + t] + red[6 * STAT_W + t]);
-        unsafeAtomicAdd(f.acc + (blockIdx.x % STAT_COPIES) * 2 * STAT_W + t, (double)v);
+        stat_add(f.acc + (blockIdx.x % STAT_COPIES) * 2 * STAT_W + t, v, f.det);
     }
     // order the accumulator atomics before the arrival count WITHOUT a release fence: a device-scope fence writes the whole
     // L2 back on this multi-die part (tens of microseconds per launch); the atomics themselves are performed at the coherent
@@ -144,8 +161,8 @@ __device__ __forceinline__ void stat_flush(float (&s0)[NT], float (&s1)[NT], int
     if (c < ncol) {
         double a0 = 0.0, a1 = 0.0;
         for (int k = 0; k < STAT_COPIES; ++k) {
-            a0 += __hip_atomic_load(f.acc + k * 2 * STAT_W + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a1 += __hip_atomic_load(f.acc + k * 2 * STAT_W + STAT_W + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a0 += stat_load(f.acc + k * 2 * STAT_W + c, f.det);          // (16 multiples of 2^-28: exact in double, any order)
+            a1 += stat_load(f.acc + k * 2 * STAT_W + STAT_W + c, f.det);
             f.acc[k * 2 * STAT_W + c] = 0.0; f.acc[k * 2 * STAT_W + STAT_W + c] = 0.0;
         }
         if (f.defer) {                                                // SyncBN: local sums out, the layer is finished after the all-reduce
@@ -1837,6 +1854,19 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int* idx, int N, in
         edge[atomicAdd(cursor + (i / N) * N + idx[e], 1)] = (int)e;
     }
 }
+// the fill above hands out a list's slots in arrival order: sort every list (edge ids ascending) so that whatever is summed over it
+// - the dQ gather of the EdgeConv backward, the latent's gradient, the Chamfer gradient - adds in ONE order, run after run
+__global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ off, int* __restrict__ edge, int T) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= T) return;
+    const int lo = off[j], hi = off[j + 1];
+    for (int a = lo + 1; a < hi; ++a) {
+        const int v = edge[a];
+        int b = a - 1;
+        while (b >= lo && edge[b] > v) { edge[b + 1] = edge[b]; --b; }
+        edge[b + 1] = v;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ growth-weight gradients
 // part[chunk][c][u] = sum over the chunk's edges of dYfull[e, c] * lrelu(bn(Y[e, u])), c < S (growth layers then conv_out),
@@ -2189,6 +2219,151 @@ __global__ __launch_bounds__(512) void ec_dw3_kernel(EcDw2Args g2) {
             }
 }
 
+// Round 5: the same jobs with the B operand - act(Y), the SAME for all eight row strips - staged ONCE per workgroup.
+// ec_dw3_kernel lets every wave load and convert its own copy: 32 of its 40 four-byte loads per 16-edge step and, worse, 224 of
+// its 264 vector instructions per step (BatchNorm + LeakyReLU + the bf16 split of 32 values per lane) were identical work in
+// eight waves - the kernel ran at the VALU rate (~30 us of its 57 per 128-channel unit), not at the matrix or memory rate.
+// Here a stage = 64 edges: every thread fetches two (column, 8-edge) runs of Y, applies the activation, splits them and writes
+// the two ready-made B fragments (hi | mid, 16 bytes each) into LDS in MFMA operand order; a wave then reads its nct tiles'
+// fragments with ds_read_b128 and keeps only its own A operand (dy rows) private.  Two LDS buffers, one barrier per stage, the
+// next stage's Y in registers during the MFMAs.  Same values, same split, same product order per tile: partials are bit for
+// bit those of ec_dw3_kernel.
+// MEASURED NEGATIVE (round 5, same box, rocprofv3 per-step sums over the 7 units): 513 us against ec_dw3_kernel's 400 us, the
+// step 4.60 against 4.51 ms - the per-stage barrier and the LDS round trip cost more than the eight-fold conversion saves; the
+// kernel is kept for the A/B only (-DPF_EC_DW4=1).
+#ifndef PF_EC_DW4
+#define PF_EC_DW4 0
+#endif
+constexpr int DW4_SE = 64;                                    // edges per stage
+#if PF_EC_DW4
+__global__ __launch_bounds__(512) void ec_dw4_kernel(EcDw2Args g2) {
+    const EcDwArgs& a = g2.d;
+    extern __shared__ __attribute__((aligned(16))) uint4 dw4_lds[];        // [2 buffers][4 steps][NCT tiles][hi | mid][64 lanes]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+    const int NCT = a.GT / 32;
+    const bool has_job = wave < g2.njob;
+    const EcDw2Job jb = g2.job[has_job ? wave : 0];
+    const int nct = has_job ? jb.nct : 0;
+    const int e_lo = blockIdx.x * a.chunk, e_hi = min((int)a.E, e_lo + a.chunk);      // multiples of 16
+    const int crow = jb.rt * 32 + col;
+    const bool outj = jb.out != 0;
+    // ---- staging role: unit u = (edge group of 8, column); this thread's units u = tid, tid + 512
+    const int nunit = 8 * a.GT;                               // per stage
+    int ucol[2], ueg[2];
+    bool uok[2];
+    float usc[2], ush[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = threadIdx.x + 512 * i;
+        uok[i] = u < nunit;
+        ueg[i] = uok[i] ? u / a.GT : 0;
+        ucol[i] = uok[i] ? u - ueg[i] * a.GT : 0;
+        usc[i] = a.aff[ucol[i]];
+        ush[i] = a.aff[a.ld + ucol[i]];
+    }
+    float yb[2][8];
+    auto fetch_b = [&](int e0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = e0 + 8 * ueg[i] + j;
+                const bool ok = uok[i] && e < e_hi;
+                const float v = a.Y[(size_t)(ok ? e : e_lo) * a.ld + ucol[i]];
+                yb[i][j] = ok ? v : 0.f;
+            }
+    };
+    auto stash_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!uok[i]) continue;
+            float bv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float z = fmaf(yb[i][j], usc[i], ush[i]);
+                bv[j] = fmaxf(z, z * a.slope);
+            }
+            const Bf2 B = dw3_split(bv);
+            const int step = ueg[i] >> 1, hh = ueg[i] & 1, t = ucol[i] >> 5, ln = (ucol[i] & 31) + 32 * hh;
+            uint4* dst = dw4_lds + (((size_t)buf * 4 + step) * NCT + t) * 2 * 64 + ln;
+            dst[0] = __builtin_bit_cast(uint4, B.hi);
+            dst[64] = __builtin_bit_cast(uint4, B.mid);
+        }
+    };
+    f16v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float asum = 0.f;
+    float an[8];
+    auto fetch_a = [&](int e0) {
+        if (outj && a.pooled) {
+            const int ii = e0 >> 4;
+            const float dv = a.dh[(size_t)ii * a.odim + crow];
+            const int kk = a.arg[(size_t)ii * a.odim + crow];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) an[j] = (8 * h + j == kk) ? dv : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const size_t e = (size_t)(e0 + 8 * h + j);
+                an[j] = outj ? a.dyout[e * a.odim + crow] : a.dY[e * a.ld + crow];
+            }
+        }
+    };
+    if (e_lo < e_hi) {
+        fetch_b(e_lo);
+        if (has_job) fetch_a(e_lo);
+        stash_b(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int s0 = e_lo; s0 < e_hi; s0 += DW4_SE) {
+        const bool more = s0 + DW4_SE < e_hi;
+        if (more) fetch_b(s0 + DW4_SE);
+        if (has_job) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int e0 = s0 + 16 * st;
+                if (e0 >= e_hi) break;
+                float ac[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ac[j] = an[j]; asum += an[j]; }
+                if (e0 + 16 < e_hi) fetch_a(e0 + 16);
+                const Bf2 A = dw3_split(ac);
+                const uint4* src = dw4_lds + (((size_t)buf * 4 + st) * NCT) * 2 * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t < nct) {
+                        const bf8 bh = __builtin_bit_cast(bf8, src[(t * 2 + 0) * 64]), bm = __builtin_bit_cast(bf8, src[(t * 2 + 1) * 64]);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.mid, bh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, bm, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, bh, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) stash_b(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (!has_job) return;
+    const int rowbase = outj ? a.GT : 0;
+    asum += __shfl_xor(asum, 32);
+    if (h == 0) a.bpart[(size_t)blockIdx.x * a.S + rowbase + crow] = asum;
+    float* out = a.part + ((size_t)blockIdx.x * a.S + rowbase + jb.rt * 32) * a.GT;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (t < nct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)ri * a.GT + t * 32 + col] = acc[t][r];
+            }
+}
+#endif
+
 // dWpq [R, C] = dPQ^T x for a unit whose input has C <= 4 channels (the first unit: the coordinates): one thread per output row
 // r, a chunk of points per workgroup, partial sums as split-K slabs for the reduction kernel of the point GEMMs.  The general
 // GEMM takes its scalar staging path for these shapes (C is not a multiple of 4): 69 us for 2.4 M products.
@@ -2309,8 +2484,7 @@ __global__ __launch_bounds__(256) void ec_zero_kernel(f4* p, long long n4) {
 
 template <typename KERNEL>
 void allow_lds(KERNEL k, size_t bytes) {
-    if (bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    pf_allow_lds(reinterpret_cast<const void*>(k), bytes);
 }
 
 // SyncBN on the fused kernels: after a launch whose StatFin defers (the local sums sit in fin.defer), the caller's callback
@@ -2389,21 +2563,29 @@ size_t ecp_lds_bytes() {
     for (int t = 1; t < 4; ++t) fl += (size_t)((G + 15) / 16) * 16 * (((G * t + 15) & ~15) + 4);
     return fl * sizeof(float) + (size_t)(ODIM / 16) * (G * 4 / 32) * 2 * 64 * 16;
 }
+// (the occupancy answers are cached per device: the queries ran on every call of the 1 ms step and inside graph captures - ADVICE r4)
+constexpr int ECP_MAXDEV = 16;
 template <int G, int ODIM>
 int ecp_capacity() {
-    const size_t lds = ecp_lds_bytes<G, ODIM>();
-    allow_lds(ec_fwdp_kernel<G, 4, ODIM>, lds);
+    static int cache[ECP_MAXDEV];                   // 0 = not asked yet, -1 = does not fit, > 0 = workgroups that can be resident
+    static std::mutex mu;
     int ncu = 0, dev = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < ECP_MAXDEV && cache[dev] != 0) return cache[dev] > 0 ? cache[dev] : 0;
+    const size_t lds = ecp_lds_bytes<G, ODIM>();
+    allow_lds(ec_fwdp_kernel<G, 4, ODIM>, lds);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ec_fwdp_kernel<G, 4, ODIM>, ECP_T, lds) != hipSuccess) {
-        (void)hipGetLastError();
-        return 0;
-    }
-    return per_cu >= 1 ? ncu : 0;                  // one workgroup per CU at most: each wants most of a CU's registers
+    int cap = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ec_fwdp_kernel<G, 4, ODIM>, ECP_T, lds) != hipSuccess) (void)hipGetLastError();
+    else cap = per_cu >= 1 ? ncu : 0;              // one workgroup per CU at most: each wants most of a CU's registers
+    if (dev >= 0 && dev < ECP_MAXDEV) cache[dev] = cap > 0 ? cap : -1;
+    return cap;
 }
 bool ec_persistent_ok(const PfEcTrain* p, const Dims& d) {
-    if (!(p->flags & PF_EC_PERSISTENT) || !p->sync || !p->pooling || p->K != 16 || p->nconv != 4 || p->sync_sums) return false;
+    if (!(p->flags & PF_EC_PERSISTENT) || (p->flags & PF_TRAIN_DETERMINISTIC) || !p->sync || !p->pooling || p->K != 16 || p->nconv != 4 ||
+        p->sync_sums)
+        return false;
     int cap = 0;
     if (p->growth == 8 && p->odim == 32) cap = ecp_capacity<8, 32>();
     else if (p->growth == 16 && p->odim == 64) cap = ecp_capacity<16, 64>();
@@ -2422,14 +2604,19 @@ size_t ecpb_lds_bytes() {
 }
 template <int G, int ODIM>
 bool ecpb_fits() {
+    static int cache[ECP_MAXDEV];                   // 0 = not asked yet, 1 = fits, -1 = does not
+    static std::mutex mu;
+    int dev = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < ECP_MAXDEV && cache[dev] != 0) return cache[dev] > 0;
     const size_t lds = ecpb_lds_bytes<G, ODIM>();
     allow_lds(ec_bwdp_kernel<G, 4, ODIM>, lds);
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ec_bwdp_kernel<G, 4, ODIM>, ECP_T, lds) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return per_cu >= 1;
+    bool fits = false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ec_bwdp_kernel<G, 4, ODIM>, ECP_T, lds) != hipSuccess) (void)hipGetLastError();
+    else fits = per_cu >= 1;
+    if (dev >= 0 && dev < ECP_MAXDEV) cache[dev] = fits ? 1 : -1;
+    return fits;
 }
 bool ec_bwd_persistent_fits(const PfEcTrain* p) {
     return p->growth == 8 ? ecpb_fits<8, 32>() : (p->growth == 16 ? ecpb_fits<16, 64>() : ecpb_fits<32, 128>());
@@ -2498,6 +2685,7 @@ extern "C" int pf_knn_csr(const int* idx, int B, int N, int K, int* off, int* ed
     hipLaunchKernelGGL(csr_count_kernel, dim3(g), dim3(256), 0, s, idx, N, K, E, cnt);
     hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, T, off);
     hipLaunchKernelGGL(csr_fill_kernel, dim3(g), dim3(256), 0, s, idx, N, K, E, cnt, edge);
+    hipLaunchKernelGGL(csr_sort_kernel, dim3((T + 255) / 256), dim3(256), 0, s, off, edge, T);
     return pf_last_launch_status();
 }
 
@@ -2529,6 +2717,7 @@ extern "C" int pf_ec_train_fwd(const PfEcTrain* p, void* stream) {
         a.kin = g * t; a.col0 = g * t; a.nout = g;
         a.fin = StatFin{p->stat, 1, g, g * t, d.GT, p->aff, p->gamma[t], p->beta[t], p->run_mean[t], p->run_var[t], p->eps,
                         p->momentum, nullptr, nullptr, nullptr, (double)d.E, p->sync_sums};
+        a.fin.det = PF_DET(p);
         const int kin16 = (a.kin + 15) & ~15;
         const int nt = g > 16 ? 2 : 1;
         const size_t lds = sizeof(float) * ((size_t)nt * 16 * (kin16 + 4) + 2 * kin16);
@@ -2604,6 +2793,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         a.s = sl; a.nc = nc; a.g = g; a.ntiles = d.ntiles; a.slope = p->slope;
         a.fin = StatFin{p->stat, 2, g, g * sl, d.GT, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, p->coef,
                         p->dgamma[sl], p->dbeta[sl], (double)d.E, p->sync_sums};
+        a.fin.det = PF_DET(p);
         const int g16 = (g + 15) & ~15, od16 = (p->odim + 15) & ~15, ntg = g16 / 16;
 #ifdef PF_EC_BWDG_F32
         const size_t lds = sizeof(float) * ((size_t)ntg * 16 * ((od16 + 4) + (size_t)(nc - 1 - sl) * (g16 + 4)) + 6 * g16);
@@ -2633,6 +2823,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         a.sc0 = g * (nc - 1); a.sg = g; a.ntiles = d.ntiles; a.slope = p->slope;
         a.fin = StatFin{p->stat, 2, g, g * (nc - 1), d.GT, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, p->coef,
                         p->dgamma[nc - 1], p->dbeta[nc - 1], (double)d.E};
+        a.fin.det = PF_DET(p);
         const int nt = d.GT / 16 <= 2 ? 2 : (d.GT / 16 <= 4 ? 4 : 8);
         const size_t lds = sizeof(float) * ((size_t)nt * 16 * (((p->odim + 15) & ~15) + 4));
 #define PF_ECB(NT, SRC)                                                                                                   \
@@ -2649,6 +2840,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         a.sc0 = g * (t - 1); a.sg = g; a.ntiles = d.ntiles; a.slope = p->slope;
         a.fin = StatFin{p->stat, 2, g, g * (t - 1), d.GT, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, p->coef,
                         p->dgamma[t - 1], p->dbeta[t - 1], (double)d.E};
+        a.fin.det = PF_DET(p);
         const int nt16 = (a.nout + 15) / 16;
         const int nt = nt16 <= 1 ? 1 : (nt16 <= 2 ? 2 : (nt16 <= 4 ? 4 : 8));
         const int kin16 = (g + 15) & ~15;
@@ -2701,14 +2893,19 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
 #ifdef PF_EC_DW_F32
             hipLaunchKernelGGL(ec_dw2_kernel, dim3(d.nchunk), dim3(64 * nj), 0, s, a2);
 #else
-            hipLaunchKernelGGL(ec_dw3_kernel, dim3(d.nchunk), dim3(64 * nj), 0, s, a2);
+#if PF_EC_DW4
+            if (EC_DW_CHUNK % DW4_SE == 0) {
+                const size_t lds = (size_t)2 * 4 * (d.GT / 32) * 2 * 64 * 16;
+                allow_lds(ec_dw4_kernel, lds);
+                hipLaunchKernelGGL(ec_dw4_kernel, dim3(d.nchunk), dim3(512), lds, s, a2);
+            } else
+#endif
+                hipLaunchKernelGGL(ec_dw3_kernel, dim3(d.nchunk), dim3(64 * nj), 0, s, a2);
 #endif
         } else {
             const int ramax = p->odim > d.GT ? p->odim : d.GT;
             const size_t lds = sizeof(float) * (size_t)DW_EB * ((ramax + 16) + (d.GT + 16));
-            if (lds > 64 * 1024)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ec_dw_kernel<EC_DW_WAVES>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            pf_allow_lds(reinterpret_cast<const void*>(ec_dw_kernel<EC_DW_WAVES>), lds);
             hipLaunchKernelGGL(ec_dw_kernel<EC_DW_WAVES>, dim3(d.nchunk, 2), dim3(64 * EC_DW_WAVES), lds, s, a);
         }
     }
@@ -3224,6 +3421,7 @@ extern "C" int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream) {
         a.slope = p->slope; a.out = p->y[l]; a.nout = p->width[l]; a.rows = p->rows; a.ntiles = ntiles;
         if (bn) a.fin = StatFin{p->stat, 1, p->width[l], 0, p->width[l], p->aff[l], p->gamma[l], p->beta[l], p->run_mean[l],
                                 p->run_var[l], p->eps, p->momentum, nullptr, nullptr, nullptr, (double)p->rows, p->sync_sums};
+        if (bn) a.fin.det = PF_DET(p);
         if (l == 0) {
             a.X = p->xa; a.ldx = p->kin0a; a.kin = p->kin0a; a.W = p->W[0]; a.ldw = in0; a.bias = p->b[0];
             a.want_stats = bn && p->kin0b == 0;
@@ -3283,6 +3481,7 @@ extern "C" int pf_bnmlp_train_bwd(const PfBnMlpTrain* p, void* stream) {
             a.xpre = p->y[l - 1]; a.aff_prev = p->aff[l - 1]; a.want_stats = 1;
             a.fin = StatFin{p->stat, 2, p->width[l - 1], 0, p->width[l - 1], nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f,
                             p->coef[l - 1], p->dgamma[l - 1], p->dbeta[l - 1], (double)p->rows, p->sync_sums};
+            a.fin.det = PF_DET(p);
             bnl_bwd_dispatch(a, bn ? 2 : 1, grid, s);
             if ((st = stat_sync(a.fin, p->width[l - 1], p->sync_cb, p->sync_user, s))) return st;   // SyncBN: global sums of layer l - 1
             dw(dyl, p->width[l], p->y[l - 1], p->width[l - 1], p->width[l - 1], p->aff[l - 1], p->aff[l - 1] + p->width[l - 1],

@@ -76,8 +76,30 @@ __global__ __launch_bounds__(256) void interp_wsum_bwd_kernel(const float* __res
         g0s += ak * g0; g1s += ak * g1; g2s += ak * g2;
     }
     for (int r = R; r < ldw; ++r) dw[tk * ldw + r] = 0.f;
+    if (!dz) return;                                             // deterministic form: interp_dz_gather_kernel below
     float* dp = dz + (base + j) * 3;
     atomicAdd(dp, g0s); atomicAdd(dp + 1, g1s); atomicAdd(dp + 2, g2s);
+}
+// dz without float atomics: one thread per point j walks the (sorted) list of the (point t, neighbour k) pairs that point AT j
+// (pf_knn_csr of the interpolation's neighbour lists: edge id = t 8 + k) and adds sum_r a du in list order - the same sum, one
+// order, run after run
+__global__ __launch_bounds__(256) void interp_dz_gather_kernel(const float* __restrict__ a, const float* __restrict__ du,
+                                                              const int* __restrict__ off, const int* __restrict__ edge, int R,
+                                                              long long T, float* __restrict__ dz) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= T) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int q = off[j]; q < off[j + 1]; ++q) {
+        const long long tk = edge[q], t = tk / IW_K;
+        float g0s = 0.f, g1s = 0.f, g2s = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float* gp = du + (t * R + r) * 3;
+            const float ak = a[tk * R + r];
+            g0s += ak * gp[0]; g1s += ak * gp[1]; g2s += ak * gp[2];
+        }
+        s0 += g0s; s1 += g1s; s2 += g2s;
+    }
+    dz[j * 3 + 0] = s0; dz[j * 3 + 1] = s1; dz[j * 3 + 2] = s2;
 }
 __global__ __launch_bounds__(256) void glue_zero_kernel(float* p, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0.f;
@@ -163,11 +185,21 @@ extern "C" int pf_interp_wsum_fwd(const float* w, int ldw, const float* z, const
 // du [T R, 3] -> dw [T, 8, ldw], dz [B N, 3] (zero-filled here, then accumulated)
 extern "C" int pf_interp_wsum_bwd(const float* a, const float* z, const int* idx, const float* du, int N, int K, int R, int ldw,
                                   long long T, float* dw, float* dz, void* stream) {
+    return pf_interp_wsum_bwd_det(a, z, idx, du, N, K, R, ldw, T, dw, dz, nullptr, nullptr, stream);
+}
+// csr_off / csr_edge (pf_knn_csr of idx, both or neither): dz as a gather in a fixed order instead of float atomics
+extern "C" int pf_interp_wsum_bwd_det(const float* a, const float* z, const int* idx, const float* du, int N, int K, int R, int ldw,
+                                      long long T, float* dw, float* dz, const int* csr_off, const int* csr_edge, void* stream) {
     if (!a || !z || !idx || !du || !dw || !dz) return PF_ERR_NULL;
     if (K != IW_K || R <= 0 || R > IW_RMAX || R > ldw || T <= 0 || N <= 0 || T % N != 0) return PF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(glue_zero_kernel, dim3(glue_grid(T * 3)), dim3(256), 0, (hipStream_t)stream, dz, T * 3);
+    if ((csr_off == nullptr) != (csr_edge == nullptr)) return PF_ERR_NULL;
+    const bool det = csr_off != nullptr;
+    if (!det) hipLaunchKernelGGL(glue_zero_kernel, dim3(glue_grid(T * 3)), dim3(256), 0, (hipStream_t)stream, dz, T * 3);
     hipLaunchKernelGGL(interp_wsum_bwd_kernel, dim3((unsigned)((T * IW_K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, z,
-                       idx, du, N, R, ldw, T, dw, dz);
+                       idx, du, N, R, ldw, T, dw, det ? (float*)nullptr : dz);
+    if (det)
+        hipLaunchKernelGGL(interp_dz_gather_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, du, csr_off,
+                           csr_edge, R, T, dz);
     return pf_last_launch_status();
 }
 

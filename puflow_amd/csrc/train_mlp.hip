@@ -603,8 +603,7 @@ __global__ __launch_bounds__(256) void mlp_desc_upload_kernel(MlpBatch b, unsign
 
 template <typename KERNEL>
 void allow_lds(KERNEL k, size_t bytes) {
-    if (bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    pf_allow_lds(reinterpret_cast<const void*>(k), bytes);
 }
 
 int mlp_check(const PfMlpTrain* p) {

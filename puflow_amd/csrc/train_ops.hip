@@ -338,13 +338,7 @@ void gemm2_launch(const GemmArgs& g, int split, hipStream_t s) {
     constexpr int LDA = BM % 32 == 0 ? BM + 16 : BM + 32, LDB = BN % 32 == 0 ? BN + 16 : BN + 32;
     constexpr int loop_floats = 2 * 32 * (LDA + LDB), out_floats = BM * (BN + 4);
     constexpr size_t lds = sizeof(float) * (size_t)(loop_floats > out_floats ? loop_floats : out_floats);
-    static const bool once = [] {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<WAVES_M, WAVES_N, TM, TN>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        return true;
-    }();
-    (void)once;
+    pf_allow_lds(reinterpret_cast<const void*>(gemm2_kernel<WAVES_M, WAVES_N, TM, TN>), lds);
     auto al16 = [](const void* p) { return (reinterpret_cast<unsigned long long>(p) & 15ull) == 0; };
     const long long ldc = g.ldc;
     const int cvec = (ldc % 4 == 0) && al16(g.C) && (!g.bias || al16(g.bias)) && (((long long)g.M * ldc) % 4 == 0);
@@ -1143,6 +1137,26 @@ extern "C" int pf_scatter_rows(const float* g, const int* idx, int B, int N, int
     if (B <= 0 || N <= 0 || K <= 0 || C <= 0) return PF_ERR_SHAPE;
     const long long total = (long long)B * N * K * C;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, idx, N, K, C, total, out);
+    return pf_last_launch_status();
+}
+
+// the same sum as a gather over the transposed lists (pf_knn_csr of idx, lists sorted): one order, run after run - the
+// deterministic form (PF_TRAIN_DETERMINISTIC) of the un-fused latent gather's backward
+__global__ __launch_bounds__(256) void scatter_rows_det_kernel(const float* __restrict__ g, const int* __restrict__ off,
+                                                              const int* __restrict__ edge, int C, long long total,
+                                                              float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long long j = t / C;
+    const int c = (int)(t - j * C);
+    float s = 0.f;
+    for (int q = off[j]; q < off[j + 1]; ++q) s += g[(long long)edge[q] * C + c];
+    out[t] = s;
+}
+extern "C" int pf_scatter_rows_det(const float* g, const int* csr_off, const int* csr_edge, long long T, int C, float* out, void* stream) {
+    if (!g || !csr_off || !csr_edge || !out) return PF_ERR_NULL;
+    if (T <= 0 || C <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(scatter_rows_det_kernel, dim3((unsigned)((T * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, csr_off, csr_edge, C, T * C, out);
     return pf_last_launch_status();
 }
 

@@ -182,7 +182,7 @@ class PuganLossFn(Function):
                                          w_cd, seeds[0].data_ptr(), seeds[1].data_ptr(), seeds[2].data_ptr(), dlogp.data_ptr(),
                                          gx.data_ptr(), gy.data_ptr(), ops._stream()), "pf_pugan_loss_bwd")
         if w_cd != 0.0:
-            _lib.check(lib.pf_chamfer_bwd(pred.data_ptr(), gt.data_ptr(), i1.data_ptr(), i2.data_ptr(), seeds[1].data_ptr(),
+            _lib.check(ops._chamfer_bwd(lib)(pred.data_ptr(), gt.data_ptr(), i1.data_ptr(), i2.data_ptr(), seeds[1].data_ptr(),
                                           seeds[2].data_ptr(), gx.data_ptr(), gy.data_ptr(), B, n, n, ops._stream()), "pf_chamfer_bwd")
         _lib.check(lib.pf_emd_backward(pred.data_ptr(), gt.data_ptr(), gx.data_ptr(), seeds[0].data_ptr(), assign2[0].data_ptr(),
                                        B, n, ops._stream()), "pf_emd_backward")

@@ -41,6 +41,12 @@ def knn_idx32(p1: torch.Tensor, p2: torch.Tensor, K: int, want_dist: bool = Fals
     return idx, dist
 
 
+def _chamfer_bwd(lib):
+    """pf_chamfer_bwd, or its atomics-free form under train_ops.set_deterministic(True) (a debugging switch)."""
+    from . import train_ops
+    return lib.pf_chamfer_bwd_det if train_ops.deterministic() else lib.pf_chamfer_bwd
+
+
 def knn_points(p1: torch.Tensor, p2: torch.Tensor, K: int, return_nn: bool = False, return_sorted: bool = True,
                **_unused) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """(dists [B,N,K] squared L2, idx [B,N,K] int64, nn or None); always sorted by (dist, idx)."""
@@ -97,7 +103,7 @@ class _ChamferFn(torch.autograd.Function):
         g1 = (gper / N).view(B, 1).expand(B, N).contiguous()
         g2 = (gper / M).view(B, 1).expand(B, M).contiguous()
         gx, gy = torch.zeros_like(x), torch.zeros_like(y)
-        _lib.check(lib.pf_chamfer_bwd(x.data_ptr(), y.data_ptr(), i1.data_ptr(), i2.data_ptr(), g1.data_ptr(),
+        _lib.check(_chamfer_bwd(lib)(x.data_ptr(), y.data_ptr(), i1.data_ptr(), i2.data_ptr(), g1.data_ptr(),
                                       g2.data_ptr(), gx.data_ptr(), gy.data_ptr(), B, N, M, _stream()), "pf_chamfer_bwd")
         return gx, gy
 

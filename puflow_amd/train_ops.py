@@ -316,6 +316,24 @@ def sync_bn(on: bool):
         _SYNC_BN.reset(tok)
 
 
+# Bit-reproducible training steps (debugging switch; VERDICT / ADVICE r4): `net.deterministic = True` (TrainerModule:
+# `cfg.deterministic`).  forward_train copies it here at the start of every train-mode forward and the autograd functions read it
+# when they run (the backward of that forward included): BatchNorm statistics as exact 64-bit fixed-point sums
+# (PF_TRAIN_DETERMINISTIC: csrc/train_fused.hip stat_add; the persistent kernels are not used), the latent's gradient as a gather
+# over the sorted transposed neighbour lists, the Chamfer gradient by pf_chamfer_bwd_det.  Everything else in the fused step is
+# already order-fixed (split-K partials reduced in index order, the dQ gather over the now sorted lists, the auction).
+_DET = False
+
+
+def set_deterministic(on: bool) -> None:
+    global _DET
+    _DET = bool(on)
+
+
+def deterministic() -> bool:
+    return _DET
+
+
 def _multi_rank() -> bool:
     import torch.distributed as dist
     from .dist import multi_rank
@@ -428,6 +446,12 @@ class GatherRowsFn(Function):
         (idx,) = ctx.saved_tensors
         B, N, K, C = ctx.dims
         g = g.contiguous()
+        if _DET:                                              # ordered gather over the sorted transposed lists: no float atomics
+            off, edge = knn_csr(idx.contiguous())
+            dz = torch.empty((B, N, C), dtype=torch.float32, device=g.device)
+            _lib.check(lib.pf_scatter_rows_det(g.data_ptr(), off.data_ptr(), edge.data_ptr(), B * N, C, dz.data_ptr(), _stream()),
+                       "pf_scatter_rows_det")
+            return dz, None
         dz = torch.zeros((B, N, C), dtype=torch.float32, device=g.device)
         _lib.check(lib.pf_scatter_rows(g.data_ptr(), idx.data_ptr(), B, N, K, C, dz.data_ptr(), _stream()), "pf_scatter_rows")
         return dz, None
@@ -487,8 +511,9 @@ class InterpWsumFn(Function):
     backward (csrc/train_glue.hip); replaces GatherRowsFn + SoftmaxWsumFn + a transposing copy."""
 
     @staticmethod
-    def forward(ctx, w, z, idx8, R):
+    def forward(ctx, w, z, idx8, R, csr=None):
         lib = _lib.load()
+        ctx.csr = csr                                          # deterministic mode: (off, edge) of pf_knn_csr(idx8)
         w, z, idx8 = w.contiguous(), z.contiguous(), idx8.contiguous()
         B, N, _ = z.shape
         T, K, ldw = w.shape
@@ -508,9 +533,14 @@ class InterpWsumFn(Function):
         du = du.contiguous()
         dw = torch.empty((T, K, ldw), dtype=torch.float32, device=du.device)
         dz = torch.empty_like(z)
-        _lib.check(lib.pf_interp_wsum_bwd(a.data_ptr(), z.data_ptr(), idx8.data_ptr(), du.data_ptr(), N, K, R, ldw, T, dw.data_ptr(),
-                                          dz.data_ptr(), _stream()), "pf_interp_wsum_bwd")
-        return dw, dz, None, None
+        csr = ctx.csr if _DET else None
+        if csr is not None:                                   # dz as an ordered gather over the sorted transposed lists
+            _lib.check(lib.pf_interp_wsum_bwd_det(a.data_ptr(), z.data_ptr(), idx8.data_ptr(), du.data_ptr(), N, K, R, ldw, T, dw.data_ptr(),
+                                                  dz.data_ptr(), csr[0].data_ptr(), csr[1].data_ptr(), _stream()), "pf_interp_wsum_bwd_det")
+        else:
+            _lib.check(lib.pf_interp_wsum_bwd(a.data_ptr(), z.data_ptr(), idx8.data_ptr(), du.data_ptr(), N, K, R, ldw, T, dw.data_ptr(),
+                                              dz.data_ptr(), _stream()), "pf_interp_wsum_bwd")
+        return dw, dz, None, None, None
 
 
 def _det_inv3(W: Tensor):
@@ -776,8 +806,10 @@ class EdgeConvUnitFn(Function):
         ws = _ws(dev, need)
         d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
         d.stat = _stat(dev).data_ptr()
-        if len(cfg) > 11 and cfg[11]:                         # the whole forward as one persistent launch where the library can
+        if len(cfg) > 11 and cfg[11] and not _DET:            # the whole forward as one persistent launch where the library can
             d.flags, d.sync = 1, _sync_words(dev).data_ptr()
+        if _DET:
+            d.flags |= 2                                      # PF_TRAIN_DETERMINISTIC
         if len(cfg) > 12 and cfg[12]:                         # SyncBN: statistics over all ranks (fixed at forward time: the
             _attach_sync(d, dev)                              # backward runs after the sync_bn() scope has ended)
         _lib.check(lib.pf_ec_train_fwd(ctypes.byref(d), _stream()), "pf_ec_train_fwd")
@@ -827,8 +859,10 @@ class EdgeConvUnitFn(Function):
         csr = cfg[10] if len(cfg) > 10 else None
         if csr is not None:                                   # transposed neighbour lists: dQ as a gather, no float atomics
             d.csr_off, d.csr_edge = csr[0].data_ptr(), csr[1].data_ptr()
-        if len(cfg) > 11 and cfg[11]:                         # the dense block's backward as one persistent launch (see forward)
+        if len(cfg) > 11 and cfg[11] and not _DET:            # the dense block's backward as one persistent launch (see forward)
             d.flags, d.sync = 1, _sync_words(dev).data_ptr()
+        if _DET:
+            d.flags |= 2
         if len(cfg) > 12 and cfg[12]:
             _attach_sync(d, dev)
         _lib.check(lib.pf_ec_train_bwd(ctypes.byref(d), _stream()), "pf_ec_train_bwd")
@@ -1309,6 +1343,7 @@ class BnMlpFn(Function):
             d.gamma[l], d.beta[l], d.aff[l] = gb[2 * l].data_ptr(), gb[2 * l + 1].data_ptr(), affs[l].data_ptr()
             d.run_mean[l], d.run_var[l] = _ptr(rmeans[l]), _ptr(rvars[l])
         d.stat = _stat(dev).data_ptr()
+        d.flags = 2 if _DET else 0
         if len(cfg) > 5 and cfg[5]:
             _attach_sync(d, dev)
         _lib.check(lib.pf_bnmlp_train_fwd(ctypes.byref(d), _stream()), "pf_bnmlp_train_fwd")
@@ -1347,6 +1382,7 @@ class BnMlpFn(Function):
         ws = _ws(dev, need)
         d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
         d.stat = _stat(dev).data_ptr()
+        d.flags = 2 if _DET else 0
         if len(ctx.cfg) > 5 and ctx.cfg[5]:
             _attach_sync(d, dev)
         _lib.check(lib.pf_bnmlp_train_bwd(ctypes.byref(d), _stream()), "pf_bnmlp_train_bwd")
@@ -1651,6 +1687,7 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     """PointInterpFlow.forward in train() mode (interpflow.py:327-337) with gradients."""
     global _NBT_PENDING
     _NBT_PENDING = []
+    set_deterministic(getattr(net, "deterministic", False))
     try:
         with sync_bn(getattr(net, "sync_batchnorm", False)):
             return _forward_train(net, xyz, upratio)
@@ -1711,7 +1748,11 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     for i in range(net.num_blocks):
         # the main chain's units may run as persistent grid-barrier launches: nothing else with a grid barrier runs beside them
         # (the side stream's interpolation unit keeps the per-layer kernels; the EMD auction starts after the forward)
-        h = edgeconv_train(net.feat_convs[i], h, idx16, csr=csr16, persistent=getattr(net, "train_persistent", True))
+        # An explicit opt-in: TrainerModule sets `network.train_persistent` from its configuration (on, unless the
+        # device is shared: cfg.emd_workgroups == 1 / cfg.persistent_kernels = False); a bare PointInterpFlow.train() forward on a
+        # GPU it may share with another process keeps the per-layer kernels - a grid barrier whose workgroups are not all resident
+        # spins for seconds before its bounded time-out makes the output NaN.
+        h = edgeconv_train(net.feat_convs[i], h, idx16, csr=csr16, persistent=getattr(net, "train_persistent", False))
         m = net.merge_convs[i]
         if _FUSED:
             cs.append(mlp_fused(None, h, 0, 1, (0.0,), [m.conv1, m.conv2]).view(B, N, -1))
@@ -1753,7 +1794,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
             for t in (csr16 or ()) + (csr8 or ()):
                 t.record_stream(torch.cuda.current_stream())
         if _GLUE and R <= 8:
-            u = InterpWsumFn.apply(w.view(B * N, 8, -1), z, idx8, R)
+            u = InterpWsumFn.apply(w.view(B * N, 8, -1), z, idx8, R, csr8 if _DET else None)
         else:
             zj = GatherRowsFn.apply(z, idx8)
             fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)

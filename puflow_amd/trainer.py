@@ -28,10 +28,12 @@ except Exception:                        # pragma: no cover - not installed in t
 def default_cfg(**kw):
     # sync_batchnorm: BatchNorm statistics over ALL ranks (an extension: the reference trains on one GPU, where it is
     # the same thing; default False = each rank normalises with its own shard, like DDP without SyncBatchNorm)
+    # deterministic: bit-reproducible training steps (a debugging switch: BatchNorm statistics as exact fixed-point sums, the
+    # remaining float-atomic gradients as ordered gathers; slower - no persistent kernels; train_ops.set_deterministic)
     # persistent_kernels: the training step's grid-barrier kernels (EdgeConv units as one launch each).  None = on, unless
     # emd_workgroups == 1 says the device is shared with other processes (grid barriers need every workgroup resident)
     cfg = dict(net="UpsamplingFlow", learning_rate=1e-3, sched_patience=10, sched_factor=0.5, seed=2021, sync_batchnorm=False,
-               fused_optimizer=True, emd_workgroups=0, persistent_kernels=None)
+               fused_optimizer=True, emd_workgroups=0, persistent_kernels=None, deterministic=False)
     cfg.update(kw)
     return SimpleNamespace(**cfg)
 
@@ -46,6 +48,7 @@ class TrainerModule(_Base):
         self.loss_mix = loss_mix
         self.network = PointInterpFlow(pc_channel=3)
         self.network.sync_batchnorm = bool(getattr(self.cfg, "sync_batchnorm", False))     # an argument of its train-mode forward
+        self.network.deterministic = bool(getattr(self.cfg, "deterministic", False))
         pk = getattr(self.cfg, "persistent_kernels", None)
         self.network.train_persistent = bool(pk) if pk is not None else int(getattr(self.cfg, "emd_workgroups", 0)) != 1
         # cfg.emd_workgroups: workgroups per sample of the EMD auction (0 = chosen from the device, 1 = safe on a GPU that is

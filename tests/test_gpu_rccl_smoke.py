@@ -36,24 +36,27 @@ def test_training_step_over_rccl_one_rank(graph):
 
 
 def test_forced_collectives_do_not_change_the_step():
-    """The forced one-rank path (gradient packing -> RCCL all-reduce -> / world -> clip + Adam) sees the same gradient as the plain
-    single-process path: the global gradient norm of the FIRST step from the same state agrees to the noise of the step's float
-    atomics (a wrong scale, a double reduction or a missed bucket would show at once; losses of LATER steps are not comparable -
-    Adam turns rounding noise into different trajectories within a few updates)."""
+    """The forced one-rank path (gradient packing -> RCCL all-reduce -> / world -> clip + Adam) takes the same steps as the plain
+    single-process path.  Under cfg.deterministic (PF_BENCH_DETERMINISTIC=1: BatchNorm statistics as exact sums, ordered gathers
+    instead of float atomics; PF_BENCH_ACTNORM_INITED=1: no data-dependent ActNorm init, which the two paths run through different
+    kernels) the step is bit-reproducible, so the comparison is made where it means something again: the
+    loss after THREE optimisation steps and the gradient norm of the last one (round 4 had to retreat to the first step's
+    gradient norm - without the switch Adam turns the atomics' rounding noise into different trajectories within a few updates)."""
     recs = []
     for force in ("1", "0"):
         env = _env()
         if force == "0":
             for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PF_BENCH_FORCE_DIST"):
                 env.pop(k)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--steps", "1", "--warmup", "0",
-                              "--no-cpu-baseline", "--no-grad-parity"], cwd=ROOT, env=dict(env, PF_BENCH_GRAPH="0"), capture_output=True,
-                             text=True, timeout=900)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--steps", "3", "--warmup", "0",
+                              "--no-cpu-baseline", "--no-grad-parity"], cwd=ROOT, env=dict(env, PF_BENCH_GRAPH="0", PF_BENCH_DETERMINISTIC="1", PF_BENCH_ACTNORM_INITED="1"),
+                             capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-3000:]
         recs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+    assert recs[0]["config"]["deterministic"] is True
     g0, g1 = recs[0]["grad_norm_last_step"], recs[1]["grad_norm_last_step"]
-    assert g0 > 0 and abs(g0 - g1) <= 1e-4 * g1, (g0, g1)
-    assert abs(recs[0]["loss"] - recs[1]["loss"]) <= 1e-5 * abs(recs[1]["loss"])
+    assert g0 > 0 and abs(g0 - g1) <= 1e-6 * g1, (g0, g1)
+    assert abs(recs[0]["loss"] - recs[1]["loss"]) <= 1e-6 * abs(recs[1]["loss"]), (recs[0]["loss"], recs[1]["loss"])
 
 
 def test_inference_bench_over_rccl_one_rank():
