@@ -112,11 +112,38 @@ def main():
             from puflow_amd.dist import force_collectives
             force_collectives(True)
         backend = os.environ.get("PF_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        rccl_log = None
+        if backend == "nccl" and os.environ.get("PF_BENCH_RCCL_DEBUG", "1") == "1" and args.mode == "infer":
+            # what RCCL says about itself goes to a per-rank file (NCCL_DEBUG_FILE), parsed after the first collective: the line
+            # then carries the transport the rings really use (P2P over xGMI / SHM / NET) instead of an assumption
+            import tempfile
+            rccl_log = os.path.join(tempfile.gettempdir(), f"pf_bench_rccl_{os.environ.get('MASTER_PORT', '0')}_r{rank}.log")
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+            os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)                            # the first collective: creates the communicator, may fail on IPC set-up
+            torch.cuda.synchronize()
+        except Exception as ex:
+            # a fresh child, nothing to retry here: say what to look at and leave (HSA_ENABLE_IPC_MODE_LEGACY=0 is what this
+            # pool's host driver needs for cross-process device-memory sharing; self_launch exports it)
+            print(f"[bench] rank {rank}: process group / first collective failed: {type(ex).__name__}: {str(ex)[:500]}\n"
+                  f"[bench] environment: HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')} "
+                  f"NCCL_DEBUG_FILE={os.environ.get('NCCL_DEBUG_FILE')} backend={backend} world={world} "
+                  "(hipIpcGetMemHandle: invalid argument => the dmabuf IPC mode is not set in THIS process's environment)",
+                  file=sys.stderr, flush=True)
+            raise SystemExit(4)
+        seen = int(round(float(probe.item())))               # ranks that took part in the sum = the communicator's size
+        if seen != args.gpus or dist.get_world_size() != args.gpus:
+            print(f"[bench] the communicator has {seen} rank(s) (torch says {dist.get_world_size()}), --gpus says {args.gpus}", file=sys.stderr)
+            raise SystemExit(3)
         args.collectives = {"backend": dist.get_backend(), "world_size": world, "forced_one_rank_group": world == 1}
+        args.rccl_log = rccl_log
     else:
         args.collectives = None
 
@@ -227,6 +254,12 @@ def main():
     value = patches * passes / el
     el /= passes                                          # per K-step pass from here on (ms_per_step = el / K)
 
+    strong = coll = None
+    if use_dist and args.scaling == "weak":
+        # one invocation, both scalings: the weak-scaling figure above is `value`; the same ranks are re-timed
+        # on a fixed total of 32 patches (the metric's own batch) and 256 (32 per GPU at 8 GPUs)
+        strong = strong_block(args, world, rank, dev, dist, net)
+        coll = collectives_probe(args, world, rank, dev, dist)
     out = None
     if rank == 0:
         # ---- dominant kernel: EdgeConv (units 2..5 share one kernel); live HIP-event timing on the launch stream
@@ -361,12 +394,97 @@ def main():
                           "same 1e-5 bar; PF_EC_MODE=f32 selects the bit-exact f32-MFMA EdgeConv kernels)", "launch": ("hipGraph replay (one launch per step)" + (f", {pipe} steps in flight on {pipe} streams" if pipe > 1 else "")) if use_graph else "eager (18 launches per step)",
                           "patches_per_gpu": args.batch, "total_batch": args.total_batch if args.scaling == "strong" else world * args.batch,
                           "npoint": args.npoint,
-                          "upratio": 4, "sharding": f"patch batch over {world} rank(s), no data-path collective"},
+                          "upratio": 4, "sharding": f"patch batch over {world} rank(s), no data-path collective",
+                          "collectives": args.collectives},
                "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)
+        if strong is not None:
+            out["strong"] = strong
+        if coll is not None and out["config"].get("collectives") is not None:
+            out["config"]["collectives"] = dict(out["config"]["collectives"], **coll)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def collectives_probe(args, world, rank, dev, dist):
+    """What the first multi-GPU run should say about itself: the size of the communicator as the first
+    all-reduce saw it (checked at start-up), the latency of the training step's ONE collective - an all-reduce of the flat
+    806 103-float gradient bucket, 10 timed calls - and, for RCCL, the transports its rings use, parsed from rank 0's
+    NCCL_DEBUG=INFO log.  Every rank runs this (the all-reduces are collective); rank 0 returns the dict."""
+    n = 806103
+    buf = torch.ones(n, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    t = torch.tensor([sorted(ts)[len(ts) // 2], max(ts)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    info = {"communicator_ranks_seen_by_first_all_reduce": args.gpus,
+            "gradient_bucket_all_reduce": {"floats": n, "bytes": 4 * n, "median_us": float(t[0]) * 1e6, "max_us": float(t[1]) * 1e6,
+                                           "calls": 10, "note": "host wall time per call incl. synchronisation, max over ranks"}}
+    log = getattr(args, "rccl_log", None)
+    if rank == 0 and log:
+        tr = {"P2P": 0, "SHM": 0, "NET": 0}
+        other = []
+        try:
+            import glob
+            for fn in glob.glob(log + "*"):
+                for line in open(fn, errors="replace"):
+                    if " via " in line:
+                        for k in tr:
+                            if f"via {k}" in line:
+                                tr[k] += 1
+                    if ("xGMI" in line or "XGMI" in line or "Rings" in line or "nChannels" in line or "RCCL version" in line or
+                            "NCCL version" in line) and len(other) < 6:
+                        other.append(line.strip()[-160:])
+            info["rccl"] = {"channel_connections_by_transport": tr, "log_excerpt": other,
+                            "source": "NCCL_DEBUG=INFO (INIT, GRAPH) of rank 0, NCCL_DEBUG_FILE; P2P = direct peer access (xGMI inside a node)"}
+        except Exception as ex:
+            info["rccl"] = {"failed": f"{type(ex).__name__}: {ex}"[:200]}
+    return info
+
+
+def strong_block(args, world, rank, dev, dist, net, totals=(32, 256)):
+    """The SAME ranks re-timed with a fixed TOTAL batch split over them (contiguous shards, no collective on the data path):
+    one `--gpus N` invocation then yields the weak figure (`value`) and the strong ones.  A rank whose shard is empty only
+    joins the barriers.  Returns {total: {...}} on rank 0."""
+    from puflow_amd.dist import shard_bounds
+    from puflow_amd.weights import synth_patches
+    out = {}
+    for total in totals:
+        lo, hi = shard_bounds(total, rank, world)
+        bs = hi - lo
+        run = xyz_s = None
+        if bs > 0:
+            xyz_s = synth_patches(bs, args.npoint, seed=4000 + total + rank).to(dev)
+            try:
+                run = net.graphed(bs, args.npoint, 4)
+            except Exception:
+                run = lambda inp: net(inp, 4)
+        steps, warm = max(args.steps, 20), max(min(args.warmup, 10), 3)
+        for _ in range(warm):
+            if run is not None:
+                run(xyz_s)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if run is not None:
+                run(xyz_s)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        out[str(total)] = {"total_batch": total, "patches_per_rank": [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)],
+                           "value": total * steps / el, "unit": "patches/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+                           "scaling": "strong"}
+        del run, xyz_s
+    return out
 
 
 def self_launch(n: int) -> int:

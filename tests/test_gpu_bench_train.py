@@ -89,6 +89,11 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["total_batch"] == 8 and rec["value"] > 0
     assert rec["cpu_baseline"] is None                        # N = 1 only
     assert "launching" in out.stderr
+    # the same invocation also carries the strong-scaling figures and the communicator's own account (2 ranks over gloo)
+    assert rec["strong"]["32"]["patches_per_rank"] == [16, 16] and rec["strong"]["256"]["patches_per_rank"] == [128, 128]
+    assert all(v["value"] > 0 for v in rec["strong"].values())
+    col = rec["config"]["collectives"]
+    assert col["world_size"] == 2 and col["communicator_ranks_seen_by_first_all_reduce"] == 2 and col["gradient_bucket_all_reduce"]["median_us"] > 0
     # a launcher environment that disagrees with --gpus is an error, not a mislabeled run
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT,
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
@@ -104,7 +109,11 @@ def test_bench_cnf_line():
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["unit"] == "patches/s" and rec["value"] > 0 and rec["steps"] == 2 and "configs[4]" in rec["config"]["workload"]
     work = rec["config"]["solver_work"]
-    assert work["nfe"] >= 300 and work["rejected"] >= 1            # not the trivial 168-evaluation ODE of random-init weights
+    per = work["per_input_set"]                                    # the timed loop rotates four input sets
+    assert min(per["nfe"]) >= 300 and min(per["rejected"]) >= 1    # not the trivial 168-evaluation ODE of random-init weights
+    bl = work["blind"]
+    assert bl["forwards"] == 2 and bl["attempts_taken"] > 0 and bl["fell_back"] <= bl["ran_blind"] <= bl["forwards"]
+    assert rec["roofline"]["attempts_timed"]["real"] > 0 and "pf_cnf_steps" in rec["roofline"]["kernel"]
     roof, cpu, par = rec["roofline"], rec["cpu_baseline"], rec["parity"]
     assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and cpu["kind"] == "port" and cpu["value"] > 0
     assert par["nfe"][0] == par["nfe"][1] and par["accepted"][0] == par["accepted"][1] and par["rejected"][0] == par["rejected"][1]

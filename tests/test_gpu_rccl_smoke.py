@@ -65,6 +65,15 @@ def test_inference_bench_over_rccl_one_rank():
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0
+    # one invocation carries both scalings and says what the communicator is
+    assert set(rec["strong"]) == {"32", "256"} and all(v["value"] > 0 and v["scaling"] == "strong" for v in rec["strong"].values())
+    assert rec["strong"]["32"]["patches_per_rank"] == [32]
+    col = rec["config"]["collectives"]
+    assert col["backend"] == "nccl" and col["communicator_ranks_seen_by_first_all_reduce"] == 1
+    ar = col["gradient_bucket_all_reduce"]
+    assert ar["floats"] == 806103 and 0 < ar["median_us"] < 1e5
+    assert "rccl" in col and "channel_connections_by_transport" in col["rccl"], col.get("rccl")
+    print("RCCL (1 rank): bucket all-reduce", ar["median_us"], "us;", col["rccl"])
 
 
 @pytest.mark.parametrize("graph", ["1", "0"])
