@@ -554,6 +554,8 @@ class PointInterpFlow(nn.Module):
             ws = self._engine(upratio).logp_ws(B, N, dev)  # this graph's own log-likelihood workspace (graphs may replay concurrently)
         torch.cuda.current_stream(dev).wait_stream(side)
         engine = self._engine(upratio)                     # pinned: the graph reads this engine's blob
+        from .train_graph import drain_collective_watchdog
+        drain_collective_watchdog(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # see train_graph._CAPTURE_MODE: other threads (an RCCL
                                                                               # watchdog polling its events) must not break the capture

@@ -35,6 +35,18 @@ from torch import Tensor
 _CAPTURE_MODE = "thread_local"
 
 
+def drain_collective_watchdog(dev) -> None:
+    """Before a capture, under an RCCL process group: let the group's watchdog thread finish with the eager collectives issued
+    so far (broadcasts, warm-up all-reduces, bench.py's start-up probe).  It polls their events every ~100 ms, and a poll that
+    lands inside a capture has taken the process down ("operation not permitted when stream is capturing", intermittent: round 4
+    moved the captures to thread-local error mode, round 5 saw it once more with one more eager collective in front).  The
+    collectives are complete after the synchronize; one poll interval later the watchdog has dropped them."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl":
+        import time
+        torch.cuda.synchronize(dev)
+        time.sleep(0.35)
+
+
 def make_capturable(optimizer: torch.optim.Optimizer, device) -> torch.optim.Optimizer:
     """Adam(capturable=True) with the learning rate and the step counters as device tensors (required for capture)."""
     for g in optimizer.param_groups:
@@ -89,6 +101,7 @@ class GraphedTrainStep:
                 self._update()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        drain_collective_watchdog(dev)
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
         if not self.multi:
