@@ -3,6 +3,7 @@ restatement against closed-form ODE solutions, the state-dict surface, and the h
 import math
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import cnf_ref as C
@@ -198,3 +199,20 @@ def test_rhs_vjp_matches_autograd(golden_dir):
             assert close(got[f"gate_pre{l}"].t() @ tc, ref[f"{p}.{l}._hyper_gate.weight"])
             assert close(got[f"gate_pre{l}"].sum(0), ref[f"{p}.{l}._hyper_gate.bias"])
             assert close(got[f"bias_pre{l}"].t() @ tc, ref[f"{p}.{l}._hyper_bias.weight"])
+
+
+def test_cached_oracle_outputs_match_a_fresh_run(golden_dir):
+    """tests/golden/cnf_oracle_cache.npz (tools/make_golden_cnf_oracle.py) spares the GPU suite a minute of CPU oracle time per
+    run; here, on the CPU, the cheaper half of it is re-derived: the fp32 oracle on the trained-checkpoint input (1 x 256)."""
+    import os
+    path = os.path.join(golden_dir, "cnf_oracle_cache.npz")
+    if not os.path.exists(path):
+        pytest.skip("no cache fixture")
+    c = np.load(path)
+    g = np.load(os.path.join(golden_dir, "pretrained_cnf.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    xyz = torch.from_numpy(g["xyz"])
+    noise = [torch.from_numpy(n) for n in g["noise"]]
+    o32 = C.forward(sd, xyz, 4, noise=noise, stages=True)
+    assert int(c["pre_o32_nfe"]) == o32["nfe"] and int(c["pre_o32_rejected"]) == o32["rejected"]
+    assert np.abs(c["pre_o32_x"] - o32["x"].numpy()).max() <= 1e-5
