@@ -50,13 +50,18 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float rx, 
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// hipcc folds `c ? bi[i - 1] : bi[i]` on the INT list into one load through a selected address, which keeps the list in scratch
+// (48 bytes per lane, ~60 scratch instructions per query with a run-time offset in knn5_kernel<16, .>: round 5, found in the ISA;
+// the float list next to it stays in registers).  An empty asm makes the two values opaque: the selects stay selects.
+__device__ __forceinline__ int knn_opaque(int v) { asm("" : "+v"(v)); return v; }
+
 // shifting insert of (d, j) into the ascending lists bd/bi (see header comment for the tie rule)
 template <int K>
 __device__ __forceinline__ void topk_insert(float (&bd)[K], int (&bi)[K], float d, int j) {
 #pragma unroll
     for (int i = K - 1; i >= 1; --i) {
         const bool ltl = d < bd[i - 1], lti = d < bd[i];
-        bi[i] = ltl ? bi[i - 1] : (lti ? j : bi[i]);
+        bi[i] = ltl ? knn_opaque(bi[i - 1]) : (lti ? j : knn_opaque(bi[i]));
         bd[i] = ltl ? bd[i - 1] : (lti ? d : bd[i]);
     }
     if (d < bd[0]) { bd[0] = d; bi[0] = j; }
@@ -69,7 +74,7 @@ __device__ __forceinline__ void topk_insert_head(float (&bd)[K], int (&bi)[K], f
 #pragma unroll
     for (int i = TOP; i >= 1; --i) {
         const bool ltl = d < bd[i - 1], lti = d < bd[i];
-        bi[i] = ltl ? bi[i - 1] : (lti ? j : bi[i]);
+        bi[i] = ltl ? knn_opaque(bi[i - 1]) : (lti ? j : knn_opaque(bi[i]));
         bd[i] = ltl ? bd[i - 1] : (lti ? d : bd[i]);
     }
     if (d < bd[0]) { bd[0] = d; bi[0] = j; }
