@@ -369,6 +369,209 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop2_kernel(const float* __restri
     if (g == 0 && tid == 0) { fps_st(abort_w + 1, (unsigned long long)rounds); fps_st(abort_w, FPSC_ST_DONE); }
 }
 
+// ---- many samples per exchange (the shipped kernel; -DPF_FPS_TWO_SAMPLE / -DPF_FPS_ONE_SAMPLE build the predecessors) -------
+// A round of fps_coop2_kernel knows more than it uses.  Every wave publishes its KW best points; wave 0 of every workgroup
+// holds ALL published candidates (keys and, after one gather, coordinates).  Let B = the largest of the waves' LAST published
+// keys: every point nobody published lies below its own wave's last key, hence below B - and adding samples only lowers
+// min-distances, i.e. keys.  So wave 0 can run the sequential algorithm on the published candidates alone: take the largest
+// key c1 (always the true next sample); lower the candidates' keys by c1 exactly as the update will (min(md, sqd(cand, c1)),
+// the same unfused arithmetic, same argument order); the largest updated key K' is the true next sample iff K' >= B (nothing
+// unpublished can reach it) and its distance is > 0 (a zero distance would tie with the samples already taken, whose keys are
+// (0, index): the sequential algorithm then picks by index among points this round does not know).  Repeat until the test
+// fails or MS samples are out.  Unlike the two-sample rule a TOUCHED candidate may still be taken (its lowered key is exact),
+// and so may the third, fourth, ... .  Every workgroup runs the same chain on the same words and reaches the same samples.
+// CPU simulation of the CLI's merge shape (99 840 -> 20 024, 100 waves): KW = 2, MS = 8: 7.3 samples per round (cap reached
+// in 76 % of the rounds); KW = 2, MS = 16: 11.3; KW = 4, MS = 16: 15.5 - against 1.6-1.7 of fps_coop2_kernel.
+#ifndef PF_FPS_KW
+#define PF_FPS_KW 2                                      // words (best points) a wave publishes per round: 2 or 4
+#endif
+#ifndef PF_FPS_MS
+#define PF_FPS_MS 16                                     // samples a round may emit
+#endif
+constexpr int FPSM_KW = PF_FPS_KW, FPSM_MS = PF_FPS_MS;
+static_assert(FPSM_KW == 2 || FPSM_KW == 4, "lane l polls words l + 64 t: word index mod KW must be lane mod KW");
+constexpr int FPSC_SLOTSM = FPSM_KW * FPSC_SLOTS;
+constexpr int FPSC_RINGM = 4 * FPSC_SLOTSM;              // status word of this kernel's ring
+constexpr int FPSM_NT = FPSM_KW * 2;                     // words a lane of wave 0 polls (<= 128 waves per cloud)
+
+typedef float fps_f2 __attribute__((ext_vector_type(2)));
+// two squared distances at once: the same unfused fp32 operations as sqd(), issued as packed v_pk_add / v_pk_mul
+__device__ __forceinline__ fps_f2 sqd2(fps_f2 ax, fps_f2 ay, fps_f2 az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+    const fps_f2 dx = ax - bx, dy = ay - by, dz = az - bz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : 2)) void fps_coopm_kernel(const float* __restrict__ xyz, int N,
+                                                                                 int npoint, int G,
+                                                                                 unsigned long long* __restrict__ ringbuf,
+                                                                                 long long ring_stride, int* __restrict__ out) {
+    constexpr int NW = FPSC_T / 64, KW = FPSM_KW, MS = FPSM_MS, NT = FPSM_NT, PH = (PPT + 1) / 2;
+    __shared__ float s_l[2][3 * MS + 4];                                // samples of a round, [3 MS] = count, [3 MS + 1] = alive
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const float* p = xyz + (size_t)b * N * 3;
+    unsigned long long* ring = ringbuf + (size_t)b * ring_stride;       // [4][FPSC_SLOTSM] + status word
+    unsigned long long* abort_w = ring + FPSC_RINGM;
+    int* o = out + (size_t)b * npoint;
+    const int SW = KW * G * NW;                                         // words per round
+
+    fps_f2 px[PH], py[PH], pz[PH], md[PH];                              // points 2h, 2h + 1 of this thread
+#pragma unroll
+    for (int k = 0; k < 2 * PH; ++k) {
+        const int i = (g * PPT + k) * FPSC_T + tid;                     // increasing in k: first maximum = smallest index
+        const bool in = k < PPT && i < N;
+        const int ic = in ? i : N - 1;
+        px[k >> 1][k & 1] = p[ic * 3 + 0]; py[k >> 1][k & 1] = p[ic * 3 + 1]; pz[k >> 1][k & 1] = p[ic * 3 + 2];
+        md[k >> 1][k & 1] = in ? 1e10f : -1.f;                          // padding can never be the farthest point
+    }
+    if (tid == 0) {
+        if (g == 0) o[0] = 0;
+        s_l[1][0] = p[0]; s_l[1][1] = p[1]; s_l[1][2] = p[2];           // "round -1" emitted point 0
+        s_l[1][3 * MS] = 1.f; s_l[1][3 * MS + 1] = 1.f;
+    }
+    __syncthreads();
+    int j = 1, rounds = 0;
+    for (int r = 0; j < npoint; ++r) {
+        // update with the samples of the previous round
+        {
+            const float* sp = s_l[(r + 1) & 1];
+            const int m = (int)sp[3 * MS];
+            for (int s = 0; s < m; ++s) {
+                const float lx = sp[3 * s], ly = sp[3 * s + 1], lz = sp[3 * s + 2];
+#pragma unroll
+                for (int h = 0; h < PH; ++h) {
+                    const fps_f2 d = sqd2(px[h], py[h], pz[h], lx, ly, lz);
+                    md[h][0] = fminf(md[h][0], d[0]); md[h][1] = fminf(md[h][1], d[1]);
+                }
+            }
+        }
+        // per-lane best KW by (distance, then smaller index): indices grow with k, strict comparisons keep the smaller
+        float bv[KW];
+        int bk[KW];                                                     // k of the point: its index is (g PPT + k) FPSC_T + tid
+#pragma unroll
+        for (int q = 0; q < KW; ++q) { bv[q] = -1.f; bk[q] = 0; }
+#pragma unroll
+        for (int k = 0; k < 2 * PH; ++k) {
+            const float d = md[k >> 1][k & 1];
+            bool gt[KW];
+#pragma unroll
+            for (int q = 0; q < KW; ++q) gt[q] = d > bv[q];
+#pragma unroll
+            for (int q = KW - 1; q >= 0; --q) {
+                const bool up = q > 0 && gt[q > 0 ? q - 1 : 0];         // the element above moves down into q
+                bv[q] = gt[q] ? (up ? bv[q > 0 ? q - 1 : 0] : d) : bv[q];
+                bk[q] = gt[q] ? (up ? bk[q > 0 ? q - 1 : 0] : k) : bk[q];
+            }
+        }
+        // the wave's best KW (distances are >= 0 or the -1 of padding: their bit patterns order like signed integers)
+        unsigned long long* slot = ring + (r & 3) * FPSC_SLOTSM;
+        const unsigned tag = ((unsigned)(((r >> 2) & 3) << 1) | 1u) << 29;      // see fps_coop_kernel
+#pragma unroll
+        for (int e = 0; e < KW; ++e) {
+            const int vb = __float_as_int(bv[0]);
+            const unsigned ib = (unsigned)((g * PPT + bk[0]) * FPSC_T + tid);
+            const int vmax = wave_max_i32(vb);
+            const unsigned imin = ~wave_max_u32(vb == vmax ? ~ib : 0u);
+            const bool mine = vb == vmax && ib == imin;                 // the lane that holds this one pops it
+            if (lane == 0) fps_st(slot + KW * (g * NW + wave) + e, fps_key(vmax, imin, tag));
+#pragma unroll
+            for (int q = 0; q + 1 < KW; ++q) { bv[q] = mine ? bv[q + 1] : bv[q]; bk[q] = mine ? bk[q + 1] : bk[q]; }
+            bv[KW - 1] = mine ? -1.f : bv[KW - 1];
+        }
+        if (wave == 0) {
+            unsigned long long kk[NT];
+            unsigned spins = 0;
+            bool dead = false;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    kk[t] = lane + 64 * t < SW ? fps_ld(slot + lane + 64 * t) : (unsigned long long)tag;
+                    ok = ok && ((unsigned)kk[t] & (7u << 29)) == tag;
+                }
+                if (!__any(!ok)) break;
+                if (++spins > FPSC_SPIN_MAX || (spins % 1024 == 0 && fps_ld(abort_w) == FPSC_ST_ABORT)) { dead = true; break; }
+            }
+            float* sl = s_l[r & 1];
+            if (dead) {                                                     // uniform over the wave
+                if (lane == 0) { fps_st(abort_w, FPSC_ST_ABORT); sl[3 * MS + 1] = -1.f; }
+            } else {
+                // every candidate's coordinates (the cloud is read-only: plain cached loads)
+                fps_f2 cx[NT / 2], cy[NT / 2], cz[NT / 2];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const unsigned q = (~(unsigned)kk[t]) & 0x1fffffffu;
+                    const unsigned qc = q < (unsigned)N ? q : 0u;           // padding words carry md bits 0: never updated, never taken
+                    cx[t >> 1][t & 1] = p[qc * 3 + 0]; cy[t >> 1][t & 1] = p[qc * 3 + 1]; cz[t >> 1][t & 1] = p[qc * 3 + 2];
+                }
+                // B: the largest LAST key of a wave (word index mod KW == KW - 1  <=>  lane mod KW == KW - 1)
+                unsigned long long lastk = 0ull;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) lastk = u64max(lastk, kk[t]);
+                const unsigned long long Bk = wave_max_u64((lane & (KW - 1)) == KW - 1 ? lastk : 0ull);
+                int m = 0;
+                for (;;) {
+                    // this lane's best, then the wave's
+                    unsigned long long f = kk[0];
+                    float fx = cx[0][0], fy = cy[0][0], fz = cz[0][0];
+#pragma unroll
+                    for (int t = 1; t < NT; ++t) {
+                        const bool gt = kk[t] > f;
+                        f = gt ? kk[t] : f;
+                        fx = gt ? cx[t >> 1][t & 1] : fx; fy = gt ? cy[t >> 1][t & 1] : fy; fz = gt ? cz[t >> 1][t & 1] : fz;
+                    }
+                    const unsigned fh = (unsigned)(f >> 32), fl = (unsigned)f;
+                    const unsigned hmax = wave_max_u32(fh);
+                    unsigned long long own = __ballot(fh == hmax);
+                    unsigned lmax;
+                    if (__builtin_popcountll(own) == 1) {                  // the usual case: one lane holds the largest distance
+                        lmax = (unsigned)__builtin_amdgcn_readlane((int)fl, __builtin_ctzll(own));
+                    } else {
+                        lmax = wave_max_u32(fh == hmax ? fl : 0u);
+                        own = __ballot(fh == hmax && fl == lmax);
+                    }
+                    const unsigned long long K = ((unsigned long long)hmax << 32) | lmax;
+                    if (m > 0 && !(K >= Bk && __uint_as_float(hmax) > 0.f)) break;
+                    const int w = __builtin_ctzll(own);
+                    auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+                    const float sx = rl(fx, w), sy = rl(fy, w), sz = rl(fz, w);
+                    const unsigned idx = (~lmax) & 0x1fffffffu;
+                    if (lane == 0) {
+                        sl[3 * m] = sx; sl[3 * m + 1] = sy; sl[3 * m + 2] = sz;
+                        if (g == 0) o[j + m] = (int)idx;
+                    }
+                    ++m;
+                    if (m == MS || j + m >= npoint || idx >= (unsigned)N) break;
+                    // lower the candidates' keys exactly as the update will (the sample itself falls to distance 0)
+#pragma unroll
+                    for (int t = 0; t < NT; t += 2) {
+                        const fps_f2 d = sqd2(cx[t >> 1], cy[t >> 1], cz[t >> 1], sx, sy, sz);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const unsigned kh = (unsigned)(kk[t + u] >> 32);
+                            if (d[u] < __uint_as_float(kh))
+                                kk[t + u] = ((unsigned long long)__float_as_uint(d[u]) << 32) | (unsigned)kk[t + u];
+                        }
+                    }
+                }
+                if (lane == 0) { sl[3 * MS] = (float)m; sl[3 * MS + 1] = 1.f; }
+            }
+        }
+        // s_l is double-buffered (see fps_coop_kernel): one barrier per round
+        __syncthreads();
+        const float* sl = s_l[r & 1];
+        if (sl[3 * MS + 1] < 0.f) return;                                 // uniform over the workgroup: aborted
+        j += (int)sl[3 * MS];
+        rounds = r + 1;
+    }
+    // the word after the status word: exchange rounds this cloud took (measurement only: bench.py --mode pugan reports
+    // samples per round and the time per round next to the exchange floor of pf_fps_exchange_probe)
+    if (g == 0 && tid == 0) { fps_st(abort_w + 1, (unsigned long long)rounds); fps_st(abort_w, FPSC_ST_DONE); }
+}
+
 // ---- the exchange alone: what a round of fps_coop2_kernel costs with NO points to update ------------------------------
 // Same protocol, same ring, same shapes (G workgroups of FPSC_T threads, two words per wave, wave 0 polls 4 words per lane,
 // reduces them and hands a result to the other waves through the double-buffered LDS words, one barrier per round) - only the
@@ -537,15 +740,18 @@ __global__ __launch_bounds__(256) void fps_init_kernel(float* p, long long n, in
 // stride_words = 64-bit words between the rings of consecutive clouds, abort_word = index of the abort word in a ring
 // two samples per exchange (fps_coop2_kernel, the shipped kernel); -DPF_FPS_ONE_SAMPLE builds the one-sample kernel instead
 // (tools/time_fps.py A/B) - a compile-time choice: pf_fps and pf_fps_scratch_layout must agree
-#ifdef PF_FPS_ONE_SAMPLE
-static constexpr bool fps_two() { return false; }
+#if defined(PF_FPS_ONE_SAMPLE)
+static constexpr int fps_mode() { return 1; }
+#elif defined(PF_FPS_TWO_SAMPLE)
+static constexpr int fps_mode() { return 2; }
 #else
-static constexpr bool fps_two() { return true; }
+static constexpr int fps_mode() { return 3; }                             // fps_coopm_kernel
 #endif
+static constexpr int fps_status_word() { return fps_mode() == 1 ? FPSC_RING : fps_mode() == 2 ? FPSC_RING2 : FPSC_RINGM; }
 
 extern "C" int pf_fps_scratch_layout(int N, long long* stride_words, long long* abort_word) {
     if (stride_words) *stride_words = ((long long)N / 2) & ~1ll;
-    if (abort_word) *abort_word = fps_two() ? FPSC_RING2 : FPSC_RING;
+    if (abort_word) *abort_word = fps_status_word();
     return N >= 8192 && N <= FPSC_GMAX * 1024 * 8 ? 1 : 0;
 }
 
@@ -565,10 +771,11 @@ extern "C" int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, i
         // cleared by a kernel, not hipMemsetAsync: a memset node inside a captured hipGraph was observed to race with the
         // kernel node that follows it (csrc/emd.hip)
         hipLaunchKernelGGL(fps_init_kernel, dim3(256), dim3(256), 0, s, mind, (long long)B * N, B, stride,
-                           fps_two() ? FPSC_RING2 : FPSC_RING);
+                           fps_status_word());
         const dim3 grid(B * G), block(FPSC_T);
 #define PF_FPS_LAUNCH(PPT)                                                                                                  \
-        if (fps_two()) hipLaunchKernelGGL(fps_coop2_kernel<PPT>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); \
+        if (fps_mode() == 3) hipLaunchKernelGGL(fps_coopm_kernel<PPT>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); \
+        else if (fps_mode() == 2) hipLaunchKernelGGL(fps_coop2_kernel<PPT>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); \
         else hipLaunchKernelGGL(fps_coop_kernel<PPT>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out)
         switch (ppt) {
             case 1: PF_FPS_LAUNCH(1); break;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times pf_fps on the CLI's merge shape (99 840 -> 20 024 points; 1 and 8 clouds at once).
+"""Times pf_fps on the CLI's merge shape (99 840 -> 20 024 points; 1, 8 and 32 clouds at once).
   python tools/time_fps.py [n_points] [n_sample] [n_clouds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ from puflow_amd import ops
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 99840
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 20024
-for B in [int(sys.argv[3])] if len(sys.argv) > 3 else [1, 8]:
+for B in [int(b) for b in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1, 8, 32]:
     g = torch.Generator().manual_seed(7)
     pc = torch.rand(B, N, 3, generator=g).cuda()
     idx = ops.furthest_point_sample(pc, M)
