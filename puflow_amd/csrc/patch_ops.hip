@@ -418,14 +418,26 @@ __global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : 2)) void fps_coopm_kernel(
     int* o = out + (size_t)b * npoint;
     const int SW = KW * G * NW;                                         // words per round
 
+    // a thread holds PPT CONSECUTIVE points, a wave 64 PPT consecutive points: indices grow with k (first maximum = smallest
+    // index), and when the input has any spatial order (the CLI's merge: 1024 consecutive candidates = one patch) a wave's
+    // points share a small bounding box - see the culling test below
+    const int base = ((g * NW + wave) * 64 + lane) * PPT;
     fps_f2 px[PH], py[PH], pz[PH], md[PH];                              // points 2h, 2h + 1 of this thread
+    float lox = 3e38f, loy = 3e38f, loz = 3e38f, hix = -3e38f, hiy = -3e38f, hiz = -3e38f;
 #pragma unroll
     for (int k = 0; k < 2 * PH; ++k) {
-        const int i = (g * PPT + k) * FPSC_T + tid;                     // increasing in k: first maximum = smallest index
+        const int i = base + k;
         const bool in = k < PPT && i < N;
         const int ic = in ? i : N - 1;
-        px[k >> 1][k & 1] = p[ic * 3 + 0]; py[k >> 1][k & 1] = p[ic * 3 + 1]; pz[k >> 1][k & 1] = p[ic * 3 + 2];
+        const float x = p[ic * 3 + 0], y = p[ic * 3 + 1], z = p[ic * 3 + 2];
+        px[k >> 1][k & 1] = x; py[k >> 1][k & 1] = y; pz[k >> 1][k & 1] = z;
         md[k >> 1][k & 1] = in ? 1e10f : -1.f;                          // padding can never be the farthest point
+        if (in) { lox = fminf(lox, x); loy = fminf(loy, y); loz = fminf(loz, z); hix = fmaxf(hix, x); hiy = fmaxf(hiy, y); hiz = fmaxf(hiz, z); }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {                            // the wave's bounding box (once)
+        lox = fminf(lox, __shfl_xor(lox, off)); loy = fminf(loy, __shfl_xor(loy, off)); loz = fminf(loz, __shfl_xor(loz, off));
+        hix = fmaxf(hix, __shfl_xor(hix, off)); hiy = fmaxf(hiy, __shfl_xor(hiy, off)); hiz = fmaxf(hiz, __shfl_xor(hiz, off));
     }
     if (tid == 0) {
         if (g == 0) o[0] = 0;
@@ -433,14 +445,32 @@ __global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : 2)) void fps_coopm_kernel(
         s_l[1][3 * MS] = 1.f; s_l[1][3 * MS + 1] = 1.f;
     }
     __syncthreads();
+    float Dw = 1e10f;                                                   // >= every min-distance of this wave (its last published best)
+    int pv[KW];                                                         // the wave's last published keys (distance bits, index)
+    unsigned pidx[KW];
+#pragma unroll
+    for (int e = 0; e < KW; ++e) { pv[e] = -1; pidx[e] = 0u; }
     int j = 1, rounds = 0;
     for (int r = 0; j < npoint; ++r) {
-        // update with the samples of the previous round
+        // update with the samples of the previous round - those that can reach this wave.  Lane s looks at sample s: the
+        // nearest point q of the wave's box to it is at least as close as every point of the wave, in fp32 as computed by
+        // sqd() too (subtraction, multiplication and addition round monotonically), so sqd(q, c) >= Dw >= md means
+        // fminf(md, sqd(p, c)) = md for the whole wave: the sample is skipped EXACTLY.  Late in a merge a sample reaches a
+        // few per cent of the waves; a wave no sample reached publishes its previous keys again.
+        bool touched = false;
         {
             const float* sp = s_l[(r + 1) & 1];
             const int m = (int)sp[3 * MS];
-            for (int s = 0; s < m; ++s) {
-                const float lx = sp[3 * s], ly = sp[3 * s + 1], lz = sp[3 * s + 2];
+            const int ls = lane < MS ? lane : MS - 1;
+            const float cx = sp[3 * ls], cy = sp[3 * ls + 1], cz = sp[3 * ls + 2];
+            const float bd = sqd(fminf(fmaxf(cx, lox), hix), fminf(fmaxf(cy, loy), hiy), fminf(fmaxf(cz, loz), hiz), cx, cy, cz);
+            unsigned long long need = __ballot(lane < m && bd < Dw);
+            touched = need != 0ull;
+            while (need) {
+                const int s = __builtin_ctzll(need);
+                need &= need - 1ull;
+                auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+                const float lx = rl(cx, s), ly = rl(cy, s), lz = rl(cz, s);
 #pragma unroll
                 for (int h = 0; h < PH; ++h) {
                     const fps_f2 d = sqd2(px[h], py[h], pz[h], lx, ly, lz);
@@ -448,38 +478,45 @@ __global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : 2)) void fps_coopm_kernel(
                 }
             }
         }
-        // per-lane best KW by (distance, then smaller index): indices grow with k, strict comparisons keep the smaller
-        float bv[KW];
-        int bk[KW];                                                     // k of the point: its index is (g PPT + k) FPSC_T + tid
-#pragma unroll
-        for (int q = 0; q < KW; ++q) { bv[q] = -1.f; bk[q] = 0; }
-#pragma unroll
-        for (int k = 0; k < 2 * PH; ++k) {
-            const float d = md[k >> 1][k & 1];
-            bool gt[KW];
-#pragma unroll
-            for (int q = 0; q < KW; ++q) gt[q] = d > bv[q];
-#pragma unroll
-            for (int q = KW - 1; q >= 0; --q) {
-                const bool up = q > 0 && gt[q > 0 ? q - 1 : 0];         // the element above moves down into q
-                bv[q] = gt[q] ? (up ? bv[q > 0 ? q - 1 : 0] : d) : bv[q];
-                bk[q] = gt[q] ? (up ? bk[q > 0 ? q - 1 : 0] : k) : bk[q];
-            }
-        }
-        // the wave's best KW (distances are >= 0 or the -1 of padding: their bit patterns order like signed integers)
         unsigned long long* slot = ring + (r & 3) * FPSC_SLOTSM;
         const unsigned tag = ((unsigned)(((r >> 2) & 3) << 1) | 1u) << 29;      // see fps_coop_kernel
+        if (touched) {                                                  // uniform over the wave
+            // per-lane best KW by (distance, then smaller index): indices grow with k, strict comparisons keep the smaller
+            float bv[KW];
+            int bk[KW];
 #pragma unroll
-        for (int e = 0; e < KW; ++e) {
-            const int vb = __float_as_int(bv[0]);
-            const unsigned ib = (unsigned)((g * PPT + bk[0]) * FPSC_T + tid);
-            const int vmax = wave_max_i32(vb);
-            const unsigned imin = ~wave_max_u32(vb == vmax ? ~ib : 0u);
-            const bool mine = vb == vmax && ib == imin;                 // the lane that holds this one pops it
-            if (lane == 0) fps_st(slot + KW * (g * NW + wave) + e, fps_key(vmax, imin, tag));
+            for (int q = 0; q < KW; ++q) { bv[q] = -1.f; bk[q] = 0; }
 #pragma unroll
-            for (int q = 0; q + 1 < KW; ++q) { bv[q] = mine ? bv[q + 1] : bv[q]; bk[q] = mine ? bk[q + 1] : bk[q]; }
-            bv[KW - 1] = mine ? -1.f : bv[KW - 1];
+            for (int k = 0; k < 2 * PH; ++k) {
+                const float d = md[k >> 1][k & 1];
+                bool gt[KW];
+#pragma unroll
+                for (int q = 0; q < KW; ++q) gt[q] = d > bv[q];
+#pragma unroll
+                for (int q = KW - 1; q >= 0; --q) {
+                    const bool up = q > 0 && gt[q > 0 ? q - 1 : 0];     // the element above moves down into q
+                    bv[q] = gt[q] ? (up ? bv[q > 0 ? q - 1 : 0] : d) : bv[q];
+                    bk[q] = gt[q] ? (up ? bk[q > 0 ? q - 1 : 0] : k) : bk[q];
+                }
+            }
+            // the wave's best KW (distances are >= 0 or the -1 of padding: their bit patterns order like signed integers)
+#pragma unroll
+            for (int e = 0; e < KW; ++e) {
+                const int vb = __float_as_int(bv[0]);
+                const unsigned ib = (unsigned)(base + bk[0]);
+                const int vmax = wave_max_i32(vb);
+                const unsigned imin = ~wave_max_u32(vb == vmax ? ~ib : 0u);
+                const bool mine = vb == vmax && ib == imin;             // the lane that holds this one pops it
+                pv[e] = vmax; pidx[e] = imin;
+#pragma unroll
+                for (int q = 0; q + 1 < KW; ++q) { bv[q] = mine ? bv[q + 1] : bv[q]; bk[q] = mine ? bk[q + 1] : bk[q]; }
+                bv[KW - 1] = mine ? -1.f : bv[KW - 1];
+            }
+            Dw = __int_as_float(pv[0]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int e = 0; e < KW; ++e) fps_st(slot + KW * (g * NW + wave) + e, fps_key(pv[e], pidx[e], tag));
         }
         if (wave == 0) {
             unsigned long long kk[NT];
