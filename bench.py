@@ -1081,7 +1081,7 @@ def bench_pugan(args, world, rank, dev, dist):
             st["fps_merge"], _ = ev_ms(lambda: ops.furthest_point_sample(flat, npoint))
             den = PatchHelper.merge_patches(cand, npoint).transpose(1, 2).contiguous()
             st["remove_outliers"], _ = ev_ms(lambda: PatchHelper.remove_outliers(den, pc, NOUT))
-            # ---- dominant kernel: the cooperative FPS merge (fps_coop2_kernel).  One launch = B clouds x G workgroups; a cloud's
+            # ---- dominant kernel: the cooperative FPS merge (fps_coopm_kernel).  One launch = B clouds x G workgroups; a cloud's
             # samples are sequential BY DEFINITION (sample j+1 needs the min-distances after sample j), so a launch is bound by
             # the latency of one dependent exchange round x the rounds of one cloud, not by bytes or flops: the whole cloud
             # lives in registers and the algorithmic HBM traffic is one read of the candidates + one write of the indices.
@@ -1103,24 +1103,44 @@ def bench_pugan(args, world, rank, dev, dist):
             assert int(ring[1024].item()) == 0, "exchange probe did not complete"
         alg_bytes = B * (M * 12 + npoint * 4)
         merge_ms = st["fps_merge"]
-        roof = {"bound": "hbm", "kernel": f"fps_coop2_kernel<{ppt}> (csrc/patch_ops.hip): FPS merge 99 840 -> 20 024 per cloud, "
-                                          f"{B} clouds x {G} cooperating workgroups per launch",
-                "achieved": alg_bytes / (merge_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg_bytes / (merge_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": merge_ms,
-                "bytes_basis": f"algorithmic: {M} candidates x 12 B read once + {npoint} indices x 4 B written, per cloud, {B} clouds per launch; "
-                               "live HIP-event duration on the launch stream",
-                "bound_note": "the contract's two bounds do not describe this kernel: FPS is sequential in its output count, every point and "
-                              "its running min-distance live in registers for the whole launch, HBM traffic is ~1.3 MB per cloud.  What bounds "
-                              "it is `latency`: dependent exchange rounds x the round-trip of one exchange",
+        # HBM bytes of one launch from the committed PMC pass (tools/pmc_cmd.sh over tools/time_fps.py 99840 20024 32 patch)
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_pugan_latest.json")))
+            ent = [v for k_, v in pm.get("kernels", {}).items() if "fps_coopm_kernel" in k_ and "hbm_bytes_per_launch" in v]
+            if ent:
+                ent = max(ent, key=lambda v: v.get("pct", 0.0))
+                traffic = {"bytes_per_launch": ent["hbm_bytes_per_launch"], "profiled_avg_us": ent.get("avg_us"),
+                           "valu_insts_per_launch": ent.get("SQ_INSTS_VALU_mean"),
+                           "source": "profiles/pmc_pugan_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over 32 patch-ordered clouds, "
+                                     "FETCH_SIZE doubled per the gfx950 note): almost all of it is the polled exchange words, which are agent-scope "
+                                     "atomic loads that bypass the L2 - the cloud itself is read once (1.2 MB per cloud)"}
+        except Exception:
+            traffic = None
+        us_round_one = one_ms * 1e3 / max(rounds, 1)
+        floor_us = probe_ms * 1e3 / PROBE_ROUNDS
+        roof = {"bound": "latency", "kernel": f"fps_coopm_kernel<{ppt}> (csrc/patch_ops.hip): FPS merge {M} -> {npoint} per cloud, "
+                                              f"{B} clouds x {G} cooperating workgroups per launch",
+                "achieved": us_round_one, "peak": floor_us, "unit": "us per exchange round (one cloud alone; lower is better)",
+                "frac": floor_us / us_round_one, "traffic": traffic, "avg_launch_ms": merge_ms,
+                "bound_note": "the contract's two bounds do not describe this kernel: FPS is sequential in its output count (sample j+1 needs the "
+                              "min-distances after sample j), every point and its running min-distance live in registers for the whole launch and "
+                              "the algorithmic HBM traffic is ~1.3 MB per cloud.  What bounds a cloud is the number of DEPENDENT exchange rounds x "
+                              "the time of a round; `peak` is the measured floor of a round (pf_fps_exchange_probe: the same ring protocol between "
+                              "the same number of workgroups with no points), `achieved` the time of a round of one cloud alone - which now also "
+                              "holds the chain that takes up to 64 samples out of one exchange (~0.25 us per sample, serial in one wave)",
                 "latency": {"samples_per_cloud": npoint, "rounds_per_cloud": rounds, "samples_per_round": npoint / max(rounds, 1),
-                            "one_cloud_ms": one_ms, "us_per_round_one_cloud": one_ms * 1e3 / max(rounds, 1),
+                            "one_cloud_ms": one_ms, "us_per_round_one_cloud": us_round_one,
                             "us_per_sample_one_cloud": one_ms * 1e3 / npoint,
-                            "exchange_floor_us_per_round": probe_ms * 1e3 / PROBE_ROUNDS,
-                            "floor_frac": (probe_ms / PROBE_ROUNDS) / (one_ms / max(rounds, 1)),
+                            "exchange_floor_us_per_round": floor_us,
+                            "floor_ms_per_cloud": floor_us * rounds * 1e-3,
                             "batch_ms": merge_ms, "us_per_sample_in_batch": merge_ms * 1e3 / (B * npoint),
-                            "note": "exchange floor = pf_fps_exchange_probe: the same ring protocol between the same number of workgroups with no "
-                                    "points to update, timed live; floor_frac = floor / achieved time per round of ONE cloud alone; in a batch the "
-                                    "clouds' rounds overlap (independent rings)"}}
+                            "note": "in a batch the clouds' rounds overlap (independent rings): batch_ms / one_cloud_ms clouds' worth of time for "
+                                    f"{B} clouds"},
+                "hbm": {"achieved": alg_bytes / (merge_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg_bytes / (merge_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "bytes_basis": f"algorithmic: {M} candidates x 12 B read once + {npoint} indices x 4 B written, per cloud, {B} clouds per "
+                                       "launch; live HIP-event duration on the launch stream"}}
         extra["stage_ms"] = st
         if world == 1 and not args.no_cpu_baseline:
             from oracle import patch_ref as P, ref_cpu as O

@@ -383,13 +383,17 @@ __global__ __launch_bounds__(FPSC_T) void fps_coop2_kernel(const float* __restri
 // CPU simulation of the CLI's merge shape (99 840 -> 20 024, 100 waves): KW = 2, MS = 8: 7.3 samples per round (cap reached
 // in 76 % of the rounds); KW = 2, MS = 16: 11.3; KW = 4, MS = 16: 15.5 - against 1.6-1.7 of fps_coop2_kernel.
 #ifndef PF_FPS_KW
-#define PF_FPS_KW 2                                      // words (best points) a wave publishes per round: 2 or 4
+#define PF_FPS_KW 4                                      // words (best points) a wave publishes per round: 2 or 4
 #endif
 #ifndef PF_FPS_MS
-#define PF_FPS_MS 16                                     // samples a round may emit
+#define PF_FPS_MS 64                                     // samples a round may emit
 #endif
 constexpr int FPSM_KW = PF_FPS_KW, FPSM_MS = PF_FPS_MS;
-static_assert(FPSM_KW == 2 || FPSM_KW == 4, "lane l polls words l + 64 t: word index mod KW must be lane mod KW");
+#ifndef PF_FPS_NC
+#define PF_FPS_NC 2                                      // candidates per lane the chain of wave 0 works on
+#endif
+static_assert(FPSM_KW >= 2 && FPSM_KW <= 4, "2 .. 4 words per wave");
+constexpr int FPSM_NC = PF_FPS_NC;
 constexpr int FPSC_SLOTSM = FPSM_KW * FPSC_SLOTS;
 constexpr int FPSC_RINGM = 4 * FPSC_SLOTSM;              // status word of this kernel's ring
 constexpr int FPSM_NT = FPSM_KW * 2;                     // words a lane of wave 0 polls (<= 128 waves per cloud)
@@ -407,7 +411,8 @@ __global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : 2)) void fps_coopm_kernel(
                                                                                  int npoint, int G,
                                                                                  unsigned long long* __restrict__ ringbuf,
                                                                                  long long ring_stride, int* __restrict__ out) {
-    constexpr int NW = FPSC_T / 64, KW = FPSM_KW, MS = FPSM_MS, NT = FPSM_NT, PH = (PPT + 1) / 2;
+    constexpr int NW = FPSC_T / 64, KW = FPSM_KW, MS = FPSM_MS, NT = FPSM_NT, PH = (PPT + 1) / 2, NC = FPSM_NC, CAP = 64 * NC;
+    __shared__ unsigned long long s_ck[CAP];                            // wave 0: the round's compacted candidates
     __shared__ float s_l[2][3 * MS + 4];                                // samples of a round, [3 MS] = count, [3 MS + 1] = alive
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -536,29 +541,62 @@ __global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : 2)) void fps_coopm_kernel(
             if (dead) {                                                     // uniform over the wave
                 if (lane == 0) { fps_st(abort_w, FPSC_ST_ABORT); sl[3 * MS + 1] = -1.f; }
             } else {
-                // every candidate's coordinates (the cloud is read-only: plain cached loads)
-                fps_f2 cx[NT / 2], cy[NT / 2], cz[NT / 2];
+                // B: the largest LAST key of a wave (word w = KW * wave + e is a last key iff w mod KW == KW - 1)
+                unsigned long long lastk = 0ull, f0 = 0ull;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const unsigned q = (~(unsigned)kk[t]) & 0x1fffffffu;
-                    const unsigned qc = q < (unsigned)N ? q : 0u;           // padding words carry md bits 0: never updated, never taken
-                    cx[t >> 1][t & 1] = p[qc * 3 + 0]; cy[t >> 1][t & 1] = p[qc * 3 + 1]; cz[t >> 1][t & 1] = p[qc * 3 + 2];
+                    f0 = u64max(f0, kk[t]);
+                    if ((lane + 64 * t) % KW == KW - 1) lastk = u64max(lastk, kk[t]);
                 }
-                // B: the largest LAST key of a wave (word index mod KW == KW - 1  <=>  lane mod KW == KW - 1)
-                unsigned long long lastk = 0ull;
+                const unsigned long long Bk = wave_max_u64(lastk);
+                const unsigned long long K1 = wave_max_u64(f0);            // the round's first sample: the largest key of all
+                // Only candidates with a key >= B (and a distance > 0) can follow it in this round - keys only fall: compact
+                // them, NC per lane, through LDS (this wave only; the LDS operations of a wave execute in order) and chain on
+                // those alone.  On the CLI's merge 12 (KW = 2), 34 (3) or 65 (4) candidates qualify on average, 144 at most; a
+                // round with more than 64 NC emits its first sample only (still exact; KW = 4: 0.7 % of the rounds).
+                unsigned long long rm[NT];
+                int cnt = 0;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) lastk = u64max(lastk, kk[t]);
-                const unsigned long long Bk = wave_max_u64((lane & (KW - 1)) == KW - 1 ? lastk : 0ull);
+                for (int t = 0; t < NT; ++t) {
+                    rm[t] = __ballot(kk[t] == K1 || (kk[t] >= Bk && (unsigned)(kk[t] >> 32) != 0u));
+                    cnt += __builtin_popcountll(rm[t]);
+                }
+                if (cnt > CAP) {                                            // uniform
+                    cnt = 1;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) rm[t] = __ballot(kk[t] == K1);
+                }
+                {
+                    int before = 0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int pos = before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(rm[t] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rm[t], 0u));
+                        if ((rm[t] >> lane) & 1ull) s_ck[pos] = kk[t];
+                        before += __builtin_popcountll(rm[t]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                unsigned long long ck[NC];
+                float cx[NC], cy[NC], cz[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    ck[c] = lane + 64 * c < cnt ? s_ck[lane + 64 * c] : 0ull;
+                    const unsigned q = (~(unsigned)ck[c]) & 0x1fffffffu;
+                    const unsigned qc = q < (unsigned)N ? q : 0u;           // the cloud is read-only: plain cached loads
+                    cx[c] = p[qc * 3 + 0]; cy[c] = p[qc * 3 + 1]; cz[c] = p[qc * 3 + 2];
+                }
+                __builtin_amdgcn_wave_barrier();                            // s_ck is written again next round, after these reads
                 int m = 0;
                 for (;;) {
                     // this lane's best, then the wave's
-                    unsigned long long f = kk[0];
-                    float fx = cx[0][0], fy = cy[0][0], fz = cz[0][0];
+                    unsigned long long f = ck[0];
+                    float fx = cx[0], fy = cy[0], fz = cz[0];
 #pragma unroll
-                    for (int t = 1; t < NT; ++t) {
-                        const bool gt = kk[t] > f;
-                        f = gt ? kk[t] : f;
-                        fx = gt ? cx[t >> 1][t & 1] : fx; fy = gt ? cy[t >> 1][t & 1] : fy; fz = gt ? cz[t >> 1][t & 1] : fz;
+                    for (int c = 1; c < NC; ++c) {
+                        const bool gt = ck[c] > f;
+                        f = gt ? ck[c] : f;
+                        fx = gt ? cx[c] : fx; fy = gt ? cy[c] : fy; fz = gt ? cz[c] : fz;
                     }
                     const unsigned fh = (unsigned)(f >> 32), fl = (unsigned)f;
                     const unsigned hmax = wave_max_u32(fh);
@@ -584,14 +622,10 @@ __global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : 2)) void fps_coopm_kernel(
                     if (m == MS || j + m >= npoint || idx >= (unsigned)N) break;
                     // lower the candidates' keys exactly as the update will (the sample itself falls to distance 0)
 #pragma unroll
-                    for (int t = 0; t < NT; t += 2) {
-                        const fps_f2 d = sqd2(cx[t >> 1], cy[t >> 1], cz[t >> 1], sx, sy, sz);
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const unsigned kh = (unsigned)(kk[t + u] >> 32);
-                            if (d[u] < __uint_as_float(kh))
-                                kk[t + u] = ((unsigned long long)__float_as_uint(d[u]) << 32) | (unsigned)kk[t + u];
-                        }
+                    for (int c = 0; c < NC; ++c) {
+                        const float d = sqd(cx[c], cy[c], cz[c], sx, sy, sz);
+                        const unsigned kh = (unsigned)(ck[c] >> 32);
+                        if (d < __uint_as_float(kh)) ck[c] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)ck[c];
                     }
                 }
                 if (lane == 0) { sl[3 * MS] = (float)m; sl[3 * MS + 1] = 1.f; }
