@@ -319,6 +319,8 @@ typedef struct PfEcTrain {
     int (*sync_cb)(void* user, double* sums, int n, void* stream);
     void* sync_user;
     double* sync_sums;
+    float* ws_dw; long long ws_dw_floats; /* backward with pf_train_set_dw_stream: a second workspace (>= pf_ec_train_ws_floats()) that
+                                     * only the weight-gradient stream's kernels use; NULL = weight gradients on the calling stream */
 } PfEcTrain;
 #define PF_EC_PERSISTENT 1
 /* flags bit (PfEcTrain, PfBnMlpTrain): BatchNorm's batch statistics are accumulated as 64-bit fixed-point sums (quantum 2^-28)
@@ -329,7 +331,18 @@ typedef struct PfEcTrain {
  * puflow_amd sets it from `net.deterministic` / `cfg.deterministic`. */
 #define PF_TRAIN_DETERMINISTIC 2
 /* transposed neighbour lists of idx [B*N, K]: off [T+1], edge [T*K]; cnt: T ints (4-aligned size) of scratch */
+/* Weight gradients beside the backward chain.  With a stream set here (per host thread; NULL = off, the default) the backward
+ * entry points pf_ec_train_bwd, pf_mlp_train_bwd, pf_mlp_train_bwd_batch and pf_mlp_train_dw_batch enqueue their split-K
+ * weight-gradient kernels and reductions on it, ordered by an event behind what their own stream holds at that point, and
+ * return without waiting: the input gradient stays on the calling stream.  The caller (1) hands those calls workspaces that
+ * nothing on another stream touches (PfEcTrain.ws_dw; PfMlpTrain.ws is weight-gradient scratch only), (2) keeps every buffer
+ * of the call alive until (3) it has made the consumer of the weight gradients wait for the stream.  Inside a hipGraph
+ * capture the stream must belong to the capture (it joins it through the event) and is a parallel branch of the graph. */
+int pf_train_set_dw_stream(void* stream);
 int pf_knn_csr(const int* idx, int B, int N, int K, int* off, int* edge, int* cnt, void* stream);
+/* sorts every list of pf_knn_csr (edge ids ascending; T = B*N lists): sums over a list then add in one order, run after run -
+ * what PF_TRAIN_DETERMINISTIC's gather-form gradients need; the default mode does not call it */
+int pf_knn_csr_sort(const int* off, int* edge, int T, void* stream);
 long long pf_ec_train_ws_floats(const PfEcTrain* p);
 int pf_ec_train_fwd(const PfEcTrain* p, void* stream);
 int pf_ec_train_bwd(const PfEcTrain* p, void* stream);

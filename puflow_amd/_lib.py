@@ -22,7 +22,8 @@ class PfEcTrain(ctypes.Structure):
                 ("arg", c_void_p), ("dout", c_void_p), ("dA", c_void_p), ("dPQ", c_void_p), ("coef", c_void_p),
                 ("dWpq", c_void_p), ("dx", c_void_p), ("dW", c_void_p * 9), ("dbias", c_void_p * 9),
                 ("dgamma", c_void_p * 8), ("dbeta", c_void_p * 8), ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p), ("csr_off", c_void_p), ("csr_edge", c_void_p),
-                ("flags", c_int), ("sync", c_void_p), ("sync_cb", c_void_p), ("sync_user", c_void_p), ("sync_sums", c_void_p)]
+                ("flags", c_int), ("sync", c_void_p), ("sync_cb", c_void_p), ("sync_user", c_void_p), ("sync_sums", c_void_p),
+                ("ws_dw", c_void_p), ("ws_dw_floats", c_longlong)]
 
 
 class PfBnMlpTrain(ctypes.Structure):
@@ -179,7 +180,9 @@ SIGNATURES = {
     "pf_bnmlp_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_bnmlp_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_bnmlp_train_bwd": (c_int, [c_void_p, c_void_p]),
+    "pf_train_set_dw_stream": (c_int, [c_void_p]),
     "pf_knn_csr": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_knn_csr_sort": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "pf_ec_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_ec_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_ec_train_bwd": (c_int, [c_void_p, c_void_p]),

@@ -28,3 +28,14 @@ static inline void pf_allow_lds(const void* kernel, size_t bytes) {
     (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes > PF_LDS_CAP ? bytes : PF_LDS_CAP));
     done.emplace_back(dev, kernel);
 }
+
+// ---- weight gradients beside the backward chain (pf_train_set_dw_stream, csrc/api.hip) ------------------------------------
+// A backward entry point produces two kinds of results: the gradient wrt its INPUT, which the layer before it waits for, and
+// the gradients wrt its WEIGHTS, which nobody reads before the optimizer.  With a weight-gradient stream set (per host thread)
+// the split-K weight-gradient kernels and their reductions are enqueued there, after an event that orders them behind what
+// the calling stream holds at that point; the caller joins the stream once, before the optimizer (puflow_amd/train_ops.py does
+// it at the end of the autograd pass).  Inside a hipGraph capture the event becomes an edge: a parallel branch of the graph.
+void* pf_dw_stream_get();
+// the stream weight-gradient work of a call should go to: s itself when none is set (or it IS s), else the weight-gradient stream,
+// made to wait for everything enqueued on s so far
+hipStream_t pf_dw_fork(hipStream_t s);

@@ -2685,7 +2685,15 @@ extern "C" int pf_knn_csr(const int* idx, int B, int N, int K, int* off, int* ed
     hipLaunchKernelGGL(csr_count_kernel, dim3(g), dim3(256), 0, s, idx, N, K, E, cnt);
     hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, T, off);
     hipLaunchKernelGGL(csr_fill_kernel, dim3(g), dim3(256), 0, s, idx, N, K, E, cnt, edge);
-    hipLaunchKernelGGL(csr_sort_kernel, dim3((T + 255) / 256), dim3(256), 0, s, off, edge, T);
+    return pf_last_launch_status();
+}
+
+// Sorts every list of pf_knn_csr (edge ids ascending).  The fill hands out a list's slots in arrival order; whatever is summed over
+// a sorted list adds in ONE order, run after run (PF_TRAIN_DETERMINISTIC: the gather-form gradients).  Not needed otherwise.
+extern "C" int pf_knn_csr_sort(const int* off, int* edge, int T, void* stream) {
+    if (!off || !edge) return PF_ERR_NULL;
+    if (T <= 0) return PF_ERR_SHAPE;
+    hipLaunchKernelGGL(csr_sort_kernel, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, off, edge, T);
     return pf_last_launch_status();
 }
 
@@ -2769,9 +2777,13 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const EcConvs cv = ec_convs(p, d);
     const int g = p->growth, nc = p->nconv;
-    float* dwpart = p->ws;
+    // weight gradients on their own stream (pf_train_set_dw_stream) take the second workspace: the partial slabs and the
+    // scratch of the dWpq GEMM; the calling stream keeps p->ws for the dx GEMM
+    const bool dw_side = pf_dw_stream_get() && pf_dw_stream_get() != stream && p->ws_dw && p->ws_dw_floats >= pf_ec_train_ws_floats(p);
+    float* dwpart = dw_side ? p->ws_dw : p->ws;
     float* bpart = dwpart + (long long)d.nchunk * d.S * d.GT;
-    float* gws = bpart + (long long)d.nchunk * d.S;
+    float* gws_dw = bpart + (long long)d.nchunk * d.S;
+    float* gws = p->ws + (long long)d.nchunk * d.S * (d.GT + 1);
     const bool csr = p->csr_off && p->csr_edge;
     // cleared by a kernel rather than hipMemsetAsync: see csrc/emd.hip (memset nodes inside a captured hipGraph)
     if (!csr)
@@ -2867,7 +2879,15 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         if (csr) hipLaunchKernelGGL(ec_pq_bwd_csr_kernel, grid4, dim3(256), 0, s, EcPqCsrArgs{a, p->csr_off, p->csr_edge});
         else hipLaunchKernelGGL(ec_pq_bwd_kernel, grid, dim3(256), 0, s, a);
     }
-    // ---- growth-weight gradients (partials), dx, dWpq
+    // ---- dx first: it is what the unit before this one waits for
+    if (p->dx) {
+        st = pf_gemm(p->dPQ, 2 * d.S, 1, p->Wpq, p->C, 1, p->dx, p->C, nullptr, d.T, p->C, 2 * d.S, gws,
+                     pf_gemm_ws_floats(d.T, p->C, 2 * d.S), stream);
+        if (st) return st;
+    }
+    // ---- growth-weight gradients (partials), dWpq, assembly: nobody reads them before the optimizer
+    hipStream_t sm = s;                                   // (the kernels below are written with `s` and `stream`)
+    if (dw_side) { s = pf_dw_fork(sm); stream = (void*)s; }
     {
         EcDwArgs a{p->dA, p->Y, d.GT, p->aff, p->dout, p->arg, p->dout, p->pooling, g, d.GT, p->odim, d.S, p->K, d.E, EC_DW_CHUNK,
                    p->slope, dwpart, bpart};
@@ -2909,21 +2929,16 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
             hipLaunchKernelGGL(ec_dw_kernel<EC_DW_WAVES>, dim3(d.nchunk, 2), dim3(64 * EC_DW_WAVES), lds, s, a);
         }
     }
-    if (p->dx) {
-        st = pf_gemm(p->dPQ, 2 * d.S, 1, p->Wpq, p->C, 1, p->dx, p->C, nullptr, d.T, p->C, 2 * d.S, gws,
-                     pf_gemm_ws_floats(d.T, p->C, 2 * d.S), stream);
-        if (st) return st;
-    }
     // slabs of the small-C kernel: as many as the GEMM scratch of this unit holds, at most 128
     const long long dw_cap = gemm_ws_max(p, d) / ((long long)2 * d.S * p->C);
     const int dw_want = (int)(dw_cap < 128 ? dw_cap : 128);
     const int dw_chunk = dw_want > 0 ? (d.T + dw_want - 1) / dw_want : d.T, dw_slabs = (d.T + dw_chunk - 1) / dw_chunk;
     if (p->C <= 4 && dw_want >= 16) {
         hipLaunchKernelGGL(ec_dwpq_small_kernel, dim3(dw_slabs, (2 * d.S + 255) / 256), dim3(256), 0, s, p->dPQ, p->x, 2 * d.S, p->C,
-                           d.T, dw_chunk, gws);
-        st = pf_gemm_reduce(gws, p->dWpq, 2 * d.S, p->C, p->C, dw_slabs, stream);
+                           d.T, dw_chunk, gws_dw);
+        st = pf_gemm_reduce(gws_dw, p->dWpq, 2 * d.S, p->C, p->C, dw_slabs, stream);
     } else
-        st = pf_gemm(p->dPQ, 1, 2 * d.S, p->x, p->C, 1, p->dWpq, p->C, nullptr, 2 * d.S, p->C, d.T, gws,
+        st = pf_gemm(p->dPQ, 1, 2 * d.S, p->x, p->C, 1, p->dWpq, p->C, nullptr, 2 * d.S, p->C, d.T, gws_dw,
                      pf_gemm_ws_floats(2 * d.S, p->C, d.T), stream);
     if (st) return st;
     int total = 0;
@@ -3348,7 +3363,10 @@ __global__ __launch_bounds__(256) void bnl_reduce_kernel(const float* part, cons
     else dW[(size_t)c * ldw + coff + u] = (float)s;
 }
 
-constexpr int BNL_CHUNK = 256;
+#ifndef PF_BNL_CHUNK
+#define PF_BNL_CHUNK 256
+#endif
+constexpr int BNL_CHUNK = PF_BNL_CHUNK;
 
 int bnl_check(const PfBnMlpTrain* p) {
     if (!p) return PF_ERR_NULL;

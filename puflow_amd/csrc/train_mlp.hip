@@ -38,7 +38,10 @@ constexpr int MLP_LD = 144;            // LDS row stride of the weight-gradient 
 constexpr int MLP_EB = 32, MLP_DW_WAVES = PF_MLP_DW_WAVES, MLP_SLOTS = (36 + MLP_DW_WAVES - 1) / MLP_DW_WAVES;   // 36 = 4 x 9 tiles of the widest layer
 // rows per split-K chunk (multiple of MLP_EB): the descriptor's choice (batched launches have networks x layers of parallelism
 // already and want long chunks: fewer partial sums to write and add), else sized so that one network fills the chip
-__host__ __device__ inline int mlp_chunk(const PfMlpTrain& p) { return p.chunk > 0 ? p.chunk : (p.rows > 16384 ? 128 : 64); }
+#ifndef PF_MLP_CHUNK_BIG
+#define PF_MLP_CHUNK_BIG 128
+#endif
+__host__ __device__ inline int mlp_chunk(const PfMlpTrain& p) { return p.chunk > 0 ? p.chunk : (p.rows > 16384 ? PF_MLP_CHUNK_BIG : 64); }
 
 __device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 c) {
     c = pf_mfma(a.x, b.x, c); c = pf_mfma(a.y, b.y, c); c = pf_mfma(a.z, b.z, c); c = pf_mfma(a.w, b.w, c);
@@ -675,6 +678,7 @@ extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
     }
     const int chunk = mlp_chunk(*p);
     const int nchunk = (p->rows + chunk - 1) / chunk;
+    s = pf_dw_fork(s);                                   // weight gradients: on their own stream when one is set (pf_train_set_dw_stream)
     {
         int ramax = 0, rbmax = 0;
         for (int l = 0; l < p->nl; ++l) { ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l]; }
@@ -763,6 +767,7 @@ extern "C" int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_
     const PfMlpTrain* dd = (const PfMlpTrain*)dev_descs;
     if (descs[0].nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(gmax, 1, n), dim3(256), lds_b, s, b.p[0], dd); }
     else { allow_lds(mlp_bwd_kernel<3>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(gmax, 1, n), dim3(256), lds_b, s, b.p[0], dd); }
+    s = pf_dw_fork(s);                                   // (dev_descs must then be this call's own: the next upload is not ordered behind it)
     hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b.p[0], dd);
     hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(64 * MLP_RG), 0, s, b.p[0], dd);
     return pf_last_launch_status();
@@ -800,7 +805,7 @@ extern "C" int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_d
         tmax = total > tmax ? total : tmax;
         b.p[k] = *p;
     }
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = pf_dw_fork((hipStream_t)stream);     // all of it is weight-gradient work
     hipLaunchKernelGGL(mlp_desc_upload_kernel, dim3(1), dim3(256), 0, s, b, (unsigned*)dev_descs, (int)(n * sizeof(PfMlpTrain) / 4));
     const PfMlpTrain* dd = (const PfMlpTrain*)dev_descs;
     hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b.p[0], dd);

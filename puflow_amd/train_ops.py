@@ -334,6 +334,76 @@ def deterministic() -> bool:
     return _DET
 
 
+# Weight gradients beside the backward chain (csrc/api.hip pf_train_set_dw_stream) - an opt-in that did NOT pay at the bench
+# shape.  The backward of a unit produces the gradient of its input - which the unit before it waits for - and the gradients of
+# its weights, which nothing reads before the optimizer: with the switch on (`net.train_dw_stream = True` / cfg.dw_stream, or
+# PF_TRAIN_DW_STREAM=1; =0 forces it off) the split-K weight-gradient kernels and their reductions of the EdgeConv units and the
+# conditioner / merge MLPs go to one more stream (a third parallel branch of the captured step), ~0.9 ms of the main chain's
+# ~3.9 ms of kernels at 32 x (256 -> 1024).  Their workspaces come from that stream's own pool, every buffer they read is kept
+# alive until the join, and the join - the calling stream waits for the weight-gradient stream - is an autograd end-of-pass
+# callback, queued by the first backward function that uses the stream: whoever reads `.grad` after `backward()` sees finished
+# gradients, eager or captured.  Same kernels, same arithmetic, same bits (tests/test_gpu_train.py).  Measured, same box, two
+# rounds each: 4.54 -> 4.79 ms per captured step with the persistent EdgeConv kernels, 5.22 -> 5.31 without - the step is bound
+# by the SUM of its kernels' work (each of them fills the chip), not by the length of the dependent chain, and kernels that share
+# the chip slow each other down by more than the chain gets shorter.  (The flow chains stay on the calling stream in any case:
+# f and g share their parameters, so autograd adds their gradients there before any join.)
+_DW_ENV = os.environ.get("PF_TRAIN_DW_STREAM")
+_DW_NET = False
+_DW_STREAMS = {}
+_DW_PASS = {"pending": False, "keep": [], "streams": []}
+
+
+def _dw_join() -> None:
+    """End of the autograd pass (calling thread): the consumer of the gradients waits for the weight-gradient stream."""
+    for st in _DW_PASS["streams"]:
+        torch.cuda.current_stream(st.device).wait_stream(st)
+    _DW_PASS["pending"] = False
+    _DW_PASS["keep"] = []
+    _DW_PASS["streams"] = []
+
+
+def _dw_begin(dev, *keep):
+    """The weight-gradient stream for one backward call on `dev`, or None (switch off, SyncBN, not inside an autograd pass).
+    `keep`: tensors the side kernels read - held until the join so that the allocator cannot hand their memory to the main chain."""
+    if not (_DW_ENV == "1" or (_DW_ENV is None and _DW_NET)) or _sync_bn_active():
+        return None
+    if not _DW_PASS["pending"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_dw_join)
+        except RuntimeError:                               # a backward function called by hand, outside an autograd pass
+            return None
+        _DW_PASS["pending"] = True
+    st = _DW_STREAMS.get(dev)
+    if st is None:
+        st = _DW_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    if st not in _DW_PASS["streams"]:
+        _DW_PASS["streams"].append(st)
+    _DW_PASS["keep"].append(keep)
+    return st
+
+
+def _dw_ws(st, dev, n: int) -> Tensor:
+    with torch.cuda.stream(st):
+        return _ws(dev, n)
+
+
+class _dw_call:
+    """`with _dw_call(st):` around ONE backward entry point: the library's weight-gradient stream is a per-thread setting (the
+    autograd engine runs backward functions on its own device threads), set for exactly that call."""
+
+    def __init__(self, st):
+        self.st = st
+
+    def __enter__(self):
+        if self.st is not None:
+            _lib.load().pf_train_set_dw_stream(self.st.cuda_stream)
+
+    def __exit__(self, *exc):
+        if self.st is not None:
+            _lib.load().pf_train_set_dw_stream(None)
+        return False
+
+
 def _multi_rank() -> bool:
     import torch.distributed as dist
     from .dist import multi_rank
@@ -865,7 +935,12 @@ class EdgeConvUnitFn(Function):
             d.flags |= 2
         if len(cfg) > 12 and cfg[12]:
             _attach_sync(d, dev)
-        _lib.check(lib.pf_ec_train_bwd(ctypes.byref(d), _stream()), "pf_ec_train_bwd")
+        dwst = _dw_begin(dev, sv, dout, dA, dPQ, coef, dWpq, ws)
+        if dwst is not None:                                  # weight gradients on their own stream, with their own workspace
+            ws2 = _dw_ws(dwst, dev, need)
+            d.ws_dw, d.ws_dw_floats = ws2.data_ptr(), ws2.numel()
+        with _dw_call(dwst):
+            _lib.check(lib.pf_ec_train_bwd(ctypes.byref(d), _stream()), "pf_ec_train_bwd")
         return (dx, None, None, *dWs, *dbs, *dgs, *dbe)
 
 
@@ -1141,6 +1216,8 @@ class FlowChainFn(Function):
         d.part = ws.data_ptr()
         d.ws, d.ws_floats = ws.data_ptr() + 4 * npart, need
         d.dev_descs = _desc_buf(dev).data_ptr()
+        # (not on the weight-gradient stream: the f and the g chain share their parameters, so autograd ADDS the two chains'
+        # gradients on this stream as soon as the second one returns - before any join)
         _lib.check(lib.pf_flowchain_bwd(ctypes.byref(d), _stream()), "pf_flowchain_bwd")
         grads = [g.view(shp) for g, shp in zip(gp, pshapes)]
         return (None, None, None, None, dx, dcflat, dst, None, *grads)
@@ -1212,7 +1289,12 @@ class CondNetStackFn(Function):
             gp.append(flat[off:off + n_])
             off += n_
         need = [lib.pf_mlp_train_ws_floats(ctypes.byref(descs[k])) for k in range(n)]
-        ws = _ws(dev, sum(need))
+        dwst = _dw_begin(dev, sv, dst, dz, dc2, flat)
+        ws = _ws(dev, sum(need)) if dwst is None else _dw_ws(dwst, dev, sum(need))     # weight-gradient scratch only
+        ddesc = _desc_buf(dev)
+        if dwst is not None:                                  # the side kernels read the descriptors: this call's own copy
+            ddesc = torch.empty(16 * ctypes.sizeof(_lib.PfMlpTrain), dtype=torch.uint8, device=dev)
+            _DW_PASS["keep"].append((ddesc,))
         woff = 0
         for k in range(n):
             d = descs[k]
@@ -1225,7 +1307,8 @@ class CondNetStackFn(Function):
             d.ws, d.ws_floats = ws.data_ptr() + 4 * woff, need[k]
             woff += need[k]
             descs[k] = d
-        _lib.check(lib.pf_mlp_train_bwd_batch(descs, n, _desc_buf(dev).data_ptr(), _stream()), "pf_mlp_train_bwd_batch")
+        with _dw_call(dwst):
+            _lib.check(lib.pf_mlp_train_bwd_batch(descs, n, ddesc.data_ptr(), _stream()), "pf_mlp_train_bwd_batch")
         return (None, None, dc2[0] + dc2[1], *[g.view(p.shape) for g, p in zip(gp, prm)])
 
 
@@ -1296,9 +1379,11 @@ class MlpFn(Function):
         need = lib.pf_mlp_train_ws_floats(ctypes.byref(d))
         if need < 0:
             raise _lib.PuflowHipError("pf_mlp_train: unsupported shape")
-        ws = _ws(c.device, need)
+        dwst = _dw_begin(c.device, list(ctx.saved_tensors), dout, dzs, hs)
+        ws = _ws(c.device, need) if dwst is None else _dw_ws(dwst, c.device, need)     # weight-gradient scratch only
         d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
-        _lib.check(lib.pf_mlp_train_bwd(ctypes.byref(d), _stream()), "pf_mlp_train_bwd")
+        with _dw_call(dwst):
+            _lib.check(lib.pf_mlp_train_bwd(ctypes.byref(d), _stream()), "pf_mlp_train_bwd")
         grads = []
         for l in range(nl):
             grads += [dWs[l], dbs[l]]
@@ -1542,6 +1627,8 @@ def knn_csr(idx: Tensor):
     cnt = torch.empty((T + 3) // 4 * 4, dtype=torch.int32, device=dev)
     _lib.check(_lib.load().pf_knn_csr(idx.data_ptr(), B, N, K, off.data_ptr(), edge.data_ptr(), cnt.data_ptr(), _stream()),
                "pf_knn_csr")
+    if _DET:                                               # one summation order over every list, run after run
+        _lib.check(_lib.load().pf_knn_csr_sort(off.data_ptr(), edge.data_ptr(), T, _stream()), "pf_knn_csr_sort")
     return off, edge
 
 
@@ -1688,6 +1775,8 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     global _NBT_PENDING
     _NBT_PENDING = []
     set_deterministic(getattr(net, "deterministic", False))
+    global _DW_NET
+    _DW_NET = bool(getattr(net, "train_dw_stream", False))
     try:
         with sync_bn(getattr(net, "sync_batchnorm", False)):
             return _forward_train(net, xyz, upratio)

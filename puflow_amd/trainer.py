@@ -33,7 +33,7 @@ def default_cfg(**kw):
     # persistent_kernels: the training step's grid-barrier kernels (EdgeConv units as one launch each).  None = on, unless
     # emd_workgroups == 1 says the device is shared with other processes (grid barriers need every workgroup resident)
     cfg = dict(net="UpsamplingFlow", learning_rate=1e-3, sched_patience=10, sched_factor=0.5, seed=2021, sync_batchnorm=False,
-               fused_optimizer=True, emd_workgroups=0, persistent_kernels=None, deterministic=False)
+               fused_optimizer=True, emd_workgroups=0, persistent_kernels=None, deterministic=False, dw_stream=False)
     cfg.update(kw)
     return SimpleNamespace(**cfg)
 
@@ -49,6 +49,9 @@ class TrainerModule(_Base):
         self.network = PointInterpFlow(pc_channel=3)
         self.network.sync_batchnorm = bool(getattr(self.cfg, "sync_batchnorm", False))     # an argument of its train-mode forward
         self.network.deterministic = bool(getattr(self.cfg, "deterministic", False))
+        # weight gradients on their own stream beside the backward chain (train_ops._dw_begin): measured slower at the bench shape
+        # (4.54 -> 4.79 ms per step), so an opt-in
+        self.network.train_dw_stream = bool(getattr(self.cfg, "dw_stream", False))
         pk = getattr(self.cfg, "persistent_kernels", None)
         self.network.train_persistent = bool(pk) if pk is not None else int(getattr(self.cfg, "emd_workgroups", 0)) != 1
         # cfg.emd_workgroups: workgroups per sample of the EMD auction (0 = chosen from the device, 1 = safe on a GPU that is

@@ -426,6 +426,55 @@ def test_deterministic_switch_makes_the_step_bit_reproducible():
     train_ops.set_deterministic(False)
 
 
+def test_weight_gradient_stream_changes_no_bit():
+    """The split-K weight-gradient kernels of the EdgeConv units, the conditioner MLPs and the flow chains run on one more stream
+    beside the backward chain (train_ops._dw_begin, csrc/api.hip pf_train_set_dw_stream), joined by an autograd end-of-pass
+    callback.  Same kernels on the same data: under cfg.deterministic the loss and EVERY gradient element are the bits of the
+    one-chain order (cfg.dw_stream = False), step after step - eagerly, and replayed from a captured graph with the graph's
+    optimizer step applied (so the join really is ahead of the consumer)."""
+    from puflow_amd.trainer import TrainerModule, default_cfg
+    from puflow_amd import train_ops
+    dense = ((synth_patches(8, 1024, seed=5) + 1) / 2).to(DEV)
+    batch = (dense[:, ::4].contiguous(), dense, torch.ones(8, device=DEV))
+
+    def run(dw, graphed):
+        torch.manual_seed(0)
+        tm = TrainerModule(default_cfg(learning_rate=1e-3, deterministic=True, dw_stream=dw), loss_mix="pugan")
+        tm.network.load_state_dict(synth_state_dict(21))
+        tm = tm.to(DEV).train()
+        tm._sync_actnorm_init(batch)
+        out = []
+        if graphed:
+            opt = tm.configure_optimizers()["optimizer"]
+            gs = tm.graphed_train_step(batch, opt, warmup=1)
+            for _ in range(3):
+                out.append(float(gs(batch)))
+            torch.cuda.synchronize()
+            return out, {k: p.detach().clone() for k, p in tm.named_parameters()}
+        for _ in range(3):         # the first pass initialises ActNorm (per-block autograd nodes), the next ones run the chain kernels
+            tm.zero_grad(set_to_none=True)
+            loss = tm.training_step(batch, 0)
+            loss.backward()
+            # no device-wide synchronize here: whoever reads .grad on the CURRENT stream must see finished gradients
+            out.append((float(loss), {k: p.grad.detach().clone() for k, p in tm.named_parameters() if p.grad is not None}))
+        return out
+
+    try:
+        ra, rb = run(True, False), run(False, False)
+        assert train_ops._DW_STREAMS, "the weight-gradient stream was never used"
+        for (la, ga), (lb, gb) in zip(ra, rb):
+            assert la == lb, (la, lb)
+            assert ga.keys() == gb.keys() and len(ga) > 150
+            bad = [k for k in ga if not torch.equal(ga[k], gb[k])]
+            assert not bad, bad[:5]
+        (la, pa), (lb, pb) = run(True, True), run(False, True)
+        assert la == lb, (la, lb)
+        bad = [k for k in pa if not torch.equal(pa[k], pb[k])]
+        assert not bad, bad[:5]
+    finally:
+        train_ops.set_deterministic(False)
+
+
 def test_side_stream_branch_of_the_training_forward_changes_nothing():
     """The interpolation weights of the train-mode forward run on a side stream beside the feature extractor / flow f chain
     (a parallel branch of a captured step).  Same loss, same outputs, same gradients as the one-stream order (float atomics of
