@@ -290,6 +290,9 @@ __device__ __forceinline__ float pf_rsmax16(float a, float b) {
 #ifndef PF_MMN_TERMS
 #define PF_MMN_TERMS 3
 #endif
+#ifndef PF_MMN_PRIO
+#define PF_MMN_PRIO 0
+#endif
 template <bool SWAP, int OB, int CP, int WCP, bool FENCE = true, class WS, int P, int NIN, int NACC>
 __device__ __forceinline__ void pf_mmn(const WS& ws, int frag0, const PfPairN (&feat)[P][NIN], f4 (&acc)[P][NACC], int in0 = 0, int acc0 = 0) {
     constexpr int D = WS::DEPTH;                  // fragments in flight: 2 from LDS, 8 behind buffer loads (L2 latency)
@@ -303,6 +306,9 @@ __device__ __forceinline__ void pf_mmn(const WS& ws, int frag0, const PfPairN (&
     for (int i = 0; i < DD; ++i)
 #pragma unroll
         for (int s = 0; s < 2; ++s) wb[i][s] = ws.load(frag0 + OBI(i) * WCP + CPI(i), s);
+#if PF_MMN_PRIO
+    __builtin_amdgcn_s_setprio(PF_MMN_PRIO);      // tuning build: a wave inside an MFMA chain wins the issue arbitration
+#endif
 #pragma unroll
     for (int i = 0; i < NFRAG; ++i) {
         const int ob = OBI(i), cp = CPI(i);
@@ -332,6 +338,9 @@ __device__ __forceinline__ void pf_mmn(const WS& ws, int frag0, const PfPairN (&
         }
         if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);      // FENCE = false: the caller interleaves two streams itself
     }
+#if PF_MMN_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 
