@@ -1078,7 +1078,8 @@ def bench_pugan(args, world, rank, dev, dist):
             st["network"], cand = ev_ms(lambda: PatchHelper.upsampling_patches(net, patches, UP))
             M = cand.shape[1] * cand.shape[2]
             flat = cand.reshape(B, M, 3).contiguous()
-            st["fps_merge"], _ = ev_ms(lambda: ops.furthest_point_sample(flat, npoint))
+            GRP = cand.shape[2]                                                        # candidates per patch: the merge's layout hint
+            st["fps_merge"], _ = ev_ms(lambda: ops.furthest_point_sample(flat, npoint, group=GRP))
             den = PatchHelper.merge_patches(cand, npoint).transpose(1, 2).contiguous()
             st["remove_outliers"], _ = ev_ms(lambda: PatchHelper.remove_outliers(den, pc, NOUT))
             # ---- dominant kernel: the cooperative FPS merge (fps_coopm_kernel).  One launch = B clouds x G workgroups; a cloud's
@@ -1089,13 +1090,15 @@ def bench_pugan(args, world, rank, dev, dist):
             idx1 = torch.zeros((1, npoint), dtype=torch.int32, device=dev)
             one = flat[:1].contiguous()
             s = torch.cuda.current_stream().cuda_stream
-            one_ms, _ = ev_ms(lambda: _lib.check(lib.pf_fps(one.data_ptr(), 1, M, npoint, mind.data_ptr(), idx1.data_ptr(), s), "pf_fps"))
+            one_ms, _ = ev_ms(lambda: _lib.check(lib.pf_fps_grouped(one.data_ptr(), 1, M, npoint, GRP, mind.data_ptr(), idx1.data_ptr(), s), "pf_fps"))
             stride, word = ctypes.c_longlong(0), ctypes.c_longlong(0)
             coop = bool(lib.pf_fps_scratch_layout(M, ctypes.byref(stride), ctypes.byref(word)))
             rounds = int(mind.view(-1)[: M // 2 * 2].view(torch.int64)[word.value + 1].item()) if coop else npoint
             ppt = 4 if M >= 16 * 256 else 1                                           # pf_fps's choice of points per thread and
             while -(-M // (256 * ppt)) > 32:                                            # workgroups per cloud (csrc/patch_ops.hip)
                 ppt *= 2
+            if GRP % 64 == 0 and GRP // 64 in (12, 20, 24) and -(-M // (256 * (GRP // 64))) <= 32:
+                ppt = GRP // 64                                                          # one patch per wave (pf_fps_grouped)
             G = -(-M // (256 * ppt))
             ring = torch.zeros(2048, dtype=torch.int64, device=dev)
             PROBE_ROUNDS = 20000

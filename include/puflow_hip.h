@@ -530,6 +530,11 @@ int pf_clip_adam(float* flat_g, float* m, float* v, float* const* params, const 
  * 8-byte aligned (running min-distances, or - clouds of >= 8192 points, <= 32 cooperating workgroups per cloud -
  * the candidate exchange ring; overwritten either way). */
 int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, int* idx_out, void* stream);
+/* the same samples (bit for bit) with a layout hint: group > 0 = every `group` consecutive points are one spatial neighbourhood
+ * (PatchHelper.merge_pc, modules/utils/patch.py:142-165: the candidates arrive patch after patch, 256 x (upratio + 1) each).  For
+ * group = 768 / 1280 / 1536 a wave of the cooperative kernel then holds exactly one neighbourhood, whose bounding box lets it skip
+ * the samples that cannot reach it.  group = 0 or any other value: pf_fps. */
+int pf_fps_grouped(const float* xyz, int B, int N, int npoint, int group, float* mind, int* idx_out, void* stream);
 
 /* Layout of pf_fps's scratch when the cooperative kernel runs (return value 1; 0 = single-workgroup kernel, no ring):
  * cloud b's ring starts at 64-bit word b * stride_words of `mind`; word `abort_word` of a ring is the cloud's status after

@@ -142,6 +142,7 @@ SIGNATURES = {
     "pf_batch_sum_bwd": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p]),
     "pf_dist_feature": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pf_fps": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pf_fps_grouped": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_fps_scratch_layout": (c_int, [c_int, POINTER(c_longlong), POINTER(c_longlong)]),
     "pf_fps_exchange_probe": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "pf_flow_params_fwd": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),

@@ -407,7 +407,7 @@ __device__ __forceinline__ fps_f2 sqd2(fps_f2 ax, fps_f2 ay, fps_f2 az, float bx
 }
 
 template <int PPT>
-__global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : 2)) void fps_coopm_kernel(const float* __restrict__ xyz, int N,
+__global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : (PPT <= 24 ? 3 : 2))) void fps_coopm_kernel(const float* __restrict__ xyz, int N,
                                                                                  int npoint, int G,
                                                                                  unsigned long long* __restrict__ ringbuf,
                                                                                  long long ring_stride, int* __restrict__ out) {
@@ -827,15 +827,31 @@ extern "C" int pf_fps_scratch_layout(int N, long long* stride_words, long long* 
 }
 
 // xyz [B,N,3] -> idx [B,npoint] int32; mind: [B,N] float scratch
+// points per thread of the cooperative kernel.  `group` > 0: the caller says that every `group` consecutive points are one
+// spatial neighbourhood (the CLI's merge: 1280 candidates per patch); when a wave can hold exactly one group (64 x 12 / 20 / 24
+// points) its bounding box is that neighbourhood's, which is what the culling of fps_coopm_kernel lives on.
+static int fps_ppt(int N, int group) {
+    if (fps_mode() == 3 && group > 0 && group % 64 == 0) {
+        const int p = group / 64;
+        if ((p == 12 || p == 20 || p == 24) && (N + FPSC_T * p - 1) / (FPSC_T * p) <= FPSC_GMAX && N >= FPSC_T * p * 2) return p;
+    }
+    int ppt = N >= 16 * FPSC_T ? 4 : 1;                                               // fewer, fuller workgroups
+    while ((N + FPSC_T * ppt - 1) / (FPSC_T * ppt) > FPSC_GMAX) ppt *= 2;              // -> 1, 4, 8 (16, 32) points per thread
+    return ppt;
+}
+
 extern "C" int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, int* idx_out, void* stream) {
+    return pf_fps_grouped(xyz, B, N, npoint, 0, mind, idx_out, stream);
+}
+
+extern "C" int pf_fps_grouped(const float* xyz, int B, int N, int npoint, int group, float* mind, int* idx_out, void* stream) {
     if (!xyz || !mind || !idx_out) return PF_ERR_NULL;
-    if (B <= 0 || N <= 0 || npoint <= 0 || npoint > N) return PF_ERR_SHAPE;
+    if (B <= 0 || N <= 0 || npoint <= 0 || npoint > N || group < 0) return PF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     // cooperative kernel when the cloud is worth more than one CU; the candidate ring (4 x 32 + 1 64-bit words)
     // lives at the start of each cloud's N-float scratch row
     if (N >= 8192 && N <= FPSC_GMAX * 1024 * 8 && ((size_t)mind & 7) == 0) {
-        int ppt = N >= 16 * FPSC_T ? 4 : 1;                                           // fewer, fuller workgroups
-        while ((N + FPSC_T * ppt - 1) / (FPSC_T * ppt) > FPSC_GMAX) ppt *= 2;          // -> 1, 4, 8 (16, 32) points per thread
+        const int ppt = fps_ppt(N, group);
         const int G = (N + FPSC_T * ppt - 1) / (FPSC_T * ppt);
         const long long stride = ((long long)N / 2) & ~1ll;                           // 64-bit words per cloud
         unsigned long long* ring = reinterpret_cast<unsigned long long*>(mind);
@@ -848,13 +864,18 @@ extern "C" int pf_fps(const float* xyz, int B, int N, int npoint, float* mind, i
         if (fps_mode() == 3) hipLaunchKernelGGL(fps_coopm_kernel<PPT>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); \
         else if (fps_mode() == 2) hipLaunchKernelGGL(fps_coop2_kernel<PPT>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out); \
         else hipLaunchKernelGGL(fps_coop_kernel<PPT>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out)
+#define PF_FPS_LAUNCHM(PPT) hipLaunchKernelGGL(fps_coopm_kernel<PPT>, grid, block, 0, s, xyz, N, npoint, G, ring, stride, idx_out)
         switch (ppt) {
             case 1: PF_FPS_LAUNCH(1); break;
             case 4: PF_FPS_LAUNCH(4); break;
             case 8: PF_FPS_LAUNCH(8); break;
+            case 12: PF_FPS_LAUNCHM(12); break;                                        // (group-aligned shapes: fps_mode() == 3 only)
             case 16: PF_FPS_LAUNCH(16); break;
+            case 20: PF_FPS_LAUNCHM(20); break;
+            case 24: PF_FPS_LAUNCHM(24); break;
             default: PF_FPS_LAUNCH(32); break;
         }
+#undef PF_FPS_LAUNCHM
 #undef PF_FPS_LAUNCH
         return pf_last_launch_status();
     }

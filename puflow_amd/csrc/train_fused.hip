@@ -39,7 +39,10 @@ extern "C" long long pf_gemm_ws_floats(int M, int N, int K);
 
 namespace {
 
-constexpr int EC_GRID = 512;          // persistent workgroups of the per-edge kernels (2 per CU)
+#ifndef PF_EC_GRID
+#define PF_EC_GRID 512
+#endif
+constexpr int EC_GRID = PF_EC_GRID;   // persistent workgroups of the per-edge kernels (2 per CU)
 
 __device__ __forceinline__ float lrelu1(float v, float s) { return fmaxf(v, v * s); }
 __device__ __forceinline__ f4 lrelu4(f4 z, float s) {

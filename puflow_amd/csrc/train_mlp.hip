@@ -24,7 +24,10 @@
 
 namespace {
 
-constexpr int MLP_GRID = 512;
+#ifndef PF_MLP_GRID
+#define PF_MLP_GRID 512
+#endif
+constexpr int MLP_GRID = PF_MLP_GRID;
 #ifndef PF_MLP_DW_WAVES
 #define PF_MLP_DW_WAVES 4
 #endif

@@ -145,14 +145,16 @@ class chamfer_3DDist:
 # ----------------------------------------------------------------------------------------
 # Patch pipeline operators (pointnet2_ops / knn_cuda surfaces used by modules/utils/patch.py)
 # ----------------------------------------------------------------------------------------
-def furthest_point_sample(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
-    """pointnet2_ops.pointnet2_utils.furthest_point_sample: xyz [B,N,3] -> int32 [B,npoint] (starts at index 0)."""
+def furthest_point_sample(xyz: torch.Tensor, npoint: int, group: int = 0) -> torch.Tensor:
+    """pointnet2_ops.pointnet2_utils.furthest_point_sample: xyz [B,N,3] -> int32 [B,npoint] (starts at index 0).
+    group > 0: a layout hint, not a change of the result - every `group` consecutive points are one spatial neighbourhood
+    (pf_fps_grouped: the cooperative kernel then gives a wave exactly one neighbourhood when it can)."""
     lib = _lib.load()
     xyz = _f32c(xyz)
     B, N, _ = xyz.shape
     idx = torch.zeros((B, npoint), dtype=torch.int32, device=xyz.device)
     mind = torch.empty((B, N), dtype=torch.float32, device=xyz.device)
-    _lib.check(lib.pf_fps(xyz.data_ptr(), B, N, npoint, mind.data_ptr(), idx.data_ptr(), _stream()), "pf_fps")
+    _lib.check(lib.pf_fps_grouped(xyz.data_ptr(), B, N, npoint, int(group), mind.data_ptr(), idx.data_ptr(), _stream()), "pf_fps")
     _check_fps_abort(lib, mind, B, N)
     return idx
 

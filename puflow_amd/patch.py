@@ -77,12 +77,13 @@ class PatchHelper(object):
     # ---- patch.py:142-158
     @staticmethod
     def merge_patches(patches: Tensor, npoint: int, origins: Tensor = None) -> Tensor:
-        B, _, _, C = patches.shape
+        B, _, per_patch, C = patches.shape
         patches = patches.reshape(B, -1, C)
         if origins is not None:
             patches = torch.cat([patches, origins], dim=1)
         patches = patches.contiguous()
-        idx = ops.furthest_point_sample(patches, npoint)
+        # layout hint (same indices, bit for bit): the candidates arrive patch after patch, `per_patch` consecutive points each
+        idx = ops.furthest_point_sample(patches, npoint, group=per_patch if origins is None else 0)
         return ops.gather_operation(patches.transpose(1, 2).contiguous(), idx)     # [B,3,npoint]
 
     # ---- patch.py:168-178

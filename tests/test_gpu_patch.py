@@ -29,6 +29,31 @@ def test_fps_bit_exact(B, N, npoint):
     assert got[:, 0].eq(0).all()
 
 
+@pytest.mark.parametrize("group,N,npoint", [(768, 30720, 3001), (1280, 99840, 1500), (1280, 20480, 2048), (1536, 36864, 777), (640, 20480, 500)])
+def test_fps_group_hint_changes_no_index(group, N, npoint):
+    """pf_fps_grouped: the layout hint of the merge (every `group` consecutive points are one patch) gives a wave of the
+    cooperative kernel exactly one patch (12 / 20 / 24 points per thread) - other points per thread, other workgroups per cloud,
+    the same samples bit for bit: against the oracle, on patch-ordered clouds with duplicates and on clouds in no order; a group
+    the kernel has no shape for (640) is ignored."""
+    from puflow_amd import ops
+    g = torch.Generator().manual_seed(group + N)
+    base = torch.nn.functional.normalize(torch.randn(2, 2000, 3, generator=g), dim=-1)
+    npatch = N // group
+    seeds = base[:, torch.randperm(2000, generator=g)[:npatch]]
+    nn = torch.cdist(seeds, base).topk(128, largest=False).indices
+    pts = torch.gather(base.unsqueeze(1).expand(2, npatch, 2000, 3), 2, nn.unsqueeze(-1).expand(2, npatch, 128, 3))
+    rep = -(-group // 128)
+    pts = (pts.repeat_interleave(rep, dim=2)[:, :, :group] + 0.01 * torch.randn(2, npatch, group, 3, generator=g))
+    xyz = pts.reshape(2, N, 3).contiguous()
+    xyz[0, 5] = xyz[0, 9]                              # duplicates: ties resolve to the first maximum
+    xyz[1] = xyz[1, torch.randperm(N, generator=g)]    # second cloud: the same kind of points in no order (the hint is then wrong, not harmful)
+    ref = P.fps(xyz, npoint)
+    plain = ops.furthest_point_sample(xyz.to(DEV), npoint)
+    hinted = ops.furthest_point_sample(xyz.to(DEV), npoint, group=group)
+    assert torch.equal(plain.cpu().long(), ref)
+    assert torch.equal(hinted, plain)
+
+
 @pytest.mark.parametrize("sites,N,npoint", [(3, 8736, 617), (5, 11684, 2428), (9, 10000, 900), (2, 9000, 40)])
 def test_fps_on_lattices_and_past_the_last_distinct_point(sites, N, npoint):
     """Cooperative FPS on lattice clouds: thousands of exact ties, and (first two cases) more samples than distinct points -
