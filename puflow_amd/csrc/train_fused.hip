@@ -2135,6 +2135,9 @@ __device__ __forceinline__ Bf2 dw3_split(const float (&x)[8]) {
     return r;
 }
 
+#ifndef PF_EC_DW3_DEPTH
+#define PF_EC_DW3_DEPTH 1
+#endif
 __global__ __launch_bounds__(512) void ec_dw3_kernel(EcDw2Args g2) {
     const EcDwArgs& a = g2.d;
     // the wave index through readfirstlane: its job (row strip, column tile count) is then wave-uniform to the compiler - scalar
@@ -2158,39 +2161,46 @@ __global__ __launch_bounds__(512) void ec_dw3_kernel(EcDw2Args g2) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float asum = 0.f;
-    float an[8], bn[4][8];                               // the next 16-edge step's operands, in flight
-    auto fetch = [&](int e0) {
+    // PF_EC_DW3_DEPTH 16-edge steps' operands in flight.  Measured (round 5, same box, whole step): depth 1 4.566 ms, 2 4.571,
+    // 3 4.58 - 4.79: the kernel does not wait for its loads
+    float an[PF_EC_DW3_DEPTH][8], bn[PF_EC_DW3_DEPTH][4][8];
+    auto fetch = [&](int e0, float (&an_)[8], float (&bn_)[4][8]) {
         if (outj && a.pooled) {
             const int ii = e0 >> 4;
             const float dv = a.dh[(size_t)ii * a.odim + crow];
             const int kk = a.arg[(size_t)ii * a.odim + crow];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) an[j] = (8 * h + j == kk) ? dv : 0.f;
+            for (int j = 0; j < 8; ++j) an_[j] = (8 * h + j == kk) ? dv : 0.f;
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const size_t e = (size_t)(e0 + 8 * h + j);
-                an[j] = outj ? a.dyout[e * a.odim + crow] : a.dY[e * a.ld + crow];
+                an_[j] = outj ? a.dyout[e * a.odim + crow] : a.dY[e * a.ld + crow];
             }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float* yr = a.Y + (size_t)(e0 + 8 * h + j) * a.ld + col;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bn[t][j] = t < jb.nct ? yr[t * 32] : 0.f;
+            for (int t = 0; t < 4; ++t) bn_[t][j] = t < jb.nct ? yr[t * 32] : 0.f;
         }
     };
-    if (e_lo < e_hi) fetch(e_lo);
-    for (int e0 = e_lo; e0 < e_hi; e0 += 16) {
+#pragma unroll
+    for (int u = 0; u < PF_EC_DW3_DEPTH; ++u)
+        if (e_lo + 16 * u < e_hi) fetch(e_lo + 16 * u, an[u], bn[u]);
+    for (int e0 = e_lo; e0 < e_hi; e0 += 16 * PF_EC_DW3_DEPTH)
+#pragma unroll
+    for (int u = 0; u < PF_EC_DW3_DEPTH; ++u) {
+        if (e0 + 16 * u >= e_hi) break;
         float ac[8], bc[4][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            ac[j] = an[j];
-            asum += an[j];
+            ac[j] = an[u][j];
+            asum += an[u][j];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bc[t][j] = bn[t][j];
+            for (int t = 0; t < 4; ++t) bc[t][j] = bn[u][t][j];
         }
-        if (e0 + 16 < e_hi) fetch(e0 + 16);
+        if (e0 + 16 * (u + PF_EC_DW3_DEPTH) < e_hi) fetch(e0 + 16 * (u + PF_EC_DW3_DEPTH), an[u], bn[u]);
         const Bf2 A = dw3_split(ac);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -2220,6 +2230,128 @@ __global__ __launch_bounds__(512) void ec_dw3_kernel(EcDw2Args g2) {
                 const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;
                 out[(size_t)ri * a.GT + t * 32 + col] = acc[t][r];
             }
+}
+
+// Round 5: TWO row strips per wave.  ec_dw3_kernel ran at the VALU rate: every wave loads its own copy of the B operand
+// act(Y) - BatchNorm + LeakyReLU + the bf16 split of 32 values per lane and 16-edge step - although it is the same for all row
+// strips; staging it once per workgroup through LDS (ec_dw4_kernel below) lost to its own barriers.  Here a wave simply owns
+// two strips (jobs 2 w and 2 w + 1; the launcher orders the jobs so that a pair's tile counts add up evenly): the B tile is
+// converted once for both, the conversions per MFMA fall from 5/4 to 6/8, eight accumulator tiles live in the (unified)
+// register file.  Same operands, same split, same product order per (strip, tile): the partials are bit for bit those of
+// ec_dw3_kernel.
+// MEASURED NEGATIVE (round 5, same box): the step 4.68 against 4.53 ms with ec_dw3_kernel - 343 registers leave one wave per
+// SIMD, and the strip's dependent MFMA chains (3 products per tile into one accumulator) then have nothing to interleave with.
+// Kept for the A/B only (-DPF_EC_DW5=1).
+#ifndef PF_EC_DW5
+#define PF_EC_DW5 0
+#endif
+__global__ __launch_bounds__(256) void ec_dw5_kernel(EcDw2Args g2) {
+    const EcDwArgs& a = g2.d;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+    const int j0 = 2 * wave;
+    if (j0 >= g2.njob) return;
+    const bool two = j0 + 1 < g2.njob;
+    const EcDw2Job jb[2] = {g2.job[j0], g2.job[two ? j0 + 1 : j0]};
+    const int nct[2] = {jb[0].nct, two ? jb[1].nct : 0};
+    const int nctm = nct[0] > nct[1] ? nct[0] : nct[1];
+    const int e_lo = blockIdx.x * a.chunk, e_hi = min((int)a.E, e_lo + a.chunk);      // multiples of 16
+    const int crow[2] = {jb[0].rt * 32 + col, jb[1].rt * 32 + col};
+    const bool outj[2] = {jb[0].out != 0, jb[1].out != 0};
+    float sc[4], sh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = t * 32 + col;
+        sc[t] = t < nctm ? a.aff[c] : 0.f;
+        sh[t] = t < nctm ? a.aff[a.ld + c] : 0.f;
+    }
+    f16v acc[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][t][r] = 0.f;
+    float asum[2] = {0.f, 0.f};
+    float an[2][8], bn[4][8];                            // the next 16-edge step's operands, in flight
+    auto fetch = [&](int e0) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 1 && !two) break;
+            if (outj[s] && a.pooled) {
+                const int ii = e0 >> 4;
+                const float dv = a.dh[(size_t)ii * a.odim + crow[s]];
+                const int kk = a.arg[(size_t)ii * a.odim + crow[s]];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) an[s][j] = (8 * h + j == kk) ? dv : 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const size_t e = (size_t)(e0 + 8 * h + j);
+                    an[s][j] = outj[s] ? a.dyout[e * a.odim + crow[s]] : a.dY[e * a.ld + crow[s]];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* yr = a.Y + (size_t)(e0 + 8 * h + j) * a.ld + col;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bn[t][j] = t < nctm ? yr[t * 32] : 0.f;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) an[1][j] = 0.f;
+    if (e_lo < e_hi) fetch(e_lo);
+    for (int e0 = e_lo; e0 < e_hi; e0 += 16) {
+        float ac[2][8], bc[4][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ac[0][j] = an[0][j]; ac[1][j] = an[1][j];
+            asum[0] += an[0][j]; asum[1] += an[1][j];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bc[t][j] = bn[t][j];
+        }
+        if (e0 + 16 < e_hi) fetch(e0 + 16);
+        const Bf2 A0 = dw3_split(ac[0]), A1 = dw3_split(ac[1]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < nctm) {
+                float bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float z = fmaf(bc[t][j], sc[t], sh[t]);
+                    bv[j] = fmaxf(z, z * a.slope);
+                }
+                const Bf2 B = dw3_split(bv);
+                if (t < nct[0]) {
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0.mid, B.hi, acc[0][t], 0, 0, 0);
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0.hi, B.mid, acc[0][t], 0, 0, 0);
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0.hi, B.hi, acc[0][t], 0, 0, 0);
+                }
+                if (t < nct[1]) {
+                    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1.mid, B.hi, acc[1][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1.hi, B.mid, acc[1][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1.hi, B.hi, acc[1][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (s == 1 && !two) break;
+        const int rowbase = outj[s] ? a.GT : 0;
+        float as = asum[s];
+        as += __shfl_xor(as, 32);
+        if (h == 0) a.bpart[(size_t)blockIdx.x * a.S + rowbase + crow[s]] = as;
+        float* out = a.part + ((size_t)blockIdx.x * a.S + rowbase + jb[s].rt * 32) * a.GT;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < nct[s])
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    out[(size_t)ri * a.GT + t * 32 + col] = acc[s][t][r];
+                }
+    }
 }
 
 // Round 5: the same jobs with the B operand - act(Y), the SAME for all eight row strips - staged ONCE per workgroup.
@@ -2923,7 +3055,26 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
                 hipLaunchKernelGGL(ec_dw4_kernel, dim3(d.nchunk), dim3(512), lds, s, a2);
             } else
 #endif
+            {
+#if PF_EC_DW5
+                // two strips per wave: the conv_out strips pair up as they come (equal tile counts), the growth strips - tile
+                // counts descending - as (first, last), (second, second to last), ... so that every wave has about the same work
+                EcDw2Args a5 = a2;
+                int no = 0;
+                while (no < nj && a2.job[no].out) ++no;                 // conv_out jobs first in a2
+                int k = 0;
+                for (int i = 0; i < no; ++i) a5.job[k++] = a2.job[i];
+                if (no & 1) { a5.job[k++] = a2.job[nj - 1]; }           // an odd conv_out strip takes the lightest growth strip
+                const int g_lo = no, g_hi = (no & 1) ? nj - 1 : nj;     // growth jobs left: [g_lo, g_hi)
+                for (int lo = g_lo, hi = g_hi - 1; lo <= hi; ++lo, --hi) {
+                    a5.job[k++] = a2.job[lo];
+                    if (hi != lo) a5.job[k++] = a2.job[hi];
+                }
+                hipLaunchKernelGGL(ec_dw5_kernel, dim3(d.nchunk), dim3(64 * ((nj + 1) / 2)), 0, s, a5);
+#else
                 hipLaunchKernelGGL(ec_dw3_kernel, dim3(d.nchunk), dim3(64 * nj), 0, s, a2);
+#endif
+            }
 #endif
         } else {
             const int ramax = p->odim > d.GT ? p->odim : d.GT;
