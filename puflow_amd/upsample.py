@@ -75,6 +75,22 @@ def upsampling(data_paths: List[str], target_path: str, checkpoint_path: str, up
     # time unless asked otherwise.  The discrete model's patches never interact.
     if cloud_batch is None:
         cloud_batch = 16 if network_cls is PointInterpFlow else 1
+    # The host side of this loop is a 5000-element permutation and two small copies per file: ONE intra-op thread.  torch's
+    # default is one thread per visible CPU (128 on the MI355X boxes, whose containers own 16 CPUs' worth of quota): every tiny
+    # CPU op then wakes a pool of spinning OpenMP threads, the cgroup's CPU quota is gone within a few ms of each 100 ms period
+    # and the WHOLE process - the thread waiting for the GPU included - is throttled for the rest of it: a third of the clouds took
+    # 70 ms instead of 11 (tools/fps_interplay_probe.py shuffle [1]; round 5).
+    host_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        return _upsampling(data_paths, target_path, checkpoint_path, up_ratio, num_outlier, num_patch, num_upsampling, seed,
+                           state_dict, network_cls, cloud_batch)
+    finally:
+        torch.set_num_threads(host_threads)
+
+
+def _upsampling(data_paths, target_path, checkpoint_path, up_ratio, num_outlier, num_patch, num_upsampling, seed, state_dict,
+                network_cls, cloud_batch):
     if seed is not None:
         np.random.seed(seed)
         torch.random.manual_seed(seed)
