@@ -75,6 +75,10 @@ def main():
                     help="--mode cnf: integration end times of the six blocks - pu1k = those of the reference's trained checkpoint "
                          "(weights.CNF_PU1K_END_TIMES), init = 0.5 everywhere (cnf.py:41)")
     args = ap.parse_args()
+    # torch's CPU ops default to one OpenMP thread per VISIBLE CPU (128 on the MI355X boxes); a container owns far fewer CPUs' worth of
+    # quota, and a pool of spinning threads exhausts it within ms - the whole process, the thread waiting for the GPU included, is
+    # then throttled until the next 100 ms period.  Keep the host side within the CPUs the bench uses.
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), _ncpu())))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has made no GPU call

@@ -134,6 +134,8 @@ def train(phase: str = "Train", checkpoint_path: Optional[str] = None, begin_che
 def main(argv=None) -> None:
     from .data import SyntheticPatchData, patch_data_from_file
     a = model_specific_args().parse_args(argv)
+    from ._host import limit_host_threads
+    limit_host_threads()                       # torch's OpenMP pool within the container's CPU quota (puflow_amd/_host.py)
     if "RANK" in os.environ and not torch.distributed.is_initialized():
         torch.distributed.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
     rank, world = _dist()
