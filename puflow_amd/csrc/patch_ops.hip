@@ -588,6 +588,7 @@ __global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : (PPT <= 24 ? 3 : 2))) void
                 }
                 __builtin_amdgcn_wave_barrier();                            // s_ck is written again next round, after these reads
                 int m = 0;
+                int kx = 0, ky = 0, kz = 0, ki = 0;
                 for (;;) {
                     // this lane's best, then the wave's
                     unsigned long long f = ck[0];
@@ -614,9 +615,12 @@ __global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : (PPT <= 24 ? 3 : 2))) void
                     auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
                     const float sx = rl(fx, w), sy = rl(fy, w), sz = rl(fz, w);
                     const unsigned idx = (~lmax) & 0x1fffffffu;
-                    if (lane == 0) {
-                        sl[3 * m] = sx; sl[3 * m + 1] = sy; sl[3 * m + 2] = sz;
-                        if (g == 0) o[j + m] = (int)idx;
+                    // lane m keeps sample m (a select on the wave-uniform values): ONE LDS write and one index store per
+                    // lane after the chain instead of an exec-masked write + store per sample
+                    {
+                        const bool me = lane == m;
+                        kx = me ? __float_as_int(sx) : kx; ky = me ? __float_as_int(sy) : ky;
+                        kz = me ? __float_as_int(sz) : kz; ki = me ? (int)idx : ki;
                     }
                     ++m;
                     if (m == MS || j + m >= npoint || idx >= (unsigned)N) break;
@@ -627,6 +631,10 @@ __global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : (PPT <= 24 ? 3 : 2))) void
                         const unsigned kh = (unsigned)(ck[c] >> 32);
                         if (d < __uint_as_float(kh)) ck[c] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)ck[c];
                     }
+                }
+                if (lane < m) {
+                    sl[3 * lane] = __int_as_float(kx); sl[3 * lane + 1] = __int_as_float(ky); sl[3 * lane + 2] = __int_as_float(kz);
+                    if (g == 0) o[j + lane] = ki;
                 }
                 if (lane == 0) { sl[3 * MS] = (float)m; sl[3 * MS + 1] = 1.f; }
             }
