@@ -3124,6 +3124,9 @@ struct BnlFwdArgs {
     StatFin fin;
 };
 
+#ifndef PF_BNL_PREFETCH
+#define PF_BNL_PREFETCH 0
+#endif
 template <int NT>
 __global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
     extern __shared__ float lds[];
@@ -3161,24 +3164,37 @@ __global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
         bv[nt] = (a.bias && col < a.nout) ? a.bias[col] : 0.f;
         piv[nt] = (a.want_stats && a.fin.run_mean && col < a.nout) ? a.fin.run_mean[col] : 0.f;
     }
-    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
-        const int r0 = tile * 16;
-        const int rr = min(r0 + row, a.rows - 1);
+    // -DPF_BNL_PREFETCH=1: the NEXT tile's rows in flight while this one is multiplied (a wave has ~2 tiles at the bench shape and
+    // pays one memory latency for each).  MEASURED NEGATIVE (round 5, same box, whole step): 4.592 vs 4.557 ms - 32 more
+    // registers take the 128-wide shape from 3 to 2 waves per SIMD, and the branch runs beside the main chain anyway
+    auto loadx = [&](int tile, f4 (&xv_)[8]) {
+        const int rr = min(tile * 16 + row, a.rows - 1);
         const float* xrow = a.X + (size_t)rr * a.ldx;
-        f4 xv[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            xv[ks] = pf_splat(0.f);
+            xv_[ks] = pf_splat(0.f);
             const int u = ks * 16 + 4 * q;
             if (ks < KS && u < a.kin) {
-                if (vec) xv[ks] = *reinterpret_cast<const f4*>(xrow + u);
+                if (vec) xv_[ks] = *reinterpret_cast<const f4*>(xrow + u);
                 else {
 #pragma unroll
                     for (int w = 0; w < 4; ++w)
-                        if (u + w < a.kin) xv[ks][w] = xrow[u + w];
+                        if (u + w < a.kin) xv_[ks][w] = xrow[u + w];
                 }
             }
         }
+    };
+    f4 xn[8];
+    const int tstep = gridDim.x * 4;
+    if ((int)(blockIdx.x * 4 + wave) < a.ntiles) loadx(blockIdx.x * 4 + wave, xn);
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += tstep) {
+        const int r0 = tile * 16;
+        f4 xv[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xv[ks] = xn[ks];
+#if PF_BNL_PREFETCH
+        if (tile + tstep < a.ntiles) loadx(tile + tstep, xn);
+#endif
         f4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = pf_splat(0.f);
@@ -3210,6 +3226,9 @@ __global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
                 }
             }
         }
+#if !PF_BNL_PREFETCH
+        if (tile + tstep < a.ntiles) loadx(tile + tstep, xn);
+#endif
     }
     if (a.want_stats) stat_flush<NT>(s0, s1, 0, a.nout, a.fin, red);
 }
