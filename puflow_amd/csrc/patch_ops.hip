@@ -392,7 +392,7 @@ constexpr int FPSM_KW = PF_FPS_KW, FPSM_MS = PF_FPS_MS;
 #ifndef PF_FPS_NC
 #define PF_FPS_NC 2                                      // candidates per lane the chain of wave 0 works on
 #endif
-static_assert(FPSM_KW >= 2 && FPSM_KW <= 4, "2 .. 4 words per wave");
+static_assert(FPSM_KW >= 2 && 4 * FPSM_KW * FPSC_SLOTS + 2 <= 8192 / 2, "the ring must fit the scratch row of the smallest cooperative cloud (8192 points = 4096 words)");
 constexpr int FPSM_NC = PF_FPS_NC;
 constexpr int FPSC_SLOTSM = FPSM_KW * FPSC_SLOTS;
 constexpr int FPSC_RINGM = 4 * FPSC_SLOTSM;              // status word of this kernel's ring
