@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: randomised bit-exactness stress of the selection kernels against the CPU oracle - kNN (all slice counts, K, tie
-structures), nearest neighbour (Chamfer), cooperative FPS (one- and two-sample exchange paths are both taken inside one run:
-whether a round emits two samples depends on the data).  Not part of the test-suite (minutes of CPU oracle time); run once
+structures), nearest neighbour (Chamfer), cooperative FPS (how many samples a round emits depends on the data; with and without the layout hint).  Not part of the test-suite (minutes of CPU oracle time); run once
 after a change to csrc/knn.hip or csrc/patch_ops.hip:   python tools/stress_exact.py [seconds] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -67,8 +66,9 @@ while time.time() < t_end:
     n = int(torch.randint(8192, 30000, (1,), generator=g)); m = int(torch.randint(2, 3000, (1,), generator=g))
     c = cloud(int(torch.randint(1, 4, (1,), generator=g)), n, kind)
     ref = P.fps(c, m)
-    got = ops.furthest_point_sample(c.to(DEV), m)
-    assert torch.equal(got.cpu().long(), ref), ("fps", kind, tuple(c.shape), m)
+    grp = [0, 768, 1280, 1536][int(torch.randint(0, 4, (1,), generator=g))]         # the merge's layout hint: other points per thread /
+    got = ops.furthest_point_sample(c.to(DEV), m, group=grp)                        # workgroups per cloud, the same samples
+    assert torch.equal(got.cpu().long(), ref), ("fps", kind, tuple(c.shape), m, grp)
     n_fps += 1
     print(f"ok  kNN {n_knn}  nn1 {n_nn1}  fps {n_fps}   (last: {kind})", flush=True)
 print(f"stress passed: {n_knn} kNN, {n_nn1} nearest-neighbour, {n_fps} FPS configurations, all bit-identical to the oracle")
