@@ -367,12 +367,18 @@ def _dw_begin(dev, *keep):
     `keep`: tensors the side kernels read - held until the join so that the allocator cannot hand their memory to the main chain."""
     if not (_DW_ENV == "1" or (_DW_ENV is None and _DW_NET)) or _sync_bn_active():
         return None
-    if not _DW_PASS["pending"]:
+    # one join per autograd pass, keyed by the pass's id: a pass that died with an exception must not leave the next one without
+    tid = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else 0
+    if tid < 0:
+        return None                                        # a backward function called by hand, outside an autograd pass
+    if _DW_PASS["pending"] is not True or _DW_PASS.get("task") != tid:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_dw_join)
-        except RuntimeError:                               # a backward function called by hand, outside an autograd pass
+        except RuntimeError:
             return None
-        _DW_PASS["pending"] = True
+        if _DW_PASS.get("task") != tid:                    # leftovers of a pass that never reached its join
+            _DW_PASS["keep"], _DW_PASS["streams"] = [], []
+        _DW_PASS["pending"], _DW_PASS["task"] = True, tid
     st = _DW_STREAMS.get(dev)
     if st is None:
         st = _DW_STREAMS[dev] = torch.cuda.Stream(device=dev)
