@@ -398,6 +398,7 @@ constexpr int FPSC_SLOTSM = FPSM_KW * FPSC_SLOTS;
 constexpr int FPSC_RINGM = 4 * FPSC_SLOTSM;              // status word of this kernel's ring
 constexpr int FPSM_NT = FPSM_KW * 2;                     // words a lane of wave 0 polls (<= 128 waves per cloud)
 
+template <int V> struct FpsInt { static constexpr int value = V; };
 typedef float fps_f2 __attribute__((ext_vector_type(2)));
 // two squared distances at once: the same unfused fp32 operations as sqd(), issued as packed v_pk_add / v_pk_mul
 __device__ __forceinline__ fps_f2 sqd2(fps_f2 ax, fps_f2 ay, fps_f2 az, float bx, float by, float bz) {
@@ -577,61 +578,67 @@ __global__ __launch_bounds__(FPSC_T, (PPT <= 16 ? 4 : (PPT <= 24 ? 3 : 2))) void
                 }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                unsigned long long ck[NC];
-                float cx[NC], cy[NC], cz[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    ck[c] = lane + 64 * c < cnt ? s_ck[lane + 64 * c] : 0ull;
-                    const unsigned q = (~(unsigned)ck[c]) & 0x1fffffffu;
-                    const unsigned qc = q < (unsigned)N ? q : 0u;           // the cloud is read-only: plain cached loads
-                    cx[c] = p[qc * 3 + 0]; cy[c] = p[qc * 3 + 1]; cz[c] = p[qc * 3 + 2];
-                }
-                __builtin_amdgcn_wave_barrier();                            // s_ck is written again next round, after these reads
+                // the chain on NCC candidates per lane: one when the round's candidates fit the wave (the usual case on the
+                // pipeline's clouds: ~20 qualify), NC otherwise
                 int m = 0;
                 int kx = 0, ky = 0, kz = 0, ki = 0;
-                for (;;) {
-                    // this lane's best, then the wave's
-                    unsigned long long f = ck[0];
-                    float fx = cx[0], fy = cy[0], fz = cz[0];
+                auto chain = [&](auto ncc_) {
+                    constexpr int NCC = decltype(ncc_)::value;
+                    unsigned long long ck[NCC];
+                    float cx[NCC], cy[NCC], cz[NCC];
 #pragma unroll
-                    for (int c = 1; c < NC; ++c) {
-                        const bool gt = ck[c] > f;
-                        f = gt ? ck[c] : f;
-                        fx = gt ? cx[c] : fx; fy = gt ? cy[c] : fy; fz = gt ? cz[c] : fz;
+                    for (int c = 0; c < NCC; ++c) {
+                        ck[c] = lane + 64 * c < cnt ? s_ck[lane + 64 * c] : 0ull;
+                        const unsigned q = (~(unsigned)ck[c]) & 0x1fffffffu;
+                        const unsigned qc = q < (unsigned)N ? q : 0u;           // the cloud is read-only: plain cached loads
+                        cx[c] = p[qc * 3 + 0]; cy[c] = p[qc * 3 + 1]; cz[c] = p[qc * 3 + 2];
                     }
-                    const unsigned fh = (unsigned)(f >> 32), fl = (unsigned)f;
-                    const unsigned hmax = wave_max_u32(fh);
-                    unsigned long long own = __ballot(fh == hmax);
-                    unsigned lmax;
-                    if (__builtin_popcountll(own) == 1) {                  // the usual case: one lane holds the largest distance
-                        lmax = (unsigned)__builtin_amdgcn_readlane((int)fl, __builtin_ctzll(own));
-                    } else {
-                        lmax = wave_max_u32(fh == hmax ? fl : 0u);
-                        own = __ballot(fh == hmax && fl == lmax);
-                    }
-                    const unsigned long long K = ((unsigned long long)hmax << 32) | lmax;
-                    if (m > 0 && !(K >= Bk && __uint_as_float(hmax) > 0.f)) break;
-                    const int w = __builtin_ctzll(own);
-                    auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-                    const float sx = rl(fx, w), sy = rl(fy, w), sz = rl(fz, w);
-                    const unsigned idx = (~lmax) & 0x1fffffffu;
-                    // lane m keeps sample m (a select on the wave-uniform values): ONE LDS write and one index store per
-                    // lane after the chain instead of an exec-masked write + store per sample
-                    {
-                        const bool me = lane == m;
-                        kx = me ? __float_as_int(sx) : kx; ky = me ? __float_as_int(sy) : ky;
-                        kz = me ? __float_as_int(sz) : kz; ki = me ? (int)idx : ki;
-                    }
-                    ++m;
-                    if (m == MS || j + m >= npoint || idx >= (unsigned)N) break;
-                    // lower the candidates' keys exactly as the update will (the sample itself falls to distance 0)
+                    __builtin_amdgcn_wave_barrier();                            // s_ck is written again next round, after these reads
+                    for (;;) {
+                        // this lane's best, then the wave's
+                        unsigned long long f = ck[0];
+                        float fx = cx[0], fy = cy[0], fz = cz[0];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        const float d = sqd(cx[c], cy[c], cz[c], sx, sy, sz);
-                        const unsigned kh = (unsigned)(ck[c] >> 32);
-                        if (d < __uint_as_float(kh)) ck[c] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)ck[c];
+                        for (int c = 1; c < NCC; ++c) {
+                            const bool gt = ck[c] > f;
+                            f = gt ? ck[c] : f;
+                            fx = gt ? cx[c] : fx; fy = gt ? cy[c] : fy; fz = gt ? cz[c] : fz;
+                        }
+                        const unsigned fh = (unsigned)(f >> 32), fl = (unsigned)f;
+                        const unsigned hmax = wave_max_u32(fh);
+                        unsigned long long own = __ballot(fh == hmax);
+                        unsigned lmax;
+                        if (__builtin_popcountll(own) == 1) {                  // the usual case: one lane holds the largest distance
+                            lmax = (unsigned)__builtin_amdgcn_readlane((int)fl, __builtin_ctzll(own));
+                        } else {
+                            lmax = wave_max_u32(fh == hmax ? fl : 0u);
+                            own = __ballot(fh == hmax && fl == lmax);
+                        }
+                        const unsigned long long K = ((unsigned long long)hmax << 32) | lmax;
+                        if (m > 0 && !(K >= Bk && __uint_as_float(hmax) > 0.f)) break;
+                        const int w = __builtin_ctzll(own);
+                        auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+                        const float sx = rl(fx, w), sy = rl(fy, w), sz = rl(fz, w);
+                        const unsigned idx = (~lmax) & 0x1fffffffu;
+                        // lane m keeps sample m (a select on the wave-uniform values): ONE LDS write and one index store per
+                        // lane after the chain instead of an exec-masked write + store per sample
+                        {
+                            const bool me = lane == m;
+                            kx = me ? __float_as_int(sx) : kx; ky = me ? __float_as_int(sy) : ky;
+                            kz = me ? __float_as_int(sz) : kz; ki = me ? (int)idx : ki;
+                        }
+                        ++m;
+                        if (m == MS || j + m >= npoint || idx >= (unsigned)N) break;
+                        // lower the candidates' keys exactly as the update will (the sample itself falls to distance 0)
+#pragma unroll
+                        for (int c = 0; c < NCC; ++c) {
+                            const float d = sqd(cx[c], cy[c], cz[c], sx, sy, sz);
+                            const unsigned kh = (unsigned)(ck[c] >> 32);
+                            if (d < __uint_as_float(kh)) ck[c] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)ck[c];
+                        }
                     }
-                }
+                };
+                if (cnt <= 64) chain(FpsInt<1>{}); else chain(FpsInt<NC>{});
                 if (lane < m) {
                     sl[3 * lane] = __int_as_float(kx); sl[3 * lane + 1] = __int_as_float(ky); sl[3 * lane + 2] = __int_as_float(kz);
                     if (g == 0) o[j + lane] = ki;
