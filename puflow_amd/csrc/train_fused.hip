@@ -1422,7 +1422,13 @@ struct EcBwdPArgs {
     int ntiles;
     float slope; double R;
     double* acc; unsigned* sync;
+    float* dP; int ldp;                              // nullable: dPQ [T, ldp] - the P half's growth columns = sum of dA over a point's 16 edges
 };
+
+// -DPF_EC_BWDP_DP=0: the P half's growth columns are summed by ec_pq_bwd_csr_kernel from dA again (the A/B reference)
+#ifndef PF_EC_BWDP_DP
+#define PF_EC_BWDP_DP 1
+#endif
 
 template <int G, int NC, int ODIM>
 __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
@@ -1678,6 +1684,14 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
                 const f4 v = bsc * (A(t, nt) - m1 - xh[t][nt] * m2);
                 if (ok[t]) *reinterpret_cast<f4*>(a.dA + ((size_t)tl[t] * 16 + col) * a.ld + 16 * (b0 + nt) + 4 * q) = v;
                 dy[t][b0 + nt] = v;
+                // a tile = the 16 edges of ONE point (K = 16), an edge = a lane of the 16-lane row: the sum over the row IS the point's
+                // dP for these columns - the column sums ec_pq_bwd_csr_kernel otherwise reads all of dA again for (67 MB per 128-wide unit)
+                if (a.dP) {
+                    f4 ps;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ps[r] = ecp_rowsum16(v[r]);
+                    if (ok[t] && col == 0) *reinterpret_cast<f4*>(a.dP + (size_t)tl[t] * a.ldp + 16 * (b0 + nt) + 4 * q) = ps;
+                }
             }
         }
     });
@@ -1773,6 +1787,7 @@ __global__ __launch_bounds__(256) void ec_pq_bwd_kernel(EcPqBwdArgs a) {
 struct EcPqCsrArgs {
     EcPqBwdArgs b;
     const int* off; const int* edge;
+    int p_done;                                      // the P half's growth columns were written by ec_bwdp_kernel
 };
 __global__ __launch_bounds__(256) void ec_pq_bwd_csr_kernel(EcPqCsrArgs a) {
     // one thread per (point, 4 channels): float4 loads, four edges in flight per accumulation step (a scalar thread per channel
@@ -1789,7 +1804,8 @@ __global__ __launch_bounds__(256) void ec_pq_bwd_csr_kernel(EcPqCsrArgs a) {
             const size_t ld = c < b.GT ? (size_t)b.ld : (size_t)b.odim;
             const float* own = src + (size_t)i * b.K * ld;
             f4 s1 = pf_splat(0.f), s2 = pf_splat(0.f), s3 = pf_splat(0.f);
-            int k = 0;
+            const bool have_p = a.p_done && c < b.GT;
+            int k = have_p ? b.K : 0;
             for (; k + 3 < b.K; k += 4) {
                 const f4 v0 = *reinterpret_cast<const f4*>(own + (size_t)k * ld), v1 = *reinterpret_cast<const f4*>(own + (size_t)(k + 1) * ld);
                 const f4 v2 = *reinterpret_cast<const f4*>(own + (size_t)(k + 2) * ld), v3 = *reinterpret_cast<const f4*>(own + (size_t)(k + 3) * ld);
@@ -1820,7 +1836,7 @@ __global__ __launch_bounds__(256) void ec_pq_bwd_csr_kernel(EcPqCsrArgs a) {
                 if ((int)(g4 >> 24) == k) q.w += dv.w;
             }
         }
-        *reinterpret_cast<f4*>(b.dPQ + (size_t)i * 2 * b.S + c) = sum;
+        if (!(a.p_done && c < b.GT)) *reinterpret_cast<f4*>(b.dPQ + (size_t)i * 2 * b.S + c) = sum;
         *reinterpret_cast<f4*>(b.dPQ + (size_t)i * 2 * b.S + b.S + c) = q;
     }
 }
@@ -2773,6 +2789,9 @@ int ec_bwd_persistent(const PfEcTrain* p, const Dims& d, const EcConvs& cv, hipS
         a.dgamma[t] = p->dgamma[t]; a.dbeta[t] = p->dbeta[t];
     }
     a.ntiles = d.ntiles; a.slope = p->slope; a.R = (double)d.E; a.acc = p->stat; a.sync = p->sync;
+#if PF_EC_BWDP_DP
+    if (p->K == 16 && p->csr_off && p->csr_edge) { a.dP = p->dPQ; a.ldp = 2 * d.S; }       // (the scatter form zeroes and accumulates dPQ itself)
+#endif
     const int grid = ecp_grid(d);
     const size_t l8 = ecpb_lds_bytes<8, 32>(), l16 = ecpb_lds_bytes<16, 64>(), l32 = ecpb_lds_bytes<32, 128>();
     if (p->growth == 8) hipLaunchKernelGGL((ec_bwdp_kernel<8, 4, 32>), dim3(grid), dim3(ECP_T), l8, s, a);
@@ -3011,7 +3030,8 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
         const long long n = (long long)d.T * d.S;
         const dim3 grid((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256));
         const dim3 grid4((unsigned)((n / 4 + 255) / 256 > 8192 ? 8192 : (n / 4 + 255) / 256));
-        if (csr) hipLaunchKernelGGL(ec_pq_bwd_csr_kernel, grid4, dim3(256), 0, s, EcPqCsrArgs{a, p->csr_off, p->csr_edge});
+        const int p_done = (PF_EC_BWDP_DP && persistent && p->K == 16) ? 1 : 0;
+        if (csr) hipLaunchKernelGGL(ec_pq_bwd_csr_kernel, grid4, dim3(256), 0, s, EcPqCsrArgs{a, p->csr_off, p->csr_edge, p_done});
         else hipLaunchKernelGGL(ec_pq_bwd_kernel, grid, dim3(256), 0, s, a);
     }
     // ---- dx first: it is what the unit before this one waits for
