@@ -373,8 +373,13 @@ typedef struct PfBnMlpTrain {
     int (*sync_cb)(void* user, double* sums, int n, void* stream);      /* SyncBN, as in PfEcTrain */
     void* sync_user;
     double* sync_sums;
-    int flags;                      /* PF_TRAIN_DETERMINISTIC */
+    int flags;                      /* PF_TRAIN_DETERMINISTIC, PF_BNMLP_SUM_INPUTS */
 } PfBnMlpTrain;
+/* PfBnMlpTrain.flags: layer 0 is no product - its pre-BatchNorm output is xa + xb (kin0a = kin0b = width[0]; W[0], b[0], dW[0],
+ * db[0], dxa, dxb unused: the gradient of BOTH inputs is d[0] after the backward call).  For a first layer whose weights were
+ * folded into the last linear layers of the two producers (WeightEstimationUnit's conv 0 over cat[DistanceEncoder, EdgeConv],
+ * modules/discrete/interpflow.py:134,144-146: no nonlinearity between them) - the same function, 2 x 128 x 128 MACs per row less. */
+#define PF_BNMLP_SUM_INPUTS 4
 long long pf_bnmlp_train_ws_floats(const PfBnMlpTrain* p);
 int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream);
 int pf_bnmlp_train_bwd(const PfBnMlpTrain* p, void* stream);
@@ -485,6 +490,16 @@ int pf_couple_inject2_bwd(const float* out, const float* dout, const float* dssu
 int pf_inject_inv2_fwd(const float* u, const float* s, const float* t, int Rr, long long R, float* v, void* stream);
 int pf_inject_inv2_bwd(const float* u, const float* s, const float* dv, int Rr, long long R, float* du, float* ds, float* dt,
                        void* stream);
+
+/* WeightEstimationUnit's first conv folded into its producers' last linear layers (interpflow.py:98, 134, 144-146, 219-221: no
+ * nonlinearity between them): W0 = [W0a | W0b] [o, 2 o], W6 [o, k6], Wout [o, ko]  ->  W6f = W0a W6, b6f = W0a b6 + b0,
+ * Wof = W0b Wout, bof = W0b bout; _bwd: the chain rule from the gradients of those four back to W0, b0, W6, b6, Wout, bout.
+ * Tiny, fixed summation order (bit-reproducible), one launch each. */
+int pf_fold_wu_fwd(const float* W0, const float* b0, const float* W6, const float* b6, const float* Wout, const float* bout,
+                   int o, int k6, int ko, float* W6f, float* b6f, float* Wof, float* bof, void* stream);
+int pf_fold_wu_bwd(const float* W0, const float* W6, const float* b6, const float* Wout, const float* bout, int o, int k6, int ko,
+                   const float* dW6f, const float* db6f, const float* dWof, const float* dbof, float* dW0, float* db0,
+                   float* dW6, float* db6, float* dWout, float* dbout, void* stream);
 
 /* ---- fused glue of the training step (csrc/train_glue.hip): what were chains of one-element torch launches ----
  * pf_interp_wsum: interpolation of the latent (modules/discrete/interpflow.py:153-186, 312-318): softmax over the K = 8

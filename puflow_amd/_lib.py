@@ -182,6 +182,8 @@ SIGNATURES = {
     "pf_bnmlp_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_bnmlp_train_bwd": (c_int, [c_void_p, c_void_p]),
     "pf_train_set_dw_stream": (c_int, [c_void_p]),
+    "pf_fold_wu_fwd": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 5),
+    "pf_fold_wu_bwd": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 11),
     "pf_knn_csr": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_knn_csr_sort": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "pf_ec_train_ws_floats": (c_longlong, [c_void_p]),

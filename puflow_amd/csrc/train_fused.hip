@@ -3132,6 +3132,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
 namespace {
 
 struct BnlFwdArgs {
+    const float* addA; const float* addB;      // both non-NULL: no product at all - out = addA + addB ([rows, nout] each), statistics as usual
     const float* X; int ldx, kin;              // input rows [rows, ldx], kin <= 128 columns used
     const float* sc; const float* sh;          // BatchNorm scale / shift of the producing layer (nullable: raw input)
     float slope;
@@ -3147,7 +3148,7 @@ struct BnlFwdArgs {
 #ifndef PF_BNL_PREFETCH
 #define PF_BNL_PREFETCH 0
 #endif
-template <int NT>
+template <int NT, bool SUM2 = false>
 __global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
     extern __shared__ float lds[];
     __shared__ float red[8 * STAT_W];
@@ -3155,7 +3156,8 @@ __global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
     float* Wl = lds;
     float* al = lds + NT * 16 * kp;
     float* bl = al + kin16;
-    for (int c = threadIdx.x >> 4; c < NT * 16; c += 16) {
+    constexpr bool sum2 = SUM2;                                   // its own instantiation: out = addA + addB, no weights, no product
+    for (int c = threadIdx.x >> 4; c < NT * 16 && !sum2; c += 16) {
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -3204,23 +3206,38 @@ __global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
             }
         }
     };
-    f4 xn[8];
     const int tstep = gridDim.x * 4;
-    if ((int)(blockIdx.x * 4 + wave) < a.ntiles) loadx(blockIdx.x * 4 + wave, xn);
+#if PF_BNL_PREFETCH
+    f4 xn[8];
+    if (!sum2 && (int)(blockIdx.x * 4 + wave) < a.ntiles) loadx(blockIdx.x * 4 + wave, xn);
+#endif
     for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += tstep) {
         const int r0 = tile * 16;
         f4 xv[8];
+#if PF_BNL_PREFETCH
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) xv[ks] = xn[ks];
-#if PF_BNL_PREFETCH
-        if (tile + tstep < a.ntiles) loadx(tile + tstep, xn);
+        if (!sum2 && tile + tstep < a.ntiles) loadx(tile + tstep, xn);
+#else
+        if (!sum2) loadx(tile, xv);
 #endif
         f4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = pf_splat(0.f);
+        if (sum2) {                                               // the accumulator layout read straight from the two tensors
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = nt * 16 + row;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rw = r0 + 4 * q + r;
+                    if (col < a.nout && rw < a.rows) acc[nt][r] = a.addA[(size_t)rw * a.nout + col] + a.addB[(size_t)rw * a.nout + col];
+                }
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            if (ks < KS) {
+            if (ks < KS && !sum2) {
                 const int u = ks * 16 + 4 * q;
                 const f4 av = lrelu4(xv[ks] * *reinterpret_cast<const f4*>(al + u) + *reinterpret_cast<const f4*>(bl + u), slope);
 #pragma unroll
@@ -3246,9 +3263,6 @@ __global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
                 }
             }
         }
-#if !PF_BNL_PREFETCH
-        if (tile + tstep < a.ntiles) loadx(tile + tstep, xn);
-#endif
     }
     if (a.want_stats) stat_flush<NT>(s0, s1, 0, a.nout, a.fin, red);
 }
@@ -3568,8 +3582,10 @@ int bnl_check(const PfBnMlpTrain* p) {
     if (p->kin0b > 0 && (p->kin0a & 3)) return PF_ERR_UNSUPPORTED;
     for (int l = 0; l < p->nl; ++l)
         if (p->width[l] < 16 || p->width[l] > 128 || p->width[l] % 16 != 0) return PF_ERR_UNSUPPORTED;
+    const bool sum_in = (p->flags & PF_BNMLP_SUM_INPUTS) != 0;
+    if (sum_in && (p->nl < 2 || p->kin0a != p->width[0] || p->kin0b != p->width[0] || !p->xb)) return PF_ERR_SHAPE;
     for (int l = 0; l < p->nl; ++l)
-        if (!p->W[l] || !p->y[l]) return PF_ERR_NULL;
+        if ((!p->W[l] && !(sum_in && l == 0)) || !p->y[l]) return PF_ERR_NULL;
     for (int l = 0; l < p->nl - 1; ++l)
         if (!p->gamma[l] || !p->beta[l] || !p->aff[l]) return PF_ERR_NULL;
     if (!p->xa || (p->kin0b > 0 && !p->xb) || !p->stat) return PF_ERR_NULL;
@@ -3581,8 +3597,13 @@ template <int NT>
 void bnl_fwd_launch(const BnlFwdArgs& a, int grid, hipStream_t s) {
     const int kin16 = (a.kin + 15) & ~15;
     const size_t lds = sizeof(float) * ((size_t)NT * 16 * (kin16 + 4) + 2 * kin16);
-    allow_lds(bnl_fwd_kernel<NT>, lds);
-    hipLaunchKernelGGL(bnl_fwd_kernel<NT>, dim3(grid), dim3(256), lds, s, a);
+    if (a.addA) {
+        allow_lds((bnl_fwd_kernel<NT, true>), lds);
+        hipLaunchKernelGGL((bnl_fwd_kernel<NT, true>), dim3(grid), dim3(256), lds, s, a);
+        return;
+    }
+    allow_lds((bnl_fwd_kernel<NT, false>), lds);
+    hipLaunchKernelGGL((bnl_fwd_kernel<NT, false>), dim3(grid), dim3(256), lds, s, a);
 }
 void bnl_fwd_dispatch(const BnlFwdArgs& a, int grid, hipStream_t s) {
     switch (bnl_nt(a.nout)) {
@@ -3633,7 +3654,13 @@ extern "C" int pf_bnmlp_train_fwd(const PfBnMlpTrain* p, void* stream) {
         if (bn) a.fin = StatFin{p->stat, 1, p->width[l], 0, p->width[l], p->aff[l], p->gamma[l], p->beta[l], p->run_mean[l],
                                 p->run_var[l], p->eps, p->momentum, nullptr, nullptr, nullptr, (double)p->rows, p->sync_sums};
         if (bn) a.fin.det = PF_DET(p);
-        if (l == 0) {
+        if (l == 0 && (p->flags & PF_BNMLP_SUM_INPUTS)) {
+            // layer 0 is NOT a product: its pre-BatchNorm output is the sum of the two inputs (their producers' last linear layers
+            // carry this layer's weights folded in - train_ops.py interp_weights): y[0] = xa + xb, statistics as usual
+            a.addA = p->xa; a.addB = p->xb; a.X = p->xa; a.ldx = p->kin0a; a.kin = 16; a.W = nullptr; a.ldw = 0; a.bias = nullptr;
+            a.want_stats = bn;
+            bnl_fwd_dispatch(a, grid, s);
+        } else if (l == 0) {
             a.X = p->xa; a.ldx = p->kin0a; a.kin = p->kin0a; a.W = p->W[0]; a.ldw = in0; a.bias = p->b[0];
             a.want_stats = bn && p->kin0b == 0;
             bnl_fwd_dispatch(a, grid, s);
@@ -3658,7 +3685,7 @@ extern "C" int pf_bnmlp_train_bwd(const PfBnMlpTrain* p, void* stream) {
     if (st) return st;
     if (!p->dout || !p->ws) return PF_ERR_NULL;
     for (int l = 0; l < p->nl; ++l)
-        if (!p->dW[l]) return PF_ERR_NULL;
+        if (!p->dW[l] && !((p->flags & PF_BNMLP_SUM_INPUTS) && l == 0)) return PF_ERR_NULL;
     for (int l = 0; l < p->nl - 1; ++l)
         if (!p->d[l] || !p->coef[l] || !p->dgamma[l] || !p->dbeta[l]) return PF_ERR_NULL;
     if (p->ws_floats < pf_bnmlp_train_ws_floats(p)) return PF_ERR_WORKSPACE;
@@ -3697,6 +3724,10 @@ extern "C" int pf_bnmlp_train_bwd(const PfBnMlpTrain* p, void* stream) {
             if ((st = stat_sync(a.fin, p->width[l - 1], p->sync_cb, p->sync_user, s))) return st;   // SyncBN: global sums of layer l - 1
             dw(dyl, p->width[l], p->y[l - 1], p->width[l - 1], p->width[l - 1], p->aff[l - 1], p->aff[l - 1] + p->width[l - 1],
                p->dW[l], p->width[l - 1], 0, p->db[l]);
+        } else if (p->flags & PF_BNMLP_SUM_INPUTS) {
+            // y[0] = xa + xb: the gradient of both inputs is d[0] after its BatchNorm backward (converted in place); no weights
+            a.W = nullptr; a.ldw = 0; a.dx = nullptr; a.nout = 0;
+            if (bn) bnl_bwd_dispatch(a, 2, grid, s);
         } else {
             // first layer: one pass per input tensor; the first pass also converts d[0] in place
             a.W = p->W[0]; a.ldw = in0; a.dx = p->dxa; a.nout = p->kin0a;

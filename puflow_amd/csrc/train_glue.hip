@@ -230,3 +230,107 @@ extern "C" int pf_pugan_loss_bwd(const float* g, const float* radius, int B, int
                        w_emd, w_cd, graddist, g1, g2, dlogp, gx, gy);
     return pf_last_launch_status();
 }
+
+// ---- the weight unit's first conv folded into its two producers' last linear layers (train_ops.py interp_weights) ------------
+// WeightEstimationUnit.mlp[0] (interpflow.py:144) sees cat[d, feat] where d = DistanceEncoder's last conv (W6, b6: linear,
+// interpflow.py:98) and feat = the EdgeConv's conv_out (Wout, bout: linear, :219-221) - no nonlinearity in between.  So
+//   W0 [d; feat] + b0 = (W0a W6) a2 + (W0b Wout) e + (W0a b6 + W0b bout + b0),   W0 = [W0a | W0b]  ([o, 2 o]).
+// Forward: the four product tensors; backward: the chain rule back to W0, b0, W6, b6, Wout, bout.  A few hundred thousand MACs:
+// one thread per output element, fixed summation order (bit-reproducible, capturable), two launches per step.
+namespace {
+struct FoldWuArgs {
+    const float* W0; const float* b0; const float* W6; const float* b6; const float* Wout; const float* bout;
+    int o, k6, ko;                       // W0 [o, 2 o], W6 [o, k6], Wout [o, ko]
+    float* W6f; float* b6f; float* Wof; float* bof;                       // forward outputs [o, k6], [o], [o, ko], [o]
+    const float* dW6f; const float* db6f; const float* dWof; const float* dbof;
+    float* dW0; float* db0; float* dW6; float* db6; float* dWout; float* dbout;
+};
+__global__ __launch_bounds__(256) void fold_wu_fwd_kernel(FoldWuArgs a) {
+    const int o = a.o, n6 = o * a.k6, no = o * a.ko;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n6 + no + 2 * o; i += gridDim.x * 256) {
+        float s = 0.f;
+        if (i < n6) {                                                       // W6f[r, c] = sum_m W0a[r, m] W6[m, c]
+            const int r = i / a.k6, c = i % a.k6;
+            for (int m = 0; m < o; ++m) s = fmaf(a.W0[(size_t)r * 2 * o + m], a.W6[(size_t)m * a.k6 + c], s);
+            a.W6f[i] = s;
+        } else if (i < n6 + no) {                                           // Wof[r, c] = sum_m W0b[r, m] Wout[m, c]
+            const int j = i - n6, r = j / a.ko, c = j % a.ko;
+            for (int m = 0; m < o; ++m) s = fmaf(a.W0[(size_t)r * 2 * o + o + m], a.Wout[(size_t)m * a.ko + c], s);
+            a.Wof[j] = s;
+        } else if (i < n6 + no + o) {                                       // b6f = W0a b6 + b0
+            const int r = i - n6 - no;
+            for (int m = 0; m < o; ++m) s = fmaf(a.W0[(size_t)r * 2 * o + m], a.b6[m], s);
+            a.b6f[r] = s + a.b0[r];
+        } else {                                                            // bof = W0b bout
+            const int r = i - n6 - no - o;
+            for (int m = 0; m < o; ++m) s = fmaf(a.W0[(size_t)r * 2 * o + o + m], a.bout[m], s);
+            a.bof[r] = s;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void fold_wu_bwd_kernel(FoldWuArgs a) {
+    const int o = a.o, k6 = a.k6, ko = a.ko;
+    const int n0 = o * 2 * o, n6 = o * k6, no = o * ko;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n0 + n6 + no + 3 * o; i += gridDim.x * 256) {
+        float s = 0.f;
+        if (i < n0) {                                                       // dW0[r, m]
+            const int r = i / (2 * o), m = i % (2 * o);
+            if (m < o) {                                                    // dW0a = dW6f W6^T + db6f (x) b6
+                for (int c = 0; c < k6; ++c) s = fmaf(a.dW6f[(size_t)r * k6 + c], a.W6[(size_t)m * k6 + c], s);
+                s = fmaf(a.db6f[r], a.b6[m], s);
+            } else {                                                        // dW0b = dWof Wout^T + dbof (x) bout
+                const int mm = m - o;
+                for (int c = 0; c < ko; ++c) s = fmaf(a.dWof[(size_t)r * ko + c], a.Wout[(size_t)mm * ko + c], s);
+                s = fmaf(a.dbof[r], a.bout[mm], s);
+            }
+            a.dW0[i] = s;
+        } else if (i < n0 + n6) {                                           // dW6[m, c] = sum_r W0a[r, m] dW6f[r, c]
+            const int j = i - n0, m = j / k6, c = j % k6;
+            for (int r = 0; r < o; ++r) s = fmaf(a.W0[(size_t)r * 2 * o + m], a.dW6f[(size_t)r * k6 + c], s);
+            a.dW6[j] = s;
+        } else if (i < n0 + n6 + no) {                                      // dWout[m, c] = sum_r W0b[r, m] dWof[r, c]
+            const int j = i - n0 - n6, m = j / ko, c = j % ko;
+            for (int r = 0; r < o; ++r) s = fmaf(a.W0[(size_t)r * 2 * o + o + m], a.dWof[(size_t)r * ko + c], s);
+            a.dWout[j] = s;
+        } else {
+            const int j = i - n0 - n6 - no, which = j / o, m = j % o;
+            if (which == 0) a.db0[m] = a.db6f[m];
+            else if (which == 1) {                                          // db6 = W0a^T db6f
+                for (int r = 0; r < o; ++r) s = fmaf(a.W0[(size_t)r * 2 * o + m], a.db6f[r], s);
+                a.db6[m] = s;
+            } else {                                                        // dbout = W0b^T dbof
+                for (int r = 0; r < o; ++r) s = fmaf(a.W0[(size_t)r * 2 * o + o + m], a.dbof[r], s);
+                a.dbout[m] = s;
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int pf_fold_wu_fwd(const float* W0, const float* b0, const float* W6, const float* b6, const float* Wout,
+                              const float* bout, int o, int k6, int ko, float* W6f, float* b6f, float* Wof, float* bof,
+                              void* stream) {
+    if (!W0 || !b0 || !W6 || !b6 || !Wout || !bout || !W6f || !b6f || !Wof || !bof) return PF_ERR_NULL;
+    if (o < 1 || o > 1024 || k6 < 1 || ko < 1 || k6 > 4096 || ko > 4096) return PF_ERR_SHAPE;
+    FoldWuArgs a{};
+    a.W0 = W0; a.b0 = b0; a.W6 = W6; a.b6 = b6; a.Wout = Wout; a.bout = bout; a.o = o; a.k6 = k6; a.ko = ko;
+    a.W6f = W6f; a.b6f = b6f; a.Wof = Wof; a.bof = bof;
+    const int n = o * (k6 + ko + 2);
+    hipLaunchKernelGGL(fold_wu_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return pf_last_launch_status();
+}
+
+extern "C" int pf_fold_wu_bwd(const float* W0, const float* W6, const float* b6, const float* Wout, const float* bout, int o,
+                              int k6, int ko, const float* dW6f, const float* db6f, const float* dWof, const float* dbof,
+                              float* dW0, float* db0, float* dW6, float* db6, float* dWout, float* dbout, void* stream) {
+    if (!W0 || !W6 || !b6 || !Wout || !bout || !dW6f || !db6f || !dWof || !dbof || !dW0 || !db0 || !dW6 || !db6 || !dWout || !dbout)
+        return PF_ERR_NULL;
+    if (o < 1 || o > 1024 || k6 < 1 || ko < 1 || k6 > 4096 || ko > 4096) return PF_ERR_SHAPE;
+    FoldWuArgs a{};
+    a.W0 = W0; a.W6 = W6; a.b6 = b6; a.Wout = Wout; a.bout = bout; a.o = o; a.k6 = k6; a.ko = ko;
+    a.dW6f = dW6f; a.db6f = db6f; a.dWof = dWof; a.dbof = dbof;
+    a.dW0 = dW0; a.db0 = db0; a.dW6 = dW6; a.db6 = db6; a.dWout = dWout; a.dbout = dbout;
+    const int n = o * (2 * o + k6 + ko + 3);
+    hipLaunchKernelGGL(fold_wu_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return pf_last_launch_status();
+}

@@ -941,7 +941,7 @@ class EdgeConvUnitFn(Function):
             d.flags |= 2
         if len(cfg) > 12 and cfg[12]:
             _attach_sync(d, dev)
-        dwst = _dw_begin(dev, sv, dout, dA, dPQ, coef, dWpq, ws)
+        dwst = None if (len(cfg) > 13 and cfg[13]) else _dw_begin(dev, sv, dout, dA, dPQ, coef, dWpq, ws)
         if dwst is not None:                                  # weight gradients on their own stream, with their own workspace
             ws2 = _dw_ws(dwst, dev, need)
             d.ws_dw, d.ws_dw_floats = ws2.data_ptr(), ws2.numel()
@@ -1396,6 +1396,42 @@ class MlpFn(Function):
         return (dy, dc, None, None, None, *grads)
 
 
+class FoldWuFn(Function):
+    """(W0 [o, 2 o, 1, 1], b0, W6 [o, k6, 1, 1], b6, Wout [o, ko, 1, 1], bout) -> (W0a W6, W0a b6 + b0, W0b Wout, W0b bout) in the
+    shapes of W6 / b6 / Wout / bout: WeightEstimationUnit's first conv folded into the last linear layers of its two producers
+    (csrc/train_glue.hip pf_fold_wu_fwd / _bwd: fixed summation order, one launch per direction)."""
+
+    @staticmethod
+    def forward(ctx, W0, b0, W6, b6, Wout, bout):
+        lib = _lib.load()
+        W0, b0, W6, b6, Wout, bout = (t.contiguous() for t in (W0, b0, W6, b6, Wout, bout))
+        o = W0.shape[0]
+        k6, ko = W6.numel() // o, Wout.numel() // o
+        assert W0.numel() == 2 * o * o and W6.shape[0] == o and Wout.shape[0] == o
+        W6f, b6f, Wof, bof = torch.empty_like(W6), torch.empty_like(b6), torch.empty_like(Wout), torch.empty_like(bout)
+        _lib.check(lib.pf_fold_wu_fwd(W0.data_ptr(), b0.data_ptr(), W6.data_ptr(), b6.data_ptr(), Wout.data_ptr(), bout.data_ptr(),
+                                      o, k6, ko, W6f.data_ptr(), b6f.data_ptr(), Wof.data_ptr(), bof.data_ptr(), _stream()),
+                   "pf_fold_wu_fwd")
+        ctx.save_for_backward(W0, W6, b6, Wout, bout)
+        return W6f, b6f, Wof, bof
+
+    @staticmethod
+    def backward(ctx, dW6f, db6f, dWof, dbof):
+        lib = _lib.load()
+        W0, W6, b6, Wout, bout = ctx.saved_tensors
+        o = W0.shape[0]
+        k6, ko = W6.numel() // o, Wout.numel() // o
+        z = lambda g, like: torch.zeros_like(like) if g is None else g.contiguous()
+        dW6f, db6f, dWof, dbof = z(dW6f, W6), z(db6f, b6), z(dWof, Wout), z(dbof, bout)
+        dW0, db0 = torch.empty_like(W0), torch.empty_like(b6)
+        dW6, db6, dWout, dbout = torch.empty_like(W6), torch.empty_like(b6), torch.empty_like(Wout), torch.empty_like(bout)
+        _lib.check(lib.pf_fold_wu_bwd(W0.data_ptr(), W6.data_ptr(), b6.data_ptr(), Wout.data_ptr(), bout.data_ptr(), o, k6, ko,
+                                      dW6f.data_ptr(), db6f.data_ptr(), dWof.data_ptr(), dbof.data_ptr(), dW0.data_ptr(),
+                                      db0.data_ptr(), dW6.data_ptr(), db6.data_ptr(), dWout.data_ptr(), dbout.data_ptr(),
+                                      _stream()), "pf_fold_wu_bwd")
+        return dW0, db0, dW6, db6, dWout, dbout
+
+
 class BnMlpFn(Function):
     """[Conv2d 1x1 + BatchNorm2d(train) + LeakyReLU] x 2 + Conv2d 1x1 on rows (DistanceEncoder / WeightEstimationUnit,
     interpflow.py:85-151) on cat[xa, xb] without building it: 3-4 launches forward, ~10 backward (csrc/train_fused.hip).
@@ -1434,7 +1470,7 @@ class BnMlpFn(Function):
             d.gamma[l], d.beta[l], d.aff[l] = gb[2 * l].data_ptr(), gb[2 * l + 1].data_ptr(), affs[l].data_ptr()
             d.run_mean[l], d.run_var[l] = _ptr(rmeans[l]), _ptr(rvars[l])
         d.stat = _stat(dev).data_ptr()
-        d.flags = 2 if _DET else 0
+        d.flags = (2 if _DET else 0) | (4 if (len(cfg) > 6 and cfg[6]) else 0)      # 4 = PF_BNMLP_SUM_INPUTS: y[0] = xa + xb
         if len(cfg) > 5 and cfg[5]:
             _attach_sync(d, dev)
         _lib.check(lib.pf_bnmlp_train_fwd(ctypes.byref(d), _stream()), "pf_bnmlp_train_fwd")
@@ -1473,10 +1509,13 @@ class BnMlpFn(Function):
         ws = _ws(dev, need)
         d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
         d.stat = _stat(dev).data_ptr()
-        d.flags = 2 if _DET else 0
+        sum_in = len(ctx.cfg) > 6 and ctx.cfg[6]
+        d.flags = (2 if _DET else 0) | (4 if sum_in else 0)
         if len(ctx.cfg) > 5 and ctx.cfg[5]:
             _attach_sync(d, dev)
         _lib.check(lib.pf_bnmlp_train_bwd(ctypes.byref(d), _stream()), "pf_bnmlp_train_bwd")
+        if sum_in:                                           # y[0] = xa + xb: both inputs take d[0]; layer 0 has no weights of its own
+            return (ds[0], ds[0], None, None, None, dWs[1], dbs[1], dWs[2], dbs[2], dgs[0], dbe[0], dgs[1], dbe[1])
         return (dxa, dxb, None, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dgs[0], dbe[0], dgs[1], dbe[1])
 
 
@@ -1493,12 +1532,20 @@ def _count_batches(bns) -> None:
         torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
 
 
-def bnmlp_fused(mlp, xa: Tensor, xb=None) -> Tensor:
+def bnmlp_fused(mlp, xa: Tensor, xb=None, last=None, sum_inputs: bool = False) -> Tensor:
+    """last = (W, b): other tensors for the last (linear) layer - the next module's first layer folded in (interp_weights);
+    sum_inputs: layer 0 = xa + xb (its weights live folded in the two producers' last layers)."""
     convs, bns = [mlp[0], mlp[3], mlp[6]], [mlp[1], mlp[4]]
     cfg = (0.01, float(bns[0].eps), float(bns[0].momentum), [bn.running_mean for bn in bns], [bn.running_var for bn in bns],
-           _sync_bn_active())
+           _sync_bn_active(), bool(sum_inputs))
     prm = []
-    for c in convs:
+    for i, c in enumerate(convs):
+        if i == 2 and last is not None:
+            prm += [last[0], last[1]]
+            continue
+        if i == 0 and sum_inputs:                               # shapes only: no gradient comes back for these two
+            prm += [c.weight.detach(), c.bias.detach()]
+            continue
         prm += [c.weight, c.bias]
     for bn in bns:
         prm += [bn.weight, bn.bias]
@@ -1619,6 +1666,7 @@ def mlp_fused(y, c: Tensor, td: int, cdiv: int, slopes, layers) -> Tensor:
 
 
 _FUSED = os.environ.get("PF_TRAIN_FUSED", "1") != "0"
+_FOLD_WU = os.environ.get("PF_TRAIN_FOLD_WU", "1") != "0"    # the weight unit's first conv folded into its producers (interp_weights); "0" = A/B reference
 
 
 def knn_csr(idx: Tensor):
@@ -1647,10 +1695,21 @@ def _ec_fused_supported(p, x: Tensor, idx: Tensor, pooling: bool) -> bool:
             and (B * N * K) % 16 == 0 and (K == 16 or not pooling))
 
 
-def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None, persistent: bool = False) -> Tensor:
+def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None, persistent: bool = False, out=None) -> Tensor:
+    """out = (W, b): other tensors for conv_out (the next module's first layer folded in, interp_weights)."""
     convs = [seq[0] for seq in p.convs] + [p.conv_out]
     bns = [seq[1] for seq in p.convs]
     g, nconv, odim = convs[0].weight.shape[0], len(bns), p.conv_out.weight.shape[0]
+    if out is not None:
+        ws = [c.weight for c in convs[:-1]] + [out[0]]
+        bs = [c.bias for c in convs[:-1]] + [out[1]]
+        cfg = (idx.shape[-1], g, nconv, odim, bool(pooling), 0.05, float(bns[0].eps), float(bns[0].momentum),
+               [bn.running_mean for bn in bns], [bn.running_var for bn in bns], csr,
+               bool(persistent) and _PERSIST and not _sync_bn_active(), _sync_bn_active(),
+               True)         # [13]: conv_out's gradient is consumed INSIDE the pass (FoldWuFn): no weight-gradient stream for this unit
+        res = EdgeConvUnitFn.apply(x, idx, cfg, *ws, *bs, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
+        _count_batches(bns)
+        return res
     cfg = (idx.shape[-1], g, nconv, odim, bool(pooling), 0.05, float(bns[0].eps), float(bns[0].momentum),
            [bn.running_mean for bn in bns], [bn.running_var for bn in bns], csr,
            bool(persistent) and _PERSIST and not _sync_bn_active(), _sync_bn_active())
@@ -1819,10 +1878,24 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         fd = torch.empty((B * N * 8, 10), dtype=torch.float32, device=xyz.device)        # inputs only: no gradient
         _lib.check(_lib.load().pf_dist_feature(xyz.data_ptr(), idx8.data_ptr(), B, N, 8, fd.data_ptr(), _stream()), "pf_dist_feature")
         fused_bn = _FUSED
-        d = bnmlp_fused(ip.knn_context.distance_encoder.mlp, fd) if fused_bn else _mlp_bn(ip.knn_context.distance_encoder.mlp, fd)
-        feat = edgeconv_train(ip.knn_context.feat_conv, xyz, idx8, pooling=False, csr=csr8)      # d, feat: [E8,128]
+        de, wu, fc = ip.knn_context.distance_encoder.mlp, ip.weight_unit.mlp, ip.knn_context.feat_conv
+        if (fused_bn and _FOLD_WU and _ec_fused_supported(fc, xyz, idx8, False)
+                and wu[0].weight.shape[0] == de[6].weight.shape[0] == fc.conv_out.weight.shape[0] == wu[0].weight.shape[1] // 2):
+            # The weight unit's first conv sees cat[d, feat] with NO nonlinearity after the producers' last (linear) layers
+            # (interpflow.py:134,144-146), so W0 [d; feat] + b0 = (W0a W6) a2 + (W0b Wout) e + (W0a b6 + W0b bout + b0): the
+            # producers' last layers run with the PRODUCT weights and emit the two halves of the pre-BatchNorm output directly;
+            # the first layer of the weight unit is their sum (PF_BNMLP_SUM_INPUTS) - two [E8, 128] x [128, 128] products per
+            # direction less, same function.  The products and their chain rule back to W0, W6, Wout and the three biases are one
+            # small launch each (FoldWuFn; the same algebra as the eval path's packing.fold_state_dict).
+            W6f, b6f, Wof, bof = FoldWuFn.apply(wu[0].weight, wu[0].bias, de[6].weight, de[6].bias, fc.conv_out.weight,
+                                                fc.conv_out.bias)
+            d = bnmlp_fused(de, fd, last=(W6f, b6f))
+            feat = edgeconv_train_fused(fc, xyz, idx8, False, csr8, False, out=(Wof, bof))
+            return bnmlp_fused(wu, d, feat, sum_inputs=True)
+        d = bnmlp_fused(de, fd) if fused_bn else _mlp_bn(de, fd)
+        feat = edgeconv_train(fc, xyz, idx8, pooling=False, csr=csr8)                            # d, feat: [E8,128]
         if fused_bn:
-            return bnmlp_fused(ip.weight_unit.mlp, d, feat)       # on cat[d, feat] (interpflow.py:146) without building it
+            return bnmlp_fused(wu, d, feat)                       # on cat[d, feat] (interpflow.py:146) without building it
         return _mlp_bn(ip.weight_unit.mlp, torch.cat([d, feat], dim=1))  # [E8,32]
 
     side = None

@@ -509,6 +509,63 @@ def test_side_stream_branch_of_the_training_forward_changes_nothing():
         assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-6, atol=1e-7), k
 
 
+def test_weight_unit_fold_is_the_same_function():
+    """WeightEstimationUnit's first conv sees cat[DistanceEncoder, EdgeConv] with no nonlinearity after the producers' last
+    (linear) layers (interpflow.py:98,134,144-146,219-221): in the training step those layers run with the product weights
+    (train_ops.FoldWuFn: pf_fold_wu_fwd / _bwd) and the first conv is the sum of their outputs (PF_BNMLP_SUM_INPUTS) - two
+    [E8, 128] x [128, 128] products per direction less.  Same outputs, loss, running statistics and gradients (also of the six
+    folded tensors, which now get theirs through the fold's chain rule) as the unfolded order, to rounding; and the fold kernels
+    against torch's matmul autograd."""
+    from puflow_amd import ops, train_ops as T
+    from puflow_amd.interpflow import PointInterpFlow
+    g = torch.Generator().manual_seed(3)
+    W0, b0 = torch.randn(128, 256, 1, 1, generator=g).to(DEV).requires_grad_(), torch.randn(128, generator=g).to(DEV).requires_grad_()
+    W6, b6 = torch.randn(128, 64, 1, 1, generator=g).to(DEV).requires_grad_(), torch.randn(128, generator=g).to(DEV).requires_grad_()
+    Wo, bo = torch.randn(128, 137, 1, 1, generator=g).to(DEV).requires_grad_(), torch.randn(128, generator=g).to(DEV).requires_grad_()
+    outs = T.FoldWuFn.apply(W0, b0, W6, b6, Wo, bo)
+    W0m = W0.reshape(128, 256).double()
+    refs = ((W0m[:, :128] @ W6.reshape(128, 64).double()).reshape(W6.shape), W0m[:, :128] @ b6.double() + b0.double(),
+            (W0m[:, 128:] @ Wo.reshape(128, 137).double()).reshape(Wo.shape), W0m[:, 128:] @ bo.double())
+    cot = [torch.randn(o.shape, generator=g).to(DEV) for o in outs]
+    got = torch.autograd.grad(outs, (W0, b0, W6, b6, Wo, bo), cot)
+    ref = torch.autograd.grad(refs, (W0, b0, W6, b6, Wo, bo), [c.double() for c in cot])
+    for o, r in zip(outs, refs):
+        assert float((o.double() - r).abs().max()) <= 1e-5 * float(r.abs().max())
+    for a, r in zip(got, ref):
+        assert float((a.double() - r.double()).abs().max()) <= 1e-5 * float(r.abs().max())
+
+    sd = synth_state_dict(33)
+    dense = synth_patches(4, 1024, seed=34).to(DEV)
+    sparse = dense[:, ::4].contiguous()
+    res = {}
+    was = T._FOLD_WU
+    try:
+        for fold in (False, True):
+            T._FOLD_WU = fold
+            net = PointInterpFlow(3)
+            net.load_state_dict(sd)
+            net.set_to_initialized_state()
+            net = net.to(DEV).train()
+            x, logp = net(sparse, 4)
+            cd, _ = ops.chamfer_distance(x, dense)
+            loss = logp * 1e-4 + cd * 1e-1
+            loss.backward()
+            torch.cuda.synchronize()
+            res[fold] = (x.detach().clone(), float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None},
+                         {k: b.detach().clone() for k, b in net.named_buffers()})
+    finally:
+        T._FOLD_WU = was
+    xa, la, ga, ba = res[False]
+    xb, lb, gb, bb = res[True]
+    assert float((xa - xb).abs().max()) <= 2e-5 and abs(la - lb) <= 1e-5 * abs(la)
+    assert ga.keys() == gb.keys() and len(ga) > 150
+    floor = 1e-4 * max(float(g_.abs().max()) for g_ in ga.values())       # a bias in front of a BatchNorm has gradient 0 + rounding noise
+    for k in ga:
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-3 * float(ga[k].abs().max()) + floor, k
+    for k in ba:
+        assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-4, atol=1e-6), k
+
+
 @pytest.mark.parametrize("B,N", [(4, 256), (3, 100)])
 def test_flow_chain_node_matches_the_per_block_nodes(B, N):
     """All flow blocks of a direction as one autograd node (csrc/train_flowchain.hip, FlowChainFn) against one node per block

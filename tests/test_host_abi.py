@@ -82,6 +82,8 @@ def test_training_entry_points_validate_their_descriptors(built_lib):
     assert lib.pf_knn_csr(None, 1, 16, 4, None, None, None, None) == -1
     assert lib.pf_knn_csr(8, 0, 16, 4, 8, 8, 8, None) == -2
     assert lib.pf_fps_grouped(None, 1, 16, 4, 0, None, None, None) == -1 and lib.pf_fps_grouped(8, 1, 16, 4, -1, 8, 8, None) == -2
+    assert lib.pf_fold_wu_fwd(*([None] * 6), 128, 64, 137, *([None] * 5)) == -1
+    assert lib.pf_fold_wu_bwd(*([8] * 5), 0, 64, 137, *([8] * 10), None) == -2
     assert lib.pf_knn_csr_sort(None, None, 4, None) == -1 and lib.pf_knn_csr_sort(8, 8, 0, None) == -2
     assert lib.pf_cnf_steps(None, None, None, None, None, None, None, None, None, 1e-5, 1e-5, 16, 1, 1, None, 0, None) == -1
 
