@@ -1657,6 +1657,68 @@ class CondNetBatchFn(Function):
         return (None, *dc_out, *grads)
 
 
+class MergeBatchFn(Function):
+    """The FeatMergeUnits of all EdgeConv units (Linear + ReLU + Linear without bias, interpflow.py:251-258) in ONE launch forward
+    and three backward (csrc/train_mlp.hip, batched entry points: one descriptor per unit, shapes may differ) instead of one /
+    three per unit: their outputs are only read by the flow stage, so nothing waits for them before the last unit is done.
+    apply(n, *hs, *[W1, b1, W2 per unit]) -> one [rows, cdim] tensor per unit.  Same kernels, same arithmetic as `mlp_fused`."""
+
+    @staticmethod
+    def _descs(hs, prm):
+        n = len(hs)
+        descs = (_lib.PfMlpTrain * n)()
+        rows = None
+        for k in range(n):
+            W1, b1, W2 = prm[3 * k:3 * k + 3]
+            descs[k], rows = MlpFn._desc(None, hs[k], 0, 1, (0.0,), [W1, W2], [b1, None])
+        return descs, rows
+
+    @staticmethod
+    def forward(ctx, n, *ts):
+        lib = _lib.load()
+        hs = [h.contiguous() for h in ts[:n]]
+        prm = [w.contiguous() for w in ts[n:]]
+        descs, rows = MergeBatchFn._descs(hs, prm)
+        f32 = dict(dtype=torch.float32, device=hs[0].device)
+        mids = [torch.empty((rows, prm[3 * k].shape[0]), **f32) for k in range(n)]
+        outs = [torch.empty((rows, prm[3 * k + 2].shape[0]), **f32) for k in range(n)]
+        for k in range(n):
+            descs[k].h[0], descs[k].out = mids[k].data_ptr(), outs[k].data_ptr()
+        _lib.check(lib.pf_mlp_train_fwd_batch(descs, n, _desc_buf(hs[0].device).data_ptr(), _stream()), "pf_mlp_train_fwd_batch")
+        ctx.n = n
+        ctx.save_for_backward(*hs, *prm, *mids)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        lib = _lib.load()
+        n = ctx.n
+        sv = list(ctx.saved_tensors)
+        hs, prm, mids = sv[:n], sv[n:4 * n], sv[4 * n:]
+        dev = hs[0].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        descs, rows = MergeBatchFn._descs(hs, prm)
+        need = [lib.pf_mlp_train_ws_floats(ctypes.byref(descs[k])) for k in range(n)]
+        ws = _ws(dev, sum(need))
+        keep, dhs, grads, off = [], [], [], 0
+        for k in range(n):
+            W1, b1, W2 = prm[3 * k:3 * k + 3]
+            dout = douts[k].contiguous() if douts[k] is not None else torch.zeros((rows, W2.shape[0]), **f32)
+            dz, dh = torch.empty_like(mids[k]), torch.empty_like(hs[k])
+            dW1, db1, dW2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2)
+            d = descs[k]
+            d.h[0], d.dz[0], d.dout, d.dc = mids[k].data_ptr(), dz.data_ptr(), dout.data_ptr(), dh.data_ptr()
+            d.dW[0], d.dW[1], d.db[0] = dW1.data_ptr(), dW2.data_ptr(), db1.data_ptr()
+            d.ws, d.ws_floats = ws.data_ptr() + 4 * off, need[k]
+            off += need[k]
+            descs[k] = d
+            keep += [dout, dz]
+            dhs.append(dh)
+            grads += [dW1, db1, dW2]
+        _lib.check(lib.pf_mlp_train_bwd_batch(descs, n, _desc_buf(dev).data_ptr(), _stream()), "pf_mlp_train_bwd_batch")
+        return (None, *dhs, *grads)
+
+
 def mlp_fused(y, c: Tensor, td: int, cdiv: int, slopes, layers) -> Tensor:
     """layers: nn.Linear modules.  -> [rows, out]"""
     wb = []
@@ -1666,6 +1728,7 @@ def mlp_fused(y, c: Tensor, td: int, cdiv: int, slopes, layers) -> Tensor:
 
 
 _FUSED = os.environ.get("PF_TRAIN_FUSED", "1") != "0"
+_MERGE_BATCH = os.environ.get("PF_TRAIN_MERGE_BATCH", "1") != "0"   # the FeatMergeUnits of all units in one batched launch; "0" = one per unit
 _FOLD_WU = os.environ.get("PF_TRAIN_FOLD_WU", "1") != "0"    # the weight unit's first conv folded into its producers (interp_weights); "0" = A/B reference
 
 
@@ -1912,6 +1975,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     # ---- feature extractor  (the merge units on a second side stream beside EdgeConv unit i + 1 were tried: 7.65 -> 8.35 ms per
     # captured step - six fork / join pairs of tiny kernels cost more in graph dependencies than their overlap returns)
     cs: List[Tensor] = []
+    hs_all: List[Tensor] = []
     h = xyz
     for i in range(net.num_blocks):
         # the main chain's units may run as persistent grid-barrier launches: nothing else with a grid barrier runs beside them
@@ -1922,10 +1986,17 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         # spins for seconds before its bounded time-out makes the output NaN.
         h = edgeconv_train(net.feat_convs[i], h, idx16, csr=csr16, persistent=getattr(net, "train_persistent", False))
         m = net.merge_convs[i]
-        if _FUSED:
+        if _FUSED and _MERGE_BATCH and net.num_blocks <= 16:
+            hs_all.append(h)                                      # all merge units in one batched launch below
+        elif _FUSED:
             cs.append(mlp_fused(None, h, 0, 1, (0.0,), [m.conv1, m.conv2]).view(B, N, -1))
         else:
             cs.append(linear(ActFn.apply(linear(h, m.conv1.weight, m.conv1.bias), 0.0), m.conv2.weight))
+    if hs_all:
+        mp = []
+        for m in net.merge_convs:
+            mp += [m.conv1.weight, m.conv1.bias, m.conv2.weight]
+        cs = [c.view(B, N, -1) for c in MergeBatchFn.apply(len(hs_all), *hs_all, *mp)]
 
     # ---- injector nets (s, t) of every block: functions of cs[i] only - one batched launch (and shared by f and g)
     st_all = None
