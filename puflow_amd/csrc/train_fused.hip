@@ -3267,6 +3267,58 @@ __global__ __launch_bounds__(256) void bnl_fwd_kernel(BnlFwdArgs a) {
     if (a.want_stats) stat_flush<NT>(s0, s1, 0, a.nout, a.fin, red);
 }
 
+// out = addA + addB ([rows, nout], nout = 16 NT) with the column statistics of the sum (PF_BNMLP_SUM_INPUTS): a streaming kernel -
+// float4 per thread along the row, the column sums kept per thread over its rows, added over the workgroup's row groups through
+// LDS and handed to stat_flush in the accumulator layout it expects (wave 0, the q = 0 lanes).  (The first version read the sum
+// in the MFMA accumulator layout of bnl_fwd_kernel - 4-byte loads, 16 rows apart: 105 us for 100 MB.)
+template <int NT>
+__global__ __launch_bounds__(256) void bnl_sum_kernel(BnlFwdArgs a) {
+    constexpr int C = 16 * NT, C4 = C / 4, RPP = 256 / C4;             // threads per row, rows per pass
+    static_assert(256 % C4 == 0 && C4 <= 256, "shape");
+    __shared__ float red[8 * STAT_W];
+    __shared__ float part[2][RPP][C];
+    const int c4 = threadIdx.x % C4, rr = threadIdx.x / C4;
+    f4 piv = pf_splat(0.f);
+    if (a.want_stats && a.fin.run_mean) piv = *reinterpret_cast<const f4*>(a.fin.run_mean + 4 * c4);
+    f4 s0 = pf_splat(0.f), s1 = pf_splat(0.f);
+    const long long step = (long long)gridDim.x * RPP;
+    long long row = (long long)blockIdx.x * RPP + rr;
+    for (; row + 3 * step < a.rows; row += 4 * step) {                     // eight loads in flight per thread
+        f4 x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x[u] = *reinterpret_cast<const f4*>(a.addA + (row + u * step) * C + 4 * c4);
+            y[u] = *reinterpret_cast<const f4*>(a.addB + (row + u * step) * C + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f4 v = x[u] + y[u];
+            *reinterpret_cast<f4*>(a.out + (row + u * step) * C + 4 * c4) = v;
+            const f4 vc = v - piv;
+            s0 += vc; s1 += vc * vc;
+        }
+    }
+    for (; row < a.rows; row += step) {
+        const f4 v = *reinterpret_cast<const f4*>(a.addA + row * C + 4 * c4) + *reinterpret_cast<const f4*>(a.addB + row * C + 4 * c4);
+        *reinterpret_cast<f4*>(a.out + row * C + 4 * c4) = v;
+        const f4 vc = v - piv;
+        s0 += vc; s1 += vc * vc;
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { part[0][rr][4 * c4 + w] = s0[w]; part[1][rr][4 * c4 + w] = s1[w]; }
+    __syncthreads();
+    float t0[NT], t1[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        t0[nt] = t1[nt] = 0.f;
+        if (threadIdx.x < 16) {                                           // wave 0, q = 0: column nt * 16 + lane
+            const int c = nt * 16 + threadIdx.x;
+            for (int g = 0; g < RPP; ++g) { t0[nt] += part[0][g][c]; t1[nt] += part[1][g][c]; }
+        }
+    }
+    if (a.want_stats) stat_flush<NT>(t0, t1, 0, a.nout, a.fin, red);
+}
+
 // backward through one layer.  SRC 1: dy [rows, kin] dense (the last layer, or a later K-pass of an already converted buffer);
 // SRC 2: dy = BatchNorm + LeakyReLU backward of dbuf (gradient wrt the layer's ACTIVATED output), formed on load and stored
 // back in place.  dx [rows, nout] = dy W (nullable: conversion only); epilogue: BatchNorm-backward sums of the layer that
@@ -3598,6 +3650,10 @@ void bnl_fwd_launch(const BnlFwdArgs& a, int grid, hipStream_t s) {
     const int kin16 = (a.kin + 15) & ~15;
     const size_t lds = sizeof(float) * ((size_t)NT * 16 * (kin16 + 4) + 2 * kin16);
     if (a.addA) {
+        if (a.nout == 16 * NT && NT >= 1) {                               // the streaming form (full 16-column blocks)
+            hipLaunchKernelGGL(bnl_sum_kernel<NT>, dim3(grid), dim3(256), 0, s, a);
+            return;
+        }
         allow_lds((bnl_fwd_kernel<NT, true>), lds);
         hipLaunchKernelGGL((bnl_fwd_kernel<NT, true>), dim3(grid), dim3(256), lds, s, a);
         return;
