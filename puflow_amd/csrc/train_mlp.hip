@@ -115,8 +115,14 @@ __device__ __forceinline__ MlpG mlp_glob(const PfMlpTrain& p) {
 // the descriptor of this workgroup's network with wave-uniform shapes and global pointers (see above): with the fields as they
 // come out of the vector loads hipcc treats every shape derived from them as lane-dependent - exec-masked regions around each
 // tile's read + MFMA, one LDS read waited for per MFMA (mlp_dw_kernel: ~7 us per 32-row block of the widest layer)
-__device__ __forceinline__ PfMlpTrain mlp_desc(const PfMlpTrain& p0, const PfMlpTrain* descs) {
-    PfMlpTrain p = descs ? descs[blockIdx.z] : p0;             // batched launch: one network per blockIdx.z
+// Up to 16 descriptors travel as ONE kernel argument (16 x 248 B = 3968 B of the 4 KB): network blockIdx.z of a batched launch,
+// entry 0 of a single one.  (Round 5: they used to be copied into device memory by a launch of their own in front of every
+// batched call - six launches per training step - and came back through vector loads.)
+constexpr int MLP_BATCH_MAX = 16;
+struct MlpBatch { PfMlpTrain p[MLP_BATCH_MAX]; };
+static_assert(sizeof(MlpBatch) <= 4032, "kernel argument block");
+__device__ __forceinline__ PfMlpTrain mlp_desc(const MlpBatch& bb) {
+    PfMlpTrain p = bb.p[blockIdx.z];
     p.rows = rfl(p.rows); p.nl = rfl(p.nl); p.td = rfl(p.td); p.cc = rfl(p.cc); p.cdiv = rfl(p.cdiv); p.ldy = rfl(p.ldy); p.chunk = rfl(p.chunk);
 #pragma unroll
     for (int i = 0; i < 3; ++i) { p.width[i] = rfl(p.width[i]); p.W[i] = rflp(p.W[i]); p.b[i] = rflp(p.b[i]); p.dW[i] = rflp(p.dW[i]); p.db[i] = rflp(p.db[i]); }
@@ -127,9 +133,9 @@ __device__ __forceinline__ PfMlpTrain mlp_desc(const PfMlpTrain& p0, const PfMlp
 }
 
 template <int NL>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpBatch bb) {
     extern __shared__ float lds[];
-    const PfMlpTrain p = mlp_desc(p0, descs);
+    const PfMlpTrain p = mlp_desc(bb);
     const MlpG G = mlp_glob(p);
     const int ntiles = (p.rows + 15) / 16;
     const MlpShape sh = mlp_shape(p);
@@ -225,9 +231,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(PfMlpTrain p0, const PfMlp
 
 // ------------------------------------------------------------------------------------------------ backward, chain
 template <int NL>
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBatch bb) {
     extern __shared__ float lds[];
-    const PfMlpTrain p = mlp_desc(p0, descs);
+    const PfMlpTrain p = mlp_desc(bb);
     const MlpG G = mlp_glob(p);
     const int ntiles = (p.rows + 15) / 16;
     const MlpShape sh = mlp_shape(p);
@@ -386,10 +392,10 @@ __device__ __forceinline__ void dw_block(const float* ar0, const float* br0, con
 #ifndef PF_DW_OCC
 #define PF_DW_OCC 1
 #endif
-__global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(PfMlpTrain p0, const PfMlpTrain* __restrict__ descs) {
+__global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(MlpBatch bb) {
     constexpr int NTH = 64 * MLP_DW_WAVES;
     extern __shared__ float lds[];
-    const PfMlpTrain p = mlp_desc(p0, descs);
+    const PfMlpTrain p = mlp_desc(bb);
     const MlpG G = mlp_glob(p);
     const int chunk = mlp_chunk(p);
     if ((int)blockIdx.x * chunk >= p.rows || (int)blockIdx.y >= p.nl) return;
@@ -549,8 +555,8 @@ __global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(Pf
 
 // partial sums -> dW[l] [wo, in_l] (column j < td of layer 0 sits behind the cc conditioning columns in the partials), db[l]
 constexpr int MLP_RG = PF_MLP_RG;           // groups of 64 threads that share the chunk range of an output element
-__global__ __launch_bounds__(64 * MLP_RG) void mlp_dw_reduce_kernel(PfMlpTrain p0, const PfMlpTrain* descs) {
-    const PfMlpTrain p = mlp_desc(p0, descs);
+__global__ __launch_bounds__(64 * MLP_RG) void mlp_dw_reduce_kernel(MlpBatch bb) {
+    const PfMlpTrain p = mlp_desc(bb);
     const MlpG G = mlp_glob(p);
     gcp part = G.ws;
     const int nchunk = (p.rows + mlp_chunk(p) - 1) / mlp_chunk(p);
@@ -599,13 +605,7 @@ __global__ __launch_bounds__(64 * MLP_RG) void mlp_dw_reduce_kernel(PfMlpTrain p
     else sel3(G.dW, l)[(size_t)c * inl + j] = (float)s;
 }
 
-// descriptors of a batched launch travel as kernel arguments of this copy kernel (capturable in a hipGraph, no host copy)
-constexpr int MLP_BATCH_MAX = 16;
-struct MlpBatch { PfMlpTrain p[MLP_BATCH_MAX]; };
-__global__ __launch_bounds__(256) void mlp_desc_upload_kernel(MlpBatch b, unsigned* dst, int nwords) {
-    const unsigned* src = reinterpret_cast<const unsigned*>(&b);
-    for (int i = threadIdx.x; i < nwords; i += 256) dst[i] = src[i];
-}
+static inline MlpBatch mlp_one(const PfMlpTrain& p) { MlpBatch b; b.p[0] = p; return b; }
 
 template <typename KERNEL>
 void allow_lds(KERNEL k, size_t bytes) {
@@ -653,8 +653,8 @@ extern "C" int pf_mlp_train_fwd(const PfMlpTrain* p, void* stream) {
     const int ntiles = (p->rows + 15) / 16;
     const int grid = (ntiles + 3) / 4 < MLP_GRID ? (ntiles + 3) / 4 : MLP_GRID;
     hipStream_t s = (hipStream_t)stream;
-    if (p->nl == 2) { allow_lds(mlp_fwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<2>, dim3(grid), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr); }
-    else { allow_lds(mlp_fwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<3>, dim3(grid), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr); }
+    if (p->nl == 2) { allow_lds(mlp_fwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<2>, dim3(grid), dim3(256), lds, s, mlp_one(*p)); }
+    else { allow_lds(mlp_fwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<3>, dim3(grid), dim3(256), lds, s, mlp_one(*p)); }
     return pf_last_launch_status();
 }
 
@@ -676,8 +676,8 @@ extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
         lds = (lds + (size_t)sh.wo16[0] * 4) * sizeof(float);
         const int ntiles = (p->rows + 15) / 16;
         const int grid = (ntiles + 3) / 4 < MLP_GRID ? (ntiles + 3) / 4 : MLP_GRID;
-        if (p->nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr); }
-        else { allow_lds(mlp_bwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(grid), dim3(256), lds, s, *p, (const PfMlpTrain*)nullptr); }
+        if (p->nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, mlp_one(*p)); }
+        else { allow_lds(mlp_bwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(grid), dim3(256), lds, s, mlp_one(*p)); }
     }
     const int chunk = mlp_chunk(*p);
     const int nchunk = (p->rows + chunk - 1) / chunk;
@@ -686,11 +686,11 @@ extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
         int ramax = 0, rbmax = 0;
         for (int l = 0; l < p->nl; ++l) { ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l]; }
         const size_t lds = sizeof(float) * (size_t)MLP_EB * 2 * MLP_LD;
-        hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(64 * MLP_DW_WAVES), lds, s, *p, (const PfMlpTrain*)nullptr);
+        hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(64 * MLP_DW_WAVES), lds, s, mlp_one(*p));
     }
     int total = 0;
     for (int l = 0; l < p->nl; ++l) total += sh.wo[l] * (sh.in[l] + 1);
-    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((total + 63) / 64), dim3(64 * MLP_RG), 0, s, *p, (const PfMlpTrain*)nullptr);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((total + 63) / 64), dim3(64 * MLP_RG), 0, s, mlp_one(*p));
     return pf_last_launch_status();
 }
 
@@ -721,10 +721,9 @@ extern "C" int pf_mlp_train_fwd_batch(const PfMlpTrain* descs, int n, void* dev_
         b.p[k] = *p;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(mlp_desc_upload_kernel, dim3(1), dim3(256), 0, s, b, (unsigned*)dev_descs, (int)(n * sizeof(PfMlpTrain) / 4));
-    const PfMlpTrain* dd = (const PfMlpTrain*)dev_descs;
-    if (descs[0].nl == 2) { allow_lds(mlp_fwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<2>, dim3(gmax, 1, n), dim3(256), lds, s, b.p[0], dd); }
-    else { allow_lds(mlp_fwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<3>, dim3(gmax, 1, n), dim3(256), lds, s, b.p[0], dd); }
+    (void)dev_descs;                                      // (kept in the ABI: the descriptors now travel as the kernels' own argument)
+    if (descs[0].nl == 2) { allow_lds(mlp_fwd_kernel<2>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<2>, dim3(gmax, 1, n), dim3(256), lds, s, b); }
+    else { allow_lds(mlp_fwd_kernel<3>, lds); hipLaunchKernelGGL(mlp_fwd_kernel<3>, dim3(gmax, 1, n), dim3(256), lds, s, b); }
     return pf_last_launch_status();
 }
 
@@ -766,13 +765,12 @@ extern "C" int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_
         b.p[k] = *p;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(mlp_desc_upload_kernel, dim3(1), dim3(256), 0, s, b, (unsigned*)dev_descs, (int)(n * sizeof(PfMlpTrain) / 4));
-    const PfMlpTrain* dd = (const PfMlpTrain*)dev_descs;
-    if (descs[0].nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(gmax, 1, n), dim3(256), lds_b, s, b.p[0], dd); }
-    else { allow_lds(mlp_bwd_kernel<3>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(gmax, 1, n), dim3(256), lds_b, s, b.p[0], dd); }
+    (void)dev_descs;                                      // (kept in the ABI: the descriptors now travel as the kernels' own argument)
+    if (descs[0].nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(gmax, 1, n), dim3(256), lds_b, s, b); }
+    else { allow_lds(mlp_bwd_kernel<3>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(gmax, 1, n), dim3(256), lds_b, s, b); }
     s = pf_dw_fork(s);                                   // (dev_descs must then be this call's own: the next upload is not ordered behind it)
-    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b.p[0], dd);
-    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(64 * MLP_RG), 0, s, b.p[0], dd);
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(64 * MLP_RG), 0, s, b);
     return pf_last_launch_status();
 }
 
@@ -809,9 +807,8 @@ extern "C" int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_d
         b.p[k] = *p;
     }
     hipStream_t s = pf_dw_fork((hipStream_t)stream);     // all of it is weight-gradient work
-    hipLaunchKernelGGL(mlp_desc_upload_kernel, dim3(1), dim3(256), 0, s, b, (unsigned*)dev_descs, (int)(n * sizeof(PfMlpTrain) / 4));
-    const PfMlpTrain* dd = (const PfMlpTrain*)dev_descs;
-    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b.p[0], dd);
-    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(64 * MLP_RG), 0, s, b.p[0], dd);
+    (void)dev_descs;                                      // (kept in the ABI: the descriptors now travel as the kernels' own argument)
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b);
+    hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(64 * MLP_RG), 0, s, b);
     return pf_last_launch_status();
 }
