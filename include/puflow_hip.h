@@ -321,6 +321,9 @@ typedef struct PfEcTrain {
     double* sync_sums;
     float* ws_dw; long long ws_dw_floats; /* backward with pf_train_set_dw_stream: a second workspace (>= pf_ec_train_ws_floats()) that
                                      * only the weight-gradient stream's kernels use; NULL = weight gradients on the calling stream */
+    const float* dx_add;            /* backward, nullable: [B*N, C] added to dx in the epilogue of its GEMM - the part of x's gradient
+                                     * that x's OTHER consumer (the unit's FeatMergeUnit, interpflow.py:251-258) has produced already,
+                                     * instead of a separate add launch afterwards */
 } PfEcTrain;
 #define PF_EC_PERSISTENT 1
 /* flags bit (PfEcTrain, PfBnMlpTrain): BatchNorm's batch statistics are accumulated as 64-bit fixed-point sums (quantum 2^-28)
@@ -330,6 +333,9 @@ typedef struct PfEcTrain {
  * quantisation (~4e-9 absolute per workgroup partial).  The persistent kernels are not used under it.  Debugging switch:
  * puflow_amd sets it from `net.deterministic` / `cfg.deterministic`. */
 #define PF_TRAIN_DETERMINISTIC 2
+/* flags bit (PfEcTrain): Wpq / bpq were filled by pf_ec_train_fold_batch since the parameters last changed - pf_ec_train_fwd
+ * skips its own fold launch */
+#define PF_EC_PREFOLDED 4
 /* transposed neighbour lists of idx [B*N, K]: off [T+1], edge [T*K]; cnt: T ints (4-aligned size) of scratch */
 /* Weight gradients beside the backward chain.  With a stream set here (per host thread; NULL = off, the default) the backward
  * entry points pf_ec_train_bwd, pf_mlp_train_bwd, pf_mlp_train_bwd_batch and pf_mlp_train_dw_batch enqueue their split-K
@@ -345,6 +351,10 @@ int pf_knn_csr(const int* idx, int B, int N, int K, int* off, int* edge, int* cn
 int pf_knn_csr_sort(const int* off, int* edge, int T, void* stream);
 long long pf_ec_train_ws_floats(const PfEcTrain* p);
 int pf_ec_train_fwd(const PfEcTrain* p, void* stream);
+/* The folded edge-feature weights Wpq / bpq of n <= 8 units (only C, growth, nconv, odim, B, N, K, W, bias, Wpq, bpq of each
+ * descriptor are read) in ONE launch: they depend on parameters only (interpflow.py:190-248 applies the convolutions to
+ * cat[x_i, x_j, x_j - x_i]; W_p = W_a - W_c, W_q = W_b + W_c), so a step folds all units before the first one runs. */
+int pf_ec_train_fold_batch(const PfEcTrain* descs, int n, void* stream);
 int pf_ec_train_bwd(const PfEcTrain* p, void* stream);
 
 /* ---- BatchNorm MLP of the interpolation module in the training step, fused (csrc/train_fused.hip) ----
@@ -490,6 +500,11 @@ int pf_couple_inject2_bwd(const float* out, const float* dout, const float* dssu
 int pf_inject_inv2_fwd(const float* u, const float* s, const float* t, int Rr, long long R, float* v, void* stream);
 int pf_inject_inv2_bwd(const float* u, const float* s, const float* dv, int Rr, long long R, float* du, float* ds, float* dt,
                        void* stream);
+
+/* out = ((p0 + p1) + p2) + ... for n_terms in 2..8 tensors of n floats each (n % 4 == 0, 16-byte aligned): the gradient of a
+ * tensor with several consumers in ONE launch instead of autograd's n_terms - 1 pairwise adds (train_ops.FanoutFn).  ptrs: host
+ * array of device pointers.  `out` may be one of the operands. */
+int pf_sum_n(const float* const* ptrs, int n_terms, float* out, long long n, void* stream);
 
 /* WeightEstimationUnit's first conv folded into its producers' last linear layers (interpflow.py:98, 134, 144-146, 219-221: no
  * nonlinearity between them): W0 = [W0a | W0b] [o, 2 o], W6 [o, k6], Wout [o, ko]  ->  W6f = W0a W6, b6f = W0a b6 + b0,

@@ -23,7 +23,7 @@ class PfEcTrain(ctypes.Structure):
                 ("dWpq", c_void_p), ("dx", c_void_p), ("dW", c_void_p * 9), ("dbias", c_void_p * 9),
                 ("dgamma", c_void_p * 8), ("dbeta", c_void_p * 8), ("ws", c_void_p), ("ws_floats", c_longlong), ("stat", c_void_p), ("csr_off", c_void_p), ("csr_edge", c_void_p),
                 ("flags", c_int), ("sync", c_void_p), ("sync_cb", c_void_p), ("sync_user", c_void_p), ("sync_sums", c_void_p),
-                ("ws_dw", c_void_p), ("ws_dw_floats", c_longlong)]
+                ("ws_dw", c_void_p), ("ws_dw_floats", c_longlong), ("dx_add", c_void_p)]
 
 
 class PfBnMlpTrain(ctypes.Structure):
@@ -188,6 +188,7 @@ SIGNATURES = {
     "pf_knn_csr_sort": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "pf_ec_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_ec_train_fwd": (c_int, [c_void_p, c_void_p]),
+    "pf_ec_train_fold_batch": (c_int, [c_void_p, c_int, c_void_p]),
     "pf_ec_train_bwd": (c_int, [c_void_p, c_void_p]),
     "pf_cnf_init": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double,
                             c_void_p, c_double, c_int, c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
@@ -203,6 +204,7 @@ SIGNATURES = {
                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pf_cnf_step": (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_float, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pf_sum_n": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_longlong, c_void_p]),
     "pf_lincomb": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, c_void_p, c_longlong, c_void_p]),
     "pf_scaled_sumsq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_float), c_int, c_float, c_float,
                                 c_float, c_longlong, c_void_p, c_void_p, c_void_p]),

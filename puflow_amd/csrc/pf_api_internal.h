@@ -39,3 +39,7 @@ void* pf_dw_stream_get();
 // the stream weight-gradient work of a call should go to: s itself when none is set (or it IS s), else the weight-gradient stream,
 // made to wait for everything enqueued on s so far
 hipStream_t pf_dw_fork(hipStream_t s);
+// pf_gemm_ex with an addend: C = A B + bias + addend (addend [M, ldc] laid out like C, nullable, may alias C) - csrc/train_ops.hip
+int pf_gemm_addend(int arith, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
+                   float* C, long long ldc, const float* bias, const float* addend, int M, int N, int K, float* ws,
+                   long long ws_floats, void* stream);

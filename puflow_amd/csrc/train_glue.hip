@@ -334,3 +334,50 @@ extern "C" int pf_fold_wu_bwd(const float* W0, const float* W6, const float* b6,
     hipLaunchKernelGGL(fold_wu_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return pf_last_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ gradient fan-in
+// out = ((p0 + p1) + p2) + ... over n <= 8 tensors of the same size, 16-byte loads, ONE launch: a tensor with several consumers
+// (the flattened conditioning features: both flow chains and the two families of injector nets) gets its gradient from one
+// pass over the operands instead of autograd's n - 1 pairwise adds (each a full read-read-write of the running sum).
+namespace {
+typedef float sum_f4 __attribute__((ext_vector_type(4)));
+struct SumNArgs { const sum_f4* p[8]; sum_f4* out; long long n4; };
+template <int N>
+__global__ __launch_bounds__(256) void sum_n_kernel(SumNArgs a) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (long long)gridDim.x * 256) {
+        sum_f4 v[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = __builtin_nontemporal_load(a.p[j] + i);
+        sum_f4 s = v[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) s += v[j];
+        a.out[i] = s;
+    }
+}
+}  // namespace
+
+extern "C" int pf_sum_n(const float* const* ptrs, int n_terms, float* out, long long n, void* stream) {
+    if (!ptrs || !out) return PF_ERR_NULL;
+    if (n_terms < 2 || n_terms > 8 || n <= 0 || n % 4 != 0) return PF_ERR_SHAPE;
+    SumNArgs a{};
+    for (int j = 0; j < n_terms; ++j) {
+        if (!ptrs[j]) return PF_ERR_NULL;
+        if (((uintptr_t)ptrs[j]) & 15) return PF_ERR_SHAPE;
+        a.p[j] = reinterpret_cast<const sum_f4*>(ptrs[j]);
+    }
+    if (((uintptr_t)out) & 15) return PF_ERR_SHAPE;
+    a.out = reinterpret_cast<sum_f4*>(out); a.n4 = n / 4;
+    const long long want = (a.n4 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+    hipStream_t s = (hipStream_t)stream;
+    switch (n_terms) {
+        case 2: hipLaunchKernelGGL(sum_n_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(sum_n_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(sum_n_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL(sum_n_kernel<5>, dim3(grid), dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL(sum_n_kernel<6>, dim3(grid), dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL(sum_n_kernel<7>, dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(sum_n_kernel<8>, dim3(grid), dim3(256), 0, s, a); break;
+    }
+    return pf_last_launch_status();
+}

@@ -27,7 +27,8 @@ struct GemmArgs {
     float* C; long long ldc;                 // C(m,n) = C[m*ldc + n]   (or slab z: C + z*M*ldc)
     const float* bias;                       // per column n, nullable (ignored when splitk > 1: added by the reduce)
     int M, N, K, kchunk;                     // kchunk = K range per blockIdx.z
-};
+    const float* add;                        // nullable: C(m,n) += add[m*ldc + n] (same layout as C; may BE C; ignored when splitk > 1:
+};                                           //           added by the reduce) - a gradient that already holds another consumer's part
 
 // Output tile BM x BN per 256-thread workgroup: WAVES_M x WAVES_N waves, each TM x TN MFMA tiles of 16x16; K-step 16.
 // The launcher picks the shape from (M, N): layer GEMMs here are very skinny (N = 8..128 forward, M = 8..128 for dW),
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + (wm * TM + i) * 16 + 4 * (lane >> 4) + r;
-                if (m < g.M && n < g.N) C[m * g.ldc + n] = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f);
+                if (m < g.M && n < g.N) C[m * g.ldc + n] = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f) + (g.add ? g.add[m * g.ldc + n] : 0.f);
             }
         }
 }
@@ -323,11 +324,12 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmArgs g, int cvec) {
         f4 x = *reinterpret_cast<const f4*>(Cs + row * LDC + c4);
         if (cvec && n + 3 < g.N) {
             if (g.bias) { const f4 bb = *reinterpret_cast<const f4*>(g.bias + n); x += bb; }
+            if (g.add) { const f4 aa = *reinterpret_cast<const f4*>(g.add + m * g.ldc + n); x += aa; }
             *reinterpret_cast<f4*>(C + m * g.ldc + n) = x;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (n + e < g.N) C[m * g.ldc + n + e] = x[e] + (g.bias ? g.bias[n + e] : 0.f);
+                if (n + e < g.N) C[m * g.ldc + n + e] = x[e] + (g.bias ? g.bias[n + e] : 0.f) + (g.add ? g.add[m * g.ldc + n + e] : 0.f);
         }
     }
 }
@@ -341,7 +343,7 @@ void gemm2_launch(const GemmArgs& g, int split, hipStream_t s) {
     pf_allow_lds(reinterpret_cast<const void*>(gemm2_kernel<WAVES_M, WAVES_N, TM, TN>), lds);
     auto al16 = [](const void* p) { return (reinterpret_cast<unsigned long long>(p) & 15ull) == 0; };
     const long long ldc = g.ldc;
-    const int cvec = (ldc % 4 == 0) && al16(g.C) && (!g.bias || al16(g.bias)) && (((long long)g.M * ldc) % 4 == 0);
+    const int cvec = (ldc % 4 == 0) && al16(g.C) && (!g.bias || al16(g.bias)) && (!g.add || al16(g.add)) && (((long long)g.M * ldc) % 4 == 0);
     const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, split);
     hipLaunchKernelGGL((gemm2_kernel<WAVES_M, WAVES_N, TM, TN>), grid, dim3(256), lds, s, g, cvec);
 }
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + (wm * TM + i) * 16 + 4 * (lane >> 4) + r;
-                if (m < g.M && n < g.N) C[m * g.ldc + n] = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f);
+                if (m < g.M && n < g.N) C[m * g.ldc + n] = acc[i][j][r] + (g.bias ? g.bias[n] : 0.f) + (g.add ? g.add[m * g.ldc + n] : 0.f);
             }
         }
 }
@@ -537,9 +539,9 @@ inline void gemm_tile_dims(int shape, int& bm, int& bn) {
 }
 
 // C = sum over split-K slabs (+ bias): 64 consecutive outputs x 4 slab lanes per workgroup, fixed combine order
-__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C,
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ slabs, float* C,
                                                          const float* __restrict__ bias, int M, int N, long long ldc,
-                                                         int nslab) {
+                                                         int nslab, const float* add) {
     __shared__ float sh[4][64];
     const int l = threadIdx.x & 63, part = threadIdx.x >> 6;
     const long long t = (long long)blockIdx.x * 64 + l;
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restric
     __syncthreads();
     if (part == 0 && t < MN) {
         const int m = (int)(t / N), n = (int)(t % N);
-        C[m * ldc + n] = ((sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l])) + (bias ? bias[n] : 0.f);
+        C[m * ldc + n] = ((sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l])) + (bias ? bias[n] : 0.f) + (add ? add[m * ldc + n] : 0.f);
     }
 }
 
@@ -907,6 +909,12 @@ extern "C" long long pf_gemm_ws_floats(int M, int N, int K) {
 extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
                           float* C, long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats,
                           void* stream) {
+    return pf_gemm_addend(arith, A, sam, sak, B, sbk, sbn, C, ldc, bias, nullptr, M, N, K, ws, ws_floats, stream);
+}
+// (internal, pf_api_internal.h) the same with an addend: C = A B + bias + addend, addend [M, ldc] laid out like C (it may be C)
+int pf_gemm_addend(int arith, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
+                   float* C, long long ldc, const float* bias, const float* addend, int M, int N, int K, float* ws,
+                   long long ws_floats, void* stream) {
     if (arith != 0 && arith != 1 && arith != 2 && arith != 3) return PF_ERR_UNSUPPORTED;
     if (!A || !B || !C) return PF_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return PF_ERR_SHAPE;
@@ -915,7 +923,8 @@ extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sa
     if (need && (!ws || ws_floats < need)) return PF_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const bool use_ws = split > 1;
-    GemmArgs g{A, sam, sak, B, sbk, sbn, use_ws ? ws : C, use_ws ? (long long)N : ldc, use_ws ? nullptr : bias, M, N, K, 0};
+    GemmArgs g{A, sam, sak, B, sbk, sbn, use_ws ? ws : C, use_ws ? (long long)N : ldc, use_ws ? nullptr : bias, M, N, K, 0,
+               use_ws ? nullptr : addend};
     g.kchunk = ((K + split - 1) / split + 31) / 32 * 32;
     split = (K + g.kchunk - 1) / g.kchunk;
     // float4 path: the contiguous dimension of each operand must be 4-aligned in extent, stride and base
@@ -962,7 +971,7 @@ extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sa
     }
     if (use_ws)
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(((long long)M * N + 63) / 64)), dim3(256), 0, s, ws, C, bias, M,
-                           N, ldc, split);
+                           N, ldc, split, addend);
     return pf_last_launch_status();
 }
 
@@ -972,7 +981,7 @@ extern "C" int pf_gemm_reduce(const float* slabs, float* C, int M, int N, long l
     if (!slabs || !C) return PF_ERR_NULL;
     if (M <= 0 || N <= 0 || nslab <= 0) return PF_ERR_SHAPE;
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(((long long)M * N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, slabs, C,
-                       (const float*)nullptr, M, N, ldc, nslab);
+                       (const float*)nullptr, M, N, ldc, nslab, (const float*)nullptr);
     return pf_last_launch_status();
 }
 

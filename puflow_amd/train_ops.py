@@ -792,7 +792,8 @@ def edgeconv_train_unfolded(p, x: Tensor, idx: Tensor, pooling: bool = True) -> 
     return MaxPoolKFn.apply(y, K).view(B, N, -1)
 
 
-def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None, persistent: bool = False) -> Tensor:
+def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None, persistent: bool = False, prefold=None,
+                   tap: bool = False) -> Tensor:
     """FeatureExtractUnit in train mode (interpflow.py:234-248). x [B,N,C]; returns [B,N,odim] or [B*N*K, odim].
 
     Same algebra as the inference path's edge-feature fold (packing.fold_edgeconv): every conv of the dense block sees
@@ -804,7 +805,7 @@ def edgeconv_train(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None, pe
     if _UNFOLDED:
         return edgeconv_train_unfolded(p, x, idx, pooling)
     if _FUSED and _ec_fused_supported(p, x, idx, pooling):
-        return edgeconv_train_fused(p, x, idx, pooling, csr, persistent)
+        return edgeconv_train_fused(p, x, idx, pooling, csr, persistent, prefold=prefold, tap=tap)   # tap: -> (out, x again)
     B, N, C = x.shape
     K = idx.shape[-1]
     convs = [seq[0] for seq in p.convs] + [p.conv_out]
@@ -862,13 +863,17 @@ class EdgeConvUnitFn(Function):
         bs = [b.contiguous() for b in params[nc1:2 * nc1]]
         gammas = [t.contiguous() for t in params[2 * nc1:2 * nc1 + nconv]]
         betas = [t.contiguous() for t in params[2 * nc1 + nconv:]]
+        x_in = x
         x = x.contiguous()
         B, N, C = x.shape
         T, E, GT = B * N, B * N * K, g * nconv
         S = GT + odim
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
-        Wpq, bpq = torch.empty((2 * S, C), **f32), torch.empty((2 * S,), **f32)
+        pre = cfg[14] if len(cfg) > 14 else None              # (Wpq, bpq) folded by ec_prefold for this forward
+        if pre is not None and tuple(pre[0].shape) != (2 * S, C):
+            raise ValueError("EdgeConvUnitFn: prefolded weights of another unit")
+        Wpq, bpq = pre if pre is not None else (torch.empty((2 * S, C), **f32), torch.empty((2 * S,), **f32))
         PQ, Y, aff = torch.empty((T, 2 * S), **f32), torch.empty((E, GT), **f32), torch.empty((4, GT), **f32)
         out = torch.empty((T if pooling else E, odim), **f32)
         arg = torch.empty((T, odim), dtype=torch.uint8, device=dev) if pooling else None
@@ -886,16 +891,23 @@ class EdgeConvUnitFn(Function):
             d.flags, d.sync = 1, _sync_words(dev).data_ptr()
         if _DET:
             d.flags |= 2                                      # PF_TRAIN_DETERMINISTIC
+        if pre is not None:
+            d.flags |= 4                                      # PF_EC_PREFOLDED
         if len(cfg) > 12 and cfg[12]:                         # SyncBN: statistics over all ranks (fixed at forward time: the
             _attach_sync(d, dev)                              # backward runs after the sync_bn() scope has ended)
         _lib.check(lib.pf_ec_train_fwd(ctypes.byref(d), _stream()), "pf_ec_train_fwd")
         ctx.cfg = cfg
         ctx.has_arg = pooling
         ctx.save_for_backward(x, idx, Wpq, PQ, Y, aff, *(() if arg is None else (arg,)), *Ws, *gammas)
-        return out.view(B, N, odim) if pooling else out
+        res = out.view(B, N, odim) if pooling else out
+        if len(cfg) > 15 and cfg[15]:
+            # tap: x again, as a second output for x's OTHER consumer - that consumer's gradient then arrives HERE (dtap) and is
+            # added in the epilogue of the dx GEMM (PfEcTrain.dx_add) instead of by a launch of autograd's own
+            return res, x_in.view_as(x_in)
+        return res
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dtap=None):
         lib = _lib.load()
         cfg = ctx.cfg
         K, g, nconv, odim, pooling = cfg[:5]
@@ -924,6 +936,11 @@ class EdgeConvUnitFn(Function):
         dbe = [torch.empty((g,), **f32) for _ in range(nconv)]
         d.dA, d.dPQ, d.coef, d.dWpq = dA.data_ptr(), dPQ.data_ptr(), coef.data_ptr(), dWpq.data_ptr()
         d.dx = dx.data_ptr() if dx is not None else None
+        if dtap is not None and dx is not None:
+            dtap = dtap.contiguous()
+            if dtap.shape != x.shape or dtap.dtype != torch.float32:
+                raise ValueError("EdgeConvUnitFn: gradient of the tap has another shape than x")
+            d.dx_add = dtap.data_ptr()
         for t in range(nc1):
             d.dW[t], d.dbias[t] = dWs[t].data_ptr(), dbs[t].data_ptr()
         for t in range(nconv):
@@ -1229,10 +1246,43 @@ class FlowChainFn(Function):
         return (None, None, None, None, dx, dcflat, dst, None, *grads)
 
 
+_FANOUT = os.environ.get("PF_TRAIN_FANOUT", "1") != "0"       # gradients of the flattened conditioning features summed in one launch
+
+
+class FanoutFn(Function):
+    """apply(n, x) -> n aliases of x, one per consumer; backward: the n gradients summed in ONE launch (pf_sum_n,
+    ((g0 + g1) + g2) + ...) instead of autograd's n - 1 pairwise adds over the running sum."""
+
+    @staticmethod
+    def forward(ctx, n, x):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g.contiguous() for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return None, gs[0]
+        g0 = gs[0]
+        if (g0.numel() % 4 or len(gs) > 8 or not g0.is_cuda
+                or any(g.dtype != torch.float32 or g.shape != g0.shape or g.data_ptr() % 16 for g in gs)):
+            out = gs[0] + gs[1]
+            for g in gs[2:]:
+                out = out + g
+            return None, out
+        out = torch.empty_like(g0)
+        ptrs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+        _lib.check(_lib.load().pf_sum_n(ptrs, len(gs), out.data_ptr(), g0.numel(), _stream()), "pf_sum_n")
+        return None, out
+
+
 class CondNetStackFn(Function):
     """The injector scale / shift conditioners (LinearA1D, first layer without bias, interpflow.py:22-43) of ALL flow blocks on the
     flattened conditioning features: one launch forward, four backward (csrc/train_mlp.hip, batched entry points), ONE output
-    tensor.  apply(ccs, T, cflat, *[W0, W1, b1, W2, b2 per net]) -> st [n, T, 3]; net k reads block k // 2's features."""
+    tensor.  apply(ccs, T, cflat, cflat2, *[W0, W1, b1, W2, b2 per net]) -> st [n, T, 3]; net k reads block k // 2's features.
+    cflat2: None, or a second alias of cflat (FanoutFn) - the gradient through the scale nets then goes to cflat and the one
+    through the shift nets to cflat2, un-added (the fan-out sums them with the other consumers' in its one launch)."""
 
     @staticmethod
     def _descs(ccs, T, cflat, prm, n):
@@ -1255,9 +1305,10 @@ class CondNetStackFn(Function):
         return descs, offs
 
     @staticmethod
-    def forward(ctx, ccs, T, cflat, *prm):
+    def forward(ctx, ccs, T, cflat, cflat2, *prm):
         lib = _lib.load()
         n = len(prm) // 5
+        ctx.two = cflat2 is not None
         cflat = cflat.contiguous()
         prm = [w.contiguous() for w in prm]
         dev = cflat.device
@@ -1315,7 +1366,9 @@ class CondNetStackFn(Function):
             descs[k] = d
         with _dw_call(dwst):
             _lib.check(lib.pf_mlp_train_bwd_batch(descs, n, ddesc.data_ptr(), _stream()), "pf_mlp_train_bwd_batch")
-        return (None, None, dc2[0] + dc2[1], *[g.view(p.shape) for g, p in zip(gp, prm)])
+        if ctx.two:
+            return (None, None, dc2[0], dc2[1], *[g.view(p.shape) for g, p in zip(gp, prm)])
+        return (None, None, dc2[0] + dc2[1], None, *[g.view(p.shape) for g, p in zip(gp, prm)])
 
 
 class MlpFn(Function):
@@ -1661,7 +1714,8 @@ class MergeBatchFn(Function):
     """The FeatMergeUnits of all EdgeConv units (Linear + ReLU + Linear without bias, interpflow.py:251-258) in ONE launch forward
     and three backward (csrc/train_mlp.hip, batched entry points: one descriptor per unit, shapes may differ) instead of one /
     three per unit: their outputs are only read by the flow stage, so nothing waits for them before the last unit is done.
-    apply(n, *hs, *[W1, b1, W2 per unit]) -> one [rows, cdim] tensor per unit.  Same kernels, same arithmetic as `mlp_fused`."""
+    apply(n, *hs, *[W1, b1, W2 per unit]) -> ONE flat tensor, the units' [rows, cdim] outputs one after the other (the layout the
+    flow chains and the injector stack read: no concatenation afterwards).  Same kernels, same arithmetic as `mlp_fused`."""
 
     @staticmethod
     def _descs(hs, prm):
@@ -1681,18 +1735,22 @@ class MergeBatchFn(Function):
         descs, rows = MergeBatchFn._descs(hs, prm)
         f32 = dict(dtype=torch.float32, device=hs[0].device)
         mids = [torch.empty((rows, prm[3 * k].shape[0]), **f32) for k in range(n)]
-        outs = [torch.empty((rows, prm[3 * k + 2].shape[0]), **f32) for k in range(n)]
+        cds = [int(prm[3 * k + 2].shape[0]) for k in range(n)]
+        flat = torch.empty((rows * sum(cds),), **f32)
+        off = 0
         for k in range(n):
-            descs[k].h[0], descs[k].out = mids[k].data_ptr(), outs[k].data_ptr()
+            descs[k].h[0], descs[k].out = mids[k].data_ptr(), flat.data_ptr() + 4 * off
+            off += rows * cds[k]
         _lib.check(lib.pf_mlp_train_fwd_batch(descs, n, _desc_buf(hs[0].device).data_ptr(), _stream()), "pf_mlp_train_fwd_batch")
         ctx.n = n
         ctx.save_for_backward(*hs, *prm, *mids)
-        return tuple(outs)
+        return flat
 
     @staticmethod
-    def backward(ctx, *douts):
+    def backward(ctx, dflat):
         lib = _lib.load()
         n = ctx.n
+        dflat = dflat.contiguous()
         sv = list(ctx.saved_tensors)
         hs, prm, mids = sv[:n], sv[n:4 * n], sv[4 * n:]
         dev = hs[0].device
@@ -1700,10 +1758,11 @@ class MergeBatchFn(Function):
         descs, rows = MergeBatchFn._descs(hs, prm)
         need = [lib.pf_mlp_train_ws_floats(ctypes.byref(descs[k])) for k in range(n)]
         ws = _ws(dev, sum(need))
-        keep, dhs, grads, off = [], [], [], 0
+        keep, dhs, grads, off, doff = [], [], [], 0, 0
         for k in range(n):
             W1, b1, W2 = prm[3 * k:3 * k + 3]
-            dout = douts[k].contiguous() if douts[k] is not None else torch.zeros((rows, W2.shape[0]), **f32)
+            dout = dflat[doff:doff + rows * W2.shape[0]]
+            doff += rows * W2.shape[0]
             dz, dh = torch.empty_like(mids[k]), torch.empty_like(hs[k])
             dW1, db1, dW2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2)
             d = descs[k]
@@ -1758,8 +1817,51 @@ def _ec_fused_supported(p, x: Tensor, idx: Tensor, pooling: bool) -> bool:
             and (B * N * K) % 16 == 0 and (K == 16 or not pooling))
 
 
-def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None, persistent: bool = False, out=None) -> Tensor:
-    """out = (W, b): other tensors for conv_out (the next module's first layer folded in, interp_weights)."""
+_TAP = os.environ.get("PF_TRAIN_TAP", "1") != "0"     # a unit's output gradient from its merge unit added inside the next unit's dx GEMM
+_PREFOLD = os.environ.get("PF_TRAIN_PREFOLD", "1") != "0"     # the feature units' folded weights in one launch at the top of the forward
+
+
+def ec_prefold(units, x0: Tensor, K: int):
+    """Folded edge-feature weights (Wpq, bpq) of a CHAIN of pooled units (unit i + 1 reads unit i's output) in one launch
+    (pf_ec_train_fold_batch) -> one pair per unit for `edgeconv_train_fused(..., prefold=)`, or None where the fused path
+    does not apply.  Parameters only: valid until the next optimizer update."""
+    if not (_FUSED and _PREFOLD) or _UNFOLDED or not 1 <= len(units) <= 8:
+        return None
+    B, N, C = x0.shape
+    if (B * N * K) % 16:
+        return None
+    dev = x0.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    descs = (_lib.PfEcTrain * len(units))()
+    outs = []
+    for k, p in enumerate(units):
+        convs = [seq[0] for seq in p.convs] + [p.conv_out]
+        g, nconv, odim = convs[0].weight.shape[0], len(p.convs), p.conv_out.weight.shape[0]
+        if g not in (8, 16, 32) or g * nconv not in (32, 64, 128) or odim % 16 or not 16 <= odim <= 128 or K != 16:
+            return None
+        if any(c.weight.dtype != torch.float32 or not c.weight.is_contiguous() or c.bias is None for c in convs):
+            return None
+        if convs[0].weight.reshape(g, -1).shape[1] != 3 * C:
+            return None
+        S = g * nconv + odim
+        Wpq, bpq = torch.empty((2 * S, C), **f32), torch.empty((2 * S,), **f32)
+        d = _lib.PfEcTrain()
+        d.B, d.N, d.K, d.C, d.growth, d.nconv, d.odim, d.pooling = B, N, K, C, g, nconv, odim, 1
+        for t, c in enumerate(convs):
+            d.W[t], d.bias[t] = c.weight.data_ptr(), c.bias.data_ptr()
+        d.Wpq, d.bpq = Wpq.data_ptr(), bpq.data_ptr()
+        descs[k] = d
+        outs.append((Wpq, bpq))
+        C = odim
+    _lib.check(_lib.load().pf_ec_train_fold_batch(descs, len(units), _stream()), "pf_ec_train_fold_batch")
+    return outs
+
+
+def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=None, persistent: bool = False, out=None,
+                         prefold=None, tap: bool = False) -> Tensor:
+    """out = (W, b): other tensors for conv_out (the next module's first layer folded in, interp_weights).
+    prefold = (Wpq, bpq) from `ec_prefold`.  tap: return (result, x) - an alias of x for x's other consumer, whose gradient the
+    unit's backward then adds inside its dx GEMM (EdgeConvUnitFn)."""
     convs = [seq[0] for seq in p.convs] + [p.conv_out]
     bns = [seq[1] for seq in p.convs]
     g, nconv, odim = convs[0].weight.shape[0], len(bns), p.conv_out.weight.shape[0]
@@ -1775,7 +1877,8 @@ def edgeconv_train_fused(p, x: Tensor, idx: Tensor, pooling: bool = True, csr=No
         return res
     cfg = (idx.shape[-1], g, nconv, odim, bool(pooling), 0.05, float(bns[0].eps), float(bns[0].momentum),
            [bn.running_mean for bn in bns], [bn.running_var for bn in bns], csr,
-           bool(persistent) and _PERSIST and not _sync_bn_active(), _sync_bn_active())
+           bool(persistent) and _PERSIST and not _sync_bn_active(), _sync_bn_active(), False, prefold,
+           bool(tap) and x.requires_grad)
     out = EdgeConvUnitFn.apply(x, idx, cfg, *[c.weight for c in convs], *[c.bias for c in convs],
                                *[bn.weight for bn in bns], *[bn.bias for bn in bns])
     _count_batches(bns)
@@ -1961,6 +2064,9 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
             return bnmlp_fused(wu, d, feat)                       # on cat[d, feat] (interpflow.py:146) without building it
         return _mlp_bn(ip.weight_unit.mlp, torch.cat([d, feat], dim=1))  # [E8,32]
 
+    # folded edge-feature weights of the six feature units: parameters only - one launch here instead of one per unit
+    pre = ec_prefold(list(net.feat_convs), xyz, 16) if (fused_ec and not _sync_bn_active()) else None
+
     side = None
     if use_side:
         side = _side_stream(xyz.device)
@@ -1984,7 +2090,11 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         # device is shared: cfg.emd_workgroups == 1 / cfg.persistent_kernels = False); a bare PointInterpFlow.train() forward on a
         # GPU it may share with another process keeps the per-layer kernels - a grid barrier whose workgroups are not all resident
         # spins for seconds before its bounded time-out makes the output NaN.
-        h = edgeconv_train(net.feat_convs[i], h, idx16, csr=csr16, persistent=getattr(net, "train_persistent", False))
+        batch_merge = _FUSED and _MERGE_BATCH and net.num_blocks <= 16
+        h = edgeconv_train(net.feat_convs[i], h, idx16, csr=csr16, persistent=getattr(net, "train_persistent", False),
+                           prefold=pre[i] if pre is not None else None, tap=_TAP and batch_merge and i > 0)
+        if isinstance(h, tuple):                                  # (output, the input again): the merge unit reads the alias, so
+            h, hs_all[i - 1] = h                                  # its gradient reaches the previous unit through THIS unit's dx GEMM
         m = net.merge_convs[i]
         if _FUSED and _MERGE_BATCH and net.num_blocks <= 16:
             hs_all.append(h)                                      # all merge units in one batched launch below
@@ -1996,7 +2106,12 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         mp = []
         for m in net.merge_convs:
             mp += [m.conv1.weight, m.conv1.bias, m.conv2.weight]
-        cs = [c.view(B, N, -1) for c in MergeBatchFn.apply(len(hs_all), *hs_all, *mp)]
+        cflat_m = MergeBatchFn.apply(len(hs_all), *hs_all, *mp)
+        off = 0
+        for m in net.merge_convs:
+            cd = m.conv2.weight.shape[0]
+            cs.append(cflat_m[off:off + B * N * cd].view(B, N, cd))
+            off += B * N * cd
 
     # ---- injector nets (s, t) of every block: functions of cs[i] only - one batched launch (and shared by f and g)
     st_all = None
@@ -2019,13 +2134,17 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     if chain:
         pf, pg = _flow_chain_params(net)
         ccs = tuple(int(c.shape[-1]) for c in cs)
-        cflat = torch.cat([c.reshape(-1) for c in cs])               # one tensor for its three consumers
-        st = CondNetStackFn.apply(ccs, B * N, cflat, *st_prm)
+        cflat = cflat_m if hs_all else torch.cat([c.reshape(-1) for c in cs])       # one tensor for its consumers
+        cflat_t = None
+        cflat_f = cflat_g = cflat
+        if _FANOUT:                                                   # their four gradients: one launch (FanoutFn)
+            cflat, cflat_t, cflat_f, cflat_g = FanoutFn.apply(4, cflat)
+        st = CondNetStackFn.apply(ccs, B * N, cflat, cflat_t, *st_prm)
         if _GLUE and nb < 8:
-            z, logp1 = FlowChainFn.apply(0, 1, float(N), ccs, xyz, cflat, st, B, *pf)       # log-likelihood from the kernel's epilogue
+            z, logp1 = FlowChainFn.apply(0, 1, float(N), ccs, xyz, cflat_f, st, B, *pf)     # log-likelihood from the kernel's epilogue
             logp = logp1.view(())
         else:
-            z, ssum, ld = FlowChainFn.apply(0, 1, float(N), ccs, xyz, cflat, st, 0, *pf)
+            z, ssum, ld = FlowChainFn.apply(0, 1, float(N), ccs, xyz, cflat_f, st, 0, *pf)
             logp = -(BatchSumFn.apply(z, 1).mean() + ld.sum() - ssum.sum() / B)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
@@ -2038,7 +2157,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
             zj = GatherRowsFn.apply(z, idx8)
             fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)
             u = fz.transpose(1, 2).reshape(B, N * R, 3)
-        x = FlowChainFn.apply(1, R, float(N), ccs, u, cflat, st, 0, *pg)
+        x = FlowChainFn.apply(1, R, float(N), ccs, u, cflat_g, st, 0, *pg)
         return x, logp
 
     # ---- f + log-likelihood

@@ -566,6 +566,104 @@ def test_weight_unit_fold_is_the_same_function():
         assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-4, atol=1e-6), k
 
 
+def test_batched_weight_fold_changes_no_bit():
+    """The six feature units' folded edge-feature weights (W_p = W_a - W_c | W_q = W_b + W_c, interpflow.py:190-248 on
+    cat[x_i, x_j, x_j - x_i]) come from ONE launch at the top of the forward (pf_ec_train_fold_batch) instead of one at the head of
+    every unit: same expressions, so - in the bit-reproducible mode, where two runs can be compared at all - the same output,
+    loss and gradients bit for bit; and the batched call against the expressions themselves."""
+    from puflow_amd import ops, train_ops as T
+    from puflow_amd.interpflow import PointInterpFlow
+    sd = synth_state_dict(51)
+    dense = synth_patches(4, 1024, seed=52).to(DEV)
+    sparse = dense[:, ::4].contiguous()
+    net = PointInterpFlow(3)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    pre = T.ec_prefold(list(net.feat_convs), sparse, 16)
+    assert pre is not None and len(pre) == len(net.feat_convs)
+    C = 3
+    for (Wpq, bpq), u in zip(pre, net.feat_convs):
+        convs = [seq[0] for seq in u.convs] + [u.conv_out]
+        Ws = [c.weight.reshape(c.weight.shape[0], -1) for c in convs]
+        Wp = torch.cat([w[:, :C] - w[:, 2 * C:3 * C] for w in Ws])
+        Wq = torch.cat([w[:, C:2 * C] + w[:, 2 * C:3 * C] for w in Ws])
+        assert torch.equal(Wpq, torch.cat([Wp, Wq]))
+        assert torch.equal(bpq, torch.cat([torch.cat([c.bias for c in convs]), torch.zeros_like(bpq[:Wp.shape[0]])]))
+        C = u.conv_out.weight.shape[0]
+    res = _step_under_switch(T, "_PREFOLD", sd, sparse, dense)
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    assert res[False][2].keys() == res[True][2].keys() and len(res[True][2]) > 150
+    for k in res[False][2]:
+        assert torch.equal(res[False][2][k], res[True][2][k]), k
+
+
+def _step_under_switch(T, name, sd, sparse, dense):
+    """forward + backward of the bit-reproducible mode with train_ops.<name> off and on -> {flag: (x, loss, gradients)}"""
+    from puflow_amd import ops
+    from puflow_amd.interpflow import PointInterpFlow
+    res = {}
+    was = getattr(T, name)
+    try:
+        for on in (False, True):
+            setattr(T, name, on)
+            net = PointInterpFlow(3)
+            net.load_state_dict(sd)
+            net.set_to_initialized_state()
+            net = net.to(DEV).train()
+            net.deterministic = True
+            x, logp = net(sparse, 4)
+            cd, _ = ops.chamfer_distance(x, dense)
+            loss = logp * 1e-4 + cd * 1e-1
+            loss.backward()
+            torch.cuda.synchronize()
+            res[on] = (x.detach().clone(), loss.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    finally:
+        setattr(T, name, was)
+        T.set_deterministic(False)
+    return res
+
+
+def test_gradient_fan_in_without_add_launches():
+    """Two places where autograd summed a tensor's gradients with launches of its own, now inside kernels of ours:
+    (a) a feature unit's output h_i feeds its FeatMergeUnit and unit i + 1 (interpflow.py:300-306): unit i + 1 hands h_i on to the
+        merge unit as a second output (tap), so the merge unit's gradient arrives at unit i + 1's backward and is added in the
+        epilogue of its dx GEMM (PfEcTrain.dx_add) - the same two addends, hence the same bits;
+    (b) the flattened conditioning features feed both flow chains and both injector families: FanoutFn sums the four gradients in
+        one launch (pf_sum_n) - another association of the same four addends, hence rounding-level differences only.
+    And pf_sum_n against torch for every operand count."""
+    from puflow_amd import _lib, train_ops as T
+    import ctypes
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for n in range(2, 9):
+        ts = [torch.randn(4 * 1031, generator=g).to(DEV) for _ in range(n)]
+        out = torch.empty_like(ts[0])
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        assert lib.pf_sum_n(ptrs, n, out.data_ptr(), out.numel(), None) == 0
+        ref = ts[0].clone()
+        for t in ts[1:]:
+            ref = ref + t
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), n
+    assert lib.pf_sum_n(ptrs, 8, out.data_ptr(), 6, None) == -2 and lib.pf_sum_n(ptrs, 1, out.data_ptr(), 8, None) == -2
+
+    sd = synth_state_dict(61)
+    dense = synth_patches(4, 1024, seed=62).to(DEV)
+    sparse = dense[:, ::4].contiguous()
+    res = _step_under_switch(T, "_TAP", sd, sparse, dense)
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    assert res[False][2].keys() == res[True][2].keys() and len(res[True][2]) > 150
+    for k in res[False][2]:
+        assert torch.equal(res[False][2][k], res[True][2][k]), k
+    res = _step_under_switch(T, "_FANOUT", sd, sparse, dense)
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    assert res[False][2].keys() == res[True][2].keys()
+    floor = 1e-5 * max(float(v.abs().max()) for v in res[False][2].values())      # the sums' rounding, carried through six units' backward
+    for k in res[False][2]:
+        a, b = res[False][2][k], res[True][2][k]
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + floor, k
+
+
 @pytest.mark.parametrize("B,N", [(4, 256), (3, 100)])
 def test_flow_chain_node_matches_the_per_block_nodes(B, N):
     """All flow blocks of a direction as one autograd node (csrc/train_flowchain.hip, FlowChainFn) against one node per block

@@ -59,6 +59,7 @@ def test_training_entry_points_validate_their_descriptors(built_lib):
     ec.K, ec.nconv = 16, 3
     assert lib.pf_ec_train_fwd(ctypes.byref(ec), None) == -3                      # growth * nconv must be 32 / 64 / 128
     assert lib.pf_ec_train_fwd(None, None) == -1 and lib.pf_ec_train_bwd(None, None) == -1
+    assert lib.pf_ec_train_fold_batch(None, 1, None) == -1 and lib.pf_ec_train_fold_batch(ctypes.byref(ec), 9, None) == -2
     m = _lib.PfMlpTrain()
     assert lib.pf_mlp_train_ws_floats(ctypes.byref(m)) == -1
     m.rows, m.nl, m.td, m.cc, m.cdiv = 64, 3, 1, 48, 1

@@ -17,7 +17,7 @@ opt = tm.configure_optimizers()["optimizer"]
 for _ in range(3):
     tm.train_step(batch, opt)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     tm.train_step(batch, opt)
     torch.cuda.synchronize()
 want = ("aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::copy_", "aten::clone", "aten::contiguous", "aten::zeros",
@@ -30,6 +30,8 @@ for e in prof.events():
             if "/root/repo" in fr or "puflow_amd" in fr or "tools/" in fr:
                 site = fr.split("/")[-1][:70]
                 break
+        if site.startswith("<"):
+            site += " " + str([tuple(x) for x in (e.input_shapes or []) if x])[:60]      # autograd's own adds: the shapes name the tensor
         cnt[(e.name, site)] += 1
-for (name, site), c in cnt.most_common(40):
+for (name, site), c in cnt.most_common(60):
     print(f"{c:5d}  {name:18s} {site}")
