@@ -346,6 +346,11 @@ typedef struct PfEcTrain {
  * capture the stream must belong to the capture (it joins it through the event) and is a parallel branch of the graph. */
 int pf_train_set_dw_stream(void* stream);
 int pf_knn_csr(const int* idx, int B, int N, int K, int* off, int* edge, int* cnt, void* stream);
+/* pf_knn_csr for idx [B*N, K] and for its first K2 <= K columns (as if those were stored contiguously: edge ids i K2 + k) from one
+ * pass: off [T+1], edge [T*K], off2 [T+1], edge2 [T*K2]; cnt: 2 x ((T + 3) / 4 * 4) ints of scratch.  The training step uses both
+ * (16 neighbours: feature units, 8: the interpolation unit, interpflow.py:85-151,300-306). */
+int pf_knn_csr_pair(const int* idx, int B, int N, int K, int K2, int* off, int* edge, int* off2, int* edge2, int* cnt, void* stream);
+
 /* sorts every list of pf_knn_csr (edge ids ascending; T = B*N lists): sums over a list then add in one order, run after run -
  * what PF_TRAIN_DETERMINISTIC's gather-form gradients need; the default mode does not call it */
 int pf_knn_csr_sort(const int* off, int* edge, int T, void* stream);
@@ -505,6 +510,11 @@ int pf_inject_inv2_bwd(const float* u, const float* s, const float* dv, int Rr, 
  * tensor with several consumers in ONE launch instead of autograd's n_terms - 1 pairwise adds (train_ops.FanoutFn).  ptrs: host
  * array of device pointers.  `out` may be one of the operands. */
 int pf_sum_n(const float* const* ptrs, int n_terms, float* out, long long n, void* stream);
+
+/* n <= 8 contiguous device regions of 32-bit words (4-byte aligned), dst[j][0 .. words[j]) = src[j][...], in ONE launch: the
+ * batch of a captured training step into the tensors its graph reads (train_graph.GraphedTrainStep).  src / dst / words: host
+ * arrays. */
+int pf_copy_n(const void* const* src, void* const* dst, const long long* words, int n, void* stream);
 
 /* WeightEstimationUnit's first conv folded into its producers' last linear layers (interpflow.py:98, 134, 144-146, 219-221: no
  * nonlinearity between them): W0 = [W0a | W0b] [o, 2 o], W6 [o, k6], Wout [o, ko]  ->  W6f = W0a W6, b6f = W0a b6 + b0,

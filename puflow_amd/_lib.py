@@ -185,6 +185,7 @@ SIGNATURES = {
     "pf_fold_wu_fwd": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 5),
     "pf_fold_wu_bwd": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 11),
     "pf_knn_csr": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_knn_csr_pair": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_knn_csr_sort": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "pf_ec_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_ec_train_fwd": (c_int, [c_void_p, c_void_p]),
@@ -205,6 +206,7 @@ SIGNATURES = {
     "pf_cnf_step": (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_float, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pf_sum_n": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_longlong, c_void_p]),
+    "pf_copy_n": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_longlong), c_int, c_void_p]),
     "pf_lincomb": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, c_void_p, c_longlong, c_void_p]),
     "pf_scaled_sumsq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_float), c_int, c_float, c_float,
                                 c_float, c_longlong, c_void_p, c_void_p, c_void_p]),

@@ -1873,6 +1873,46 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int* idx, int N, in
         edge[atomicAdd(cursor + (i / N) * N + idx[e], 1)] = (int)e;
     }
 }
+// Two lists from one pass over idx [T, K]: all K columns (cnt / edge ids i K + k) and the first K2 columns (cnt2 / edge ids
+// i K2 + k: what pf_knn_csr gives for idx[:, :K2] stored contiguously) - the training step needs both (K = 16: feature units,
+// K2 = 8: the interpolation unit), and each launch here is a few microseconds of work behind a launch of its own.
+__global__ __launch_bounds__(256) void csr_count2_kernel(const int* idx, int N, int K, int K2, long long E, int* cnt, int* cnt2) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long long)gridDim.x * 256) {
+        const long long i = e / K;
+        const long long j = (i / N) * N + idx[e];
+        atomicAdd(cnt + j, 1);
+        if ((int)(e - i * K) < K2) atomicAdd(cnt2 + j, 1);
+    }
+}
+__global__ __launch_bounds__(1024) void csr_scan2_kernel(int* cnt, int T, int Tpad, int* off, int* off2) {
+    __shared__ int part[1024];
+    if (blockIdx.x) { cnt += Tpad; off = off2; }
+    const int per = (T + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(T, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += cnt[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int i = lo; i < hi; ++i) { const int c = cnt[i]; off[i] = run; cnt[i] = run; run += c; }
+    if (threadIdx.x == 1023) off[T] = part[1023];
+}
+__global__ __launch_bounds__(256) void csr_fill2_kernel(const int* idx, int N, int K, int K2, long long E, int* cursor, int* cursor2,
+                                                        int* edge, int* edge2) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long long)gridDim.x * 256) {
+        const long long i = e / K;
+        const long long j = (i / N) * N + idx[e];
+        const int k = (int)(e - i * K);
+        edge[atomicAdd(cursor + j, 1)] = (int)e;
+        if (k < K2) edge2[atomicAdd(cursor2 + j, 1)] = (int)(i * K2 + k);
+    }
+}
 // the fill above hands out a list's slots in arrival order: sort every list (edge ids ascending) so that whatever is summed over it
 // - the dQ gather of the EdgeConv backward, the latent's gradient, the Chamfer gradient - adds in ONE order, run after run
 __global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ off, int* __restrict__ edge, int T) {
@@ -2863,6 +2903,23 @@ extern "C" int pf_knn_csr(const int* idx, int B, int N, int K, int* off, int* ed
     hipLaunchKernelGGL(csr_count_kernel, dim3(g), dim3(256), 0, s, idx, N, K, E, cnt);
     hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, T, off);
     hipLaunchKernelGGL(csr_fill_kernel, dim3(g), dim3(256), 0, s, idx, N, K, E, cnt, edge);
+    return pf_last_launch_status();
+}
+
+// pf_knn_csr for idx [B*N, K] AND for its first K2 columns (as if stored contiguously: edge ids i K2 + k) in the same four
+// launches: off / edge as above, off2 [T+1], edge2 [T*K2]; cnt: 2 x ((T + 3) / 4 * 4) ints of scratch.
+extern "C" int pf_knn_csr_pair(const int* idx, int B, int N, int K, int K2, int* off, int* edge, int* off2, int* edge2, int* cnt,
+                               void* stream) {
+    if (!idx || !off || !edge || !off2 || !edge2 || !cnt) return PF_ERR_NULL;
+    if (B <= 0 || N <= 0 || K <= 0 || K2 <= 0 || K2 > K || (long long)B * N > (1ll << 26)) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = B * N, Tpad = (T + 3) / 4 * 4;
+    const long long E = (long long)T * K;
+    const unsigned g = (unsigned)((E + 255) / 256 > 2048 ? 2048 : (E + 255) / 256);
+    hipLaunchKernelGGL(ec_zero_kernel, dim3(64), dim3(256), 0, s, reinterpret_cast<f4*>(cnt), (long long)(2 * Tpad) / 4);
+    hipLaunchKernelGGL(csr_count2_kernel, dim3(g), dim3(256), 0, s, idx, N, K, K2, E, cnt, cnt + Tpad);
+    hipLaunchKernelGGL(csr_scan2_kernel, dim3(2), dim3(1024), 0, s, cnt, T, Tpad, off, off2);
+    hipLaunchKernelGGL(csr_fill2_kernel, dim3(g), dim3(256), 0, s, idx, N, K, K2, E, cnt, cnt + Tpad, edge, edge2);
     return pf_last_launch_status();
 }
 

@@ -381,3 +381,39 @@ extern "C" int pf_sum_n(const float* const* ptrs, int n_terms, float* out, long 
     }
     return pf_last_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ batch hand-over
+// n <= 8 contiguous regions of 32-bit words copied by ONE launch (blockIdx.y = region): a captured training step takes its batch
+// (points, ground truth, radii, ...) into the tensors the graph reads - one copy launch per tensor before, each with its own
+// submission in front of the replay.
+namespace {
+struct CopyNArgs { const unsigned* src[8]; unsigned* dst[8]; long long words[8]; };
+__global__ __launch_bounds__(256) void copy_n_kernel(CopyNArgs a) {
+    const int r = blockIdx.y;
+    const unsigned* s = a.src[r];
+    unsigned* d = a.dst[r];
+    const long long n = a.words[r];
+    const bool vec = ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0;
+    const long long n4 = vec ? n / 4 : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) d[i] = s[i];
+}
+}  // namespace
+
+extern "C" int pf_copy_n(const void* const* src, void* const* dst, const long long* words, int n, void* stream) {
+    if (!src || !dst || !words) return PF_ERR_NULL;
+    if (n < 1 || n > 8) return PF_ERR_SHAPE;
+    CopyNArgs a{};
+    long long most = 0;
+    for (int j = 0; j < n; ++j) {
+        if (!src[j] || !dst[j]) return PF_ERR_NULL;
+        if (words[j] <= 0 || ((((uintptr_t)src[j]) | ((uintptr_t)dst[j])) & 3)) return PF_ERR_SHAPE;
+        a.src[j] = static_cast<const unsigned*>(src[j]); a.dst[j] = static_cast<unsigned*>(dst[j]); a.words[j] = words[j];
+        most = words[j] > most ? words[j] : most;
+    }
+    const long long want = (most / 4 + 255) / 256;
+    const unsigned gx = (unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want));
+    hipLaunchKernelGGL(copy_n_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a);
+    return pf_last_launch_status();
+}

@@ -163,6 +163,7 @@ class PuganLossFn(Function):
         ctx.cfg = (B, n, (w_logp, w_emd, w_cd), radius is not None, logp.shape)
         terms = out[1:4]
         ctx.mark_non_differentiable(terms)
+        ctx.set_materialize_grads(False)                   # no zero-filled gradient for `terms` (a launch per step)
         return out[0], terms
 
     @staticmethod
@@ -174,6 +175,8 @@ class PuganLossFn(Function):
         radius = sv[5] if has_r else None
         dev = pred.device
         f32 = dict(dtype=torch.float32, device=dev)
+        if g is None:                                      # (set_materialize_grads(False): only `terms` was used)
+            return (None,) * 8
         g1d = g.contiguous().float().view(1)
         seeds = torch.empty((3, B, n), **f32)              # graddist | g1 | g2
         dlogp = torch.empty((1,), **f32)

@@ -132,7 +132,22 @@ class GraphedTrainStep:
             pairs = [(d, v) for d, v in zip(self.static, batch) if isinstance(v, Tensor)]
         pairs = [(d, v) for d, v in pairs if d.data_ptr() != v.data_ptr() or d.shape != v.shape]      # already in place
         fast = [(d, v) for d, v in pairs if v.dtype == d.dtype and v.device == d.device and v.shape == d.shape]
-        if len(fast) > 1:
+        words = [(d, v) for d, v in fast if d.is_cuda and d.element_size() == 4 and d.is_contiguous() and v.is_contiguous()
+                 and d.numel() > 0]
+        if len(words) > 1:                                  # 32-bit tensors on the device: one launch of ours for up to 8 of them
+            import ctypes
+            from . import _lib
+            from .train_ops import _stream
+            lib = _lib.load()
+            for k in range(0, len(words), 8):
+                grp = words[k:k + 8]
+                n = len(grp)
+                src = (ctypes.c_void_p * n)(*[v.data_ptr() for _, v in grp])
+                dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in grp])
+                cnt = (ctypes.c_longlong * n)(*[d.numel() for d, _ in grp])
+                _lib.check(lib.pf_copy_n(src, dst, cnt, n, _stream()), "pf_copy_n")
+            fast = words
+        elif len(fast) > 1:
             torch._foreach_copy_([d for d, _ in fast], [v for _, v in fast])
         else:
             fast = []
@@ -143,7 +158,7 @@ class GraphedTrainStep:
     def _fwd_bwd(self) -> Tensor:
         self.bucket.drop_grads()
         loss = self.module.training_step(self.static, 0)
-        loss.backward()
+        loss.backward(self.module.backward_seed(loss) if hasattr(self.module, "backward_seed") else None)
         if self.multi:
             self.bucket.pack()
         return loss.detach()

@@ -1808,6 +1808,24 @@ def knn_csr(idx: Tensor):
     return off, edge
 
 
+def knn_csr_pair(idx: Tensor, K2: int):
+    """knn_csr(idx) and knn_csr(idx[..., :K2].contiguous()) from one pass over idx (pf_knn_csr_pair: 4 launches instead of 8)."""
+    B, N, K = idx.shape
+    T = B * N
+    dev = idx.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    off, edge = torch.empty(T + 1, **i32), torch.empty(T * K, **i32)
+    off2, edge2 = torch.empty(T + 1, **i32), torch.empty(T * K2, **i32)
+    cnt = torch.empty(2 * ((T + 3) // 4 * 4), **i32)
+    lib = _lib.load()
+    _lib.check(lib.pf_knn_csr_pair(idx.data_ptr(), B, N, K, K2, off.data_ptr(), edge.data_ptr(), off2.data_ptr(), edge2.data_ptr(),
+                                   cnt.data_ptr(), _stream()), "pf_knn_csr_pair")
+    if _DET:
+        _lib.check(lib.pf_knn_csr_sort(off.data_ptr(), edge.data_ptr(), T, _stream()), "pf_knn_csr_sort")
+        _lib.check(lib.pf_knn_csr_sort(off2.data_ptr(), edge2.data_ptr(), T, _stream()), "pf_knn_csr_sort")
+    return (off, edge), (off2, edge2)
+
+
 def _ec_fused_supported(p, x: Tensor, idx: Tensor, pooling: bool) -> bool:
     """Shapes the fused unit kernels are built for (csrc/train_fused.hip: ec_dims); anything else takes the per-op path."""
     g, nconv, odim = p.convs[0][0].weight.shape[0], len(p.convs), p.conv_out.weight.shape[0]
@@ -2032,7 +2050,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     csr16 = csr8 = None
     csr_side = use_side and _CSR_SIDE
     if fused_ec and not csr_side:
-        csr16, csr8 = knn_csr(idx16), knn_csr(idx8)
+        csr16, csr8 = knn_csr_pair(idx16, 8)
 
     # ---- interpolation weights (interpflow.py:85-151): a function of xyz and the neighbour lists only, independent of the
     # feature extractor / flow f chain that follows.  At 32 x 256 points no kernel of the step fills the chip, so this branch
@@ -2073,7 +2091,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             if fused_ec and csr_side:
-                csr8, csr16 = knn_csr(idx8), knn_csr(idx16)
+                csr16, csr8 = knn_csr_pair(idx16, 8)
             w = interp_weights()
     else:
         w = interp_weights()

@@ -244,6 +244,16 @@ class TrainerModule(_Base):
             self._fused_opt = optimizer                         # check_device_status reports its skipped updates
         return GraphedTrainStep(self, optimizer, batch, clip, warmup)
 
+    def backward_seed(self, loss: Tensor) -> Tensor:
+        """d loss / d loss = 1 as a tensor that exists already: `loss.backward()` would fill a new one each step (a launch)."""
+        one = getattr(self, "_seed_one", None)
+        if one is None or one.device != loss.device or one.dtype != loss.dtype or one.shape != loss.shape:
+            if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+                return torch.ones_like(loss)
+            one = torch.ones_like(loss)
+            self._seed_one = one
+        return one
+
     def train_step(self, batch, optimizer: torch.optim.Optimizer, clip: float = 1e-2) -> Tensor:
         self.train()
         self._sync_actnorm_init(batch)
@@ -251,7 +261,7 @@ class TrainerModule(_Base):
             self._bucket = FlatGradBucket(self.parameters())
         self._bucket.drop_grads()                               # = optimizer.zero_grad(set_to_none=True): no fill, no accumulate
         loss = self.training_step(batch, 0)
-        loss.backward()
+        loss.backward(self.backward_seed(loss))
         from .optim import FusedClipAdam
         if isinstance(optimizer, FusedClipAdam):
             self._fused_opt = optimizer

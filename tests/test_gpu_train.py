@@ -597,6 +597,41 @@ def test_batched_weight_fold_changes_no_bit():
         assert torch.equal(res[False][2][k], res[True][2][k]), k
 
 
+def test_batch_hand_over_in_one_launch():
+    """pf_copy_n: up to eight 32-bit regions copied by one launch (aligned and unaligned bases, sizes that are no multiple of 4),
+    and GraphedTrainStep._copy_in through it: the tensors the captured step reads hold the new batch."""
+    import ctypes
+    from puflow_amd import _lib
+    from puflow_amd.train_graph import GraphedTrainStep
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(8)
+    sizes = [1, 3, 4, 32 * 256 * 3, 32 * 1024 * 3, 32, 1023, 4099]
+    base = [torch.randn(n + 1, generator=g).to(DEV) for n in sizes]
+    src = [b[1:] if k % 2 else b[:-1] for k, b in enumerate(base)]             # odd ones start 4 bytes off a 16-byte boundary
+    dst = [torch.zeros(n + 2, device=DEV) for n in sizes]
+    dv = [d[2:] if k % 3 == 0 else d[:-2] for k, d in enumerate(dst)]
+    n = len(sizes)
+    assert lib.pf_copy_n((ctypes.c_void_p * n)(*[t.data_ptr() for t in src]), (ctypes.c_void_p * n)(*[t.data_ptr() for t in dv]),
+                         (ctypes.c_longlong * n)(*sizes), n, None) == 0
+    torch.cuda.synchronize()
+    for a, b, d, k in zip(src, dv, dst, range(n)):
+        assert torch.equal(a, b)
+        assert float(d[:2].abs().sum() if k % 3 == 0 else d[-2:].abs().sum()) == 0.0       # nothing written outside the region
+    assert lib.pf_copy_n(None, None, None, 1, None) == -1
+
+    class _Holder:
+        pass
+    h = _Holder()
+    h.static = (torch.zeros(4, 256, 3, device=DEV), torch.zeros(4, 1024, 3, device=DEV), torch.zeros(4, device=DEV),
+                torch.zeros(5, dtype=torch.int64, device=DEV))
+    new = (torch.randn(4, 256, 3, generator=g).to(DEV), torch.randn(4, 1024, 3, generator=g).to(DEV), torch.randn(4, generator=g).to(DEV),
+           torch.arange(5, device=DEV))
+    GraphedTrainStep._copy_in(h, new)
+    torch.cuda.synchronize()
+    for a, b in zip(h.static, new):
+        assert torch.equal(a, b)
+
+
 def _step_under_switch(T, name, sd, sparse, dense):
     """forward + backward of the bit-reproducible mode with train_ops.<name> off and on -> {flag: (x, loss, gradients)}"""
     from puflow_amd import ops

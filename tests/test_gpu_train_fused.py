@@ -485,3 +485,27 @@ def test_gemm_conflict_free_kernel_is_bit_identical(M, N, K, a_kfast, b_nfast, b
         ref = ref + b.double()
     assert torch.equal(out[0], out[1]), float((out[0] - out[1]).abs().max())
     assert float((out[0].double() - ref).abs().max()) <= 2e-6 * K ** 0.5 * float(ref.abs().max() + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(4, 256), (3, 100)])
+def test_paired_transposed_lists_equal_the_single_builds(B, N):
+    """pf_knn_csr_pair: the transposed neighbour lists of idx [B, N, 16] and of its first 8 columns from ONE pass (4 launches) -
+    the same offsets and, list by list, the same edge ids as pf_knn_csr on each tensor alone (slots inside a list are handed
+    out in arrival order: compared as sorted lists); every edge id appears exactly once."""
+    from puflow_amd import ops, train_ops
+    from puflow_amd.weights import synth_patches
+    xyz = synth_patches(B, N, seed=19).cuda()
+    idx16, _ = ops.knn_idx32(xyz, xyz, 16)
+    idx8 = idx16[..., :8].contiguous()
+    (o16, e16), (o8, e8) = train_ops.knn_csr_pair(idx16, 8)
+    for (off, edge), ref_idx, K in (((o16, e16), idx16, 16), ((o8, e8), idx8, 8)):
+        roff, redge = train_ops.knn_csr(ref_idx)
+        assert torch.equal(off, roff)
+        assert torch.equal(torch.sort(edge).values, torch.arange(B * N * K, dtype=torch.int32, device="cuda"))
+        seg = torch.repeat_interleave(torch.arange(B * N, device="cuda"), (off[1:] - off[:-1]).long())
+        key = seg * (B * N * K) + edge.long()                         # (list, edge id): sorting it sorts every list in place
+        rkey = seg * (B * N * K) + redge.long()
+        assert torch.equal(torch.sort(key).values, torch.sort(rkey).values)
+        tgt = (torch.arange(B * N, device="cuda") // N * N).repeat_interleave(K) + ref_idx.reshape(-1).long()
+        assert torch.equal(tgt[edge.long()], seg)                      # every edge sits in the list of the point it points at

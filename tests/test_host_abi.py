@@ -82,6 +82,9 @@ def test_training_entry_points_validate_their_descriptors(built_lib):
     assert lib.pf_clip_adam(None, None, None, None, None, 4, None, None, 0.9, 0.999, 1e-8, 1e-2, None, None, None, None) == -1
     assert lib.pf_knn_csr(None, 1, 16, 4, None, None, None, None) == -1
     assert lib.pf_knn_csr(8, 0, 16, 4, 8, 8, 8, None) == -2
+    assert lib.pf_sum_n(None, 2, None, 4, None) == -1 and lib.pf_copy_n(None, None, None, 1, None) == -1
+    assert lib.pf_knn_csr_pair(None, 1, 16, 4, 2, None, None, None, None, None, None) == -1
+    assert lib.pf_knn_csr_pair(8, 1, 16, 4, 5, 8, 8, 8, 8, 8, None) == -2          # K2 > K
     assert lib.pf_fps_grouped(None, 1, 16, 4, 0, None, None, None) == -1 and lib.pf_fps_grouped(8, 1, 16, 4, -1, 8, 8, None) == -2
     assert lib.pf_fold_wu_fwd(*([None] * 6), 128, 64, 137, *([None] * 5)) == -1
     assert lib.pf_fold_wu_bwd(*([8] * 5), 0, 64, 137, *([8] * 10), None) == -2

@@ -32,7 +32,8 @@ f = glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]), r.get("Queue_Id", "")) for r in csv.DictReader(open(f))]
 rows.sort()
 ends = [i for i, r in enumerate(rows) if "adam_update_kernel" in r[2]]
-a, b = ends[-2] + 1, ends[-1] + 1
+# bench.py runs 3 EAGER steps (its call profile) after the timed replays: the last REPLAY ends at the fourth-last optimizer kernel
+a, b = ends[-5] + 1, ends[-4] + 1
 step = rows[a:b]
 t0 = step[0][0]
 busy, cur_s, cur_e = 0, step[0][0], step[0][1]
