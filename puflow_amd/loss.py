@@ -2,6 +2,7 @@
 metric/emd/emd_module.py:31-79), backed by the HIP library."""
 from __future__ import annotations
 
+import os
 import torch
 import torch.nn as nn
 from torch import Tensor
@@ -117,6 +118,9 @@ class ChamferCUDA(nn.Module):
                                     point_reduction="mean")
 
 
+_CD_SIDE = os.environ.get("PF_LOSS_CD_SIDE", "1") != "0"      # Chamfer's nearest neighbours beside the EMD auction (side stream)
+
+
 class PuganLossFn(Function):
     """The PU-GAN training loss (train_pugan.py:52-67) as ONE autograd node:
         loss = w_logp logp + w_emd sum_b sum_n emd_dist[b, n] / radius[b] + w_cd mean_b chamfer(pred_b, gt_b)
@@ -141,20 +145,31 @@ class PuganLossFn(Function):
         assign2 = torch.empty((2, B, n), dtype=torch.int32, device=dev)
         scratch = torch.empty((5, B, n), dtype=torch.int32, device=dev)
         dist = torch.empty((B, n), **f32)
+        # ---- Chamfer (metric/loss.py:39-42: mean over points of both directions, mean over the batch) reads pred and gt only, like
+        # the auction: on the side stream beside it (two nearest-neighbour launches + two reductions, ~35 us the auction's chain
+        # does not wait for).  w_cd = 0: the EMD-only mix of train_pu1k.py:62-67 - no nearest-neighbour search at all
+        w_logp, w_emd, w_cd = (float(v) for v in weights)
+        per = None
+        i1 = i2 = torch.empty((0,), dtype=torch.int32, device=dev)
+        cd_side = None
+        if w_cd != 0.0 and _CD_SIDE and pred.is_cuda:
+            from .train_ops import _side_stream
+            cd_side = _side_stream(dev)
+            cd_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cd_side):
+                d1, d2, i1, i2, per, _ = ops.chamfer_nn(pred, gt)
         _lib.check(lib.pf_emd_init(price.data_ptr(), assign2.data_ptr(), B * n, ops._stream()), "pf_emd_init")
         max_inc, bid_inc, max_idx, bid, unass_idx = scratch[0], scratch[1], scratch[2], scratch[3], scratch[4]
         _lib.check(lib.pf_emd_forward_ex(pred.data_ptr(), gt.data_ptr(), dist.data_ptr(), assign2[0].data_ptr(), price.data_ptr(),
                                          assign2[1].data_ptr(), bid.data_ptr(), bid_inc.data_ptr(), max_inc.data_ptr(),
                                          unass_idx.data_ptr(), max_idx.data_ptr(), float(eps), int(iters), B, n, int(groups),
                                          _emd_status(dev).data_ptr(), ops._stream()), "pf_emd_forward")
-        # ---- Chamfer (metric/loss.py:39-42: mean over points of both directions, mean over the batch); w_cd = 0: the EMD-only
-        # mix of train_pu1k.py:62-67 - no nearest-neighbour search at all
-        w_logp, w_emd, w_cd = (float(v) for v in weights)
-        if w_cd != 0.0:
+        if cd_side is not None:
+            torch.cuda.current_stream().wait_stream(cd_side)
+            for t in (d1, d2, i1, i2, per):
+                t.record_stream(torch.cuda.current_stream())
+        elif w_cd != 0.0:
             d1, d2, i1, i2, per, _ = ops.chamfer_nn(pred, gt)
-        else:
-            i1 = i2 = torch.empty((0,), dtype=torch.int32, device=dev)
-            per = None
         out = torch.empty((4,), **f32)
         _lib.check(lib.pf_pugan_loss_fwd(logp1.data_ptr(), dist.data_ptr(), radius.data_ptr() if radius is not None else None,
                                          per.data_ptr() if per is not None else None, B, n, w_logp, w_emd, w_cd, out.data_ptr(),

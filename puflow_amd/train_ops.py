@@ -1835,6 +1835,10 @@ def _ec_fused_supported(p, x: Tensor, idx: Tensor, pooling: bool) -> bool:
             and (B * N * K) % 16 == 0 and (K == 16 or not pooling))
 
 
+# The interpolation branch runs on the side stream either way; this is only WHEN the host issues it: before the feature units
+# (default) or after them - autograd replays nodes in reverse creation order, so issued late it is the FIRST thing the backward
+# enqueues after the flow stage instead of the last
+_SIDE_LATE = os.environ.get("PF_TRAIN_SIDE_LATE", "0") == "1"
 _TAP = os.environ.get("PF_TRAIN_TAP", "1") != "0"     # a unit's output gradient from its merge unit added inside the next unit's dx GEMM
 _PREFOLD = os.environ.get("PF_TRAIN_PREFOLD", "1") != "0"     # the feature units' folded weights in one launch at the top of the forward
 
@@ -2092,7 +2096,8 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         with torch.cuda.stream(side):
             if fused_ec and csr_side:
                 csr16, csr8 = knn_csr_pair(idx16, 8)
-            w = interp_weights()
+            if not _SIDE_LATE:
+                w = interp_weights()
     else:
         w = interp_weights()
 
@@ -2120,6 +2125,9 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
             cs.append(mlp_fused(None, h, 0, 1, (0.0,), [m.conv1, m.conv2]).view(B, N, -1))
         else:
             cs.append(linear(ActFn.apply(linear(h, m.conv1.weight, m.conv1.bias), 0.0), m.conv2.weight))
+    if side is not None and _SIDE_LATE:
+        with torch.cuda.stream(side):
+            w = interp_weights()
     if hs_all:
         mp = []
         for m in net.merge_convs:
