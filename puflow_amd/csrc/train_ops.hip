@@ -516,12 +516,25 @@ void gemm_launch(const GemmArgs& g, int split, bool vec, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_kernel<WAVES_M, WAVES_N, TM, TN, false>), grid, dim3(256), 0, s, g);
 }
 
+#ifndef PF_GEMM_SMALL_TILES
+#define PF_GEMM_SMALL_TILES 1
+#endif
+// 64 x 64 tiles (shape 7), or - where those leave the chip with one 4-wave workgroup per CU or less (the [8192, 32..128] input
+// gradients of the EdgeConv units: 128 / 256 tiles, every k-step's loads exposed) - 32 x 64 (8) or 32 x 32 (9)
+inline int gemm_small_tile(int M, int N) {
+#if PF_GEMM_SMALL_TILES
+    const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    if (t64 <= 128 && M >= 32 && N > 32) return 9;
+    if (t64 <= 256 && M >= 32) return 8;
+#endif
+    return 7;
+}
 // tile shape for (M, N): 0 = 128x128, 1..3 = 256 x {16,32,64} (skinny N), 4..6 = {16,32,64} x 256 (skinny M)
 inline int gemm_shape(int M, int N) {
     // a skinny output whose 256-row tiles would not even give every second CU a workgroup (the [8192, 16..64] input-gradient
     // GEMMs of the training step: 32 tiles, 65 us for 0.27 G MAC) takes 64 x 64 tiles instead: 4 x the workgroups, no split-K
     // reduction, the wasted tile columns cost nothing at this size
-    if (N <= 64 && M > 64 && (M + 255) / 256 < 128 && (M + 63) / 64 >= 64) return 7;
+    if (N <= 64 && M > 64 && (M + 255) / 256 < 128 && (M + 63) / 64 >= 64) return gemm_small_tile(M, N);
     if (N <= 16) return 1;
     if (N <= 32) return 2;
     if (N <= 64 && M > 64) return 3;
@@ -530,11 +543,12 @@ inline int gemm_shape(int M, int N) {
     if (M <= 64) return 6;
     // 128 x 128 tiles leave most CUs idle on the point-level GEMMs of the training step ([8192, 128..512] outputs: 64..256
     // tiles, one 1-wave-per-SIMD workgroup per CU): 64 x 64 tiles there
-    if ((long long)((M + 127) / 128) * ((N + 127) / 128) < 1024) return 7;
+    if ((long long)((M + 127) / 128) * ((N + 127) / 128) < 1024) return gemm_small_tile(M, N);
     return 0;
 }
 inline void gemm_tile_dims(int shape, int& bm, int& bn) {
-    static const int d[8][2] = {{128, 128}, {256, 16}, {256, 32}, {256, 64}, {16, 256}, {32, 256}, {64, 256}, {64, 64}};
+    static const int d[10][2] = {{128, 128}, {256, 16}, {256, 32}, {256, 64}, {16, 256}, {32, 256}, {64, 256}, {64, 64}, {32, 64},
+                                 {32, 32}};
     bm = d[shape][0]; bn = d[shape][1];
 }
 
@@ -944,7 +958,7 @@ int pf_gemm_addend(int arith, const float* A, long long sam, long long sak, cons
             case 3: gemm_split_launch<4, 1, 4, 4>(arith, g, split, vec2, s); break;
             case 4: gemm_split_launch<1, 4, 1, 4>(arith, g, split, vec2, s); break;
             case 5: gemm_split_launch<1, 4, 2, 4>(arith, g, split, vec2, s); break;
-            case 7: gemm_split_launch<2, 2, 2, 2>(arith, g, split, vec2, s); break;
+            case 7: case 8: case 9: gemm_split_launch<2, 2, 2, 2>(arith, g, split, vec2, s); break;
             default: gemm_split_launch<1, 4, 4, 4>(arith, g, split, vec2, s); break;
         }
     } else if (arith == 0 && vec) {
@@ -956,6 +970,8 @@ int pf_gemm_addend(int arith, const float* A, long long sam, long long sak, cons
             case 4: gemm2_launch<1, 4, 1, 4>(g, split, s); break;
             case 5: gemm2_launch<1, 4, 2, 4>(g, split, s); break;
             case 7: gemm2_launch<2, 2, 2, 2>(g, split, s); break;
+            case 8: gemm2_launch<2, 2, 1, 2>(g, split, s); break;
+            case 9: gemm2_launch<2, 2, 1, 1>(g, split, s); break;
             default: gemm2_launch<1, 4, 4, 4>(g, split, s); break;
         }
     } else
@@ -966,7 +982,7 @@ int pf_gemm_addend(int arith, const float* A, long long sam, long long sak, cons
         case 3: gemm_launch<4, 1, 4, 4>(g, split, vec, s); break;
         case 4: gemm_launch<1, 4, 1, 4>(g, split, vec, s); break;
         case 5: gemm_launch<1, 4, 2, 4>(g, split, vec, s); break;
-        case 7: gemm_launch<2, 2, 2, 2>(g, split, vec, s); break;
+        case 7: case 8: case 9: gemm_launch<2, 2, 2, 2>(g, split, vec, s); break;
         default: gemm_launch<1, 4, 4, 4>(g, split, vec, s); break;
     }
     if (use_ws)

@@ -36,3 +36,25 @@ for name, M, N, K, akf, bnf in shapes:
     tot[0] += m0; tot[1] += m1
     print(f"{name:12s} [{M} x {N} x {K}]  gemm2 {m0:7.1f} us   gemm(v1) {m1:7.1f} us   {'bit-identical' if same else 'DIFFERENT'}", flush=True)
 print(f"sum          gemm2 {tot[0]:7.1f} us   gemm(v1) {tot[1]:7.1f} us")
+# the same shapes on the 16-bit pipe: arith 2 = split-fp16 (three products per term), 3 = split-bf16; error against float64
+for name, M, N, K, akf, bnf in shapes:
+    A = torch.randn((M, K) if akf else (K, M), device="cuda")
+    Bm = torch.randn((K, N) if bnf else (N, K), device="cuda")
+    sam, sak = (K, 1) if akf else (1, M)
+    sbk, sbn = (N, 1) if bnf else (1, K)
+    ref = (A.double() if akf else A.double().t()) @ (Bm.double() if bnf else Bm.double().t())
+    row = f"{name:12s} [{M} x {N} x {K}] "
+    for a in (0, 2, 3):
+        C = torch.empty((M, N), device="cuda")
+        ts = []
+        for rnd in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                T._gemm(A, sam, sak, Bm, sbk, sbn, C, N, None, M, N, K, a)
+            e1.record(); torch.cuda.synchronize()
+            if rnd:
+                ts.append(e0.elapsed_time(e1) / 10 * 1e3)
+        err = float((C.double() - ref).abs().max() / ref.abs().max())
+        row += f"  arith {a}: {sorted(ts)[len(ts) // 2]:6.1f} us (err {err:.1e})"
+    print(row, flush=True)
