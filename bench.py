@@ -678,8 +678,13 @@ def bench_train(args, world, rank, dev, dist):
                 with open(os.path.join(ROOT, "profiles", "pmc_train_latest.json")) as f:
                     pk = json.load(f)
                 pk = pk.get("kernels", pk)
-                gemm = "gemm2_kernel<2, 2, 2, 2>" if "gemm2_kernel<2, 2, 2, 2>" in pk else "gemm_kernel<2, 2, 2, 2, true>"    # round 5 / before
-                group = {"ec_pq_bwd_csr_kernel": 1, "ec_dw3_kernel": 1, gemm: 2, "gemm_reduce_kernel": 1, "ec_assemble_kernel": 1}
+                if "gemm2_kernel<2, 2, 1, 1>" in pk:                      # both point GEMMs of the call on 32 x 32 tiles (end of round 5)
+                    gemms = {"gemm2_kernel<2, 2, 1, 1>": 2}
+                elif "gemm2_kernel<2, 2, 2, 2>" in pk:
+                    gemms = {"gemm2_kernel<2, 2, 2, 2>": 2}
+                else:
+                    gemms = {"gemm_kernel<2, 2, 2, 2, true>": 2}          # before round 5
+                group = {"ec_pq_bwd_csr_kernel": 1, "ec_dw3_kernel": 1, **gemms, "gemm_reduce_kernel": 1, "ec_assemble_kernel": 1}
                 group.update({"ec_bwdp_kernel<32, 4, 128>": 1} if persist else {"ec_bwdg16_kernel<2, 0>": 4, "ec_bwd0_kernel": 1})
                 tot, us = 0.0, 0.0
                 for k, n in group.items():

@@ -516,15 +516,19 @@ void gemm_launch(const GemmArgs& g, int split, bool vec, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_kernel<WAVES_M, WAVES_N, TM, TN, false>), grid, dim3(256), 0, s, g);
 }
 
+#ifndef PF_GEMM_T9
+#define PF_GEMM_T9 256
+#endif
 #ifndef PF_GEMM_SMALL_TILES
 #define PF_GEMM_SMALL_TILES 1
 #endif
 // 64 x 64 tiles (shape 7), or - where those leave the chip with one 4-wave workgroup per CU or less (the [8192, 32..128] input
-// gradients of the EdgeConv units: 128 / 256 tiles, every k-step's loads exposed) - 32 x 64 (8) or 32 x 32 (9)
+// gradients of the EdgeConv units: 128 / 256 tiles, every k-step's loads exposed) - 32 x 32 (9; 32 x 64 = 8 for N <= 32).  Same box,
+// [8192, C] x K = 4 S: C = 32: 14.4 -> 10.6 us, 64: 24.9 -> 15.7, 128: 25.1 -> 21.9; training step 4.13 -> 4.08 ms
 inline int gemm_small_tile(int M, int N) {
 #if PF_GEMM_SMALL_TILES
     const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
-    if (t64 <= 128 && M >= 32 && N > 32) return 9;
+    if (t64 <= PF_GEMM_T9 && M >= 32 && N > 32) return 9;
     if (t64 <= 256 && M >= 32) return 8;
 #endif
     return 7;
