@@ -422,7 +422,15 @@ typedef struct PfMlpTrain {
     float* dW[3]; float* db[3];     /* db[l] nullable */
     float* ws; long long ws_floats; /* >= pf_mlp_train_ws_floats() */
     int chunk;                      /* rows per split-K chunk of the weight-gradient launch: 0 = default, else a multiple of 32 */
+    int flags;                      /* PF_MLP_DW_DZSUM (pf_mlp_train_dw_batch only; 0 everywhere else) */
 } PfMlpTrain;
+/* PfMlpTrain.flags, pf_mlp_train_dw_batch with cdiv > 1 and cc a multiple of 16: `dc` is an INPUT - [rows / cdiv, width[0]], the sum
+ * of dz[0] over the cdiv consecutive rows that share a conditioning row (pf_flowchain_bwd writes it: PfFlowChain.dz1s).  The
+ * conditioning columns of layer 0's weight gradient are then accumulated over the rows / cdiv summed rows,
+ *   sum_rows dz0[row]^T c[row / cdiv] = sum_points (sum_r dz0[point cdiv + r])^T c[point],
+ * and only the td <= 3 coordinate columns over all rows: a third of the layer's matrix work at cdiv = 4, same value up to the
+ * order of the additions. */
+#define PF_MLP_DW_DZSUM 1
 long long pf_mlp_train_ws_floats(const PfMlpTrain* p);
 int pf_mlp_train_fwd(const PfMlpTrain* p, void* stream);
 int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream);
@@ -480,6 +488,9 @@ typedef struct PfFlowChain {
     float* dw4[PF_FLOWCHAIN_MAXB]; float* db4[PF_FLOWCHAIN_MAXB];
     float* ws; long long ws_floats;
     void* dev_descs;
+    float* dz1s;                     /* backward, nullable, R > 1: [nb][rows / R, 64] = dz1 summed over the R rows of a conditioning
+                                      * row - with it the weight-gradient launch runs layer 0's conditioning columns over rows / R
+                                      * summed rows (PF_MLP_DW_DZSUM) */
 } PfFlowChain;
 long long pf_flowchain_ws_floats(const PfFlowChain* a);
 long long pf_flowchain_part_floats(const PfFlowChain* a);

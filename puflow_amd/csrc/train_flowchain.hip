@@ -198,7 +198,7 @@ __device__ __forceinline__ void fc_mlp_fwd(const float* lds, const float (&xv)[3
 // replicas of a conditioning row; sj = gradient of the leading coordinates
 __device__ __forceinline__ void fc_mlp_bwd(const float* lds, float do0, float do1, int td, const float* __restrict__ h1p,
                                            const float* __restrict__ h2p, float* dz1p, float* dz2p, float* dcp, int cc, int R,
-                                           bool valid, int col, int q, float (&sj)[3]) {
+                                           bool valid, int col, int q, float (&sj)[3], float* dz1sp) {
     f4 gl = pf_splat(0.f);
     if (q == 0) { gl[0] = do0; gl[1] = td == 1 ? do1 : 0.f; }
     f4 g2[4], g1[4];
@@ -222,6 +222,16 @@ __device__ __forceinline__ void fc_mlp_bwd(const float* lds, float do0, float do
         for (int r = 0; r < 4; ++r) acc[r] *= hv[r] > 0.f ? 1.f : FC_SLOPE;
         if (valid) *reinterpret_cast<f4*>(dz1p + ub * 16 + 4 * q) = acc;
         g1[ub] = acc;
+        if (dz1sp) {                                      // the same gradient summed over the R rows of this conditioning row (wave-uniform)
+            f4 sm = acc;
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1)
+                if (m < R) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sm[r] += __shfl_xor(sm[r], m);
+                }
+            if (valid && (col & (R - 1)) == 0) *reinterpret_cast<f4*>(dz1sp + ub * 16 + 4 * q) = sm;
+        }
     }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -461,7 +471,8 @@ __global__ __launch_bounds__(64 * FC_NW) void flowchain_bwd_kernel(PfFlowChain a
         }
         float sj[3];
         fc_mlp_bwd(lds, do0, do1, td, a.h1 + slab * 64, a.h2 + slab * 64, a.dz1 + slab * 64, a.dz2 + slab * 64,
-                   a.dc[i] + (size_t)pt * a.cc[i], a.cc[i], a.R, valid, col, q, sj);
+                   a.dc[i] + (size_t)pt * a.cc[i], a.cc[i], a.R, valid, col, q, sj,
+                   (a.dz1s && a.R > 1) ? a.dz1s + ((size_t)i * (rows / a.R) + pt) * 64 : nullptr);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (j < td) dmid[j] += sj[j];
@@ -595,19 +606,29 @@ int fc_check(const PfFlowChain* a, bool bwd) {
     return PF_OK;
 }
 
+#ifndef PF_FC_CHUNK_BIG
+#define PF_FC_CHUNK_BIG 512
+#endif
+#ifndef PF_FC_CHUNK
+#define PF_FC_CHUNK 256
+#endif
 void fc_desc(const PfFlowChain* a, int i, PfMlpTrain* d) {
     *d = PfMlpTrain{};
     const size_t slab = (size_t)i * a->rows;
     d->rows = a->rows; d->nl = 3; d->td = a->td[i]; d->ldy = 3; d->cc = a->cc[i]; d->cdiv = a->R;
     d->width[0] = 64; d->width[1] = 64; d->width[2] = 3 - a->td[i];
     d->slope[0] = d->slope[1] = FC_SLOPE;
-    d->chunk = a->rows >= 32768 ? 512 : 256;            // nb networks x 3 layers in one launch: long split-K chunks (tools/time_mlpdw.py: 129 vs 141 us, 55 vs 57 us)
+    d->chunk = a->rows >= 32768 ? PF_FC_CHUNK_BIG : PF_FC_CHUNK;            // nb networks x 3 layers in one launch: long split-K chunks (tools/time_mlpdw.py: 129 vs 141 us, 55 vs 57 us)
     d->y = a->mid ? a->mid + slab * 3 : nullptr;
     d->c = a->c[i];
     d->W[0] = a->w0[i]; d->W[1] = a->w2[i]; d->W[2] = a->w4[i];
     d->h[0] = a->h1 ? a->h1 + slab * 64 : nullptr; d->h[1] = a->h2 ? a->h2 + slab * 64 : nullptr;
     d->dout = a->dob ? a->dob + slab * 2 : nullptr;
     d->dz[0] = a->dz1 ? a->dz1 + slab * 64 : nullptr; d->dz[1] = a->dz2 ? a->dz2 + slab * 64 : nullptr;
+    if (a->dz1s && a->R > 1 && a->cc[i] % 16 == 0) {        // layer 0's conditioning columns over rows / R summed rows (PF_MLP_DW_DZSUM)
+        d->dc = a->dz1s + (size_t)i * (a->rows / a->R) * 64;
+        d->flags = PF_MLP_DW_DZSUM;
+    }
     d->dW[0] = a->dw0[i]; d->dW[1] = a->dw2[i]; d->dW[2] = a->dw4[i];
     d->db[1] = a->db2[i]; d->db[2] = a->db4[i];
 }

@@ -387,8 +387,76 @@ __device__ __forceinline__ void dw_block(const float* ar0, const float* br0, con
     }
 }
 
+// Products with a NARROW side on the vector ALU: S[w][n] = sum over rows [r_lo, r_hi) of wide[row, w] nar[row, n], n < NN <= 3
+// (the last layer of a conditioner has 1 - 3 outputs: dW = dout^T h; the td <= 3 coordinate columns of layer 0: dz0^T y), with the
+// column sums of both operands (whichever is the layer's A gives its bias gradient).  As a 32-row staged MFMA block such a product
+// fills 4 of a block's 36 tile slots and still pays the block's load -> LDS -> two barriers: the workgroup's time was its 16
+// blocks' latency.  Here: 16-byte loads of the wide rows straight into registers (W / 4 column groups x 256 / (W / 4) row lanes,
+// four rows in flight per thread), the row lanes' sums joined through LDS in a fixed order.
+// WIDE_OUT: S is written as out[off + w RB + col0 + n] (w = output channel), the bias from the wide sums; else as
+// out[off + n RB + w] (n = output channel), the bias from the narrow sums.
+template <bool WIDE_OUT>
+__device__ __forceinline__ void dw_narrow(gcp wide, int W, gcp nar, int ldn, int NN, int r_lo, int r_hi, float* lds, gp out,
+                                          int off, int boff, int RB, int col0) {
+    const int cgs = W >> 2, RL = 256 / cgs;
+    const int cg = threadIdx.x % cgs, rl = threadIdx.x / cgs;
+    f4 acc0 = pf_splat(0.f), acc1 = pf_splat(0.f), acc2 = pf_splat(0.f), wsum = pf_splat(0.f);
+    float ns0 = 0.f, ns1 = 0.f, ns2 = 0.f;
+    const int j1 = NN > 1 ? 1 : 0, j2 = NN > 2 ? 2 : 0;
+    for (int r = r_lo + rl; r < r_hi; r += 4 * RL) {
+        f4 w[4];
+        float n0[4], n1[4], n2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * RL;
+            const bool ok = rr < r_hi;
+            const size_t rc = ok ? rr : r_lo;
+            const f4 wv = *(gc4p)(wide + rc * W + cg * 4);
+            const float a = nar[rc * ldn], b = nar[rc * ldn + j1], c = nar[rc * ldn + j2];
+            w[u] = ok ? wv : pf_splat(0.f);
+            n0[u] = ok ? a : 0.f; n1[u] = (ok && NN > 1) ? b : 0.f; n2[u] = (ok && NN > 2) ? c : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc0 += w[u] * n0[u]; acc1 += w[u] * n1[u]; acc2 += w[u] * n2[u]; wsum += w[u];
+            ns0 += n0[u]; ns1 += n1[u]; ns2 += n2[u];
+        }
+    }
+    // [rl][w] -> (S[w][0], S[w][1], S[w][2], wsum[w]); behind it [rl] -> the narrow sums (column group 0 holds every row once)
+    f4* l4 = reinterpret_cast<f4*>(lds);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) l4[rl * W + cg * 4 + c] = f4{acc0[c], acc1[c], acc2[c], wsum[c]};
+    f4* ln = l4 + RL * W;
+    if (cg == 0) ln[rl] = f4{ns0, ns1, ns2, 0.f};
+    __syncthreads();
+    for (int wv = threadIdx.x; wv < W; wv += 256) {
+        f4 t = l4[wv];
+        for (int k = 1; k < RL; ++k) t += l4[k * W + wv];
+        if (WIDE_OUT) {
+            out[off + wv * RB + col0] = t[0];
+            if (NN > 1) out[off + wv * RB + col0 + 1] = t[1];
+            if (NN > 2) out[off + wv * RB + col0 + 2] = t[2];
+            out[boff + wv] = t[3];
+        } else {
+            out[off + wv] = t[0];
+            if (NN > 1) out[off + RB + wv] = t[1];
+            if (NN > 2) out[off + 2 * RB + wv] = t[2];
+        }
+    }
+    if (!WIDE_OUT && threadIdx.x == 0) {
+        f4 t = ln[0];
+        for (int k = 1; k < RL; ++k) t += ln[k];
+        out[boff] = t[0];
+        if (NN > 1) out[boff + 1] = t[1];
+        if (NN > 2) out[boff + 2] = t[2];
+    }
+}
+
 // MLP_DW_WAVES waves share one staged block (as csrc/train_fused.hip ec_dw_kernel: more waves per SIMD keep the matrix pipe fed
 // while others sit in the load -> LDS -> barrier phase)
+#ifndef PF_MLP_DW_NARROW
+#define PF_MLP_DW_NARROW 1
+#endif
 #ifndef PF_DW_OCC
 #define PF_DW_OCC 1
 #endif
@@ -398,11 +466,33 @@ __global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(Ml
     const PfMlpTrain p = mlp_desc(bb);
     const MlpG G = mlp_glob(p);
     const int chunk = mlp_chunk(p);
-    if ((int)blockIdx.x * chunk >= p.rows || (int)blockIdx.y >= p.nl) return;
+    // PF_MLP_DW_DZSUM: layer 0 in two pieces - the conditioning columns from the replica-summed dz0 over rows / cdiv rows (the extra
+    // blockIdx.y = nl), the td coordinate columns over all rows (blockIdx.y = 0, ONE column tile) - both into chunk blockIdx.x's
+    // partial tile, disjoint column tiles, so the reduction does not know
+    const bool split0 = (p.flags & PF_MLP_DW_DZSUM) != 0 && p.cdiv > 1;
+    const bool cpart = split0 && (int)blockIdx.y == p.nl;
+    if ((int)blockIdx.x * chunk >= p.rows || ((int)blockIdx.y >= p.nl && !cpart)) return;
     gp part = G.ws;
     const MlpShape sh = mlp_shape(p);
     const MlpDwLayout L = mlp_dw_layout(p, sh);
-    const int l = blockIdx.y;
+    const int l = cpart ? 0 : (int)blockIdx.y;
+    const bool ypart = split0 && !cpart && l == 0;
+#if PF_MLP_DW_NARROW
+    {
+        const int r_lo = blockIdx.x * chunk, r_hi = min(p.rows, r_lo + chunk);
+        gp outp = part + (size_t)blockIdx.x * L.total;
+        if (ypart) {                                   // dz0^T y: [64, td] behind the conditioning columns; dz0's column sums = the bias gradient
+            dw_narrow<true>((gcp)G.dz[0], sh.wo[0], G.y, p.ldy, p.td, r_lo, r_hi, lds, outp, L.off[0], L.boff[0], L.wb16[0], p.cc);
+            return;
+        }
+        const int wol = sel3(sh.wo, l), wil_ = sel3(sh.wi, l);
+        if (!cpart && l == p.nl - 1 && l > 0 && wol <= 3 && (wil_ == 16 || wil_ == 32 || wil_ == 64 || wil_ == 128)) {
+            dw_narrow<false>((gcp)sel2(G.h, l - 1), wil_, G.dout, wol, wol, r_lo, r_hi, lds, outp, sel3(L.off, l), sel3(L.boff, l),
+                             sel3(L.wb16, l), 0);
+            return;
+        }
+    }
+#endif
     // the wave index through readfirstlane: everything derived from it (a wave's tile list, the branch on its tile count) is then
     // wave-uniform TO THE COMPILER - with `threadIdx.x >> 6` hipcc put every tile's read + MFMA under its own exec mask
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), row = lane & 15, q = lane >> 4;
@@ -414,11 +504,12 @@ __global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(Ml
     constexpr int lda = MLP_LD, ldb = MLP_LD;
     float* As = lds;
     float* Bs = lds + MLP_EB * lda;
-    gcp asrc = l == p.nl - 1 ? G.dout : (gcp)sel2(G.dz, l);
+    gcp asrc = cpart ? (gcp)G.dc : (l == p.nl - 1 ? G.dout : (gcp)sel2(G.dz, l));
     gcp hsrc = l > 0 ? (gcp)sel2(G.h, l - 1) : (gcp)nullptr;
     const int wa = sel3(sh.wo, l), wil = sel3(sh.wi, l);
     const int offl = sel3(L.off, l), boffl = sel3(L.boff, l);
-    const int NT = RB / 16, NRT = RA / 16;
+    const int ct0 = ypart ? p.cc / 16 : 0;                                   // first column tile / column tiles of this workgroup
+    const int NT = ypart ? 1 : (cpart ? p.cc / 16 : RB / 16), NRT = RA / 16;
     // a wave's output tiles are CONSECUTIVE ids (row tile major): with 4 row tiles (64 output channels) and 4 waves they are one
     // row tile's columns, so the A fragment of a k step is read once for all of them (round 4 dealt the tiles round-robin: two
     // ds_read_b32 per MFMA, the LDS pipe next to saturated)
@@ -429,7 +520,7 @@ __global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(Ml
     for (int s = 0; s < MLP_SLOTS; ++s) {
         const int id = wave * nper + s;
         val[s] = s < nper && id < NRT * NT;
-        rts[s] = val[s] ? id / NT : 0; cts[s] = val[s] ? id % NT : 0;
+        rts[s] = val[s] ? id / NT : 0; cts[s] = ct0 + (val[s] ? id % NT : 0);
     }
     bool same = true;                                  // all of this wave's tiles in one row tile: one A read per k step
 #pragma unroll
@@ -438,7 +529,12 @@ __global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(Ml
     f4 acc[MLP_SLOTS];
 #pragma unroll
     for (int s = 0; s < MLP_SLOTS; ++s) acc[s] = pf_splat(0.f);
-    const int r_lo = blockIdx.x * chunk, r_hi = min(p.rows, r_lo + chunk);
+    const int dsh = 31 - __clz(p.cdiv);                 // cdiv is a power of two
+    const int esh = cpart ? dsh : 0;                     // the conditioning piece walks rows / cdiv summed rows (chunk and rows are multiples of cdiv)
+    const int r_lo = blockIdx.x * (chunk >> esh), r_hi = min(p.rows >> esh, r_lo + (chunk >> esh));
+    // (true by the early return above; without it hipcc guards the block loop and the kernel comes out at 174 + 104 registers,
+    // one wave per SIMD, instead of 123 + 72, two)
+    __builtin_assume(r_lo < r_hi);
     // staging in float4 units: a block's A image is 32 rows x RA columns, its B image 32 rows x bw columns (layer 0: the cc
     // conditioning columns; the td <= 3 columns behind them come from y, one scalar per thread).  RA / 4 and bw / 4 divide the
     // 256 threads, so unit n of a thread is ITS unit 0 moved down by n * (256 / units-per-row) rows: one pointer, one LDS
@@ -448,7 +544,6 @@ __global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(Ml
     // exec-masked regions with their own waits.
     constexpr int UN = (MLP_EB * 32 + NTH - 1) / NTH;                  // <= 4 units per thread and operand (128 columns)
     const bool vecA = (wa & 3) == 0;                   // the last layer of a conditioner has 1 - 3 output columns: scalar loads
-    const int dsh = 31 - __clz(p.cdiv);                 // cdiv is a power of two
     const int ra4 = RA / 4;
     const int bw = l > 0 ? wil : p.cc, bw4 = bw / 4;    // both are multiples of 16
     gcp bsrc = l > 0 ? hsrc : G.c;
@@ -456,14 +551,14 @@ __global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(Ml
     const int elB0 = threadIdx.x / bw4, cB = (threadIdx.x - elB0 * bw4) * 4, dEB = NTH / bw4;
     const bool colA = cA < wa;
     gcp pA = asrc + (size_t)(r_lo + min(elA0, MLP_EB - 1)) * wa + (colA ? cA : 0);
-    const int bsh = l > 0 ? 0 : dsh;                    // layer 0 reads the conditioning row of point (row >> dsh)
+    const int bsh = (l > 0 || cpart) ? 0 : dsh;         // layer 0 reads the conditioning row of point (row >> dsh)
     int rowB = r_lo + elB0;
     const long long offA = (long long)dEA * wa;        // unit n + 1 from unit n
     const long long stepA = (long long)MLP_EB * wa;
     float* const ldsA = As + elA0 * lda + cA;
     float* const ldsB = Bs + elB0 * ldb + cB;
     // layer 0: the td <= 3 columns behind the conditioning part come from y (row stride ldy): one scalar per thread and block
-    const bool ycol = l == 0 && p.td > 0 && (int)threadIdx.x < MLP_EB * p.td;
+    const bool ycol = l == 0 && !cpart && p.td > 0 && (int)threadIdx.x < MLP_EB * p.td;
     const int yel = ycol ? threadIdx.x / p.td : 0, yw = ycol ? threadIdx.x - yel * p.td : 0;
     gcp pY = ycol ? G.y + (size_t)(r_lo + yel) * p.ldy + yw : bsrc;
     const long long stepY = ycol ? (long long)MLP_EB * p.ldy : 0;
@@ -494,7 +589,7 @@ __global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(Ml
         pA += stepA;
 #pragma unroll
         for (int n = 0; n < UN; ++n) {
-            const bool ok = elB0 + n * dEB < MLP_EB && rb + elB0 + n * dEB < r_hi;
+            const bool ok = !ypart && elB0 + n * dEB < MLP_EB && rb + elB0 + n * dEB < r_hi;
             const f4 v = *(gc4p)(ok ? bsrc + (size_t)((rowB + n * dEB) >> bsh) * bw + cB : bsrc);
             rbv[n] = ok ? v : pf_splat(0.f);
         }
@@ -545,7 +640,7 @@ __global__ __launch_bounds__(64 * MLP_DW_WAVES, PF_DW_OCC) void mlp_dw_kernel(Ml
     if ((int)threadIdx.x < RA)
         for (int gI = 0; gI < NTH / RA; ++gI) bsum += As[gI * lda + threadIdx.x];
     gp out = part + (size_t)blockIdx.x * L.total;
-    if (threadIdx.x < RA) out[boffl + threadIdx.x] = bsum;
+    if (threadIdx.x < RA && !cpart) out[boffl + threadIdx.x] = bsum;
 #pragma unroll
     for (int s = 0; s < MLP_SLOTS; ++s)
         if (val[s])
@@ -661,6 +756,7 @@ extern "C" int pf_mlp_train_fwd(const PfMlpTrain* p, void* stream) {
 extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
     int st = mlp_check(p);
     if (st) return st;
+    if (p->flags) return PF_ERR_UNSUPPORTED;             // PF_MLP_DW_DZSUM reads dc: only where dc is not an output (pf_mlp_train_dw_batch)
     if (!p->dout || !p->ws) return PF_ERR_NULL;
     for (int l = 0; l < p->nl - 1; ++l)
         if (!p->h[l] || !p->dz[l]) return PF_ERR_NULL;
@@ -737,6 +833,7 @@ extern "C" int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_
         const PfMlpTrain* p = descs + k;
         int st = mlp_check(p);
         if (st) return st;
+        if (p->flags) return PF_ERR_UNSUPPORTED;
         if (p->nl != descs[0].nl || !p->dout || !p->ws) return PF_ERR_NULL;
         for (int l = 0; l < p->nl - 1; ++l)
             if (!p->h[l] || !p->dz[l]) return PF_ERR_NULL;
@@ -780,7 +877,7 @@ extern "C" int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_d
     if (!descs || !dev_descs) return PF_ERR_NULL;
     if (n < 1 || n > MLP_BATCH_MAX) return PF_ERR_SHAPE;
     size_t lds_w = 0;
-    int cmax = 1, tmax = 1;
+    int cmax = 1, tmax = 1, extra = 0;
     MlpBatch b{};
     for (int k = 0; k < n; ++k) {
         const PfMlpTrain* p = descs + k;
@@ -792,6 +889,12 @@ extern "C" int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_d
         for (int l = 0; l < p->nl; ++l)
             if (!p->dW[l]) return PF_ERR_NULL;
         if (p->ws_floats < pf_mlp_train_ws_floats(p)) return PF_ERR_WORKSPACE;
+        if (p->flags & ~PF_MLP_DW_DZSUM) return PF_ERR_UNSUPPORTED;
+        if ((p->flags & PF_MLP_DW_DZSUM) && p->cdiv > 1) {               // dc = the replica-summed dz[0] (see the header)
+            if (!p->dc) return PF_ERR_NULL;
+            if (p->cc % 16 != 0 || mlp_chunk(*p) % p->cdiv != 0) return PF_ERR_SHAPE;
+            extra = 1;
+        }
         const MlpShape sh = mlp_shape(*p);
         const MlpDwLayout L = mlp_dw_layout(*p, sh);
         int ramax = 0, rbmax = 0, total = 0;
@@ -808,7 +911,7 @@ extern "C" int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_d
     }
     hipStream_t s = pf_dw_fork((hipStream_t)stream);     // all of it is weight-gradient work
     (void)dev_descs;                                      // (kept in the ABI: the descriptors now travel as the kernels' own argument)
-    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b);
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl + extra, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b);
     hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(64 * MLP_RG), 0, s, b);
     return pf_last_launch_status();
 }

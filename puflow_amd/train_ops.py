@@ -1216,6 +1216,12 @@ class FlowChainFn(Function):
         dz = torch.empty((2, nb, rows, 64), **f32)
         dob = torch.empty((nb, rows, 2), **f32)
         d.dz1, d.dz2, d.dob = dz[0].data_ptr(), dz[1].data_ptr(), dob.data_ptr()
+        dzs = None
+        if R > 1 and _DZSUM:
+            # the first hidden layer's gradient summed over the R rows that share a conditioning row: the weight-gradient launch
+            # then runs that layer's conditioning columns (cc of cc + td) over rows / R summed rows (PF_MLP_DW_DZSUM)
+            dzs = torch.empty((nb, T, 64), **f32)
+            d.dz1s = dzs.data_ptr()
         sizes = [int(p.numel()) for p in prm]
         flat = torch.empty((sum(sizes),), **f32)                         # every parameter gradient of the chain, one buffer
         gp, off = [], 0
@@ -1246,6 +1252,7 @@ class FlowChainFn(Function):
         return (None, None, None, None, dx, dcflat, dst, None, *grads)
 
 
+_DZSUM = os.environ.get("PF_TRAIN_DZSUM", "1") != "0"         # g chain: conditioner weight gradients from replica-summed dz (FlowChainFn.backward)
 _FANOUT = os.environ.get("PF_TRAIN_FANOUT", "1") != "0"       # gradients of the flattened conditioning features summed in one launch
 
 
