@@ -38,7 +38,10 @@ constexpr int MLP_GRID = PF_MLP_GRID;
 #define PF_DW_ABL 0            // timing-only ablations of mlp_dw_kernel (tools/time_mlpdw.py): 1 no MFMA block, 2 no loads in the loop, 4 no LDS stores
 #endif
 constexpr int MLP_LD = 144;            // LDS row stride of the weight-gradient kernel's staged blocks: >= 128 / 144 columns, = 16 (mod 32) floats
-constexpr int MLP_EB = 32, MLP_DW_WAVES = PF_MLP_DW_WAVES, MLP_SLOTS = (36 + MLP_DW_WAVES - 1) / MLP_DW_WAVES;   // 36 = 4 x 9 tiles of the widest layer
+#ifndef PF_MLP_EB
+#define PF_MLP_EB 32
+#endif
+constexpr int MLP_EB = PF_MLP_EB, MLP_DW_WAVES = PF_MLP_DW_WAVES, MLP_SLOTS = (36 + MLP_DW_WAVES - 1) / MLP_DW_WAVES;   // 36 = 4 x 9 tiles of the widest layer
 // rows per split-K chunk (multiple of MLP_EB): the descriptor's choice (batched launches have networks x layers of parallelism
 // already and want long chunks: fewer partial sums to write and add), else sized so that one network fills the chip
 #ifndef PF_MLP_CHUNK_BIG
@@ -782,6 +785,7 @@ extern "C" int pf_mlp_train_bwd(const PfMlpTrain* p, void* stream) {
         int ramax = 0, rbmax = 0;
         for (int l = 0; l < p->nl; ++l) { ramax = ramax > sh.wo16[l] ? ramax : sh.wo16[l]; rbmax = rbmax > L.wb16[l] ? rbmax : L.wb16[l]; }
         const size_t lds = sizeof(float) * (size_t)MLP_EB * 2 * MLP_LD;
+        allow_lds(mlp_dw_kernel, lds);
         hipLaunchKernelGGL(mlp_dw_kernel, dim3(nchunk, p->nl), dim3(64 * MLP_DW_WAVES), lds, s, mlp_one(*p));
     }
     int total = 0;
@@ -866,6 +870,7 @@ extern "C" int pf_mlp_train_bwd_batch(const PfMlpTrain* descs, int n, void* dev_
     if (descs[0].nl == 2) { allow_lds(mlp_bwd_kernel<2>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(gmax, 1, n), dim3(256), lds_b, s, b); }
     else { allow_lds(mlp_bwd_kernel<3>, lds_b); hipLaunchKernelGGL(mlp_bwd_kernel<3>, dim3(gmax, 1, n), dim3(256), lds_b, s, b); }
     s = pf_dw_fork(s);                                   // (dev_descs must then be this call's own: the next upload is not ordered behind it)
+    allow_lds(mlp_dw_kernel, lds_w);
     hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b);
     hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(64 * MLP_RG), 0, s, b);
     return pf_last_launch_status();
@@ -911,6 +916,7 @@ extern "C" int pf_mlp_train_dw_batch(const PfMlpTrain* descs, int n, void* dev_d
     }
     hipStream_t s = pf_dw_fork((hipStream_t)stream);     // all of it is weight-gradient work
     (void)dev_descs;                                      // (kept in the ABI: the descriptors now travel as the kernels' own argument)
+    allow_lds(mlp_dw_kernel, lds_w);
     hipLaunchKernelGGL(mlp_dw_kernel, dim3(cmax, descs[0].nl + extra, n), dim3(64 * MLP_DW_WAVES), lds_w, s, b);
     hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((tmax + 63) / 64, 1, n), dim3(64 * MLP_RG), 0, s, b);
     return pf_last_launch_status();

@@ -36,6 +36,10 @@ def build(kind, chunk):
             d.y, d.c = y.data_ptr(), c.data_ptr()
             d.h[0], d.h[1], d.dz[0], d.dz[1], d.dout = h[0].data_ptr(), h[1].data_ptr(), dz[0].data_ptr(), dz[1].data_ptr(), dout.data_ptr()
             d.chunk = chunk
+            if kind == "g" and os.environ.get("PF_TIME_DZSUM", "1") != "0":      # as pf_flowchain_bwd hands it over: dc = replica-summed dz[0]
+                dzs = dz[0].view(T, R, 64).sum(1).contiguous()
+                keep.append(dzs)
+                d.dc, d.flags = dzs.data_ptr(), 1
             descs.append(d)
     else:
         for k in range(12):
@@ -73,7 +77,7 @@ s = torch.cuda.current_stream().cuda_stream
 chunks = [int(a) for a in sys.argv[1:]] or [0]
 for kind in ("g", "f", "cond"):
     for chunk in chunks:
-        ch = chunk or {"g": 256, "f": 128, "cond": 256}[kind]
+        ch = chunk or {"g": 512, "f": 256, "cond": 256}[kind]           # what the training step uses
         arr, n, keep, wsf = build(kind, ch)
         ts = []
         for rnd in range(6):
