@@ -1846,6 +1846,7 @@ def _ec_fused_supported(p, x: Tensor, idx: Tensor, pooling: bool) -> bool:
 # (default) or after them - autograd replays nodes in reverse creation order, so issued late it is the FIRST thing the backward
 # enqueues after the flow stage instead of the last
 _SIDE_LATE = os.environ.get("PF_TRAIN_SIDE_LATE", "0") == "1"
+_SIDE_STREAM = os.environ.get("PF_TRAIN_STREAMS", "1") != "0"      # "0": the interpolation branch on the calling stream (timing reference)
 _TAP = os.environ.get("PF_TRAIN_TAP", "1") != "0"     # a unit's output gradient from its merge unit added inside the next unit's dx GEMM
 _PREFOLD = os.environ.get("PF_TRAIN_PREFOLD", "1") != "0"     # the feature units' folded weights in one launch at the top of the forward
 
@@ -2055,7 +2056,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     idx16, _ = ops.knn_idx32(xyz, xyz, 16)
     idx8 = idx16[..., :8].contiguous()
     fused_ec = _FUSED                                     # also under SyncBN: the fused kernels defer a layer's statistics to an all-reduce
-    use_side = getattr(net, "train_streams", True) and not _sync_bn_active()
+    use_side = getattr(net, "train_streams", True) and not _sync_bn_active() and _SIDE_STREAM
     # transposed neighbour lists: only the BACKWARD of the EdgeConv units reads them - with a side stream they are built there,
     # off the main chain (8 small launches, ~55 us), and joined with the interpolation weights
     csr16 = csr8 = None
