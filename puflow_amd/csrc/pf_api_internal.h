@@ -40,6 +40,8 @@ void* pf_dw_stream_get();
 // made to wait for everything enqueued on s so far
 hipStream_t pf_dw_fork(hipStream_t s);
 // pf_gemm_ex with an addend: C = A B + bias + addend (addend [M, ldc] laid out like C, nullable, may alias C) - csrc/train_ops.hip
+// slabs_left: nullable; when given and the product is split over K, the slabs stay in ws ([n][M, N], *slabs_left = n, no reduction
+// launch: the caller sums them where it reads the result) - else *slabs_left = 0 and C holds the product
 int pf_gemm_addend(int arith, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
                    float* C, long long ldc, const float* bias, const float* addend, int M, int N, int K, float* ws,
-                   long long ws_floats, void* stream);
+                   long long ws_floats, void* stream, int* slabs_left);

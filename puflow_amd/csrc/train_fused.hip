@@ -2643,7 +2643,10 @@ __global__ __launch_bounds__(256) void ec_fold_batch_kernel(EcFoldBatch fb) {
 // dW_t[r, :] = [dWp | dWq | dWq - dWp | sum_chunks part[:, rowoff_t + r, :g t]],  dbias_t[r] = sum_chunks bpart[:, rowoff_t + r].
 // 64 consecutive elements per workgroup, the chunk sum split four ways (threadIdx.y) and joined through LDS.
 constexpr int ASM_G = 16;            // groups of 64 threads that share the chunk range of an output element
-__global__ __launch_bounds__(64 * ASM_G) void ec_assemble_kernel(EcConvs cv, const float* dWpq, const float* part, int nchunk,
+// dWpq arrives as `nslab` split-K slabs [nslab][2 S, C] of its point GEMM (nslab = 1: the finished product): their sum is taken here,
+// by the same 16 lanes per element that add the growth partials - it was a launch of its own (gemm_reduce_kernel) in front of this
+// one, seven per step, and a replayed step pays ~5 - 10 us per kernel boundary.
+__global__ __launch_bounds__(64 * ASM_G) void ec_assemble_kernel(EcConvs cv, const float* dWpq, int nslab, const float* part, int nchunk,
                                                                 const float* bpart, int total) {
     __shared__ double sh[ASM_G][64], shb[ASM_G][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -2669,16 +2672,23 @@ __global__ __launch_bounds__(64 * ASM_G) void ec_assemble_kernel(EcConvs cv, con
         }
         for (; k < nchunk; k += ASM_G) s += (double)part[((size_t)k * cv.S + srow) * cv.GT + u];
     }
+    if (ok && !grow) {                                 // [dWp | dWq | dWq - dWp] from the slabs of dWpq = [dWp; dWq]
+        const int kind = col / cv.C, cc = col - kind * cv.C;
+        const size_t ip = (size_t)srow * cv.C + cc, iq = (size_t)(cv.S + srow) * cv.C + cc, stride = (size_t)2 * cv.S * cv.C;
+        double sp = 0.0, sq = 0.0;
+        for (int k = ty; k < nslab; k += ASM_G) {
+            const float vp = dWpq[k * stride + (kind != 1 ? ip : iq)], vq = dWpq[k * stride + (kind != 0 ? iq : ip)];
+            sp += (double)vp; sq += (double)vq;
+        }
+        s = kind == 0 ? sp : (kind == 1 ? sq : sq - sp);
+    }
     if (ok && col == 0)
         for (int k = ty; k < nchunk; k += ASM_G) sb += (double)bpart[(size_t)k * cv.S + srow];
     sh[ty][tx] = s; shb[ty][tx] = sb;
     __syncthreads();
     if (ty != 0 || !ok) return;
     float v;
-    if (col < cv.C) v = dWpq[(size_t)srow * cv.C + col];
-    else if (col < 2 * cv.C) v = dWpq[(size_t)(cv.S + srow) * cv.C + col - cv.C];
-    else if (col < 3 * cv.C) v = dWpq[(size_t)(cv.S + srow) * cv.C + col - 2 * cv.C] - dWpq[(size_t)srow * cv.C + col - 2 * cv.C];
-    else {
+    {
         double a = 0.0;
 #pragma unroll
         for (int k = 0; k < ASM_G; ++k) a += sh[k][tx];
@@ -3144,7 +3154,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     // ---- dx first: it is what the unit before this one waits for
     if (p->dx) {
         st = pf_gemm_addend(0, p->dPQ, 2 * d.S, 1, p->Wpq, p->C, 1, p->dx, p->C, nullptr, p->dx_add, d.T, p->C, 2 * d.S, gws,
-                            pf_gemm_ws_floats(d.T, p->C, 2 * d.S), stream);
+                            pf_gemm_ws_floats(d.T, p->C, 2 * d.S), stream, nullptr);
         if (st) return st;
     }
     // ---- growth-weight gradients (partials), dWpq, assembly: nobody reads them before the optimizer
@@ -3214,17 +3224,24 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     const long long dw_cap = gemm_ws_max(p, d) / ((long long)2 * d.S * p->C);
     const int dw_want = (int)(dw_cap < 128 ? dw_cap : 128);
     const int dw_chunk = dw_want > 0 ? (d.T + dw_want - 1) / dw_want : d.T, dw_slabs = (d.T + dw_chunk - 1) / dw_chunk;
+    const float* asm_src = p->dWpq;
+    int asm_slabs = 1;
     if (p->C <= 4 && dw_want >= 16) {
         hipLaunchKernelGGL(ec_dwpq_small_kernel, dim3(dw_slabs, (2 * d.S + 255) / 256), dim3(256), 0, s, p->dPQ, p->x, 2 * d.S, p->C,
                            d.T, dw_chunk, gws_dw);
-        st = pf_gemm_reduce(gws_dw, p->dWpq, 2 * d.S, p->C, p->C, dw_slabs, stream);
-    } else
-        st = pf_gemm(p->dPQ, 1, 2 * d.S, p->x, p->C, 1, p->dWpq, p->C, nullptr, 2 * d.S, p->C, d.T, gws_dw,
-                     pf_gemm_ws_floats(2 * d.S, p->C, d.T), stream);
+        st = pf_last_launch_status();
+        asm_src = gws_dw; asm_slabs = dw_slabs;
+    } else {
+        int nsl = 0;                                    // split-K slabs left in gws_dw (0: the product went straight into dWpq)
+        st = pf_gemm_addend(0, p->dPQ, 1, 2 * d.S, p->x, p->C, 1, p->dWpq, p->C, nullptr, nullptr, 2 * d.S, p->C, d.T, gws_dw,
+                            pf_gemm_ws_floats(2 * d.S, p->C, d.T), stream, &nsl);
+        if (nsl > 0) { asm_src = gws_dw; asm_slabs = nsl; }
+    }
     if (st) return st;
     int total = 0;
     for (int t = 0; t < d.nconvs; ++t) total += cv.rows[t] * cv.width[t];
-    hipLaunchKernelGGL(ec_assemble_kernel, dim3((total + 63) / 64), dim3(64 * ASM_G), 0, s, cv, p->dWpq, dwpart, d.nchunk, bpart, total);
+    hipLaunchKernelGGL(ec_assemble_kernel, dim3((total + 63) / 64), dim3(64 * ASM_G), 0, s, cv, asm_src, asm_slabs, dwpart, d.nchunk, bpart,
+                       total);
     return pf_last_launch_status();
 }
 

@@ -927,12 +927,13 @@ extern "C" long long pf_gemm_ws_floats(int M, int N, int K) {
 extern "C" int pf_gemm_ex(int arith, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
                           float* C, long long ldc, const float* bias, int M, int N, int K, float* ws, long long ws_floats,
                           void* stream) {
-    return pf_gemm_addend(arith, A, sam, sak, B, sbk, sbn, C, ldc, bias, nullptr, M, N, K, ws, ws_floats, stream);
+    return pf_gemm_addend(arith, A, sam, sak, B, sbk, sbn, C, ldc, bias, nullptr, M, N, K, ws, ws_floats, stream, nullptr);
 }
 // (internal, pf_api_internal.h) the same with an addend: C = A B + bias + addend, addend [M, ldc] laid out like C (it may be C)
 int pf_gemm_addend(int arith, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
                    float* C, long long ldc, const float* bias, const float* addend, int M, int N, int K, float* ws,
-                   long long ws_floats, void* stream) {
+                   long long ws_floats, void* stream, int* slabs_left) {
+    if (slabs_left) *slabs_left = 0;
     if (arith != 0 && arith != 1 && arith != 2 && arith != 3) return PF_ERR_UNSUPPORTED;
     if (!A || !B || !C) return PF_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return PF_ERR_SHAPE;
@@ -989,7 +990,8 @@ int pf_gemm_addend(int arith, const float* A, long long sam, long long sak, cons
         case 7: case 8: case 9: gemm_launch<2, 2, 2, 2>(g, split, vec, s); break;
         default: gemm_launch<1, 4, 4, 4>(g, split, vec, s); break;
     }
-    if (use_ws)
+    if (use_ws && slabs_left && !bias && !addend) *slabs_left = split;       // the caller sums the slabs itself
+    else if (use_ws)
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(((long long)M * N + 63) / 64)), dim3(256), 0, s, ws, C, bias, M,
                            N, ldc, split, addend);
     return pf_last_launch_status();
