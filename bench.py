@@ -666,7 +666,7 @@ def bench_train(args, world, rank, dev, dist):
             roof = {"bound": "mfma", "kernel": "pf_ec_train_bwd of a 128-channel EdgeConv unit (csrc/train_fused.hip: " +
                                              ("ec_bwdp_kernel - the dense block's backward as one persistent launch with a grid barrier per "
                                               "BatchNorm layer - " if persist else "ec_bwdg16_kernel x4, ec_bwd0_kernel, ") +
-                                             "ec_pq_bwd_csr_kernel, ec_dw3_kernel, two gemm2_kernel + gemm_reduce_kernel, ec_assemble_kernel)",
+                                             "ec_pq_bwd_csr_kernel, ec_dw3_kernel, two gemm2_kernel, ec_assemble_kernel)",
                     "achieved": flops / (ec_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": flops / (ec_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None, "avg_launch_ms": ec_ms,
                     "flops_basis": f"algorithmic: {EC_BWD_MAC_PER_EDGE} MAC per edge x {E} edges per call, each product once (split-bf16 "
@@ -684,7 +684,9 @@ def bench_train(args, world, rank, dev, dist):
                     gemms = {"gemm2_kernel<2, 2, 2, 2>": 2}
                 else:
                     gemms = {"gemm_kernel<2, 2, 2, 2, true>": 2}          # before round 5
-                group = {"ec_pq_bwd_csr_kernel": 1, "ec_dw3_kernel": 1, **gemms, "gemm_reduce_kernel": 1, "ec_assemble_kernel": 1}
+                group = {"ec_pq_bwd_csr_kernel": 1, "ec_dw3_kernel": 1, **gemms, "ec_assemble_kernel": 1}
+                if "gemm_reduce_kernel" in pk:                            # (until ec_assemble_kernel took over dWpq's slab sums)
+                    group["gemm_reduce_kernel"] = 1
                 group.update({"ec_bwdp_kernel<32, 4, 128>": 1} if persist else {"ec_bwdg16_kernel<2, 0>": 4, "ec_bwd0_kernel": 1})
                 tot, us = 0.0, 0.0
                 for k, n in group.items():
