@@ -483,6 +483,16 @@ __global__ __launch_bounds__(256) void ec_fwd16_kernel(EcFwdArgs a) {
 // other barrier kernel of this process can be in flight); the spin is bounded anyway: on timeout the status word sync[3] is
 // set, the unit's output becomes NaN and the grid drains.
 constexpr int ECP_WAVES = 8, ECP_T = 64 * ECP_WAVES, ECP_TPW = 4;
+// Tiles per wave of the narrow units (growth 8 / 16) as a build parameter.  They wait 82 - 84 % of their cycles (PMC) with two
+// waves per SIMD; at 2 tiles per wave they need half the registers (86 - 120 VGPRs) and run as 512 workgroups, two per CU.  Measured
+// (round 5, -DPF_ECP_TPW_SMALL=2): the unit's forward alone 78 -> 102 us (twice the arrivals per barrier, twice the weight staging),
+// and inside the training step - where the side stream's kernels hold wave slots and a grid of exactly 2 x 256 workgroups has no
+// slack - barrier time-outs.  Not used: 4, like the 128-channel units (which at 2 tiles per wave would need 143 - 176 registers: two
+// workgroups do not fit a CU).
+#ifndef PF_ECP_TPW_SMALL
+#define PF_ECP_TPW_SMALL 4
+#endif
+__host__ __device__ constexpr int ecp_tpw(int G) { return G <= 16 ? PF_ECP_TPW_SMALL : ECP_TPW; }
 constexpr int ECP_SPIN = 1 << 22;
 // timing-only ablations of ec_fwdp_kernel (tools/time_ecunit.py with -DPF_ECP_DBG=mask builds; results are WRONG with any bit set):
 // 1 no conv_out, 2 barriers pass at once, 4 no weight staging, 8 no Y stores, 16 no statistics atomics
@@ -550,6 +560,7 @@ __device__ __forceinline__ bool ecp_barrier(unsigned* sync, unsigned gen, int* f
 
 template <int G, int NC, int ODIM>
 __global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
+    constexpr int TPW = ecp_tpw(G);                   // tiles of 16 edges a wave owns for the whole launch
     constexpr int GT = G * NC, NB = GT / 16, NTG = (G + 15) / 16, NTO = ODIM / 16, NCP = NB / 2;
 #ifndef PF_ECP_OCH
 #define PF_ECP_OCH 1
@@ -565,30 +576,30 @@ __global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
 
     // ---- this wave's tiles
-    int tl[ECP_TPW], jr[ECP_TPW];
-    bool ok[ECP_TPW];
+    int tl[TPW], jr[TPW];
+    bool ok[TPW];
 #pragma unroll
-    for (int s = 0; s < ECP_TPW; ++s) {
+    for (int s = 0; s < TPW; ++s) {
         tl[s] = blockIdx.x * ECP_WAVES + wave + s * gridDim.x * ECP_WAVES;
         ok[s] = tl[s] < a.ntiles;
         const int tt = ok[s] ? tl[s] : 0;
         jr[s] = (tt / a.N) * a.N + a.idx[(size_t)tt * 16 + col];
         tl[s] = tt;
     }
-    f4 f[ECP_TPW][NB];
+    f4 f[TPW][NB];
 #pragma unroll
-    for (int s = 0; s < ECP_TPW; ++s)
+    for (int s = 0; s < TPW; ++s)
 #pragma unroll
         for (int b = 0; b < NB; ++b) f[s][b] = pf_splat(0.f);
     // the addends P_t[i] + Q_t[j] of layer t for all the wave's tiles (independent gathers, all in flight together).  OWN layers
     // accumulate in the feature slots they are about to fill (free until then), so layer t + 1's addends can be fetched BEFORE
     // the barrier of layer t and their latency disappears behind it
-    f4 accs[OWN ? 1 : ECP_TPW][NTG];
+    f4 accs[OWN ? 1 : TPW][NTG];
     auto addends = [&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr int col0 = G * t, b0 = col0 / 16;
 #pragma unroll
-        for (int s = 0; s < ECP_TPW; ++s)
+        for (int s = 0; s < TPW; ++s)
 #pragma unroll
             for (int nt = 0; nt < NTG; ++nt) {
                 const int c4 = 16 * (b0 + nt) + 4 * q;
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
         if constexpr (!OWN && t > 0) addends(tc);
         // this lane's channels of the layer: c4 = 16 (b0 + nt) + 4 q .. + 3
         bool cv[NTG];
-        f4 piv[NTG], s0[NTG], s1[NTG], ycur[OWN ? 1 : ECP_TPW][NTG];
+        f4 piv[NTG], s0[NTG], s1[NTG], ycur[OWN ? 1 : TPW][NTG];
 #pragma unroll
         for (int nt = 0; nt < NTG; ++nt) {
             const int c4 = 16 * (b0 + nt) + 4 * q;
@@ -683,11 +694,11 @@ __global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
                 for (int nt = 0; nt < NTG; ++nt) {
                     const f4 w = *reinterpret_cast<const f4*>(Wl + (nt * 16 + col) * kp + ks * 16 + 4 * q);
 #pragma unroll
-                    for (int s = 0; s < ECP_TPW; ++s) A(s, nt) = mfma4(w, f[s][ks], A(s, nt));
+                    for (int s = 0; s < TPW; ++s) A(s, nt) = mfma4(w, f[s][ks], A(s, nt));
                 }
         }
 #pragma unroll
-        for (int s = 0; s < ECP_TPW; ++s)
+        for (int s = 0; s < TPW; ++s)
 #pragma unroll
             for (int nt = 0; nt < NTG; ++nt) {
                 const f4 v = A(s, nt);
@@ -775,7 +786,7 @@ __global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
             // the raw tile goes to memory only now (the backward reads it): its stores are in flight during the next layer
             // instead of in front of this layer's barrier, whose s_waitcnt would have waited for them
 #pragma unroll
-            for (int s = 0; s < ECP_TPW; ++s) {
+            for (int s = 0; s < TPW; ++s) {
                 f4 raw;
                 if constexpr (OWN) raw = f[s][b0 + nt];
                 else raw = ycur[s][nt];
@@ -797,21 +808,21 @@ __global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
     // 64 KiB of fragments.  Here the features are converted ONCE into split operand pairs - in place of the fp32 registers they
     // replace, same count - and every fragment read serves all of the wave's tiles: a quarter of the LDS bytes.
     if (alive && !(PF_ECP_DBG & 1)) {
-        PfPair2 fp[ECP_TPW][NCP];
+        PfPair2 fp[TPW][NCP];
 #pragma unroll
-        for (int s = 0; s < ECP_TPW; ++s)
+        for (int s = 0; s < TPW; ++s)
 #pragma unroll
             for (int cp = 0; cp < NCP; ++cp) fp[s][cp] = pf_pair2(f[s][2 * cp], f[s][2 * cp + 1]);
-        int jq[ECP_TPW][4];
+        int jq[TPW][4];
 #pragma unroll
-        for (int s = 0; s < ECP_TPW; ++s)
+        for (int s = 0; s < TPW; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) jq[s][r] = __shfl(jr[s], 4 * q + r);
 #pragma unroll
         for (int oc = 0; oc < NTO; oc += OCH) {
-            f4 acc[ECP_TPW][OCH], accx[ECP_TPW][OCH];
+            f4 acc[TPW][OCH], accx[TPW][OCH];
 #pragma unroll
-            for (int s = 0; s < ECP_TPW; ++s)
+            for (int s = 0; s < TPW; ++s)
 #pragma unroll
                 for (int o = 0; o < OCH; ++o) {
                     const int c = GT + 16 * (oc + o) + col;
@@ -827,14 +838,14 @@ __global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
                     const h8 wh = __builtin_bit_cast(h8, Wf[(((oc + o) * NCP + cp) * 2 + 0) * 64 + lane]);
                     const h8 wl = __builtin_bit_cast(h8, Wf[(((oc + o) * NCP + cp) * 2 + 1) * 64 + lane]);
 #pragma unroll
-                    for (int s = 0; s < ECP_TPW; ++s) {
+                    for (int s = 0; s < TPW; ++s) {
                         acc[s][o] = pf_mfma_f16(fp[s][cp].h, wh, acc[s][o]);
                         accx[s][o] = pf_mfma_f16(fp[s][cp].l, wh, accx[s][o]);
                         accx[s][o] = pf_mfma_f16(fp[s][cp].h, wl, accx[s][o]);
                     }
                 }
 #pragma unroll
-            for (int s = 0; s < ECP_TPW; ++s)
+            for (int s = 0; s < TPW; ++s)
 #pragma unroll
                 for (int o = 0; o < OCH; ++o) {
                     const f4 v = acc[s][o] + accx[s][o] * PF_LO_INV;
@@ -858,7 +869,7 @@ __global__ __launch_bounds__(ECP_T) void ec_fwdp_kernel(EcFwdPArgs a) {
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < ECP_TPW; ++s)
+        for (int s = 0; s < TPW; ++s)
             if (ok[s] && col == 0)
                 for (int c = 4 * q; c < ODIM; c += 16)
                     *reinterpret_cast<f4*>(a.out + (size_t)tl[s] * ODIM + c) = pf_splat(__builtin_nanf(""));
@@ -1432,6 +1443,7 @@ struct EcBwdPArgs {
 
 template <int G, int NC, int ODIM>
 __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
+    constexpr int TPW = ecp_tpw(G);
     constexpr int GT = G * NC, NB = GT / 16, NTG = (G + 15) / 16, NCO = ODIM / 32, NCP = GT / 32;
     constexpr bool OWN = G % 16 == 0;
     static_assert(GT % 32 == 0 && ODIM % 32 == 0 && 32 * NC <= STAT_W && G <= 32, "shape");
@@ -1503,17 +1515,17 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
     }
 #endif
     // ---- this wave's tiles
-    int tl[ECP_TPW];
-    bool ok[ECP_TPW];
+    int tl[TPW];
+    bool ok[TPW];
 #pragma unroll
-    for (int s = 0; s < ECP_TPW; ++s) {
+    for (int s = 0; s < TPW; ++s) {
         tl[s] = blockIdx.x * ECP_WAVES + wave + s * gridDim.x * ECP_WAVES;
         ok[s] = tl[s] < a.ntiles;
         tl[s] = ok[s] ? tl[s] : 0;
     }
-    f4 dy[ECP_TPW][NB];
+    f4 dy[TPW][NB];
 #pragma unroll
-    for (int s = 0; s < ECP_TPW; ++s)
+    for (int s = 0; s < TPW; ++s)
 #pragma unroll
         for (int b = 0; b < NB; ++b) dy[s][b] = pf_splat(0.f);
     __syncthreads();
@@ -1533,7 +1545,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
 #pragma unroll
     for (int co = 0; co < NCO; ++co) {
 #pragma unroll
-        for (int t = 0; t < ECP_TPW; ++t) {
+        for (int t = 0; t < TPW; ++t) {
             const float* dp = a.dh + (size_t)tl[t] * ODIM + 32 * co + 4 * q;
             const unsigned char* ap = a.arg + (size_t)tl[t] * ODIM + 32 * co + 4 * q;
             const f4 d0 = *reinterpret_cast<const f4*>(dp), d1 = *reinterpret_cast<const f4*>(dp + 16);
@@ -1572,7 +1584,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
             bnc[w * 32 + c] = c < G ? a.aff[w * a.ld + col0 + c] : 0.f;
         }
         bool cv[NTG];
-        f4 yv[ECP_TPW][NTG], accs[OWN ? 1 : ECP_TPW][NTG];
+        f4 yv[TPW][NTG], accs[OWN ? 1 : TPW][NTG];
         auto A = [&](int t, int nt) -> f4& {
             if constexpr (OWN) return dy[t][b0 + nt];                // the layer's own slots hold conv_out's part already
             else return accs[t][nt];
@@ -1582,7 +1594,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
             const int c4 = 16 * (b0 + nt) + 4 * q;
             cv[nt] = c4 >= col0 && c4 < col0 + G;
 #pragma unroll
-            for (int t = 0; t < ECP_TPW; ++t) {
+            for (int t = 0; t < TPW; ++t) {
                 yv[t][nt] = pf_splat(0.f);
                 if (cv[nt] && ok[t]) yv[t][nt] = *reinterpret_cast<const f4*>(a.Y + ((size_t)tl[t] * 16 + col) * a.ld + c4);
                 if constexpr (!OWN) accs[t][nt] = cv[nt] ? dy[t][b0 + nt] : pf_splat(0.f);   // rows of the layer that shares the block: not ours
@@ -1592,7 +1604,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
 #pragma unroll
         for (int cp = CP0; cp < NCP; ++cp) {
 #pragma unroll
-            for (int t = 0; t < ECP_TPW; ++t) {
+            for (int t = 0; t < TPW; ++t) {
 #ifdef PF_EC_BWDG_F32
 #pragma unroll
                 for (int nt = 0; nt < NTG; ++nt) {
@@ -1612,7 +1624,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
         }
         __syncthreads();                                              // bnc
         // ---- dz (it replaces the raw gradient), its sums; xhat stays for the transform behind the barrier
-        f4 s0[NTG], s1[NTG], xh[ECP_TPW][NTG];
+        f4 s0[NTG], s1[NTG], xh[TPW][NTG];
 #pragma unroll
         for (int nt = 0; nt < NTG; ++nt) {
             s0[nt] = s1[nt] = pf_splat(0.f);
@@ -1620,7 +1632,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
             const f4 bsc = *reinterpret_cast<const f4*>(bnc + cl), bsh = *reinterpret_cast<const f4*>(bnc + 32 + cl);
             const f4 bmu = *reinterpret_cast<const f4*>(bnc + 64 + cl), brs = *reinterpret_cast<const f4*>(bnc + 96 + cl);
 #pragma unroll
-            for (int t = 0; t < ECP_TPW; ++t) {
+            for (int t = 0; t < TPW; ++t) {
                 const f4 y = yv[t][nt], z = y * bsc + bsh;
                 xh[t][nt] = (y - bmu) * brs;
                 f4 dz;
@@ -1680,7 +1692,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
             const f4 m1 = *reinterpret_cast<const f4*>(m12 + cl), m2 = *reinterpret_cast<const f4*>(m12 + 32 + cl);
             const f4 bsc = *reinterpret_cast<const f4*>(bnc + cl);
 #pragma unroll
-            for (int t = 0; t < ECP_TPW; ++t) {
+            for (int t = 0; t < TPW; ++t) {
                 const f4 v = bsc * (A(t, nt) - m1 - xh[t][nt] * m2);
                 if (ok[t]) *reinterpret_cast<f4*>(a.dA + ((size_t)tl[t] * 16 + col) * a.ld + 16 * (b0 + nt) + 4 * q) = v;
                 dy[t][b0 + nt] = v;
@@ -1697,7 +1709,7 @@ __global__ __launch_bounds__(ECP_T) void ec_bwdp_kernel(EcBwdPArgs a) {
     });
     if (!alive) {                                                     // loud: the layers that were not finished
 #pragma unroll
-        for (int t = 0; t < ECP_TPW; ++t)
+        for (int t = 0; t < TPW; ++t)
             if (ok[t])
                 for (int c = 4 * q; c < GT; c += 16)
                     *reinterpret_cast<f4*>(a.dA + ((size_t)tl[t] * 16 + col) * a.ld + c) = pf_splat(__builtin_nanf(""));
@@ -2727,12 +2739,15 @@ int stat_sync(const StatFin& fin, int ncol, PfSyncFn cb, void* user, hipStream_t
 struct Dims {
     int T, GT, S, nconvs;
     long long E;
-    int ntiles, grid, grid_light, nchunk;
+    int ntiles, grid, grid_light, nchunk, chunk;
 };
 #ifndef PF_EC_DW_CHUNK
 #define PF_EC_DW_CHUNK 512
 #endif
 constexpr int EC_DW_CHUNK = PF_EC_DW_CHUNK;
+#ifndef PF_EC_DW_CHUNK_SCALE
+#define PF_EC_DW_CHUNK_SCALE 1
+#endif
 #ifndef EC_DW_WAVES
 #define EC_DW_WAVES 8
 #endif
@@ -2755,7 +2770,10 @@ int ec_dims(const PfEcTrain* p, Dims& d) {
     // growth-layer kernels: measured (layer with 96 input channels, 131 072 edges) 44 / 30 / 29 / 41 us at 128 / 256 / 512 / 2048
     // workgroups: beyond 2 per CU the fixed cost per workgroup (weight staging, 64 statistics atomics) outweighs the latency hiding
     d.grid_light = d.grid;
-    d.nchunk = (int)((d.E + EC_DW_CHUNK - 1) / EC_DW_CHUNK);
+    // edges per split-K chunk of the weight-gradient launch: one workgroup per chunk with (odim + GT) / 32 waves - the narrow units
+    // (GT = 32 / 64: 2 / 4 waves) get shorter chunks so that they, too, put two waves on every SIMD
+    d.chunk = PF_EC_DW_CHUNK_SCALE ? (d.GT <= 32 ? EC_DW_CHUNK / 4 : (d.GT <= 64 ? EC_DW_CHUNK / 2 : EC_DW_CHUNK)) : EC_DW_CHUNK;
+    d.nchunk = (int)((d.E + d.chunk - 1) / d.chunk);
     return PF_OK;
 }
 EcConvs ec_convs(const PfEcTrain* p, const Dims& d) {
@@ -2803,7 +2821,10 @@ int ecp_capacity() {
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     int cap = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ec_fwdp_kernel<G, 4, ODIM>, ECP_T, lds) != hipSuccess) (void)hipGetLastError();
-    else cap = per_cu >= 1 ? ncu : 0;              // one workgroup per CU at most: each wants most of a CU's registers
+    else {
+        const int want = ECP_TPW / ecp_tpw(G);      // workgroups per CU the unit's grid needs resident (2 for the narrow units)
+        cap = (per_cu < want ? per_cu : want) * ncu;
+    }
     if (dev >= 0 && dev < ECP_MAXDEV) cache[dev] = cap > 0 ? cap : -1;
     return cap;
 }
@@ -2815,7 +2836,7 @@ bool ec_persistent_ok(const PfEcTrain* p, const Dims& d) {
     if (p->growth == 8 && p->odim == 32) cap = ecp_capacity<8, 32>();
     else if (p->growth == 16 && p->odim == 64) cap = ecp_capacity<16, 64>();
     else if (p->growth == 32 && p->odim == 128) cap = ecp_capacity<32, 128>();
-    return cap > 0 && (long long)d.ntiles <= (long long)cap * ECP_WAVES * ECP_TPW;
+    return cap > 0 && (long long)d.ntiles <= (long long)cap * ECP_WAVES * ecp_tpw(p->growth);
 }
 template <int G, int ODIM>
 size_t ecpb_lds_bytes() {
@@ -2839,15 +2860,15 @@ bool ecpb_fits() {
     allow_lds(ec_bwdp_kernel<G, 4, ODIM>, lds);
     bool fits = false;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ec_bwdp_kernel<G, 4, ODIM>, ECP_T, lds) != hipSuccess) (void)hipGetLastError();
-    else fits = per_cu >= 1;
+    else fits = per_cu >= ECP_TPW / ecp_tpw(G);
     if (dev >= 0 && dev < ECP_MAXDEV) cache[dev] = fits ? 1 : -1;
     return fits;
 }
 bool ec_bwd_persistent_fits(const PfEcTrain* p) {
     return p->growth == 8 ? ecpb_fits<8, 32>() : (p->growth == 16 ? ecpb_fits<16, 64>() : ecpb_fits<32, 128>());
 }
-int ecp_grid(const Dims& d) {
-    const int wgs = (d.ntiles + ECP_WAVES * ECP_TPW - 1) / (ECP_WAVES * ECP_TPW);     // fewest workgroups that hold every tile ...
+int ecp_grid(const Dims& d, int tpw) {
+    const int wgs = (d.ntiles + ECP_WAVES * tpw - 1) / (ECP_WAVES * tpw);               // fewest workgroups that hold every tile ...
     int ncu = 0, dev = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2866,7 +2887,7 @@ int ec_bwd_persistent(const PfEcTrain* p, const Dims& d, const EcConvs& cv, hipS
 #if PF_EC_BWDP_DP
     if (p->K == 16 && p->csr_off && p->csr_edge) { a.dP = p->dPQ; a.ldp = 2 * d.S; }       // (the scatter form zeroes and accumulates dPQ itself)
 #endif
-    const int grid = ecp_grid(d);
+    const int grid = ecp_grid(d, ecp_tpw(p->growth));
     const size_t l8 = ecpb_lds_bytes<8, 32>(), l16 = ecpb_lds_bytes<16, 64>(), l32 = ecpb_lds_bytes<32, 128>();
     if (p->growth == 8) hipLaunchKernelGGL((ec_bwdp_kernel<8, 4, 32>), dim3(grid), dim3(ECP_T), l8, s, a);
     else if (p->growth == 16) hipLaunchKernelGGL((ec_bwdp_kernel<16, 4, 64>), dim3(grid), dim3(ECP_T), l16, s, a);
@@ -2883,7 +2904,7 @@ int ec_fwd_persistent(const PfEcTrain* p, const Dims& d, const EcConvs& cv, hipS
     }
     a.Wout = p->W[p->nconv] + 3 * p->C; a.ldwout = cv.width[p->nconv];
     a.eps = p->eps; a.momentum = p->momentum; a.R = (double)d.E; a.acc = p->stat; a.sync = p->sync;
-    const int grid = ecp_grid(d);
+    const int grid = ecp_grid(d, ecp_tpw(p->growth));
     const size_t l8 = ecp_lds_bytes<8, 32>(), l16 = ecp_lds_bytes<16, 64>(), l32 = ecp_lds_bytes<32, 128>();
     if (p->growth == 8) hipLaunchKernelGGL((ec_fwdp_kernel<8, 4, 32>), dim3(grid), dim3(ECP_T), l8, s, a);
     else if (p->growth == 16) hipLaunchKernelGGL((ec_fwdp_kernel<16, 4, 64>), dim3(grid), dim3(ECP_T), l16, s, a);
@@ -3161,13 +3182,13 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
     hipStream_t sm = s;                                   // (the kernels below are written with `s` and `stream`)
     if (dw_side) { s = pf_dw_fork(sm); stream = (void*)s; }
     {
-        EcDwArgs a{p->dA, p->Y, d.GT, p->aff, p->dout, p->arg, p->dout, p->pooling, g, d.GT, p->odim, d.S, p->K, d.E, EC_DW_CHUNK,
+        EcDwArgs a{p->dA, p->Y, d.GT, p->aff, p->dout, p->arg, p->dout, p->pooling, g, d.GT, p->odim, d.S, p->K, d.E, d.chunk,
                    p->slope, dwpart, bpart};
         // jobs of the no-LDS kernel: conv_out strips, then growth strips (a strip's column tiles: what its LAST row's layer sees)
         EcDw2Args a2{};
         a2.d = a;
         int nj = 0;
-        bool direct = d.GT % 32 == 0 && p->odim % 32 == 0 && d.GT <= 128 && (!p->pooling || p->K == 16) && EC_DW_CHUNK % 16 == 0;
+        bool direct = d.GT % 32 == 0 && p->odim % 32 == 0 && d.GT <= 128 && (!p->pooling || p->K == 16) && d.chunk % 16 == 0;
 #ifdef PF_EC_DW_STAGED
         direct = false;
 #endif
@@ -3186,7 +3207,7 @@ extern "C" int pf_ec_train_bwd(const PfEcTrain* p, void* stream) {
             hipLaunchKernelGGL(ec_dw2_kernel, dim3(d.nchunk), dim3(64 * nj), 0, s, a2);
 #else
 #if PF_EC_DW4
-            if (EC_DW_CHUNK % DW4_SE == 0) {
+            if (d.chunk % DW4_SE == 0) {
                 const size_t lds = (size_t)2 * 4 * (d.GT / 32) * 2 * 64 * 16;
                 allow_lds(ec_dw4_kernel, lds);
                 hipLaunchKernelGGL(ec_dw4_kernel, dim3(d.nchunk), dim3(512), lds, s, a2);
