@@ -571,6 +571,12 @@ int pf_pugan_loss_bwd(const float* g, const float* radius, int B, int N, int M, 
 int pf_clip_adam(float* flat_g, float* m, float* v, float* const* params, const int* chunks, int nchunks, const float* lr,
                  float* step, float beta1, float beta2, float eps, float max_norm, double* partial, unsigned* counter,
                  float* coef, void* stream);
+/* pf_clip_adam with the gradients where autograd left them: grads = device array of nparams gradient addresses in the chunk
+ * table's tensor order (contiguous fp32, one per parameter; point a parameter without gradient at zeros) instead of one flat
+ * buffer - no concatenation launch in front of the update.  The clipped gradients are written back through the table. */
+int pf_clip_adam_ptrs(float* const* grads, float* m, float* v, float* const* params, const int* chunks, int nchunks, const float* lr,
+                      float* step, float beta1, float beta2, float eps, float max_norm, double* partial, unsigned* counter,
+                      float* coef, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Patch pipeline around the network (modules/utils/patch.py:35-214), csrc/patch_ops.hip

@@ -158,6 +158,8 @@ SIGNATURES = {
     "pf_inject_inv2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_clip_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_float,
                              c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_clip_adam_ptrs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_float,
+                             c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pf_mlp_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_mlp_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_mlp_train_bwd": (c_int, [c_void_p, c_void_p]),

@@ -24,6 +24,7 @@ struct AdamArgs {
     const float* lr; float* step;    // device scalars
     float beta1, beta2, eps, max_norm;
     double* partial; unsigned* counter; float* coef;
+    float* const* gtab;              // nullable: device array of the gradient tensors' addresses (parameter order) - g is not read then
 };
 
 __global__ __launch_bounds__(256) void adam_norm_kernel(AdamArgs a) {
@@ -31,8 +32,9 @@ __global__ __launch_bounds__(256) void adam_norm_kernel(AdamArgs a) {
     __shared__ int last;
     const int c = blockIdx.x;
     const int len = a.chunks[c * 4 + 2], fo = a.chunks[c * 4 + 3];
+    const float* gp = a.gtab ? a.gtab[a.chunks[c * 4 + 0]] + a.chunks[c * 4 + 1] : a.g + fo;
     double s = 0.0;
-    for (int i = threadIdx.x; i < len; i += 256) { const float x = a.g[fo + i]; s += (double)x * (double)x; }
+    for (int i = threadIdx.x; i < len; i += 256) { const float x = gp[i]; s += (double)x * (double)x; }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -73,15 +75,16 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs a) {
     const int c = blockIdx.x;
     const int tid = a.chunks[c * 4 + 0], lo = a.chunks[c * 4 + 1], len = a.chunks[c * 4 + 2], fo = a.chunks[c * 4 + 3];
     float* p = a.params[tid] + lo;
+    float* gp = a.gtab ? a.gtab[tid] + lo : a.g + fo;
     if (a.coef[2] != 0.f) return;                         // non-finite gradient norm: this update is skipped (adam_norm_kernel)
     const float cf = a.coef[0], lr = a.lr[0], t = a.step[0];
     const float bc1 = 1.f - powf(a.beta1, t), bc2 = 1.f - powf(a.beta2, t);
     const float step_size = lr / bc1, bc2s = sqrtf(bc2);
     for (int i = threadIdx.x; i < len; i += 256) {
-        const float g = a.g[fo + i] * cf;
+        const float g = gp[i] * cf;
         const float m = a.beta1 * a.m[fo + i] + (1.f - a.beta1) * g;
         const float v = a.beta2 * a.v[fo + i] + (1.f - a.beta2) * g * g;
-        a.g[fo + i] = g;
+        gp[i] = g;
         a.m[fo + i] = m;
         a.v[fo + i] = v;
         p[i] -= step_size * (m / (sqrtf(v) / bc2s + a.eps));
@@ -101,7 +104,23 @@ extern "C" int pf_clip_adam(float* flat_g, float* m, float* v, float* const* par
                             unsigned* counter, float* coef, void* stream) {
     if (!flat_g || !m || !v || !params || !chunks || !lr || !step || !partial || !counter || !coef) return PF_ERR_NULL;
     if (nchunks <= 0) return PF_ERR_SHAPE;
-    AdamArgs a{flat_g, m, v, params, chunks, nchunks, lr, step, beta1, beta2, eps, max_norm, partial, counter, coef};
+    AdamArgs a{flat_g, m, v, params, chunks, nchunks, lr, step, beta1, beta2, eps, max_norm, partial, counter, coef, nullptr};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_norm_kernel, dim3(nchunks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(adam_update_kernel, dim3(nchunks), dim3(256), 0, s, a);
+    return pf_last_launch_status();
+}
+
+// The same update with the gradients where autograd left them: grads = device array of the gradient tensors' addresses, one per
+// parameter in the chunk table's order (each contiguous, as long as its parameter; a parameter without a gradient points at
+// zeros).  No concatenation into a flat buffer first - inside a captured training step the addresses are the same at every replay,
+// so the table is written once.  The clipped gradients are written back into those tensors.
+extern "C" int pf_clip_adam_ptrs(float* const* grads, float* m, float* v, float* const* params, const int* chunks, int nchunks,
+                                 const float* lr, float* step, float beta1, float beta2, float eps, float max_norm, double* partial,
+                                 unsigned* counter, float* coef, void* stream) {
+    if (!grads || !m || !v || !params || !chunks || !lr || !step || !partial || !counter || !coef) return PF_ERR_NULL;
+    if (nchunks <= 0) return PF_ERR_SHAPE;
+    AdamArgs a{nullptr, m, v, params, chunks, nchunks, lr, step, beta1, beta2, eps, max_norm, partial, counter, coef, grads};
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_norm_kernel, dim3(nchunks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(adam_update_kernel, dim3(nchunks), dim3(256), 0, s, a);

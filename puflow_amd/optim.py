@@ -77,6 +77,44 @@ class FusedClipAdam(torch.optim.Optimizer):
         # eval plan of PointInterpFlow, which is keyed on the version counters)
         torch._C._increment_version(self.params)
 
+    @torch.no_grad()
+    def step_table(self, grad_table: torch.Tensor) -> None:
+        """One clipped Adam update with the gradients where autograd left them: grad_table = device int64 [n parameters], the
+        address of every parameter's (contiguous fp32) gradient in `self.params` order - `grad_table_of()` builds it.  For a
+        captured training step: the gradients' addresses are the same at every replay, so the table is written once and the
+        step needs no concatenation launches (pf_clip_adam_ptrs)."""
+        if grad_table.dtype != torch.int64 or grad_table.numel() != len(self.params) or not grad_table.is_cuda:
+            raise ValueError("FusedClipAdam.step_table: one int64 device address per parameter")
+        if tuple(p.data_ptr() for p in self.params) != self._ptr_sig:
+            self._ptrs.copy_(torch.tensor([p.data_ptr() for p in self.params], dtype=torch.int64))
+            self._ptr_sig = tuple(p.data_ptr() for p in self.params)
+        g = self.param_groups[0]
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        _lib.check(self.lib.pf_clip_adam_ptrs(grad_table.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                              self._ptrs.data_ptr(), self._chunks.data_ptr(), self._chunks.shape[0],
+                                              self.lr_t.data_ptr(), self.step_t.data_ptr(), float(g["betas"][0]), float(g["betas"][1]),
+                                              float(g["eps"]), float(g["max_norm"]), self._partial.data_ptr(),
+                                              self._counter.data_ptr(), self.coef.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "pf_clip_adam_ptrs")
+        torch._C._increment_version(self.params)
+
+    def grad_table_of(self, zeros: torch.Tensor):
+        """Host list of gradient addresses for `step_table` (parameters without a gradient -> `zeros`, a zero fp32 buffer at least
+        as long as the longest parameter), or None when a gradient is not a contiguous fp32 tensor of its parameter's size."""
+        out = []
+        for p in self.params:
+            gr = p.grad
+            if gr is None:
+                if zeros.numel() < p.numel():
+                    return None
+                out.append(zeros.data_ptr())
+            elif gr.dtype != torch.float32 or not gr.is_contiguous() or gr.numel() != p.numel() or gr.device != p.device:
+                return None
+            else:
+                out.append(gr.data_ptr())
+        return out
+
     def skipped_updates(self, reset: bool = True) -> int:
         """Updates the kernel SKIPPED since the last call because the global gradient norm was not finite (parameters, moments
         and step counter were left untouched).  One device read: call where the host synchronises anyway."""

@@ -24,6 +24,7 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
 import torch
 from torch import Tensor
 
@@ -59,6 +60,11 @@ def make_capturable(optimizer: torch.optim.Optimizer, device) -> torch.optim.Opt
     return optimizer
 
 
+# single-process captured step: the fused optimizer reads the gradients through a table of addresses instead of one concatenated
+# buffer ("0": concatenate - the A/B reference)
+_GRAD_TABLE = os.environ.get("PF_TRAIN_GRAD_TABLE", "1") != "0"
+
+
 class GraphedTrainStep:
     def __init__(self, module, optimizer: torch.optim.Optimizer, batch, clip: float = 1e-2, warmup: int = 2):
         from . import train_ops
@@ -77,6 +83,8 @@ class GraphedTrainStep:
         self.multi = multi_rank()           # the two-graph form with the eager all-reduce in between (dist.force_collectives: also with one rank)
         from .optim import FusedClipAdam
         self.fused = isinstance(optimizer, FusedClipAdam)
+        self._gtab = self._gtab_zeros = None                # (the warm-up steps below run _update before the table exists)
+        self._gtab_used = False
         if self.fused:
             optimizer.param_groups[0]["max_norm"] = clip
             optimizer.sync_lr()
@@ -104,10 +112,21 @@ class GraphedTrainStep:
         drain_collective_watchdog(dev)
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
+        if not self.multi and self.fused and _GRAD_TABLE:
+            self._gtab = torch.zeros(len(optimizer.params), dtype=torch.int64, device=dev)
+            self._gtab_zeros = torch.zeros(max(p.numel() for p in optimizer.params), dtype=torch.float32, device=dev)
         if not self.multi:
             with torch.cuda.graph(self.graph_a, stream=side, capture_error_mode=_CAPTURE_MODE):
                 self.loss = self._fwd_bwd()
                 self._update()
+            if self._gtab_used:
+                ptrs = optimizer.grad_table_of(self._gtab_zeros)
+                if ptrs is None:
+                    raise RuntimeError("graphed_train_step: a captured gradient is not a contiguous fp32 tensor of its parameter's "
+                                       "size (set PF_TRAIN_GRAD_TABLE=0 to concatenate the gradients instead)")
+                self._gtab.copy_(torch.tensor(ptrs, dtype=torch.int64))
+                self._gtab_keep = [p.grad for p in optimizer.params]          # the captured tensors: their memory IS the table's targets
+                torch.cuda.synchronize(dev)
         else:
             with torch.cuda.graph(self.graph_a, stream=side, capture_error_mode=_CAPTURE_MODE):
                 self.loss = self._fwd_bwd()
@@ -170,6 +189,13 @@ class GraphedTrainStep:
 
     def _update(self) -> None:
         if self.fused:                                      # clip + Adam as two launches on the flat gradient buffer
+            if self._gtab is not None and torch.cuda.is_current_stream_capturing():
+                # single process, inside the capture: the optimizer reads the gradients where the backward left them, through a
+                # table of their addresses that __init__ fills right after the capture (they are the same at every replay) -
+                # no concatenation launches in front of the update
+                self._gtab_used = True
+                self.optimizer.step_table(self._gtab)
+                return
             if not self.multi:
                 self.bucket.pack()
             self.optimizer.step_flat(self.bucket.flat)

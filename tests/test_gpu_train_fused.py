@@ -252,6 +252,37 @@ def test_fused_clip_adam_matches_torch():
     assert float(fa.step_t) == 5.0
 
 
+def test_fused_clip_adam_through_a_gradient_table():
+    """pf_clip_adam_ptrs (FusedClipAdam.step_table): the gradients read where autograd left them, through a device table of their
+    addresses - what the captured training step uses instead of concatenating ~240 tensors first.  Same update, bit for bit, as
+    the flat-buffer entry point on the same gradients (one of them missing: a table entry that points at zeros); the clipped
+    gradients are written back into the tensors."""
+    from puflow_amd.optim import FusedClipAdam
+    torch.manual_seed(7)
+    shapes = [(64, 129), (64,), (3, 3), (128, 384, 1, 1), (5000,), (4097,)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    fa, fb = FusedClipAdam(pa, lr=1e-3, max_norm=1e-2), FusedClipAdam(pb, lr=1e-3, max_norm=1e-2)
+    zeros = torch.zeros(max(p.numel() for p in pa), device="cuda")
+    for it in range(3):
+        grads = [torch.randn_like(p) * (10.0 if it != 1 else 1e-4) for p in pa]
+        for k, (p, q, g) in enumerate(zip(pa, pb, grads)):
+            p.grad, q.grad = (None, None) if k == 2 else (g.clone(), g.clone())
+        ptrs = fa.grad_table_of(zeros)
+        assert ptrs is not None and ptrs[2] == zeros.data_ptr()
+        fa.step_table(torch.tensor(ptrs, dtype=torch.int64, device="cuda"))
+        fb.step()                                                       # concatenation + pf_clip_adam
+        assert torch.equal(fa.coef[:3], fb.coef[:3])
+        for k, (p, q) in enumerate(zip(pa, pb)):
+            assert torch.equal(p, q), (it, k)
+            if k != 2:
+                assert torch.equal(p.grad, grads[k] * fa.coef[0]), (it, k)          # clipped in place
+        assert torch.equal(fa.exp_avg, fb.exp_avg) and torch.equal(fa.exp_avg_sq, fb.exp_avg_sq)
+    assert float(zeros.abs().max()) == 0.0
+    pa[0].grad = pa[0].grad.t().contiguous().t() if pa[0].grad.dim() == 2 else pa[0].grad      # not contiguous: no table
+    assert fa.grad_table_of(zeros) is None
+
+
 def test_fused_clip_adam_skips_a_non_finite_gradient():
     """A NaN / inf anywhere in the flat gradient (what a timed-out EMD barrier or a NaN loss leaves) must not reach the
     parameters or the moments: the update is skipped ON THE DEVICE (a captured step reads its status words only every few
