@@ -2054,9 +2054,11 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     B, N, _ = xyz.shape
     R = upratio
     idx16, _ = ops.knn_idx32(xyz, xyz, 16)
-    idx8 = idx16[..., :8].contiguous()
     fused_ec = _FUSED                                     # also under SyncBN: the fused kernels defer a layer's statistics to an all-reduce
     use_side = getattr(net, "train_streams", True) and not _sync_bn_active() and _SIDE_STREAM
+    # the 8 nearest of the 16: only the interpolation branch (and, after the join, the latent's interpolation) reads them - with a
+    # side stream the copy is made there, off the chain knn -> fold -> first unit
+    idx8 = None if use_side else idx16[..., :8].contiguous()
     # transposed neighbour lists: only the BACKWARD of the EdgeConv units reads them - with a side stream they are built there,
     # off the main chain (8 small launches, ~55 us), and joined with the interpolation weights
     csr16 = csr8 = None
@@ -2102,6 +2104,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         side = _side_stream(xyz.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            idx8 = idx16[..., :8].contiguous()
             if fused_ec and csr_side:
                 csr16, csr8 = knn_csr_pair(idx16, 8)
             if not _SIDE_LATE:
@@ -2183,7 +2186,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             w.record_stream(torch.cuda.current_stream())
-            for t in (csr16 or ()) + (csr8 or ()):
+            for t in (csr16 or ()) + (csr8 or ()) + (idx8,):
                 t.record_stream(torch.cuda.current_stream())
         if _GLUE and R <= 8:
             u = InterpWsumFn.apply(w.view(B * N, 8, -1), z, idx8, R, csr8 if _DET else None)
@@ -2246,7 +2249,7 @@ def _forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     if side is not None:
         torch.cuda.current_stream().wait_stream(side)
         w.record_stream(torch.cuda.current_stream())
-        for t in (csr16 or ()) + (csr8 or ()):
+        for t in (csr16 or ()) + (csr8 or ()) + (idx8,):
             t.record_stream(torch.cuda.current_stream())
     zj = GatherRowsFn.apply(z, idx8)                              # [E8,3]
     fz = SoftmaxWsumFn.apply(w.view(B * N, 8, -1), zj.view(B * N, 8, 3), R)      # [T,3,R]
