@@ -559,6 +559,13 @@ int pf_pugan_loss_fwd(const float* logp, const float* dist, const float* radius,
                       float w_emd, float w_cd, float* out, void* stream);
 int pf_pugan_loss_bwd(const float* g, const float* radius, int B, int N, int M, float w_logp, float w_emd, float w_cd,
                       float* graddist, float* g1, float* g2, float* dlogp, float* gx, float* gy, void* stream);
+/* The prediction's gradient of the same loss in two launches instead of four (pf_pugan_loss_bwd + pf_chamfer_bwd + pf_emd_backward:
+ * train_pugan.py:52-67, emd_cuda.cu:284-300, metric/loss.py:39-42): g [1] = d loss, x [B,n,3] prediction, y [B,n,3] ground truth,
+ * assign [B,n] the auction's assignment, idx1 / idx2 [B,n] Chamfer's nearest neighbours (both NULL: no Chamfer term), radius [B]
+ * nullable -> gx [B,n,3] (own terms stored, the second Chamfer direction added with float atomics), dlogp [1] = g w_logp.  No
+ * gradient for y. */
+int pf_pugan_grad(const float* g, const float* radius, const float* x, const float* y, const int* assign, const int* idx1,
+                  const int* idx2, int B, int n, int m, float w_logp, float w_emd, float w_cd, float* gx, float* dlogp, void* stream);
 
 /* ---- gradient clipping (L2 norm over all parameters) + Adam for the whole model in two launches (csrc/optim.hip) ----
  * Replaces torch.nn.utils.clip_grad_norm_ (Lightning gradient_clip_val, train_pu1k.py:149) + torch.optim.Adam.step

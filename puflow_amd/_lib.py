@@ -180,6 +180,7 @@ SIGNATURES = {
     "pf_pugan_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
     "pf_pugan_loss_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pf_pugan_grad": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_float] * 3 + [c_void_p] * 3),
     "pf_bnmlp_train_ws_floats": (c_longlong, [c_void_p]),
     "pf_bnmlp_train_fwd": (c_int, [c_void_p, c_void_p]),
     "pf_bnmlp_train_bwd": (c_int, [c_void_p, c_void_p]),

@@ -166,6 +166,52 @@ __global__ __launch_bounds__(256) void pugan_loss_bwd_kernel(const float* __rest
     if (blockIdx.x == 0 && threadIdx.x == 0) dlogp[0] = gv * w_logp;
 }
 
+// The prediction's gradient of the whole loss head in two launches (it was four: seeds + zero fill, two Chamfer directions, EMD):
+//   own terms, plain stores:   gx[b,i] = 2 gd_b (x_i - y_assign(i)) + 2 g1 (x_i - y_idx1(i)),   gd_b = g w_emd / radius_b, g1 = g w_cd / (B N)
+//   (emd_cuda.cu:284-300; the first Chamfer direction, d dist1 / d x)
+// then the second Chamfer direction scattered onto it with float atomics:  gx[b, idx2(j)] -= 2 g2 (y_j - x_idx2(j)),  g2 = g w_cd / (B M).
+// For the default path only: the ground truth gets no gradient here and the sums come in arrival order (PuganLossFn keeps the
+// four-launch form for a ground truth that wants its gradient and for the bit-reproducible mode).
+__global__ __launch_bounds__(256) void pugan_grad_own_kernel(const float* __restrict__ g, const float* __restrict__ radius,
+                                                            const float* __restrict__ x, const float* __restrict__ y,
+                                                            const int* __restrict__ assign, const int* __restrict__ idx1, int B, int n,
+                                                            float w_logp, float w_emd, float w_cd, float* __restrict__ gx,
+                                                            float* __restrict__ dlogp) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const float gv = g[0];
+    if (t == 0) dlogp[0] = gv * w_logp;
+    if (t >= (long long)B * n) return;
+    const long long b = t / n;
+    const float ge = 2.f * (gv * w_emd / (radius ? radius[b] : 1.f));
+    const int j = assign[t];
+    float o[3];
+    if ((unsigned)j >= (unsigned)n) {                             // an assignment that is not an index: loud, never out of bounds
+        o[0] = o[1] = o[2] = __builtin_nanf("");
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = ge * (x[t * 3 + c] - y[(b * n + j) * 3 + c]);
+    }
+    if (idx1) {
+        const float w = 2.f * (gv * w_cd / ((float)B * (float)n));
+        const int j1 = idx1[t];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] += w * (x[t * 3 + c] - y[(b * n + j1) * 3 + c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gx[t * 3 + c] = o[c];
+}
+__global__ __launch_bounds__(256) void pugan_grad_other_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                              const float* __restrict__ y, const int* __restrict__ idx2, int B, int n,
+                                                              int m, float w_cd, float* __restrict__ gx) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * m) return;
+    const long long b = t / m;
+    const float w = 2.f * (g[0] * w_cd / ((float)B * (float)m));
+    const int j = idx2[t];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) atomicAdd(&gx[(b * n + j) * 3 + c], -(w * (y[t * 3 + c] - x[(b * n + j) * 3 + c])));
+}
+
 inline unsigned glue_grid(long long n) {
     long long g = (n + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -208,6 +254,22 @@ extern "C" int pf_emd_init(float* price, int* assign2, long long Bn, void* strea
     if (!price || !assign2) return PF_ERR_NULL;
     if (Bn <= 0) return PF_ERR_SHAPE;
     hipLaunchKernelGGL(emd_init_kernel, dim3(glue_grid(2 * Bn)), dim3(256), 0, (hipStream_t)stream, price, assign2, Bn);
+    return pf_last_launch_status();
+}
+
+// g [1] = d loss; pred x [B, n, 3], ground truth y [B, m, 3] (m = n for the EMD), assign [B, n] (the auction's assignment), idx1
+// [B, n] / idx2 [B, m] (Chamfer's nearest neighbours; both NULL: no Chamfer term), radius [B] (nullable) -> gx [B, n, 3], dlogp [1]
+extern "C" int pf_pugan_grad(const float* g, const float* radius, const float* x, const float* y, const int* assign, const int* idx1,
+                             const int* idx2, int B, int n, int m, float w_logp, float w_emd, float w_cd, float* gx, float* dlogp,
+                             void* stream) {
+    if (!g || !x || !y || !assign || !gx || !dlogp || (idx1 == nullptr) != (idx2 == nullptr)) return PF_ERR_NULL;
+    if (B <= 0 || n <= 0 || m != n) return PF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const long long t1 = (long long)B * n, t2 = (long long)B * m;
+    hipLaunchKernelGGL(pugan_grad_own_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, g, radius, x, y, assign, idx1, B, n,
+                       w_logp, w_emd, w_cd, gx, dlogp);
+    if (idx2)
+        hipLaunchKernelGGL(pugan_grad_other_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, g, x, y, idx2, B, n, m, w_cd, gx);
     return pf_last_launch_status();
 }
 

@@ -118,6 +118,14 @@ class ChamferCUDA(nn.Module):
                                     point_reduction="mean")
 
 
+_GRAD_FUSED = os.environ.get("PF_LOSS_GRAD_FUSED", "1") != "0"   # the loss head's backward in two launches (pf_pugan_grad); "0": four
+
+
+def train_ops_deterministic() -> bool:
+    from . import train_ops
+    return train_ops.deterministic()
+
+
 _CD_SIDE = os.environ.get("PF_LOSS_CD_SIDE", "1") != "0"      # Chamfer's nearest neighbours beside the EMD auction (side stream)
 
 
@@ -193,6 +201,17 @@ class PuganLossFn(Function):
         if g is None:                                      # (set_materialize_grads(False): only `terms` was used)
             return (None,) * 8
         g1d = g.contiguous().float().view(1)
+        if _GRAD_FUSED and not ctx.needs_input_grad[1] and not train_ops_deterministic():
+            # the prediction's gradient in two launches: own terms (EMD + first Chamfer direction) stored, the second direction
+            # scattered onto them (pf_pugan_grad) - it was four, all on the chain between the auction and the flow's backward
+            dlogp = torch.empty((1,), **f32)
+            gx = torch.empty_like(pred)
+            cd = w_cd != 0.0
+            _lib.check(lib.pf_pugan_grad(g1d.data_ptr(), radius.data_ptr() if radius is not None else None, pred.data_ptr(),
+                                         gt.data_ptr(), assign2[0].data_ptr(), i1.data_ptr() if cd else None,
+                                         i2.data_ptr() if cd else None, B, n, n, w_logp, w_emd, w_cd, gx.data_ptr(), dlogp.data_ptr(),
+                                         ops._stream()), "pf_pugan_grad")
+            return gx, None, None, dlogp.view(lshape), None, None, None, None
         seeds = torch.empty((3, B, n), **f32)              # graddist | g1 | g2
         dlogp = torch.empty((1,), **f32)
         gx, gy = torch.empty_like(pred), torch.empty_like(gt)

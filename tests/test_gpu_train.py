@@ -769,8 +769,11 @@ def test_fused_glue_of_the_training_step_matches_the_torch_expressions():
                 loss = tm.training_step(batch, 0)
                 loss.backward()
             torch.cuda.synchronize()
-            for name in ("pf_pugan_loss_fwd", "pf_pugan_loss_bwd", "pf_interp_wsum_fwd", "pf_interp_wsum_bwd"):
+            # (the loss head's backward: pf_pugan_grad - two launches; pf_pugan_loss_bwd + pf_chamfer_bwd + pf_emd_backward remain
+            # for a ground truth that wants its gradient and for the bit-reproducible mode)
+            for name in ("pf_pugan_loss_fwd", "pf_pugan_grad", "pf_interp_wsum_fwd", "pf_interp_wsum_bwd"):
                 assert len(prof.events.get(name, [])) == (1 if glue else 0), name
+            assert "pf_pugan_loss_bwd" not in prof.events
             res[glue] = (float(loss), tm.logged_values(), {k: p.grad.detach().clone() for k, p in tm.named_parameters() if p.grad is not None})
     finally:
         T._GLUE = keep
@@ -862,3 +865,13 @@ def test_pugan_loss_node_matches_the_separate_losses(with_radius):
         assert abs(got - want) <= 2e-6 * abs(want) + 1e-9
     assert float((p1.grad - p2.grad).abs().max()) <= 2e-6 * float(p2.grad.abs().max())
     assert abs(float(l1.grad) - float(l2.grad)) <= 1e-9
+    # a ground truth that wants its gradient takes the four-launch backward (pf_pugan_loss_bwd + pf_chamfer_bwd + pf_emd_backward):
+    # the same prediction gradient as the two-launch form above, and the Chamfer term's gradient for the ground truth
+    p3, l3, g3 = pred0.clone().requires_grad_(True), lp0.clone().requires_grad_(True), gt.clone().requires_grad_(True)
+    loss3, _ = PuganLossFn.apply(p3, g3, radius, l3, 0.005, 50, 0, (1e-4, 5e-2, 1e-1))
+    loss3.backward()
+    p4, g4 = pred0.clone().requires_grad_(True), gt.clone().requires_grad_(True)
+    cd4, _ = ChamferCUDA()(p4, g4)
+    (cd4 * 1e-1).backward()
+    assert float((p3.grad - p1.grad).abs().max()) <= 2e-6 * float(p1.grad.abs().max())
+    assert float((g3.grad - g4.grad).abs().max()) <= 2e-6 * float(g4.grad.abs().max())
