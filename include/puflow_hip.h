@@ -491,6 +491,8 @@ typedef struct PfFlowChain {
     float* dz1s;                     /* backward, nullable, R > 1: [nb][rows / R, 64] = dz1 summed over the R rows of a conditioning
                                       * row - with it the weight-gradient launch runs layer 0's conditioning columns over rows / R
                                       * summed rows (PF_MLP_DW_DZSUM) */
+    int img_ready;                   /* forward: img already holds the packed weights of these parameters (the other direction's call
+                                      * of the same forward packed them: the image does not depend on inv / R) - no pack launch */
 } PfFlowChain;
 long long pf_flowchain_ws_floats(const PfFlowChain* a);
 long long pf_flowchain_part_floats(const PfFlowChain* a);

@@ -60,7 +60,7 @@ class PfFlowChain(ctypes.Structure):
                 ("dout", c_void_p), ("dssum", c_void_p), ("dld", c_void_p), ("dlogp", c_void_p), ("dx", c_void_p),
                 ("dc", _P8), ("ds", _P8), ("dt", _P8), ("dz1", c_void_p), ("dz2", c_void_p), ("dob", c_void_p),
                 ("dlogs", _P8), ("dbias", _P8), ("dW", _P8), ("dw0", _P8), ("dw2", _P8), ("db2", _P8), ("dw4", _P8), ("db4", _P8),
-                ("ws", c_void_p), ("ws_floats", c_longlong), ("dev_descs", c_void_p), ("dz1s", c_void_p)]
+                ("ws", c_void_p), ("ws_floats", c_longlong), ("dev_descs", c_void_p), ("dz1s", c_void_p), ("img_ready", c_int)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/puflow_hip.h

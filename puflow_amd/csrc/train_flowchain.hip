@@ -667,7 +667,7 @@ extern "C" int pf_flowchain_fwd(const PfFlowChain* a, void* stream) {
     if (st) return st;
     const int ntiles = (a->rows + 15) / 16;
     const size_t lds = FF_FLOATS * sizeof(float);
-    hipLaunchKernelGGL(flowchain_pack_kernel, dim3(a->nb, 2, 14), dim3(256), 0, (hipStream_t)stream, *a);
+    if (!a->img_ready) hipLaunchKernelGGL(flowchain_pack_kernel, dim3(a->nb, 2, 14), dim3(256), 0, (hipStream_t)stream, *a);
     hipLaunchKernelGGL(flowchain_fwd_kernel, dim3((ntiles + FC_NW - 1) / FC_NW), dim3(64 * FC_NW), lds, (hipStream_t)stream, *a);
     return pf_last_launch_status();
 }

@@ -1115,6 +1115,11 @@ class InjectInv2Fn(Function):
         return du, ds, dt, None
 
 
+_FC_IMG = {}                     # device -> (key, image) of the last flow-chain forward (FlowChainFn.forward)
+_FC_SCOPE = [0, 0]               # [id of the forward_train call in progress (0: none), calls so far]
+_IMG_SHARE = os.environ.get("PF_TRAIN_IMG_SHARE", "1") != "0"
+
+
 class FlowChainFn(Function):
     """All flow blocks of one direction as ONE autograd node: two launches forward, four backward (csrc/train_flowchain.hip).
     apply(inv, R, n_ld, ccs, x, cflat, st, Bsz, *[logs, bias, W, w0, w2, b2, w4, b4] per block)
@@ -1173,7 +1178,16 @@ class FlowChainFn(Function):
             d.logp, d.Bsz = logp.data_ptr(), int(Bsz)
         d.part = _ws(dev, (nb + 1) * ((rows + 15) // 16)).data_ptr()
         d.counter = _counter(dev).data_ptr()
-        img = torch.empty((lib.pf_flowchain_img_floats(ctypes.byref(d)),), **f32)      # packed weights, kept for the backward
+        # packed weights (the conditioner nets' LDS images), kept for the backward.  They do not depend on the direction: the g chain
+        # of a forward takes the image the f chain packed from the same parameters on the same stream (one pack launch fewer)
+        key = (_FC_SCOPE[0], tuple(int(c) for c in ccs), _stream(), tuple((t.data_ptr(), t._version) for t in prm))
+        cached = _FC_IMG.get(dev) if (_IMG_SHARE and _FC_SCOPE[0]) else None      # only inside one forward_train call
+        if cached is not None and cached[0] == key:
+            img = cached[1]
+            d.img_ready = 1
+        else:
+            img = torch.empty((lib.pf_flowchain_img_floats(ctypes.byref(d)),), **f32)
+            _FC_IMG[dev] = (key, img)
         d.img = img.data_ptr()
         _lib.check(lib.pf_flowchain_fwd(ctypes.byref(d), _stream()), "pf_flowchain_fwd")
         ctx.cfg = (inv, R, float(n_ld), tuple(ccs), [t.shape for t in prm], int(Bsz) if logp is not None else 0)
@@ -2038,10 +2052,14 @@ def forward_train(net, xyz: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     set_deterministic(getattr(net, "deterministic", False))
     global _DW_NET
     _DW_NET = bool(getattr(net, "train_dw_stream", False))
+    _FC_SCOPE[1] += 1
+    _FC_SCOPE[0] = _FC_SCOPE[1]
     try:
         with sync_bn(getattr(net, "sync_batchnorm", False)):
             return _forward_train(net, xyz, upratio)
     finally:
+        _FC_SCOPE[0] = 0
+        _FC_IMG.clear()
         pending, _NBT_PENDING = _NBT_PENDING, None
         if pending:                                   # on the calling stream, after the side stream has been joined
             with torch.no_grad():
