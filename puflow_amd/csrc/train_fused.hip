@@ -1838,14 +1838,35 @@ __global__ __launch_bounds__(256) void ec_pq_bwd_csr_kernel(EcPqCsrArgs a) {
         } else {
             const int co = c - b.GT;
             sum = *reinterpret_cast<const f4*>(b.dh + (size_t)i * b.odim + co);
-            for (int n = lo; n < hi; ++n) {
-                const int e = a.edge[n], ii = e / b.K, k = e - ii * b.K;
-                const unsigned g4 = *reinterpret_cast<const unsigned*>(b.arg + (size_t)ii * b.odim + co);
-                const f4 dv = *reinterpret_cast<const f4*>(b.dh + (size_t)ii * b.odim + co);
+            // the pooled gradient reaches this point through the edges whose argmax it is: four edges in flight (edge id -> its
+            // point's argmax word and gradient row: two dependent loads per edge - one edge at a time was the kernel's longest chain)
+            auto take = [&](int e, unsigned g4, const f4& dv) {
+                const int k = e - (e / b.K) * b.K;
                 if ((int)(g4 & 255u) == k) q.x += dv.x;
                 if ((int)((g4 >> 8) & 255u) == k) q.y += dv.y;
                 if ((int)((g4 >> 16) & 255u) == k) q.z += dv.z;
                 if ((int)(g4 >> 24) == k) q.w += dv.w;
+            };
+            int n = lo;
+            for (; n + 3 < hi; n += 4) {
+                int e[4];
+                unsigned g4[4];
+                f4 dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[u] = a.edge[n + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const size_t ii = (size_t)(e[u] / b.K);
+                    g4[u] = *reinterpret_cast<const unsigned*>(b.arg + ii * b.odim + co);
+                    dv[u] = *reinterpret_cast<const f4*>(b.dh + ii * b.odim + co);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) take(e[u], g4[u], dv[u]);                  // (in list order: the same sums as before)
+            }
+            for (; n < hi; ++n) {
+                const int e = a.edge[n];
+                const size_t ii = (size_t)(e / b.K);
+                take(e, *reinterpret_cast<const unsigned*>(b.arg + ii * b.odim + co), *reinterpret_cast<const f4*>(b.dh + ii * b.odim + co));
             }
         }
         if (!(a.p_done && c < b.GT)) *reinterpret_cast<f4*>(b.dPQ + (size_t)i * 2 * b.S + c) = sum;
