@@ -37,6 +37,10 @@ constexpr int MLP_GRID = PF_MLP_GRID;
 #ifndef PF_DW_ABL
 #define PF_DW_ABL 0            // timing-only ablations of mlp_dw_kernel (tools/time_mlpdw.py): 1 no MFMA block, 2 no loads in the loop, 4 no LDS stores
 #endif
+#ifndef PF_MLP_STAGE
+#define PF_MLP_STAGE 16
+#endif
+constexpr int MLP_STAGE = PF_MLP_STAGE;   // weight elements a thread has in flight while a workgroup stages a layer's weights into LDS
 constexpr int MLP_LD = 144;            // LDS row stride of the weight-gradient kernel's staged blocks: >= 128 / 144 columns, = 16 (mod 32) floats
 #ifndef PF_MLP_EB
 #define PF_MLP_EB 32
@@ -153,15 +157,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpBatch bb) {
         const int ld = sh.wi16[l] + 4, off = l == 0 ? p.td : 0;
         const int sft = 31 - __clz(sh.wi16[l]);                          // wi16 is a power of two (16 .. 128)
         // 8 loads in flight per thread, then 8 LDS stores: a load -> store loop pays a full memory latency per element
-        for (int i0 = threadIdx.x; i0 < sh.wo16[l] * sh.wi16[l]; i0 += 256 * 8) {
-            float v[8];
+        for (int i0 = threadIdx.x; i0 < sh.wo16[l] * sh.wi16[l]; i0 += 256 * MLP_STAGE) {
+            float v[MLP_STAGE];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < MLP_STAGE; ++k) {
                 const int i = i0 + 256 * k, c = i >> sft, u = i & (sh.wi16[l] - 1);
                 v[k] = (i < sh.wo16[l] * sh.wi16[l] && c < sh.wo[l] && u < sh.wi[l]) ? G.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < MLP_STAGE; ++k) {
                 const int i = i0 + 256 * k, c = i >> sft, u = i & (sh.wi16[l] - 1);
                 if (i < sh.wo16[l] * sh.wi16[l]) Wl[l][c * ld + u] = v[k];
             }
@@ -249,15 +253,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBatch bb) {
     for (int l = 0; l < NL; ++l) {
         const int ld = sh.wo16[l] + 4, off = l == 0 ? p.td : 0;
         const int sft = 31 - __clz(sh.wi16[l]);                          // wi16 is a power of two (16 .. 128)
-        for (int i0 = threadIdx.x; i0 < sh.wo16[l] * sh.wi16[l]; i0 += 256 * 8) {   // consecutive threads: consecutive u (contiguous in W)
-            float v[8];
+        for (int i0 = threadIdx.x; i0 < sh.wo16[l] * sh.wi16[l]; i0 += 256 * MLP_STAGE) {   // consecutive threads: consecutive u (contiguous in W)
+            float v[MLP_STAGE];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < MLP_STAGE; ++k) {
                 const int i = i0 + 256 * k, c = i >> sft, u = i & (sh.wi16[l] - 1);
                 v[k] = (i < sh.wo16[l] * sh.wi16[l] && c < sh.wo[l] && u < sh.wi[l]) ? G.W[l][(size_t)c * sh.in[l] + off + u] : 0.f;
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < MLP_STAGE; ++k) {
                 const int i = i0 + 256 * k, c = i >> sft, u = i & (sh.wi16[l] - 1);
                 if (i < sh.wo16[l] * sh.wi16[l]) Wt[l][u * ld + c] = v[k];
             }
