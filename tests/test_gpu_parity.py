@@ -381,6 +381,15 @@ def test_graphed_forward_is_bit_identical(lib):
         assert torch.equal(x_g, x_e) and torch.equal(lp_g, lp_e)
     with pytest.raises(ValueError):
         run(synth_patches(2, 256, seed=1).to(DEV))
+    # zero-copy hand-over: the producer writes into the graph's own input buffer
+    xyz = synth_patches(3, 256, seed=5).to(DEV)
+    x_e, lp_e = net(xyz, 4)
+    assert tuple(run.input.shape) == (3, 256, 3)
+    run.input.copy_(xyz)
+    x_g, lp_g = run(run.input)
+    assert torch.equal(x_g, x_e) and torch.equal(lp_g, lp_e)
+    x_g, lp_g = run(synth_patches(3, 256, seed=1).to(DEV))           # and a foreign tensor is still copied in
+    assert torch.equal(x_g, net(synth_patches(3, 256, seed=1).to(DEV), 4)[0])
 
 
 def test_graphed_forward_is_pinned_to_its_plan(lib):
