@@ -59,6 +59,12 @@ def test_bench_reduced_precision_line():
     # secondary two-steps-in-flight figure: part of the line only when it beats the headline on this box
     pl = rec.get("pipelined")
     assert pl is None or (pl["steps_in_flight"] == 2 and pl["value"] > rec["value"])
+    # the launch mode of the timed region is the faster of the two probed ones, and the line says which and by how much
+    lp = rec["launch_probe"]
+    assert lp["chosen"] in ("graph", "eager") and lp["graph_replay_ms_per_step"] > 0 and lp["eager_ms_per_step"] > 0
+    assert (lp["chosen"] == "graph") == (lp["graph_replay_ms_per_step"] <= lp["eager_ms_per_step"])
+    assert rec["config"]["launch"].startswith("hipGraph replay" if lp["chosen"] == "graph" else "eager")
+    assert rec["zero_copy_input"]["value"] > 0
 
 
 def test_bench_pipeline_option_small_batch():
@@ -92,6 +98,8 @@ def test_bench_gpus_n_starts_its_own_ranks():
     # the same invocation also carries the strong-scaling figures and the communicator's own account (2 ranks over gloo)
     assert rec["strong"]["32"]["patches_per_rank"] == [16, 16] and rec["strong"]["256"]["patches_per_rank"] == [128, 128]
     assert all(v["value"] > 0 for v in rec["strong"].values())
+    assert all(v["launch"] in ("graph", "eager") and v["ms_per_step"] == min(v["ms_per_step_graph_replay"], v["ms_per_step_eager"])
+               for v in rec["strong"].values())
     col = rec["config"]["collectives"]
     assert col["world_size"] == 2 and col["communicator_ranks_seen_by_first_all_reduce"] == 2 and col["gradient_bucket_all_reduce"]["median_us"] > 0
     # a launcher environment that disagrees with --gpus is an error, not a mislabeled run
