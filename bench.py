@@ -173,12 +173,13 @@ def main():
         if use_dist:
             dist.barrier()
 
-    # One step = the whole hot path on one batch.  By default the 18 launches of a step are replayed as ONE hipGraph
+    # One step = the whole hot path on one batch.  The launches of a step (16 at 32 patches, 11 at small batches) can be replayed as ONE hipGraph
     # (PointInterpFlow.graphed: same kernels, same order, bit-identical results - tests/test_gpu_parity.py); the input is
     # copied into the graph's static buffer inside the timed step.  PF_BENCH_GRAPH=0 times the eager path.
     # PF_BENCH_GRAPH=auto (default): both launch modes - same kernels, same bits - are probed after the capture and the faster
-    # one carries the timed region (the line's `launch_probe` holds both figures; on a quiet host the eager stream's back-to-back
-    # launches hand over faster than the graph's kernel nodes, under host jitter the graph wins); =1 / =0 force one.
+    # one carries the timed region (the line's `launch_probe` holds both figures; the kernels and their durations are the same -
+    # on a quiet host the eager stream saves the input copy and the ~9 us between two graph launches, under host jitter the
+    # graph wins); =1 / =0 force one.
     gmode = os.environ.get("PF_BENCH_GRAPH", "auto")
     use_graph = gmode != "0"
     eager_step = lambda inp: net(inp, 4)
@@ -451,7 +452,7 @@ def main():
                "config": {"workload": "BASELINE configs[1]: PU1K discrete x4 inference, 32 x 2048-pt patches per GPU "
                                       "(fp32-parity mode)", "arithmetic": "fp32 inputs, accumulators and results; the dense layers run as 2-term split-fp16 "
                           "products on the fp16 MFMA pipe (hi.hi + hi.lo + lo.hi, fp32-class accuracy: parity tests hold the "
-                          "same 1e-5 bar; PF_EC_MODE=f32 selects the bit-exact f32-MFMA EdgeConv kernels)", "launch": ("hipGraph replay (one launch per step" + (", batch resident in the graph's input buffer: PF_BENCH_ZERO_COPY=1)" if zero_copy else ", behind a device-to-device copy of the batch into the graph's input buffer)") + (f", {pipe} steps in flight on {pipe} streams" if pipe > 1 else "")) if headline_graph else "eager (one stream, 18 launches per step, the caller's tensor read in place)",
+                          "same 1e-5 bar; PF_EC_MODE=f32 selects the bit-exact f32-MFMA EdgeConv kernels)", "launch": ("hipGraph replay (one launch per step" + (", batch resident in the graph's input buffer: PF_BENCH_ZERO_COPY=1)" if zero_copy else ", behind a device-to-device copy of the batch into the graph's input buffer)") + (f", {pipe} steps in flight on {pipe} streams" if pipe > 1 else "")) if headline_graph else "eager (one stream, one launch per kernel - the graph's kernels in the graph's order - the caller's tensor read in place)",
                           "patches_per_gpu": args.batch, "total_batch": args.total_batch if args.scaling == "strong" else world * args.batch,
                           "npoint": args.npoint,
                           "upratio": 4, "sharding": f"patch batch over {world} rank(s), no data-path collective",
@@ -543,7 +544,7 @@ def strong_block(args, world, rank, dev, dist, net, totals=(32, 256)):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         # both launch modes (same kernels, same bits), each a full barrier-bracketed pass with the max over ranks; the faster one is
-        # the figure, both are in the line (small shards: the eager stream's launches hand over faster than a graph's kernel nodes)
+        # the figure, both are in the line (small shards: an eager step has no input copy and no gap between two graph launches)
         el_g = one_pass(run)
         el_e = one_pass(None if run is None else (lambda inp: net(inp, 4)))
         el = min(el_g, el_e)

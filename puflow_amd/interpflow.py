@@ -537,7 +537,7 @@ class PointInterpFlow(nn.Module):
 
     @torch.no_grad()
     def graphed(self, B: int, N: int, upratio: int = 4):
-        """The eval forward for a fixed [B, N, 3] shape captured in a hipGraph: ONE launch per call instead of 18, so the
+        """The eval forward for a fixed [B, N, 3] shape captured in a hipGraph: ONE launch per call instead of 11 - 16, so the
         step no longer depends on host launch latency / jitter (8 ranks sharing one host).  Returns `run(xyz) -> (x, logp)`;
         the results live in static buffers that the next call overwrites (clone them to keep them) and are
         bit-identical to `forward` (same kernels, same order).  `run.input` is the graph's own input buffer: a producer
