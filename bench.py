@@ -283,6 +283,10 @@ def main():
         x, logp = runner(args.steps)
         torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
         el += time.perf_counter() - t0
+    # per-stage HIP-event times (the roofline's live kernel duration) straight after the timed region, before the secondary legs
+    # add another few seconds of load: 5 iterations are sensitive to what ran before them (0.131 vs 0.136 ms for the dominant
+    # kernel with the secondary legs in front)
+    prof_stages = net._engine(4).profile_stages(xyz, iters=5) if rank == 0 else None
     # secondary figure (never `value`): the same K steps with two of them in flight on two streams - independent batches
     # overlap; what a serving loop with more than one batch queued gets
     el_pipe = None
@@ -318,7 +322,7 @@ def main():
     if rank == 0:
         # ---- dominant kernel: EdgeConv (units 2..5 share one kernel); live HIP-event timing on the launch stream
         eng = net._engine(4)
-        prof = eng.profile_stages(xyz, iters=5)
+        prof = prof_stages
         T = args.batch * args.npoint
         ec_ms = prof["edgeconv5"]                       # C=128 unit (the last one: never fused with a P|Q GEMM): avg ms per launch
         ec_fl = edgeconv_ref_flops(T, 128, 32, 4, 128)
